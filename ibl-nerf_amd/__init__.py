@@ -1,0 +1,10 @@
+"""ibl_nerf_amd — MI355X-native forward/inference renderer for IBL-NeRF's hot path.
+
+Only what the path needs: `csrc/` (HIP kernels + the C-ABI of include/iblnerf.h),
+and the host-side mirror of the reference's Python seam (`render_decomp`, `render_rays`,
+`network_query_fn`, `sample_pdf`, `get_rays`, `create_IBLNeRF`).  Import as `ibl_nerf_amd`
+through `_pkg.load()` at the repo root.
+"""
+from . import checkpoint  # noqa: F401
+
+__all__ = ["checkpoint"]

@@ -1,0 +1,132 @@
+"""Checkpoint schema of the reference `IBLNeRF` module and host-side helpers.
+
+Mirrors the state-dict layout of `src/nerf_models/ibl_nerf.py:14-75` (key order is the
+module registration order, verified against the reference in this container) and the
+`.tar` dict written by `src/train.py:180-191` / read by `src/nerf_models/ibl_nerf.py:345-378`.
+
+Nothing here computes on the hot path: it turns a state dict into the flat fp32 "blob"
+(`[out,in]` row-major weight then bias, per layer, in `SCHEMA` order) that
+`iblnerf_upload_weights` (include/iblnerf.h) consumes.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+# (key prefix, out_features, in_features) in the reference's registration order.
+SCHEMA = (
+    [("positions_linears.0", 256, 63)]
+    + [("positions_linears.%d" % i, 256, 256) for i in (1, 2, 3, 4)]
+    + [("positions_linears.5", 256, 319)]
+    + [("positions_linears.%d" % i, 256, 256) for i in (6, 7)]
+    + [
+        ("views_linears.0", 256, 283),
+        ("feature_linear", 256, 256),
+        ("sigma_linear", 1, 256),
+        ("albedo_feature_linear", 128, 256),
+        ("albedo_linear", 3, 128),
+        ("roughness_linear", 1, 256),
+        ("irradiance_feature_linear", 128, 256),
+        ("irradiance_linear", 1, 128),
+        ("radiance_linear", 3, 256),
+    ]
+    + [("additional_radiance_feature_linear.%d" % i, 128, 256) for i in range(3)]
+    + [("additional_radiance_linear.%d" % i, 3, 128) for i in range(3)]
+)
+N_PARAMS = sum(o * i + o for _, o, i in SCHEMA)  # 798 994
+assert N_PARAMS == 798994
+
+
+def synthetic_state_dict(seed: int, gain: float = 1.0, sigma_bias: float = 0.3) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic stand-in for a trained checkpoint (no checkpoint ships with the reference).
+
+    Every weight and bias ~ U(-g/sqrt(fan_in), +g/sqrt(fan_in)) — PyTorch's `nn.Linear`
+    default is g = 1 — from numpy's legacy `RandomState(seed)` stream (bit-stable across
+    numpy versions/platforms), then `sigma_linear.bias = sigma_bias` so density is non-zero
+    (SURVEY.md §8 d).
+    """
+    rng = np.random.RandomState(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, out_f, in_f in SCHEMA:
+        bound = gain / np.sqrt(in_f)
+        sd[name + ".weight"] = rng.uniform(-bound, bound, size=(out_f, in_f)).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-bound, bound, size=(out_f,)).astype(np.float32)
+    sd["sigma_linear.bias"][:] = np.float32(sigma_bias)
+    return sd
+
+
+def _to_numpy(v) -> np.ndarray:
+    if isinstance(v, np.ndarray):
+        return v
+    return v.detach().cpu().numpy()  # torch.Tensor / nn.Parameter
+
+
+def state_dict_to_blob(sd) -> np.ndarray:
+    """Flatten a reference-schema state dict (numpy arrays or torch tensors) into the fp32 blob."""
+    parts = []
+    for name, out_f, in_f in SCHEMA:
+        w = np.ascontiguousarray(_to_numpy(sd[name + ".weight"]), dtype=np.float32)
+        b = np.ascontiguousarray(_to_numpy(sd[name + ".bias"]), dtype=np.float32)
+        if w.shape != (out_f, in_f) or b.shape != (out_f,):
+            raise ValueError("state dict entry %s has shape %s/%s, expected (%d,%d)/(%d,)"
+                             % (name, w.shape, b.shape, out_f, in_f, out_f))
+        parts.append(w.ravel())
+        parts.append(b.ravel())
+    blob = np.concatenate(parts)
+    assert blob.size == N_PARAMS
+    return blob
+
+
+def blob_to_state_dict(blob: np.ndarray) -> "OrderedDict[str, np.ndarray]":
+    blob = np.asarray(blob, dtype=np.float32)
+    if blob.size != N_PARAMS:
+        raise ValueError("blob has %d floats, expected %d" % (blob.size, N_PARAMS))
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    off = 0
+    for name, out_f, in_f in SCHEMA:
+        sd[name + ".weight"] = blob[off:off + out_f * in_f].reshape(out_f, in_f).copy()
+        off += out_f * in_f
+        sd[name + ".bias"] = blob[off:off + out_f].copy()
+        off += out_f
+    return sd
+
+
+def blob_checksum(blob: np.ndarray) -> str:
+    """Short stable fingerprint of a blob (stored next to golden vectors instead of 3.2 MB of weights)."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(blob, dtype="<f4").tobytes()).hexdigest()[:16]
+
+
+def find_checkpoint(basedir: str, expname: str, ft_path=None, target_load_N_iter: int = -1):
+    """Checkpoint discovery rule of `ibl_nerf.py:345-350`: explicit path, else a named
+    iteration, else the lexicographically last file whose name contains 'tar'."""
+    if ft_path is not None and ft_path != "None":
+        return ft_path
+    if target_load_N_iter > 0:
+        return os.path.join(basedir, expname, "{:06d}.tar".format(target_load_N_iter))
+    d = os.path.join(basedir, expname)
+    ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f]
+    return ckpts[-1] if ckpts else None
+
+
+def load_checkpoint(path: str):
+    """Read a reference `.tar` (torch.save dict, `train.py:180-191`).
+
+    Returns (global_step, coarse_state_dict, fine_state_dict_or_None)."""
+    import torch
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    fine = ckpt.get("network_fine_state_dict")
+    return ckpt.get("global_step", 0), ckpt["network_fn_state_dict"], fine
+
+
+def save_checkpoint(path: str, global_step: int, coarse_sd, fine_sd=None, elapsed_time: float = 0.0):
+    """Write the same dict schema `train.py:180-191` writes (optimizer state left empty)."""
+    import torch
+    to_t = lambda sd: OrderedDict((k, torch.from_numpy(np.array(_to_numpy(v)))) for k, v in sd.items())
+    d = {"global_step": global_step, "network_fn_state_dict": to_t(coarse_sd),
+         "optimizer_state_dict": {}, "elapsed_time": elapsed_time}
+    if fine_sd is not None:
+        d["network_fine_state_dict"] = to_t(fine_sd)
+    torch.save(d, path)

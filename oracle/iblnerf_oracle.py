@@ -1,0 +1,391 @@
+"""CPU ORACLE (test infrastructure, NOT the product) — numpy fp32 restatement of IBL-NeRF's
+forward/inference hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module, and only as the checker / reported baseline.  The shipped path is the HIP library behind
+include/iblnerf.h; nothing under `ibl-nerf_amd/` imports `oracle/`.
+
+Parity status: PINNED.  The reference ships no golden vectors, so the pins are
+outputs of the reference itself, run in the build container by tests/golden/make_golden.py and
+committed as tests/golden/*.npz; tests/test_oracle_golden.py checks every function below against
+them.
+
+Every function cites the reference lines it restates (paths relative to /root/reference/src).
+All arithmetic is float32 unless the reference's CPU kernels accumulate wider (cumsum/cumprod:
+ATen's CPU scan kernels accumulate float tensors in double and round each prefix to float).
+Operation ORDER is kept where rounding matters downstream (positions are multiplied by up to 2^9
+inside the positional encoding): `o + d*z` is a rounded multiply followed by a rounded add.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+GAMMA = 2.2          # nerf_models/ibl_nerf_renderer.py:22
+EPS_SRGB = 1e-12     # nerf_models/ibl_nerf_renderer.py:23
+
+
+# --------------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------------
+def torch_linspace(start, end, steps):
+    """float32 `torch.linspace` as ATen's CPU kernel computes it: symmetric fill from both ends,
+    `start + step*i` for i < steps/2 and `end - step*(steps-1-i)` above, each evaluated as ONE fused
+    multiply-add (verified bit-for-bit against torch.linspace in tests).  The fma is emulated in
+    float64, which holds the 24-bit x small-int product and the sum exactly before the one rounding."""
+    start, end = F32(start), F32(end)
+    if steps == 1:
+        return np.array([start], dtype=F32)
+    step = np.float64(F32((end - start) / F32(steps - 1)))
+    idx = np.arange(steps)
+    lo = (np.float64(start) + step * idx).astype(F32)
+    hi = (np.float64(end) - step * (steps - 1 - idx)).astype(F32)
+    return np.where(idx < steps // 2, lo, hi).astype(F32)
+
+
+def sigmoid(x):
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def relu(x):
+    return np.maximum(x, F32(0))
+
+
+def rgb_to_srgb(x):
+    """nerf_models/ibl_nerf_renderer.py:26-27."""
+    return np.power(x + F32(EPS_SRGB), F32(1.0 / GAMMA), dtype=F32)
+
+
+def normalize(v, eps=1e-12):
+    """torch.nn.functional.normalize(dim=-1)."""
+    n = np.sqrt(np.sum(v * v, -1, keepdims=True, dtype=F32), dtype=F32)
+    return (v / np.maximum(n, F32(eps))).astype(F32)
+
+
+def cross(a, b):
+    return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                     a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                     a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], -1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------------
+# A.1 rays — nerf_models/nerf_renderer_helper.py:36-45
+# --------------------------------------------------------------------------------------------
+def get_rays(H, W, K, c2w):
+    K = np.asarray(K, dtype=F32)
+    c2w = np.asarray(c2w, dtype=F32)
+    i = np.broadcast_to(torch_linspace(0, W - 1, W)[None, :], (H, W))   # column index
+    j = np.broadcast_to(torch_linspace(0, H - 1, H)[:, None], (H, W))   # row index
+    dirs = np.stack([(i - K[0, 2]) / K[0, 0], -(j - K[1, 2]) / K[1, 1], -np.ones_like(i)], -1).astype(F32)
+    rays_d = np.sum(dirs[..., None, :] * c2w[:3, :3], -1, dtype=F32)
+    rays_o = np.broadcast_to(c2w[:3, -1], rays_d.shape).astype(F32)
+    return rays_o, rays_d
+
+
+# --------------------------------------------------------------------------------------------
+# A.3 positional encoding — nerf_models/positional_embedder.py:4-52
+# --------------------------------------------------------------------------------------------
+def embed(x, n_freqs):
+    x = np.asarray(x, dtype=F32)
+    out = [x]
+    for k in range(n_freqs):
+        f = F32(2.0 ** k)           # 2.**linspace(0, L-1, L): exact powers of two
+        out.append(np.sin(x * f, dtype=F32))
+        out.append(np.cos(x * f, dtype=F32))
+    return np.concatenate(out, -1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------------
+# A.4 MLP — nerf_models/ibl_nerf.py:154-210 (forward_not_freezed)
+# --------------------------------------------------------------------------------------------
+def _lin(sd, name, x):
+    return (x @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(F32)
+
+
+def mlp_forward(sd, e_pts, e_dirs=None):
+    """e_pts [P,63]; e_dirs [P,27] or None.  Returns [P,18], or [P,1] (sigma) if e_dirs is None."""
+    h = e_pts
+    for i in range(8):
+        h = relu(_lin(sd, "positions_linears.%d" % i, h))
+        if i == 4:
+            h = np.concatenate([e_pts, h], -1)                         # :168 skip order [x63, h]
+    sigma = _lin(sd, "sigma_linear", h)
+    if e_dirs is None:
+        return sigma                                                   # :175-176 early return
+    albedo = _lin(sd, "albedo_linear", relu(_lin(sd, "albedo_feature_linear", h)))
+    rough = _lin(sd, "roughness_linear", h)
+    irr = _lin(sd, "irradiance_linear", relu(_lin(sd, "irradiance_feature_linear", h)))
+    feat = _lin(sd, "feature_linear", h)                               # no activation (:193)
+    h2 = relu(_lin(sd, "views_linears.0", np.concatenate([feat, e_dirs], -1)))   # :194-197
+    ret = [sigma, albedo, rough, irr, _lin(sd, "radiance_linear", h2)]
+    for k in range(3):                                                 # taken from h2 (:202-206)
+        f = relu(_lin(sd, "additional_radiance_feature_linear.%d" % k, h2))
+        ret.append(_lin(sd, "additional_radiance_linear.%d" % k, f))
+    return np.concatenate(ret, -1).astype(F32)
+
+
+def network_query(sd, pts, viewdirs):
+    """`network_query_fn` = run_network, nerf_models/ibl_nerf.py:236-252.
+    pts [N,S,3]; viewdirs [N,3] (expanded over the S samples) or None."""
+    pts = np.asarray(pts, dtype=F32)
+    N, S, _ = pts.shape
+    e = embed(pts.reshape(-1, 3), 10)
+    if viewdirs is None:
+        return mlp_forward(sd, e).reshape(N, S, 1)
+    d = np.broadcast_to(np.asarray(viewdirs, dtype=F32)[:, None, :], pts.shape).reshape(-1, 3)
+    return mlp_forward(sd, e, embed(d, 4)).reshape(N, S, 18)
+
+
+# --------------------------------------------------------------------------------------------
+# A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
+# --------------------------------------------------------------------------------------------
+def ray_dists(z_vals, rays_d):
+    d = z_vals[..., 1:] - z_vals[..., :-1]
+    d = np.concatenate([d, np.full_like(d[..., :1], F32(1e10))], -1)
+    nrm = np.sqrt(np.sum(rays_d * rays_d, -1, dtype=F32), dtype=F32)[..., None]
+    return (d * nrm).astype(F32)
+
+
+def alpha_weights(sigma_raw, dists):
+    alpha = (F32(1) - np.exp(-relu(sigma_raw) * dists, dtype=F32)).astype(F32)
+    one_m = (F32(1) - alpha + F32(1e-10)).astype(F32)
+    # ATen's CPU cumprod accumulates float tensors in double, rounding each prefix to float.
+    T = np.cumprod(np.concatenate([np.ones_like(one_m[:, :1]), one_m], -1).astype(np.float64), -1).astype(F32)[:, :-1]
+    return (alpha * T).astype(F32)
+
+
+# --------------------------------------------------------------------------------------------
+# A.6 fine sampling — nerf_models/nerf_renderer_helper.py:91-134 with det=True
+# --------------------------------------------------------------------------------------------
+def sample_pdf(bins, weights, n_samples):
+    bins = np.asarray(bins, dtype=F32)
+    w = (np.asarray(weights, dtype=F32) + F32(1e-5)).astype(F32)
+    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32)
+    cdf = np.cumsum(pdf.astype(np.float64), -1).astype(F32)           # double accumulate (ATen CPU)
+    cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)
+    u = np.broadcast_to(torch_linspace(0, 1, n_samples), cdf.shape[:-1] + (n_samples,))
+    nb = cdf.shape[-1]
+    inds = np.stack([np.searchsorted(cdf[r], u[r], side="right") for r in range(cdf.shape[0])])
+    below = np.maximum(inds - 1, 0)
+    above = np.minimum(inds, nb - 1)
+    c0, c1 = np.take_along_axis(cdf, below, -1), np.take_along_axis(cdf, above, -1)
+    b0, b1 = np.take_along_axis(bins, below, -1), np.take_along_axis(bins, above, -1)
+    den = (c1 - c0).astype(F32)
+    den = np.where(den < F32(1e-5), F32(1), den)
+    t = ((u - c0) / den).astype(F32)
+    return (b0 + t * (b1 - b0)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------------
+# A.7 epsilon normal — nerf_models/normal_from_depth.py:139-183
+# --------------------------------------------------------------------------------------------
+def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=False):
+    eps = F32(eps)
+    up0 = np.broadcast_to(np.array([0, 1, 0], dtype=F32), rays_d.shape)
+    right = cross(rays_d, up0)
+    up = cross(right, rays_d)
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)
+    offs = [eps * right, -(eps * right), eps * up, -(eps * up)]        # pts +- eps*v (:151-154)
+    new_pts = np.concatenate([(pts + o[:, None, :]).astype(F32) for o in offs], 0)
+    raw = network_query(sd, new_pts, None)[..., 0]
+    dists = ray_dists(z_vals, rays_d)
+    N = rays_o.shape[0]
+    D = [np.sum(alpha_weights(raw[s * N:(s + 1) * N], dists) * z_vals, -1, dtype=F32) for s in range(4)]
+    dx = (F32(2) * eps * right + (D[0] - D[1])[:, None] * rays_d).astype(F32)
+    dy = (F32(2) * eps * up + (D[2] - D[3])[:, None] * rays_d).astype(F32)
+    n = normalize(cross(dx, dy))
+    return (n, np.stack(D, 0)) if return_depths else n
+
+
+# --------------------------------------------------------------------------------------------
+# A.9 pieces
+# --------------------------------------------------------------------------------------------
+def lut_fetch(lut, n_dot_v, rough):
+    """F.grid_sample(bilinear, zeros padding, align_corners=True), ibl_nerf_renderer.py:418-421.
+    lut [3,512,512] (row = roughness, col = n.v).  Returns [N,3]."""
+    Hh, Ww = lut.shape[1:]
+    gx = (F32(2) * n_dot_v - F32(1)).astype(F32)
+    gy = (F32(2) * rough - F32(1)).astype(F32)
+    x = (((gx + F32(1)) / F32(2)) * F32(Ww - 1)).astype(F32)
+    y = (((gy + F32(1)) / F32(2)) * F32(Hh - 1)).astype(F32)
+    x0, y0 = np.floor(x), np.floor(y)
+    out = np.zeros((x.shape[0], 3), dtype=F32)
+    for dx_, dy_ in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        xi, yi = x0 + dx_, y0 + dy_
+        wx = (x0 + F32(1) - x) if dx_ == 0 else (x - x0)
+        wy = (y0 + F32(1) - y) if dy_ == 0 else (y - y0)
+        ok = (xi >= 0) & (xi <= Ww - 1) & (yi >= 0) & (yi <= Hh - 1)
+        xc, yc = np.clip(xi, 0, Ww - 1).astype(np.int64), np.clip(yi, 0, Hh - 1).astype(np.int64)
+        v = lut[:, yc, xc].T
+        out += np.where(ok[:, None], v * (wx * wy).astype(F32)[:, None], F32(0)).astype(F32)
+    return out
+
+
+def fresnel_schlick_roughness(cos_theta, F0, rough):
+    """nerf_models/microfacet.py:8-12."""
+    c, r = cos_theta[:, None], rough[:, None]
+    F1 = np.maximum(F32(1) - r, F0) - F0
+    return (F0 + F1 * np.power(np.clip(F32(1) - c, 0, 1), F32(5), dtype=F32)).astype(F32)
+
+
+def composite_reflected(raw, z_vals, dirs):
+    """raw2outputs_simple, ibl_nerf_renderer.py:38-68 -> [N,4,3] (radiance, coarse radiance 1..3)."""
+    w = alpha_weights(raw[..., 0], ray_dists(z_vals, dirs))
+    maps = [np.sum(w[..., None] * sigmoid(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
+    return np.stack(maps, 1).astype(F32)
+
+
+def decode_masks(mask_img, n_obj):
+    """ibl_nerf_renderer.py:223-228 / :233-238: object q <=> 9(q+1)/255 < m < 11(q+1)/255."""
+    m = mask_img[:, 0]
+    masks = [np.logical_and(F32(11 * (q + 1) / 255.) > m, m > F32(9 * (q + 1) / 255.)) for q in range(n_obj)]
+    return masks, m > 0
+
+
+# --------------------------------------------------------------------------------------------
+# one pass: raw2outputs, ibl_nerf_renderer.py:153-527 (approximate_radiance=True, shipped flags)
+# --------------------------------------------------------------------------------------------
+def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None):
+    gt = gt or {}
+    edit = edit or {}
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)       # :200
+    raw = network_query(sd, pts, rays_d)                                                    # :201 (rays_d, not viewdirs)
+    dists = ray_dists(z_vals, rays_d)
+    masks, mask_all = None, None
+    if edit.get("edit_intrinsic"):
+        assert edit["num_edit_objects"] > 0
+        masks, mask_all = decode_masks(gt["edit_intrinsic_mask"], edit["num_edit_objects"])
+    elif edit.get("insert_object"):
+        assert edit["num_insert_objects"] > 0
+        masks, mask_all = decode_masks(gt["object_insert_mask"], edit["num_insert_objects"])
+    w = alpha_weights(raw[..., 0], dists)                                                   # :241-245
+    depth = np.sum(w * z_vals, -1, dtype=F32)                                               # :249
+    if edit.get("edit_intrinsic") and edit.get("edit_depth"):
+        depth[mask_all] = gt["edit_depth"][:, 0][mask_all]                                  # :253-254 (aliases depth_map)
+    if edit.get("insert_object"):
+        depth[mask_all] = gt["object_insert_depth"][:, 0][mask_all]                         # :255-256
+    acc = np.sum(w, -1, dtype=F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        disp = (F32(1) / np.maximum(F32(1e-10), depth / acc)).astype(F32)                   # :258
+    x_surface = (rays_o + rays_d * depth[:, None]).astype(F32)                              # :262
+    albedo = np.sum(w[..., None] * sigmoid(raw[..., 1:4]), -2, dtype=F32)                   # :281-282
+    rough = np.sum(w * sigmoid(raw[..., 4]), -1, dtype=F32)                                 # :284-285
+    irr = np.sum(w * sigmoid(raw[..., 5]), -1, dtype=F32)[:, None]                          # :287-288, :328
+    rad = [np.sum(w[..., None] * sigmoid(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
+
+    normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01)                    # :358-361
+    if stages is not None:
+        stages["normal_raw"] = normal.copy()
+    if edit.get("edit_intrinsic"):                                                          # :378-398
+        if edit.get("edit_normal"):
+            normal[mask_all] = normalize(F32(2) * gt["edit_normal"] - F32(1))[mask_all]
+        if edit.get("edit_albedo"):
+            if edit.get("edit_albedo_by_img"):
+                albedo[mask_all] = gt["edit_albedo"][mask_all]
+            else:
+                lst = np.asarray(edit["editing_target_albedo_list"], dtype=F32)
+                for q in range(edit["num_edit_objects"]):
+                    albedo[masks[q]] = lst[3 * q:3 * q + 3]
+        if edit.get("edit_roughness"):
+            for q, r in enumerate(edit["editing_target_roughness_list"]):
+                rough[masks[q]] = F32(r)
+    elif edit.get("insert_object"):                                                         # :400-410
+        normal[mask_all] = normalize(F32(2) * gt["object_insert_normal"] - F32(1))[mask_all]
+        al = np.asarray(edit["inserting_target_albedo_list"], dtype=F32)
+        for q in range(edit["num_insert_objects"]):
+            rough[masks[q]] = F32(edit["inserting_target_roughness_list"][q])
+            if edit["inserting_target_irradiance_list"][q] > 0:
+                irr[masks[q]] = F32(edit["inserting_target_irradiance_list"][q])
+            albedo[masks[q]] = al[3 * q:3 * q + 3]
+
+    ndv = np.clip(np.sum(-rays_d * normal, -1, dtype=F32), 0, 1).astype(F32)                # :412-413
+    env = lut_fetch(lut, ndv, rough)                                                        # :418-421
+    metal = (F32(1) - rough)[:, None]
+    F0 = (F32(0.04) * (F32(1) - metal) + albedo * metal).astype(F32)                        # :424-427
+    fres = fresnel_schlick_roughness(ndv, F0, rough)
+    spec_coef = (fres * env[:, 0:1] + env[:, 1:2]).astype(F32)                              # :434 ('F')
+    refl_d = (rays_d - F32(2) * np.sum(normal * rays_d, -1, keepdims=True, dtype=F32) * normal).astype(F32)
+    refl_pts = (x_surface[:, None, :] + refl_d[:, None, :] * z_const[:, :, None]).astype(F32)   # :440
+    refl_raw = network_query(sd, refl_pts, refl_d)                                          # :445
+    pref_maps = composite_reflected(refl_raw, z_const, refl_d)                              # :446-448
+    depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
+    level = np.clip(rough * depth / depth_0, 0, 1).astype(F32)                              # :458-459
+    i1 = np.clip((level * F32(3)).astype(np.int64), 0, 3)                                   # :464-465
+    i2 = np.clip(i1 + 1, 0, 3)
+    rem = ((level * F32(3)) - i1.astype(F32))[:, None].astype(F32)
+    ar = np.arange(pref_maps.shape[0])
+    pref = ((F32(1) - rem) * pref_maps[ar, i1] + rem * pref_maps[ar, i2]).astype(F32)       # :468-470
+    diffuse = ((F32(1) - fres) * (F32(1) - metal) * albedo * irr).astype(F32)               # :472
+    specular = (spec_coef * pref).astype(F32)
+    color = (diffuse + specular).astype(F32)
+    if stages is not None:
+        stages.update(raw=raw, refl_raw=refl_raw, pref_maps=pref_maps, env=env, refl_d=refl_d,
+                      x_surface=x_surface, level=level)
+    g = rgb_to_srgb
+    res = {"color_map": g(color), "radiance_map": g(rad[0])}
+    for k in range(3):
+        res["radiance_map_%d" % (k + 1)] = g(rad[k + 1])
+    for k in range(3):
+        res["reflected_coarse_radiance_map_%d" % (k + 1)] = g(pref_maps[:, k + 1])
+    res.update({
+        "irradiance_map": g(irr), "reflected_radiance_map": g(pref_maps[:, 0]),
+        "prefiltered_reflected_map": g(pref), "albedo_map": g(albedo), "roughness_map": rough,
+        "specular_map": g(specular), "diffuse_map": g(diffuse), "n_dot_v_map": ndv,
+        "target_normal_map": normal, "disp_map": disp, "acc_map": acc, "depth_map": depth,
+        "target_depth_map": depth, "weights": w})
+    return res
+
+
+# --------------------------------------------------------------------------------------------
+# render_rays / render_decomp — ibl_nerf_renderer.py:629-732, :759-813 (perturb=0, raw_noise_std=0)
+# --------------------------------------------------------------------------------------------
+def coarse_z(near, far, n_samples, n_rays):
+    t = torch_linspace(0, 1, n_samples)
+    z = (F32(near) * (F32(1) - t) + F32(far) * t).astype(F32)                              # :672
+    return np.broadcast_to(z, (n_rays, n_samples)).copy()
+
+
+def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64, n_importance=128,
+                gt=None, edit=None, stages=None):
+    rays_o = np.ascontiguousarray(rays_o, dtype=F32)
+    rays_d = np.ascontiguousarray(rays_d, dtype=F32)
+    N = rays_o.shape[0]
+    z = coarse_z(near, far, n_samples, N)
+    st_c = {} if stages is not None else None
+    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c)
+    if n_importance > 0:
+        mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)                             # :701
+        zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance)                       # :702-703
+        zf = np.sort(np.concatenate([z, zs], -1), -1)                                      # :707
+        st_f = {} if stages is not None else None
+        fine = raw2outputs(sd_fine if sd_fine is not None else sd_coarse, rays_o, rays_d, zf, z,
+                           near, far, lut, gt, edit, st_f)
+        for k, v in res.items():
+            fine[k + "0"] = v                                                              # :712-713
+        res = fine
+        res["z_std"] = np.std(zs, -1, dtype=F32)                                           # :718
+        if stages is not None:
+            stages.update(c=st_c, f=st_f, z_samples=zs, z_fine=zf)
+    elif stages is not None:
+        stages.update(c=st_c)
+    return res
+
+
+def render_decomp(H, W, K, sd_coarse, sd_fine, lut, near, far, rays=None, c2w=None, chunk=1024,
+                  n_samples=64, n_importance=128, gt_values=None, **edit):
+    """ibl_nerf_renderer.py:759-813.  Exactly one of rays ([2,N,3]) / c2w ([3,4])."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    sh = rays_d.shape
+    ro, rd = np.reshape(rays_o, (-1, 3)).astype(F32), np.reshape(rays_d, (-1, 3)).astype(F32)
+    gt_values = gt_values or {}
+    outs = {}
+    for i in range(0, ro.shape[0], chunk):                                                 # batchify_rays :735-756
+        gt = {k: np.array(v[i:i + chunk], dtype=F32) for k, v in gt_values.items()}
+        r = render_rays(sd_coarse, sd_fine, ro[i:i + chunk], rd[i:i + chunk], near, far, lut,
+                        n_samples, n_importance, gt, edit)
+        for k, v in r.items():
+            outs.setdefault(k, []).append(v)
+    return {k: np.concatenate(v, 0).reshape(sh[:-1] + v[0].shape[1:]) for k, v in outs.items()}

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import _pkg  # noqa: E402
+
+_pkg.load()  # registers `ibl_nerf_amd`
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_lut_rgb():
+    """tests/golden/ibl_brdf_lut.png -> float32 [3,512,512] exactly as test.py:79-87 builds it."""
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(GOLDEN, "ibl_brdf_lut.png")).convert("RGB"), dtype=np.float32)
+    return np.ascontiguousarray((img / np.float32(255.0)).transpose(2, 0, 1))
+
+
+@pytest.fixture(scope="session")
+def lut():
+    return load_lut_rgb()
+
+
+def load_golden(name):
+    """Returns (npz, coarse_sd, fine_sd, gt dict, edit dict) for a render fixture."""
+    from ibl_nerf_amd import checkpoint as ck
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sdc = ck.synthetic_state_dict(int(g["seed_coarse"]), float(g["gain"]))
+    sdf = ck.synthetic_state_dict(int(g["seed_fine"]), float(g["gain"]))
+    assert ck.blob_checksum(ck.state_dict_to_blob(sdc)) == str(g["ck_coarse"])
+    assert ck.blob_checksum(ck.state_dict_to_blob(sdf)) == str(g["ck_fine"])
+    edit = {k[6:]: g[k].tolist() for k in g.files if k.startswith("edit__")}
+    gt = {k[4:]: g[k] for k in g.files if k.startswith("gt__")}
+    return g, sdc, sdf, gt, edit
+
+
+def rel_linf(x, ref):
+    """SURVEY.md §8 d: max|x - ref| / max|ref| (the per-channel parity metric of north_star)."""
+    x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.nanmax(np.abs(x.reshape(ref.shape) - ref)) / max(float(np.nanmax(np.abs(ref))), 1e-30))
+
+
+RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10"]

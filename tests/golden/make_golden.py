@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Run from the repo root (only where /root/reference exists — never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What it does (SURVEY.md §8 c): puts /root/reference/src on sys.path, registers empty stub
+modules for the reference's non-numeric imports (imageio, cv2, torchvision, configargparse),
+imports `nerf_models.ibl_nerf_renderer` / `nerf_models.ibl_nerf`, builds the two `IBLNeRF`
+modules through the reference's own `create_IBLNeRF`, loads OUR synthetic checkpoint
+(`checkpoint.synthetic_state_dict`, regenerated from a seed — only its checksum is stored),
+and calls the reference's `render_decomp`, `get_rays`, `sample_pdf` on seeded inputs.  Stage
+boundaries are captured by wrapping the reference's own callables at run time (no reference
+source is copied): network_query_fn, sample_pdf, get_normal_from_depth_gradient_epsilon,
+raw2outputs_simple, F.grid_sample.
+
+Outputs are data only: .npz files of inputs + expected outputs, plus a copy of the reference's
+BRDF LUT asset (data/ibl_brdf_lut.png, MIT-licensed input data, md5 recorded in SURVEY.md §2 #9).
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, REPO)
+import _pkg  # noqa: E402
+
+pkg = _pkg.load()
+ck = pkg.checkpoint
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(REF, "src"))
+    for m in ["imageio", "cv2", "torchvision", "torchvision.transforms", "configargparse"]:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import torch
+    import nerf_models.ibl_nerf_renderer as R
+    import nerf_models.ibl_nerf as M
+    import nerf_models.nerf_renderer_helper as Hh
+    torch.autograd.set_detect_anomaly(False)  # import switched it on (nerf_renderer_helper.py:2)
+    return torch, R, M, Hh
+
+
+def reference_args(tmp, n_importance):
+    """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
+    os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
+    return SimpleNamespace(
+        multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=64,
+        N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
+        color_independent_to_direction=False, use_illumination_feature_layer=False,
+        use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
+        infer_normal=False, infer_normal_at_surface=False, infer_albedo_separate=False,
+        infer_roughness_separate=False, infer_irradiance_separate=False, use_environment_map=False,
+        N_envmap_size=16, lrate=5e-4, lrate_env_map=5e-4, basedir=tmp, expname="exp", ft_path=None,
+        target_load_N_iter=-1, no_reload=True, perturb=1.0, use_viewdirs=True, white_bkgd=False,
+        raw_noise_std=0.0, lindisp=False, use_monte_carlo_integration=False,
+        monte_carlo_integration_method="surface", use_gradient_for_incident_radiance=False,
+        use_radiance_linear=False, gamma_correct=True, lut_coefficient="F",
+        depth_map_from_ground_truth=False,
+        calculating_normal_type="normal_map_from_depth_gradient_epsilon",
+        calculate_albedo_from_gt=False, calculate_roughness_from_gt=False,
+        calculate_irradiance_from_gt=False, epsilon_for_numerical_normal=0.01,
+        epsilon_direction_for_numerical_normal=0.005, N_hemisphere_sample_sqrt=16,
+        roughness_exp_coefficient=1.0, albedo_multiplier=1.0,
+        correct_depth_for_prefiltered_radiance_infer=True)
+
+
+def load_lut(torch):
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(REF, "data", "ibl_brdf_lut.png")).convert("RGB"), dtype=np.float32) / 255.0
+    return torch.from_numpy(img).permute(2, 0, 1).contiguous()  # == test.py:79-87 (cv2 drops alpha)
+
+
+def camera_rays(rng, n, H=800, W=800, fov_deg=60.0):
+    """n seeded pixels of the synthetic 800x800 pinhole view (SURVEY.md §8 d), identity pose,
+    reference ray convention (nerf_renderer_helper.py:36-45).  Returns pixel ids too."""
+    f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(fov_deg)))
+    pix = rng.permutation(H * W)[:n]
+    pix[:4] = [0, W - 1, (H - 1) * W, H * W - 1]  # frame corners: largest |d|
+    i = (pix % W).astype(np.float32)
+    j = (pix // W).astype(np.float32)
+    d = np.stack([(i - np.float32(W / 2)) / f, -(j - np.float32(H / 2)) / f, -np.ones_like(i)], -1).astype(np.float32)
+    o = np.zeros_like(d)
+    return o, d, pix, f
+
+
+EDIT_KEYS_OFF = dict(
+    edit_intrinsic=False, editing_img_idx=0, num_edit_objects=0, edit_roughness=False, edit_albedo=False,
+    edit_normal=False, edit_depth=False, edit_albedo_by_img=False, edit_normal_by_img=False,
+    edit_roughness_by_img=False, edit_irradiance_by_img=False, editing_target_roughness_list=[],
+    editing_target_albedo_list=[], editing_target_irradiance_list=[],
+    insert_object=False, inserting_img_idx=0, num_insert_objects=0, inserting_target_roughness_list=[],
+    inserting_target_irradiance_list=[], inserting_target_albedo_list=[])
+
+
+class Recorder:
+    """Wraps reference callables to record stage boundaries of ONE render_rays chunk."""
+
+    def __init__(self, torch, R, kw, n_keep):
+        self.torch, self.R, self.kw, self.n_keep = torch, R, kw, n_keep
+        self.q, self.pdf, self.nrm, self.simple, self.lut = [], [], [], [], []
+
+    def __enter__(self):
+        R, kw = self.R, self.kw
+        self._q0, self._pdf0 = kw["network_query_fn"], R.sample_pdf
+        self._n0, self._s0, self._g0 = R.get_normal_from_depth_gradient_epsilon, R.raw2outputs_simple, R.F.grid_sample
+        k = self.n_keep
+
+        def q(inputs, viewdirs, fn):
+            out = self._q0(inputs, viewdirs, fn)
+            n = inputs.shape[0]
+            if viewdirs is None:  # eps-normal query: 4 stacked copies of the ray set
+                nr = n // 4
+                sel = np.concatenate([np.arange(k) + s * nr for s in range(4)])
+            else:
+                sel = np.arange(k)
+            self.q.append(dict(pts=inputs[sel].numpy().copy(),
+                               dirs=None if viewdirs is None else viewdirs[sel].numpy().copy(),
+                               raw=out[sel].numpy().copy()))
+            return out
+
+        def pdf(bins, weights, N, det=False, pytest=False):
+            out = self._pdf0(bins, weights, N, det=det, pytest=pytest)
+            self.pdf.append(dict(bins=bins.numpy().copy(), weights=weights.numpy().copy(), samples=out.numpy().copy()))
+            return out
+
+        def nrm(*a, **k_):
+            out = self._n0(*a, **k_)
+            self.nrm.append(out.numpy().copy())
+            return out
+
+        def simple(*a, **k_):
+            rad, coarse = self._s0(*a, **k_)
+            self.simple.append(np.stack([rad.numpy()] + [c.numpy() for c in coarse], 1).copy())
+            return rad, coarse
+
+        def grid(inp, grid_, **k_):
+            out = self._g0(inp, grid_, **k_)
+            self.lut.append(dict(uv=grid_.numpy().copy().reshape(-1, 2), val=out.numpy().copy().reshape(3, -1).T.copy()))
+            return out
+
+        kw["network_query_fn"] = q
+        R.sample_pdf, R.get_normal_from_depth_gradient_epsilon = pdf, nrm
+        R.raw2outputs_simple, R.F.grid_sample = simple, grid
+        return self
+
+    def __exit__(self, *exc):
+        R, kw = self.R, self.kw
+        kw["network_query_fn"] = self._q0
+        R.sample_pdf, R.get_normal_from_depth_gradient_epsilon = self._pdf0, self._n0
+        R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
+
+
+def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6):
+    tmp = tempfile.mkdtemp()
+    try:
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
+    sd_f = ck.synthetic_state_dict(seed=2 * seed + 1, gain=gain)
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    if kw["network_fine"] is not None:
+        kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    near, far = 0.5, 8.0
+    kw.update(near=near, far=far)
+    kw["brdf_lut"] = lut
+
+    rng = np.random.RandomState(1000 + seed)
+    o, d, pix, focal = camera_rays(rng, n_rays)
+    edit = dict(EDIT_KEYS_OFF)
+    gt = {}
+    if mode == "edit":  # configs/IBL-NeRF/kitchen/edit_intrinsic.txt:8-16 (+ by-list albedo on a 2nd object)
+        edit.update(edit_intrinsic=True, num_edit_objects=2, edit_roughness=True, edit_normal=True,
+                    edit_normal_by_img=True, editing_target_roughness_list=[0.0, 0.35],
+                    edit_albedo=True, editing_target_albedo_list=[0.8, 0.1, 0.2, 0.3, 0.6, 0.9])
+        level = rng.choice([0, 10, 20], size=n_rays, p=[0.5, 0.3, 0.2]).astype(np.float32) / np.float32(255)
+        gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["edit_normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    elif mode == "insert":  # configs/IBL-NeRF/living-room-2/object_insert.txt:8-14
+        edit.update(insert_object=True, num_insert_objects=4, inserting_target_roughness_list=[1, 1, 1, 1],
+                    inserting_target_albedo_list=[0.870588, 0.3215686, 0.443137254, .05, .05, .05, .2, .2, .2, .05, .05, .05],
+                    inserting_target_irradiance_list=[0.5, 0.1, 0.2, 0.0])
+        level = rng.choice([0, 10, 20, 30, 40], size=n_rays, p=[0.4, 0.15, 0.15, 0.15, 0.15]).astype(np.float32) / np.float32(255)
+        gt["object_insert_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["object_insert_depth"] = rng.uniform(1, 2, (n_rays, 1)).astype(np.float32)
+        gt["object_insert_normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+
+    rays = torch.from_numpy(np.stack([o, d], 0))
+    gt_t = {k: torch.from_numpy(v.copy()) for k, v in gt.items()}
+    K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
+    with torch.no_grad(), Recorder(torch, R, kw, n_keep) as rec:
+        ret = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values=gt_t,
+                              approximate_radiance=True, **kw, **edit)
+
+    out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(near), far=np.float32(far),
+               gain=np.float64(gain), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1),
+               n_importance=np.int64(n_importance),
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
+               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
+               mode=np.array(mode))
+    for k, v in gt.items():
+        out["gt__" + k] = v
+    for k, v in edit.items():
+        if isinstance(v, list):
+            out["edit__" + k] = np.asarray(v, dtype=np.float32)
+        else:
+            out["edit__" + k] = np.asarray(v)
+    for k, v in ret.items():
+        out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+    # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
+    passes = ["c", "f"] if n_importance > 0 else ["c"]
+    for pi, p in enumerate(passes):
+        main, eps, refl = rec.q[3 * pi:3 * pi + 3]
+        out["q_%s_main_pts" % p], out["q_%s_main_dirs" % p], out["q_%s_main_raw" % p] = main["pts"], main["dirs"], main["raw"]
+        out["q_%s_eps_pts" % p], out["q_%s_eps_sigma" % p] = eps["pts"], eps["raw"]
+        out["q_%s_refl_pts" % p], out["q_%s_refl_dirs" % p], out["q_%s_refl_raw" % p] = refl["pts"], refl["dirs"], refl["raw"]
+        out["normal_raw_%s" % p] = rec.nrm[pi]          # before edit/insert overrides
+        out["prefiltered_env_%s" % p] = rec.simple[pi]  # [N,4,3] linear (pre-gamma)
+        out["lut_uv_%s" % p], out["lut_val_%s" % p] = rec.lut[pi]["uv"], rec.lut[pi]["val"]
+    if n_importance > 0:
+        out["pdf_bins"], out["pdf_weights"], out["pdf_samples"] = rec.pdf[0]["bins"], rec.pdf[0]["weights"], rec.pdf[0]["samples"]
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %4d rays  %s  color range [%.3f, %.3f]  %.2f MB" % (
+        name, n_rays, mode, float(ret["color_map"].min()), float(ret["color_map"].max()), os.path.getsize(path) / 1e6))
+
+
+def small_vectors(torch, R, Hh):
+    """get_rays / sample_pdf / embedder known-answer vectors on tiny seeded inputs."""
+    rng = np.random.RandomState(7)
+    out = {}
+    # get_rays with a non-trivial pose, non-square image
+    H, W, f = 5, 7, np.float32(6.3)
+    K = np.array([[f, 0, 3.25], [0, f * 1.1, 2.5], [0, 0, 1]], dtype=np.float32)
+    A = rng.normal(size=(3, 3))
+    Q, _ = np.linalg.qr(A)
+    c2w = np.concatenate([Q, rng.normal(size=(3, 1))], 1).astype(np.float32)
+    ro, rd = Hh.get_rays(H, W, K, torch.from_numpy(c2w))
+    out.update(gr_H=np.int64(H), gr_W=np.int64(W), gr_K=K, gr_c2w=c2w, gr_o=ro.numpy().copy(), gr_d=rd.numpy().copy())
+    # sample_pdf(det=True): generic, spiky, flat/zero weights, and non-uniform bins
+    bins = np.sort(rng.uniform(0.5, 8, (6, 63)).astype(np.float32), -1)
+    w = rng.uniform(0, 1, (6, 62)).astype(np.float32)
+    w[1] = 0; w[1, 30] = 1.0          # one spike
+    w[2] = 0                          # all zero -> uniform pdf from the 1e-5 floor
+    w[3, :31] = 0                     # half empty
+    w[4] = 1e-7                       # tiny
+    s = Hh.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), 128, det=True)
+    out.update(sp_bins=bins, sp_weights=w, sp_samples=s.numpy().copy())
+    s16 = Hh.sample_pdf(torch.from_numpy(bins[:, :9].copy()), torch.from_numpy(w[:, :8].copy()), 16, det=True)
+    out.update(sp16_samples=s16.numpy().copy())
+    # embedders (positional_embedder.py:4-52)
+    import nerf_models.positional_embedder as PE
+    e10, d10 = PE.get_embedder(10, 0)
+    e4, d4 = PE.get_embedder(4, 0)
+    x = np.concatenate([rng.uniform(-9, 9, (24, 3)), np.array([[0, 0, 0], [8.0, -8.0, 1e-4], [3.1415927, -1.5707964, 6.2831855]])], 0).astype(np.float32)
+    out.update(pe_x=x, pe_e10=e10(torch.from_numpy(x)).numpy().copy(), pe_e4=e4(torch.from_numpy(x)).numpy().copy())
+    assert d10 == 63 and d4 == 27
+    np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **out)
+    print("small_vectors.npz written")
+
+
+def main():
+    torch, R, M, Hh = import_reference()
+    torch.manual_seed(0)
+    lut = load_lut(torch)
+    shutil.copyfile(os.path.join(REF, "data", "ibl_brdf_lut.png"), os.path.join(OUT, "ibl_brdf_lut.png"))
+    small_vectors(torch, R, Hh)
+    # config 1 (BASELINE.json configs[0]): coarse only
+    run_fixture("cfg1_coarse_g10", torch, R, M, lut, n_rays=128, n_importance=0, gain=1.0, seed=0)
+    # configs 2/3 kernel mix: 64+128, well-conditioned and wide-range checkpoints
+    run_fixture("plain_g10", torch, R, M, lut, n_rays=256, n_importance=128, gain=1.0, seed=0)
+    run_fixture("plain_g16", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.6, seed=1)
+    # config 4 / config 5 override paths
+    run_fixture("edit_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=2, mode="edit")
+    run_fixture("insert_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=3, mode="insert")
+
+
+if __name__ == "__main__":
+    main()
