@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the forward/inference render path (64 coarse + 128 fine samples)
+on the 800x800 "Kitchen" test view of BASELINE.json configs[1], synthetic checkpoint and camera
+(SURVEY.md §8 d: no dataset or checkpoint ships with the reference).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one full frame (640 000 rays): every rank renders its row tile of the frame and the
+ranks reassemble it with one RCCL all-gather (strong scaling: the frame is fixed, N divides it).
+Inputs (weights, LUT, camera) are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line.  The `roofline` object times the dominant kernel (the fused MLP) with HIP events on
+the launch stream; `cpu_baseline` times the numpy oracle on a bounded sample of the same rays.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+H = W = 800
+FOV_DEG = 60.0
+NEAR, FAR = 0.5, 8.0
+N_SAMPLES, N_IMPORTANCE = 64, 128
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def load_lut():
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "ibl_brdf_lut.png")).convert("RGB"), dtype=np.float32)
+    return np.ascontiguousarray((img / np.float32(255.0)).transpose(2, 0, 1))
+
+
+def camera():
+    f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(FOV_DEG)))
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    return K, c2w
+
+
+def cpu_baseline(sdc, sdf, lut, K, c2w, gpu_color_fn, min_seconds=10.0, batch=256, max_batches=8):
+    """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import iblnerf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ro, rd = O.get_rays(H, W, K, c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    pix = np.random.RandomState(0).permutation(H * W)
+    n, t, colors, idx = 0, 0.0, [], []
+    for b in range(max_batches):
+        sel = pix[b * batch:(b + 1) * batch]
+        t0 = time.perf_counter()
+        res = O.render_rays(sdc, sdf, ro[sel], rd[sel], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)
+        t += time.perf_counter() - t0
+        n += len(sel)
+        colors.append(res["color_map"])
+        idx.append(sel)
+        if t >= min_seconds:
+            break
+    idx = np.concatenate(idx)
+    ref = np.concatenate(colors).astype(np.float64)
+    got = gpu_color_fn(idx).astype(np.float64)
+    mse = float(np.mean((got - ref) ** 2))
+    psnr = float(10 * np.log10(1.0 / max(mse, 1e-30)))
+    return {"value": n / t, "unit": "rays/s", "cores": int(cores), "kind": "port",
+            "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm)" % n}, psnr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays-per-launch", type=int, default=65536)
+    ap.add_argument("--inference-min", action="store_true",
+                    help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = _pkg.load()
+    from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R
+    sdc, sdf = ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
+    lut = load_lut()
+    K, c2w = camera()
+    r = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=not args.inference_min,
+                   max_rays_per_launch=args.rays_per_launch)
+    r.load_weights(0, sdc)
+    r.load_weights(1, sdf)
+    r.load_lut(lut)
+    row0, n_rows = D.tile_rows(H, rank, world)
+    ro, rd = r.get_rays(H, W, K, c2w, row0, n_rows)     # rays resident in HBM before the timed region
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+    def step():
+        maps = r.render_rays(ro, rd, NEAR, FAR)
+        if world > 1:
+            buf, _ = D.pack_maps(maps, D.EXPORT_KEYS, n_rows, W)
+            D.all_gather_frame(buf, H, W)
+        return maps
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        maps = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
+    r.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    mlp_ms, n_launch, flop = r.last_mlp_time()
+    r.set_profiling(False)
+    achieved = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            "metric": "rays/sec (64c+128f samples) at 800x800 Kitchen; PSNR vs ref",
+            "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (bf16 hi/lo split, 3 MFMA products, fp32 accumulate)",
+            "data": "synthetic (seeded checkpoint in the reference state-dict schema, synthetic pinhole camera)",
+            "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
+                                   + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
+                       "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
+                       "parallelism": "ray-tile x%d + RCCL all-gather" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "ibl::mlp_kernel<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
+                         "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
+                         "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; the kernel issues 3 bf16 MFMA products per MAC"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            color = maps["color_map"]
+
+            def gpu_color(idx):
+                return color[torch.as_tensor(idx, device=color.device)].cpu().numpy()
+
+            line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(sdc, sdf, lut, K, c2w, gpu_color)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of the C-ABI in include/iblnerf.h (libiblnerf_hip.so, built by build.py).
+
+There is no CPU fallback: if the library is missing, or no HIP device is present, the compute
+entry points raise.  Nothing in this package imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiblnerf_hip.so")
+
+EXPORTS = [
+    "iblnerf_default_options", "iblnerf_create", "iblnerf_destroy", "iblnerf_last_error", "iblnerf_blob_floats",
+    "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host", "iblnerf_stream_bytes",
+    "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
+    "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
+]
+
+
+class IblNerfError(RuntimeError):
+    """A negative iblnerf_status came back; message from iblnerf_last_error."""
+
+
+class Options(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("n_importance", C.c_int32), ("epsilon", C.c_float),
+                ("gamma_correct", C.c_int32), ("lut_coefficient_f0", C.c_int32),
+                ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
+                ("max_rays_per_launch", C.c_int32), ("device", C.c_int32)]
+
+
+FP = C.c_void_p  # device float*
+
+
+class Overrides(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("num_objects", C.c_int32), ("edit_depth", C.c_int32),
+                ("edit_normal", C.c_int32), ("edit_albedo", C.c_int32), ("edit_albedo_by_img", C.c_int32),
+                ("edit_roughness", C.c_int32), ("n_roughness_list", C.c_int32),
+                ("d_mask", FP), ("d_depth", FP), ("d_normal", FP), ("d_albedo", FP),
+                ("roughness_list", C.c_float * 8), ("albedo_list", C.c_float * 24),
+                ("irradiance_list", C.c_float * 8)]
+
+
+class Maps(C.Structure):
+    _fields_ = [("color_map", FP), ("radiance_map", FP), ("radiance_map_k", FP * 3),
+                ("reflected_coarse_radiance_map_k", FP * 3), ("irradiance_map", FP),
+                ("reflected_radiance_map", FP), ("prefiltered_reflected_map", FP), ("albedo_map", FP),
+                ("roughness_map", FP), ("specular_map", FP), ("diffuse_map", FP), ("n_dot_v_map", FP),
+                ("target_normal_map", FP), ("disp_map", FP), ("acc_map", FP), ("depth_map", FP),
+                ("target_depth_map", FP), ("weights", FP)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("fine", Maps), ("coarse", Maps), ("z_std", FP)]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and declare prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise IblNerfError("%s not found: build it with `python ibl-nerf_amd/build.py` "
+                           "(there is no CPU fallback for the render path)" % path)
+    lib = C.CDLL(path)
+    lib.iblnerf_default_options.argtypes = [C.POINTER(Options)]
+    lib.iblnerf_default_options.restype = None
+    lib.iblnerf_create.argtypes = [C.POINTER(Options), C.POINTER(C.c_void_p)]
+    lib.iblnerf_destroy.argtypes = [C.c_void_p]
+    lib.iblnerf_destroy.restype = None
+    lib.iblnerf_last_error.argtypes = [C.c_void_p]
+    lib.iblnerf_last_error.restype = C.c_char_p
+    lib.iblnerf_blob_floats.restype = C.c_size_t
+    lib.iblnerf_stream_bytes.restype = C.c_size_t
+    lib.iblnerf_table_floats.restype = C.c_size_t
+    lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.iblnerf_upload_lut.argtypes = [C.c_void_p, C.c_void_p]
+    lib.iblnerf_pack_weights_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.iblnerf_encode_host.argtypes = [C.c_float, C.c_int, C.c_void_p]
+    lib.iblnerf_encode_host.restype = None
+    lib.iblnerf_get_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, FP, FP]
+    lib.iblnerf_network_query.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, C.c_int, FP, FP]
+    lib.iblnerf_sample_pdf.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP]
+    lib.iblnerf_render_rays.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
+                                        C.POINTER(Overrides), C.POINTER(Outputs)]
+    lib.iblnerf_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.iblnerf_last_mlp_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    for n in ("iblnerf_create", "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host",
+              "iblnerf_get_rays", "iblnerf_network_query", "iblnerf_sample_pdf", "iblnerf_render_rays",
+              "iblnerf_set_profiling", "iblnerf_last_mlp_time"):
+        getattr(lib, n).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def default_options() -> Options:
+    o = Options()
+    load_library().iblnerf_default_options(C.byref(o))
+    return o
+
+
+def check(ctx, rc: int):
+    if rc != 0:
+        msg = load_library().iblnerf_last_error(ctx)
+        raise IblNerfError("iblnerf status %d: %s" % (rc, (msg or b"").decode()))

@@ -1,0 +1,71 @@
+"""Build recipe for the HIP library (csrc/ -> ibl-nerf_amd/libiblnerf_hip.so), gfx950 only.
+
+    python ibl-nerf_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is built IN-TREE (git-ignored, but it travels to
+the GPU box with the gpurun snapshot).  render_kernels.hip is compiled with -ffp-contract=off:
+the reference's elementwise torch ops round multiply and add separately and sample positions
+are sensitive to that (see the file header).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libiblnerf_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(os.path.dirname(HERE), "include")]
+# (source, extra flags placed before -c)
+SOURCES = [
+    ("mlp_kernel.hip", []),
+    ("render_kernels.hip", ["-ffp-contract=off"]),
+    ("api.cpp", ["-x", "hip"]),
+    ("pack.cpp", ["-x", "hip"]),
+]
+HEADERS = ["layout.h", "kernels.h", "pack.h", "sincos_enc.h", os.path.join("..", "..", "include", "iblnerf.h")]
+
+
+def _digest(paths, extra):
+    h = hashlib.sha256(" ".join(extra).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(verbose=True, force=False):
+    """Compile every source whose inputs changed, then link.  Returns the library path."""
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, relink = [], force or not os.path.exists(LIB)
+    for src, flags in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src + ".o")
+        stamp = op + ".sha"
+        dg = _digest([sp] + hdrs, COMMON + flags)
+        old = open(stamp).read() if os.path.exists(stamp) else ""
+        if force or old != dg or not os.path.exists(op):
+            cmd = [HIPCC] + COMMON + flags + ["-c", sp, "-o", op]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(dg)
+            relink = True
+        objs.append(op)
+    if relink:
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

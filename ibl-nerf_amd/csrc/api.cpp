@@ -1,0 +1,395 @@
+// C-ABI implementation (include/iblnerf.h): context, weight/LUT upload, workspace, and the
+// render_rays orchestration that strings the kernels together.
+#include "../../include/iblnerf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "pack.h"
+#include "sincos_enc.h"
+
+using namespace ibl;
+
+namespace {
+std::string g_create_error;
+
+// algorithmic FLOPs per point (SURVEY.md §8 d): 2 * MACs of the nn.Linear layers on the path
+constexpr double FLOP_FULL = 1591552.0, FLOP_TRUNK = 982528.0, FLOP_REFL = 1458944.0;
+}  // namespace
+
+struct iblnerf_ctx {
+    iblnerf_options opt;
+    std::string err;
+    int n_cu = 256;
+    // per network
+    char* d_stream[2] = {nullptr, nullptr};
+    float* d_tables[2] = {nullptr, nullptr};
+    bool have_net[2] = {false, false};
+    float* d_lut = nullptr;
+    bool have_lut = false;
+    // workspace
+    long ws_rays = 0;
+    int Sc = 0, Sf = 0, Smax = 0;
+    float *zc = nullptr, *z_fine = nullptr, *pts = nullptr, *raw = nullptr, *sig4 = nullptr, *w_c = nullptr,
+          *w_f = nullptr, *state = nullptr, *refl_o = nullptr, *refl_d = nullptr, *refl_raw = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double flop_alg = 0.0;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, expr)                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return (ctx)->fail(IBLNERF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+void iblnerf_default_options(iblnerf_options* o) {
+    std::memset(o, 0, sizeof *o);
+    o->n_samples = 64;
+    o->n_importance = 128;
+    o->epsilon = 0.01f;
+    o->gamma_correct = 1;
+    o->lut_coefficient_f0 = 0;
+    o->correct_depth_for_prefiltered_radiance = 1;
+    o->coarse_outputs = 1;
+    o->max_rays_per_launch = 65536;
+    o->device = 0;
+}
+
+size_t iblnerf_blob_floats(void) { return blob_floats(); }
+size_t iblnerf_stream_bytes(void) { return (size_t)STREAM_BYTES; }
+size_t iblnerf_table_floats(void) { return (size_t)TAB_FLOATS; }
+
+int iblnerf_pack_weights_host(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                              float* h_tables, size_t table_floats) {
+    if (!h_blob || !h_stream || !h_tables) return IBLNERF_ERR_INVALID;
+    if (n_floats != blob_floats() || stream_bytes != (size_t)STREAM_BYTES || table_floats != (size_t)TAB_FLOATS)
+        return IBLNERF_ERR_INVALID;
+    pack_network(h_blob, h_stream, h_tables);
+    return IBLNERF_OK;
+}
+
+void iblnerf_encode_host(float x, int n_freq, float* h_out) {
+    const TurnPair t = to_turns(x);
+    for (int k = 0; k < n_freq; ++k) sincos_turns(t, (float)(1 << k), &h_out[2 * k], &h_out[2 * k + 1]);
+}
+
+const char* iblnerf_last_error(const iblnerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
+    if (!opts || !out_ctx) { g_create_error = "null argument"; return IBLNERF_ERR_INVALID; }
+    if (opts->n_samples < 3 || opts->n_samples > 256 || opts->n_importance < 0 ||
+        opts->n_samples + opts->n_importance > 256 || opts->max_rays_per_launch < 1) {
+        g_create_error = "unsupported sample counts: need 3 <= N_samples, N_samples + N_importance <= 256";
+        return IBLNERF_ERR_INVALID;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0 || opts->device >= n_dev) {
+        g_create_error = std::string("no usable HIP device (the renderer has no CPU fallback): ") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device ordinal out of range");
+        return IBLNERF_ERR_HIP;
+    }
+    if ((e = hipSetDevice(opts->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return IBLNERF_ERR_HIP; }
+    iblnerf_ctx* c = new iblnerf_ctx();
+    c->opt = *opts;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, opts->device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    c->Sc = opts->n_samples;
+    c->Sf = opts->n_samples + opts->n_importance;
+    c->Smax = c->Sf;
+    c->ws_rays = opts->max_rays_per_launch;
+    const size_t R = (size_t)c->ws_rays, Sm = (size_t)c->Smax, Sc = (size_t)c->Sc;
+    struct { float** p; size_t n; } bufs[] = {
+        {&c->zc, Sc}, {&c->z_fine, R * Sm}, {&c->pts, 4 * R * Sm * 3}, {&c->raw, R * Sm * RAW_CH},
+        {&c->sig4, 4 * R * Sm}, {&c->w_c, R * Sc}, {&c->w_f, R * Sm}, {&c->state, R * ST_FLOATS},
+        {&c->refl_o, R * 3}, {&c->refl_d, R * 3}, {&c->refl_raw, R * Sc * REFL_CH}};
+    for (auto& b : bufs)
+        if (hipMalloc((void**)b.p, b.n * sizeof(float)) != hipSuccess) {
+            g_create_error = "hipMalloc of the render workspace failed";
+            iblnerf_destroy(c);
+            return IBLNERF_ERR_NOMEM;
+        }
+    for (int w = 0; w < 2; ++w)
+        if (hipMalloc((void**)&c->d_stream[w], STREAM_BYTES) != hipSuccess ||
+            hipMalloc((void**)&c->d_tables[w], TAB_BYTES) != hipSuccess) {
+            g_create_error = "hipMalloc of the weight stream failed";
+            iblnerf_destroy(c);
+            return IBLNERF_ERR_NOMEM;
+        }
+    if (hipMalloc((void**)&c->d_lut, 3 * 512 * 512 * sizeof(float)) != hipSuccess) {
+        g_create_error = "hipMalloc of the LUT failed";
+        iblnerf_destroy(c);
+        return IBLNERF_ERR_NOMEM;
+    }
+    *out_ctx = c;
+    return IBLNERF_OK;
+}
+
+void iblnerf_destroy(iblnerf_ctx* c) {
+    if (!c) return;
+    float* bufs[] = {c->zc, c->z_fine, c->pts, c->raw, c->sig4, c->w_c, c->w_f, c->state, c->refl_o, c->refl_d,
+                     c->refl_raw, c->d_lut, c->d_tables[0], c->d_tables[1]};
+    for (float* b : bufs)
+        if (b) (void)hipFree(b);
+    for (int w = 0; w < 2; ++w)
+        if (c->d_stream[w]) (void)hipFree(c->d_stream[w]);
+    for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete c;
+}
+
+int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_t n_floats) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || !h_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights: which must be 0/1, blob non-null");
+    if (n_floats != blob_floats())
+        return c->fail(IBLNERF_ERR_INVALID, "upload_weights: blob has %zu floats, the IBLNeRF state dict has %zu", n_floats, blob_floats());
+    std::vector<char> stream((size_t)STREAM_BYTES);
+    std::vector<float> tab((size_t)TAB_FLOATS);
+    pack_network(h_blob, stream.data(), tab.data());
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());   // a previous render may still be reading the old stream
+    HIP_TRY(c, hipMemcpy(c->d_stream[which], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tables[which], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
+    c->have_net[which] = true;
+    return IBLNERF_OK;
+}
+
+int iblnerf_upload_lut(iblnerf_ctx* c, const float* h_rgb) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!h_rgb) return c->fail(IBLNERF_ERR_INVALID, "upload_lut: null LUT");
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(c->d_lut, h_rgb, 3 * 512 * 512 * sizeof(float), hipMemcpyHostToDevice));
+    c->have_lut = true;
+    return IBLNERF_OK;
+}
+
+int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_K, const float* h_c2w, int row0,
+                     int n_rows, float* d_rays_o, float* d_rays_d) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!h_K || !h_c2w || !d_rays_o || !d_rays_d || H <= 0 || W <= 0 || row0 < 0 || n_rows < 0 || row0 + n_rows > H)
+        return c->fail(IBLNERF_ERR_INVALID, "get_rays: bad arguments (H=%d W=%d row0=%d n_rows=%d)", H, W, row0, n_rows);
+    Camera cam;
+    std::memcpy(cam.K, h_K, sizeof cam.K);
+    std::memcpy(cam.c2w, h_c2w, sizeof cam.c2w);
+    HIP_TRY(c, launch_get_rays(W, row0, n_rows, cam, d_rays_o, d_rays_d, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
+                   int pts_per_ray, long n_pts, float* out) {
+    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
+    MlpArgs a;
+    a.stream = c->d_stream[which];
+    a.tables = c->d_tables[which];
+    a.pts = pts;
+    a.dirs = dirs;
+    a.out = out;
+    a.n_pts = n_pts;
+    a.pts_per_ray = pts_per_ray;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (c->profiling) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(c, hipEventCreate(&e0));
+            HIP_TRY(c, hipEventCreate(&e1));
+            c->ev_pool.emplace_back(e0, e1);
+        }
+        ev = &c->ev_pool[c->ev_used++];
+        HIP_TRY(c, hipEventRecord(ev->first, s));
+    }
+    HIP_TRY(c, launch_mlp(variant, a, c->n_cu, s));
+    if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
+    c->flop_alg += (double)n_pts * (variant == VAR_FULL ? FLOP_FULL : variant == VAR_TRUNK ? FLOP_TRUNK : FLOP_REFL);
+    return IBLNERF_OK;
+}
+
+int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                          const float* d_viewdirs, float* d_out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || !d_pts || !d_out || n_rays < 0 || n_samples < 1)
+        return c->fail(IBLNERF_ERR_INVALID, "network_query: bad arguments");
+    if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "network_query: weights of network %d not uploaded", which);
+    return run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
+                   (long)n_rays * n_samples, d_out);
+}
+
+int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
+                       int n_bins, int n_out, float* d_samples) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!d_bins || !d_weights || !d_samples || n_rays < 0 || n_bins < 2 || n_bins > 257 || n_out < 1)
+        return c->fail(IBLNERF_ERR_INVALID, "sample_pdf: need 2 <= n_bins <= 257, n_out >= 1");
+    HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_samples,
+                                 (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S) {
+    auto off = [&](float* p, long w) { return p ? p + r0 * w : nullptr; };
+    PassOutputs o;
+    o.color = off(m.color_map, 3);
+    o.radiance = off(m.radiance_map, 3);
+    for (int k = 0; k < 3; ++k) {
+        o.radiance_k[k] = off(m.radiance_map_k[k], 3);
+        o.refl_coarse_k[k] = off(m.reflected_coarse_radiance_map_k[k], 3);
+    }
+    o.irradiance = off(m.irradiance_map, 1);
+    o.reflected_radiance = off(m.reflected_radiance_map, 3);
+    o.prefiltered = off(m.prefiltered_reflected_map, 3);
+    o.albedo = off(m.albedo_map, 3);
+    o.roughness = off(m.roughness_map, 1);
+    o.specular = off(m.specular_map, 3);
+    o.diffuse = off(m.diffuse_map, 3);
+    o.n_dot_v = off(m.n_dot_v_map, 1);
+    o.normal = off(m.target_normal_map, 3);
+    o.disp = off(m.disp_map, 1);
+    o.acc = off(m.acc_map, 1);
+    o.depth = off(m.depth_map, 1);
+    o.target_depth = off(m.target_depth_map, 1);
+    o.weights = off(m.weights, S);
+    return o;
+}
+
+// One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
+static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
+                     int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
+                     const PassOutputs& out) {
+    const int Sc = c->Sc;
+    // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
+    HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
+    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw);
+    if (rc) return rc;
+    // epsilon-normal: 4 offset copies, trunk only (normal_from_depth.py:139-158)
+    HIP_TRY(c, launch_make_points(1, ro, rd, z, z_stride, c->opt.epsilon, R, S, c->pts, s));
+    rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
+    if (rc) return rc;
+    PassAArgs a;
+    a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
+    a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = c->opt.epsilon;
+    a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
+    a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
+    a.ov = ov; a.state = c->state; a.refl_o = c->refl_o; a.refl_d = c->refl_d; a.R = R; a.S = S;
+    HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
+    // reflected ray through the same network, always on the coarse z grid (:439-446)
+    HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, c->zc, 0, 0.f, R, Sc, c->pts, s));
+    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw);
+    if (rc) return rc;
+    PassBArgs b;
+    b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = Sc;
+    b.gamma_correct = c->opt.gamma_correct; b.out = out; b.R = R;
+    HIP_TRY(c, launch_pass_b(b, s));
+    return IBLNERF_OK;
+}
+
+int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                        float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_outputs* outs) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!d_rays_o || !d_rays_d || !outs || n_rays < 0) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays/outputs");
+    const bool fine = c->opt.n_importance > 0;
+    if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
+    if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");
+    const int fine_net = c->have_net[1] ? 1 : 0;   // run_fn = network_fn if network_fine is None (:705)
+    OverrideArgs ov;
+    std::memset(&ov, 0, sizeof ov);
+    if (ovr && ovr->mode != 0) {
+        if (ovr->mode != 1 && ovr->mode != 2) return c->fail(IBLNERF_ERR_INVALID, "overrides.mode must be 0, 1 or 2");
+        if (ovr->num_objects <= 0 || ovr->num_objects > 8)   // reference: assert num_*_objects > 0 (:222, :232)
+            return c->fail(IBLNERF_ERR_INVALID, "num_edit_objects / num_insert_objects must be in 1..8");
+        if (!ovr->d_mask) return c->fail(IBLNERF_ERR_INVALID, "overrides need the mask image rows");
+        if (ovr->mode == 2 && (!ovr->d_depth || !ovr->d_normal))
+            return c->fail(IBLNERF_ERR_INVALID, "insert_object needs object_insert_depth and object_insert_normal rows");
+        if (ovr->mode == 1 && ovr->edit_depth && !ovr->d_depth) return c->fail(IBLNERF_ERR_INVALID, "edit_depth needs edit_depth rows");
+        if (ovr->mode == 1 && ovr->edit_normal && !ovr->d_normal) return c->fail(IBLNERF_ERR_INVALID, "edit_normal needs edit_normal rows");
+        if (ovr->mode == 1 && ovr->edit_albedo && ovr->edit_albedo_by_img && !ovr->d_albedo)
+            return c->fail(IBLNERF_ERR_INVALID, "edit_albedo_by_img needs edit_albedo rows");
+        if (ovr->n_roughness_list < 0 || ovr->n_roughness_list > 8) return c->fail(IBLNERF_ERR_INVALID, "roughness list too long");
+        ov.mode = ovr->mode; ov.num_objects = ovr->num_objects;
+        ov.edit_depth = ovr->edit_depth; ov.edit_normal = ovr->edit_normal; ov.edit_albedo = ovr->edit_albedo;
+        ov.edit_albedo_by_img = ovr->edit_albedo_by_img; ov.edit_roughness = ovr->edit_roughness;
+        ov.n_rough_list = ovr->n_roughness_list;
+        ov.mask_stride = 3; ov.depth_stride = 1;
+        std::memcpy(ov.rough_list, ovr->roughness_list, sizeof ov.rough_list);
+        std::memcpy(ov.albedo_list, ovr->albedo_list, sizeof ov.albedo_list);
+        std::memcpy(ov.irr_list, ovr->irradiance_list, sizeof ov.irr_list);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    c->ev_used = 0;
+    c->flop_alg = 0.0;
+    const int Sc = c->Sc, Sf = c->Sf;
+    HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->zc, s));
+    for (long r0 = 0; r0 < n_rays; r0 += c->ws_rays) {
+        const long R = (n_rays - r0 < c->ws_rays) ? n_rays - r0 : c->ws_rays;
+        const float* ro = d_rays_o + 3 * r0;
+        const float* rd = d_rays_d + 3 * r0;
+        OverrideArgs o = ov;
+        if (o.mode) {
+            o.mask = ovr->d_mask + 3 * r0;
+            o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;
+            o.normal_img = ovr->d_normal ? ovr->d_normal + 3 * r0 : nullptr;
+            o.albedo_img = ovr->d_albedo ? ovr->d_albedo + 3 * r0 : nullptr;
+        }
+        int rc;
+        if (!fine) {
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc));
+            if (rc) return rc;
+            continue;
+        }
+        if (c->opt.coarse_outputs) {
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc));
+            if (rc) return rc;
+        } else {   // density only: all the fine sampling needs from the coarse network
+            HIP_TRY(c, launch_make_points(0, ro, rd, c->zc, 0, 0.f, R, Sc, c->pts, s));
+            rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4);
+            if (rc) return rc;
+            HIP_TRY(c, launch_sigma_weights(rd, c->zc, 0, c->sig4, R, Sc, c->w_c, s));
+        }
+        HIP_TRY(c, launch_fine_z(c->zc, Sc, c->w_c, R, c->opt.n_importance, c->z_fine, outs->z_std ? outs->z_std + r0 : nullptr, s));
+        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf));
+        if (rc) return rc;
+    }
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_profiling(iblnerf_ctx* c, int enabled) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    c->profiling = enabled != 0;
+    return IBLNERF_OK;
+}
+
+int iblnerf_last_mlp_time(iblnerf_ctx* c, float* ms_total, int* n_launches, double* flop_algorithmic) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    float tot = 0.f;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (n_launches) *n_launches = (int)c->ev_used;
+    if (flop_algorithmic) *flop_algorithmic = c->flop_alg;
+    return IBLNERF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Internal kernel launch interface (device pointers everywhere).  The public surface is
+// include/iblnerf.h; these are the pieces api.cpp strings together.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace ibl {
+
+struct MlpArgs {
+    const char* stream;   // packed weight stream of one network (STREAM_BYTES)
+    const float* tables;  // TAB_FLOATS floats
+    const float* pts;     // [n_pts,3]
+    const float* dirs;    // [n_pts / pts_per_ray, 3] view directions (null for VAR_TRUNK)
+    float* out;           // [n_pts,18] (FULL) | [n_pts] (TRUNK) | [n_pts,13] (REFL)
+    long n_pts;
+    int pts_per_ray;
+};
+hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);
+
+// --- per-ray kernels (render_kernels.hip) ------------------------------------------------------
+
+// nerf_renderer_helper.py:36-45.  Rows [row0, row0+n_rows) of an H x W image.
+struct Camera { float K[9]; float c2w[12]; };   // 3x3 intrinsics, 3x4 camera-to-world, row-major (kernel argument)
+hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s);
+
+// ibl_nerf_renderer.py:670-672: z_k = near (1 - t_k) + far t_k, t = linspace(0,1,S)
+hipError_t launch_coarse_z(float near, float far, int S, float* z, hipStream_t s);
+
+// Point batches (rays x samples packed contiguously, [V][R][S][3]):
+//   mode 0: origin + dir * z                                  (ibl_nerf_renderer.py:200, :440)
+//   mode 1: V = 4 epsilon-offset copies (+-eps*right, +-eps*up) (normal_from_depth.py:143-156)
+// z_stride = 0 -> one z row shared by all rays, else per-ray rows of length z_stride.
+hipError_t launch_make_points(int mode, const float* origin, const float* dir, const float* z, int z_stride,
+                              float eps, long R, int S, float* out, hipStream_t s);
+
+struct OverrideArgs {          // edit_intrinsic / insert_object branches, ibl_nerf_renderer.py:218-238, 253-256, 378-410
+    int mode;                  // 0 none, 1 edit_intrinsic, 2 insert_object
+    int num_objects;
+    int edit_depth, edit_normal, edit_albedo, edit_albedo_by_img, edit_roughness;
+    int n_rough_list;
+    const float* mask;         // [R, mask_stride] (channel 0 is read)
+    int mask_stride;
+    const float* depth_img;    // [R] (edit_depth / object_insert_depth, channel 0)
+    int depth_stride;
+    const float* normal_img;   // [R,3] in [0,1]
+    const float* albedo_img;   // [R,3]
+    float rough_list[8];
+    float albedo_list[24];
+    float irr_list[8];
+};
+
+constexpr int ST_FLOATS = 12;  // per-ray record handed from pass A to pass B (see render_kernels.hip)
+
+struct PassOutputs {           // any pointer may be null (skipped).  Shapes per ray.
+    float* color;              // 3
+    float* radiance;           // 3
+    float* radiance_k[3];      // 3 each
+    float* refl_coarse_k[3];   // 3 each
+    float* irradiance;         // 1
+    float* reflected_radiance; // 3
+    float* prefiltered;        // 3
+    float* albedo;             // 3
+    float* roughness;          // 1
+    float* specular;           // 3
+    float* diffuse;            // 3
+    float* n_dot_v;            // 1
+    float* normal;             // 3
+    float* disp;               // 1
+    float* acc;                // 1
+    float* depth;              // 1
+    float* target_depth;       // 1
+    float* weights;            // S
+};
+
+struct PassAArgs {
+    const float* rays_o; const float* rays_d;   // [R,3]
+    const float* z; int z_stride;               // see launch_make_points
+    const float* raw;                           // [R,S,18]
+    const float* sig4;                          // [4,R,S]
+    float* weights;                             // [R,S] (always written: sample_pdf input / output map)
+    const float* lut;                           // [3,512,512]
+    float near, far, eps;
+    int lut_coefficient_F0;                     // 0 -> 'F' (shipped), 1 -> 'F0'
+    int correct_depth;                          // correct_depth_for_prefiltered_radiance_infer
+    OverrideArgs ov;
+    float* state;                               // [R, ST_FLOATS]
+    float* refl_o; float* refl_d;               // [R,3] reflected-ray origin / direction
+    long R; int S;
+};
+hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma_correct, hipStream_t s);
+
+// coarse pass of the inference-minimum mode: compositing weights only (ibl_nerf_renderer.py:203-206, 241-245)
+hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, long R, int S,
+                                float* weights, hipStream_t s);
+
+struct PassBArgs {
+    const float* state;        // [R, ST_FLOATS]
+    const float* refl_raw;     // [R,64,13]
+    const float* refl_d;       // [R,3]
+    const float* zc;           // [Sc] coarse z (z_vals_constant)
+    int Sc;
+    int gamma_correct;
+    PassOutputs out;
+    long R;
+};
+hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s);
+
+// nerf_renderer_helper.py:91-134 (det=True).  bins [R,nb], weights [R,nb-1] -> samples [R,n_out]
+hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, long R, int nb,
+                             int n_out, float* samples, hipStream_t s);
+
+// ibl_nerf_renderer.py:701-707, :718: mids of zc, sample_pdf on weights[:,1:-1], sort(cat), z_std
+hipError_t launch_fine_z(const float* zc, int Sc, const float* weights_c, long R, int n_imp, float* z_fine,
+                         float* z_std, hipStream_t s);
+
+}  // namespace ibl

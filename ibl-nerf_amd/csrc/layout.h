@@ -1,0 +1,106 @@
+// Device weight-stream layout shared by the host packer (pack.cpp) and the fused MLP kernel
+// (mlp_kernel.hip).
+//
+// The reference evaluates IBLNeRF.forward (src/nerf_models/ibl_nerf.py:154-210) as 23 separate
+// nn.Linear calls.  Here one wavefront owns 32 sample points and keeps their 256-wide activation
+// in registers for the whole network; the weights are the MFMA *A* operand and arrive as a stream
+// of 32 KiB "chunks" through an LDS ring.  Every fp32 weight w is stored as a bf16 pair
+// (hi = rne(w), lo = rne(w - hi)) and every GEMM is three MFMA products
+// (Wh*Xh + Wh*Xl + Wl*Xh, fp32 accumulate): ~17 significand bits per operand, which is what the
+// 1e-3 parity bar needs.
+//
+// MFMA shape: v_mfma_f32_32x32x16_bf16.  Lane l = (i = l & 31, h = l >> 5).
+//   A (weights):      lane holds 8 k-slots (8h .. 8h+7) of output row i of the 32-row tile
+//   B (activations):  lane holds the same 8 k-slots of point column i
+//   D (result):       lane holds, for point column i, rows (r&3) + 8*(r>>2) + 4h, r = 0..15
+// The result layout of one layer IS the B layout of the next if the next layer's k-slots are
+// numbered accordingly, so the packer permutes the K order of every weight matrix and no
+// activation ever leaves the register file:
+//   k-step j = 2t + s (t = input tile 0..7, s = 0..1), slot (h, e)  <->  input feature
+//   32t + (e&3) + 8*(2s + (e>>2)) + 4h            (= accumulator register r = 8s + e of tile t)
+//
+// One k-step of one 32-row tile is 2 KiB: [64 lanes x 8 bf16 hi][64 lanes x 8 bf16 lo], so a
+// lane's fragment is one conflict-free ds_read_b128 at lane*16.
+#pragma once
+#include <stdint.h>
+
+namespace ibl {
+
+constexpr int KSTEP_BYTES = 2048;
+constexpr int CHUNK_KSTEPS = 16;
+constexpr int CHUNK_BYTES = KSTEP_BYTES * CHUNK_KSTEPS;  // 32 KiB
+constexpr int RING_SLOTS = 3;
+
+// The stream is a flat sequence of k-steps; a chunk is 16 consecutive k-steps regardless of tile
+// boundaries.  Per layer, tile after tile; inside a tile first the encoding k-steps (if the layer
+// has a concatenated encoding input), then the 16 k-steps over the 256-feature activation:
+//   layer                          k-steps/tile   tiles   chunks   first chunk
+constexpr int CH_L0 = 0;     // positions_linears.0        4 (PE)          8       2
+constexpr int CH_L1 = 2;     // positions_linears.1..4     16              8       8 each (2..33)
+constexpr int CH_L5 = 34;    // positions_linears.5        4 (PE) + 16     8       10
+constexpr int CH_L6 = 44;    // positions_linears.6        16              8       8
+constexpr int CH_L7 = 52;    // positions_linears.7        16              8       8   (trunk-only eval ends at 60)
+constexpr int CH_FEAT = 60;  // feature_linear             16              8       8
+constexpr int CH_ALB = 68;   // albedo_feature_linear      16              4       4
+constexpr int CH_IRR = 72;   // irradiance_feature_linear  16              4       4
+constexpr int CH_VIEW = 76;  // views_linears.0            2 (DE) + 16     8       9
+constexpr int CH_AR = 85;    // additional_radiance_feature_linear.{0,1,2}  16   4 each   12
+constexpr int N_CHUNKS = 97;
+constexpr int N_CHUNKS_TRUNK = 60;
+constexpr int PE_KSTEPS = 4;   // 64 slots, 63 used
+constexpr int DE_KSTEPS = 2;   // 32 slots, 27 used
+constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 3.06 MiB per network
+
+// fp32 side tables (biases in accumulator-lane layout + the tiny N=1/3 heads that run on the VALU)
+// Lane-layout entry [tile][h][r] holds the value for feature 32*tile_local + (r&3) + 8*(r>>2) + 4h.
+constexpr int BT_L0 = 0;      // bias tiles: layer l tile t -> 8*l + t   (0..63)
+constexpr int BT_FEAT = 64;   // 64..71
+constexpr int BT_ALB = 72;    // 72..75
+constexpr int BT_IRR = 76;    // 76..79
+constexpr int BT_VIEW = 80;   // 80..87
+constexpr int BT_AR = 88;     // 88..99
+constexpr int N_BIAS_TILES = 100;
+constexpr int TAB_BIAS = 0;                         // [100][2][16]
+constexpr int TAB_SIG = TAB_BIAS + N_BIAS_TILES * 32;   // sigma_linear.weight      [8][2][16]
+constexpr int TAB_ROUGH = TAB_SIG + 256;            // roughness_linear.weight  [8][2][16]
+constexpr int TAB_ALB = TAB_ROUGH + 256;            // albedo_linear.weight     [3][4][2][16]
+constexpr int TAB_IRR = TAB_ALB + 384;              // irradiance_linear.weight [4][2][16]
+constexpr int TAB_RAD = TAB_IRR + 128;              // radiance_linear.weight   [3][8][2][16]
+constexpr int TAB_AR = TAB_RAD + 768;               // additional_radiance_linear.k.weight [3][3][4][2][16]
+constexpr int TAB_SCALAR = TAB_AR + 1152;           // 18 output biases in raw-channel order
+constexpr int TAB_FLOATS = TAB_SCALAR + 32;
+constexpr int TAB_BYTES = TAB_FLOATS * 4;           // 24 704 B
+
+constexpr int LDS_RING_BYTES = RING_SLOTS * CHUNK_BYTES;   // 96 KiB
+constexpr int LDS_BYTES = LDS_RING_BYTES + TAB_BYTES;      // 123 008 B
+
+// feature held by accumulator register r of lane-half h (tile-local, 0..31)
+__host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Encoding slot maps.  A half-wave h owns slots sl = 8*jj + e (jj = encoding k-step, e = 0..7).
+// Returns the reference embedding index (positional_embedder.py:33-34 order
+// [x, sin(2^0 x), cos(2^0 x), ...]) or -1 for a zero pad slot.
+//   positions (L=10): 30 (freq k, coord c) pairs m = 3k + c; half h owns m = 15h .. 15h+14;
+//                     slot 2u = sin(pair 15h+u), 2u+1 = cos; slots 30,31 = (x,y) | (z,pad)
+//   directions (L=4): 12 pairs; half h owns m = 6h .. 6h+5; slots 12,13 = (x,y) | (z,pad); 14,15 pad
+__host__ __device__ constexpr int enc_ref_index(int sl, int h, int pairs_per_half) {
+    const int n = 2 * pairs_per_half;
+    if (sl < n) {
+        const int m = pairs_per_half * h + (sl >> 1);
+        return 3 + 6 * (m / 3) + ((sl & 1) ? 3 : 0) + (m % 3);
+    }
+    if (sl == n) return h == 0 ? 0 : 2;
+    if (sl == n + 1) return h == 0 ? 1 : -1;
+    return -1;
+}
+constexpr int PE_PAIRS_PER_HALF = 15;
+constexpr int DE_PAIRS_PER_HALF = 6;
+
+// Raw output channel order of IBLNeRF.forward (ibl_nerf.py:200-208):
+// [sigma, albedo3, roughness, irradiance, radiance3, radiance_1 x3, radiance_2 x3, radiance_3 x3]
+constexpr int RAW_CH = 18;
+constexpr int REFL_CH = 13;   // sigma + channels 6..17 (what raw2outputs_simple reads, ibl_nerf_renderer.py:38-68)
+
+enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2 };
+
+}  // namespace ibl

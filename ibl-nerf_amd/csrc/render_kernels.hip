@@ -1,0 +1,628 @@
+// Per-ray kernels of the render path (everything except the MLP): ray generation, packed point
+// batches, alpha compositing with wavefront scans, epsilon-normal, split-sum shading, inverse-CDF
+// fine sampling.  fp32 throughout; this file is compiled with -ffp-contract=off so that
+// "multiply then add" stays two roundings exactly where the reference's elementwise torch ops
+// round twice (sample positions feed a 2^9 frequency multiplier in the encoding).
+//
+// Work decomposition: ONE WAVEFRONT PER RAY, samples spread over lanes (S = 64 -> 1 per lane,
+// S = 192 -> 3 consecutive per lane), transmittance by a 64-lane multiplicative scan, all
+// per-ray sums by butterfly reductions.  These kernels are HBM/latency-trivial next to the MLP
+// (about 22 KB read per ray against >1 GFLOP of MFMA work).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace ibl {
+
+namespace {
+
+constexpr int MAX_NPL = 4;   // samples per lane: S <= 256
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float srgb(float x, int on) { return on ? powf(x + 1e-12f, (float)(1.0 / 2.2)) : x; }
+
+// torch.linspace(start, end, steps)[i] in fp32 (ATen CPU kernel: symmetric fill, one fma each)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+}
+
+// Front-to-back compositing weights of one ray (ibl_nerf_renderer.py:203-206, 241-245):
+//   dist_k = (z_{k+1} - z_k) * |d|, last = 1e10 * |d|;  alpha = 1 - exp(-relu(sigma) * dist)
+//   T_k = prod_{j<k} (1 - alpha_j + 1e-10)  — accumulated in double and rounded per prefix, which
+//   is what ATen's CPU cumprod does for float tensors;  w = alpha * T.
+// Lane owns samples lane*NPL .. lane*NPL+NPL-1.
+template <int NPL>
+__device__ __forceinline__ void ray_weights(const float (&sigma)[NPL], const float (&z)[NPL], const float (&zn)[NPL],
+                                            float norm, int S, int lane, float (&w)[NPL]) {
+    float alpha[NPL];
+    double om[NPL];
+    double lane_prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        const float dist = (s == S - 1 ? 1e10f : (zn[i] - z[i])) * norm;
+        float a = 1.0f - expf(-fmaxf(sigma[i], 0.0f) * dist);
+        if (s >= S) a = 0.0f;
+        alpha[i] = a;
+        om[i] = s < S ? (double)((1.0f - a) + 1e-10f) : 1.0;
+        lane_prod *= om[i];
+    }
+    // exclusive multiplicative scan over lanes
+    double incl = lane_prod;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(incl, d);
+        if (lane >= d) incl *= o;
+    }
+    double T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        w[i] = alpha[i] * (float)T;
+        T *= om[i];
+    }
+}
+
+__device__ __forceinline__ void cross3(const float (&a)[3], const float (&b)[3], float (&c)[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void normalize3(float (&v)[3]) {   // F.normalize(dim=-1, eps=1e-12)
+    const float n = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+// right = d x (0,1,0); up = right x d   (normal_from_depth.py:143-147)
+__device__ __forceinline__ void right_up(const float (&d)[3], float (&right)[3], float (&up)[3]) {
+    const float up0[3] = {0.0f, 1.0f, 0.0f};
+    cross3(d, up0, right);
+    cross3(right, d, up);
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_get_rays(int W, int row0, int n_rows, Camera cam, float* __restrict__ ro, float* __restrict__ rd) {
+    const float* K = cam.K;
+    const float* c2w = cam.c2w;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_rows * W) return;
+    const int col = (int)(idx % W), row = row0 + (int)(idx / W);
+    const float dir[3] = {((float)col - K[2]) / K[0], -((float)row - K[5]) / K[4], -1.0f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rd[3 * idx + c] = (dir[0] * c2w[4 * c + 0] + dir[1] * c2w[4 * c + 1]) + dir[2] * c2w[4 * c + 2];
+        ro[3 * idx + c] = c2w[4 * c + 3];
+    }
+}
+
+__global__ void k_coarse_z(float near, float far, int S, float* __restrict__ z) {
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= S) return;
+    const float t = linspace_at(0.0f, 1.0f, S, i);
+    z[i] = near * (1.0f - t) + far * t;
+}
+
+__global__ void k_make_points(int mode, const float* __restrict__ origin, const float* __restrict__ dir,
+                              const float* __restrict__ z, int z_stride, float eps, long R, int S,
+                              float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (r, s)
+    if (idx >= R * S) return;
+    const long r = idx / S;
+    const int s = (int)(idx - r * S);
+    const float zz = z[(long)z_stride * r + s];
+    const float o[3] = {origin[3 * r], origin[3 * r + 1], origin[3 * r + 2]};
+    const float d[3] = {dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = o[c] + d[c] * zz;
+    if (mode == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * idx + c] = p[c];
+        return;
+    }
+    float right[3], up[3];
+    right_up(d, right, up);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float er = eps * right[c], eu = eps * up[c];
+        out[3 * (0 * R * S + idx) + c] = p[c] + er;
+        out[3 * (1 * R * S + idx) + c] = p[c] - er;
+        out[3 * (2 * R * S + idx) + c] = p[c] + eu;
+        out[3 * (3 * R * S + idx) + c] = p[c] - eu;
+    }
+}
+
+// F.grid_sample(lut[1,3,512,512], bilinear, zeros padding, align_corners=True) at
+// (2 n.v - 1, 2 rough - 1)  (ibl_nerf_renderer.py:418-421); returns channels 0 and 1.
+__device__ __forceinline__ void lut_fetch(const float* __restrict__ lut, float ndv, float rough, float& e0, float& e1) {
+    constexpr int N = 512;
+    const float gx = 2.0f * ndv - 1.0f, gy = 2.0f * rough - 1.0f;
+    const float x = ((gx + 1.0f) / 2.0f) * (float)(N - 1);
+    const float y = ((gy + 1.0f) / 2.0f) * (float)(N - 1);
+    const float x0 = floorf(x), y0 = floorf(y);
+    e0 = 0.0f;
+    e1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = k & 1, dy = k >> 1;
+        const float xi = x0 + (float)dx, yi = y0 + (float)dy;
+        const float wx = dx ? (x - x0) : (x0 + 1.0f - x);
+        const float wy = dy ? (y - y0) : (y0 + 1.0f - y);
+        if (xi >= 0.0f && xi <= (float)(N - 1) && yi >= 0.0f && yi <= (float)(N - 1)) {
+            const int o = (int)yi * N + (int)xi;
+            const float wgt = wx * wy;
+            e0 += lut[o] * wgt;
+            e1 += lut[N * N + o] * wgt;
+        }
+    }
+}
+
+__device__ __forceinline__ void store3(float* p, long r, const float (&v)[3], int g) {
+    if (p) { p[3 * r] = srgb(v[0], g); p[3 * r + 1] = srgb(v[1], g); p[3 * r + 2] = srgb(v[2], g); }
+}
+
+// State record handed from pass A to pass B (floats): 0-2 albedo, 3 rough, 4 irr, 5-7 fresnel,
+// 8-10 specular coefficient, 11 mip level.
+
+// Pass A: raw2outputs up to the reflected-ray set-up (ibl_nerf_renderer.py:200-440).
+template <int NPL>
+__global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, int gamma) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int S = a.S;
+    const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
+    const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = a.z + (long)a.z_stride * r;
+
+    float z[NPL], zn[NPL], sig[NPL], w[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
+        sig[i] = s < S ? a.raw[((long)r * S + s) * RAW_CH] : 0.0f;
+    }
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+
+    float depth = 0.f, acc = 0.f, ch[17];
+#pragma unroll
+    for (int c = 0; c < 17; ++c) ch[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (s < S) {
+            a.weights[(long)r * S + s] = w[i];
+            if (out.weights) out.weights[(long)r * S + s] = w[i];
+            depth += w[i] * z[i];
+            acc += w[i];
+            const float* row = a.raw + ((long)r * S + s) * RAW_CH;
+#pragma unroll
+            for (int c = 0; c < 17; ++c) ch[c] += w[i] * sigmoidf_(row[1 + c]);
+        }
+    }
+    depth = wave_sum(depth);
+    acc = wave_sum(acc);
+#pragma unroll
+    for (int c = 0; c < 17; ++c) ch[c] = wave_sum(ch[c]);
+
+    // epsilon-normal depths (normal_from_depth.py:158-176): same z / dists, trunk-only sigma
+    float D[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float sv[NPL], wv[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int s = lane * NPL + i;
+            sv[i] = s < S ? a.sig4[((long)v * a.R + r) * S + s] : 0.0f;
+        }
+        ray_weights<NPL>(sv, z, zn, norm, S, lane, wv);
+        float dv = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) dv += wv[i] * z[i];
+        D[v] = wave_sum(dv);
+    }
+
+    // ---- per-ray scalar section (all lanes compute, lane 0 stores) ---------------------------
+    float albedo[3] = {ch[0], ch[1], ch[2]};
+    float rough = ch[3], irr = ch[4];
+    const OverrideArgs& ov = a.ov;
+    float m = 0.0f;
+    bool mask_all = false;
+    if (ov.mode != 0) {   // ibl_nerf_renderer.py:223-228 / :233-238
+        m = ov.mask[(long)r * ov.mask_stride];
+        mask_all = m > 0.0f;
+    }
+    // object q <=> 9(q+1)/255 < m < 11(q+1)/255
+    auto in_obj = [&](int q) { return (float)(11 * (q + 1) / 255.) > m && m > (float)(9 * (q + 1) / 255.); };
+    if (mask_all && ((ov.mode == 1 && ov.edit_depth) || ov.mode == 2)) depth = ov.depth_img[(long)r * ov.depth_stride];   // :253-256
+    const float disp = 1.0f / fmaxf(1e-10f, depth / acc);   // :258
+    float xs[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xs[c] = o[c] + d[c] * depth;   // :262
+
+    float right[3], up[3], dxv[3], dyv[3], nrm[3];
+    right_up(d, right, up);
+    const float two_eps = 2.0f * a.eps;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dxv[c] = two_eps * right[c] + (D[0] - D[1]) * d[c];
+        dyv[c] = two_eps * up[c] + (D[2] - D[3]) * d[c];
+    }
+    cross3(dxv, dyv, nrm);
+    normalize3(nrm);
+
+    if (mask_all && ((ov.mode == 1 && ov.edit_normal) || ov.mode == 2)) {   // :380-382, :401-403
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = 2.0f * ov.normal_img[3 * r + c] - 1.0f;
+        normalize3(g);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = g[c];
+    }
+    // masked assignments are applied object by object in list order, as the reference's loops do
+    if (ov.mode == 1) {
+        if (ov.edit_albedo) {
+            if (ov.edit_albedo_by_img) {
+                if (mask_all) for (int c = 0; c < 3; ++c) albedo[c] = ov.albedo_img[3 * r + c];
+            } else {
+                for (int q = 0; q < ov.num_objects; ++q)
+                    if (in_obj(q)) for (int c = 0; c < 3; ++c) albedo[c] = ov.albedo_list[3 * q + c];
+            }
+        }
+        if (ov.edit_roughness)
+            for (int q = 0; q < ov.n_rough_list; ++q)
+                if (in_obj(q)) rough = ov.rough_list[q];
+    } else if (ov.mode == 2) {   // :406-410
+        for (int q = 0; q < ov.num_objects; ++q)
+            if (in_obj(q)) {
+                rough = ov.rough_list[q];
+                if (ov.irr_list[q] > 0.0f) irr = ov.irr_list[q];
+                for (int c = 0; c < 3; ++c) albedo[c] = ov.albedo_list[3 * q + c];
+            }
+    }
+
+    float ndv = ((-d[0] * nrm[0]) + (-d[1] * nrm[1])) + (-d[2] * nrm[2]);   // :412
+    ndv = fminf(fmaxf(ndv, 0.0f), 1.0f);
+    float e0, e1;
+    lut_fetch(a.lut, ndv, rough, e0, e1);
+    const float metal = 1.0f - rough;
+    float F0[3], fres[3], spec[3], rdir[3];
+    const float p5 = powf(fminf(fmaxf(1.0f - ndv, 0.0f), 1.0f), 5.0f);
+    const float ndotd = (nrm[0] * d[0] + nrm[1] * d[1]) + nrm[2] * d[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        F0[c] = 0.04f * (1.0f - metal) + albedo[c] * metal;                       // :427
+        fres[c] = F0[c] + (fmaxf(1.0f - rough, F0[c]) - F0[c]) * p5;              // microfacet.py:8-12
+        spec[c] = (a.lut_coefficient_F0 ? F0[c] : fres[c]) * e0 + e1;             // :433-436
+        rdir[c] = d[c] - (2.0f * ndotd) * nrm[c];                                 // :439
+    }
+    float level = rough;
+    if (a.correct_depth) {
+        const float depth_0 = (a.far + a.near) * 0.5f;                            // :456-460
+        level = fminf(fmaxf(rough * depth / depth_0, 0.0f), 1.0f);
+    }
+
+    if (lane == 0) {
+        float* st = a.state + r * ST_FLOATS;
+        st[0] = albedo[0]; st[1] = albedo[1]; st[2] = albedo[2];
+        st[3] = rough; st[4] = irr;
+        st[5] = fres[0]; st[6] = fres[1]; st[7] = fres[2];
+        st[8] = spec[0]; st[9] = spec[1]; st[10] = spec[2];
+        st[11] = level;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a.refl_o[3 * r + c] = xs[c]; a.refl_d[3 * r + c] = rdir[c]; }
+        // maps that do not depend on the reflected pass (ibl_nerf_renderer.py:494-525)
+        const float rad[3] = {ch[5], ch[6], ch[7]};
+        store3(out.radiance, r, rad, gamma);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float rk[3] = {ch[8 + 3 * k], ch[9 + 3 * k], ch[10 + 3 * k]};
+            store3(out.radiance_k[k], r, rk, gamma);
+        }
+        if (out.irradiance) out.irradiance[r] = srgb(irr, gamma);
+        store3(out.albedo, r, albedo, gamma);
+        if (out.roughness) out.roughness[r] = rough;
+        if (out.n_dot_v) out.n_dot_v[r] = ndv;
+        store3(out.normal, r, nrm, 0);
+        if (out.disp) out.disp[r] = disp;
+        if (out.acc) out.acc[r] = acc;
+        if (out.depth) out.depth[r] = depth;
+        if (out.target_depth) out.target_depth[r] = depth;
+    }
+}
+
+// Pass B: reflected-ray composite (raw2outputs_simple, :38-68), mip interpolation between the
+// prefiltered radiances (:455-470), diffuse / specular / colour (:472-474), output mapping.
+template <int NPL>
+__global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int S = a.Sc;
+    const float d[3] = {a.refl_d[3 * r], a.refl_d[3 * r + 1], a.refl_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    float z[NPL], zn[NPL], sig[NPL], w[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? a.zc[s] : 0.0f;
+        zn[i] = s + 1 < S ? a.zc[s + 1] : 0.0f;
+        sig[i] = s < S ? a.refl_raw[((long)r * S + s) * REFL_CH] : 0.0f;
+    }
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+    float maps[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) maps[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (s < S) {
+            const float* row = a.refl_raw + ((long)r * S + s) * REFL_CH;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) maps[c] += w[i] * sigmoidf_(row[1 + c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) maps[c] = wave_sum(maps[c]);
+    if (lane != 0) return;
+
+    const float* st = a.state + r * ST_FLOATS;
+    const float albedo[3] = {st[0], st[1], st[2]};
+    const float rough = st[3], irr = st[4], level = st[11];
+    const float metal = 1.0f - rough;
+    int i1 = (int)(level * 3.0f);                       // .long() truncation (:464)
+    i1 = i1 < 0 ? 0 : (i1 > 3 ? 3 : i1);
+    const int i2 = i1 + 1 > 3 ? 3 : i1 + 1;
+    const float rem = level * 3.0f - (float)i1;
+    float pref[3], diffuse[3], specular[3], color[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pref[c] = (1.0f - rem) * maps[3 * i1 + c] + rem * maps[3 * i2 + c];
+        diffuse[c] = (1.0f - st[5 + c]) * (1.0f - metal) * albedo[c] * irr;
+        specular[c] = st[8 + c] * pref[c];
+        color[c] = diffuse[c] + specular[c];
+    }
+    const int g = a.gamma_correct;
+    const PassOutputs& out = a.out;
+    store3(out.color, r, color, g);
+    const float m0[3] = {maps[0], maps[1], maps[2]};
+    store3(out.reflected_radiance, r, m0, g);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float mk[3] = {maps[3 + 3 * k], maps[4 + 3 * k], maps[5 + 3 * k]};
+        store3(out.refl_coarse_k[k], r, mk, g);
+    }
+    store3(out.prefiltered, r, pref, g);
+    store3(out.specular, r, specular, g);
+    store3(out.diffuse, r, diffuse, g);
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__ rays_d, const float* __restrict__ zbase,
+                                                      int z_stride, const float* __restrict__ sigma, long R, int S,
+                                                      float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zbase + (long)z_stride * r;
+    float z[NPL], zn[NPL], sig[NPL], w[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
+        sig[i] = s < S ? sigma[r * S + s] : 0.0f;
+    }
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (s < S) weights[r * S + s] = w[i];
+    }
+}
+
+// sample_pdf(det=True), nerf_renderer_helper.py:91-134, for one ray held by one wavefront.
+// cdf/bins live in LDS (nb <= 257).  Writes n_out samples to `dst` (LDS or global).
+template <class Dst>
+__device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, int nb, int n_out, int lane,
+                                                float* cdf /*LDS [nb]*/, const float* bins /*LDS [nb]*/, Dst&& put) {
+    const int nw = nb - 1;
+    // lane owns weights lane*NPL .. (contiguous) so the cumulative sum is lane-local + wave scan
+    const int npl = (nw + 63) / 64;
+    float wl[MAX_NPL + 1];
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_NPL + 1; ++i) {
+        const int k = lane * npl + i;
+        wl[i] = (i < npl && k < nw) ? wts[k] + 1e-5f : 0.0f;
+        lsum += wl[i];
+    }
+    const float tot = wave_sum(lsum);
+    double run = 0.0, lane_tot = 0.0;
+    float pdf[MAX_NPL + 1];
+#pragma unroll
+    for (int i = 0; i < MAX_NPL + 1; ++i) {
+        const int k = lane * npl + i;
+        pdf[i] = (i < npl && k < nw) ? wl[i] / tot : 0.0f;
+        lane_tot += (double)pdf[i];
+    }
+    double incl = lane_tot;   // inclusive scan over lanes (double accumulate == ATen CPU cumsum)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    run = incl - lane_tot;
+    if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAX_NPL + 1; ++i) {
+        const int k = lane * npl + i;
+        if (i < npl && k < nw) {
+            run += (double)pdf[i];
+            cdf[k + 1] = (float)run;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // same-wave LDS writes -> reads: in-order LDS queue, compiler inserts the lgkmcnt
+    for (int j = lane; j < n_out; j += 64) {
+        const float u = linspace_at(0.0f, 1.0f, n_out, j);
+        int lo = 0, hi = nb;   // searchsorted(right=True): number of cdf entries <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 < 0 ? 0 : lo - 1;
+        const int above = lo > nb - 1 ? nb - 1 : lo;
+        const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+        float den = c1 - c0;
+        if (den < 1e-5f) den = 1.0f;
+        const float t = (u - c0) / den;
+        put(j, b0 + t * (b1 - b0));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_pdf(const float* __restrict__ bins, int bins_stride,
+                                                   const float* __restrict__ weights, int w_stride, long R, int nb,
+                                                   int n_out, float* __restrict__ samples) {
+    __shared__ float lds[4][2][260];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    for (int k = lane; k < nb; k += 64) lds[wv][1][k] = bins[r * bins_stride + k];
+    sample_pdf_wave(weights + r * w_stride, nb, n_out, lane, lds[wv][0], lds[wv][1],
+                    [&](int j, float v) { samples[r * n_out + j] = v; });
+}
+
+// z_vals_mid -> sample_pdf(weights[1:-1]) -> sort(cat([z, z_samples])) -> z_std
+// (ibl_nerf_renderer.py:701-707, :718).  Sc + n_imp <= 512.
+__global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc, int Sc, const float* __restrict__ wc,
+                                               long R, int n_imp, float* __restrict__ z_fine,
+                                               float* __restrict__ z_std) {
+    __shared__ float lds[4][2][260];
+    __shared__ float vals[4][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    const int nb = Sc - 1;
+    for (int k = lane; k < nb; k += 64) lds[wv][1][k] = 0.5f * (zc[k + 1] + zc[k]);
+    for (int k = lane; k < Sc; k += 64) vals[wv][k] = zc[k];
+    sample_pdf_wave(wc + r * Sc + 1, nb, n_imp, lane, lds[wv][0], lds[wv][1],
+                    [&](int j, float v) { vals[wv][Sc + j] = v; });
+    __builtin_amdgcn_wave_barrier();
+    const int n = Sc + n_imp;
+    // z_std = std(z_samples, unbiased=False)
+    double s1 = 0.0;
+    for (int j = lane; j < n_imp; j += 64) s1 += (double)vals[wv][Sc + j];
+    const double mean = wave_sum_d(s1) / n_imp;
+    double s2 = 0.0;
+    for (int j = lane; j < n_imp; j += 64) {
+        const double dv = (double)vals[wv][Sc + j] - mean;
+        s2 += dv * dv;
+    }
+    s2 = wave_sum_d(s2);
+    if (lane == 0 && z_std) z_std[r] = (float)sqrt(s2 / n_imp);
+    // rank sort (values only; ties keep index order)
+    for (int e = lane; e < n; e += 64) {
+        const float v = vals[wv][e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float u = vals[wv][j];
+            rank += (u < v || (u == v && j < e)) ? 1 : 0;
+        }
+        z_fine[r * n + rank] = v;
+    }
+}
+
+template <class F>
+hipError_t by_npl(int S, F&& f) {
+    const int npl = (S + 63) / 64;
+    switch (npl) {
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s) {
+    const long n = (long)n_rows * W;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, row0, n_rows, cam, rays_o, rays_d);
+    return hipGetLastError();
+}
+
+hipError_t launch_coarse_z(float near, float far, int S, float* z, hipStream_t s) {
+    hipLaunchKernelGGL(k_coarse_z, dim3((S + 63) / 64), dim3(64), 0, s, near, far, S, z);
+    return hipGetLastError();
+}
+
+hipError_t launch_make_points(int mode, const float* origin, const float* dir, const float* z, int z_stride, float eps,
+                              long R, int S, float* out, hipStream_t s) {
+    const long n = R * S;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mode, origin, dir, z, z_stride,
+                       eps, R, S, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma, hipStream_t s) {
+    if (a.R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.R + 3) / 4));
+    return by_npl(a.S, [&](auto N) {
+        hipLaunchKernelGGL(k_pass_a<decltype(N)::value>, grid, dim3(256), 0, s, a, out, gamma);
+    });
+}
+
+hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, long R, int S,
+                                float* weights, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((R + 3) / 4));
+    return by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, R, S, weights);
+    });
+}
+
+hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s) {
+    if (a.R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.R + 3) / 4));
+    return by_npl(a.Sc, [&](auto N) { hipLaunchKernelGGL(k_pass_b<decltype(N)::value>, grid, dim3(256), 0, s, a); });
+}
+
+hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, long R, int nb,
+                             int n_out, float* samples, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (nb < 2 || nb > 257 || n_out < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, bins, bins_stride, weights, w_stride,
+                       R, nb, n_out, samples);
+    return hipGetLastError();
+}
+
+hipError_t launch_fine_z(const float* zc, int Sc, const float* weights_c, long R, int n_imp, float* z_fine, float* z_std,
+                         hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (Sc < 3 || Sc > 256 || Sc + n_imp > 512 || n_imp < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fine_z, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, zc, Sc, weights_c, R, n_imp, z_fine, z_std);
+    return hipGetLastError();
+}
+
+}  // namespace ibl

@@ -1,0 +1,125 @@
+"""Host-side mirror of the reference's model factory (src/nerf_models/ibl_nerf.py).
+
+`IBLNeRF` here is a weight container with the reference module's state-dict surface
+(`state_dict()`, `load_state_dict()`, `coarse_radiance_number`); the forward pass lives in
+csrc/mlp_kernel.hip and is reached through `network_query_fn` / `render_decomp`.
+`create_IBLNeRF(args)` follows ibl_nerf.py:255-428: builds both networks, finds and loads the
+`.tar` checkpoint by the reference's discovery rule, and returns the same render_kwargs dicts,
+so `test.py`'s call sequence works unchanged.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from . import checkpoint as ck
+
+
+class IBLNeRF:
+    """Weight container with the schema of the reference nn.Module (ibl_nerf.py:14-75)."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), coarse_radiance_number=3,
+                 is_color_independent_to_direction=False, **_ignored):
+        if (D, W, input_ch, input_ch_views, tuple(skips), coarse_radiance_number) != (8, 256, 63, 27, (4,), 3):
+            raise NotImplementedError("the HIP path is built for the shipped architecture: D=8, W=256, multires=10, "
+                                      "multires_views=4, skips=[4], coarse_radiance_number=3")
+        if is_color_independent_to_direction:
+            raise NotImplementedError("color_independent_to_direction=True is not built (SURVEY.md §8 f-4)")
+        self.coarse_radiance_number = coarse_radiance_number
+        self._sd = ck.synthetic_state_dict(seed=0)       # placeholder values until load_state_dict
+        self._version = 0
+
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd):
+        self._sd = ck.blob_to_state_dict(ck.state_dict_to_blob(sd))   # validates names and shapes
+        self._version += 1
+        for v in self._sd.values():
+            v.setflags(write=False)
+        # a fresh first array => renderer_for() sees a new data pointer and re-uploads
+        return self
+
+    def eval(self):
+        return self
+
+
+def network_query_fn(inputs, viewdirs, network_fn, renderer=None, which=0):
+    """ibl_nerf.py:327-329.  `network_fn` selects coarse/fine by identity when a renderer with
+    both networks uploaded is passed; stand-alone it uploads `network_fn` as network 0."""
+    from . import renderer as R
+    r = renderer
+    if r is None:
+        r = R.Renderer(inputs.shape[1], 0, max_rays_per_launch=1)
+        r.load_weights(0, network_fn.state_dict())
+        which = 0
+    return r.network_query(inputs, viewdirs, which)
+
+
+def create_IBLNeRF(args):
+    """ibl_nerf.py:255-428.  Returns (render_kwargs_train, render_kwargs_test, start, elapsed_time,
+    grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
+    if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
+        raise NotImplementedError("embedders other than multires=10 / multires_views=4 are not built")
+    for flag in ("infer_depth", "infer_visibility", "infer_normal", "infer_albedo_separate", "infer_roughness_separate",
+                 "infer_irradiance_separate", "use_environment_map"):
+        if getattr(args, flag, False):
+            raise NotImplementedError("%s is outside the shipped-config path (SURVEY.md §8 f-4)" % flag)
+    mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, coarse_radiance_number=args.coarse_radiance_number,
+                         is_color_independent_to_direction=args.color_independent_to_direction)
+    model = mk()
+    model_fine = mk() if args.N_importance > 0 else None
+    start, elapsed = 0, 0
+    path = ck.find_checkpoint(args.basedir, args.expname, getattr(args, "ft_path", None),
+                              getattr(args, "target_load_N_iter", -1))
+    if path is not None and not getattr(args, "no_reload", False):
+        start, sd_c, sd_f = ck.load_checkpoint(path)
+        model.load_state_dict(sd_c)
+        if model_fine is not None and sd_f is not None:
+            model_fine.load_state_dict(sd_f)
+    train = {
+        "network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
+        "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,
+        "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
+        "ndc": False, "lindisp": args.lindisp,
+        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": None, "albedo_mlp": None, "roughness_mlp": None,
+        "irradiance_mlp": None, "infer_depth": False, "infer_visibility": False, "infer_normal": False,
+        "infer_normal_at_surface": getattr(args, "infer_normal_at_surface", False),
+        "coarse_radiance_number": args.coarse_radiance_number,
+        "use_monte_carlo_integration": getattr(args, "use_monte_carlo_integration", False),
+        "use_gradient_for_incident_radiance": getattr(args, "use_gradient_for_incident_radiance", False),
+        "use_radiance_linear": args.use_radiance_linear, "gamma_correct": args.gamma_correct,
+        "monte_carlo_integration_method": getattr(args, "monte_carlo_integration_method", "surface"),
+        "use_environment_map": False, "env_map": None, "lut_coefficient": args.lut_coefficient,
+        "depth_map_from_ground_truth": args.depth_map_from_ground_truth,
+        "target_normal_map_for_radiance_calculation": args.calculating_normal_type,
+        "calculate_albedo_from_gt": args.calculate_albedo_from_gt,
+        "calculate_roughness_from_gt": args.calculate_roughness_from_gt,
+        "calculate_irradiance_from_gt": args.calculate_irradiance_from_gt,
+        "epsilon": args.epsilon_for_numerical_normal,
+        "epsilon_direction": getattr(args, "epsilon_direction_for_numerical_normal", 0.005),
+        "N_hemisphere_sample_sqrt": getattr(args, "N_hemisphere_sample_sqrt", 16),
+        "roughness_exp_coefficient": getattr(args, "roughness_exp_coefficient", 1.0),
+        "albedo_multiplier": getattr(args, "albedo_multiplier", 1.0),
+        "correct_depth_for_prefiltered_radiance_infer": args.correct_depth_for_prefiltered_radiance_infer,
+    }
+    test = dict(train)
+    test["perturb"] = False                                                         # ibl_nerf.py:425-426
+    test["raw_noise_std"] = 0
+    return train, test, start, elapsed, None, None
+
+
+def default_args(**over):
+    """Effective flag values of configs/IBL-NeRF/<scene>/IBL-NeRF.txt."""
+    from types import SimpleNamespace
+    d = dict(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=64, N_importance=128,
+             netchunk=65536, chunk=1024, coarse_radiance_number=3, color_independent_to_direction=False,
+             use_illumination_feature_layer=False, use_instance_feature_layer=False, basedir=".", expname="exp",
+             ft_path=None, target_load_N_iter=-1, no_reload=True, perturb=1.0, use_viewdirs=True, white_bkgd=False,
+             raw_noise_std=0.0, lindisp=False, use_radiance_linear=False, gamma_correct=True, lut_coefficient="F",
+             depth_map_from_ground_truth=False, calculating_normal_type="normal_map_from_depth_gradient_epsilon",
+             calculate_albedo_from_gt=False, calculate_roughness_from_gt=False, calculate_irradiance_from_gt=False,
+             epsilon_for_numerical_normal=0.01, correct_depth_for_prefiltered_radiance_infer=True)
+    d.update(over)
+    return SimpleNamespace(**d)

@@ -1,0 +1,383 @@
+"""Host-side mirror of the reference's renderer seam, backed by the HIP library.
+
+Same names, argument meaning and error behaviour as the reference's Python functions
+(paths relative to /root/reference/src):
+
+    get_rays                 nerf_models/nerf_renderer_helper.py:36-45
+    sample_pdf (det=True)    nerf_models/nerf_renderer_helper.py:91-134
+    network_query_fn         nerf_models/ibl_nerf.py:327-329 (run_network :236-252)
+    render_rays              nerf_models/ibl_nerf_renderer.py:629-732
+    render_decomp            nerf_models/ibl_nerf_renderer.py:759-813
+
+All tensors live on the GPU (torch is used for device memory and streams only); the arithmetic
+runs in csrc/ behind include/iblnerf.h.  Forward/inference flags of the shipped configs are
+supported; anything else raises (see `_check_supported`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+from . import checkpoint as ck
+
+MAP_KEYS_3 = ["color_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3",
+              "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3",
+              "reflected_radiance_map", "prefiltered_reflected_map", "albedo_map", "specular_map", "diffuse_map",
+              "target_normal_map"]
+MAP_KEYS_1 = ["roughness_map", "n_dot_v_map", "disp_map", "acc_map", "depth_map", "target_depth_map"]
+# order in which raw2outputs fills its result dict (ibl_nerf_renderer.py:494-525), None entries dropped
+RESULT_ORDER = ["color_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3",
+                "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2",
+                "reflected_coarse_radiance_map_3", "irradiance_map", "reflected_radiance_map",
+                "prefiltered_reflected_map", "albedo_map", "roughness_map", "specular_map", "diffuse_map",
+                "n_dot_v_map", "target_normal_map", "disp_map", "acc_map", "depth_map", "target_depth_map", "weights"]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev_f32(x, device):
+    torch = _torch()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Renderer:
+    """One HIP context = one (N_samples, N_importance, flag set) on one GPU."""
+
+    def __init__(self, N_samples=64, N_importance=128, *, epsilon=0.01, gamma_correct=True, lut_coefficient="F",
+                 correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
+                 max_rays_per_launch=65536, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise B.IblNerfError("no HIP device visible to torch: the render path has no CPU fallback")
+        if lut_coefficient not in ("F", "F0"):
+            raise ValueError("lut_coefficient must be 'F' or 'F0'")          # ibl_nerf_renderer.py:437-438
+        self.lib = B.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        o = B.default_options()
+        o.n_samples, o.n_importance = int(N_samples), int(N_importance)
+        o.epsilon = float(epsilon)
+        o.gamma_correct = int(bool(gamma_correct))
+        o.lut_coefficient_f0 = int(lut_coefficient == "F0")
+        o.correct_depth_for_prefiltered_radiance = int(bool(correct_depth_for_prefiltered_radiance_infer))
+        o.coarse_outputs = int(bool(coarse_outputs))
+        o.max_rays_per_launch = int(max_rays_per_launch)
+        o.device = self.device.index
+        self.opt = o
+        self.N_samples, self.N_importance = int(N_samples), int(N_importance)
+        self.coarse_outputs = bool(coarse_outputs)
+        ctx = C.c_void_p()
+        rc = self.lib.iblnerf_create(C.byref(o), C.byref(ctx))
+        if rc != 0:
+            raise B.IblNerfError("iblnerf_create failed (%d): %s" % (rc, self.lib.iblnerf_last_error(None).decode()))
+        self.ctx = ctx
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.iblnerf_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- uploads --------------------------------------------------------------------------------
+    def load_weights(self, which, state_dict_or_blob):
+        """which: 0 = network_fn (coarse), 1 = network_fine.  Accepts a reference-schema state dict
+        (torch tensors or numpy arrays) or an already-flattened blob."""
+        blob = state_dict_or_blob
+        if not isinstance(blob, np.ndarray):
+            blob = ck.state_dict_to_blob(blob)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
+
+    def load_lut(self, lut):
+        """lut: float [3,512,512] exactly as test.py:79-87 builds `brdf_lut`."""
+        if not isinstance(lut, np.ndarray):
+            lut = lut.detach().cpu().numpy()
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        if lut.shape != (3, 512, 512):
+            raise ValueError("brdf_lut must have shape [3,512,512], got %s" % (lut.shape,))
+        B.check(self.ctx, self.lib.iblnerf_upload_lut(self.ctx, lut.ctypes.data))
+
+    def set_profiling(self, on):
+        B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
+
+    def last_mlp_time(self):
+        """(ms of MLP kernels in the last render_rays call, launches, algorithmic FLOPs) — HIP events
+        recorded on the launch stream."""
+        ms, n, fl = C.c_float(), C.c_int(), C.c_double()
+        B.check(self.ctx, self.lib.iblnerf_last_mlp_time(self.ctx, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    # -- reference functions ----------------------------------------------------------------------
+    def get_rays(self, H, W, K, c2w, row0=0, n_rows=None):
+        torch = _torch()
+        n_rows = H - row0 if n_rows is None else n_rows
+        K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(3, 3))
+        c2w_h = c2w.detach().cpu().numpy() if not isinstance(c2w, np.ndarray) else c2w
+        c2w_h = np.ascontiguousarray(np.asarray(c2w_h, dtype=np.float32)[:3, :4])
+        ro = torch.empty((n_rows, W, 3), dtype=torch.float32, device=self.device)
+        rd = torch.empty((n_rows, W, 3), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_get_rays(self.ctx, self._stream(), int(H), int(W), K.ctypes.data,
+                                                    c2w_h.ctypes.data, int(row0), int(n_rows), ro.data_ptr(), rd.data_ptr()))
+        return ro, rd
+
+    def network_query(self, inputs, viewdirs, which=0):
+        torch = _torch()
+        inputs = _dev_f32(inputs, self.device)
+        N, S = inputs.shape[0], inputs.shape[1]
+        vd = None if viewdirs is None else _dev_f32(viewdirs, self.device)
+        out = torch.empty((N, S, 18 if vd is not None else 1), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_network_query(self.ctx, self._stream(), int(which), inputs.data_ptr(), N, S,
+                                                         None if vd is None else vd.data_ptr(), out.data_ptr()))
+        return out
+
+    def sample_pdf(self, bins, weights, N_samples):
+        torch = _torch()
+        bins, weights = _dev_f32(bins, self.device), _dev_f32(weights, self.device)
+        if weights.shape[-1] != bins.shape[-1] - 1:
+            raise ValueError("sample_pdf: weights must have one entry fewer than bins")
+        out = torch.empty((bins.shape[0], N_samples), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_sample_pdf(self.ctx, self._stream(), bins.data_ptr(), weights.data_ptr(),
+                                                      bins.shape[0], bins.shape[1], int(N_samples), out.data_ptr()))
+        return out
+
+    def _alloc_maps(self, n, S, want=True):
+        torch = _torch()
+        m, t = B.Maps(), {}
+        if not want:
+            return m, t
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=self.device)
+        for k in MAP_KEYS_3:
+            t[k] = e(n, 3)
+        for k in MAP_KEYS_1:
+            t[k] = e(n)
+        t["irradiance_map"] = e(n, 1)
+        t["weights"] = e(n, S)
+        for k in ("color_map", "radiance_map", "irradiance_map", "reflected_radiance_map", "prefiltered_reflected_map",
+                  "albedo_map", "roughness_map", "specular_map", "diffuse_map", "n_dot_v_map", "target_normal_map",
+                  "disp_map", "acc_map", "depth_map", "target_depth_map", "weights"):
+            setattr(m, k, t[k].data_ptr())
+        for i in range(3):
+            m.radiance_map_k[i] = t["radiance_map_%d" % (i + 1)].data_ptr()
+            m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
+        return m, t
+
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, **edit):
+        """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
+        (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std')."""
+        torch = _torch()
+        rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
+        n = rays_o.shape[0]
+        ov, keep = self._overrides(gt_values or {}, edit, n)
+        Sc, Sf = self.N_samples, self.N_samples + self.N_importance
+        outs = B.Outputs()
+        fine = self.N_importance > 0
+        outs.fine, t_fine = self._alloc_maps(n, Sf if fine else Sc)
+        t_coarse = {}
+        if fine and self.coarse_outputs:
+            outs.coarse, t_coarse = self._alloc_maps(n, Sc)
+        z_std = None
+        if fine:
+            z_std = torch.empty((n,), dtype=torch.float32, device=self.device)
+            outs.z_std = z_std.data_ptr()
+        B.check(self.ctx, self.lib.iblnerf_render_rays(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
+                                                       float(near), float(far), C.byref(ov) if ov is not None else None,
+                                                       C.byref(outs)))
+        self._keep = keep   # override rows must outlive the asynchronous launch
+        res = {k: t_fine[k] for k in RESULT_ORDER}
+        for k in RESULT_ORDER:
+            if k in t_coarse:
+                res[k + "0"] = t_coarse[k]
+        if z_std is not None:
+            res["z_std"] = z_std
+        return res
+
+    def _overrides(self, gt, edit, n):
+        """gt_values rows + the edit/insert kwargs of test.py:115-139 -> iblnerf_overrides."""
+        ei, io = bool(edit.get("edit_intrinsic", False)), bool(edit.get("insert_object", False))
+        assert not (edit.get("load_edit_intrinsic_mask") and io), \
+            "edit_intrinsic and insert_object cannot be True at the same time"          # ibl_nerf_renderer.py:218
+        if not ei and not io:
+            return None, []
+        ov, keep = B.Overrides(), []
+
+        def rows(key, width):
+            if key not in gt:
+                raise KeyError("gt_values[%r] is required by the requested edit" % key)
+            t = _dev_f32(gt[key], self.device).reshape(n, -1)
+            if t.shape[1] < width:
+                raise ValueError("gt_values[%r] must have %d channel(s)" % (key, width))
+            t = t[:, :width].contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        if ei:                                                                          # :219-228 (wins over insert, elif)
+            nobj = int(edit.get("num_edit_objects") or 0)
+            assert nobj > 0, "num_edit_objects must be greater than 0"
+            ov.mode, ov.num_objects = 1, nobj
+            ov.d_mask = rows("edit_intrinsic_mask", 3)
+            ov.edit_depth = int(bool(edit.get("edit_depth", False)))
+            ov.edit_normal = int(bool(edit.get("edit_normal", False)))
+            ov.edit_albedo = int(bool(edit.get("edit_albedo", False)))
+            ov.edit_albedo_by_img = int(bool(edit.get("edit_albedo_by_img", False)))
+            ov.edit_roughness = int(bool(edit.get("edit_roughness", False)))
+            if ov.edit_depth:
+                ov.d_depth = rows("edit_depth", 1)
+            if ov.edit_normal:
+                ov.d_normal = rows("edit_normal", 3)
+            alb = list(edit.get("editing_target_albedo_list") or [])
+            rgh = list(edit.get("editing_target_roughness_list") or [])
+            assert not ov.edit_albedo or not len(alb) == 0, "Cannot load both edit_albedo and editing_target_albedo_list"
+            assert not ov.edit_roughness or not len(rgh) == 0, "Cannot load both edit_roughness and editing_target_roughness_list"
+            if ov.edit_albedo and ov.edit_albedo_by_img:
+                ov.d_albedo = rows("edit_albedo", 3)
+            if ov.edit_roughness and edit.get("edit_roughness_by_img"):
+                raise NotImplementedError("edit_roughness_by_img (ibl_nerf_renderer.py:394-395) is not on the shipped-config path")
+            if ov.edit_albedo and not ov.edit_albedo_by_img and len(alb) < 3 * nobj:
+                raise IndexError("editing_target_albedo_list needs 3 values per edit object")
+        else:                                                                           # :229-238
+            nobj = int(edit.get("num_insert_objects") or 0)
+            assert nobj > 0, "num_insert_objects must be greater than 0"
+            rgh = list(edit.get("inserting_target_roughness_list") or [])
+            alb = list(edit.get("inserting_target_albedo_list") or [])
+            irr = list(edit.get("inserting_target_irradiance_list") or [])
+            assert nobj == len(rgh), "Number of inserting objects does not match number of roughness values"
+            assert nobj == len(alb) / 3, "Number of inserting objects does not match number of albedo values"
+            if len(irr) < nobj:
+                raise IndexError("inserting_target_irradiance_list needs one value per inserted object")
+            ov.mode, ov.num_objects = 2, nobj
+            ov.d_mask = rows("object_insert_mask", 3)
+            ov.d_depth = rows("object_insert_depth", 1)
+            ov.d_normal = rows("object_insert_normal", 3)
+            for i, v in enumerate(irr[:8]):
+                ov.irradiance_list[i] = float(v)
+        if nobj > 8 or len(rgh) > 8:
+            raise ValueError("at most 8 edit / insert objects are supported")
+        ov.n_roughness_list = len(rgh)
+        for i, v in enumerate(rgh):
+            ov.roughness_list[i] = float(v)
+        for i, v in enumerate(alb[:24]):
+            ov.albedo_list[i] = float(v)
+        return ov, keep
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-signature functions
+# ---------------------------------------------------------------------------------------------
+_UNSUPPORTED_TRUE = ["lindisp", "use_radiance_linear", "infer_normal", "infer_normal_at_surface", "infer_depth",
+                     "depth_map_from_ground_truth", "calculate_albedo_from_gt", "calculate_roughness_from_gt",
+                     "calculate_irradiance_from_gt", "use_environment_map", "white_bkgd", "retraw"]
+
+
+def _check_supported(kw):
+    """Flags outside the shipped configs are refused loudly."""
+    for k in _UNSUPPORTED_TRUE:
+        if kw.get(k):
+            raise NotImplementedError("%s=True is outside the shipped-config forward path built here (SURVEY.md §8 f-4)" % k)
+    for k in ("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp", "depth_mlp"):
+        if kw.get(k) is not None:
+            raise NotImplementedError("auxiliary %s (src/networks/MLP.py) is not built (SURVEY.md §8 f-4)" % k)
+    if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
+        raise NotImplementedError("perturb / raw_noise_std > 0 are training-time options (SURVEY.md §8 f-3)")
+    mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
+    if mode != "normal_map_from_depth_gradient_epsilon":
+        if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
+                    "normal_map_from_depth_gradient_direction", "normal_map_from_depth_gradient_direction_epsilon",
+                    "ground_truth", "inferred_normal_map"):
+            raise NotImplementedError("normal mode %r is not built (SURVEY.md §8 f-4)" % mode)
+        raise ValueError(mode)                                                       # ibl_nerf_renderer.py:374-375
+    if not kw.get("approximate_radiance", False):
+        raise NotImplementedError("approximate_radiance=False (training warm-up) is not built")
+    if kw.get("is_depth_only"):
+        raise NotImplementedError("is_depth_only is not built")
+
+
+_renderers = {}
+
+
+def _weights_key(net):
+    sd = net.state_dict()
+    ver = 0
+    for v in sd.values():
+        ver += int(getattr(v, "_version", 0))
+    first = next(iter(sd.values()))
+    ptr = first.data_ptr() if hasattr(first, "data_ptr") else first.ctypes.data
+    return (id(net), ptr, ver)
+
+
+def renderer_for(kw):
+    """Renderer for a reference-style render_kwargs dict; weights/LUT re-uploaded when they change."""
+    torch = _torch()
+    net_c, net_f = kw["network_fn"], kw.get("network_fine")
+    N_imp = int(kw.get("N_importance", 0) or 0)
+    key = (int(kw["N_samples"]), N_imp, float(kw.get("epsilon", 0.01)), bool(kw.get("gamma_correct", False)),
+           kw.get("lut_coefficient"), bool(kw.get("correct_depth_for_prefiltered_radiance_infer", False)),
+           bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device())
+    ent = _renderers.get(key)
+    if ent is None:
+        if kw.get("lut_coefficient") not in ("F", "F0"):
+            raise ValueError(kw.get("lut_coefficient"))                               # ibl_nerf_renderer.py:437-438
+        r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
+                     correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
+                     max_rays_per_launch=key[7])
+        ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
+    r = ent["r"]
+    for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):
+        if net is None:
+            continue
+        wk = _weights_key(net)
+        if ent["w"][which] != wk:
+            r.load_weights(which, net.state_dict())
+            ent["w"][which] = wk
+    lut = kw["brdf_lut"]
+    lk = (id(lut), lut.data_ptr() if hasattr(lut, "data_ptr") else 0)
+    if ent["lut"] != lk:
+        r.load_lut(lut)
+        ent["lut"] = lk
+    return r
+
+
+def _scalar(x, name):
+    torch = _torch()
+    if torch.is_tensor(x):
+        if x.numel() > 1 and not bool((x == x.reshape(-1)[0]).all()):
+            raise NotImplementedError("per-ray %s planes are not supported (all shipped datasets use one scalar)" % name)
+        return float(x.reshape(-1)[0])
+    return float(x)
+
+
+def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1., c2w_staticcam=None,
+                  is_depth_only=False, **kwargs):
+    """Drop-in for nerf_models/ibl_nerf_renderer.py:759-813.  `chunk` is accepted and ignored: the
+    library walks the rays in workspace-sized launches and chunking never changes results."""
+    _check_supported(dict(kwargs, is_depth_only=is_depth_only))
+    if c2w_staticcam is not None:
+        raise NotImplementedError("c2w_staticcam is a visualisation aid that is not built")
+    r = renderer_for(kwargs)
+    if c2w is not None:
+        rays_o, rays_d = r.get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+        rays_o, rays_d = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
+    sh = rays_d.shape
+    edit = {k: kwargs[k] for k in kwargs if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit"))}
+    ret = r.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), _scalar(near, "near"), _scalar(far, "far"),
+                        kwargs.get("gt_values"), **edit)
+    return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
+
+
+def get_rays(H, W, K, c2w):
+    """nerf_renderer_helper.py:36-45 on the current GPU (uses any cached Renderer, else a tiny one)."""
+    r = next(iter(_renderers.values()))["r"] if _renderers else Renderer(64, 0, max_rays_per_launch=1)
+    return r.get_rays(H, W, K, c2w)

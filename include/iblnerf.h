@@ -1,0 +1,164 @@
+/* iblnerf.h — C ABI of the MI355X-native IBL-NeRF forward/inference renderer.
+ *
+ * The reference (changwoonchoi/IBL-NeRF) has no FFI; its seam is a Python call signature.  Each
+ * entry point below names the reference callable it replaces (paths relative to the reference's
+ * src/).  A Python caller binds them with ctypes (ibl-nerf_amd/binding.py; INTEGRATION.md shows the
+ * stub a reference maintainer would add to test.py / train.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative iblnerf_status on failure; the message is
+ *     retrievable with iblnerf_last_error(ctx) (thread-unsafe per ctx, like the reference's
+ *     single-threaded renderer).  No exceptions cross the boundary.
+ *   - "d_" pointers are DEVICE pointers (fp32 unless stated), borrowed for the duration of the
+ *     call and never freed by the library; "h_" pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises unless stated.
+ *   - one ctx per device; calls on one ctx are serialised by the caller.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef IBLNERF_H
+#define IBLNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iblnerf_ctx iblnerf_ctx;
+
+typedef enum {
+    IBLNERF_OK = 0,
+    IBLNERF_ERR_INVALID = -1,    /* bad argument (the reference would raise AssertionError / ValueError) */
+    IBLNERF_ERR_STATE = -2,      /* weights / LUT not uploaded yet */
+    IBLNERF_ERR_HIP = -3,        /* a HIP runtime call failed */
+    IBLNERF_ERR_NOMEM = -4
+} iblnerf_status;
+
+/* Effective flag set of the shipped configs (config_parser.py defaults + configs/common.txt,
+ * configs/IBL-NeRF/.../IBL-NeRF.txt) as consumed through render_kwargs (nerf_models/ibl_nerf.py:380-426). */
+typedef struct {
+    int32_t n_samples;                 /* N_samples (64) */
+    int32_t n_importance;              /* N_importance (128; 0 = coarse pass only) */
+    float epsilon;                     /* epsilon_for_numerical_normal (0.01) */
+    int32_t gamma_correct;             /* 1 */
+    int32_t lut_coefficient_f0;        /* 0 = lut_coefficient "F" (shipped), 1 = "F0" */
+    int32_t correct_depth_for_prefiltered_radiance; /* 1 */
+    int32_t coarse_outputs;            /* 1 = also produce the coarse-pass "...0" maps exactly as
+                                          render_rays does (ibl_nerf_renderer.py:712-713); 0 = the
+                                          coarse pass only evaluates density for the fine sampling */
+    int32_t max_rays_per_launch;       /* workspace is sized for this many rays (default 65536) */
+    int32_t device;                    /* HIP device ordinal */
+} iblnerf_options;
+
+void iblnerf_default_options(iblnerf_options* o);
+
+/* replaces: create_IBLNeRF (nerf_models/ibl_nerf.py:255-428) — model construction only */
+int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx);
+void iblnerf_destroy(iblnerf_ctx* ctx);
+const char* iblnerf_last_error(const iblnerf_ctx* ctx);   /* ctx may be NULL: last create() error */
+
+/* Number of floats in one network's state-dict blob (798 994). */
+size_t iblnerf_blob_floats(void);
+
+/* replaces: model.load_state_dict(ckpt[...]) (nerf_models/ibl_nerf.py:361, :375).
+ * which: 0 = network_fn (coarse), 1 = network_fine.  h_blob = every tensor of IBLNeRF.state_dict()
+ * in registration order, weight [out,in] row-major then bias.  Weights are copied (re-upload after
+ * an optimizer step).  Synchronous. */
+int iblnerf_upload_weights(iblnerf_ctx* ctx, int which, const float* h_blob, size_t n_floats);
+
+/* replaces: brdf_lut tensor of test.py:79-87.  h_rgb = float [3,512,512] (R = scale, G = bias). */
+int iblnerf_upload_lut(iblnerf_ctx* ctx, const float* h_rgb);
+
+/* Host-only helper (no GPU needed): packs a blob into the device weight-stream format
+ * (csrc/layout.h).  Used by the CPU tests to check the MFMA fragment layout arithmetic. */
+int iblnerf_pack_weights_host(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                              float* h_tables, size_t table_floats);
+size_t iblnerf_stream_bytes(void);
+size_t iblnerf_table_floats(void);
+/* Host-only: the encoder's sin/cos (csrc/sincos_enc.h) for x * 2^k, k = 0..n_freq-1, written as
+ * [sin_0, cos_0, sin_1, cos_1, ...]. */
+void iblnerf_encode_host(float x, int n_freq, float* h_out);
+
+/* replaces: get_rays(H, W, K, c2w) (nerf_models/nerf_renderer_helper.py:36-45) for image rows
+ * [row0, row0+n_rows).  h_K = 3x3 row-major, h_c2w = 3x4 row-major.  Outputs [n_rows*W, 3]. */
+int iblnerf_get_rays(iblnerf_ctx* ctx, void* stream, int H, int W, const float* h_K, const float* h_c2w,
+                     int row0, int n_rows, float* d_rays_o, float* d_rays_d);
+
+/* replaces: network_query_fn(inputs, viewdirs, network_fn) (nerf_models/ibl_nerf.py:327-329 ->
+ * run_network :236-252).  d_pts [n_rays, n_samples, 3]; d_viewdirs [n_rays,3] or NULL.
+ * d_out [n_rays, n_samples, 18], or [n_rays, n_samples, 1] when d_viewdirs is NULL (sigma only,
+ * IBLNeRF.forward early return :175-176). */
+int iblnerf_network_query(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays,
+                          int n_samples, const float* d_viewdirs, float* d_out);
+
+/* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
+ * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
+int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,
+                       int64_t n_rays, int n_bins, int n_out, float* d_samples);
+
+/* gt_values rows + edit/insert kwargs of test.py:115-139 consumed by raw2outputs
+ * (nerf_models/ibl_nerf_renderer.py:218-238, :253-256, :378-410).  All image pointers are device
+ * pointers with one row per ray. */
+typedef struct {
+    int32_t mode;                      /* 0 none, 1 edit_intrinsic, 2 insert_object */
+    int32_t num_objects;               /* num_edit_objects / num_insert_objects (<= 8) */
+    int32_t edit_depth, edit_normal, edit_albedo, edit_albedo_by_img, edit_roughness;
+    int32_t n_roughness_list;          /* len(editing_target_roughness_list) */
+    const float* d_mask;               /* edit_intrinsic_mask / object_insert_mask [n,3] */
+    const float* d_depth;              /* edit_depth / object_insert_depth [n,1] */
+    const float* d_normal;             /* edit_normal / object_insert_normal [n,3] in [0,1] */
+    const float* d_albedo;             /* edit_albedo [n,3] */
+    float roughness_list[8];           /* editing_/inserting_target_roughness_list */
+    float albedo_list[24];             /* editing_/inserting_target_albedo_list */
+    float irradiance_list[8];          /* inserting_target_irradiance_list */
+} iblnerf_overrides;
+
+/* The 22 non-None maps raw2outputs returns per pass (ibl_nerf_renderer.py:494-525).  Device
+ * pointers, caller-allocated, fp32, one row per ray; NULL = not wanted. */
+typedef struct {
+    float* color_map;                       /* [n,3] */
+    float* radiance_map;                    /* [n,3] */
+    float* radiance_map_k[3];               /* radiance_map_1..3 [n,3] */
+    float* reflected_coarse_radiance_map_k[3]; /* [n,3] */
+    float* irradiance_map;                  /* [n,1] */
+    float* reflected_radiance_map;          /* [n,3] */
+    float* prefiltered_reflected_map;       /* [n,3] */
+    float* albedo_map;                      /* [n,3] */
+    float* roughness_map;                   /* [n] */
+    float* specular_map;                    /* [n,3] */
+    float* diffuse_map;                     /* [n,3] */
+    float* n_dot_v_map;                     /* [n] */
+    float* target_normal_map;               /* [n,3] */
+    float* disp_map;                        /* [n] */
+    float* acc_map;                         /* [n] */
+    float* depth_map;                       /* [n] */
+    float* target_depth_map;                /* [n] */
+    float* weights;                         /* [n, S]  (S = n_samples coarse, n_samples+n_importance fine) */
+} iblnerf_maps;
+
+typedef struct {
+    iblnerf_maps fine;      /* un-suffixed keys (the only pass when n_importance == 0) */
+    iblnerf_maps coarse;    /* "...0" keys; ignored unless options.coarse_outputs and n_importance > 0 */
+    float* z_std;           /* [n] (n_importance > 0) */
+} iblnerf_outputs;
+
+/* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,
+ * :629-732, :153-527) with approximate_radiance=True, perturb=0, raw_noise_std=0.
+ * d_rays_o / d_rays_d [n_rays,3] (rays_d NOT normalised, as get_rays returns it).  Any n_rays: the
+ * library walks it in workspace-sized launches (chunking never changes results, :768-769). */
+int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d,
+                        int64_t n_rays, float near_, float far_, const iblnerf_overrides* overrides,
+                        const iblnerf_outputs* outputs);
+
+/* Timing aid for bench.py: HIP-event time (ms) of the MLP kernels launched by the last
+ * iblnerf_render_rays call on this ctx, and their count.  Enabled by iblnerf_set_profiling(ctx, 1),
+ * which makes render_rays record events around every MLP launch on the launch stream. */
+int iblnerf_set_profiling(iblnerf_ctx* ctx, int enabled);
+int iblnerf_last_mlp_time(iblnerf_ctx* ctx, float* ms_total, int* n_launches, double* flop_algorithmic);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBLNERF_H */

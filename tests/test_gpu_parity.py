@@ -1,0 +1,222 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Everything goes through the C-ABI
+(ibl-nerf_amd/binding.py -> libiblnerf_hip.so); the checker is the oracle and the golden vectors
+recorded from the reference.  Tolerances: north_star's bar is 1e-3 relative L-inf per intrinsic
+channel; tighter bounds are asserted where the arithmetic allows and the reason is stated.
+"""
+import numpy as np
+import pytest
+
+import iblnerf_oracle as O
+from conftest import GOLDEN, RENDER_FIXTURES, load_golden, rel_linf
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _require_native():
+    from ibl_nerf_amd import binding as B
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    B.load_library()   # raises if the HIP library was not built: never fall back
+
+
+@pytest.fixture(scope="module")
+def R():
+    _require_native()
+    from ibl_nerf_amd import renderer
+    return renderer
+
+
+def make_renderer(R, g, sdc, sdf, lut, **kw):
+    r = R.Renderer(64, int(g["n_importance"]), **kw)
+    r.load_weights(0, sdc)
+    if int(g["n_importance"]) > 0:
+        r.load_weights(1, sdf)
+    r.load_lut(lut)
+    return r
+
+
+def to_np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
+          "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3", "target_depth_map"]
+DERIVED = ["target_normal_map", "n_dot_v_map", "specular_map", "diffuse_map", "color_map", "reflected_radiance_map",
+           "prefiltered_reflected_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2",
+           "reflected_coarse_radiance_map_3"]
+
+
+def test_get_rays(R):
+    sv = np.load(GOLDEN + "/small_vectors.npz")
+    r = R.Renderer(64, 0, max_rays_per_launch=16)
+    H, W = int(sv["gr_H"]), int(sv["gr_W"])
+    ro, rd = r.get_rays(H, W, sv["gr_K"], sv["gr_c2w"])
+    assert np.array_equal(ro.cpu().numpy(), sv["gr_o"])
+    assert np.abs(rd.cpu().numpy() - sv["gr_d"]).max() <= 2e-7
+    # row tiles concatenate to the full image (the multi-GPU partition)
+    a = r.get_rays(H, W, sv["gr_K"], sv["gr_c2w"], 0, 2)[1]
+    b = r.get_rays(H, W, sv["gr_K"], sv["gr_c2w"], 2, 3)[1]
+    assert torch.equal(torch.cat([a, b], 0), rd)
+    # 800x800 view of the bench config against the oracle, bit-exact origins, 1-ulp directions
+    K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.array([[0.1], [-0.2], [0.3]])], 1).astype(np.float32)
+    ro, rd = r.get_rays(800, 800, K, c2w)
+    oo, od = O.get_rays(800, 800, K, c2w)
+    assert np.array_equal(ro.cpu().numpy(), oo) and np.abs(rd.cpu().numpy() - od).max() <= 2e-7
+
+
+def test_sample_pdf(R):
+    sv = np.load(GOLDEN + "/small_vectors.npz")
+    r = R.Renderer(64, 0, max_rays_per_launch=16)
+    s = r.sample_pdf(sv["sp_bins"], sv["sp_weights"], 128).cpu().numpy()
+    assert np.abs(s - sv["sp_samples"]).max() <= 1e-5       # 1 ulp of a cdf entry moves a sample by ~1e-5
+    s16 = r.sample_pdf(sv["sp_bins"][:, :9].copy(), sv["sp_weights"][:, :8].copy(), 16).cpu().numpy()
+    assert np.abs(s16 - sv["sp16_samples"]).max() <= 1e-5
+    g = np.load(GOLDEN + "/plain_g10.npz")
+    s = r.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128).cpu().numpy()
+    assert np.abs(s - g["pdf_samples"]).max() <= 2e-5
+    assert np.all(np.diff(s, axis=-1) >= -1e-6)
+    with pytest.raises(ValueError):
+        r.sample_pdf(sv["sp_bins"], sv["sp_weights"][:, :-1].copy(), 8)
+
+
+@pytest.mark.parametrize("name", RENDER_FIXTURES)
+def test_network_query_stagewise(R, name, lut):
+    """Teacher-forced MLP: the reference's own query inputs -> its recorded raw outputs.
+    bf16x3 (hi/lo split, 3 MFMA products): ~2^-17 per operand, 8-12 layers deep."""
+    g, sdc, sdf, _, _ = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    tol = 6e-5 if float(g["gain"]) == 1.0 else 6e-4
+    passes = [("c", 0)] + ([("f", 1)] if int(g["n_importance"]) > 0 else [])
+    for p, which in passes:
+        raw = r.network_query(g["q_%s_main_pts" % p], g["q_%s_main_dirs" % p], which).cpu().numpy()
+        assert raw.shape == g["q_%s_main_raw" % p].shape
+        assert np.abs(raw - g["q_%s_main_raw" % p]).max() <= tol
+        sig = r.network_query(g["q_%s_eps_pts" % p], None, which).cpu().numpy()
+        assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= tol
+        refl = r.network_query(g["q_%s_refl_pts" % p], g["q_%s_refl_dirs" % p], which).cpu().numpy()
+        assert np.abs(refl - g["q_%s_refl_raw" % p]).max() <= tol
+
+
+def test_network_query_ragged_sizes_vs_oracle(R, lut):
+    """Point counts that are not multiples of the 32-point wave tile / 128-point workgroup tile,
+    a single point, and samples-per-ray that do not divide 32."""
+    g, sdc, sdf, _, _ = load_golden("plain_g10")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    rng = np.random.RandomState(0)
+    for n_rays, S in ((1, 1), (3, 5), (7, 33), (2, 191), (129, 3)):
+        pts = rng.uniform(-6, 6, (n_rays, S, 3)).astype(np.float32)
+        dirs = rng.uniform(-1, 1, (n_rays, 3)).astype(np.float32)
+        ref = O.network_query(sdc, pts, dirs)
+        got = r.network_query(pts, dirs, 0).cpu().numpy()
+        assert np.abs(got - ref).max() <= 6e-5, (n_rays, S)
+        ref_s = O.network_query(sdc, pts, None)
+        got_s = r.network_query(pts, None, 0).cpu().numpy()
+        assert np.abs(got_s - ref_s).max() <= 6e-5, (n_rays, S)
+
+
+@pytest.mark.parametrize("name", RENDER_FIXTURES)
+def test_render_rays_vs_reference_golden(R, name, lut):
+    g, sdc, sdf, gt, edit = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096)
+    res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
+    ref_keys = sorted(k[5:] for k in g.files if k.startswith("out__"))
+    assert sorted(res.keys()) == ref_keys
+    wide = float(g["gain"]) > 1.0
+    report = {}
+    for k in ref_keys:
+        assert res[k].shape == g["out__" + k].shape, k
+        report[k] = rel_linf(res[k], g["out__" + k])
+    for sfx in ([""] + (["0"] if int(g["n_importance"]) > 0 else [])):
+        for k in DIRECT:
+            # north_star bar is 1e-3; with 17-bit operands the direct channels sit well below it
+            assert report[k + sfx] <= (1e-3 if wide else 2e-4), (k + sfx, report[k + sfx])
+        for k in DERIVED:
+            # gain 1.6 fixture: the reference's own fp32-vs-fp64 runs disagree by 1e-3..5e-1 on these
+            # channels, so only a sanity bound applies there.
+            assert report[k + sfx] <= (2e-1 if wide else 1e-3), (k + sfx, report[k + sfx])
+    if int(g["n_importance"]) > 0:
+        assert report["z_std"] <= 1e-4
+    color = res["color_map"].astype(np.float64)
+    psnr = 10 * np.log10(1.0 / max(np.mean((color - g["out__color_map"]) ** 2), 1e-30))
+    assert psnr > (45 if wide else 70), psnr
+
+
+def test_render_invariances_and_edge_sizes(R, lut):
+    """Launch chunking must not change results (ibl_nerf_renderer.py:768-769); ragged ray counts;
+    coarse_outputs=False leaves the fine maps bit-identical; N_importance=0 path."""
+    g, sdc, sdf, _, _ = load_golden("plain_g10")
+    ro, rd = g["rays_o"][:37], g["rays_d"][:37]
+    big = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    small = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=5)
+    a = to_np(big.render_rays(ro, rd, 0.5, 8.0))
+    b = to_np(small.render_rays(ro, rd, 0.5, 8.0))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    one = to_np(big.render_rays(ro[:1], rd[:1], 0.5, 8.0))
+    for k in a:
+        assert np.array_equal(one[k], a[k][:1]), k
+    lean = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, coarse_outputs=False)
+    c = to_np(lean.render_rays(ro, rd, 0.5, 8.0))
+    assert not any(k.endswith("0") for k in c) and "z_std" in c
+    for k in c:
+        assert np.array_equal(c[k], a[k]), k
+    # size-independent properties
+    assert np.allclose(np.linalg.norm(a["target_normal_map"], axis=-1), 1, atol=1e-5)
+    assert np.allclose(a["weights"].sum(-1), a["acc_map"], rtol=2e-6)
+    assert np.all((a["n_dot_v_map"] >= 0) & (a["n_dot_v_map"] <= 1))
+    assert np.all(a["weights"] >= 0) and a["weights"].shape == (37, 192) and a["weights0"].shape == (37, 64)
+
+
+def test_render_decomp_dropin_surface(R, lut):
+    """The reference-signature entry point: kwargs dict from the create_IBLNeRF mirror, `rays=`
+    and `c2w=` forms, output shapes as ibl_nerf_renderer.py:810-812, edit asserts."""
+    from ibl_nerf_amd import model as M
+    g, sdc, sdf, _, _ = load_golden("plain_g10")
+    _, kw, *_ = M.create_IBLNeRF(M.default_args())
+    kw["network_fn"].load_state_dict(sdc)
+    kw["network_fine"].load_state_dict(sdf)
+    kw.update(near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut))
+    K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], dtype=np.float32)
+    rays = torch.from_numpy(np.stack([g["rays_o"][:16], g["rays_d"][:16]], 0))
+    ret = R.render_decomp(800, 800, K, chunk=1024, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    assert len(ret) == 45 and ret["color_map"].shape == (16, 3) and ret["weights"].shape == (16, 192)
+    assert rel_linf(ret["albedo_map"].cpu().numpy(), g["out__albedo_map"][:16]) <= 2e-4
+    c2w = torch.from_numpy(np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32))
+    Ks = np.array([[5.0, 0, 2], [0, 5.0, 1.5], [0, 0, 1]], dtype=np.float32)
+    img = R.render_decomp(3, 4, Ks, c2w=c2w, gt_values={}, approximate_radiance=True, **kw)
+    assert img["color_map"].shape == (3, 4, 3) and img["depth_map"].shape == (3, 4) and img["irradiance_map"].shape == (3, 4, 1)
+    ora = O.render_decomp(3, 4, Ks, sdc, sdf, lut, 0.5, 8.0, c2w=c2w.numpy())
+    assert rel_linf(img["depth_map"].cpu().numpy(), ora["depth_map"]) <= 2e-4
+    with pytest.raises(AssertionError):
+        R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, insert_object=True,
+                        num_insert_objects=0, **kw)
+    with pytest.raises(NotImplementedError):
+        R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, lindisp=True))
+    with pytest.raises(ValueError):
+        R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, lut_coefficient="Q"))
+
+
+def test_tile_sharding_matches_full_frame(R, lut):
+    """Config 3's partition at a CPU-oracle-checkable size: rendering row tiles separately and
+    concatenating equals rendering the frame in one call, bit for bit."""
+    from ibl_nerf_amd import dist as D
+    g, sdc, sdf, _, _ = load_golden("plain_g10")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=256)
+    H, W = 10, 12
+    K = np.array([[9.0, 0, 6], [0, 9.0, 5], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    full = D.render_frame(r, H, W, K, c2w, 0.5, 8.0)
+    parts = []
+    for rank in range(3):
+        row0, n = D.tile_rows(H, rank, 3)
+        ro, rd = r.get_rays(H, W, K, c2w, row0, n)
+        m = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
+        parts.append(D.pack_maps(m, D.EXPORT_KEYS, n, W)[0])
+    cat = torch.cat(parts, 0)
+    buf, layout = D.pack_maps({k: v.reshape(H * W, -1) for k, v in full.items()}, D.EXPORT_KEYS, H, W)
+    assert torch.equal(cat, buf)
+    ora = O.render_decomp(H, W, K, sdc, sdf, lut, 0.5, 8.0, c2w=c2w)
+    assert rel_linf(full["albedo_map"].cpu().numpy(), ora["albedo_map"]) <= 2e-4
+    assert rel_linf(full["target_normal_map"].cpu().numpy(), ora["target_normal_map"]) <= 1e-3

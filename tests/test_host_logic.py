@@ -1,0 +1,293 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports what include/iblnerf.h
+declares, the weight packer's MFMA fragment layout reproduces the oracle MLP when the MFMA lane
+semantics are emulated in numpy, the encoder's sin/cos meets its error bound, checkpoint I/O and
+the create_IBLNeRF mirror follow the reference's rules.  No compute call touches a GPU."""
+import ctypes as C
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+import iblnerf_oracle as O
+from conftest import ROOT
+from ibl_nerf_amd import binding as B
+from ibl_nerf_amd import checkpoint as ck
+from ibl_nerf_amd import dist as D
+from ibl_nerf_amd import model as M
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return B.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "iblnerf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(iblnerf_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(B.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.iblnerf_blob_floats() == ck.N_PARAMS == 798994
+
+
+def test_struct_sizes_match_header_layout(tmp_path):
+    """ctypes mirrors vs the real header, measured by compiling it with gcc."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "iblnerf.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu",'
+                   'sizeof(iblnerf_options), sizeof(iblnerf_overrides), sizeof(iblnerf_maps), sizeof(iblnerf_outputs),'
+                   'offsetof(iblnerf_overrides, d_mask), offsetof(iblnerf_overrides, irradiance_list),'
+                   'offsetof(iblnerf_outputs, z_std));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(B.Options), C.sizeof(B.Overrides), C.sizeof(B.Maps), C.sizeof(B.Outputs),
+            B.Overrides.d_mask.offset, B.Overrides.irradiance_list.offset, B.Outputs.z_std.offset]
+    assert got == want
+
+
+def test_no_gpu_fails_loudly(lib):
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    o = B.default_options()
+    ctx = C.c_void_p()
+    assert lib.iblnerf_create(C.byref(o), C.byref(ctx)) == -3          # IBLNERF_ERR_HIP, no CPU fallback
+    assert b"no usable HIP device" in lib.iblnerf_last_error(None)
+    from ibl_nerf_amd import renderer as R
+    with pytest.raises(B.IblNerfError):
+        R.Renderer(64, 128)
+
+
+def test_options_validation(lib):
+    o = B.default_options()
+    assert (o.n_samples, o.n_importance, o.gamma_correct, o.coarse_outputs) == (64, 128, 1, 1)
+    o.n_samples, o.n_importance = 200, 128
+    ctx = C.c_void_p()
+    assert lib.iblnerf_create(C.byref(o), C.byref(ctx)) == -1
+
+
+# --------------------------------------------------------------------------------------------
+# encoder sin/cos (csrc/sincos_enc.h)
+# --------------------------------------------------------------------------------------------
+def test_encoder_sincos_error_bound(lib):
+    rng = np.random.RandomState(0)
+    xs = np.concatenate([rng.uniform(-16, 16, 3000), rng.uniform(-1e-2, 1e-2, 500), [0.0, 8.0, -8.0, 3.1415927]]).astype(np.float32)
+    out = np.empty(20, dtype=np.float32)
+    worst = 0.0
+    for x in xs:
+        lib.iblnerf_encode_host(C.c_float(float(x)), 10, out.ctypes.data)
+        arg = np.float64(x) * (2.0 ** np.arange(10))
+        worst = max(worst, np.abs(out[0::2] - np.sin(arg)).max(), np.abs(out[1::2] - np.cos(arg)).max())
+    assert worst < 2.5e-7        # ~2 ulp of 1.0; 20x below the bf16x3 operand error it feeds
+
+
+# --------------------------------------------------------------------------------------------
+# packer layout vs oracle MLP, MFMA lane semantics emulated in numpy
+# --------------------------------------------------------------------------------------------
+KS_BYTES, CH = 2048, 16
+CH_L0, CH_L1, CH_L5, CH_L6, CH_L7, CH_FEAT, CH_ALB, CH_IRR, CH_VIEW, CH_AR = 0, 2, 34, 44, 52, 60, 68, 72, 76, 85
+TAB_BIAS, TAB_SIG, TAB_ROUGH, TAB_ALB, TAB_IRR, TAB_RAD, TAB_AR, TAB_SCALAR = 0, 3200, 3456, 3712, 4096, 4224, 4992, 6144
+
+
+def bf16_rne(x):
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split(x):
+    hi = bf16_rne(x)
+    return hi.astype(np.float64), bf16_rne((x - hi).astype(np.float32)).astype(np.float64)
+
+
+def acc_feature(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def enc_ref_index(sl, h, pph):
+    n = 2 * pph
+    if sl < n:
+        m = pph * h + (sl >> 1)
+        return 3 + 6 * (m // 3) + (3 if sl & 1 else 0) + (m % 3)
+    if sl == n:
+        return 0 if h == 0 else 2
+    if sl == n + 1:
+        return 1 if h == 0 else -1
+    return -1
+
+
+class Emu:
+    """out[p,row] = sum_{h,e} A[(row,h),e] * B[(p,h),e] per k-step, three products on (hi,lo) splits."""
+
+    def __init__(self, stream, tab):
+        ks = np.frombuffer(stream, dtype=np.uint16).reshape(-1, 2, 64, 8)
+        f = (ks.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        self.Ah, self.Al = f[:, 0].reshape(-1, 2, 32, 8), f[:, 1].reshape(-1, 2, 32, 8)  # [ks][h][row][e]
+        self.tab = tab
+
+    def frag_act(self, feat):              # [P,256] -> hi,lo [P, 16 ksteps, h, e]
+        idx = np.empty((16, 2, 8), dtype=np.int64)
+        for j in range(16):
+            for h in range(2):
+                for e in range(8):
+                    idx[j, h, e] = 32 * (j >> 1) + acc_feature(8 * (j & 1) + e, h)
+        return split(feat[:, idx])
+
+    def frag_enc(self, embedded, pph, nk):  # reference-order embedding [P, 3+6L] -> [P, nk, h, e]
+        idx = np.array([[[enc_ref_index(8 * jj + e, h, pph) for e in range(8)] for h in range(2)] for jj in range(nk)])
+        v = np.where(idx >= 0, embedded[:, np.maximum(idx, 0)], 0.0).astype(np.float32)
+        return split(v)
+
+    def ksteps(self, ks0, Bh, Bl):         # k-steps ks0.. over fragments [P, n, h, e] -> [P, 32 rows]
+        n = Bh.shape[1]
+        Ah, Al = self.Ah[ks0:ks0 + n], self.Al[ks0:ks0 + n]
+        return (np.einsum("khre,pkhe->pr", Ah, Bh) + np.einsum("khre,pkhe->pr", Ah, Bl)
+                + np.einsum("khre,pkhe->pr", Al, Bh))
+
+    def lane_vec(self, off, ntiles):       # lane-layout table -> plain feature vector
+        t = self.tab[off:off + ntiles * 32].reshape(ntiles, 2, 16)
+        v = np.empty(ntiles * 32)
+        for tt in range(ntiles):
+            for h in range(2):
+                for r in range(16):
+                    v[32 * tt + acc_feature(r, h)] = t[tt, h, r]
+        return v
+
+    def layer(self, chunk0, ntiles, act, enc=None, bias_tile=0, relu=True):
+        nke = 0 if enc is None else enc[0].shape[1]
+        per = nke + (16 if act is not None else 0)
+        out = []
+        for t in range(ntiles):
+            ks = chunk0 * CH + t * per
+            o = 0.0
+            if enc is not None:
+                o = o + self.ksteps(ks, *enc)
+            if act is not None:
+                o = o + self.ksteps(ks + nke, *act)
+            out.append(o)
+        out = np.concatenate(out, 1) + self.lane_vec(TAB_BIAS + bias_tile * 32, ntiles)
+        out = out.astype(np.float32)
+        return np.maximum(out, 0) if relu else out
+
+    def forward(self, pts, dirs):
+        pe = self.frag_enc(O.embed(pts, 10), 15, 4)
+        h = self.layer(CH_L0, 8, None, pe, 0)
+        for l in range(1, 5):
+            h = self.layer(CH_L1 + 8 * (l - 1), 8, self.frag_act(h), None, 8 * l)
+        h = self.layer(CH_L5, 8, self.frag_act(h), pe, 40)
+        h = self.layer(CH_L6, 8, self.frag_act(h), None, 48)
+        h7 = self.layer(CH_L7, 8, self.frag_act(h), None, 56)
+        sc = self.tab[TAB_SCALAR:TAB_SCALAR + 18]
+        sigma = h7 @ self.lane_vec(TAB_SIG, 8) + sc[0]
+        if dirs is None:
+            return sigma[:, None].astype(np.float32)
+        a7 = self.frag_act(h7)
+        feat = self.layer(CH_FEAT, 8, a7, None, 64, relu=False)
+        albf = self.layer(CH_ALB, 4, a7, None, 72)
+        irrf = self.layer(CH_IRR, 4, a7, None, 76)
+        de = self.frag_enc(O.embed(dirs, 4), 6, 2)
+        h2 = self.layer(CH_VIEW, 8, self.frag_act(feat), de, 80)
+        a2 = self.frag_act(h2)
+        cols = [sigma]
+        cols += [albf @ self.lane_vec(TAB_ALB + c * 128, 4) + sc[1 + c] for c in range(3)]
+        cols += [h7 @ self.lane_vec(TAB_ROUGH, 8) + sc[4], irrf @ self.lane_vec(TAB_IRR, 4) + sc[5]]
+        cols += [h2 @ self.lane_vec(TAB_RAD + c * 256, 8) + sc[6 + c] for c in range(3)]
+        for k in range(3):
+            f = self.layer(CH_AR + 4 * k, 4, a2, None, 88 + 4 * k)
+            cols += [f @ self.lane_vec(TAB_AR + (3 * k + c) * 128, 4) + sc[9 + 3 * k + c] for c in range(3)]
+        return np.stack(cols, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("gain", [1.0, 1.6])
+def test_packed_stream_reproduces_oracle_mlp(lib, gain):
+    sd = ck.synthetic_state_dict(seed=5, gain=gain)
+    blob = ck.state_dict_to_blob(sd)
+    stream = np.zeros(lib.iblnerf_stream_bytes(), dtype=np.uint8)
+    tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
+    assert stream.size == 97 * 32768 and tab.size == 6176
+    rc = lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size)
+    assert rc == 0
+    assert lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size - 1, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == -1
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(-8, 8, (24, 3)).astype(np.float32)
+    dirs = rng.uniform(-1.2, 1.2, (24, 3)).astype(np.float32)
+    emu = Emu(stream.tobytes(), tab)
+    ref = O.mlp_forward(sd, O.embed(pts, 10), O.embed(dirs, 4))
+    got = emu.forward(pts, dirs)
+    # three bf16 products on hi/lo splits: ~2^-17 per operand; 8 layers deep -> a few 1e-5 absolute
+    assert np.abs(got - ref).max() <= (4e-5 if gain == 1.0 else 4e-4), np.abs(got - ref).max()
+    ref_s = O.mlp_forward(sd, O.embed(pts, 10))
+    assert np.abs(emu.forward(pts, None) - ref_s).max() <= (2e-5 if gain == 1.0 else 2e-4)
+    # transpose / permutation detector: a wrong K order or row map gives O(0.1) errors, not 1e-5
+    assert np.abs(ref).max() > 0.05
+
+
+# --------------------------------------------------------------------------------------------
+# checkpoint + factory mirror
+# --------------------------------------------------------------------------------------------
+def test_checkpoint_roundtrip_and_discovery():
+    torch = pytest.importorskip("torch")
+    sdc, sdf = ck.synthetic_state_dict(10), ck.synthetic_state_dict(11, gain=1.3)
+    blob = ck.state_dict_to_blob(sdc)
+    back = ck.blob_to_state_dict(blob)
+    assert list(back.keys()) == list(sdc.keys())
+    assert all(np.array_equal(back[k], sdc[k]) for k in sdc)
+    assert sdc["sigma_linear.bias"][0] == np.float32(0.3)
+    with pytest.raises(ValueError):
+        ck.blob_to_state_dict(blob[:-1])
+    bad = dict(sdc)
+    bad["albedo_linear.weight"] = np.zeros((3, 64), np.float32)
+    with pytest.raises(ValueError):
+        ck.state_dict_to_blob(bad)
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "exp"))
+        ck.save_checkpoint(os.path.join(d, "exp", "000100.tar"), 100, sdc, sdf)
+        ck.save_checkpoint(os.path.join(d, "exp", "200000.tar"), 200000, sdf, sdc)
+        open(os.path.join(d, "exp", "args.txt"), "w").write("x")
+        assert ck.find_checkpoint(d, "exp").endswith("200000.tar")            # lexicographically last '*tar*'
+        assert ck.find_checkpoint(d, "exp", target_load_N_iter=100).endswith("000100.tar")
+        assert ck.find_checkpoint(d, "exp", ft_path="/x/y.tar") == "/x/y.tar"
+        step, c, f = ck.load_checkpoint(os.path.join(d, "exp", "000100.tar"))
+        assert step == 100 and torch.is_tensor(c["sigma_linear.weight"])
+        assert np.array_equal(ck.state_dict_to_blob(c), blob)
+        # the factory follows the same discovery rule and returns reference-shaped kwargs
+        args = M.default_args(basedir=d, expname="exp", no_reload=False)
+        train, test, start, _, _, _ = M.create_IBLNeRF(args)
+        assert start == 200000 and test["perturb"] is False and test["raw_noise_std"] == 0 and train["perturb"] == 1.0
+        assert np.array_equal(ck.state_dict_to_blob(test["network_fn"].state_dict()), ck.state_dict_to_blob(sdf))
+        assert np.array_equal(ck.state_dict_to_blob(test["network_fine"].state_dict()), blob)
+        for k in ("network_query_fn", "N_samples", "N_importance", "lut_coefficient", "gamma_correct", "epsilon",
+                  "target_normal_map_for_radiance_calculation", "correct_depth_for_prefiltered_radiance_infer"):
+            assert k in test
+    with pytest.raises(NotImplementedError):
+        M.create_IBLNeRF(M.default_args(infer_normal=True))
+    with pytest.raises(NotImplementedError):
+        M.IBLNeRF(W=128)
+
+
+def test_unsupported_flags_raise():
+    from ibl_nerf_amd import renderer as R
+    base = dict(approximate_radiance=True)
+    R._check_supported(base)
+    for k in ("lindisp", "use_radiance_linear", "infer_normal", "calculate_albedo_from_gt"):
+        with pytest.raises(NotImplementedError):
+            R._check_supported(dict(base, **{k: True}))
+    with pytest.raises(ValueError):
+        R._check_supported(dict(base, target_normal_map_for_radiance_calculation="bogus"))   # ibl_nerf_renderer.py:375
+    with pytest.raises(NotImplementedError):
+        R._check_supported(dict(base, perturb=1.0))
+
+
+def test_tile_rows_partition():
+    for H in (1, 7, 100, 800, 801):
+        for world in (1, 2, 3, 8):
+            spans = [D.tile_rows(H, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(n for _, n in spans) == H
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
+    with pytest.raises(ValueError):
+        D.tile_rows(10, 2, 2)
