@@ -99,8 +99,7 @@ struct Pipe {
         pos = 0;
         issue(0);
         issue(1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     }
     // begin computing chunk `pos`: returns this lane's fragment base inside the slot
     __device__ __forceinline__ const char* begin() {
@@ -110,26 +109,29 @@ struct Pipe {
     __device__ __forceinline__ void end() {
         // chunk pos+1 must have landed (mine), then everyone's; the barrier is also the WAR fence
         // for the slot that position pos+3 will overwrite.
-        if (pos + 2 < N_PROG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // (wait and barrier in ONE asm statement with a memory clobber: the s_barrier builtin alone
+        // is not a compiler memory fence, and a ds_read of the next chunk hoisted above it would
+        // read a slot other waves are still filling)
+        if (pos + 2 < N_PROG) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         ++pos;
     }
 };
 
-// One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then 16
-// k-steps over the 256-feature activation `in`; three MFMA products per k-step.  Chunk boundaries
+// One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then NKH
+// (16, or 0 for the first layer) k-steps over the 256-feature activation `in`; three MFMA products
+// per k-step.  Chunk boundaries
 // (every 16 k-steps of the flat stream) are compile-time positions.  epi(T, acc) consumes a
 // finished tile.
-template <int NT, int NKE, int VARIANT, class EPI>
+template <int NT, int NKE, int NKH = 16, int VARIANT, class EPI>
 __device__ __forceinline__ void run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, EPI&& epi) {
     const char* frag = P.begin();
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
         f32x16 acc = f32x16{0};
-        static_for<0, NKE + 16>([&](auto J) {
+        static_for<0, NKE + NKH>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            constexpr int ks = t * (NKE + 16) + j;
+            constexpr int ks = t * (NKE + NKH) + j;
             if constexpr (ks % CHUNK_KSTEPS == 0 && ks != 0) {
                 P.end();
                 frag = P.begin();
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         float part[RAW_CH];
 
         // ---- positions_linears.0 : 63 -> 256, ReLU ---------------------------------------------
-        run_layer<8, PE_KSTEPS>(P, A /*unused*/, pe, [&](auto T, const f32x16& acc) {
+        run_layer<8, PE_KSTEPS, 0>(P, A /*unused*/, pe, [&](auto T, const f32x16& acc) {
             constexpr int t = decltype(T)::value;
             split_store<t>(bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + t) * 32), A);
         });

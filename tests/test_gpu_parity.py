@@ -173,8 +173,12 @@ def test_render_decomp_dropin_surface(R, lut):
     """The reference-signature entry point: kwargs dict from the create_IBLNeRF mirror, `rays=`
     and `c2w=` forms, output shapes as ibl_nerf_renderer.py:810-812, edit asserts."""
     from ibl_nerf_amd import model as M
+    import os
+    import tempfile
     g, sdc, sdf, _, _ = load_golden("plain_g10")
-    _, kw, *_ = M.create_IBLNeRF(M.default_args())
+    with tempfile.TemporaryDirectory() as d:      # the factory lists <basedir>/<expname> like ibl_nerf.py:350
+        os.makedirs(os.path.join(d, "exp"))
+        _, kw, *_ = M.create_IBLNeRF(M.default_args(basedir=d))
     kw["network_fn"].load_state_dict(sdc)
     kw["network_fine"].load_state_dict(sdf)
     kw.update(near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut))
