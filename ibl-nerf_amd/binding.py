@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiblnerf_hip.so")
+LIB_PATH = os.environ.get("IBLNERF_LIB", os.path.join(_HERE, "libiblnerf_hip.so"))   # override: ablation builds only
 
 EXPORTS = [
     "iblnerf_default_options", "iblnerf_create", "iblnerf_destroy", "iblnerf_last_error", "iblnerf_blob_floats",

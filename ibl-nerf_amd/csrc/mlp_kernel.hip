@@ -22,6 +22,9 @@ namespace ibl {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Act { bf16x8 hi[16]; bf16x8 lo[16]; };  // 256 features = 16 k-steps of B fragments
 struct Enc { bf16x8 hi[4]; bf16x8 lo[4]; };    // up to 64 encoding slots = 4 k-steps
@@ -34,34 +37,49 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifdef IBL_ABLATE_NO_MFMA    // timing ablation only: keep the operands live, skip the matrix pipe
+__device__ __forceinline__ f32x16 mfma_stub(bf16x8 a, bf16x8 b, f32x16 c) {
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+}
+#define MFMA(a, b, c) mfma_stub((a), (b), (c))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
-// weight-stream pipeline: chunk at program position c lives in ring slot c % 3; the loads for
-// position c+2 are issued when position c starts computing.
+// weight-stream pipeline.  The program's chunks are walked cyclically and never drained: while
+// chunk c is being consumed, chunk c+1 has landed (or is landing) and the loads of chunk c+2 are
+// issued; after the last chunk of a point group the stream wraps to chunk 0 of the next group.
+// Ring slot of a chunk = (running chunk count) % 3.  No branches: begin()/end() are straight-line
+// so a whole tile (48 MFMAs + the previous tile's epilogue) is ONE basic block for the scheduler.
 // ---------------------------------------------------------------------------------------------
 template <int VARIANT>
 struct Pipe {
     static constexpr int N_PROG = VARIANT == VAR_FULL ? N_CHUNKS : (VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : N_CHUNKS - 8);
-    // program position -> stream chunk: the reflected-ray variant skips the 8 albedo / irradiance feature chunks
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
     unsigned lds_ring;   // LDS byte address of the ring (for M0)
     unsigned voff;       // lane*16 + wave*8192: this lane's byte offset inside a chunk for the DMA
     int lane, wave;
-    int pos;
+    int slot, slot2;     // ring slot of the chunk being consumed / of the chunk two ahead
+    int prog2;           // program position (0..N_PROG-1) of the chunk two ahead
 
+    // program position -> stream chunk: the reflected-ray variant skips the 8 albedo / irradiance feature chunks
     __device__ __forceinline__ static int stream_chunk(int p) {
-        if (VARIANT == VAR_REFL) return p < CH_ALB ? p : p + 8;   // skip albedo / irradiance feature chunks
+        if (VARIANT == VAR_REFL) return p < CH_ALB ? p : p + 8;
         return p;
     }
     // One 32 KiB chunk = 8 LDS-DMA instructions per wave (wave w copies bytes [8192w, 8192w+8192)).
     // Scalar base + one VGPR offset (saddr form) so no per-piece 64-bit VGPR address exists; the
-    // loads are invisible to hipcc's waitcnt bookkeeping and are counted by hand (begin()/end()).
+    // loads are invisible to hipcc's waitcnt bookkeeping and are counted by hand (end()).
     // M0 carries the wave-uniform LDS destination; the DMA adds lane*16 itself.
-    __device__ __forceinline__ void issue(int p) const {
-        const char* src = stream + (size_t)stream_chunk(p) * CHUNK_BYTES;             // uniform (SGPR pair)
-        const unsigned dst = lds_ring + (unsigned)(p % RING_SLOTS) * CHUNK_BYTES + wave * 8192;  // uniform
+    __device__ __forceinline__ void issue(int prog, int slt) const {
+#ifdef IBL_ABLATE_NO_LOADS   // timing ablation only (results are garbage): no weight traffic
+        return;
+#endif
+        const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;                 // uniform (SGPR pair)
+        const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192;           // uniform
         unsigned keep, t;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
@@ -95,50 +113,138 @@ struct Pipe {
             : "v"(voff), "s"(dst), "s"(src)
             : "memory", "scc");
     }
-    __device__ __forceinline__ void start() {   // per point-group prologue
-        pos = 0;
-        issue(0);
-        issue(1);
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    __device__ __forceinline__ void start() {   // once per kernel
+        issue(0, 0);
+        issue(1, 1);
+        slot = 0;
+        slot2 = 2;
+        prog2 = 2;
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // chunk 0 landed everywhere
     }
-    // begin computing chunk `pos`: returns this lane's fragment base inside the slot
-    __device__ __forceinline__ const char* begin() {
-        if (pos + 2 < N_PROG) issue(pos + 2);
-        return ring + (pos % RING_SLOTS) * CHUNK_BYTES + lane * 16;
-    }
+    // this lane's fragment base inside the chunk being consumed
+    __device__ __forceinline__ const char* frag() const { return ring + slot * CHUNK_BYTES + lane * 16; }
+    // issue the loads two chunks ahead (called once per chunk, right after its first fragment reads
+    // so that the ~30 scalar/DMA instructions cover the LDS latency behind the barrier)
+    __device__ __forceinline__ void prefetch() const { issue(prog2, slot2); }
+    // done with the current chunk: the next one must have landed (mine: vmcnt, everyone's: barrier).
+    // The barrier is also the WAR fence for the slot the loads issued by the next begin() overwrite.
+    // Wait and barrier are ONE asm statement with a memory clobber: the s_barrier builtin alone is
+    // not a compiler memory fence, and a ds_read of the next chunk hoisted above it would read a
+    // slot other waves are still filling.
     __device__ __forceinline__ void end() {
-        // chunk pos+1 must have landed (mine), then everyone's; the barrier is also the WAR fence
-        // for the slot that position pos+3 will overwrite.
-        // (wait and barrier in ONE asm statement with a memory clobber: the s_barrier builtin alone
-        // is not a compiler memory fence, and a ds_read of the next chunk hoisted above it would
-        // read a slot other waves are still filling)
-        if (pos + 2 < N_PROG) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        ++pos;
+#ifdef IBL_ABLATE_NO_BARRIER   // timing ablation only
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#endif
+        slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
+        slot2 = slot2 == RING_SLOTS - 1 ? 0 : slot2 + 1;
+        prog2 = prog2 == N_PROG - 1 ? 0 : prog2 + 1;
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// ReLU as a signed-integer max on the float bits: negative floats (sign bit set) are negative
+// ints, so max(bits, 0) is exactly max(x, +0) for every non-NaN x, in ONE v_max_i32 (fmaxf costs a
+// canonicalising v_max first).
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// (x0, x1) -> packed bf16 pairs hi = rne(x), lo = rne(x - hi): cvt_pk, shift, and, packed sub, cvt_pk
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 xv = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
+    const f32x2 hv = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(xv - hv, bf16x2));
+}
+
+// Keeps a value materialised where it is computed (an empty asm the optimiser cannot see through):
+// the consumers of an epilogue's results are a whole layer (or the whole kernel) away, and
+// without the pins whole epilogues are deferred out of the MFMA shadow they were placed in.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
+// Epilogue of one finished 32-feature tile, cut into 8 slices of two accumulator registers so the
+// GEMM loop of the NEXT tile can interleave one slice per k-step between its MFMAs:
+//   STORE: v = [ReLU](acc) -> (hi, lo) bf16 B fragments of k-steps 2T, 2T+1 of `dst`
+//   NCH  : running fp32 dot products of v with N=1/3 head weight rows (sigma, roughness, albedo,
+//          irradiance, radiance heads) held in lane layout in LDS.
+// The layer bias is already in the accumulator (it is the MFMA chain's initial C).
+template <bool STORE, bool RELU, int NCH>
+struct Epi {
+    Act* dst;
+    float* part[NCH > 0 ? NCH : 1];
+    const float* tab[NCH > 0 ? NCH : 1];   // this lane-half's row of tile 0 of each head table ([tile][2][16])
+    u32x4 h, l;
+
+    template <int T, int I>
+    __device__ __forceinline__ void slice(const f32x16& acc) {
+        float x0 = acc[2 * I], x1 = acc[2 * I + 1];
+        if constexpr (RELU) {
+            x0 = relu_bits(x0);
+            x1 = relu_bits(x1);
+        }
+        if constexpr (STORE) {
+            unsigned hh, ll;
+            split_pair(x0, x1, hh, ll);
+            h[I & 3] = hh;
+            l[I & 3] = ll;
+            if constexpr ((I & 3) == 3) {
+                asm volatile("" : "+v"(h), "+v"(l));
+                dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
+                dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x2 w = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
+            *part[c] = fmaf(x1, w[1], fmaf(x0, w[0], *part[c]));
+            if constexpr (I == 7) pin(*part[c]);
+        }
     }
 };
 
 // One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then NKH
 // (16, or 0 for the first layer) k-steps over the 256-feature activation `in`; three MFMA products
-// per k-step.  Chunk boundaries
-// (every 16 k-steps of the flat stream) are compile-time positions.  epi(T, acc) consumes a
-// finished tile.
-template <int NT, int NKE, int NKH = 16, int VARIANT, class EPI>
-__device__ __forceinline__ void run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, EPI&& epi) {
-    const char* frag = P.begin();
+// per k-step.  Chunk boundaries (every 16 k-steps of the flat stream) are compile-time positions.
+//
+// Software pipeline inside a tile (one wave per SIMD: nothing else hides latency):
+//   * the A fragments of k-step j+1 are read from LDS before the MFMAs of k-step j are issued;
+//   * the epilogue of the PREVIOUS tile runs one slice per k-step between this tile's MFMAs
+//     (pend(I) = slice I of the previous layer's last tile for tile 0, epi.slice<t-1, I> after);
+//   * sched_barrier(0) fences keep that order at k-step granularity (inside a k-step the compiler
+//     still interleaves the three MFMAs with the slice's VALU work).
+// The last tile's accumulator is returned for the next layer's `pend`.
+template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI>
+__device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
+                                            PEND&& pend, EPI& epi) {
+    constexpr int N = NKE + NKH;                       // k-steps per tile
+    f32x16 prev = f32x16{0};
+    const char* frag = P.frag();
+    bf16x8 ah = *reinterpret_cast<const bf16x8*>(frag);
+    bf16x8 al = *reinterpret_cast<const bf16x8*>(frag + 1024);
+    P.prefetch();
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        f32x16 acc = f32x16{0};
-        static_for<0, NKE + NKH>([&](auto J) {
+        // the accumulator starts at the layer bias (lane layout [tile][h][16]): no add in the epilogue
+        f32x16 acc = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+        static_for<0, N>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            constexpr int ks = t * (NKE + NKH) + j;
-            if constexpr (ks % CHUNK_KSTEPS == 0 && ks != 0) {
-                P.end();
-                frag = P.begin();
+            constexpr int ks = t * N + j;              // k-step index inside the layer
+            constexpr bool last = (t == NT - 1 && j == N - 1);
+            constexpr bool next_new_chunk = ((ks + 1) % CHUNK_KSTEPS == 0);
+            bf16x8 ah_n = ah, al_n = al;
+#ifndef IBL_ABLATE_NO_FRAG    // (timing ablation: reuse the first fragment, no LDS reads in the loop)
+            if constexpr (!last && !next_new_chunk) {   // prefetch the next k-step's fragments
+                constexpr int off = ((ks + 1) % CHUNK_KSTEPS) * KSTEP_BYTES;
+                ah_n = *reinterpret_cast<const bf16x8*>(frag + off);
+                al_n = *reinterpret_cast<const bf16x8*>(frag + off + 1024);
             }
-            constexpr int off = (ks % CHUNK_KSTEPS) * KSTEP_BYTES;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(frag + off);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(frag + off + 1024);
+#endif
+            // hipcc otherwise sinks these reads back to just before their first use (one k-step
+            // later), exposing the full LDS latency to a wave that has nothing else to run
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (j < NKE) {
                 acc = MFMA(ah, enc.hi[j], acc);
                 acc = MFMA(ah, enc.lo[j], acc);
@@ -148,59 +254,35 @@ __device__ __forceinline__ void run_layer(Pipe<VARIANT>& P, const Act& in, const
                 acc = MFMA(ah, in.lo[j - NKE], acc);
                 acc = MFMA(al, in.hi[j - NKE], acc);
             }
+            // previous tile's epilogue: slices spread over k-steps 1 .. N-1
+#ifndef IBL_ABLATE_NO_EPI     // (timing ablation: no epilogue work at all)
+            static_for<0, 8>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (j == 1 + (i * (N - 1)) / 8) {
+                    if constexpr (t == 0) pend(I);
+                    else epi.template slice<(t > 0 ? t - 1 : 0), i>(prev);
+                }
+            });
+#endif
+            __builtin_amdgcn_sched_barrier(0);          // [MFMA x3 + one epilogue slice] stays one k-step wide
+            if constexpr (!last && next_new_chunk) {    // the stream continues in the next ring slot
+                P.end();
+                frag = P.frag();
+                ah_n = *reinterpret_cast<const bf16x8*>(frag);
+                al_n = *reinterpret_cast<const bf16x8*>(frag + 1024);
+                P.prefetch();
+            }
+            ah = ah_n;
+            al = al_n;
         });
-        epi(T, acc);
+        // Pin the finished accumulator here: its only consumer is the deferred epilogue, and without
+        // this the optimiser sinks the whole MFMA chain across the chunk barrier to that use.
+        // "a": keep it in the accumulator file.
+        asm volatile("" : "+a"(acc));
+        prev = acc;
     });
     P.end();
-}
-
-template <bool RELU>
-__device__ __forceinline__ f32x16 bias_act(const f32x16& acc, const float* tab) {
-    f32x16 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 b = reinterpret_cast<const f32x4*>(tab)[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = acc[4 * i + j] + b[j];
-            v[4 * i + j] = RELU ? fmaxf(x, 0.0f) : x;
-        }
-    }
-    return v;
-}
-
-// fp32 tile result -> (hi, lo) bf16 B fragments of k-steps 2T, 2T+1 of the next layer
-template <int T>
-__device__ __forceinline__ void split_store(const f32x16& v, Act& out) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bf16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = v[8 * s + e];
-            const __bf16 hh = (__bf16)x;
-            h[e] = hh;
-            l[e] = (__bf16)(x - (float)hh);
-        }
-        out.hi[2 * T + s] = h;
-        out.lo[2 * T + s] = l;
-    }
-}
-
-// Keeps a running head sum materialised where it is computed: without it the optimiser defers
-// whole tile epilogues to the end of the kernel (their results are only needed there) and the
-// accumulators they read get spilled to scratch.
-__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
-
-__device__ __forceinline__ float dot16(const f32x16& v, const float* tab) {
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 w = reinterpret_cast<const f32x4*>(tab)[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s = fmaf(v[4 * i + j], w[j], s);
-    }
-    return s;
+    return prev;
 }
 
 // [x, sin(2^k x), cos(2^k x)] in the slot order of layout.h::enc_ref_index (sincos_enc.h: one
@@ -221,16 +303,16 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Enc& en
     for (int i = 2 * PAIRS + 2; i < 8 * NK; ++i) vals[i] = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < NK; ++jj) {
-        bf16x8 hv, lv;
+        u32x4 hv, lv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = vals[8 * jj + e];
-            const __bf16 hh = (__bf16)v;
+        for (int e = 0; e < 4; ++e) {
+            unsigned hh, ll;
+            split_pair(vals[8 * jj + 2 * e], vals[8 * jj + 2 * e + 1], hh, ll);
             hv[e] = hh;
-            lv[e] = (__bf16)(v - (float)hh);
+            lv[e] = ll;
         }
-        enc.hi[jj] = hv;
-        enc.lo[jj] = lv;
+        enc.hi[jj] = __builtin_bit_cast(bf16x8, hv);
+        enc.lo[jj] = __builtin_bit_cast(bf16x8, lv);
     }
 }
 
@@ -255,6 +337,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     P.wave = wave;
     P.lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     P.voff = lane * 16 + wave * 8192;
+    P.start();
 
     const long n_groups = (a.n_pts + 127) / 128;
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -266,117 +349,103 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
         }
-        Enc pe;
+        Enc pe, de;
         encode<PE_PAIRS_PER_HALF, PE_KSTEPS>(px, py, pz, h, pe);
-
-        P.start();
+        if constexpr (VARIANT != VAR_TRUNK) {
+            // direction encoding of this point's ray (run_network expands viewdirs over the samples,
+            // ibl_nerf.py:244-247)
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (valid) {
+                const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;   // n_pts < 2^31 per launch
+                dx = a.dirs[3 * (size_t)r + 0];
+                dy = a.dirs[3 * (size_t)r + 1];
+                dz = a.dirs[3 * (size_t)r + 2];
+            }
+            encode<DE_PAIRS_PER_HALF, DE_KSTEPS>(dx, dy, dz, h, de);
+        }
 
         Act A, B;
         float part[RAW_CH];
+#pragma unroll
+        for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
+        const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
+        auto none = [](auto) {};
+        // whole epilogue of a layer's last tile, run before anything else may read its results
+        auto flush = [&](auto& e, auto T, const f32x16& acc) {
+            static_for<0, 8>([&](auto I) { e.template slice<decltype(T)::value, decltype(I)::value>(acc); });
+        };
+        using T7 = std::integral_constant<int, 7>;
+        using T3 = std::integral_constant<int, 3>;
+        // ReLU -> fragments of A / B
+        Epi<true, true, 0> eA{&A, {nullptr}, {nullptr}}, eB{&B, {nullptr}, {nullptr}};
 
-        // ---- positions_linears.0 : 63 -> 256, ReLU ---------------------------------------------
-        run_layer<8, PE_KSTEPS, 0>(P, A /*unused*/, pe, [&](auto T, const f32x16& acc) {
-            constexpr int t = decltype(T)::value;
-            split_store<t>(bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + t) * 32), A);
-        });
-        // ---- positions_linears.1..4 : 256 -> 256, ReLU -----------------------------------------
-        for (int l = 1; l <= 4; ++l) {
-            run_layer<8, 0>(P, A, pe, [&](auto T, const f32x16& acc) {
-                constexpr int t = decltype(T)::value;
-                split_store<t>(bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + 8 * l + t) * 32), B);
-            });
-            A = B;
+        // ---- positions_linears.0 : 63 -> 256, ReLU  (-> A) -------------------------------------
+        f32x16 pacc = run_layer<8, PE_KSTEPS, 0>(P, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
+        // ---- positions_linears.1..4 : 256 -> 256, ReLU, two layers per trip (A -> B -> A) -------
+#ifdef IBL_ABLATE_LOOPONLY    // timing ablation: 58 layers through the SAME 2-layer loop body (I-cache resident)
+        for (int l = 1; l <= 57; l += 2) {
+#else
+        for (int l = 1; l <= 3; l += 2) {
+#endif
+            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
+                                       [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
+                                       [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
         }
-        // ---- positions_linears.5 : cat([x63, h]) -> 256, ReLU (ibl_nerf.py:167-168) ------------
-        run_layer<8, PE_KSTEPS>(P, A, pe, [&](auto T, const f32x16& acc) {
-            constexpr int t = decltype(T)::value;
-            split_store<t>(bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + 40 + t) * 32), B);
-        });
-        // ---- positions_linears.6 ----------------------------------------------------------------
-        run_layer<8, 0>(P, B, pe, [&](auto T, const f32x16& acc) {
-            constexpr int t = decltype(T)::value;
-            split_store<t>(bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + 48 + t) * 32), A);
-        });
-        // ---- positions_linears.7 ; sigma_linear / roughness_linear on its fp32 activations -----
-        part[0] = 0.0f;
-        part[4] = 0.0f;
-        run_layer<8, 0>(P, A, pe, [&](auto T, const f32x16& acc) {
-            constexpr int t = decltype(T)::value;
-            const f32x16 v = bias_act<true>(acc, ltab + TAB_BIAS + (BT_L0 + 56 + t) * 32);
-            if constexpr (VARIANT != VAR_TRUNK) split_store<t>(v, B);
-            part[0] += dot16(v, ltab + TAB_SIG + t * 32);
-            pin(part[0]);
-            if constexpr (VARIANT == VAR_FULL) {
-                part[4] += dot16(v, ltab + TAB_ROUGH + t * 32);
-                pin(part[4]);
-            }
-        });
+        // ---- positions_linears.5 : cat([x63, h]) -> 256, ReLU (ibl_nerf.py:167-168)  (A -> B) ---
+        pacc = run_layer<8, PE_KSTEPS, 16>(P, A, pe, bias + (BT_L0 + 40) * 32,
+                                           [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+        // ---- positions_linears.6  (B -> A) -------------------------------------------------------
+        pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 48) * 32,
+                                   [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
+        // ---- positions_linears.7  (A -> B); sigma_linear / roughness_linear on its fp32 activations
+        auto e7 = [&] {
+            if constexpr (VARIANT == VAR_FULL)
+                return Epi<true, true, 2>{&B, {&part[0], &part[4]}, {ltab + TAB_SIG, ltab + TAB_ROUGH}};
+            else
+                return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}};
+        }();
+        pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 56) * 32,
+                                   [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, e7);
 
-        if constexpr (VARIANT != VAR_TRUNK) {
-#pragma unroll
-            for (int c = 1; c < RAW_CH; ++c)
-                if (c != 4) part[c] = 0.0f;
+        if constexpr (VARIANT == VAR_TRUNK) {
+            flush(e7, T7{}, pacc);
+        } else {
             // ---- feature_linear : 256 -> 256, no activation (B = h7 -> A = feature) ------------
-            run_layer<8, 0>(P, B, pe, [&](auto T, const f32x16& acc) {
-                constexpr int t = decltype(T)::value;
-                split_store<t>(bias_act<false>(acc, ltab + TAB_BIAS + (BT_FEAT + t) * 32), A);
-            });
+            Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}};
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32,
+                                       [&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); }, eFeat);
+            // ---- albedo_feature_linear (ReLU) -> albedo_linear ; irradiance_feature_linear -> irradiance_linear
+            Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
+                                     {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}};
+            Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}};
             if constexpr (VARIANT == VAR_FULL) {
-                // ---- albedo_feature_linear (ReLU) -> albedo_linear -----------------------------
-                run_layer<4, 0>(P, B, pe, [&](auto T, const f32x16& acc) {
-                    constexpr int t = decltype(T)::value;
-                    const f32x16 v = bias_act<true>(acc, ltab + TAB_BIAS + (BT_ALB + t) * 32);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        part[1 + c] += dot16(v, ltab + TAB_ALB + c * 128 + t * 32);
-                        pin(part[1 + c]);
-                    }
-                });
-                // ---- irradiance_feature_linear (ReLU) -> irradiance_linear ---------------------
-                run_layer<4, 0>(P, B, pe, [&](auto T, const f32x16& acc) {
-                    constexpr int t = decltype(T)::value;
-                    const f32x16 v = bias_act<true>(acc, ltab + TAB_BIAS + (BT_IRR + t) * 32);
-                    part[5] += dot16(v, ltab + TAB_IRR + t * 32);
-                    pin(part[5]);
-                });
-            }
-            // direction encoding of this point's ray (run_network expands viewdirs over the samples,
-            // ibl_nerf.py:244-247)
-            Enc de;
-            {
-                float dx = 0.f, dy = 0.f, dz = 0.f;
-                if (valid) {
-                    const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;   // n_pts < 2^31 per launch
-                    dx = a.dirs[3 * (size_t)r + 0];
-                    dy = a.dirs[3 * (size_t)r + 1];
-                    dz = a.dirs[3 * (size_t)r + 2];
-                }
-                encode<DE_PAIRS_PER_HALF, DE_KSTEPS>(dx, dy, dz, h, de);
+                f32x16 qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32,
+                                                  [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eAlb);
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_IRR * 32,
+                                           [&](auto I) { eAlb.template slice<3, decltype(I)::value>(qacc); }, eIrr);
             }
             // ---- views_linears.0 : cat([feature, dir27]) -> 256, ReLU (A -> B) ; radiance_linear -
-            run_layer<8, DE_KSTEPS>(P, A, de, [&](auto T, const f32x16& acc) {
-                constexpr int t = decltype(T)::value;
-                const f32x16 v = bias_act<true>(acc, ltab + TAB_BIAS + (BT_VIEW + t) * 32);
-                split_store<t>(v, B);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    part[6 + c] += dot16(v, ltab + TAB_RAD + c * 256 + t * 32);
-                    pin(part[6 + c]);
-                }
-            });
+            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]},
+                                     {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}};
+            pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, [&](auto I) {
+                if constexpr (VARIANT == VAR_FULL) eIrr.template slice<3, decltype(I)::value>(pacc);
+                else eFeat.template slice<7, decltype(I)::value>(pacc);
+            }, eView);
             // ---- additional_radiance_feature_linear.k (ReLU) -> additional_radiance_linear.k ----
-            static_for<0, 3>([&](auto Kk) {
-                constexpr int k = decltype(Kk)::value;
-                run_layer<4, 0>(P, B, pe, [&](auto T, const f32x16& acc) {
-                    constexpr int t = decltype(T)::value;
-                    const f32x16 v = bias_act<true>(acc, ltab + TAB_BIAS + (BT_AR + 4 * k + t) * 32);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        part[9 + 3 * k + c] += dot16(v, ltab + TAB_AR + (3 * k + c) * 128 + t * 32);
-                        pin(part[9 + 3 * k + c]);
-                    }
-                });
-            });
+            Epi<false, true, 3> eAr0{nullptr, {&part[9], &part[10], &part[11]},
+                                     {ltab + TAB_AR, ltab + TAB_AR + 128, ltab + TAB_AR + 256}};
+            Epi<false, true, 3> eAr1{nullptr, {&part[12], &part[13], &part[14]},
+                                     {ltab + TAB_AR + 384, ltab + TAB_AR + 512, ltab + TAB_AR + 640}};
+            Epi<false, true, 3> eAr2{nullptr, {&part[15], &part[16], &part[17]},
+                                     {ltab + TAB_AR + 768, ltab + TAB_AR + 896, ltab + TAB_AR + 1024}};
+            pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32,
+                                       [&](auto I) { eView.template slice<7, decltype(I)::value>(pacc); }, eAr0);
+            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 4) * 32,
+                                       [&](auto I) { eAr0.template slice<3, decltype(I)::value>(pacc); }, eAr1);
+            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 8) * 32,
+                                       [&](auto I) { eAr1.template slice<3, decltype(I)::value>(pacc); }, eAr2);
+            flush(eAr2, T3{}, pacc);
         }
 
         // ---- combine the two lane halves, add head biases, store ------------------------------
@@ -411,9 +480,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 }
             }
         }
-        // all lanes' stores/loads retire before the next group's pipeline restarts counting
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    P.drain();   // the two chunks prefetched past the end are never consumed
 }
 
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
