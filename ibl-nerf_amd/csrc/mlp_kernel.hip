@@ -11,6 +11,7 @@
 // VALU in fp32 straight from the fp32 accumulators.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <type_traits>
 
 #include "layout.h"
@@ -47,6 +48,13 @@ __device__ __forceinline__ f32x16 mfma_stub(bf16x8 a, bf16x8 b, f32x16 c) {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #endif
 
+#ifdef IBL_TRACE   // debug build only: cycle stamps of workgroup 0 / wave 0, one layer of the first point group
+__device__ long long g_trace[256];
+#define TRACE(P, slot) do { if ((P).trace) (P).tr[(slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE(P, slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // weight-stream pipeline.  The program's chunks are walked cyclically and never drained: while
 // chunk c is being consumed, chunk c+1 has landed (or is landing) and the loads of chunk c+2 are
@@ -64,54 +72,45 @@ struct Pipe {
     int lane, wave;
     int slot, slot2;     // ring slot of the chunk being consumed / of the chunk two ahead
     int prog2;           // program position (0..N_PROG-1) of the chunk two ahead
+#ifdef IBL_TRACE
+    bool trace = false;
+    long long* tr = nullptr;
+#endif
 
     // program position -> stream chunk: the reflected-ray variant skips the 8 albedo / irradiance feature chunks
     __device__ __forceinline__ static int stream_chunk(int p) {
         if (VARIANT == VAR_REFL) return p < CH_ALB ? p : p + 8;
         return p;
     }
-    // One 32 KiB chunk = 8 LDS-DMA instructions per wave (wave w copies bytes [8192w, 8192w+8192)).
-    // Scalar base + one VGPR offset (saddr form) so no per-piece 64-bit VGPR address exists; the
-    // loads are invisible to hipcc's waitcnt bookkeeping and are counted by hand (end()).
-    // M0 carries the wave-uniform LDS destination; the DMA adds lane*16 itself.
-    __device__ __forceinline__ void issue(int prog, int slt) const {
+    // One 32 KiB chunk = 8 LDS-DMA instructions per wave (wave w copies bytes [8192w, 8192w+8192),
+    // piece i = 1 KiB).  Scalar base + one VGPR offset (saddr form) so no 64-bit VGPR address exists;
+    // the loads are invisible to hipcc's waitcnt bookkeeping and are counted by hand (end()).  M0
+    // carries the wave-uniform LDS destination; the DMA adds lane*16 itself.
+    // One LDS-DMA instruction costs the issuing wave ~60 cycles (measured with s_memtime: issuing
+    // all eight back to back after the chunk barrier stalled the wave's MFMA stream for ~500
+    // cycles per chunk), so the pieces are issued ONE PER K-STEP, each in the shadow of that
+    // k-step's MFMAs.
+    __device__ __forceinline__ void issue_piece(int prog, int slt, int i) const {
 #ifdef IBL_ABLATE_NO_LOADS   // timing ablation only (results are garbage): no weight traffic
         return;
 #endif
-        const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;                 // uniform (SGPR pair)
-        const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192;           // uniform
-        unsigned keep, t;
+        const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;                        // uniform (SGPR pair)
+        const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + i * 1024;       // uniform
+        const unsigned v = voff + i * 1024;
+        unsigned keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "v_mov_b32 %1, %2\n\t"
+            "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %1, 0x400, %1\n\t"
-            "global_load_lds_dwordx4 %1, %4\n\t"
+            "global_load_lds_dwordx4 %1, %3\n\t"
             "s_mov_b32 m0, %0"
-            : "=&s"(keep), "=&v"(t)
-            : "v"(voff), "s"(dst), "s"(src)
-            : "memory", "scc");
+            : "=&s"(keep)
+            : "v"(v), "s"(dst), "s"(src)
+            : "memory");
+    }
+    __device__ __forceinline__ void issue(int prog, int slt) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_piece(prog, slt, i);
     }
     __device__ __forceinline__ void start() {   // once per kernel
         issue(0, 0);
@@ -123,9 +122,8 @@ struct Pipe {
     }
     // this lane's fragment base inside the chunk being consumed
     __device__ __forceinline__ const char* frag() const { return ring + slot * CHUNK_BYTES + lane * 16; }
-    // issue the loads two chunks ahead (called once per chunk, right after its first fragment reads
-    // so that the ~30 scalar/DMA instructions cover the LDS latency behind the barrier)
-    __device__ __forceinline__ void prefetch() const { issue(prog2, slot2); }
+    // piece i of the chunk two ahead (one per k-step, chunk-relative k-steps DMA_K0 .. DMA_K0+7)
+    __device__ __forceinline__ void prefetch_piece(int i) const { issue_piece(prog2, slot2, i); }
     // done with the current chunk: the next one must have landed (mine: vmcnt, everyone's: barrier).
     // The barrier is also the WAR fence for the slot the loads issued by the next begin() overwrite.
     // Wait and barrier are ONE asm statement with a memory clobber: the s_barrier builtin alone is
@@ -216,6 +214,7 @@ struct Epi {
 //   * sched_barrier(0) fences keep that order at k-step granularity (inside a k-step the compiler
 //     still interleaves the three MFMAs with the slice's VALU work).
 // The last tile's accumulator is returned for the next layer's `pend`.
+constexpr int DMA_K0 = 2;   // chunk-relative k-step after which the first DMA piece of the chunk two ahead is issued
 template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI>
 __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
                                             PEND&& pend, EPI& epi) {
@@ -224,7 +223,6 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
     const char* frag = P.frag();
     bf16x8 ah = *reinterpret_cast<const bf16x8*>(frag);
     bf16x8 al = *reinterpret_cast<const bf16x8*>(frag + 1024);
-    P.prefetch();
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
         // the accumulator starts at the layer bias (lane layout [tile][h][16]): no add in the epilogue
@@ -235,6 +233,8 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
             constexpr bool last = (t == NT - 1 && j == N - 1);
             constexpr bool next_new_chunk = ((ks + 1) % CHUNK_KSTEPS == 0);
             bf16x8 ah_n = ah, al_n = al;
+            if constexpr (j == 0) TRACE(P, 4 * t + 0);
+            if constexpr (j == 8) TRACE(P, 4 * t + 1);
 #ifndef IBL_ABLATE_NO_FRAG    // (timing ablation: reuse the first fragment, no LDS reads in the loop)
             if constexpr (!last && !next_new_chunk) {   // prefetch the next k-step's fragments
                 constexpr int off = ((ks + 1) % CHUNK_KSTEPS) * KSTEP_BYTES;
@@ -254,6 +254,9 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
                 acc = MFMA(ah, in.lo[j - NKE], acc);
                 acc = MFMA(al, in.hi[j - NKE], acc);
             }
+            // one LDS-DMA piece of the chunk two ahead per k-step, behind this k-step's MFMAs
+            if constexpr (ks % CHUNK_KSTEPS >= DMA_K0 && ks % CHUNK_KSTEPS < DMA_K0 + 8)
+                P.prefetch_piece(ks % CHUNK_KSTEPS - DMA_K0);
             // previous tile's epilogue: slices spread over k-steps 1 .. N-1
 #ifndef IBL_ABLATE_NO_EPI     // (timing ablation: no epilogue work at all)
             static_for<0, 8>([&](auto I) {
@@ -265,12 +268,13 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
             });
 #endif
             __builtin_amdgcn_sched_barrier(0);          // [MFMA x3 + one epilogue slice] stays one k-step wide
+            if constexpr (next_new_chunk) TRACE(P, 4 * t + 2);
             if constexpr (!last && next_new_chunk) {    // the stream continues in the next ring slot
                 P.end();
+                TRACE(P, 4 * t + 3);
                 frag = P.frag();
                 ah_n = *reinterpret_cast<const bf16x8*>(frag);
                 al_n = *reinterpret_cast<const bf16x8*>(frag + 1024);
-                P.prefetch();
             }
             ah = ah_n;
             al = al_n;
@@ -330,6 +334,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
 
+#ifdef IBL_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_trace[41] = 777;
+#endif
     Pipe<VARIANT> P;
     P.stream = a.stream;
     P.ring = smem;
@@ -387,8 +394,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 #else
         for (int l = 1; l <= 3; l += 2) {
 #endif
+#ifdef IBL_TRACE
+            P.trace = (blockIdx.x == 0 && wave == 0 && g == (long)blockIdx.x + 2 * (long)gridDim.x && l == 1);
+            P.tr = reinterpret_cast<long long*>(smem + LDS_BYTES);
+#endif
             pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
                                        [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+#ifdef IBL_TRACE
+            if (P.trace) { for (int i = lane; i < 32; i += 64) g_trace[i] = P.tr[i]; g_trace[40] = 12345; }
+            P.trace = false;
+#endif
             pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
                                        [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
         }
@@ -490,17 +505,35 @@ hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t strea
     const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
         attr_set = true;
     }
+#ifdef IBL_TRACE
+    constexpr int LDS_LAUNCH = LDS_BYTES + 2048;
+#else
+    constexpr int LDS_LAUNCH = LDS_BYTES;
+#endif
     switch (variant) {
-        case VAR_FULL: hipLaunchKernelGGL(mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
-        case VAR_TRUNK: hipLaunchKernelGGL(mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
-        case VAR_REFL: hipLaunchKernelGGL(mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+        case VAR_FULL: hipLaunchKernelGGL(mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
+        case VAR_TRUNK: hipLaunchKernelGGL(mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
+        case VAR_REFL: hipLaunchKernelGGL(mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
         default: return hipErrorInvalidValue;
     }
+#ifdef IBL_TRACE
+    if (variant == VAR_TRUNK) {
+        (void)hipDeviceSynchronize();
+        long long h[32];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof h);
+        long long chk = 0, chk2 = 0; hipError_t e2 = hipMemcpyFromSymbol(&chk, HIP_SYMBOL(g_trace), 8, 40 * 8);
+        (void)hipMemcpyFromSymbol(&chk2, HIP_SYMBOL(g_trace), 8, 41 * 8);
+        printf("[trace] s41=%lld sentinel=%lld err=%s  tile: start->mid  mid->end  end->barrier+prefetch  | tile period\n", chk2, chk, hipGetErrorString(e2));
+        for (int t = 0; t < 8; ++t)
+            printf("[trace] t%d: %6lld %6lld %6lld | %6lld\n", t, h[4 * t + 1] - h[4 * t], h[4 * t + 2] - h[4 * t + 1],
+                   t < 7 ? h[4 * t + 3] - h[4 * t + 2] : 0LL, t < 7 ? h[4 * t + 4] - h[4 * t] : 0LL);
+    }
+#endif
     return hipGetLastError();
 }
 
