@@ -45,36 +45,54 @@ def camera():
     return K, c2w
 
 
-def cpu_baseline(sdc, sdf, lut, K, c2w, gpu_color_fn, min_seconds=10.0, batch=256, max_batches=8):
-    """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view."""
+def pmc_traffic():
+    """HBM bytes per MLP launch from the committed rocprofv3 PMC pass (profiles/<round>/pmc.json,
+    written by profiles/summarize.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
+    runs), averaged over the launches of the three kernel variants.  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))["derived"]
+    num = den = 0.0
+    for k, v in d.items():
+        if "mlp_kernel" in k and "hbm_read_bytes" in v and "hbm_write_bytes" in v and v.get("calls"):
+            num += v["calls"] * (v["hbm_read_bytes"] + v["hbm_write_bytes"])
+            den += v["calls"]
+    return (num / den if den else None), os.path.relpath(files[-1], ROOT)
+
+
+def cpu_baseline(sdc, sdf, lut, K, c2w, gpu_color_fn, min_seconds=10.0, batch=256, max_batches=8, threads=16):
+    """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view.
+    OpenBLAS is limited to `threads` threads: on the 256-thread GPU host the oracle's many small
+    sgemms run 2.6x SLOWER with the default 64 threads than with 16 (measured: 57 vs 150 rays/s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import iblnerf_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from threadpoolctl import threadpool_limits
+    threads = max(1, min(threads, os.cpu_count() or 1))
     ro, rd = O.get_rays(H, W, K, c2w)
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
     pix = np.random.RandomState(0).permutation(H * W)
     n, t, colors, idx = 0, 0.0, [], []
-    for b in range(max_batches):
-        sel = pix[b * batch:(b + 1) * batch]
-        t0 = time.perf_counter()
-        res = O.render_rays(sdc, sdf, ro[sel], rd[sel], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)
-        t += time.perf_counter() - t0
-        n += len(sel)
-        colors.append(res["color_map"])
-        idx.append(sel)
-        if t >= min_seconds:
-            break
+    with threadpool_limits(limits=threads):
+        O.render_rays(sdc, sdf, ro[:32], rd[:32], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)   # BLAS warm-up
+        for b in range(max_batches):
+            sel = pix[b * batch:(b + 1) * batch]
+            t0 = time.perf_counter()
+            res = O.render_rays(sdc, sdf, ro[sel], rd[sel], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)
+            t += time.perf_counter() - t0
+            n += len(sel)
+            colors.append(res["color_map"])
+            idx.append(sel)
+            if t >= min_seconds:
+                break
     idx = np.concatenate(idx)
     ref = np.concatenate(colors).astype(np.float64)
     got = gpu_color_fn(idx).astype(np.float64)
     mse = float(np.mean((got - ref) ** 2))
     psnr = float(10 * np.log10(1.0 / max(mse, 1e-30)))
-    return {"value": n / t, "unit": "rays/s", "cores": int(cores), "kind": "port",
-            "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm)" % n}, psnr
+    return {"value": n / t, "unit": "rays/s", "cores": int(threads), "kind": "port",
+            "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm, %d threads)" % (n, threads)}, psnr
 
 
 def main():
@@ -139,6 +157,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same frame with the coarse pass reduced to the density the fine sampling needs (no coarse
+    # '...0' maps; SURVEY.md §8 d mode ii) — reported as an extra, never as `value`
+    value_min = None
+    if world == 1 and not args.inference_min:
+        r2 = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=False, max_rays_per_launch=args.rays_per_launch)
+        r2.load_weights(0, sdc)
+        r2.load_weights(1, sdf)
+        r2.load_lut(lut)
+        r2.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r2.render_rays(ro, rd, NEAR, FAR)
+        torch.cuda.synchronize()
+        value_min = H * W / (time.perf_counter() - t1)
+        del r2
+
     # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
     r.set_profiling(True)
     step()
@@ -148,6 +182,7 @@ def main():
     achieved = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic()
         line = {
             "metric": "rays/sec (64c+128f samples) at 800x800 Kitchen; PSNR vs ref",
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -159,11 +194,14 @@ def main():
                        "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
                        "parallelism": "ray-tile x%d + RCCL all-gather" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch (reads x2-corrected + writes) from %s; points in + raw outputs out, weights stay in L2" % traffic_src,
                          "kernel": "ibl::mlp_kernel<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; the kernel issues 3 bf16 MFMA products per MAC"},
         }
+        if value_min is not None:
+            line["value_inference_min"] = value_min
         if world == 1 and not args.no_cpu_baseline:
             color = maps["color_map"]
 

@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (profiles/collect.sh) into per-kernel tables: launch count, average
-duration, and per-launch PMC sums for the MLP kernel."""
+duration, per-launch PMC sums, and derived figures for the MLP kernel (clock, MFMA utilisation, HBM
+traffic).  Also writes <out>/pmc.json, which bench.py reads for roofline.traffic.
+
+Counter notes (MI355X_MICROARCH.md): GRBM_GUI_ACTIVE is reported once per XCD (8 rows per dispatch) —
+busy cycles = sum / 8; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (busy cycles * 1024 SIMDs); FETCH_SIZE and
+WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (corrected here).
+"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+N_XCD, N_SIMD = 8, 1024
 
 
 def find(sub, suffix):
@@ -16,28 +24,54 @@ def find(sub, suffix):
 
 
 def short(name):
-    name = name.replace("ibl::(anonymous namespace)::", "").replace("void ", "")
-    return name[:70]
+    return name.replace("ibl::(anonymous namespace)::", "").replace("void ", "")[:70]
 
 
+stats = {}
 st = find("kt", "kernel_stats.csv")
 if st:
     print("== kernel-trace stats (%s)" % st)
-    rows = list(csv.DictReader(open(st)))
-    for r in rows[:14]:
+    for r in list(csv.DictReader(open(st)))[:14]:
+        k = short(r["Name"])
+        stats[k] = dict(calls=int(r["Calls"]), avg_ms=float(r["AverageNs"]) / 1e6, pct=float(r["Percentage"]))
         print("%-72s calls=%6s total_ms=%10.3f avg_ms=%9.4f pct=%6s" % (
-            short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6, r["Percentage"]))
+            k, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6, r["Percentage"]))
+pmc = defaultdict(dict)
 for sub in ("pmc_mfma", "pmc_sq", "pmc_fetch", "pmc_write"):
     f = find(sub, "counter_collection.csv")
     if not f:
         continue
-    agg = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(set)
+    agg, cnt, dur = defaultdict(lambda: defaultdict(float)), defaultdict(set), defaultdict(dict)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
+        dur[k][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     print("== %s (per-launch averages)" % sub)
     for k in agg:
         n = max(len(cnt[k]), 1)
+        for c, v in agg[k].items():
+            pmc[k][c] = v / n
+        pmc[k]["_ms_" + sub] = sum(dur[k].values()) / n
         print("%-72s launches=%4d " % (k, n) + " ".join("%s=%.4g" % (c, v / n) for c, v in sorted(agg[k].items())))
+print("== derived (MLP kernels)")
+derived = {}
+for k, v in pmc.items():
+    if "mlp_kernel" not in k:
+        continue
+    d = {}
+    if "GRBM_GUI_ACTIVE" in v:
+        cyc = v["GRBM_GUI_ACTIVE"] / N_XCD
+        d["busy_cycles"] = cyc
+        d["clock_ghz"] = cyc / (v["_ms_pmc_mfma"] * 1e6)
+        d["mfma_util"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * N_SIMD)
+    if "FETCH_SIZE" in v:
+        d["hbm_read_bytes"] = 2.0 * v["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in v:
+        d["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
+    if k in stats:
+        d["avg_ms"] = stats[k]["avg_ms"]
+        d["calls"] = stats[k]["calls"]
+    derived[k] = d
+    print("%-40s " % k[:40] + " ".join("%s=%.4g" % kv for kv in d.items()))
+json.dump(dict(kernel_stats=stats, pmc=pmc, derived=derived), open(os.path.join(out, "pmc.json"), "w"), indent=1)
