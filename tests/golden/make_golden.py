@@ -270,12 +270,58 @@ def small_vectors(torch, R, Hh):
     print("small_vectors.npz written")
 
 
+def export_fixture(torch, R, M, lut):
+    """render_decomp_path (ibl_nerf_renderer.py:819-910) on a tiny 2-view synthetic 'dataset':
+    records the float maps it returns and every 8-bit image it hands to imageio.imwrite."""
+    tmp = tempfile.mkdtemp()
+    try:
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 32))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    sd_c, sd_f = ck.synthetic_state_dict(seed=8, gain=1.0), ck.synthetic_state_dict(seed=9, gain=1.0)
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    kw.update(near=0.5, far=8.0)
+    kw["brdf_lut"] = lut
+    Hh_, Ww_, focal = 6, 8, 7.5
+    rng = np.random.RandomState(42)
+    poses = []
+    for _ in range(2):
+        Q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        poses.append(np.concatenate([np.concatenate([Q, rng.normal(size=(3, 1)) * 0.3], 1), [[0, 0, 0, 1]]], 0))
+    poses = np.stack(poses).astype(np.float32)
+
+    class FakeDataset:
+        far = 8.0
+
+        def __init__(self):
+            self.poses = torch.from_numpy(poses)
+
+        def get_resized_normal_albedo(self, render_factor, i):
+            return {}
+
+    written = {}
+    R.imageio.imwrite = lambda fn, img: written.__setitem__(os.path.basename(fn), np.array(img))
+    with torch.no_grad():
+        res = R.render_decomp_path(FakeDataset(), (Hh_, Ww_, focal), None, 1024, kw, savedir="/nonexistent",
+                                   render_factor=1, approximate_radiance=True, **EDIT_KEYS_OFF)
+    out = dict(H=np.int64(Hh_), W=np.int64(Ww_), focal=np.float64(focal), poses=poses, far=np.float64(8.0),
+               near=np.float64(0.5), seed_coarse=np.int64(8), seed_fine=np.int64(9), n_importance=np.int64(32))
+    for k, v in res.items():
+        out["res__" + k] = np.asarray(v, dtype=np.float32)
+    for k, v in written.items():
+        out["png__" + k] = v
+    np.savez_compressed(os.path.join(OUT, "export_path.npz"), **out)
+    print("export_path.npz: %d result maps, %d images (%s ...)" % (len(res), len(written), sorted(written)[:3]))
+
+
 def main():
     torch, R, M, Hh = import_reference()
     torch.manual_seed(0)
     lut = load_lut(torch)
     shutil.copyfile(os.path.join(REF, "data", "ibl_brdf_lut.png"), os.path.join(OUT, "ibl_brdf_lut.png"))
     small_vectors(torch, R, Hh)
+    export_fixture(torch, R, M, lut)
     # config 1 (BASELINE.json configs[0]): coarse only
     run_fixture("cfg1_coarse_g10", torch, R, M, lut, n_rays=128, n_importance=0, gain=1.0, seed=0)
     # configs 2/3 kernel mix: 64+128, well-conditioned and wide-range checkpoints
