@@ -27,7 +27,8 @@ class Options(C.Structure):
     _fields_ = [("n_samples", C.c_int32), ("n_importance", C.c_int32), ("epsilon", C.c_float),
                 ("gamma_correct", C.c_int32), ("lut_coefficient_f0", C.c_int32),
                 ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
-                ("max_rays_per_launch", C.c_int32), ("device", C.c_int32)]
+                ("max_rays_per_launch", C.c_int32), ("device", C.c_int32), ("lindisp", C.c_int32),
+                ("use_radiance_linear", C.c_int32)]
 
 
 FP = C.c_void_p  # device float*

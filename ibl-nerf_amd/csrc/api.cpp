@@ -288,6 +288,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = c->opt.epsilon;
     a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
     a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
+    a.radiance_linear = c->opt.use_radiance_linear;
     a.ov = ov; a.state = c->state; a.refl_o = c->refl_o; a.refl_d = c->refl_d; a.R = R; a.S = S;
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
@@ -296,7 +297,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     if (rc) return rc;
     PassBArgs b;
     b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = Sc;
-    b.gamma_correct = c->opt.gamma_correct; b.out = out; b.R = R;
+    b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = R;
     HIP_TRY(c, launch_pass_b(b, s));
     return IBLNERF_OK;
 }
@@ -337,7 +338,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
     c->ev_used = 0;
     c->flop_alg = 0.0;
     const int Sc = c->Sc, Sf = c->Sf;
-    HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->zc, s));
+    HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
     for (long r0 = 0; r0 < n_rays; r0 += c->ws_rays) {
         const long R = (n_rays - r0 < c->ws_rays) ? n_rays - r0 : c->ws_rays;
         const float* ro = d_rays_o + 3 * r0;

@@ -25,7 +25,7 @@ struct Camera { float K[9]; float c2w[12]; };   // 3x3 intrinsics, 3x4 camera-to
 hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s);
 
 // ibl_nerf_renderer.py:670-672: z_k = near (1 - t_k) + far t_k, t = linspace(0,1,S)
-hipError_t launch_coarse_z(float near, float far, int S, float* z, hipStream_t s);
+hipError_t launch_coarse_z(float near, float far, int S, int lindisp, float* z, hipStream_t s);
 
 // Point batches (rays x samples packed contiguously, [V][R][S][3]):
 //   mode 0: origin + dir * z                                  (ibl_nerf_renderer.py:200, :440)
@@ -83,6 +83,7 @@ struct PassAArgs {
     float near, far, eps;
     int lut_coefficient_F0;                     // 0 -> 'F' (shipped), 1 -> 'F0'
     int correct_depth;                          // correct_depth_for_prefiltered_radiance_infer
+    int radiance_linear;                        // use_radiance_linear: radiance_f = ReLU, LDR map x/(1+x) before gamma
     OverrideArgs ov;
     float* state;                               // [R, ST_FLOATS]
     float* refl_o; float* refl_d;               // [R,3] reflected-ray origin / direction
@@ -101,6 +102,7 @@ struct PassBArgs {
     const float* zc;           // [Sc] coarse z (z_vals_constant)
     int Sc;
     int gamma_correct;
+    int radiance_linear;
     PassOutputs out;
     long R;
 };

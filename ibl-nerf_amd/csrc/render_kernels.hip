@@ -32,6 +32,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float srgb(float x, int on) { return on ? powf(x + 1e-12f, (float)(1.0 / 2.2)) : x; }
+// output mapping of radiance-like maps: gamma(ldr(x)); on = bit0 gamma_correct, bit1 use_radiance_linear
+// (tonemap_reinherd x/(x+1), ibl_nerf_renderer.py:30-31, :480-487)
+__device__ __forceinline__ float out_map(float x, int on) { return srgb((on & 2) ? x / (x + 1.0f) : x, on & 1); }
+// radiance_f (:192-197): sigmoid, or ReLU under use_radiance_linear
+__device__ __forceinline__ float radiance_f(float x, int linear) { return linear ? fmaxf(x, 0.0f) : sigmoidf_(x); }
 
 // torch.linspace(start, end, steps)[i] in fp32 (ATen CPU kernel: symmetric fill, one fma each)
 __device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
@@ -108,11 +113,12 @@ __global__ void k_get_rays(int W, int row0, int n_rows, Camera cam, float* __res
     }
 }
 
-__global__ void k_coarse_z(float near, float far, int S, float* __restrict__ z) {
+__global__ void k_coarse_z(float near, float far, int S, int lindisp, float* __restrict__ z) {
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
     if (i >= S) return;
     const float t = linspace_at(0.0f, 1.0f, S, i);
-    z[i] = near * (1.0f - t) + far * t;
+    z[i] = lindisp ? 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t)      // ibl_nerf_renderer.py:674
+                   : near * (1.0f - t) + far * t;                            // :672
 }
 
 __global__ void k_make_points(int mode, const float* __restrict__ origin, const float* __restrict__ dir,
@@ -171,7 +177,7 @@ __device__ __forceinline__ void lut_fetch(const float* __restrict__ lut, float n
 }
 
 __device__ __forceinline__ void store3(float* p, long r, const float (&v)[3], int g) {
-    if (p) { p[3 * r] = srgb(v[0], g); p[3 * r + 1] = srgb(v[1], g); p[3 * r + 2] = srgb(v[2], g); }
+    if (p) { p[3 * r] = out_map(v[0], g); p[3 * r + 1] = out_map(v[1], g); p[3 * r + 2] = out_map(v[2], g); }
 }
 
 // State record handed from pass A to pass B (floats): 0-2 albedo, 3 rough, 4 irr, 5-7 fresnel,
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
             acc += w[i];
             const float* row = a.raw + ((long)r * S + s) * RAW_CH;
 #pragma unroll
-            for (int c = 0; c < 17; ++c) ch[c] += w[i] * sigmoidf_(row[1 + c]);
+            for (int c = 0; c < 17; ++c)   // albedo, roughness: sigmoid; irradiance, radiances: radiance_f (:281-318)
+                ch[c] += w[i] * (c < 4 ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], a.radiance_linear));
         }
     }
     depth = wave_sum(depth);
@@ -327,15 +334,16 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
 #pragma unroll
         for (int c = 0; c < 3; ++c) { a.refl_o[3 * r + c] = xs[c]; a.refl_d[3 * r + c] = rdir[c]; }
         // maps that do not depend on the reflected pass (ibl_nerf_renderer.py:494-525)
+        const int gm = (gamma ? 1 : 0) | (a.radiance_linear ? 2 : 0);
         const float rad[3] = {ch[5], ch[6], ch[7]};
-        store3(out.radiance, r, rad, gamma);
+        store3(out.radiance, r, rad, gm);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float rk[3] = {ch[8 + 3 * k], ch[9 + 3 * k], ch[10 + 3 * k]};
-            store3(out.radiance_k[k], r, rk, gamma);
+            store3(out.radiance_k[k], r, rk, gm);
         }
-        if (out.irradiance) out.irradiance[r] = srgb(irr, gamma);
-        store3(out.albedo, r, albedo, gamma);
+        if (out.irradiance) out.irradiance[r] = out_map(irr, gm);
+        store3(out.albedo, r, albedo, gamma ? 1 : 0);     // albedo_f: gamma only (:488)
         if (out.roughness) out.roughness[r] = rough;
         if (out.n_dot_v) out.n_dot_v[r] = ndv;
         store3(out.normal, r, nrm, 0);
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
         if (s < S) {
             const float* row = a.refl_raw + ((long)r * S + s) * REFL_CH;
 #pragma unroll
-            for (int c = 0; c < 12; ++c) maps[c] += w[i] * sigmoidf_(row[1 + c]);
+            for (int c = 0; c < 12; ++c) maps[c] += w[i] * radiance_f(row[1 + c], a.radiance_linear);
         }
     }
 #pragma unroll
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
         specular[c] = st[8 + c] * pref[c];
         color[c] = diffuse[c] + specular[c];
     }
-    const int g = a.gamma_correct;
+    const int g = (a.gamma_correct ? 1 : 0) | (a.radiance_linear ? 2 : 0);
     const PassOutputs& out = a.out;
     store3(out.color, r, color, g);
     const float m0[3] = {maps[0], maps[1], maps[2]};
@@ -571,8 +579,8 @@ hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float
     return hipGetLastError();
 }
 
-hipError_t launch_coarse_z(float near, float far, int S, float* z, hipStream_t s) {
-    hipLaunchKernelGGL(k_coarse_z, dim3((S + 63) / 64), dim3(64), 0, s, near, far, S, z);
+hipError_t launch_coarse_z(float near, float far, int S, int lindisp, float* z, hipStream_t s) {
+    hipLaunchKernelGGL(k_coarse_z, dim3((S + 63) / 64), dim3(64), 0, s, near, far, S, lindisp, z);
     return hipGetLastError();
 }
 

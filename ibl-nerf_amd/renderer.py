@@ -52,7 +52,7 @@ class Renderer:
 
     def __init__(self, N_samples=64, N_importance=128, *, epsilon=0.01, gamma_correct=True, lut_coefficient="F",
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
-                 max_rays_per_launch=65536, device=None):
+                 max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise B.IblNerfError("no HIP device visible to torch: the render path has no CPU fallback")
@@ -69,6 +69,8 @@ class Renderer:
         o.coarse_outputs = int(bool(coarse_outputs))
         o.max_rays_per_launch = int(max_rays_per_launch)
         o.device = self.device.index
+        o.lindisp = int(bool(lindisp))
+        o.use_radiance_linear = int(bool(use_radiance_linear))
         self.opt = o
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
         self.coarse_outputs = bool(coarse_outputs)
@@ -275,7 +277,7 @@ class Renderer:
 # ---------------------------------------------------------------------------------------------
 # reference-signature functions
 # ---------------------------------------------------------------------------------------------
-_UNSUPPORTED_TRUE = ["lindisp", "use_radiance_linear", "infer_normal", "infer_normal_at_surface", "infer_depth",
+_UNSUPPORTED_TRUE = ["infer_normal", "infer_normal_at_surface", "infer_depth",
                      "depth_map_from_ground_truth", "calculate_albedo_from_gt", "calculate_roughness_from_gt",
                      "calculate_irradiance_from_gt", "use_environment_map", "white_bkgd", "retraw"]
 
@@ -323,14 +325,15 @@ def renderer_for(kw):
     N_imp = int(kw.get("N_importance", 0) or 0)
     key = (int(kw["N_samples"]), N_imp, float(kw.get("epsilon", 0.01)), bool(kw.get("gamma_correct", False)),
            kw.get("lut_coefficient"), bool(kw.get("correct_depth_for_prefiltered_radiance_infer", False)),
-           bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device())
+           bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device(),
+           bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)))
     ent = _renderers.get(key)
     if ent is None:
         if kw.get("lut_coefficient") not in ("F", "F0"):
             raise ValueError(kw.get("lut_coefficient"))                               # ibl_nerf_renderer.py:437-438
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
-                     max_rays_per_launch=key[7])
+                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

@@ -50,6 +50,8 @@ typedef struct {
                                           coarse pass only evaluates density for the fine sampling */
     int32_t max_rays_per_launch;       /* workspace is sized for this many rays (default 65536) */
     int32_t device;                    /* HIP device ordinal */
+    int32_t lindisp;                   /* 0 (shipped) | 1: sample linearly in inverse depth (ibl_nerf_renderer.py:673-674) */
+    int32_t use_radiance_linear;       /* 0 (shipped, sigmoid radiance) | 1: ReLU radiance + Reinhard LDR map (:30-35, :480-483) */
 } iblnerf_options;
 
 void iblnerf_default_options(iblnerf_options* o);

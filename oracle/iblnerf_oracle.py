@@ -228,10 +228,11 @@ def fresnel_schlick_roughness(cos_theta, F0, rough):
     return (F0 + F1 * np.power(np.clip(F32(1) - c, 0, 1), F32(5), dtype=F32)).astype(F32)
 
 
-def composite_reflected(raw, z_vals, dirs):
+def composite_reflected(raw, z_vals, dirs, radiance_f=None):
     """raw2outputs_simple, ibl_nerf_renderer.py:38-68 -> [N,4,3] (radiance, coarse radiance 1..3)."""
+    radiance_f = radiance_f or sigmoid
     w = alpha_weights(raw[..., 0], ray_dists(z_vals, dirs))
-    maps = [np.sum(w[..., None] * sigmoid(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
+    maps = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
     return np.stack(maps, 1).astype(F32)
 
 
@@ -245,9 +246,14 @@ def decode_masks(mask_img, n_obj):
 # --------------------------------------------------------------------------------------------
 # one pass: raw2outputs, ibl_nerf_renderer.py:153-527 (approximate_radiance=True, shipped flags)
 # --------------------------------------------------------------------------------------------
-def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None):
+def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None):
+    """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
+    lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs)."""
     gt = gt or {}
     edit = edit or {}
+    flags = flags or {}
+    linear = bool(flags.get("use_radiance_linear", False))
+    radiance_f = relu if linear else sigmoid
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)       # :200
     raw = network_query(sd, pts, rays_d)                                                    # :201 (rays_d, not viewdirs)
     dists = ray_dists(z_vals, rays_d)
@@ -270,8 +276,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     x_surface = (rays_o + rays_d * depth[:, None]).astype(F32)                              # :262
     albedo = np.sum(w[..., None] * sigmoid(raw[..., 1:4]), -2, dtype=F32)                   # :281-282
     rough = np.sum(w * sigmoid(raw[..., 4]), -1, dtype=F32)                                 # :284-285
-    irr = np.sum(w * sigmoid(raw[..., 5]), -1, dtype=F32)[:, None]                          # :287-288, :328
-    rad = [np.sum(w[..., None] * sigmoid(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
+    irr = np.sum(w * radiance_f(raw[..., 5]), -1, dtype=F32)[:, None]                       # :287-288, :328
+    rad = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
 
     normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01)                    # :358-361
     if stages is not None:
@@ -303,11 +309,14 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     metal = (F32(1) - rough)[:, None]
     F0 = (F32(0.04) * (F32(1) - metal) + albedo * metal).astype(F32)                        # :424-427
     fres = fresnel_schlick_roughness(ndv, F0, rough)
-    spec_coef = (fres * env[:, 0:1] + env[:, 1:2]).astype(F32)                              # :434 ('F')
+    lutc = flags.get("lut_coefficient", "F")
+    if lutc not in ("F", "F0"):
+        raise ValueError(lutc)                                                              # :437-438
+    spec_coef = ((fres if lutc == "F" else F0) * env[:, 0:1] + env[:, 1:2]).astype(F32)     # :433-436
     refl_d = (rays_d - F32(2) * np.sum(normal * rays_d, -1, keepdims=True, dtype=F32) * normal).astype(F32)
     refl_pts = (x_surface[:, None, :] + refl_d[:, None, :] * z_const[:, :, None]).astype(F32)   # :440
     refl_raw = network_query(sd, refl_pts, refl_d)                                          # :445
-    pref_maps = composite_reflected(refl_raw, z_const, refl_d)                              # :446-448
+    pref_maps = composite_reflected(refl_raw, z_const, refl_d, radiance_f)                  # :446-448
     depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
     level = np.clip(rough * depth / depth_0, 0, 1).astype(F32)                              # :458-459
     i1 = np.clip((level * F32(3)).astype(np.int64), 0, 3)                                   # :464-465
@@ -321,7 +330,9 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     if stages is not None:
         stages.update(raw=raw, refl_raw=refl_raw, pref_maps=pref_maps, env=env, refl_d=refl_d,
                       x_surface=x_surface, level=level)
-    g = rgb_to_srgb
+    gam = rgb_to_srgb if flags.get("gamma_correct", True) else (lambda x: x)
+    ldr = (lambda x: (x / (x + F32(1))).astype(F32)) if linear else (lambda x: x)           # tonemap_reinherd :30-31
+    g = lambda x: gam(ldr(x))                                                               # output_f :487
     res = {"color_map": g(color), "radiance_map": g(rad[0])}
     for k in range(3):
         res["radiance_map_%d" % (k + 1)] = g(rad[k + 1])
@@ -329,7 +340,7 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         res["reflected_coarse_radiance_map_%d" % (k + 1)] = g(pref_maps[:, k + 1])
     res.update({
         "irradiance_map": g(irr), "reflected_radiance_map": g(pref_maps[:, 0]),
-        "prefiltered_reflected_map": g(pref), "albedo_map": g(albedo), "roughness_map": rough,
+        "prefiltered_reflected_map": g(pref), "albedo_map": gam(albedo), "roughness_map": rough,
         "specular_map": g(specular), "diffuse_map": g(diffuse), "n_dot_v_map": ndv,
         "target_normal_map": normal, "disp_map": disp, "acc_map": acc, "depth_map": depth,
         "target_depth_map": depth, "weights": w})
@@ -339,27 +350,31 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
 # --------------------------------------------------------------------------------------------
 # render_rays / render_decomp — ibl_nerf_renderer.py:629-732, :759-813 (perturb=0, raw_noise_std=0)
 # --------------------------------------------------------------------------------------------
-def coarse_z(near, far, n_samples, n_rays):
+def coarse_z(near, far, n_samples, n_rays, lindisp=False):
     t = torch_linspace(0, 1, n_samples)
-    z = (F32(near) * (F32(1) - t) + F32(far) * t).astype(F32)                              # :672
+    if lindisp:                                                                            # :674
+        z = (F32(1) / (F32(1) / F32(near) * (F32(1) - t) + F32(1) / F32(far) * t)).astype(F32)
+    else:
+        z = (F32(near) * (F32(1) - t) + F32(far) * t).astype(F32)                          # :672
     return np.broadcast_to(z, (n_rays, n_samples)).copy()
 
 
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64, n_importance=128,
-                gt=None, edit=None, stages=None):
+                gt=None, edit=None, stages=None, flags=None):
     rays_o = np.ascontiguousarray(rays_o, dtype=F32)
     rays_d = np.ascontiguousarray(rays_d, dtype=F32)
     N = rays_o.shape[0]
-    z = coarse_z(near, far, n_samples, N)
+    flags = flags or {}
+    z = coarse_z(near, far, n_samples, N, bool(flags.get("lindisp", False)))
     st_c = {} if stages is not None else None
-    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c)
+    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags)
     if n_importance > 0:
         mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)                             # :701
         zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance)                       # :702-703
         zf = np.sort(np.concatenate([z, zs], -1), -1)                                      # :707
         st_f = {} if stages is not None else None
         fine = raw2outputs(sd_fine if sd_fine is not None else sd_coarse, rays_o, rays_d, zf, z,
-                           near, far, lut, gt, edit, st_f)
+                           near, far, lut, gt, edit, st_f, flags)
         for k, v in res.items():
             fine[k + "0"] = v                                                              # :712-713
         res = fine

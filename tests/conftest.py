@@ -50,4 +50,15 @@ def rel_linf(x, ref):
     return float(np.nanmax(np.abs(x.reshape(ref.shape) - ref)) / max(float(np.nanmax(np.abs(ref))), 1e-30))
 
 
-RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10"]
+RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10"]
+
+
+def golden_flags(g):
+    """Flag variants recorded with a fixture (use_radiance_linear / lindisp / lut_coefficient)."""
+    return {k[6:]: g[k].item() for k in g.files if k.startswith("flag__")}
+
+
+def ill_conditioned(g):
+    """Fixtures whose DERIVED channels are chaotic even between two fp32 implementations: the
+    wide-range checkpoint and HDR radiance (ReLU kinks + gamma of values near 0)."""
+    return float(g["gain"]) > 1.0 or bool(golden_flags(g).get("use_radiance_linear", False))

@@ -161,7 +161,7 @@ class Recorder:
         R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
 
 
-def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6):
+def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None):
     tmp = tempfile.mkdtemp()
     try:
         _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance))
@@ -175,6 +175,7 @@ def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mod
     near, far = 0.5, 8.0
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
+    kw.update(flags or {})            # flag variants outside the shipped configs
 
     rng = np.random.RandomState(1000 + seed)
     o, d, pix, focal = camera_rays(rng, n_rays)
@@ -209,6 +210,8 @@ def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mod
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
                ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
                mode=np.array(mode))
+    for k, v in (flags or {}).items():
+        out["flag__" + k] = np.asarray(v)
     for k, v in gt.items():
         out["gt__" + k] = v
     for k, v in edit.items():
@@ -330,6 +333,9 @@ def main():
     # config 4 / config 5 override paths
     run_fixture("edit_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=2, mode="edit")
     run_fixture("insert_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=3, mode="insert")
+    # f-4 flag variants: HDR radiance (ReLU + Reinhard), inverse-depth sampling, F0 LUT coefficient
+    run_fixture("variant_lin_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=4,
+                flags=dict(use_radiance_linear=True, lindisp=True, lut_coefficient="F0"))
 
 
 if __name__ == "__main__":

@@ -273,7 +273,8 @@ def test_unsupported_flags_raise():
     from ibl_nerf_amd import renderer as R
     base = dict(approximate_radiance=True)
     R._check_supported(base)
-    for k in ("lindisp", "use_radiance_linear", "infer_normal", "calculate_albedo_from_gt"):
+    R._check_supported(dict(base, lindisp=True, use_radiance_linear=True))     # built flag variants
+    for k in ("infer_normal", "infer_depth", "calculate_albedo_from_gt", "depth_map_from_ground_truth"):
         with pytest.raises(NotImplementedError):
             R._check_supported(dict(base, **{k: True}))
     with pytest.raises(ValueError):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, load_golden, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, rel_linf
 
 # Channels that are smooth functions of the MLP outputs: the oracle must sit at fp32 round-off.
 DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
@@ -65,11 +65,12 @@ def test_network_query_stagewise(name):
 def test_render_rays_end_to_end(name, lut):
     g, sdc, sdf, gt, edit = load_golden(name)
     st = {}
+    flags = golden_flags(g)
     res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut,
-                        64, int(g["n_importance"]), gt, edit, st)
+                        64, int(g["n_importance"]), gt, edit, st, flags)
     ref_keys = sorted(k[5:] for k in g.files if k.startswith("out__"))
     assert sorted(res.keys()) == ref_keys                       # 22 maps (+22 '0' maps + z_std)
-    wide = float(g["gain"]) > 1.0
+    wide = ill_conditioned(g)
     for sfx in ([""] + (["0"] if int(g["n_importance"]) > 0 else [])):
         # fine pass: z' moves by ~1e-5 when a cdf entry moves by one ulp (see test_sample_pdf), and one
         # weight is alpha(sigma * dz): per-sample weights inherit that, their sums much less.
@@ -80,7 +81,7 @@ def test_render_rays_end_to_end(name, lut):
         for k in DERIVED:
             # gain 1.6 is the ill-conditioned stress fixture: even fp64-vs-fp32 of the reference
             # disagrees at 1e-3..1e-1 there, so only a loose bound applies.
-            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= (5e-3 if wide else 6e-4), k + sfx
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= (5e-2 if wide else 6e-4), k + sfx
     if int(g["n_importance"]) > 0:
         assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
         assert np.abs(st["z_samples"] - g["pdf_samples"]).max() <= 2e-5
@@ -88,12 +89,13 @@ def test_render_rays_end_to_end(name, lut):
         assert np.abs(O.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128) - g["pdf_samples"]).max() <= 2e-5  # 1 ulp of cdf / pdf(~2e-3) * bin width
     for p in (["c", "f"] if int(g["n_importance"]) > 0 else ["c"]):
         assert rel_linf(st[p]["normal_raw"], g["normal_raw_%s" % p]) <= (5e-3 if wide else 6e-4)
+        lin = bool(flags.get("use_radiance_linear", False))
         # teacher-forced LUT fetch and reflected-ray composite on the reference's own inputs
         uv = g["lut_uv_%s" % p]
         env = O.lut_fetch(lut, (uv[:, 0] + 1) / 2, (uv[:, 1] + 1) / 2)
         assert np.abs(env - g["lut_val_%s" % p]).max() <= 2e-6
-        zc = O.coarse_z(float(g["near"]), float(g["far"]), 64, g["q_%s_refl_raw" % p].shape[0])
-        pm = O.composite_reflected(g["q_%s_refl_raw" % p], zc, g["q_%s_refl_dirs" % p])
+        zc = O.coarse_z(float(g["near"]), float(g["far"]), 64, g["q_%s_refl_raw" % p].shape[0], bool(flags.get("lindisp", False)))
+        pm = O.composite_reflected(g["q_%s_refl_raw" % p], zc, g["q_%s_refl_dirs" % p], O.relu if lin else None)
         assert np.abs(pm - g["prefiltered_env_%s" % p][:pm.shape[0]]).max() <= 2e-6
 
 
