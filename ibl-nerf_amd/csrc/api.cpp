@@ -339,8 +339,11 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
     c->flop_alg = 0.0;
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
-    for (long r0 = 0; r0 < n_rays; r0 += c->ws_rays) {
-        const long R = (n_rays - r0 < c->ws_rays) ? n_rays - r0 : c->ws_rays;
+    // equal-sized launches (a short tail launch would leave most of the persistent grid idle)
+    const long n_launch = (n_rays + c->ws_rays - 1) / c->ws_rays;
+    const long per_launch = n_launch ? (n_rays + n_launch - 1) / n_launch : 0;
+    for (long r0 = 0; r0 < n_rays; r0 += per_launch) {
+        const long R = (n_rays - r0 < per_launch) ? n_rays - r0 : per_launch;
         const float* ro = d_rays_o + 3 * r0;
         const float* rd = d_rays_d + 3 * r0;
         OverrideArgs o = ov;

@@ -163,6 +163,16 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 // without the pins whole epilogues are deferred out of the MFMA shadow they were placed in.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 
+// Accumulator of one tile.  IBL_DUAL_ACC (experiment): two independent MFMA chains (main = Wh*Xh +
+// Wl*Xh, cross = Wh*Xl) summed in the epilogue; a pure-MFMA micro-benchmark sustains 14 % more with two
+// chains than with one dependent chain under the power cap (scratch/mfma_peak.hip).
+struct Acc {
+    f32x16 main;
+#ifdef IBL_DUAL_ACC
+    f32x16 cross;
+#endif
+};
+
 // Epilogue of one finished 32-feature tile, cut into 8 slices of two accumulator registers so the
 // GEMM loop of the NEXT tile can interleave one slice per k-step between its MFMAs:
 //   STORE: v = [ReLU](acc) -> (hi, lo) bf16 B fragments of k-steps 2T, 2T+1 of `dst`
@@ -177,8 +187,13 @@ struct Epi {
     u32x4 h, l;
 
     template <int T, int I>
-    __device__ __forceinline__ void slice(const f32x16& acc) {
+    __device__ __forceinline__ void slice(const Acc& a) {
+#ifdef IBL_DUAL_ACC
+        float x0 = a.main[2 * I] + a.cross[2 * I], x1 = a.main[2 * I + 1] + a.cross[2 * I + 1];
+#else
+        const f32x16& acc = a.main;
         float x0 = acc[2 * I], x1 = acc[2 * I + 1];
+#endif
         if constexpr (RELU) {
             x0 = relu_bits(x0);
             x1 = relu_bits(x1);
@@ -216,17 +231,28 @@ struct Epi {
 // The last tile's accumulator is returned for the next layer's `pend`.
 constexpr int DMA_K0 = 2;   // chunk-relative k-step after which the first DMA piece of the chunk two ahead is issued
 template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI>
-__device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
-                                            PEND&& pend, EPI& epi) {
+__device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
+                                         PEND&& pend, EPI& epi) {
     constexpr int N = NKE + NKH;                       // k-steps per tile
-    f32x16 prev = f32x16{0};
+    Acc prev;
+    prev.main = f32x16{0};
+#ifdef IBL_DUAL_ACC
+    prev.cross = f32x16{0};
+#endif
     const char* frag = P.frag();
     bf16x8 ah = *reinterpret_cast<const bf16x8*>(frag);
     bf16x8 al = *reinterpret_cast<const bf16x8*>(frag + 1024);
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
         // the accumulator starts at the layer bias (lane layout [tile][h][16]): no add in the epilogue
-        f32x16 acc = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+        Acc acc;
+        acc.main = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+#ifdef IBL_DUAL_ACC
+        acc.cross = f32x16{0};
+#define ACC_X acc.cross
+#else
+#define ACC_X acc.main
+#endif
         static_for<0, N>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int ks = t * N + j;              // k-step index inside the layer
@@ -246,13 +272,13 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
             // later), exposing the full LDS latency to a wave that has nothing else to run
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j < NKE) {
-                acc = MFMA(ah, enc.hi[j], acc);
-                acc = MFMA(ah, enc.lo[j], acc);
-                acc = MFMA(al, enc.hi[j], acc);
+                acc.main = MFMA(ah, enc.hi[j], acc.main);
+                ACC_X = MFMA(ah, enc.lo[j], ACC_X);
+                acc.main = MFMA(al, enc.hi[j], acc.main);
             } else {
-                acc = MFMA(ah, in.hi[j - NKE], acc);
-                acc = MFMA(ah, in.lo[j - NKE], acc);
-                acc = MFMA(al, in.hi[j - NKE], acc);
+                acc.main = MFMA(ah, in.hi[j - NKE], acc.main);
+                ACC_X = MFMA(ah, in.lo[j - NKE], ACC_X);
+                acc.main = MFMA(al, in.hi[j - NKE], acc.main);
             }
             // one LDS-DMA piece of the chunk two ahead per k-step, behind this k-step's MFMAs
             if constexpr (ks % CHUNK_KSTEPS >= DMA_K0 && ks % CHUNK_KSTEPS < DMA_K0 + 8)
@@ -282,7 +308,11 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, const Act& in, con
         // Pin the finished accumulator here: its only consumer is the deferred epilogue, and without
         // this the optimiser sinks the whole MFMA chain across the chunk barrier to that use.
         // "a": keep it in the accumulator file.
-        asm volatile("" : "+a"(acc));
+#ifdef IBL_DUAL_ACC
+        asm volatile("" : "+a"(acc.main), "+a"(acc.cross));
+#else
+        asm volatile("" : "+a"(acc.main));
+#endif
         prev = acc;
     });
     P.end();
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
         // whole epilogue of a layer's last tile, run before anything else may read its results
-        auto flush = [&](auto& e, auto T, const f32x16& acc) {
+        auto flush = [&](auto& e, auto T, const Acc& acc) {
             static_for<0, 8>([&](auto I) { e.template slice<decltype(T)::value, decltype(I)::value>(acc); });
         };
         using T7 = std::integral_constant<int, 7>;
@@ -387,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         Epi<true, true, 0> eA{&A, {nullptr}, {nullptr}}, eB{&B, {nullptr}, {nullptr}};
 
         // ---- positions_linears.0 : 63 -> 256, ReLU  (-> A) -------------------------------------
-        f32x16 pacc = run_layer<8, PE_KSTEPS, 0>(P, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
+        Acc pacc = run_layer<8, PE_KSTEPS, 0>(P, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
         // ---- positions_linears.1..4 : 256 -> 256, ReLU, two layers per trip (A -> B -> A) -------
 #ifdef IBL_ABLATE_LOOPONLY    // timing ablation: 58 layers through the SAME 2-layer loop body (I-cache resident)
         for (int l = 1; l <= 57; l += 2) {
@@ -435,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                                      {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}};
             Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}};
             if constexpr (VARIANT == VAR_FULL) {
-                f32x16 qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32,
+                Acc qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32,
                                                   [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eAlb);
                 pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_IRR * 32,
                                            [&](auto I) { eAlb.template slice<3, decltype(I)::value>(qacc); }, eIrr);

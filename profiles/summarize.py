@@ -74,4 +74,12 @@ for k, v in pmc.items():
         d["calls"] = stats[k]["calls"]
     derived[k] = d
     print("%-40s " % k[:40] + " ".join("%s=%.4g" % kv for kv in d.items()))
+print("== derived (per-ray kernels: achieved HBM GB/s = (2 x FETCH_SIZE + WRITE_SIZE) KiB / launch time)")
+for k, v in pmc.items():
+    if "mlp_kernel" in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k not in stats:
+        continue
+    byts = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    gbs = byts / (stats[k]["avg_ms"] * 1e-3) / 1e9
+    derived[k] = dict(hbm_bytes=byts, avg_ms=stats[k]["avg_ms"], hbm_gb_s=gbs, calls=stats[k]["calls"])
+    print("%-40s bytes/launch=%.3g avg_ms=%.4f -> %.0f GB/s" % (k[:40], byts, stats[k]["avg_ms"], gbs))
 json.dump(dict(kernel_stats=stats, pmc=pmc, derived=derived), open(os.path.join(out, "pmc.json"), "w"), indent=1)
