@@ -225,3 +225,40 @@ def test_tile_sharding_matches_full_frame(R, lut):
     ora = O.render_decomp(H, W, K, sdc, sdf, lut, 0.5, 8.0, c2w=c2w)
     assert rel_linf(full["albedo_map"].cpu().numpy(), ora["albedo_map"]) <= 2e-4
     assert rel_linf(full["target_normal_map"].cpu().numpy(), ora["target_normal_map"]) <= 1e-3
+
+
+def test_full_frame_800x800_properties(R, lut):
+    """BASELINE configs[1] at full size (640 000 rays, 64+128): size-independent properties of the
+    whole frame, a seeded sample of pixels against the oracle, and row-tile == whole-frame equality."""
+    from ibl_nerf_amd import checkpoint as ck
+    sdc, sdf = ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
+    r = R.Renderer(64, 128)
+    r.load_weights(0, sdc)
+    r.load_weights(1, sdf)
+    r.load_lut(lut)
+    H = W = 800
+    f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[f, 0, 400], [0, f, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    ro, rd = r.get_rays(H, W, K, c2w)
+    m = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in m.values())
+    n = m["target_normal_map"]
+    assert float((n.norm(dim=-1) - 1).abs().max()) <= 1e-5
+    assert float((m["weights"].sum(-1) - m["acc_map"]).abs().max()) <= 5e-6
+    assert float(m["weights"].min()) >= 0 and float(m["n_dot_v_map"].min()) >= 0 and float(m["n_dot_v_map"].max()) <= 1
+    assert float(m["roughness_map"].min()) > 0 and float(m["roughness_map"].max()) < 1
+    assert float(m["z_std"].min()) > 0
+    # a row tile rendered on its own is bit-identical to the same rows of the frame (multi-GPU partition)
+    rows = slice(300 * W, 310 * W)
+    t = r.render_rays(ro.reshape(-1, 3)[rows], rd.reshape(-1, 3)[rows], 0.5, 8.0)
+    for k in ("color_map", "depth_map", "target_normal_map", "weights", "albedo_map0"):
+        assert torch.equal(t[k], m[k][rows]), k
+    # seeded pixel sample against the oracle
+    pix = np.random.RandomState(3).permutation(H * W)[:96]
+    ref = O.render_rays(sdc, sdf, ro.reshape(-1, 3)[pix].cpu().numpy(), rd.reshape(-1, 3)[pix].cpu().numpy(), 0.5, 8.0, lut)
+    idx = torch.as_tensor(pix, device=n.device)
+    for k, tol in (("albedo_map", 2e-4), ("roughness_map", 2e-4), ("irradiance_map", 2e-4), ("depth_map", 2e-4),
+                   ("radiance_map", 2e-4), ("target_normal_map", 1e-3), ("prefiltered_reflected_map", 1e-3), ("color_map", 1e-3)):
+        assert rel_linf(m[k][idx].cpu().numpy(), ref[k]) <= tol, (k, rel_linf(m[k][idx].cpu().numpy(), ref[k]))
