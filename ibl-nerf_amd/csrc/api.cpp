@@ -103,6 +103,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         g_create_error = "unsupported sample counts: need 3 <= N_samples, N_samples + N_importance <= 256";
         return IBLNERF_ERR_INVALID;
     }
+    if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
+        g_create_error = "max_rays_per_launch too large: 4 * rays * samples must stay below 2^31 points per MLP launch";
+        return IBLNERF_ERR_INVALID;
+    }
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0 || opts->device >= n_dev) {
@@ -227,8 +231,9 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
 int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
                           const float* d_viewdirs, float* d_out) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (which < 0 || which > 1 || !d_pts || !d_out || n_rays < 0 || n_samples < 1)
+    if (which < 0 || which > 1 || n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_pts || !d_out)))
         return c->fail(IBLNERF_ERR_INVALID, "network_query: bad arguments");
+    if (n_rays == 0) return IBLNERF_OK;
     if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "network_query: weights of network %d not uploaded", which);
     return run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
                    (long)n_rays * n_samples, d_out);
@@ -237,8 +242,9 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
                        int n_bins, int n_out, float* d_samples) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (!d_bins || !d_weights || !d_samples || n_rays < 0 || n_bins < 2 || n_bins > 257 || n_out < 1)
+    if (n_rays < 0 || n_bins < 2 || n_bins > 257 || n_out < 1 || (n_rays > 0 && (!d_bins || !d_weights || !d_samples)))
         return c->fail(IBLNERF_ERR_INVALID, "sample_pdf: need 2 <= n_bins <= 257, n_out >= 1");
+    if (n_rays == 0) return IBLNERF_OK;
     HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_samples,
                                  (hipStream_t)stream));
     return IBLNERF_OK;
@@ -305,7 +311,9 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
 int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                         float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_outputs* outs) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (!d_rays_o || !d_rays_d || !outs || n_rays < 0) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays/outputs");
+    if (n_rays < 0 || !outs) return c->fail(IBLNERF_ERR_INVALID, "render_rays: negative ray count / null outputs");
+    if (n_rays == 0) return IBLNERF_OK;   // empty batch: torch hands out null data pointers for zero-row tensors
+    if (!d_rays_o || !d_rays_d) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays");
     const bool fine = c->opt.n_importance > 0;
     if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
     if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");

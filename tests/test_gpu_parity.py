@@ -158,6 +158,10 @@ def test_render_invariances_and_edge_sizes(R, lut):
     one = to_np(big.render_rays(ro[:1], rd[:1], 0.5, 8.0))
     for k in a:
         assert np.array_equal(one[k], a[k][:1]), k
+    none = big.render_rays(ro[:0], rd[:0], 0.5, 8.0)            # empty batch: same keys, zero rows
+    assert sorted(none.keys()) == sorted(a.keys()) and none["weights"].shape == (0, 192)
+    assert big.network_query(torch.zeros(0, 64, 3), torch.zeros(0, 3)).shape == (0, 64, 18)
+    assert big.sample_pdf(torch.zeros(0, 9), torch.zeros(0, 8), 16).shape == (0, 16)
     lean = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, coarse_outputs=False)
     c = to_np(lean.render_rays(ro, rd, 0.5, 8.0))
     assert not any(k.endswith("0") for k in c) and "z_std" in c
@@ -262,3 +266,41 @@ def test_full_frame_800x800_properties(R, lut):
     for k, tol in (("albedo_map", 2e-4), ("roughness_map", 2e-4), ("irradiance_map", 2e-4), ("depth_map", 2e-4),
                    ("radiance_map", 2e-4), ("target_normal_map", 1e-3), ("prefiltered_reflected_map", 1e-3), ("color_map", 1e-3)):
         assert rel_linf(m[k][idx].cpu().numpy(), ref[k]) <= tol, (k, rel_linf(m[k][idx].cpu().numpy(), ref[k]))
+
+
+def test_torch_module_weights_are_tracked(R, lut):
+    """render_decomp accepts a torch nn.Module with the reference's parameter names (what test.py /
+    train.py pass as network_fn) and re-uploads when a parameter changes in place (optimizer step)."""
+    from ibl_nerf_amd import checkpoint as ck
+    import torch.nn as nn
+
+    class RefShaped(nn.Module):          # same registration order / names as ibl_nerf.py:45-72
+        def __init__(self, sd):
+            super().__init__()
+            lin = lambda n: nn.Linear(sd[n + ".weight"].shape[1], sd[n + ".weight"].shape[0])
+            self.positions_linears = nn.ModuleList([lin("positions_linears.%d" % i) for i in range(8)])
+            self.views_linears = nn.ModuleList([lin("views_linears.0")])
+            for n in ("feature_linear", "sigma_linear", "albedo_feature_linear", "albedo_linear", "roughness_linear",
+                      "irradiance_feature_linear", "irradiance_linear", "radiance_linear"):
+                setattr(self, n, lin(n))
+            self.additional_radiance_feature_linear = nn.ModuleList([lin("additional_radiance_feature_linear.%d" % i) for i in range(3)])
+            self.additional_radiance_linear = nn.ModuleList([lin("additional_radiance_linear.%d" % i) for i in range(3)])
+            self.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+
+    g, sdc, sdf, _, _ = load_golden("plain_g10")
+    net_c, net_f = RefShaped(sdc), RefShaped(sdf)
+    assert list(net_c.state_dict().keys()) == [n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias")]
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, perturb=False, raw_noise_std=0,
+              lindisp=False, gamma_correct=True, lut_coefficient="F", epsilon=0.01,
+              target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_epsilon",
+              correct_depth_for_prefiltered_radiance_infer=True, near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut),
+              max_rays_per_launch=64)
+    K = np.eye(3, dtype=np.float32)
+    rays = torch.from_numpy(np.stack([g["rays_o"][:8], g["rays_d"][:8]], 0))
+    a = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    assert rel_linf(a["albedo_map"].cpu().numpy(), g["out__albedo_map"][:8]) <= 2e-4
+    with torch.no_grad():
+        net_f.albedo_linear.bias.add_(0.5)          # in-place update, as an optimizer step does
+    b = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    assert float((b["albedo_map"] - a["albedo_map"]).abs().min()) > 1e-2     # the new weights were uploaded
+    assert torch.equal(b["albedo_map0"], a["albedo_map0"])                   # the coarse network did not change

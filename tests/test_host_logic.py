@@ -68,6 +68,10 @@ def test_options_validation(lib):
     o.n_samples, o.n_importance = 200, 128
     ctx = C.c_void_p()
     assert lib.iblnerf_create(C.byref(o), C.byref(ctx)) == -1
+    o = B.default_options()
+    o.max_rays_per_launch = 3_000_000                      # 4 * 3e6 * 192 points would overflow the 2^31 launch limit
+    assert lib.iblnerf_create(C.byref(o), C.byref(ctx)) == -1
+    assert b"2^31" in lib.iblnerf_last_error(None)
 
 
 # --------------------------------------------------------------------------------------------
