@@ -15,6 +15,7 @@ DEFAULTS = dict(
     expname=None, basedir="./logs/", export_basedir=None, datadir="./data/llff/fern", dataset_type="mitsuba",
     netdepth=8, netwidth=256, multires=10, multires_views=4, i_embed=0, N_samples=64, N_importance=0,
     chunk=1024 * 16, netchunk=1024 * 64, perturb=1.0, raw_noise_std=0.0, render_factor=1, testskip=8,
+    image_scale=1.0, near_plane=1.0, far_plane=20.0,
     coarse_radiance_number=0, target_load_N_iter=-1, ft_path=None, lut_coefficient="F",
     calculating_normal_type="ground_truth", epsilon_for_numerical_normal=0.01,
     epsilon_direction_for_numerical_normal=0.005,

@@ -1,0 +1,204 @@
+"""Reader for the reference's on-disk Mitsuba scene layout: the test-time subset
+of `MitsubaDataset` / `NerfDataset` (src/dataset/dataset_mitsuba.py:8-137,
+src/dataset/dataset_interface.py:12-300) that `test.py:36-73` and `render_decomp_path`
+(ibl_nerf_renderer.py:819-868) touch:
+
+    <basedir>/transforms_<split>.json      frames[i] = {fov_degree, transform 4x4 (Mitsuba: +Z forward)}
+    <basedir>/min_max_depth.json           {min_depth, max_depth}  (load_depth_range_from_file)
+    <basedir>/train/1.png                  read once for the image size
+    <basedir>/<split>/<n>.png              n = skip*i + 1   (or n = editing_idx)
+    <basedir>/<split>/<n>_edit_intrinsic_mask.png, _edit_albedo.png, _edit_normal.png,
+                      _edit_roughness.png, _edit_irradiance.png, _edit_depth.npy
+    <basedir>/<split>/<n>_insert_mask.png, _insert_depth.npy, _insert_normal.png
+    <basedir>/<split>/<n>_{normal,albedo,roughness,irradiance,diffuse,specular}.png, <n>_depth.npy
+
+Images are decoded with PIL as 8-bit RGB / 255 (the reference's cv2.imread + BGR->RGB yields the same
+array for 8-bit PNGs; alpha is dropped by both).  `image_scale != 1` (cv2.resize) and the prior
+images used only by the training losses are not built: they raise.  Nothing here touches the GPU
+until `to_tensor`."""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+
+def load_image_from_path(path, scale=1):
+    """utils/image_utils.py:41-49."""
+    if scale != 1:
+        raise NotImplementedError("image_scale != 1 needs cv2.resize semantics, which are not built (shipped Mitsuba configs use 1)")
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / np.float32(255.0)
+
+
+def load_numpy_from_path(path, scale=1):
+    """utils/image_utils.py:61-67."""
+    if scale != 1:
+        raise NotImplementedError("image_scale != 1 is not built")
+    return np.load(path).astype(np.float32)
+
+
+# sample key -> (file suffix, loader kind, flag attribute, keep only channel 0)
+_PER_VIEW = [
+    ("image", "%d.png", "img", "load_image", False),
+    ("normal", "%d_normal.png", "img", "load_normal", False),
+    ("albedo", "%d_albedo.png", "img", "load_albedo", False),
+    ("roughness", "%d_roughness.png", "img", "load_roughness", True),
+    ("depth", "%d_depth.npy", "npy", "load_depth", False),
+    ("irradiance", "%d_irradiance.png", "img", "load_irradiance", False),
+    ("diffuse", "%d_diffuse.png", "img", "load_diffuse_specular", False),
+    ("specular", "%d_specular.png", "img", "load_diffuse_specular", False),
+]
+_EDIT = [
+    ("edit_albedo", "%d_edit_albedo.png", "img", "load_edit_albedo", False),
+    ("edit_normal", "%d_edit_normal.png", "img", "load_edit_normal", False),
+    ("edit_roughness", "%d_edit_roughness.png", "img", "load_edit_roughness", True),
+    ("edit_irradiance", "%d_edit_irradiance.png", "img", "load_edit_irradiance", False),
+    ("edit_depth", "%d_edit_depth.npy", "npy", "load_edit_depth", False),
+]
+# keys get_resized_normal_albedo hands to render_decomp as gt_values (dataset_interface.py:99-160)
+_GT_KEYS = [("albedo", "load_albedo"), ("normal", "load_normal"), ("irradiance", "load_irradiance"),
+            ("roughness", "load_roughness"), ("depth", "load_depth"),
+            ("edit_intrinsic_mask", "load_edit_intrinsic_mask"), ("edit_albedo", "load_edit_albedo"),
+            ("edit_normal", "load_edit_normal"), ("edit_depth", "load_edit_depth"),
+            ("edit_roughness", "load_edit_roughness"), ("edit_irradiance", "load_edit_irradiance"),
+            ("object_insert_mask", "object_insert"), ("object_insert_depth", "object_insert"),
+            ("object_insert_normal", "object_insert")]
+
+
+class MitsubaDataset:
+    def __init__(self, basedir, **kwargs):
+        g = kwargs.get
+        self.name = "mitsuba"
+        self.basedir = basedir
+        self.scene_name = basedir.split("/")[-1]
+        self.scale = g("image_scale", 1)
+        self.split = g("split", "train")
+        self.coarse_radiance_number = g("coarse_radiance_number")
+        self.near, self.far = g("near_plane", 1), g("far_plane", 10)           # dataset_interface.py:64-65
+        self.editing_idx = g("editing_idx", None)
+        self.load_image = g("load_image", True)
+        for f in ("load_normal", "load_albedo", "load_roughness", "load_depth", "load_diffuse_specular", "load_irradiance",
+                  "load_priors", "load_edit_intrinsic_mask", "load_edit_albedo", "load_edit_normal", "load_edit_roughness",
+                  "load_edit_irradiance", "load_edit_depth", "object_insert"):
+            setattr(self, f, bool(g(f, False)))
+        if self.load_priors:
+            raise NotImplementedError("prior albedo/irradiance images feed the training losses only (SURVEY.md §8 f-3)")
+        if g("load_depth_range_from_file", False):                                # dataset_mitsuba.py:12-16
+            with open(os.path.join(basedir, "min_max_depth.json")) as fp:
+                f = json.load(fp)
+            self.near, self.far = f["min_depth"] * 0.9, f["max_depth"] * 1.1
+        with open(os.path.join(basedir, "transforms_{}.json".format(self.split))) as fp:
+            self.meta = json.load(fp)
+        self.skip = 1 if self.split == "train" else g("skip", 1)
+        self.camera_angle_x = float(self.meta["frames"][0]["fov_degree"]) / 180.0 * math.pi
+        from PIL import Image
+        with Image.open(os.path.join(basedir, "train/1.png")) as im:
+            self.original_width, self.original_height = im.size
+        self.height = int(self.original_height * self.scale)
+        self.width = int(self.original_width * self.scale)
+        self.focal = .5 * self.width / np.tan(0.5 * self.camera_angle_x)
+        self.full_data_loaded = False
+        self._lists = {}
+        self.poses = []
+
+    def __len__(self):
+        return len(self.meta["frames"][::self.skip]) if self.editing_idx is None else 1
+
+    def __getitem__(self, index):
+        if not 0 <= index < len(self):
+            raise IndexError(index)
+        n = (self.skip * index + 1) if self.editing_idx is None else self.editing_idx
+        frame = self.meta["frames"][self.editing_idx - 1] if self.editing_idx is not None else self.meta["frames"][::self.skip][index]
+        d = os.path.join(self.basedir, self.split)
+        sample = {}
+
+        def read(table):
+            for key, pat, kind, flag, ch0 in table:
+                if getattr(self, flag):
+                    p = os.path.join(d, pat % n)
+                    if kind == "img":
+                        a = load_image_from_path(p, self.scale)
+                        sample[key] = a[..., 0:1] if ch0 else a
+                    else:
+                        sample[key] = load_numpy_from_path(p, self.scale)[..., None]
+
+        read(_PER_VIEW)
+        if self.load_edit_intrinsic_mask:                                          # dataset_mitsuba.py:105-117
+            sample["edit_intrinsic_mask"] = load_image_from_path(os.path.join(d, "%d_edit_intrinsic_mask.png" % n), self.scale)
+            read(_EDIT)
+        if self.object_insert:                                                     # :119-122
+            sample["object_insert_mask"] = load_image_from_path(os.path.join(d, "%d_insert_mask.png" % n), self.scale)
+            sample["object_insert_normal"] = load_image_from_path(os.path.join(d, "%d_insert_normal.png" % n), self.scale)
+            sample["object_insert_depth"] = load_numpy_from_path(os.path.join(d, "%d_insert_depth.npy" % n), self.scale)[..., None]
+        pose = np.array(frame["transform"]).astype(np.float32)
+        pose[:3, 0] *= -1                                                          # Mitsuba: camera forward is +Z (:128-130)
+        pose[:3, 2] *= -1
+        sample["pose"] = pose
+        return sample
+
+    def load_all_data(self, num_of_workers=1, editing_idx=None):
+        """dataset_interface.py:206-254 (sequential: the reference's DataLoader only parallelises I/O)."""
+        if self.full_data_loaded:
+            return
+        for i in range(len(self)):
+            for k, v in self[i].items():
+                if k == "pose":
+                    self.poses.append(v)
+                else:
+                    self._lists.setdefault(k, []).append(v)
+        self.full_data_loaded = True
+
+    def to_tensor(self, device):
+        """Stack per-view arrays into [n_views, H, W, C] tensors on `device` (dataset_interface.py:256-300)."""
+        import torch
+        put = lambda lst: torch.from_numpy(np.stack(lst, 0)).to(device)
+        if self.poses is not None and len(self.poses) > 0:
+            self.poses = put(self.poses)
+        self._lists = {k: put(v) for k, v in self._lists.items()}
+
+    @property
+    def images(self):
+        return self._lists.get("image", [])
+
+    def get_focal_matrix(self):
+        return np.array([[self.focal, 0, 0.5 * self.width], [0, self.focal, 0.5 * self.height], [0, 0, 1]]).astype(np.float32)
+
+    def get_near_far_plane(self):
+        return {"near": self.near, "far": self.far}
+
+    def get_resized_normal_albedo(self, resize_factor, i):
+        """gt_values of view i (dataset_interface.py:99-160).  At resize_factor 1 (every shipped config;
+        render_decomp_path also passes 0 when called without one) torchvision's Resize to the image's
+        own size returns its input, so the maps go through unchanged; other factors use the same
+        antialiased bilinear filter (`torch.nn.functional.interpolate(..., antialias=True)`)."""
+        out = {}
+        for key, flag in _GT_KEYS:
+            if not getattr(self, flag) or key not in self._lists:
+                continue
+            x = self._lists[key][i]
+            if resize_factor not in (0, 1):
+                import torch
+                t = torch.as_tensor(x).permute(2, 0, 1)[None]
+                t = torch.nn.functional.interpolate(t, size=(self.height // resize_factor, self.width // resize_factor),
+                                                    mode="bilinear", antialias=True, align_corners=False)
+                x = t[0].permute(1, 2, 0)
+            out[key] = x
+        return out
+
+    def __str__(self):
+        return "\n".join(["[Dataset]", "\t- type : %s" % self.name, "\t- split : %s" % self.split,
+                          "\t- scale : %s" % str(self.scale),
+                          "\t- size (raw) : %d x %d" % (self.original_width, self.original_height),
+                          "\t- size : %d x %d" % (self.width, self.height), "\t- image number : %d" % len(self)])
+
+
+def load_dataset(dataset_type, basedir, **kwargs):
+    """dataset_interface.py:316-331."""
+    if dataset_type == "mitsuba":
+        return MitsubaDataset(basedir, **kwargs)
+    if dataset_type in ("mitsuba_eval", "colmap"):
+        raise NotImplementedError("dataset type %r is not built (SURVEY.md §8: Mitsuba scenes are the shipped path)" % dataset_type)
+    raise ValueError("Unknown dataset type: %s" % dataset_type)
