@@ -191,8 +191,11 @@ int iblnerf_upload_lut(iblnerf_ctx* c, const float* h_rgb) {
 int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_K, const float* h_c2w, int row0,
                      int n_rows, float* d_rays_o, float* d_rays_d) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (!h_K || !h_c2w || !d_rays_o || !d_rays_d || H <= 0 || W <= 0 || row0 < 0 || n_rows < 0 || row0 + n_rows > H)
+    if (!h_K || !h_c2w || H <= 0 || W <= 0 || row0 < 0 || n_rows < 0 || row0 + n_rows > H ||
+        (n_rows > 0 && (!d_rays_o || !d_rays_d)))
         return c->fail(IBLNERF_ERR_INVALID, "get_rays: bad arguments (H=%d W=%d row0=%d n_rows=%d)", H, W, row0, n_rows);
+    if (n_rows == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
     Camera cam;
     std::memcpy(cam.K, h_K, sizeof cam.K);
     std::memcpy(cam.c2w, h_c2w, sizeof cam.c2w);
@@ -235,6 +238,7 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
         return c->fail(IBLNERF_ERR_INVALID, "network_query: bad arguments");
     if (n_rays == 0) return IBLNERF_OK;
     if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "network_query: weights of network %d not uploaded", which);
+    HIP_TRY(c, hipSetDevice(c->opt.device));
     return run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
                    (long)n_rays * n_samples, d_out);
 }
@@ -245,6 +249,7 @@ int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const 
     if (n_rays < 0 || n_bins < 2 || n_bins > 257 || n_out < 1 || (n_rays > 0 && (!d_bins || !d_weights || !d_samples)))
         return c->fail(IBLNERF_ERR_INVALID, "sample_pdf: need 2 <= n_bins <= 257, n_out >= 1");
     if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_samples,
                                  (hipStream_t)stream));
     return IBLNERF_OK;

@@ -248,7 +248,8 @@ def decode_masks(mask_img, n_obj):
 # --------------------------------------------------------------------------------------------
 def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None):
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
-    lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs)."""
+    lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
+    epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461)."""
     gt = gt or {}
     edit = edit or {}
     flags = flags or {}
@@ -279,7 +280,7 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     irr = np.sum(w * radiance_f(raw[..., 5]), -1, dtype=F32)[:, None]                       # :287-288, :328
     rad = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
 
-    normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01)                    # :358-361
+    normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
     if stages is not None:
         stages["normal_raw"] = normal.copy()
     if edit.get("edit_intrinsic"):                                                          # :378-398
@@ -318,7 +319,10 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     refl_raw = network_query(sd, refl_pts, refl_d)                                          # :445
     pref_maps = composite_reflected(refl_raw, z_const, refl_d, radiance_f)                  # :446-448
     depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
-    level = np.clip(rough * depth / depth_0, 0, 1).astype(F32)                              # :458-459
+    if flags.get("correct_depth_for_prefiltered_radiance_infer", True):
+        level = np.clip(rough * depth / depth_0, 0, 1).astype(F32)                          # :458-459
+    else:
+        level = rough.astype(F32)                                                           # :461
     i1 = np.clip((level * F32(3)).astype(np.int64), 0, 3)                                   # :464-465
     i2 = np.clip(i1 + 1, 0, 3)
     rem = ((level * F32(3)) - i1.astype(F32))[:, None].astype(F32)
@@ -387,7 +391,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
 
 
 def render_decomp(H, W, K, sd_coarse, sd_fine, lut, near, far, rays=None, c2w=None, chunk=1024,
-                  n_samples=64, n_importance=128, gt_values=None, **edit):
+                  n_samples=64, n_importance=128, gt_values=None, flags=None, **edit):
     """ibl_nerf_renderer.py:759-813.  Exactly one of rays ([2,N,3]) / c2w ([3,4])."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
@@ -400,7 +404,7 @@ def render_decomp(H, W, K, sd_coarse, sd_fine, lut, near, far, rays=None, c2w=No
     for i in range(0, ro.shape[0], chunk):                                                 # batchify_rays :735-756
         gt = {k: np.array(v[i:i + chunk], dtype=F32) for k, v in gt_values.items()}
         r = render_rays(sd_coarse, sd_fine, ro[i:i + chunk], rd[i:i + chunk], near, far, lut,
-                        n_samples, n_importance, gt, edit)
+                        n_samples, n_importance, gt, edit, None, flags)
         for k, v in r.items():
             outs.setdefault(k, []).append(v)
     return {k: np.concatenate(v, 0).reshape(sh[:-1] + v[0].shape[1:]) for k, v in outs.items()}

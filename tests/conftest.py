@@ -50,11 +50,18 @@ def rel_linf(x, ref):
     return float(np.nanmax(np.abs(x.reshape(ref.shape) - ref)) / max(float(np.nanmax(np.abs(ref))), 1e-30))
 
 
-RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10"]
+RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
+                   "edit2_g10", "variant_small_g10"]
+
+
+def n_samples(g):
+    """N_samples of a fixture (64 unless the fixture records another count)."""
+    return int(g["n_samples"]) if "n_samples" in g.files else 64
 
 
 def golden_flags(g):
-    """Flag variants recorded with a fixture (use_radiance_linear / lindisp / lut_coefficient)."""
+    """Flag variants recorded with a fixture (use_radiance_linear / lindisp / lut_coefficient / epsilon /
+    gamma_correct / correct_depth_for_prefiltered_radiance_infer)."""
     return {k[6:]: g[k].item() for k in g.files if k.startswith("flag__")}
 
 

@@ -51,11 +51,11 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance):
+def reference_args(tmp, n_importance, n_samples=64):
     """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
-        multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=64,
+        multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=n_samples,
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
         color_independent_to_direction=False, use_illumination_feature_layer=False,
         use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
@@ -161,10 +161,11 @@ class Recorder:
         R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
 
 
-def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None):
+def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
+                n_samples=64, near=0.5, far=8.0, posed=False):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
@@ -172,13 +173,17 @@ def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mod
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     if kw["network_fine"] is not None:
         kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
-    near, far = 0.5, 8.0
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
     kw.update(flags or {})            # flag variants outside the shipped configs
 
     rng = np.random.RandomState(1000 + seed)
     o, d, pix, focal = camera_rays(rng, n_rays)
+    if posed:  # a rotated + translated camera: rays_o != 0 and rays_d = R dirs, as get_rays builds them (:41-44)
+        q, _ = np.linalg.qr(np.eye(3) + 0.3 * rng.randn(3, 3))
+        q = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+        d = np.sum(d[:, None, :] * q, -1).astype(np.float32)
+        o = np.broadcast_to(np.array([0.3, -0.2, 0.4], np.float32), d.shape).copy()
     edit = dict(EDIT_KEYS_OFF)
     gt = {}
     if mode == "edit":  # configs/IBL-NeRF/kitchen/edit_intrinsic.txt:8-16 (+ by-list albedo on a 2nd object)
@@ -188,6 +193,14 @@ def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mod
         level = rng.choice([0, 10, 20], size=n_rays, p=[0.5, 0.3, 0.2]).astype(np.float32) / np.float32(255)
         gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
         gt["edit_normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    elif mode == "edit2":  # the image-driven edits: depth and albedo from images, one object, no normal edit
+        edit.update(edit_intrinsic=True, num_edit_objects=1, edit_depth=True, edit_albedo=True, edit_albedo_by_img=True,
+                    edit_roughness=True, editing_target_roughness_list=[0.6],
+                    editing_target_albedo_list=[0.5, 0.5, 0.5])  # must be non-empty (:383 assert) though the image wins
+        level = rng.choice([0, 10], size=n_rays, p=[0.5, 0.5]).astype(np.float32) / np.float32(255)
+        gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["edit_depth"] = rng.uniform(1, 3, (n_rays, 1)).astype(np.float32)
+        gt["edit_albedo"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
     elif mode == "insert":  # configs/IBL-NeRF/living-room-2/object_insert.txt:8-14
         edit.update(insert_object=True, num_insert_objects=4, inserting_target_roughness_list=[1, 1, 1, 1],
                     inserting_target_albedo_list=[0.870588, 0.3215686, 0.443137254, .05, .05, .05, .2, .2, .2, .05, .05, .05],
@@ -206,7 +219,7 @@ def run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mod
 
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(near), far=np.float32(far),
                gain=np.float64(gain), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1),
-               n_importance=np.int64(n_importance),
+               n_importance=np.int64(n_importance), n_samples=np.int64(n_samples),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
                ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
                mode=np.array(mode))
@@ -318,13 +331,21 @@ def export_fixture(torch, R, M, lut):
     print("export_path.npz: %d result maps, %d images (%s ...)" % (len(res), len(written), sorted(written)[:3]))
 
 
-def main():
+def main(only=None):
+    """`python tests/golden/make_golden.py [name ...]` regenerates all fixtures, or only the named ones."""
     torch, R, M, Hh = import_reference()
     torch.manual_seed(0)
     lut = load_lut(torch)
     shutil.copyfile(os.path.join(REF, "data", "ibl_brdf_lut.png"), os.path.join(OUT, "ibl_brdf_lut.png"))
-    small_vectors(torch, R, Hh)
-    export_fixture(torch, R, M, lut)
+    if not only or "small_vectors" in only:
+        small_vectors(torch, R, Hh)
+    if not only or "export_path" in only:
+        export_fixture(torch, R, M, lut)
+
+    def run_fixture(name, *a, **k):
+        if not only or name in only:
+            _run_fixture(name, *a, **k)
+
     # config 1 (BASELINE.json configs[0]): coarse only
     run_fixture("cfg1_coarse_g10", torch, R, M, lut, n_rays=128, n_importance=0, gain=1.0, seed=0)
     # configs 2/3 kernel mix: 64+128, well-conditioned and wide-range checkpoints
@@ -336,7 +357,13 @@ def main():
     # f-4 flag variants: HDR radiance (ReLU + Reinhard), inverse-depth sampling, F0 LUT coefficient
     run_fixture("variant_lin_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=4,
                 flags=dict(use_radiance_linear=True, lindisp=True, lut_coefficient="F0"))
+    # image-driven edits (edit_depth, edit_albedo_by_img) — flags of config_parser.py:246-256 the shipped edit config leaves off
+    run_fixture("edit2_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=5, mode="edit2")
+    # other sample counts / epsilon / planes / no gamma / roughness-only mip level, posed camera
+    run_fixture("variant_small_g10", torch, R, M, lut, n_rays=96, n_importance=48, gain=1.0, seed=6, n_samples=32,
+                near=1.0, far=5.0, posed=True,
+                flags=dict(epsilon=0.02, gamma_correct=False, correct_depth_for_prefiltered_radiance_infer=False))
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +29,7 @@ def R():
 
 def make_renderer(R, g, sdc, sdf, lut, **kw):
     kw = dict(golden_flags(g), **kw)
-    r = R.Renderer(64, int(g["n_importance"]), **kw)
+    r = R.Renderer(n_samples(g), int(g["n_importance"]), **kw)
     r.load_weights(0, sdc)
     if int(g["n_importance"]) > 0:
         r.load_weights(1, sdf)

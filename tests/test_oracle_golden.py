@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 # Channels that are smooth functions of the MLP outputs: the oracle must sit at fp32 round-off.
 DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
@@ -67,7 +67,7 @@ def test_render_rays_end_to_end(name, lut):
     st = {}
     flags = golden_flags(g)
     res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut,
-                        64, int(g["n_importance"]), gt, edit, st, flags)
+                        n_samples(g), int(g["n_importance"]), gt, edit, st, flags)
     ref_keys = sorted(k[5:] for k in g.files if k.startswith("out__"))
     assert sorted(res.keys()) == ref_keys                       # 22 maps (+22 '0' maps + z_std)
     wide = ill_conditioned(g)
@@ -86,7 +86,7 @@ def test_render_rays_end_to_end(name, lut):
         assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
         assert np.abs(st["z_samples"] - g["pdf_samples"]).max() <= 2e-5
         # stage-wise (teacher-forced) sample_pdf on the reference's own inputs
-        assert np.abs(O.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128) - g["pdf_samples"]).max() <= 2e-5  # 1 ulp of cdf / pdf(~2e-3) * bin width
+        assert np.abs(O.sample_pdf(g["pdf_bins"], g["pdf_weights"], int(g["n_importance"])) - g["pdf_samples"]).max() <= 2e-5  # 1 ulp of cdf / pdf(~2e-3) * bin width
     for p in (["c", "f"] if int(g["n_importance"]) > 0 else ["c"]):
         assert rel_linf(st[p]["normal_raw"], g["normal_raw_%s" % p]) <= (5e-3 if wide else 6e-4)
         lin = bool(flags.get("use_radiance_linear", False))
@@ -94,7 +94,7 @@ def test_render_rays_end_to_end(name, lut):
         uv = g["lut_uv_%s" % p]
         env = O.lut_fetch(lut, (uv[:, 0] + 1) / 2, (uv[:, 1] + 1) / 2)
         assert np.abs(env - g["lut_val_%s" % p]).max() <= 2e-6
-        zc = O.coarse_z(float(g["near"]), float(g["far"]), 64, g["q_%s_refl_raw" % p].shape[0], bool(flags.get("lindisp", False)))
+        zc = O.coarse_z(float(g["near"]), float(g["far"]), n_samples(g), g["q_%s_refl_raw" % p].shape[0], bool(flags.get("lindisp", False)))
         pm = O.composite_reflected(g["q_%s_refl_raw" % p], zc, g["q_%s_refl_dirs" % p], O.relu if lin else None)
         assert np.abs(pm - g["prefiltered_env_%s" % p][:pm.shape[0]]).max() <= 2e-6
 
