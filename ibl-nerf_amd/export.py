@@ -124,3 +124,59 @@ def psnr(pred, gt, data_range=1.0):
     """10 log10(range^2 / MSE) — the definition piq.psnr uses in evaluation/calculate_metrics.py:13-33."""
     mse = float(np.mean((np.asarray(pred, np.float64) - np.asarray(gt, np.float64)) ** 2))
     return float("inf") if mse == 0 else 10.0 * np.log10(data_range ** 2 / mse)
+
+
+def _gaussian_kernel(size=11, sigma=1.5):
+    c = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
+    g = np.exp(-(c ** 2) / (2.0 * sigma ** 2))
+    k = np.outer(g, g)
+    return k / k.sum()
+
+
+def ssim(pred, gt, data_range=1.0, kernel_size=11, kernel_sigma=1.5, k1=0.01, k2=0.03, downsample=True):
+    """Structural similarity of two [H,W,C] (or [H,W]) images as `piq.ssim` computes it with its defaults —
+    the call of evaluation/calculate_metrics.py:31 (`piq` is an unpinned entry of the reference's
+    requirements.txt and is absent here, so this restates piq's published algorithm: inputs / data_range;
+    average-pool by f = max(1, round(min(H,W)/256)); 11x11 Gaussian window, sigma 1.5, 'valid' convolution
+    per channel; ssim = mean over window positions of l*cs, then mean over channels)."""
+    from scipy.signal import fftconvolve
+    x = np.asarray(pred, np.float64) / data_range
+    y = np.asarray(gt, np.float64) / data_range
+    if x.ndim == 2:
+        x, y = x[..., None], y[..., None]
+    if x.shape != y.shape:
+        raise ValueError("ssim: shapes differ %r vs %r" % (x.shape, y.shape))
+    f = max(1, round(min(x.shape[:2]) / 256))
+    if f > 1 and downsample:                                  # F.avg_pool2d(kernel_size=f): floor, no padding
+        Hc, Wc = (x.shape[0] // f) * f, (x.shape[1] // f) * f
+        pool = lambda a: a[:Hc, :Wc].reshape(Hc // f, f, Wc // f, f, -1).mean((1, 3))
+        x, y = pool(x), pool(y)
+    if min(x.shape[:2]) < kernel_size:
+        raise ValueError("ssim: image smaller than the %dx%d window" % (kernel_size, kernel_size))
+    k = _gaussian_kernel(kernel_size, kernel_sigma)
+    c1, c2 = k1 ** 2, k2 ** 2
+    vals = []
+    for ch in range(x.shape[-1]):
+        a, b = x[..., ch], y[..., ch]
+        conv = lambda im: fftconvolve(im, k, mode="valid")
+        mu_a, mu_b = conv(a), conv(b)
+        s_aa, s_bb, s_ab = conv(a * a) - mu_a ** 2, conv(b * b) - mu_b ** 2, conv(a * b) - mu_a * mu_b
+        cs = (2.0 * s_ab + c2) / (s_aa + s_bb + c2)
+        ss = (2.0 * mu_a * mu_b + c1) / (mu_a ** 2 + mu_b ** 2 + c1) * cs
+        vals.append(ss.mean())
+    return float(np.mean(vals))
+
+
+def calculate_metrics(gt_path, pred_path, target="rgb", n_views=100):
+    """evaluation/calculate_metrics.py:10-33, mitsuba branch: `<pred>/<target>_{i:03d}.png` against
+    `<gt>/test/{i+1}.png`, 8-bit RGB / 255.  Returns per-view lists of ssim / psnr / mse."""
+    from PIL import Image
+    load = lambda p: np.asarray(Image.open(p).convert("RGB"), dtype=np.float32) / np.float32(255.0)
+    out = {"ssim": [], "psnr": [], "mse": []}
+    for i in range(n_views):
+        pred = load(os.path.join(pred_path, "%s_%03d.png" % (target, i)))
+        gt = load(os.path.join(gt_path, "test", "%d.png" % (i + 1)))
+        out["ssim"].append(ssim(pred, gt))
+        out["psnr"].append(psnr(pred, gt))
+        out["mse"].append(float(np.mean((pred.astype(np.float64) - gt.astype(np.float64)) ** 2)))
+    return out

@@ -89,3 +89,42 @@ def test_export_path_with_hip_renderer(gold, lut, tmp_path):
     res = E.render_decomp_path(ds, (int(g["H"]), int(g["W"]), float(g["focal"])), None, 1024, kw, savedir=str(out),
                                render_factor=1, approximate_radiance=True)
     check_against_golden(res, str(out), g, float_tol=2e-4, max_lsb_off_frac=0.35)
+
+
+def test_ssim_and_metrics(tmp_path):
+    """piq is absent: SSIM is checked against an independent torch.conv2d evaluation of the same published
+    definition and against the properties the definition implies."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    rs = np.random.RandomState(0)
+    a = rs.uniform(0, 1, (40, 52, 3))
+    b = np.clip(a + 0.1 * rs.randn(*a.shape), 0, 1)
+    assert abs(E.ssim(a, a) - 1.0) < 1e-12 and abs(E.ssim(a, b) - E.ssim(b, a)) < 1e-12
+    assert E.ssim(a, b) > E.ssim(a, np.clip(a + 0.3 * rs.randn(*a.shape), 0, 1))
+
+    def ssim_torch(x, y):                                        # grouped 'valid' convolution, as piq builds it
+        k = torch.from_numpy(E._gaussian_kernel()).repeat(3, 1, 1, 1)
+        x, y = (torch.from_numpy(t).permute(2, 0, 1)[None] for t in (x, y))
+        f = max(1, round(min(x.shape[-2:]) / 256))
+        if f > 1:
+            x, y = F.avg_pool2d(x, f), F.avg_pool2d(y, f)
+        mx, my = F.conv2d(x, k, groups=3), F.conv2d(y, k, groups=3)
+        sxx, syy, sxy = F.conv2d(x * x, k, groups=3) - mx * mx, F.conv2d(y * y, k, groups=3) - my * my, F.conv2d(x * y, k, groups=3) - mx * my
+        cs = (2 * sxy + 0.03 ** 2) / (sxx + syy + 0.03 ** 2)
+        return float(((2 * mx * my + 0.01 ** 2) / (mx * mx + my * my + 0.01 ** 2) * cs).mean((-1, -2)).mean())
+
+    assert abs(E.ssim(a, b) - ssim_torch(a, b)) < 1e-10
+    big_a = rs.uniform(0, 1, (700, 650, 3))                      # f = round(650/256) = 3: pooled to 233 x 216
+    big_b = np.clip(big_a + 0.05 * rs.randn(*big_a.shape), 0, 1)
+    assert abs(E.ssim(big_a, big_b) - ssim_torch(big_a, big_b)) < 1e-10
+    with pytest.raises(ValueError):
+        E.ssim(a[:8], b[:8])
+    from PIL import Image
+    os.makedirs(tmp_path / "gt" / "test")
+    os.makedirs(tmp_path / "pred")
+    for i in range(2):
+        Image.fromarray(E.to8b(a)).save(tmp_path / "gt" / "test" / ("%d.png" % (i + 1)))
+        Image.fromarray(E.to8b(b if i else a)).save(tmp_path / "pred" / ("rgb_%03d.png" % i))
+    m = E.calculate_metrics(str(tmp_path / "gt"), str(tmp_path / "pred"), "rgb", n_views=2)
+    assert m["mse"][0] == 0.0 and m["psnr"][0] == float("inf") and abs(m["ssim"][0] - 1) < 1e-12
+    assert 0 < m["ssim"][1] < 1 and abs(m["psnr"][1] - 10 * np.log10(1 / m["mse"][1])) < 1e-9
