@@ -117,6 +117,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # bring the RCCL communicator (rings over xGMI) up before anything is timed, even with --warmup 0
+        probe = torch.zeros(world * 256, device="cuda")
+        dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
+        dist.barrier()
+        del probe
 
     pkg = _pkg.load()
     from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R
