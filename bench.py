@@ -114,9 +114,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # IBLNERF_BENCH_BACKEND=gloo is a test hook: it lets the N>1 code path run with several ranks sharing the
+    # one GPU of a test box (RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
+    backend = os.environ.get("IBLNERF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         # bring the RCCL communicator (rings over xGMI) up before anything is timed, even with --warmup 0
         probe = torch.zeros(world * 256, device="cuda")
         dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
@@ -197,7 +205,8 @@ def main():
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
-                       "parallelism": "ray-tile x%d + RCCL all-gather" % world if world > 1 else "single GPU"},
+                       "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
+                                      if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch (reads x2-corrected + writes) from %s; points in + raw outputs out, weights stay in L2" % traffic_src,
