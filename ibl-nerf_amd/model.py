@@ -44,17 +44,56 @@ class IBLNeRF:
     def eval(self):
         return self
 
+    def parameters(self):
+        return iter(())          # a weight container: nothing here is trainable
+
+
+_query_ctx = {}     # id(network) -> {"ref": weakref, "r": Renderer, "w": weights key}
+
+
+def _query_renderer(network_fn):
+    """A small cached context holding `network_fn`'s weights; they are re-uploaded whenever a parameter
+    changed (load_state_dict, or an in-place optimizer step: torch bumps the tensors' `_version`)."""
+    import weakref
+    from . import renderer as R
+    ent = _query_ctx.get(id(network_fn))
+    if ent is None or ent["ref"]() is not network_fn:
+        ent = _query_ctx[id(network_fn)] = {"ref": weakref.ref(network_fn), "r": R.Renderer(64, 0, max_rays_per_launch=1), "w": None}
+        for k in [k for k, e in _query_ctx.items() if e["ref"]() is None]:
+            del _query_ctx[k]
+    key = R._weights_key(network_fn)
+    if ent["w"] != key:
+        ent["r"].load_weights(0, network_fn.state_dict())
+        ent["w"] = key
+    return ent["r"]
+
 
 def network_query_fn(inputs, viewdirs, network_fn, renderer=None, which=0):
-    """ibl_nerf.py:327-329.  `network_fn` selects coarse/fine by identity when a renderer with
-    both networks uploaded is passed; stand-alone it uploads `network_fn` as network 0."""
-    from . import renderer as R
-    r = renderer
-    if r is None:
-        r = R.Renderer(inputs.shape[1], 0, max_rays_per_launch=1)
-        r.load_weights(0, network_fn.state_dict())
-        which = 0
-    return r.network_query(inputs, viewdirs, which)
+    """ibl_nerf.py:327-329 on the fused HIP kernel (forward only: the result carries no autograd graph).
+    With `renderer`, `which` selects its coarse (0) / fine (1) weights; without, `network_fn`'s own
+    weights are used through a cached context."""
+    if renderer is not None:
+        return renderer.network_query(inputs, viewdirs, which)
+    return _query_renderer(network_fn).network_query(inputs, viewdirs, 0)
+
+
+def training_network_query_fn(grad_query_fn):
+    """`network_query_fn` for `render_kwargs_train` (train.py:286-297).  In the shipped training
+    configuration the eps-normal queries (ibl_nerf_renderer.py:358-361) and the reflected-ray query
+    (:442-448) run under `torch.no_grad()`: 1024 trunk + 128 full evaluations per ray, 59 % of the forward
+    FLOPs of a training step.  Those go to the fused kernel; a query that must carry gradients (the main
+    query of each pass) is handed to `grad_query_fn`, the reference's own autograd path
+    (`lambda inputs, viewdirs, network_fn: run_network(...)`, ibl_nerf.py:327-329), unchanged."""
+    import torch
+
+    def fn(inputs, viewdirs, network_fn):
+        needs_grad = torch.is_grad_enabled() and (
+            any(p.requires_grad for p in network_fn.parameters()) or getattr(inputs, "requires_grad", False)
+            or getattr(viewdirs, "requires_grad", False))
+        if needs_grad:
+            return grad_query_fn(inputs, viewdirs, network_fn)
+        return network_query_fn(inputs, viewdirs, network_fn)
+    return fn
 
 
 def create_IBLNeRF(args):

@@ -272,21 +272,7 @@ def test_torch_module_weights_are_tracked(R, lut):
     """render_decomp accepts a torch nn.Module with the reference's parameter names (what test.py /
     train.py pass as network_fn) and re-uploads when a parameter changes in place (optimizer step)."""
     from ibl_nerf_amd import checkpoint as ck
-    import torch.nn as nn
-
-    class RefShaped(nn.Module):          # same registration order / names as ibl_nerf.py:45-72
-        def __init__(self, sd):
-            super().__init__()
-            lin = lambda n: nn.Linear(sd[n + ".weight"].shape[1], sd[n + ".weight"].shape[0])
-            self.positions_linears = nn.ModuleList([lin("positions_linears.%d" % i) for i in range(8)])
-            self.views_linears = nn.ModuleList([lin("views_linears.0")])
-            for n in ("feature_linear", "sigma_linear", "albedo_feature_linear", "albedo_linear", "roughness_linear",
-                      "irradiance_feature_linear", "irradiance_linear", "radiance_linear"):
-                setattr(self, n, lin(n))
-            self.additional_radiance_feature_linear = nn.ModuleList([lin("additional_radiance_feature_linear.%d" % i) for i in range(3)])
-            self.additional_radiance_linear = nn.ModuleList([lin("additional_radiance_linear.%d" % i) for i in range(3)])
-            self.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
-
+    from torch_ref import RefShaped
     g, sdc, sdf, _, _ = load_golden("plain_g10")
     net_c, net_f = RefShaped(sdc), RefShaped(sdf)
     assert list(net_c.state_dict().keys()) == [n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias")]
@@ -304,3 +290,35 @@ def test_torch_module_weights_are_tracked(R, lut):
     b = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
     assert float((b["albedo_map"] - a["albedo_map"]).abs().min()) > 1e-2     # the new weights were uploaded
     assert torch.equal(b["albedo_map0"], a["albedo_map0"])                   # the coarse network did not change
+
+
+def test_training_query_fn_dispatch(R, lut):
+    """training_network_query_fn: no-grad queries (eps-normal, reflected) run on the fused kernel and see
+    the weights an optimizer step just wrote; grad-carrying queries keep the autograd path."""
+    from ibl_nerf_amd import model as M
+    from torch_ref import RefShaped, torch_query
+    g, sdc, _, _, _ = load_golden("plain_g10")
+    net = RefShaped(sdc).cuda()
+    calls = []
+
+    def grad_query(inputs, viewdirs, network_fn):
+        calls.append(inputs.shape)
+        return torch_query(inputs, viewdirs, network_fn)
+
+    q = M.training_network_query_fn(grad_query)
+    pts = torch.from_numpy(g["q_c_main_pts"]).cuda()
+    dirs = torch.from_numpy(g["q_c_main_dirs"]).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for step in range(2):
+        with torch.no_grad():
+            fused = q(pts, dirs, net)                         # HIP
+            sig = q(pts, None, net)
+            ref = torch_query(pts, dirs, net)
+        assert len(calls) == step and not fused.requires_grad          # the no-grad queries never reach grad_query
+        assert float((fused - ref).abs().max()) <= 6e-5 and float((sig[..., 0] - ref[..., 0]).abs().max()) <= 6e-5
+        out = q(pts, dirs, net)                               # autograd path
+        assert len(calls) == step + 1 and out.requires_grad
+        opt.zero_grad()
+        out.square().mean().backward()
+        opt.step()                                            # in-place update: the next fused query must see it
+    assert M.network_query_fn(pts, dirs, RefShaped(sdc).cuda()).shape == (pts.shape[0], pts.shape[1], 18)

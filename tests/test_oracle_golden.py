@@ -113,3 +113,18 @@ def test_render_decomp_chunking_and_c2w(lut):
     Ks = np.array([[5.0, 0, 2], [0, 5.0, 1.5], [0, 0, 1]], dtype=np.float32)
     c = O.render_decomp(3, 4, Ks, sdc, None, lut, 0.5, 8.0, c2w=c2w, n_importance=0)
     assert c["color_map"].shape == (3, 4, 3) and c["weights"].shape == (3, 4, 64)
+
+
+def test_torch_stand_in_module_matches_reference_outputs():
+    """tests/torch_ref.py (the nn.Module the GPU tests hand over as `network_fn`) reproduces the
+    reference's recorded query outputs, and its state dict has the reference's names and order."""
+    torch = pytest.importorskip("torch")
+    from ibl_nerf_amd import checkpoint as ck
+    from torch_ref import RefShaped, torch_query
+    g, sdc, _, _, _ = load_golden("plain_g10")
+    net = RefShaped(sdc)
+    assert list(net.state_dict().keys()) == [n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias")]
+    with torch.no_grad():
+        raw = torch_query(torch.from_numpy(g["q_c_main_pts"]), torch.from_numpy(g["q_c_main_dirs"]), net).numpy()
+        sig = torch_query(torch.from_numpy(g["q_c_eps_pts"]), None, net).numpy()
+    assert np.abs(raw - g["q_c_main_raw"]).max() <= 2e-6 and np.abs(sig - g["q_c_eps_sigma"]).max() <= 2e-6

@@ -1,0 +1,61 @@
+"""A plain-PyTorch module with the reference IBLNeRF's parameter names, registration order and forward
+arithmetic (nerf_models/ibl_nerf.py:45-72, :154-210), written for the tests: it plays the role of the
+module train.py / test.py hand over as `network_fn`, and of the reference's autograd query path."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class RefShaped(nn.Module):
+    def __init__(self, sd=None):
+        super().__init__()
+        W, ch, chv = 256, 63, 27
+        self.positions_linears = nn.ModuleList([nn.Linear(ch, W)] + [nn.Linear(W + ch if i == 4 else W, W) for i in range(7)])
+        self.views_linears = nn.ModuleList([nn.Linear(chv + W, W)])
+        self.feature_linear = nn.Linear(W, W)
+        self.sigma_linear = nn.Linear(W, 1)
+        self.albedo_feature_linear = nn.Linear(W, W // 2)
+        self.albedo_linear = nn.Linear(W // 2, 3)
+        self.roughness_linear = nn.Linear(W, 1)
+        self.irradiance_feature_linear = nn.Linear(W, W // 2)
+        self.irradiance_linear = nn.Linear(W // 2, 1)
+        self.radiance_linear = nn.Linear(W, 3)
+        self.additional_radiance_feature_linear = nn.ModuleList([nn.Linear(W, W // 2) for _ in range(3)])
+        self.additional_radiance_linear = nn.ModuleList([nn.Linear(W // 2, 3) for _ in range(3)])
+        if sd is not None:
+            self.load_state_dict({k: torch.as_tensor(v).clone() for k, v in sd.items()})
+
+    def forward(self, e_pts, e_dirs=None):
+        h = e_pts
+        for i, l in enumerate(self.positions_linears):
+            h = F.relu(l(h))
+            if i == 4:
+                h = torch.cat([e_pts, h], -1)
+        sigma = self.sigma_linear(h)
+        if e_dirs is None:
+            return sigma
+        albedo = self.albedo_linear(F.relu(self.albedo_feature_linear(h)))
+        rough = self.roughness_linear(h)
+        irr = self.irradiance_linear(F.relu(self.irradiance_feature_linear(h)))
+        h2 = F.relu(self.views_linears[0](torch.cat([self.feature_linear(h), e_dirs], -1)))
+        ret = [sigma, albedo, rough, irr, self.radiance_linear(h2)]
+        for fl, ol in zip(self.additional_radiance_feature_linear, self.additional_radiance_linear):
+            ret.append(ol(F.relu(fl(h2))))
+        return torch.cat(ret, -1)
+
+
+def embed(x, n_freqs):
+    out = [x]
+    for k in range(n_freqs):
+        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    return torch.cat(out, -1)
+
+
+def torch_query(inputs, viewdirs, net):
+    """run_network (ibl_nerf.py:236-252) in plain PyTorch: the autograd-carrying query path."""
+    flat = inputs.reshape(-1, 3)
+    e = embed(flat, 10)
+    if viewdirs is None:
+        return net(e).reshape(*inputs.shape[:-1], 1)
+    d = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
+    return net(e, embed(d, 4)).reshape(*inputs.shape[:-1], 18)
