@@ -29,6 +29,14 @@ def tile_rows(H: int, rank: int, world: int) -> Tuple[int, int]:
     return row0, n
 
 
+def view_indices(n_views: int, rank: int, world: int) -> range:
+    """Whole-view sharding for a multi-view export (test.py renders ~100 independent views): rank r takes
+    views r, r + world, ...  No exchange step: every rank writes its own views' files."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    return range(rank, n_views, world)
+
+
 def slice_gt_rows(gt_values: Optional[dict], W: int, row0: int, n_rows: int) -> dict:
     """gt_values arrive flattened to [H*W, C] (ibl_nerf_renderer.py:864-866); take this tile's rows."""
     if not gt_values:

@@ -81,13 +81,15 @@ def write_png(path, img8):
 
 
 def render_decomp_path(dataset_test, hwf, K, chunk, render_kwargs, savedir=None, render_factor=0, gt_values=None,
-                       render_fn=None, export_workers=8, **kwargs):
+                       render_fn=None, export_workers=8, views=None, **kwargs):
     """Drop-in for ibl_nerf_renderer.py:819-910.  `dataset_test` needs `.poses` (iterable of c2w),
     `.far` and `.get_resized_normal_albedo(render_factor, i)` like the reference's NerfDataset.
     Returns {out_name: array [n_views, H, W, ...]} and writes `<out_name>_{i:03d}.png` to savedir.
     PNG encoding (1.2 s of host time per 800x800 view, against 2.3 s of GPU time) runs on
     `export_workers` threads while the next view renders; every file is on disk when this returns.
-    `export_workers=0` writes inline like the reference."""
+    `export_workers=0` writes inline like the reference.  `views` (iterable of view indices, default all)
+    restricts the loop to this process's share of the views (`dist.view_indices`); file names keep the
+    global view index."""
     from concurrent.futures import ThreadPoolExecutor
     render_fn = render_fn or R.render_decomp
     pool = ThreadPoolExecutor(max_workers=export_workers) if (savedir is not None and export_workers > 0) else None
@@ -116,7 +118,8 @@ def render_decomp_path(dataset_test, hwf, K, chunk, render_kwargs, savedir=None,
         os.makedirs(savedir, exist_ok=True)
     plan = export_plan(render_kwargs.get("coarse_radiance_number", 3))
     try:
-        for i, c2w in enumerate(dataset_test.poses):
+        for i in (range(len(dataset_test.poses)) if views is None else views):
+            c2w = dataset_test.poses[i]
             gt = dataset_test.get_resized_normal_albedo(render_factor, i)
             gt = {k: v.reshape(-1, v.shape[-1]) for k, v in gt.items()}
             c2w34 = c2w[:3, :4]

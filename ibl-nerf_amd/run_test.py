@@ -4,6 +4,8 @@ Reads a reference config (include chain), the Mitsuba test split, the latest che
 reference's PNG set to <export_basedir>/<expname>/testset_<step:06d>/.
 
     python render_test.py --config ../configs/IBL-NeRF/kitchen/IBL-NeRF.txt [--key value ...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 render_test.py --config ...
+        (one process per GPU; the test views are dealt out round-robin, each rank writes its own files)
 """
 from __future__ import annotations
 
@@ -11,7 +13,7 @@ import os
 
 import numpy as np
 
-from . import config as C, dataset as DS, export as E, model as M
+from . import config as C, dataset as DS, dist as D, export as E, model as M
 
 
 def load_brdf_lut(path, device):
@@ -48,9 +50,14 @@ def test(args, brdf_lut_path=None, render_fn=None):
         args.export_basedir = args.basedir.replace("logs", "logs_eval")
     testsavedir = os.path.join(args.export_basedir, args.expname, "testset_{:06d}".format(start))
     os.makedirs(testsavedir, exist_ok=True)
+    views = None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        views = D.view_indices(len(dataset.poses), dist.get_rank(), dist.get_world_size())   # independent views: no collective
     with torch.no_grad():
         return E.render_decomp_path(dataset, hwf, K, args.chunk, render_kwargs_test, savedir=testsavedir, render_factor=1,
-                                    approximate_radiance=True, render_fn=render_fn, **C.edit_params(args)), testsavedir
+                                    approximate_radiance=True, render_fn=render_fn, views=views,
+                                    **C.edit_params(args)), testsavedir
 
 
 def main(argv=None):
@@ -68,5 +75,15 @@ def main(argv=None):
         d = C.DEFAULTS.get(k)
         over[k] = True if isinstance(d, bool) else C._convert(k, next(it))
     args = C.load_config(ns.config, **over)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                        # python -m torch.distributed.run --nproc-per-node N render_test.py --config ...
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     _, out = test(args, brdf_lut_path=ns.brdf_lut)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     print("Done! ->", out)

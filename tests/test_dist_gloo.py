@@ -60,3 +60,38 @@ def test_two_rank_frame_reassembly():
         assert torch.equal(a[k], b[k]), k                       # every rank holds the whole frame
         assert a[k].shape == ref[k].shape, (k, a[k].shape, ref[k].shape)
         assert np.allclose(a[k].numpy(), ref[k], rtol=0, atol=2e-5), k   # BLAS batch-shape dependence only
+
+
+def _view_worker(rank, world, init_file, cfg_path, lut_path):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _pkg
+    _pkg.load()
+    from conftest import load_lut_rgb
+    from ibl_nerf_amd import checkpoint as ck, config as C, run_test as RT
+    from test_dataset import oracle_render_fn
+    res, out = RT.test(C.load_config(cfg_path, device="cpu"), brdf_lut_path=lut_path,
+                       render_fn=oracle_render_fn(ck.synthetic_state_dict(0), ck.synthetic_state_dict(1), load_lut_rgb()))
+    assert res["rgb"].shape[0] == len(range(rank, 3, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_view_sharding(tmp_path):
+    """render_test flow on 2 ranks: views dealt out round-robin, no exchange, union of files = full set."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dataset import N_TEST, write_experiment, write_scene
+    from ibl_nerf_amd import dist as D
+    assert list(D.view_indices(7, 1, 3)) == [1, 4] and list(D.view_indices(2, 2, 3)) == []
+    root = tmp_path / "data" / "tiny"
+    os.makedirs(root)
+    write_scene(root)
+    cfg, _, _ = write_experiment(tmp_path, root, [])
+    lut_path = os.path.join(ROOT, "tests", "golden", "ibl_brdf_lut.png")
+    mp.spawn(_view_worker, args=(2, str(tmp_path / "rdzv"), cfg, lut_path), nprocs=2, join=True)
+    out = tmp_path / "logs_eval" / "tiny" / "testset_002000"
+    names = sorted(os.listdir(out))
+    assert len(names) == 21 * N_TEST and all(("rgb_%03d.png" % i) in names for i in range(N_TEST))
