@@ -16,6 +16,7 @@ EXPORTS = [
     "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host", "iblnerf_stream_bytes",
     "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
+    "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx",
 ]
 
 
@@ -28,7 +29,10 @@ class Options(C.Structure):
                 ("gamma_correct", C.c_int32), ("lut_coefficient_f0", C.c_int32),
                 ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
                 ("max_rays_per_launch", C.c_int32), ("device", C.c_int32), ("lindisp", C.c_int32),
-                ("use_radiance_linear", C.c_int32)]
+                ("use_radiance_linear", C.c_int32), ("mlp_precision", C.c_int32)]
+
+
+MLP_BF16X3, MLP_F16_MXFP6 = 0, 1
 
 
 FP = C.c_void_p  # device float*
@@ -78,6 +82,9 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_blob_floats.restype = C.c_size_t
     lib.iblnerf_stream_bytes.restype = C.c_size_t
     lib.iblnerf_table_floats.restype = C.c_size_t
+    lib.iblnerf_stream_bytes_mx.restype = C.c_size_t
+    lib.iblnerf_pack_weights_host_mx.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.iblnerf_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.iblnerf_pack_weights_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -93,7 +100,7 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_last_mlp_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     for n in ("iblnerf_create", "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host",
               "iblnerf_get_rays", "iblnerf_network_query", "iblnerf_sample_pdf", "iblnerf_render_rays",
-              "iblnerf_set_profiling", "iblnerf_last_mlp_time"):
+              "iblnerf_set_profiling", "iblnerf_last_mlp_time", "iblnerf_range_status", "iblnerf_pack_weights_host_mx"):
         getattr(lib, n).restype = C.c_int
     _lib = lib
     return lib

@@ -23,11 +23,12 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 # (source, extra flags placed before -c)
 SOURCES = [
     ("mlp_kernel.hip", []),
+    ("mlp_kernel_mx.hip", []),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
 ]
-HEADERS = ["layout.h", "kernels.h", "pack.h", "sincos_enc.h", os.path.join("..", "..", "include", "iblnerf.h")]
+HEADERS = ["layout.h", "layout_mx.h", "kernels.h", "pack.h", "sincos_enc.h", os.path.join("..", "..", "include", "iblnerf.h")]
 
 
 def _digest(paths, extra):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "layout_mx.h"
 #include "pack.h"
 #include "sincos_enc.h"
 
@@ -29,6 +30,8 @@ struct iblnerf_ctx {
     int n_cu = 256;
     // per network
     char* d_stream[2] = {nullptr, nullptr};
+    char* d_stream_mx[2] = {nullptr, nullptr};   // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
+    unsigned* d_range_flag = nullptr;
     float* d_tables[2] = {nullptr, nullptr};
     bool have_net[2] = {false, false};
     float* d_lut = nullptr;
@@ -78,6 +81,16 @@ void iblnerf_default_options(iblnerf_options* o) {
 
 size_t iblnerf_blob_floats(void) { return blob_floats(); }
 size_t iblnerf_stream_bytes(void) { return (size_t)STREAM_BYTES; }
+size_t iblnerf_stream_bytes_mx(void) { return (size_t)mx::STREAM_BYTES; }
+
+int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                                 float* h_tables, size_t table_floats) {
+    if (!h_blob || !h_stream || !h_tables) return IBLNERF_ERR_INVALID;
+    if (n_floats != blob_floats() || stream_bytes != (size_t)mx::STREAM_BYTES || table_floats != (size_t)TAB_FLOATS)
+        return IBLNERF_ERR_INVALID;
+    pack_network_mx(h_blob, h_stream, h_tables);
+    return IBLNERF_OK;
+}
 size_t iblnerf_table_floats(void) { return (size_t)TAB_FLOATS; }
 
 int iblnerf_pack_weights_host(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
@@ -101,6 +114,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     if (opts->n_samples < 3 || opts->n_samples > 256 || opts->n_importance < 0 ||
         opts->n_samples + opts->n_importance > 256 || opts->max_rays_per_launch < 1) {
         g_create_error = "unsupported sample counts: need 3 <= N_samples, N_samples + N_importance <= 256";
+        return IBLNERF_ERR_INVALID;
+    }
+    if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6) {
+        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0) or IBLNERF_MLP_F16_MXFP6 (1)";
         return IBLNERF_ERR_INVALID;
     }
     if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
@@ -141,6 +158,16 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             iblnerf_destroy(c);
             return IBLNERF_ERR_NOMEM;
         }
+    if (opts->mlp_precision == IBLNERF_MLP_F16_MXFP6) {
+        bool ok = hipMalloc((void**)&c->d_range_flag, sizeof(unsigned)) == hipSuccess &&
+                  hipMemset(c->d_range_flag, 0, sizeof(unsigned)) == hipSuccess;
+        for (int w = 0; w < 2 && ok; ++w) ok = hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess;
+        if (!ok) {
+            g_create_error = "hipMalloc of the f16 + MX-fp6 weight stream failed";
+            iblnerf_destroy(c);
+            return IBLNERF_ERR_NOMEM;
+        }
+    }
     if (hipMalloc((void**)&c->d_lut, 3 * 512 * 512 * sizeof(float)) != hipSuccess) {
         g_create_error = "hipMalloc of the LUT failed";
         iblnerf_destroy(c);
@@ -156,8 +183,11 @@ void iblnerf_destroy(iblnerf_ctx* c) {
                      c->refl_raw, c->d_lut, c->d_tables[0], c->d_tables[1]};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 2; ++w) {
         if (c->d_stream[w]) (void)hipFree(c->d_stream[w]);
+        if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
+    }
+    if (c->d_range_flag) (void)hipFree(c->d_range_flag);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
 }
@@ -174,6 +204,11 @@ int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_
     HIP_TRY(c, hipDeviceSynchronize());   // a previous render may still be reading the old stream
     HIP_TRY(c, hipMemcpy(c->d_stream[which], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tables[which], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
+    if (c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6) {
+        std::vector<char> smx((size_t)mx::STREAM_BYTES);
+        pack_network_mx(h_blob, smx.data(), tab.data());
+        HIP_TRY(c, hipMemcpy(c->d_stream_mx[which], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
+    }
     c->have_net[which] = true;
     return IBLNERF_OK;
 }
@@ -207,7 +242,9 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                    int pts_per_ray, long n_pts, float* out) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
-    a.stream = c->d_stream[which];
+    const bool use_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6;
+    a.stream = use_mx ? c->d_stream_mx[which] : c->d_stream[which];
+    a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];
     a.pts = pts;
     a.dirs = dirs;
@@ -225,7 +262,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
-    HIP_TRY(c, launch_mlp(variant, a, c->n_cu, s));
+    HIP_TRY(c, use_mx ? launch_mlp_mx(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     c->flop_alg += (double)n_pts * (variant == VAR_FULL ? FLOP_FULL : variant == VAR_TRUNK ? FLOP_TRUNK : FLOP_REFL);
     return IBLNERF_OK;
@@ -252,6 +289,19 @@ int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const 
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_samples,
                                  (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_range_status(iblnerf_ctx* c, int* out_of_range) {
+    if (!c || !out_of_range) return IBLNERF_ERR_INVALID;
+    *out_of_range = 0;
+    if (!c->d_range_flag) return IBLNERF_OK;
+    unsigned v = 0;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(&v, c->d_range_flag, sizeof v, hipMemcpyDeviceToHost));
+    if (v) HIP_TRY(c, hipMemset(c->d_range_flag, 0, sizeof v));
+    *out_of_range = v ? 1 : 0;
     return IBLNERF_OK;
 }
 

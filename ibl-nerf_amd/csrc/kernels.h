@@ -15,8 +15,10 @@ struct MlpArgs {
     float* out;           // [n_pts,18] (FULL) | [n_pts] (TRUNK) | [n_pts,13] (REFL)
     long n_pts;
     int pts_per_ray;
+    unsigned* range_flag; // f16 + MX-fp6 variant only: set to 1 if an input or activation left the f16 range (may be null)
 };
-hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);
+hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
+hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
 
 // --- per-ray kernels (render_kernels.hip) ------------------------------------------------------
 

@@ -1,0 +1,571 @@
+// Fused IBLNeRF forward, f16 + MX-fp6 product scheme (layout_mx.h) — the faster of the two variants of
+// the fused MLP kernel; mlp_kernel.hip (three bf16 products) is the wide-range variant it falls back to.
+// Replaces `run_network` + `IBLNeRF.forward_not_freezed` (src/nerf_models/ibl_nerf.py:236-252, :154-210;
+// encoder src/nerf_models/positional_embedder.py:4-52).
+//
+// Same skeleton as mlp_kernel.hip: one workgroup = 4 wavefronts (one per SIMD), 32 sample points per
+// wavefront whose 256-wide activation never leaves the register file, weights streamed once per 128
+// points through a 3-slot LDS ring by LDS-DMA, N=1/N=3 heads on the VALU from the fp32 accumulators.
+// Per K=64 block of a 32-row tile: 4 f16 MFMAs (main term) + 2 block-scaled fp6 MFMAs (the two
+// residual terms) into one fp32 accumulator = 6 "slots" of ~32 cycles.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+#include "layout_mx.h"
+#include "sincos_enc.h"
+
+namespace ibl {
+namespace mxk {
+
+using namespace ibl::mx;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// B operands of one K=64 block of this wave's 32 points: 4 f16 k-steps, fp6 of the f16 values, fp6 of
+// the f16 residuals, and the two e8m0 block scales (byte 0: x6, byte 1: l6).  29 registers.
+struct Blk {
+    u32x4 h[4];
+    u32x4 x6a, l6a;   // fp6 bits 0..127   (6-wide vectors are kept out of the structs: they defeat SROA)
+    u32x2 x6b, l6b;   // fp6 bits 128..191
+    unsigned sc;
+};
+struct Act { Blk b[4]; };   // 256 features
+
+// A operands read ahead from the LDS ring, 4 rotating entries: q for the four f16 slots of a block; q+d (+sc at
+// slot 4) for its two fp6 slots
+struct Pre {
+    u32x4 q[4];
+    u32x2 d[4];
+    unsigned sc[4];
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int SLOTS_PER_BLOCK = 6;
+constexpr int CHUNK_SLOTS = CHUNK_BLOCKS * SLOTS_PER_BLOCK;   // 24
+constexpr int PF = 4;                                          // A operands are read from LDS this many slots ahead (4 rotating entries:
+                                                               // the read for slot G+4 is issued right after slot G's MFMA has consumed its entry)
+constexpr int SYNC_SLOT = CHUNK_SLOTS - PF - 1;                // after this slot the next chunk must be readable
+// One DMA piece of the chunk two ahead is issued in each of 8 chunk-relative slots.  A piece costs its wave
+// 60+ cycles of issue, more when it meets LDS reads, so the slots chosen are those whose operand prefetch is a
+// single ds_read (block slots 2..5; slots 0 and 1 fetch the three- and two-read fp6 operands), in the first
+// half of the chunk so the data has a full chunk and a half to land before sync_next needs it.
+__host__ __device__ constexpr int dma_piece(int cr) {
+    const int b = cr / SLOTS_PER_BLOCK, s = cr % SLOTS_PER_BLOCK;
+    return (b < 2 && s >= 2) ? 4 * b + (s - 2) : -1;
+}
+// Tile-local slot after whose MFMA slice i of the previous tile's epilogue runs.  When the previous tile is
+// the last one of the PREVIOUS layer, its slices still write block 3 of this layer's input (f16 k-step 2 at
+// slice 3, k-step 3 + the fp6 forms at slice 7); that block's slots are the tile's last six, so slice 7 must
+// be done before the fourth-last slot issues.
+__host__ __device__ constexpr int slice_slot(int i, int ns) { return ns >= CHUNK_SLOTS ? 1 + (i * (ns - 5)) / 7 : 1 + (i * (ns - 1)) / 8; }
+
+// ---------------------------------------------------------------------------------------------
+// weight-stream pipeline (cf. Pipe in mlp_kernel.hip): cyclic, never drained.  While chunk c is
+// consumed, chunk c+1 has landed or is landing and chunk c+2 is being issued.  Because operands are
+// read PF slots ahead, the "next chunk has landed" wait + barrier sits PF+1 slots BEFORE the chunk
+// boundary (sync_next), and the ring indices rotate at the boundary itself (advance).
+// ---------------------------------------------------------------------------------------------
+template <int VARIANT>
+struct Pipe {
+    static constexpr int N_PROG = VARIANT == VAR_FULL ? mx::N_CHUNKS : (VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK : mx::N_CHUNKS - 8);
+    const char* stream;
+    char* ring;
+    unsigned lds_ring;
+    unsigned voff;
+    int lane, wave;
+    int slot, slot1, slot2;   // ring slots of the chunk being consumed, the next one, the one two ahead
+    int prog2;                // program position of the chunk two ahead
+
+    __device__ __forceinline__ static int stream_chunk(int p) {
+        if (VARIANT == VAR_REFL) return p < mx::CH_ALB ? p : p + 8;   // the reflected-ray variant skips albedo / irradiance features
+        return p;
+    }
+    // Piece i of a chunk (wave w copies bytes [8192 w, 8192 w + 8192) in 8 pieces of 1 KiB).  The instruction's
+    // immediate offset moves BOTH the global and the LDS address, so pieces 0..3 (and 4..7) share one M0 value
+    // and one address register; M0 is rewritten only at pieces 0 and 4.
+    template <int I>
+    __device__ __forceinline__ void issue_piece(int prog, int slt) const {
+#ifdef IBL_MX_ABLATE_NO_LOADS   // timing ablation only (results are garbage): no weight traffic
+        return;
+#endif
+        const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
+        const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + (I / 4) * 4096;
+        const unsigned v = voff + (I / 4) * 4096;
+        if constexpr (I % 4 != 0) {
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(v), "s"(src), "n"((I % 4) * 1024) : "memory");
+            return;
+        }
+        // M0 (the DMA's LDS base) is left holding `dst`: nothing else in this kernel reads M0 (gfx9+ DS and
+        // lane instructions do not), which scratch/mxdev.sh checks in the generated ISA; saving and restoring
+        // it cost two more SALU issues per piece in a loop that is issue-bound.
+        asm volatile(
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %2"
+            :
+            : "v"(v), "s"(dst), "s"(src)
+            : "memory");
+    }
+    __device__ __forceinline__ void start() {
+        static_for<0, 8>([&](auto I) { issue_piece<decltype(I)::value>(0, 0); });
+        static_for<0, 8>([&](auto I) { issue_piece<decltype(I)::value>(1, 1); });
+        slot = 0;
+        slot1 = 1;
+        slot2 = 2;
+        prog2 = 2;
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
+    // byte address of block `blk` of the current / next chunk, this lane's 16-byte column
+    __device__ __forceinline__ const char* block(bool next, int blk) const {
+        return ring + (next ? slot1 : slot) * CHUNK_BYTES + blk * BLOCK_BYTES;
+    }
+    template <int I>
+    __device__ __forceinline__ void prefetch_piece() const { issue_piece<I>(prog2, slot2); }
+    // The next chunk's 8 pieces have landed (mine: vmcnt; everyone's: barrier).  The barrier is also the WAR
+    // fence for the DMA that overwrites this chunk's ring slot two chunks from now: every wave has ISSUED all its
+    // reads of the current chunk before it arrives here (they run PF slots ahead), the first DMA piece into this
+    // ring slot is issued at least PF + 3 slots (>200 cycles) after the barrier releases and its data
+    // returns from L2 several hundred cycles later still, while an issued ds_read completes in ~100 cycles.
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ void advance() {
+        slot = slot1;
+        slot1 = slot2;
+        slot2 = slot2 == RING_SLOTS - 1 ? 0 : slot2 + 1;
+        prog2 = prog2 == N_PROG - 1 ? 0 : prog2 + 1;
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+template <int KIND, int E>
+__device__ __forceinline__ void load_frag(Pre& pf, const char* blk, int lane) {
+    if constexpr (KIND < 4) {
+        pf.q[E] = *reinterpret_cast<const u32x4*>(blk + OFF_F16 + KIND * 1024 + lane * 16);
+    } else if constexpr (KIND == 4) {
+        pf.q[E] = *reinterpret_cast<const u32x4*>(blk + OFF_W6A + lane * 16);
+        pf.d[E] = *reinterpret_cast<const u32x2*>(blk + OFF_W6B + lane * 8);
+        pf.sc[E] = *reinterpret_cast<const unsigned*>(blk + OFF_SC + lane * 4);
+    } else {
+        pf.q[E] = *reinterpret_cast<const u32x4*>(blk + OFF_R6A + lane * 16);
+        pf.d[E] = *reinterpret_cast<const u32x2*>(blk + OFF_R6B + lane * 8);
+    }
+}
+
+// 192 bits of fp6 in the low six dwords of the MFMA's 8-dword operand (the upper two are not read for fp6)
+// The two pieces go through an empty asm first: otherwise the optimiser turns "load 4 dwords, widen to 8 with
+// undefined tail" into ONE 8-dword load that runs over the neighbouring struct members, and objects accessed
+// with such overlapping loads are no longer promoted to registers (everything lands in scratch memory).
+template <bool PIN>
+__device__ __forceinline__ i32x8 fp6_operand(const u32x4& q, const u32x2& d) {
+    u32x4 qq = q;
+    u32x2 dd = d;
+    if constexpr (PIN) asm("" : "+v"(qq), "+v"(dd));   // needed for every operand that lives in a struct before SROA (Blk AND Pre)
+    i32x8 v;
+    v[0] = (int)qq[0];
+    v[1] = (int)qq[1];
+    v[2] = (int)qq[2];
+    v[3] = (int)qq[3];
+    v[4] = (int)dd[0];
+    v[5] = (int)dd[1];
+    return v;
+}
+
+// slot s of a block: accumulate one of the six products
+template <int S>
+__device__ __forceinline__ f32x16 slot_mfma(const u32x4& aq, const u32x2& ad, unsigned wsc, const Blk& b, f32x16 c) {
+    if constexpr (S < 4) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq), __builtin_bit_cast(f16x8, b.h[S]), c, 0, 0, 0);
+    } else if constexpr (S == 4) {   // fp6(W) [scale byte 0] x fp6(X - f16 X) [scale byte 1]
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(aq, ad), fp6_operand<true>(b.l6a, b.l6b), c, 2, 2, 0, (int)wsc, 1, (int)b.sc);
+    } else {                         // fp6(W - f16 W) [scale byte 1] x fp6(f16 X) [scale byte 0]
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(aq, ad), fp6_operand<true>(b.x6a, b.x6b), c, 2, 2, 1, (int)wsc, 0, (int)b.sc);
+    }
+}
+
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
+// (x0, x1) -> packed f16 pair h = rne(x) and packed f16 pair of the residuals x - h
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hb, unsigned& lb) {
+    const f32x2 xv = {x0, x1};
+    hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));
+    // x - (float)h in one instruction each (v_fma_mix reads the f16 half directly); plain C++ costs cvt + sub
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x0), "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x1), "v"(hb));
+    const f32x2 lv = {l0, l1};
+    lb = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, f16x2));
+}
+
+// Completes a block once its 32 f16 values (b.h) and their residuals (lres, same element order) are in
+// registers: block scale from the running max, fp6 forms of both, scale bytes.  `peak` keeps the
+// largest magnitude seen (for the f16 range check at the end of the kernel).
+__device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mxv, unsigned& peak) {
+    unsigned mb = (unsigned)mxv;
+    peak = mb > peak ? mb : peak;
+    mb = mb > 0x0d800000u ? mb : 0x0d800000u;          // >= 2^-100: an all-zero block gets a harmless tiny scale
+    const unsigned e = mb >> 23;                        // biased exponent of the block max
+    const float sh = __builtin_bit_cast(float, (e - 2) << 23);    // max / sh in [4, 8)
+    const float sl = __builtin_bit_cast(float, (e - 14) << 23);   // |residual| <= 2^(e-11) -> / sl <= 8
+    u32x4 h0 = b.h[0], h1 = b.h[1], h2 = b.h[2], h3 = b.h[3];
+    asm("" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));   // (see fp6_operand: keeps the optimiser from fusing these into one 64-byte load)
+    const u32x16 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3], h2[0], h2[1], h2[2], h2[3], h3[0], h3[1], h3[2], h3[3]};
+    const auto x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), sh);
+    const auto l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, lres), sl);
+    b.x6a = u32x4{(unsigned)x6[0], (unsigned)x6[1], (unsigned)x6[2], (unsigned)x6[3]};
+    b.x6b = u32x2{(unsigned)x6[4], (unsigned)x6[5]};
+    b.l6a = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
+    b.l6b = u32x2{(unsigned)l6[4], (unsigned)l6[5]};
+    b.sc = (e - 2) | ((e - 14) << 8);
+    mxv = 0;
+}
+
+// Epilogue of one finished 32-feature tile in 8 slices of two accumulator registers (cf. Epi in
+// mlp_kernel.hip).  STORE: v = [ReLU](acc) -> f16 k-steps 2(T&1), 2(T&1)+1 of block T>>1 of `dst`, residuals
+// staged in `lres`; after the odd tile of a pair the block is finished (scales + fp6 forms).
+// NCH: running fp32 dot products with N=1/3 head rows.
+template <bool STORE, bool RELU, int NCH>
+struct Epi {
+    Act* dst;
+    float* part[NCH > 0 ? NCH : 1];
+    const float* tab[NCH > 0 ? NCH : 1];
+    unsigned* peak;
+    u32x16 lres;
+    u32x4 hq;
+    int mxv;   // running block max as the int image of a non-negative float (ordering is the same; one v_max3_i32 per pair)
+
+    template <int T, int I>
+    __device__ __forceinline__ void slice(const f32x16& acc) {
+        float x0 = acc[2 * I], x1 = acc[2 * I + 1];
+        if constexpr (STORE) {
+            // block max on the raw accumulator bits: with ReLU a negative value (negative int) never wins and the
+            // max of the survivors is the max after ReLU; without it the sign bit is cleared first
+            const int b0 = __builtin_bit_cast(int, x0), b1 = __builtin_bit_cast(int, x1);
+            if constexpr (RELU) mxv = max(mxv, max(b0, b1));
+            else mxv = max(mxv, max(b0 & 0x7fffffff, b1 & 0x7fffffff));
+        }
+        if constexpr (RELU) {
+            x0 = relu_bits(x0);
+            x1 = relu_bits(x1);
+        }
+        if constexpr (STORE) {
+            constexpr int j = 2 * (T & 1) + (I >> 2);   // f16 k-step of the block
+            unsigned hb, lb;
+            split_pair(x0, x1, hb, lb);
+            hq[I & 3] = hb;
+            lres[4 * j + (I & 3)] = lb;
+            if constexpr ((I & 3) == 3) {
+                asm volatile("" : "+v"(hq));
+                dst->b[T >> 1].h[j] = hq;
+            }
+            if constexpr (I == 7 && (T & 1) == 1) finish_block(dst->b[T >> 1], lres, mxv, *peak);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x2 w = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
+            *part[c] = fmaf(x1, w[1], fmaf(x0, w[0], *part[c]));
+            if constexpr (I == 7) pin(*part[c]);
+        }
+    }
+};
+
+// One layer: NT output tiles; per tile an optional encoding block then NH (4 or 0) blocks over the
+// 256-feature activation `in`; 6 slots per block.  Software pipeline (one wave per SIMD):
+//   * the A operand of slot G+PF is read from LDS at slot G (pf[] is carried across tiles and layers);
+//   * the previous tile's epilogue runs in 8 slices spread over this tile's slots;
+//   * one LDS-DMA piece of the chunk two ahead in each of the 8 slots dma_piece() names;
+//   * sched_barrier(0) fences keep that order at slot granularity.
+template <int NT, bool HAS_ENC, int NH, int VARIANT, class PEND, class EPI>
+__device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned& wsc, const Act& in, const Blk& enc,
+                                            const float* bias_tab, PEND&& pend, EPI& epi) {
+    constexpr int NB = (HAS_ENC ? 1 : 0) + NH;   // blocks per tile
+    constexpr int NS = NB * SLOTS_PER_BLOCK;     // slots per tile
+    static_assert((NT * NS) % CHUNK_SLOTS == 0, "a layer is a whole number of chunks");
+    f32x16 prev = {0};
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);   // the chain starts at the layer bias
+        static_for<0, NS>([&](auto GS) {
+            constexpr int g = decltype(GS)::value;   // slot inside the tile
+            constexpr int G = t * NS + g;            // slot inside the layer
+            constexpr int cr = G % CHUNK_SLOTS;      // slot inside the chunk
+            constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
+            if constexpr (s == 4) wsc = pf.sc[G % 4];
+            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
+            else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
+            // A operand of slot G + PF, into the entry this slot's MFMA has just consumed
+            {
+                constexpr int Gp = G + PF;
+                constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
+                constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+            }
+            if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
+#ifndef IBL_MX_ABLATE_NO_EPI     // timing ablation only: no epilogue work
+            static_for<0, 8>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (g == slice_slot(i, NS)) {
+                    if constexpr (t == 0) pend(I);
+                    else epi.template slice<(t > 0 ? t - 1 : 0), i>(prev);
+                }
+            });
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (cr == SYNC_SLOT) P.sync_next();
+            if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
+        });
+        asm volatile("" : "+a"(acc));   // keep the finished chain where it is; its consumer is the deferred epilogue
+                                        // ("+v" instead sends the accumulators through scratch memory: 4.5x slower)
+        prev = acc;
+    });
+    return prev;
+}
+
+// [x, sin(2^k x), cos(2^k x)] in the slot order of layout.h::enc_ref_index -> one block
+template <int PAIRS>
+__device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& enc, unsigned& peak) {
+    float vals[32];
+    const float mul = h ? (float)(1 << (PAIRS / 3)) : 1.0f;
+    const TurnPair tx = to_turns(x), ty = to_turns(y), tz = to_turns(z);
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+        const TurnPair tc = (u % 3 == 0) ? tx : ((u % 3 == 1) ? ty : tz);
+        sincos_turns(tc, (float)(1 << (u / 3)) * mul, &vals[2 * u], &vals[2 * u + 1]);
+    }
+    vals[2 * PAIRS] = h ? z : x;
+    vals[2 * PAIRS + 1] = h ? 0.0f : y;
+#pragma unroll
+    for (int i = 2 * PAIRS + 2; i < 32; ++i) vals[i] = 0.0f;
+    u32x16 lres;
+    int mxv = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned hb, lb;
+            split_pair(vals[8 * j + 2 * e], vals[8 * j + 2 * e + 1], hb, lb);
+            hv[e] = hb;
+            lres[4 * j + e] = lb;
+            mxv = max(mxv, max(__builtin_bit_cast(int, vals[8 * j + 2 * e]) & 0x7fffffff, __builtin_bit_cast(int, vals[8 * j + 2 * e + 1]) & 0x7fffffff));
+        }
+        enc.h[j] = hv;
+    }
+    finish_block(enc, lres, mxv, peak);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    float* tabs = reinterpret_cast<float*>(smem + LDS_RING_BYTES);
+    for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
+        reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
+    __syncthreads();
+    const float* ltab = tabs + h * 16;
+
+#ifdef IBL_MX_ABLATE_NO_LOADS
+    for (int i = threadIdx.x; i < LDS_RING_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+#endif
+    Pipe<VARIANT> P;
+    P.stream = a.stream;
+    P.ring = smem;
+    P.lane = lane;
+    P.wave = wave;
+    P.lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    P.voff = lane * 16 + wave * 8192;
+    P.start();
+    Pre pf;
+    load_frag<0, 0>(pf, P.block(false, 0), lane);
+    load_frag<1, 1>(pf, P.block(false, 0), lane);
+    load_frag<2, 2>(pf, P.block(false, 0), lane);
+    load_frag<3, 3>(pf, P.block(false, 0), lane);
+    unsigned wsc = 0, peak = 0;
+
+    const long n_groups = (a.n_pts + 127) / 128;
+    for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const long p = g * 128 + wave * 32 + (lane & 31);
+        const bool valid = p < a.n_pts;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) {
+            px = a.pts[3 * p + 0];
+            py = a.pts[3 * p + 1];
+            pz = a.pts[3 * p + 2];
+        }
+        Blk pe, de;
+        encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak);
+        if constexpr (VARIANT != VAR_TRUNK) {
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (valid) {
+                const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;
+                dx = a.dirs[3 * (size_t)r + 0];
+                dy = a.dirs[3 * (size_t)r + 1];
+                dz = a.dirs[3 * (size_t)r + 2];
+            }
+            encode<DE_PAIRS_PER_HALF>(dx, dy, dz, h, de, peak);
+        }
+
+        Act A, B;
+        float part[RAW_CH];
+#pragma unroll
+        for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
+        const float* bias = ltab + TAB_BIAS;
+        auto none = [](auto) {};
+        auto flush = [&](auto& e, auto T, const f32x16& acc) {
+            static_for<0, 8>([&](auto I) { e.template slice<decltype(T)::value, decltype(I)::value>(acc); });
+        };
+        using T7 = std::integral_constant<int, 7>;
+        using T3 = std::integral_constant<int, 3>;
+        Epi<true, true, 0> eA{&A, {nullptr}, {nullptr}, &peak}, eB{&B, {nullptr}, {nullptr}, &peak};
+
+        // positions_linears.0 : 63 -> 256, ReLU (-> A)
+        f32x16 pacc = run_layer<8, true, 0>(P, pf, wsc, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
+        // positions_linears.1..4, two layers per trip (A -> B -> A)
+        for (int l = 1; l <= 3; l += 2) {
+            pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
+                                          [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+            pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
+                                          [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
+        }
+        // positions_linears.5 : cat([x63, h]) (ibl_nerf.py:167-168) (A -> B)
+        pacc = run_layer<8, true, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 40) * 32,
+                                     [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+        // positions_linears.6 (B -> A)
+        pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 48) * 32,
+                                      [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
+        // positions_linears.7 (A -> B); sigma_linear / roughness_linear on its fp32 activations
+        auto e7 = [&] {
+            if constexpr (VARIANT == VAR_FULL)
+                return Epi<true, true, 2>{&B, {&part[0], &part[4]}, {ltab + TAB_SIG, ltab + TAB_ROUGH}, &peak};
+            else
+                return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}, &peak};
+        }();
+        pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 56) * 32,
+                                      [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, e7);
+
+        if constexpr (VARIANT == VAR_TRUNK) {
+            flush(e7, T7{}, pacc);
+        } else {
+            // feature_linear : no activation (B = h7 -> A = feature)
+            Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}, &peak};
+                pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + BT_FEAT * 32,
+                                          [&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); }, eFeat);
+            Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
+                                     {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}, &peak};
+            Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}, &peak};
+            if constexpr (VARIANT == VAR_FULL) {
+                f32x16 qacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_ALB * 32,
+                                                     [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eAlb);
+                pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_IRR * 32,
+                                              [&](auto I) { eAlb.template slice<3, decltype(I)::value>(qacc); }, eIrr);
+            }
+            // views_linears.0 : cat([feature, dir27]) (A -> B); radiance_linear
+            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]},
+                                     {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}, &peak};
+                pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, [&](auto I) {
+                if constexpr (VARIANT == VAR_FULL) eIrr.template slice<3, decltype(I)::value>(pacc);
+                else eFeat.template slice<7, decltype(I)::value>(pacc);
+            }, eView);
+            Epi<false, true, 3> eAr0{nullptr, {&part[9], &part[10], &part[11]},
+                                     {ltab + TAB_AR, ltab + TAB_AR + 128, ltab + TAB_AR + 256}, &peak};
+            Epi<false, true, 3> eAr1{nullptr, {&part[12], &part[13], &part[14]},
+                                     {ltab + TAB_AR + 384, ltab + TAB_AR + 512, ltab + TAB_AR + 640}, &peak};
+            Epi<false, true, 3> eAr2{nullptr, {&part[15], &part[16], &part[17]},
+                                     {ltab + TAB_AR + 768, ltab + TAB_AR + 896, ltab + TAB_AR + 1024}, &peak};
+            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32,
+                                          [&](auto I) { eView.template slice<7, decltype(I)::value>(pacc); }, eAr0);
+            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 4) * 32,
+                                          [&](auto I) { eAr0.template slice<3, decltype(I)::value>(pacc); }, eAr1);
+            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 8) * 32,
+                                          [&](auto I) { eAr1.template slice<3, decltype(I)::value>(pacc); }, eAr2);
+            flush(eAr2, T3{}, pacc);
+        }
+
+        const float* sc = tabs + TAB_SCALAR;
+        if constexpr (VARIANT == VAR_TRUNK) {
+            const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
+            if (valid && h == 0) a.out[p] = s;
+        } else {
+            float tot[RAW_CH];
+#pragma unroll
+            for (int c = 0; c < RAW_CH; ++c) tot[c] = part[c] + __shfl_xor(part[c], 32) + sc[c];
+            if (valid) {
+                if constexpr (VARIANT == VAR_FULL) {
+                    float* o = a.out + p * RAW_CH;
+                    if (h == 0) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) o[c] = tot[c];
+                    } else {
+#pragma unroll
+                        for (int c = 9; c < 18; ++c) o[c] = tot[c];
+                    }
+                } else {
+                    float* o = a.out + p * REFL_CH;
+                    if (h == 0) {
+                        o[0] = tot[0];
+#pragma unroll
+                        for (int c = 1; c < 7; ++c) o[c] = tot[5 + c];
+                    } else {
+#pragma unroll
+                        for (int c = 7; c < 13; ++c) o[c] = tot[5 + c];
+                    }
+                }
+            }
+        }
+    }
+    P.drain();
+    // f16 range check: any encoded input or activation at or beyond 65520 overflowed its f16 form
+    if (a.range_flag != nullptr && peak >= 0x477ff000u) atomicOr(a.range_flag, 1u);
+}
+
+}  // namespace mxk
+
+hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
+    if (a.n_pts <= 0) return hipSuccess;
+    const long n_groups = (a.n_pts + 127) / 128;
+    const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
+    static bool attr_set = false;
+    if (!attr_set) {
+#ifndef IBL_MX_DEV_TRUNK_ONLY
+        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#endif
+        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    switch (variant) {
+#ifndef IBL_MX_DEV_TRUNK_ONLY   // development builds: one instantiation compiles in a third of the time
+        case VAR_FULL: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+        case VAR_REFL: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+#endif
+        case VAR_TRUNK: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ibl

@@ -2,9 +2,11 @@
 // layer, in the registration order of src/nerf_models/ibl_nerf.py:45-72) -> the device chunk
 // stream + side tables described in layout.h.  Pure CPU code, no HIP calls.
 #include "pack.h"
+#include "layout_mx.h"
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace ibl {
 
@@ -152,6 +154,117 @@ void pack_network(const float* blob, void* stream_out, float* tab) {
     for (int c = 0; c < 3; ++c) sc[6 + c] = n.b[L_RAD][c];
     for (int k = 0; k < 3; ++k)
         for (int c = 0; c < 3; ++c) sc[9 + 3 * k + c] = n.b[L_AR0 + k][c];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// f16 + MX-fp6 stream (layout_mx.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+inline uint16_t f16_bits(float f) { const _Float16 h = (_Float16)f; uint16_t u; std::memcpy(&u, &h, 2); return u; }
+inline float f16_round(float f) { return (float)(_Float16)f; }
+
+// round-to-nearest-even e2m3 code of x (|x| saturates at 7.5)
+inline int fp6_encode(float x) {
+    const float a = std::fabs(x);
+    int c;
+    if (a < 1.0f) c = (int)std::nearbyint(a * 8.0f);                      // subnormals m/8, and 1.0 = code 8
+    else if (a < 2.0f) c = 8 + (int)std::nearbyint((a - 1.0f) * 8.0f);
+    else if (a < 4.0f) c = 16 + (int)std::nearbyint((a - 2.0f) * 4.0f);
+    else c = 24 + (int)std::nearbyint((a - 4.0f) * 2.0f);
+    if (c > 31) c = 31;
+    return c | (x < 0.0f ? 32 : 0);
+}
+
+// 32 values of one lane -> 6 dwords of fp6 codes + the e8m0 byte of their shared scale 2^(floor(log2 max) - 2)
+inline uint8_t fp6_block(const float* v, uint32_t out[6]) {
+    float mx = 0.0f;
+    for (int j = 0; j < 32; ++j) mx = std::fmax(mx, std::fabs(v[j]));
+    for (int q = 0; q < 6; ++q) out[q] = 0;
+    if (!(mx > 0.0f)) return 127;
+    int ex;
+    std::frexp(mx, &ex);                       // mx = m * 2^ex, m in [0.5, 1): floor(log2 mx) = ex - 1
+    int se = ex - 1 - 2;
+    if (se < -126) se = -126;
+    if (se > 127) se = 127;
+    const float inv = std::ldexp(1.0f, -se);
+    for (int j = 0; j < 32; ++j) {
+        const int code = fp6_encode(v[j] * inv);
+        const int bit = 6 * j;
+        out[bit >> 5] |= (uint32_t)code << (bit & 31);
+        if ((bit & 31) > 26) out[(bit >> 5) + 1] |= (uint32_t)code >> (32 - (bit & 31));
+    }
+    return (uint8_t)(se + 127);
+}
+
+// one 8 KiB block: w(i, h, jj) = weight of tile row i for k-slot jj (0..31) of lane half h
+template <class WF>
+void pack_block(char* blk, WF&& w) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, h = lane >> 5;
+        float full[32], res[32];
+        for (int jj = 0; jj < 32; ++jj) {
+            const float x = w(i, h, jj);
+            const uint16_t hb = f16_bits(x);
+            std::memcpy(blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2, &hb, 2);
+            full[jj] = x;
+            res[jj] = x - f16_round(x);
+        }
+        uint32_t c6[6], r6[6];
+        const uint32_t sw = fp6_block(full, c6), sr = fp6_block(res, r6);
+        std::memcpy(blk + mx::OFF_W6A + lane * 16, c6, 16);
+        std::memcpy(blk + mx::OFF_R6A + lane * 16, r6, 16);
+        std::memcpy(blk + mx::OFF_W6B + lane * 8, c6 + 4, 8);
+        std::memcpy(blk + mx::OFF_R6B + lane * 8, r6 + 4, 8);
+        const uint32_t sc = sw | (sr << 8);
+        std::memcpy(blk + mx::OFF_SC + lane * 4, &sc, 4);
+    }
+}
+
+// the 4 blocks of rows [row0, row0+32) of layer l over a 256-feature activation (columns from col_base)
+void pack_h_mx(char* blk0, const Net& n, int l, int row0, int col_base) {
+    for (int b = 0; b < 4; ++b)
+        pack_block(blk0 + (size_t)b * mx::BLOCK_BYTES, [&](int i, int h, int jj) {
+            const int j = jj >> 3, e = jj & 7;
+            return n.W(l, row0 + i, col_base + 32 * (2 * b + (j >> 1)) + acc_feature(8 * (j & 1) + e, h));
+        });
+}
+// the one encoding block of rows [row0, row0+32)
+void pack_enc_mx(char* blk, const Net& n, int l, int row0, int col_base, int pairs_per_half) {
+    pack_block(blk, [&](int i, int h, int jj) {
+        const int ref = enc_ref_index(jj, h, pairs_per_half);
+        return ref < 0 ? 0.0f : n.W(l, row0 + i, col_base + ref);
+    });
+}
+
+}  // namespace
+
+void pack_network_mx(const float* blob, void* stream_out, float* tab) {
+    std::vector<char> scratch((size_t)STREAM_BYTES);
+    pack_network(blob, scratch.data(), tab);          // the side tables are common to both variants
+    const Net n(blob);
+    char* s = reinterpret_cast<char*>(stream_out);
+    std::memset(s, 0, mx::STREAM_BYTES);
+    auto at = [&](int chunk, int block = 0) { return s + (size_t)chunk * CHUNK_BYTES + (size_t)block * mx::BLOCK_BYTES; };
+    for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF);
+    for (int l = 1; l <= 4; ++l)
+        for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L1 + 8 * (l - 1) + t), n, L_POS0 + l, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) {                     // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
+        pack_enc_mx(at(mx::CH_L5, 5 * t), n, L_POS5, 32 * t, 0, PE_PAIRS_PER_HALF);
+        pack_h_mx(at(mx::CH_L5, 5 * t + 1), n, L_POS5, 32 * t, 63);
+    }
+    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L6 + t), n, L_POS6, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L7 + t), n, L_POS7, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_FEAT + t), n, L_FEATURE, 32 * t, 0);
+    for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_ALB + t), n, L_ALB_F, 32 * t, 0);
+    for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_IRR + t), n, L_IRR_F, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) {                     // views_linears.0: [feature256 | dir27] (ibl_nerf.py:194)
+        pack_enc_mx(at(mx::CH_VIEW, 5 * t), n, L_VIEWS, 32 * t, 256, DE_PAIRS_PER_HALF);
+        pack_h_mx(at(mx::CH_VIEW, 5 * t + 1), n, L_VIEWS, 32 * t, 0);
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_AR + 4 * k + t), n, L_AR_F0 + k, 32 * t, 0);
 }
 
 }  // namespace ibl

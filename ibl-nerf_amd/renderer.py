@@ -52,8 +52,16 @@ class Renderer:
 
     def __init__(self, N_samples=64, N_importance=128, *, epsilon=0.01, gamma_correct=True, lut_coefficient="F",
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
-                 max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False):
+                 max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
+                 mlp_precision=None):
+        """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
+        rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
+        activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
+        repeat the call on a bf16x3 context, so results never depend on the choice beyond round-off."""
         torch = _torch()
+        mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
+        if mlp_precision not in ("bf16x3", "f16_mxfp6"):
+            raise ValueError("mlp_precision must be 'bf16x3' or 'f16_mxfp6'")
         if not torch.cuda.is_available():
             raise B.IblNerfError("no HIP device visible to torch: the render path has no CPU fallback")
         if lut_coefficient not in ("F", "F0"):
@@ -71,6 +79,16 @@ class Renderer:
         o.device = self.device.index
         o.lindisp = int(bool(lindisp))
         o.use_radiance_linear = int(bool(use_radiance_linear))
+        o.mlp_precision = B.MLP_F16_MXFP6 if mlp_precision == "f16_mxfp6" else B.MLP_BF16X3
+        self.mlp_precision = mlp_precision
+        self._ctor = dict(N_samples=N_samples, N_importance=N_importance, epsilon=epsilon, gamma_correct=gamma_correct,
+                          lut_coefficient=lut_coefficient,
+                          correct_depth_for_prefiltered_radiance_infer=correct_depth_for_prefiltered_radiance_infer,
+                          coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
+                          lindisp=lindisp, use_radiance_linear=use_radiance_linear)
+        self._wide = None            # bf16x3 twin, created on the first out-of-range event
+        self._blobs, self._lut = {}, None
+        self.range_fallbacks = 0
         self.opt = o
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
         self.coarse_outputs = bool(coarse_outputs)
@@ -98,6 +116,10 @@ class Renderer:
             blob = ck.state_dict_to_blob(blob)
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
+        if self.mlp_precision == "f16_mxfp6":
+            self._blobs[int(which)] = blob
+            if self._wide is not None:
+                self._wide.load_weights(which, blob)
 
     def load_lut(self, lut):
         """lut: float [3,512,512] exactly as test.py:79-87 builds `brdf_lut`."""
@@ -107,6 +129,29 @@ class Renderer:
         if lut.shape != (3, 512, 512):
             raise ValueError("brdf_lut must have shape [3,512,512], got %s" % (lut.shape,))
         B.check(self.ctx, self.lib.iblnerf_upload_lut(self.ctx, lut.ctypes.data))
+        if self.mlp_precision == "f16_mxfp6":
+            self._lut = lut
+            if self._wide is not None:
+                self._wide.load_lut(lut)
+
+    def out_of_range(self):
+        """f16_mxfp6 only: True if an MLP launch since the last check left the f16 range (synchronises)."""
+        if self.mlp_precision != "f16_mxfp6":
+            return False
+        flag = C.c_int()
+        B.check(self.ctx, self.lib.iblnerf_range_status(self.ctx, C.byref(flag)))
+        return bool(flag.value)
+
+    def _wide_twin(self):
+        """The bf16x3 context a call is repeated on after an out-of-range event."""
+        if self._wide is None:
+            self._wide = Renderer(mlp_precision="bf16x3", **self._ctor)
+            for which, blob in self._blobs.items():
+                self._wide.load_weights(which, blob)
+            if self._lut is not None:
+                self._wide.load_lut(self._lut)
+        self.range_fallbacks += 1
+        return self._wide
 
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
@@ -142,6 +187,8 @@ class Renderer:
         out = torch.empty((N, S, 18 if vd is not None else 1), dtype=torch.float32, device=self.device)
         B.check(self.ctx, self.lib.iblnerf_network_query(self.ctx, self._stream(), int(which), inputs.data_ptr(), N, S,
                                                          None if vd is None else vd.data_ptr(), out.data_ptr()))
+        if self.out_of_range():
+            return self._wide_twin().network_query(inputs, vd, which)
         return out
 
     def sample_pdf(self, bins, weights, N_samples):
@@ -197,6 +244,8 @@ class Renderer:
                                                        float(near), float(far), C.byref(ov) if ov is not None else None,
                                                        C.byref(outs)))
         self._keep = keep   # override rows must outlive the asynchronous launch
+        if self.out_of_range():
+            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, **edit)
         res = {k: t_fine[k] for k in RESULT_ORDER}
         for k in RESULT_ORDER:
             if k in t_coarse:
@@ -306,6 +355,7 @@ def _check_supported(kw):
 
 
 _renderers = {}
+DEFAULT_MLP_PRECISION = "bf16x3"
 
 
 def _weights_key(net):
@@ -326,14 +376,15 @@ def renderer_for(kw):
     key = (int(kw["N_samples"]), N_imp, float(kw.get("epsilon", 0.01)), bool(kw.get("gamma_correct", False)),
            kw.get("lut_coefficient"), bool(kw.get("correct_depth_for_prefiltered_radiance_infer", False)),
            bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device(),
-           bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)))
+           bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)),
+           kw.get("mlp_precision") or DEFAULT_MLP_PRECISION)
     ent = _renderers.get(key)
     if ent is None:
         if kw.get("lut_coefficient") not in ("F", "F0"):
             raise ValueError(kw.get("lut_coefficient"))                               # ibl_nerf_renderer.py:437-438
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
-                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10])
+                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

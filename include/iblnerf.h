@@ -52,7 +52,14 @@ typedef struct {
     int32_t device;                    /* HIP device ordinal */
     int32_t lindisp;                   /* 0 (shipped) | 1: sample linearly in inverse depth (ibl_nerf_renderer.py:673-674) */
     int32_t use_radiance_linear;       /* 0 (shipped, sigmoid radiance) | 1: ReLU radiance + Reinhard LDR map (:30-35, :480-483) */
+    int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
+                                          1e-3 parity bar; no reference counterpart):
+                                          IBLNERF_MLP_BF16X3    three bf16 products on hi/lo splits, fp32 range
+                                          IBLNERF_MLP_F16_MXFP6 one f16 product + two block-scaled fp6 residual products,
+                                                                ~2x faster; inputs, weights and activations must stay
+                                                                below 65504 — see iblnerf_range_status */
 } iblnerf_options;
+enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
 
 void iblnerf_default_options(iblnerf_options* o);
 
@@ -153,6 +160,17 @@ typedef struct {
 int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d,
                         int64_t n_rays, float near_, float far_, const iblnerf_overrides* overrides,
                         const iblnerf_outputs* outputs);
+
+/* IBLNERF_MLP_F16_MXFP6 only.  Synchronises the device and reports in *out_of_range whether any MLP launch on
+ * this ctx since the last call saw an encoded input or activation at or beyond the f16 range (65504); the flag
+ * is cleared.  When it is 1 the affected outputs are invalid: render again on a ctx created with
+ * IBLNERF_MLP_BF16X3 (ibl-nerf_amd/renderer.py does this automatically).  Always 0 for IBLNERF_MLP_BF16X3. */
+int iblnerf_range_status(iblnerf_ctx* ctx, int* out_of_range);
+
+/* Host-only: the IBLNERF_MLP_F16_MXFP6 weight-stream format (csrc/layout_mx.h), for the CPU layout tests. */
+int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                                 float* h_tables, size_t table_floats);
+size_t iblnerf_stream_bytes_mx(void);
 
 /* Timing aid for bench.py: HIP-event time (ms) of the MLP kernels launched by the last
  * iblnerf_render_rays call on this ctx, and their count.  Enabled by iblnerf_set_profiling(ctx, 1),

@@ -27,6 +27,9 @@ def R():
     return renderer
 
 
+PRECISIONS = ["bf16x3", "f16_mxfp6"]   # the two product schemes of the fused MLP kernel (include/iblnerf.h: mlp_precision)
+
+
 def make_renderer(R, g, sdc, sdf, lut, **kw):
     kw = dict(golden_flags(g), **kw)
     r = R.Renderer(n_samples(g), int(g["n_importance"]), **kw)
@@ -82,12 +85,13 @@ def test_sample_pdf(R):
         r.sample_pdf(sv["sp_bins"], sv["sp_weights"][:, :-1].copy(), 8)
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
-def test_network_query_stagewise(R, name, lut):
+def test_network_query_stagewise(R, name, lut, prec):
     """Teacher-forced MLP: the reference's own query inputs -> its recorded raw outputs.
-    bf16x3 (hi/lo split, 3 MFMA products): ~2^-17 per operand, 8-12 layers deep."""
+    bf16x3 (hi/lo split, 3 MFMA products): ~2^-17 per operand, 8-12 layers deep; f16 + MX-fp6 residuals: ~2^-16."""
     g, sdc, sdf, _, _ = load_golden(name)
-    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision=prec)
     tol = 6e-5 if float(g["gain"]) == 1.0 else 6e-4
     passes = [("c", 0)] + ([("f", 1)] if int(g["n_importance"]) > 0 else [])
     for p, which in passes:
@@ -98,13 +102,15 @@ def test_network_query_stagewise(R, name, lut):
         assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= tol
         refl = r.network_query(g["q_%s_refl_pts" % p], g["q_%s_refl_dirs" % p], which).cpu().numpy()
         assert np.abs(refl - g["q_%s_refl_raw" % p]).max() <= tol
+    assert r.range_fallbacks == 0
 
 
-def test_network_query_ragged_sizes_vs_oracle(R, lut):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_network_query_ragged_sizes_vs_oracle(R, lut, prec):
     """Point counts that are not multiples of the 32-point wave tile / 128-point workgroup tile,
     a single point, and samples-per-ray that do not divide 32."""
     g, sdc, sdf, _, _ = load_golden("plain_g10")
-    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision=prec)
     rng = np.random.RandomState(0)
     for n_rays, S in ((1, 1), (3, 5), (7, 33), (2, 191), (129, 3)):
         pts = rng.uniform(-6, 6, (n_rays, S, 3)).astype(np.float32)
@@ -117,10 +123,11 @@ def test_network_query_ragged_sizes_vs_oracle(R, lut):
         assert np.abs(got_s - ref_s).max() <= 6e-5, (n_rays, S)
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
-def test_render_rays_vs_reference_golden(R, name, lut):
+def test_render_rays_vs_reference_golden(R, name, lut, prec):
     g, sdc, sdf, gt, edit = load_golden(name)
-    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec)
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
     ref_keys = sorted(k[5:] for k in g.files if k.startswith("out__"))
     assert sorted(res.keys()) == ref_keys
@@ -322,3 +329,24 @@ def test_training_query_fn_dispatch(R, lut):
         out.square().mean().backward()
         opt.step()                                            # in-place update: the next fused query must see it
     assert M.network_query_fn(pts, dirs, RefShaped(sdc).cuda()).shape == (pts.shape[0], pts.shape[1], 18)
+
+
+def test_f16_range_fallback(R, lut):
+    """f16_mxfp6 on a checkpoint whose activations leave the f16 range: the kernel flags it and the call is
+    repeated on the bf16x3 twin, so the caller gets exactly the bf16x3 result."""
+    from ibl_nerf_amd import checkpoint as ck
+    g, _, _, _, _ = load_golden("plain_g10")
+    sd = {k: (v * np.float32(16.0) if k.endswith("weight") and k.startswith("positions_linears") else v)
+          for k, v in ck.synthetic_state_dict(0).items()}          # 16^8 gain through the trunk: activations pass 65504
+    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
+    wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
+    for r in (fast, wide):
+        r.load_weights(0, sd)
+        r.load_lut(lut)
+    pts, dirs = g["q_c_main_pts"], g["q_c_main_dirs"]
+    a, b = fast.network_query(pts, dirs, 0), wide.network_query(pts, dirs, 0)
+    assert fast.range_fallbacks == 1 and torch.equal(a, b) and bool(torch.isfinite(b).all())
+    ra = fast.render_rays(g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0)
+    rb = wide.render_rays(g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0)
+    assert fast.range_fallbacks == 2 and all(torch.equal(ra[k], rb[k]) for k in rb)
+    assert not wide.out_of_range()

@@ -231,6 +231,144 @@ def test_packed_stream_reproduces_oracle_mlp(lib, gain):
 
 
 # --------------------------------------------------------------------------------------------
+# f16 + MX-fp6 stream (csrc/layout_mx.h): same check, the three MFMA forms of a K=64 block emulated
+# --------------------------------------------------------------------------------------------
+FP6_VAL = np.array([(m / 8.0 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)) * (-1.0 if s else 1.0)
+                    for s in range(2) for e in range(4) for m in range(8)])
+FP6_MAG = FP6_VAL[:32]
+
+
+def fp6_round(x):
+    """round-to-nearest-even onto the e2m3 grid, saturating at 7.5 (what v_cvt_scalef32_pk32_fp6_f16 does)."""
+    a = np.minimum(np.abs(x), 7.5)
+    step = np.where(a < 2, 0.125, np.where(a < 4, 0.25, 0.5))
+    return np.sign(x) * np.minimum(np.rint(a / step) * step, 7.5)
+
+
+def fp6_codes(dwords):
+    """[..., 6] uint32 -> [..., 32] e2m3 values (slot j at bits [6j, 6j+6))."""
+    bits = np.unpackbits(dwords.view(np.uint8), axis=-1, bitorder="little").reshape(dwords.shape[:-1] + (32, 6))
+    return FP6_VAL[(bits * (1 << np.arange(6))).sum(-1)]
+
+
+class EmuMX(Emu):
+    MX_CH = dict(L0=0, L1=2, L5=34, L6=44, L7=52, FEAT=60, ALB=68, IRR=72, VIEW=76, AR=86)
+
+    def __init__(self, stream, tab):
+        blk = np.frombuffer(stream, dtype=np.uint8).reshape(-1, 8192)
+        self.A16 = blk[:, :4096].copy().view(np.float16).reshape(-1, 4, 2, 32, 8).astype(np.float64)     # [blk][j][h][row][e]
+        sc = blk[:, 7168:7424].copy().view(np.uint32).reshape(-1, 2, 32)                                   # [blk][h][row]
+
+        def fp6(a_off, b_off, byte):
+            d = np.concatenate([blk[:, a_off:a_off + 1024].copy().view(np.uint32).reshape(-1, 64, 4),
+                                blk[:, b_off:b_off + 512].copy().view(np.uint32).reshape(-1, 64, 2)], -1)
+            scale = 2.0 ** (((sc >> (8 * byte)) & 255).astype(np.float64) - 127)
+            return fp6_codes(d).reshape(-1, 2, 32, 32) * scale[..., None]                                  # [blk][h][row][jj]
+        self.W6, self.R6 = fp6(4096, 6144, 0), fp6(5120, 6656, 1)
+        assert not blk[:, 7424:].any()
+        self.tab = tab
+
+    @staticmethod
+    def operands(v):
+        """v [P, nb, h, 32] fp32 values of each lane's block -> (f16, fp6 of the f16, fp6 of the residual), as
+        the kernel builds them (finish_block in mlp_kernel_mx.hip)."""
+        v = v.astype(np.float32)
+        xh = v.astype(np.float16).astype(np.float32)
+        xl = (v - xh).astype(np.float16).astype(np.float64)
+        mx = np.maximum(np.abs(v).max(-1, keepdims=True).astype(np.float64), 2.0 ** -100)
+        e = np.floor(np.log2(mx))
+        sh, sl = 2.0 ** (e - 2), 2.0 ** (e - 14)
+        return xh.astype(np.float64), fp6_round(xh / sh) * sh, fp6_round(xl / sl) * sl
+
+    def frag_act(self, feat):
+        idx = np.array([[[32 * (2 * b + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h) for jj in range(32)]
+                         for h in range(2)] for b in range(4)])
+        return self.operands(feat[:, idx])
+
+    def frag_enc(self, embedded, pph, nk=None):
+        idx = np.array([[[enc_ref_index(jj, h, pph) for jj in range(32)] for h in range(2)]])
+        return self.operands(np.where(idx >= 0, embedded[:, np.maximum(idx, 0)], 0.0))
+
+    def blocks(self, b0, ops):
+        xh, x6, l6 = ops
+        n = xh.shape[1]
+        A16 = self.A16[b0:b0 + n].transpose(0, 2, 3, 1, 4).reshape(n, 2, 32, 32)                          # [blk][h][row][jj = 8j + e]
+        return (np.einsum("bhrj,pbhj->pr", A16, xh) + np.einsum("bhrj,pbhj->pr", self.W6[b0:b0 + n], l6)
+                + np.einsum("bhrj,pbhj->pr", self.R6[b0:b0 + n], x6))
+
+    def layer(self, chunk0, ntiles, act, enc=None, bias_tile=0, relu=True):
+        per = (1 if enc is not None else 0) + (4 if act is not None else 0)
+        out = []
+        for t in range(ntiles):
+            b = chunk0 * 4 + t * per
+            o = 0.0
+            if enc is not None:
+                o = o + self.blocks(b, enc)
+                b += 1
+            if act is not None:
+                o = o + self.blocks(b, act)
+            out.append(o)
+        out = (np.concatenate(out, 1) + self.lane_vec(TAB_BIAS + bias_tile * 32, ntiles)).astype(np.float32)
+        return np.maximum(out, 0) if relu else out
+
+    def forward(self, pts, dirs):
+        c = self.MX_CH
+        pe = self.frag_enc(O.embed(pts, 10), 15)
+        h = self.layer(c["L0"], 8, None, pe, 0)
+        for l in range(1, 5):
+            h = self.layer(c["L1"] + 8 * (l - 1), 8, self.frag_act(h), None, 8 * l)
+        h = self.layer(c["L5"], 8, self.frag_act(h), pe, 40)
+        h = self.layer(c["L6"], 8, self.frag_act(h), None, 48)
+        h7 = self.layer(c["L7"], 8, self.frag_act(h), None, 56)
+        sc = self.tab[TAB_SCALAR:TAB_SCALAR + 18]
+        sigma = h7 @ self.lane_vec(TAB_SIG, 8) + sc[0]
+        if dirs is None:
+            return sigma[:, None].astype(np.float32)
+        a7 = self.frag_act(h7)
+        feat = self.layer(c["FEAT"], 8, a7, None, 64, relu=False)
+        albf = self.layer(c["ALB"], 4, a7, None, 72)
+        irrf = self.layer(c["IRR"], 4, a7, None, 76)
+        h2 = self.layer(c["VIEW"], 8, self.frag_act(feat), self.frag_enc(O.embed(dirs, 4), 6), 80)
+        a2 = self.frag_act(h2)
+        cols = [sigma]
+        cols += [albf @ self.lane_vec(TAB_ALB + k * 128, 4) + sc[1 + k] for k in range(3)]
+        cols += [h7 @ self.lane_vec(TAB_ROUGH, 8) + sc[4], irrf @ self.lane_vec(TAB_IRR, 4) + sc[5]]
+        cols += [h2 @ self.lane_vec(TAB_RAD + k * 256, 8) + sc[6 + k] for k in range(3)]
+        for k in range(3):
+            f = self.layer(c["AR"] + 4 * k, 4, a2, None, 88 + 4 * k)
+            cols += [f @ self.lane_vec(TAB_AR + (3 * k + q) * 128, 4) + sc[9 + 3 * k + q] for q in range(3)]
+        return np.stack(cols, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("gain", [1.0, 1.6])
+def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
+    sd = ck.synthetic_state_dict(seed=5, gain=gain)
+    blob = ck.state_dict_to_blob(sd)
+    stream = np.zeros(lib.iblnerf_stream_bytes_mx(), dtype=np.uint8)
+    tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
+    assert stream.size == 98 * 32768
+    assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == 0
+    assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size - 1, tab.ctypes.data, tab.size) == -1
+    emu = EmuMX(stream.tobytes(), tab)
+    # the f16 part of one block is the f16 rounding of the right weights (positions_linears.2, tile 3, block 1)
+    W = sd["positions_linears.2.weight"]
+    blk = (2 + 8 + 3) * 4 + 1
+    for h in range(2):
+        for jj in (0, 9, 31):
+            feat = 32 * (2 + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h)
+            assert np.array_equal(emu.A16[blk, jj >> 3, h, :, jj & 7], W[96:128, feat].astype(np.float16).astype(np.float64))
+            assert np.abs(emu.W6[blk, h, :, jj] - W[96:128, feat]).max() <= 0.07 * np.abs(W[96:128]).max()   # 4 significant bits, block-scaled
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(-8, 8, (24, 3)).astype(np.float32)
+    dirs = rng.uniform(-1.2, 1.2, (24, 3)).astype(np.float32)
+    ref = O.mlp_forward(sd, O.embed(pts, 10), O.embed(dirs, 4))
+    got = emu.forward(pts, dirs)
+    # f16 main term + fp6 residual terms: ~2^-16 per operand
+    assert np.abs(got - ref).max() <= (4e-5 if gain == 1.0 else 4e-4), np.abs(got - ref).max()
+    assert np.abs(emu.forward(pts, None) - O.mlp_forward(sd, O.embed(pts, 10))).max() <= (2e-5 if gain == 1.0 else 2e-4)
+
+
+# --------------------------------------------------------------------------------------------
 # checkpoint + factory mirror
 # --------------------------------------------------------------------------------------------
 def test_checkpoint_roundtrip_and_discovery():
