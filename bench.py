@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-precision", choices=["f16_mxfp6", "bf16x3"], default="f16_mxfp6",
+                    help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision)")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +139,7 @@ def main():
     lut = load_lut()
     K, c2w = camera()
     r = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=not args.inference_min,
-                   max_rays_per_launch=args.rays_per_launch)
+                   max_rays_per_launch=args.rays_per_launch, mlp_precision=args.mlp_precision)
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
@@ -174,7 +176,8 @@ def main():
     # '...0' maps; SURVEY.md §8 d mode ii) — reported as an extra, never as `value`
     value_min = None
     if world == 1 and not args.inference_min:
-        r2 = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=False, max_rays_per_launch=args.rays_per_launch)
+        r2 = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=False, max_rays_per_launch=args.rays_per_launch,
+                        mlp_precision=args.mlp_precision)
         r2.load_weights(0, sdc)
         r2.load_weights(1, sdf)
         r2.load_lut(lut)
@@ -200,7 +203,9 @@ def main():
             "metric": "rays/sec (64c+128f samples) at 800x800 Kitchen; PSNR vs ref",
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (bf16 hi/lo split, 3 MFMA products, fp32 accumulate)",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": ("f16 + 2x MX-fp6 residual products, fp32 accumulate (fp32 operands to ~2^-16)" if args.mlp_precision == "f16_mxfp6"
+                      else "bf16x3 (bf16 hi/lo split, 3 MFMA products, fp32 accumulate)"),
             "data": "synthetic (seeded checkpoint in the reference state-dict schema, synthetic pinhole camera)",
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
@@ -210,9 +215,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch (reads x2-corrected + writes) from %s; points in + raw outputs out, weights stay in L2" % traffic_src,
-                         "kernel": "ibl::mlp_kernel<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
+                         "kernel": ("ibl::mxk::mlp_kernel" if args.mlp_precision == "f16_mxfp6" else "ibl::mlp_kernel") + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
-                         "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; the kernel issues 3 bf16 MFMA products per MAC"},
+                         "range_fallbacks": r.range_fallbacks,
+                         "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues "
+                                 + ("1 f16 + 2 block-scaled fp6 MFMA products (= 1.5 bf16-rate products)" if args.mlp_precision == "f16_mxfp6"
+                                    else "3 bf16 MFMA products")},
         }
         if value_min is not None:
             line["value_inference_min"] = value_min

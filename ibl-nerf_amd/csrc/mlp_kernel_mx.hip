@@ -112,6 +112,9 @@ struct Pipe {
         const unsigned v = voff + (I / 4) * 4096;
         if constexpr (I % 4 != 0) {
             asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(v), "s"(src), "n"((I % 4) * 1024) : "memory");
+#ifdef IBL_MX_DOUBLE_DMA   // measurement only: every piece twice (same bytes to the same place) prices one LDS-DMA instruction
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(v), "s"(src), "n"((I % 4) * 1024) : "memory");
+#endif
             return;
         }
         // M0 (the DMA's LDS base) is left holding `dst`: nothing else in this kernel reads M0 (gfx9+ DS and
@@ -121,6 +124,9 @@ struct Pipe {
             "s_mov_b32 m0, %1\n\t"
             "s_nop 0\n\t"
             "global_load_lds_dwordx4 %0, %2"
+#ifdef IBL_MX_DOUBLE_DMA
+            "\n\tglobal_load_lds_dwordx4 %0, %2"
+#endif
             :
             : "v"(v), "s"(dst), "s"(src)
             : "memory");
@@ -132,7 +138,11 @@ struct Pipe {
         slot1 = 1;
         slot2 = 2;
         prog2 = 2;
+#ifdef IBL_MX_DOUBLE_DMA
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#endif
     }
     // byte address of block `blk` of the current / next chunk, this lane's 16-byte column
     __device__ __forceinline__ const char* block(bool next, int blk) const {
@@ -145,7 +155,11 @@ struct Pipe {
     // reads of the current chunk before it arrives here (they run PF slots ahead), the first DMA piece into this
     // ring slot is issued at least PF + 3 slots (>200 cycles) after the barrier releases and its data
     // returns from L2 several hundred cycles later still, while an issued ds_read completes in ~100 cycles.
+#ifdef IBL_MX_DOUBLE_DMA
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); }
+#else
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }
+#endif
     __device__ __forceinline__ void advance() {
         slot = slot1;
         slot1 = slot2;
@@ -303,9 +317,10 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
     constexpr int NS = NB * SLOTS_PER_BLOCK;     // slots per tile
     static_assert((NT * NS) % CHUNK_SLOTS == 0, "a layer is a whole number of chunks");
     f32x16 prev = {0};
+    f32x16 bias_next = *reinterpret_cast<const f32x16*>(bias_tab);
     static_for<0, NT>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        f32x16 acc = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);   // the chain starts at the layer bias
+        f32x16 acc = bias_next;   // the chain starts at the layer bias (read from LDS during the previous tile)
         static_for<0, NS>([&](auto GS) {
             constexpr int g = decltype(GS)::value;   // slot inside the tile
             constexpr int G = t * NS + g;            // slot inside the layer
@@ -321,6 +336,7 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
                 constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
                 load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
             }
+            if constexpr (g == NS / 2 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x16*>(bias_tab + (t + 1) * 32);
             if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
 #ifndef IBL_MX_ABLATE_NO_EPI     // timing ablation only: no epilogue work
             static_for<0, 8>([&](auto I) {
@@ -335,8 +351,11 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             if constexpr (cr == SYNC_SLOT) P.sync_next();
             if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
         });
+#ifdef IBL_MX_ACC_V
+        asm volatile("" :: "v"(acc));
+#else
         asm volatile("" : "+a"(acc));   // keep the finished chain where it is; its consumer is the deferred epilogue
-                                        // ("+v" instead sends the accumulators through scratch memory: 4.5x slower)
+#endif
         prev = acc;
     });
     return prev;

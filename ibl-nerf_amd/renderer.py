@@ -355,7 +355,7 @@ def _check_supported(kw):
 
 
 _renderers = {}
-DEFAULT_MLP_PRECISION = "bf16x3"
+DEFAULT_MLP_PRECISION = "f16_mxfp6"
 
 
 def _weights_key(net):
