@@ -150,15 +150,14 @@ struct Pipe {
     }
     template <int I>
     __device__ __forceinline__ void prefetch_piece() const { issue_piece<I>(prog2, slot2); }
-    // The next chunk's 8 pieces have landed (mine: vmcnt; everyone's: barrier).  The barrier is also the WAR
-    // fence for the DMA that overwrites this chunk's ring slot two chunks from now: every wave has ISSUED all its
-    // reads of the current chunk before it arrives here (they run PF slots ahead), the first DMA piece into this
-    // ring slot is issued at least PF + 3 slots (>200 cycles) after the barrier releases and its data
-    // returns from L2 several hundred cycles later still, while an issued ds_read completes in ~100 cycles.
+    // The next chunk's 8 pieces have landed (mine: vmcnt; everyone's: barrier).  All reads of the CURRENT chunk
+    // have been issued by this point (they run PF slots ahead) and lgkmcnt(0) completes them, so the barrier is
+    // also the WAR fence for the DMA that overwrites this chunk's ring slot two chunks from now.  (Dropping the
+    // lgkmcnt(0) measured no faster: 12.78 vs 12.77 ms on the TRUNK benchmark.)
 #ifdef IBL_MX_DOUBLE_DMA
-    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #else
-    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
     __device__ __forceinline__ void advance() {
         slot = slot1;
@@ -351,11 +350,10 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             if constexpr (cr == SYNC_SLOT) P.sync_next();
             if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
         });
-#ifdef IBL_MX_ACC_V
-        asm volatile("" :: "v"(acc));
-#else
-        asm volatile("" : "+a"(acc));   // keep the finished chain where it is; its consumer is the deferred epilogue
-#endif
+        // Keep the finished chain where it is (accumulator registers); its consumer is the deferred epilogue.
+        // Arch-VGPR accumulators would save the epilogue's v_accvgpr_reads, but "+v" sends them through scratch
+        // memory (4.5x slower) and an input-only "v" doubles the reads.
+        asm volatile("" : "+a"(acc));
         prev = acc;
     });
     return prev;
