@@ -156,6 +156,8 @@ struct Pipe {
     // lgkmcnt(0) measured no faster: 12.78 vs 12.77 ms on the TRUNK benchmark.)
 #ifdef IBL_MX_DOUBLE_DMA
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#elif defined(IBL_MX_ABLATE_NO_BARRIER)   // timing ablation only (racy)
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
 #else
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
@@ -223,12 +225,10 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hb, unsigned& lb) {
     const f32x2 xv = {x0, x1};
     hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));
-    // x - (float)h in one instruction each (v_fma_mix reads the f16 half directly); plain C++ costs cvt + sub
-    float l0, l1;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x0), "v"(hb));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x1), "v"(hb));
-    const f32x2 lv = {l0, l1};
-    lb = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, f16x2));
+    // residuals x - (float)h, rounded to f16 and written straight into the low / high half of one register:
+    // v_fma_mix{lo,hi}_f16 read the f16 half of h directly (plain C++ costs cvt + sub + cvt_pk per pair)
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(x0), "v"(hb));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(x1), "v"(hb));
 }
 
 // Completes a block once its 32 f16 values (b.h) and their residuals (lres, same element order) are in
