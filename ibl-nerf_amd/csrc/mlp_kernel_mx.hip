@@ -328,12 +328,20 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             if constexpr (s == 4) wsc = pf.sc[G % 4];
             if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
             else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
+#ifdef IBL_MX_DOUBLE_MFMA   // measurement only (results are garbage): every matrix instruction twice
+            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
+            else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
+#endif
             // A operand of slot G + PF, into the entry this slot's MFMA has just consumed
             {
                 constexpr int Gp = G + PF;
                 constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
                 constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
                 load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+#ifdef IBL_MX_DOUBLE_LDS    // measurement only: every operand read twice
+                asm volatile("" : "+v"(pf.q[Gp % 4]));
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+#endif
             }
             if constexpr (g == NS / 2 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x16*>(bias_tab + (t + 1) * 32);
             if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
