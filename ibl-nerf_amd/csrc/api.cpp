@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -136,6 +137,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     c->opt = *opts;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, opts->device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("IBLNERF_GRID")) {   // measurement aid (scratch/): persistent workgroups to launch
+        const int g = std::atoi(e);
+        if (g > 0) c->n_cu = g;
+    }
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;

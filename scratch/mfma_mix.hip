@@ -52,12 +52,13 @@ __global__ __launch_bounds__(256, 1) void k(const float* seed, const int* bits, 
     out[tid] = s;
 }
 
+static int g_grid = 256;
 template <int MODE> double run(const float* d_seed, const int* d_bits, float* d_out, int iters, const char* name) {
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, d_seed, d_bits, d_out, iters / 10);
+    hipLaunchKernelGGL(k<MODE>, dim3(g_grid), dim3(256), 0, 0, d_seed, d_bits, d_out, iters / 10);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, d_seed, d_bits, d_out, iters);
+    hipLaunchKernelGGL(k<MODE>, dim3(g_grid), dim3(256), 0, 0, d_seed, d_bits, d_out, iters);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double blocks = 1024.0 * iters * 4;   // K=64 blocks of a 32x32 tile, 1024 waves
@@ -66,7 +67,9 @@ template <int MODE> double run(const float* d_seed, const int* d_bits, float* d_
     return ms;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_grid = atoi(argv[1]);
+    printf("grid = %d workgroups (one per CU)\n", g_grid);
     std::vector<float> h(65536); srand(1);
     for (auto& x : h) x = ((float)rand() / RAND_MAX * 2 - 1) * 0.05f;
     std::vector<int> b(65536);
