@@ -49,6 +49,14 @@ def test_struct_sizes_match_header_layout(tmp_path):
     assert got == want
 
 
+def test_integration_stub_matches_options_struct():
+    """The ctypes stub printed in INTEGRATION.md must declare the same iblnerf_options fields as binding.py
+    (a shorter struct there would make iblnerf_create read past the caller's memory)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = md[md.index("class Options(C.Structure)"):md.index("opt = Options()")]
+    assert re.findall(r'\("(\w+)", C\.c_(?:int32|float)\)', stub) == [n for n, _ in B.Options._fields_]
+
+
 def test_no_gpu_fails_loudly(lib):
     torch = pytest.importorskip("torch")
     if torch.cuda.is_available():
