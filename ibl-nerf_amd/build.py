@@ -43,7 +43,7 @@ def build(verbose=True, force=False):
     """Compile every source whose inputs changed, then link.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs, relink = [], force or not os.path.exists(LIB)
+    objs, relink, jobs = [], force or not os.path.exists(LIB), []
     for src, flags in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + ".o")
@@ -51,14 +51,21 @@ def build(verbose=True, force=False):
         dg = _digest([sp] + hdrs, COMMON + flags)
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or old != dg or not os.path.exists(op):
-            cmd = [HIPCC] + COMMON + flags + ["-c", sp, "-o", op]
+            jobs.append(([HIPCC] + COMMON + flags + ["-c", sp, "-o", op], stamp, dg))
+        objs.append(op)
+    if jobs:   # the two MLP kernels take minutes each: compile the stale sources side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(job):
+            cmd, stamp, dg = job
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             with open(stamp, "w") as f:
                 f.write(dg)
-            relink = True
-        objs.append(op)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(run, jobs))
+        relink = True
     if relink:
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
