@@ -20,10 +20,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
-# (source, extra flags placed before -c)
+# (source, extra flags placed before -c[, object name]); the MX kernel's three instantiations are three objects so
+# that they compile side by side (each takes minutes)
 SOURCES = [
     ("mlp_kernel.hip", []),
-    ("mlp_kernel_mx.hip", []),
+    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
+    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
+    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
@@ -44,9 +47,10 @@ def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, relink, jobs = [], force or not os.path.exists(LIB), []
-    for src, flags in SOURCES:
+    for entry in SOURCES:
+        src, flags = entry[0], entry[1]
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + ".o")
+        op = os.path.join(OBJ, (entry[2] if len(entry) > 2 else src) + ".o")
         stamp = op + ".sha"
         dg = _digest([sp] + hdrs, COMMON + flags)
         old = open(stamp).read() if os.path.exists(stamp) else ""
@@ -63,7 +67,7 @@ def build(verbose=True, force=False):
             subprocess.check_call(cmd)
             with open(stamp, "w") as f:
                 f.write(dg)
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as pool:
             list(pool.map(run, jobs))
         relink = True
     if relink:

@@ -569,28 +569,53 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 
 }  // namespace mxk
 
+// The three instantiations are compiled as three objects (build.py passes -DIBL_MX_VARIANT=0|1|2) so that they
+// build side by side; the object for VAR_FULL also carries the dispatcher.  Without the macro (scratch/mxdev.sh
+// with -DIBL_MX_DEV_TRUNK_ONLY, or a plain compile) everything lands in one object.
+template <int VARIANT>
+static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mxk::mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+#if defined(IBL_MX_VARIANT)
+#if IBL_MX_VARIANT == 0
+hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
+#elif IBL_MX_VARIANT == 1
+hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+#else
+hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+#endif
+#else
+hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+#ifndef IBL_MX_DEV_TRUNK_ONLY
+hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
+hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+#endif
+#endif
+
+#if !defined(IBL_MX_VARIANT) || IBL_MX_VARIANT == 0
+hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
     const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
-    static bool attr_set = false;
-    if (!attr_set) {
-#ifndef IBL_MX_DEV_TRUNK_ONLY
-        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-#endif
-        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
     switch (variant) {
-#ifndef IBL_MX_DEV_TRUNK_ONLY   // development builds: one instantiation compiles in a third of the time
-        case VAR_FULL: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
-        case VAR_REFL: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+#ifndef IBL_MX_DEV_TRUNK_ONLY
+        case VAR_FULL: return launch_mlp_mx_full(a, grid, stream);
+        case VAR_REFL: return launch_mlp_mx_refl(a, grid, stream);
 #endif
-        case VAR_TRUNK: hipLaunchKernelGGL(mxk::mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_BYTES, stream, a); break;
+        case VAR_TRUNK: return launch_mlp_mx_trunk(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
+#endif
 
 }  // namespace ibl
