@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,7 @@ struct iblnerf_ctx {
     char* d_stream[2] = {nullptr, nullptr};
     char* d_stream_mx[2] = {nullptr, nullptr};   // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
     unsigned* d_range_flag = nullptr;
+    bool mx_ok[2] = {true, true};                 // false: a weight is outside the f16 range -> that network runs on the bf16x3 kernel
     float* d_tables[2] = {nullptr, nullptr};
     bool have_net[2] = {false, false};
     float* d_lut = nullptr;
@@ -210,6 +212,9 @@ int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_
     HIP_TRY(c, hipMemcpy(c->d_stream[which], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tables[which], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
     if (c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6) {
+        bool ok = true;                           // f16(W) must be finite: |w| < 65520 and not NaN
+        for (size_t i = 0; i < n_floats && ok; ++i) ok = std::fabs(h_blob[i]) < 65504.0f;
+        c->mx_ok[which] = ok;
         std::vector<char> smx((size_t)mx::STREAM_BYTES);
         pack_network_mx(h_blob, smx.data(), tab.data());
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[which], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
@@ -247,7 +252,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                    int pts_per_ray, long n_pts, float* out) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
-    const bool use_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6;
+    const bool use_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6 && c->mx_ok[which];
     a.stream = use_mx ? c->d_stream_mx[which] : c->d_stream[which];
     a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];

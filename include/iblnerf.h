@@ -56,8 +56,9 @@ typedef struct {
                                           1e-3 parity bar; no reference counterpart):
                                           IBLNERF_MLP_BF16X3    three bf16 products on hi/lo splits, fp32 range
                                           IBLNERF_MLP_F16_MXFP6 one f16 product + two block-scaled fp6 residual products,
-                                                                ~2x faster; inputs, weights and activations must stay
-                                                                below 65504 — see iblnerf_range_status */
+                                                                faster; inputs and activations must stay below 65504 —
+                                                                see iblnerf_range_status (a network with a weight
+                                                                beyond that runs on the bf16x3 kernel by itself) */
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
 

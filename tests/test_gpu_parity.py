@@ -350,3 +350,21 @@ def test_f16_range_fallback(R, lut):
     rb = wide.render_rays(g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0)
     assert fast.range_fallbacks == 2 and all(torch.equal(ra[k], rb[k]) for k in rb)
     assert not wide.out_of_range()
+
+
+def test_f16_mode_with_out_of_range_weights(R, lut):
+    """A weight beyond the f16 range: the fast mode runs that network on the bf16x3 kernel from the start
+    (no device flag, no second render), with the same result as an explicit bf16x3 context."""
+    from ibl_nerf_amd import checkpoint as ck
+    g, _, _, _, _ = load_golden("plain_g10")
+    sd = dict(ck.synthetic_state_dict(0))
+    w = sd["positions_linears.0.weight"].copy()
+    w[3, 5] = np.float32(1.0e5)
+    sd["positions_linears.0.weight"] = w
+    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
+    wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
+    for r in (fast, wide):
+        r.load_weights(0, sd)
+    a = fast.network_query(g["q_c_main_pts"], g["q_c_main_dirs"], 0)
+    b = wide.network_query(g["q_c_main_pts"], g["q_c_main_dirs"], 0)
+    assert fast.range_fallbacks == 0 and torch.equal(a, b)
