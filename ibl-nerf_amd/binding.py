@@ -16,7 +16,7 @@ EXPORTS = [
     "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host", "iblnerf_stream_bytes",
     "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
-    "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx",
+    "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
 ]
 
 
@@ -86,6 +86,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_pack_weights_host_mx.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.iblnerf_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.iblnerf_upload_weights_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.iblnerf_upload_weights_device.restype = C.c_int
     lib.iblnerf_upload_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.iblnerf_pack_weights_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.iblnerf_encode_host.argtypes = [C.c_float, C.c_int, C.c_void_p]

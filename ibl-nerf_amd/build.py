@@ -28,6 +28,7 @@ SOURCES = [
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
+    ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
 ]

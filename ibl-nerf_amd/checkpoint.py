@@ -63,6 +63,15 @@ def _to_numpy(v) -> np.ndarray:
     return v.detach().cpu().numpy()  # torch.Tensor / nn.Parameter
 
 
+def check_schema(sd):
+    """Names, order and shapes of a state dict against SCHEMA (what the blob layout assumes) without touching data."""
+    want = [(n + sfx, (o, i) if sfx == ".weight" else (o,)) for n, o, i in SCHEMA for sfx in (".weight", ".bias")]
+    got = [(k, tuple(v.shape)) for k, v in sd.items()]
+    if got != want:
+        bad = next((g for g, w in zip(got, want) if g != w), got[len(want):] or want[len(got):])
+        raise ValueError("state dict does not follow the IBLNeRF schema (first mismatch: %r)" % (bad,))
+
+
 def state_dict_to_blob(sd) -> np.ndarray:
     """Flatten a reference-schema state dict (numpy arrays or torch tensors) into the fp32 blob."""
     parts = []

@@ -34,7 +34,10 @@ struct iblnerf_ctx {
     char* d_stream[2] = {nullptr, nullptr};
     char* d_stream_mx[2] = {nullptr, nullptr};   // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
     unsigned* d_range_flag = nullptr;
-    bool mx_ok[2] = {true, true};                 // false: a weight is outside the f16 range -> that network runs on the bf16x3 kernel
+    bool mx_ok[2] = {true, true};
+    unsigned short* d_map16 = nullptr;            // gather maps of the device packer (built on first use)
+    int* d_map_mx = nullptr;
+    int* d_map_tab = nullptr;                 // false: a weight is outside the f16 range -> that network runs on the bf16x3 kernel
     float* d_tables[2] = {nullptr, nullptr};
     bool have_net[2] = {false, false};
     float* d_lut = nullptr;
@@ -168,7 +171,9 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     if (opts->mlp_precision == IBLNERF_MLP_F16_MXFP6) {
         bool ok = hipMalloc((void**)&c->d_range_flag, sizeof(unsigned)) == hipSuccess &&
                   hipMemset(c->d_range_flag, 0, sizeof(unsigned)) == hipSuccess;
-        for (int w = 0; w < 2 && ok; ++w) ok = hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess;
+        for (int w = 0; w < 2 && ok; ++w)
+            ok = hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess &&
+                 hipMemset(c->d_stream_mx[w], 0, mx::STREAM_BYTES) == hipSuccess;
         if (!ok) {
             g_create_error = "hipMalloc of the f16 + MX-fp6 weight stream failed";
             iblnerf_destroy(c);
@@ -195,6 +200,9 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
     }
     if (c->d_range_flag) (void)hipFree(c->d_range_flag);
+    if (c->d_map16) (void)hipFree(c->d_map16);
+    if (c->d_map_mx) (void)hipFree(c->d_map_mx);
+    if (c->d_map_tab) (void)hipFree(c->d_map_tab);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
 }
@@ -219,6 +227,31 @@ int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_
         pack_network_mx(h_blob, smx.data(), tab.data());
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[which], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
     }
+    c->have_net[which] = true;
+    return IBLNERF_OK;
+}
+
+int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const float* d_blob, size_t n_floats) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || !d_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights_device: which must be 0/1, blob non-null");
+    if (n_floats != blob_floats())
+        return c->fail(IBLNERF_ERR_INVALID, "upload_weights_device: blob has %zu floats, the IBLNeRF state dict has %zu", n_floats, blob_floats());
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    if (!c->d_map16) {                            // first use: build the gather maps on the host, keep them on the device
+        std::vector<uint16_t> m16;
+        std::vector<int32_t> mmx, mtab;
+        build_pack_maps(m16, mmx, mtab);
+        HIP_TRY(c, hipMalloc((void**)&c->d_map16, m16.size() * 2));
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_mx, mmx.size() * 4));
+        HIP_TRY(c, hipMalloc((void**)&c->d_map_tab, mtab.size() * 4));
+        HIP_TRY(c, hipMemcpy(c->d_map16, m16.data(), m16.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_map_mx, mmx.data(), mmx.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_map_tab, mtab.data(), mtab.size() * 4, hipMemcpyHostToDevice));
+    }
+    PackMaps maps{c->d_map16, c->d_map_mx, c->d_map_tab};
+    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_tables[which], c->d_range_flag,
+                                   (hipStream_t)stream));
+    c->mx_ok[which] = true;                       // an out-of-range weight is reported through the range flag here
     c->have_net[which] = true;
     return IBLNERF_OK;
 }

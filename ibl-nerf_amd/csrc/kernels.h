@@ -20,6 +20,15 @@ struct MlpArgs {
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
 
+// --- device-side weight packer (pack_kernels.hip): blob in HBM -> both weight streams + side tables ---------------
+struct PackMaps {                 // device copies of pack.cpp's build_pack_maps()
+    const unsigned short* id_stream;
+    const int* mx;
+    const int* tab;
+};
+hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, float* d_tab,
+                               unsigned* d_range_flag, hipStream_t s);
+
 // --- per-ray kernels (render_kernels.hip) ------------------------------------------------------
 
 // nerf_renderer_helper.py:36-45.  Rows [row0, row0+n_rows) of an H x W image.

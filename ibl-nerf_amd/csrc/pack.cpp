@@ -46,7 +46,20 @@ inline uint16_t bf16_rne(float f) {
 }
 inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
+// Index-map mode (build_pack_maps): the "weights" are 1 + their own flat index in the blob (0 = zero pad) and the
+// emitters record that index instead of converting a value, so the SAME traversal yields the gather maps the
+// device packer (pack_kernels.hip) uses.
+bool g_identity = false;
+int32_t* g_map_mx = nullptr;
+const char* g_mx_base = nullptr;
+
 inline void put_split(uint16_t* kstep_base, int lane, int e, float w) {
+    if (g_identity) {
+        const uint32_t idx = (uint32_t)w;
+        kstep_base[lane * 8 + e] = (uint16_t)(idx & 0xffffu);
+        kstep_base[512 + lane * 8 + e] = (uint16_t)(idx >> 16);
+        return;
+    }
     const uint16_t hi = bf16_rne(w);
     const uint16_t lo = bf16_rne(w - bf16_to_f32(hi));
     kstep_base[lane * 8 + e] = hi;                         // first KiB: hi fragments
@@ -203,6 +216,11 @@ template <class WF>
 void pack_block(char* blk, WF&& w) {
     for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 31, h = lane >> 5;
+        if (g_identity) {
+            int32_t* m = g_map_mx + ((size_t)((blk - g_mx_base) / mx::BLOCK_BYTES) * 64 + lane) * 32;
+            for (int jj = 0; jj < 32; ++jj) m[jj] = (int32_t)w(i, h, jj);
+            continue;
+        }
         float full[32], res[32];
         for (int jj = 0; jj < 32; ++jj) {
             const float x = w(i, h, jj);
@@ -241,11 +259,14 @@ void pack_enc_mx(char* blk, const Net& n, int l, int row0, int col_base, int pai
 }  // namespace
 
 void pack_network_mx(const float* blob, void* stream_out, float* tab) {
-    std::vector<char> scratch((size_t)STREAM_BYTES);
-    pack_network(blob, scratch.data(), tab);          // the side tables are common to both variants
+    if (tab != nullptr) {
+        std::vector<char> scratch((size_t)STREAM_BYTES);
+        pack_network(blob, scratch.data(), tab);      // the side tables are common to both variants
+    }
     const Net n(blob);
     char* s = reinterpret_cast<char*>(stream_out);
-    std::memset(s, 0, mx::STREAM_BYTES);
+    if (g_identity) g_mx_base = s;
+    else std::memset(s, 0, mx::STREAM_BYTES);
     auto at = [&](int chunk, int block = 0) { return s + (size_t)chunk * CHUNK_BYTES + (size_t)block * mx::BLOCK_BYTES; };
     for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF);
     for (int l = 1; l <= 4; ++l)
@@ -265,6 +286,23 @@ void pack_network_mx(const float* blob, void* stream_out, float* tab) {
     }
     for (int k = 0; k < 3; ++k)
         for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_AR + 4 * k + t), n, L_AR_F0 + k, 32 * t, 0);
+}
+
+void build_pack_maps(std::vector<uint16_t>& id_stream, std::vector<int32_t>& map_mx, std::vector<int32_t>& map_tab) {
+    std::vector<float> idx(blob_floats());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (float)(i + 1);     // exact: 798 995 < 2^24
+    id_stream.assign((size_t)STREAM_BYTES / 2, 0);
+    std::vector<float> tab((size_t)TAB_FLOATS);
+    map_mx.assign((size_t)mx::N_CHUNKS * mx::CHUNK_BLOCKS * 64 * 32, 0);
+    std::vector<char> dummy((size_t)mx::STREAM_BYTES);
+    g_identity = true;
+    g_map_mx = map_mx.data();
+    pack_network(idx.data(), id_stream.data(), tab.data());
+    pack_network_mx(idx.data(), dummy.data(), nullptr);
+    g_identity = false;
+    g_map_mx = nullptr;
+    map_tab.resize((size_t)TAB_FLOATS);
+    for (size_t i = 0; i < map_tab.size(); ++i) map_tab[i] = (int32_t)tab[i];
 }
 
 }  // namespace ibl

@@ -1,6 +1,8 @@
 // Host-side packer interface (see layout.h for the formats).
 #pragma once
 #include <stddef.h>
+#include <stdint.h>
+#include <vector>
 #include "layout.h"
 
 namespace ibl {
@@ -9,4 +11,8 @@ size_t blob_floats();  // 798 994: floats in one network's state-dict blob
 void pack_network(const float* blob, void* stream_out, float* tab);
 // f16 + MX-fp6 variant (layout_mx.h): stream_out holds mx::STREAM_BYTES, tab as above
 void pack_network_mx(const float* blob, void* stream_out, float* tab);
+// Gather maps for the device packer: entry = 1 + flat blob index of the weight that lands at that position, 0 = zero.
+//   id_stream[STREAM_BYTES/2]: per bf16x3 k-step, the index's low 16 bits sit in the hi-fragment slot and its high bits
+//   in the lo-fragment slot; map_mx[(block*64 + lane)*32 + slot]; map_tab[TAB_FLOATS].  Not thread-safe.
+void build_pack_maps(std::vector<uint16_t>& id_stream, std::vector<int32_t>& map_mx, std::vector<int32_t>& map_tab);
 }  // namespace ibl

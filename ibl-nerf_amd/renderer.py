@@ -109,13 +109,25 @@ class Renderer:
 
     # -- uploads --------------------------------------------------------------------------------
     def load_weights(self, which, state_dict_or_blob):
-        """which: 0 = network_fn (coarse), 1 = network_fine.  Accepts a reference-schema state dict
-        (torch tensors or numpy arrays) or an already-flattened blob."""
+        """which: 0 = network_fn (coarse), 1 = network_fine.  Accepts a reference-schema state dict (torch tensors
+        or numpy arrays) or an already-flattened blob.  Parameters that live on this GPU are flattened and packed
+        on the device (one torch.cat + one pack kernel on the current stream: no host copy, no synchronisation);
+        anything else goes through the host packer."""
+        torch = _torch()
         blob = state_dict_or_blob
-        if not isinstance(blob, np.ndarray):
-            blob = ck.state_dict_to_blob(blob)
-        blob = np.ascontiguousarray(blob, dtype=np.float32)
-        B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
+        if isinstance(blob, dict) and blob and all(torch.is_tensor(v) and v.is_cuda for v in blob.values()):
+            ck.check_schema(blob)
+            blob = torch.cat([v.detach().reshape(-1).to(torch.float32) for v in blob.values()])
+        if torch.is_tensor(blob) and blob.is_cuda:
+            blob = blob.to(self.device, torch.float32).contiguous()
+            B.check(self.ctx, self.lib.iblnerf_upload_weights_device(self.ctx, self._stream(), int(which), blob.data_ptr(), blob.numel()))
+            self._keep_w = getattr(self, "_keep_w", {})
+            self._keep_w[int(which)] = blob      # the pack kernel reads it asynchronously
+        else:
+            if not isinstance(blob, np.ndarray):
+                blob = ck.state_dict_to_blob(blob)
+            blob = np.ascontiguousarray(blob, dtype=np.float32)
+            B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
         if self.mlp_precision == "f16_mxfp6":
             self._blobs[int(which)] = blob
             if self._wide is not None:

@@ -78,6 +78,13 @@ size_t iblnerf_blob_floats(void);
  * an optimizer step).  Synchronous. */
 int iblnerf_upload_weights(iblnerf_ctx* ctx, int which, const float* h_blob, size_t n_floats);
 
+/* Same, with the blob already in device memory (e.g. torch.cat of the module's parameters): packed by a kernel
+ * enqueued on `stream`, no host copy and no synchronisation — the cheap way to follow an optimizer step
+ * (train.py:479-481).  Renders enqueued later on the same stream see the new weights; the caller orders it after
+ * earlier renders (same stream, or an event).  With IBLNERF_MLP_F16_MXFP6 a weight outside the f16 range raises the
+ * iblnerf_range_status flag instead of switching kernels. */
+int iblnerf_upload_weights_device(iblnerf_ctx* ctx, void* stream, int which, const float* d_blob, size_t n_floats);
+
 /* replaces: brdf_lut tensor of test.py:79-87.  h_rgb = float [3,512,512] (R = scale, G = bias). */
 int iblnerf_upload_lut(iblnerf_ctx* ctx, const float* h_rgb);
 

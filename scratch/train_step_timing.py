@@ -1,0 +1,31 @@
+"""Query pattern of one training step of the shipped config (N_rand = 512 rays, 64 + 128 samples; train.py:286-297):
+gradient-carrying main queries + no-grad eps-normal / reflected queries, all on the PyTorch module (as the
+reference does) vs the no-grad ones on the fused kernel (model.training_network_query_fn)."""
+import sys, time, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import _pkg; _pkg.load()
+from ibl_nerf_amd import checkpoint as ck, model as M
+from torch_ref import RefShaped, torch_query
+torch.manual_seed(0)
+nets = [RefShaped(ck.synthetic_state_dict(i)).cuda() for i in (0, 1)]
+opt = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=5e-4)
+N = 512
+def step(q):
+    loss = 0.0
+    for net, S in ((nets[0], 64), (nets[1], 192)):
+        pts = torch.rand(N, S, 3, device='cuda') * 4 - 2
+        dirs = torch.rand(N, 3, device='cuda') * 2 - 1
+        raw = q(pts, dirs, net)                                   # main query: carries gradients
+        with torch.no_grad():
+            eps = q(torch.rand(4 * N, S, 3, device='cuda') * 4 - 2, None, net)          # 4 offset copies, trunk only
+            refl = q(torch.rand(N, 64, 3, device='cuda') * 4 - 2, dirs, net)            # reflected ray, 64 coarse z
+        loss = loss + raw.square().mean() + 0.0 * (eps.mean() + refl.mean())
+    opt.zero_grad(); loss.backward(); opt.step()
+def timeit(q, n=10):
+    for _ in range(3): step(q)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step(q)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+a = timeit(torch_query)
+b = timeit(M.training_network_query_fn(torch_query))
+print("queries of one training step: all PyTorch fp32 %.1f ms; no-grad queries on the fused kernel %.1f ms (%.2fx)" % (a, b, a / b))

@@ -368,3 +368,28 @@ def test_f16_mode_with_out_of_range_weights(R, lut):
     a = fast.network_query(g["q_c_main_pts"], g["q_c_main_dirs"], 0)
     b = wide.network_query(g["q_c_main_pts"], g["q_c_main_dirs"], 0)
     assert fast.range_fallbacks == 0 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_device_side_weight_upload_is_bit_identical(R, lut, prec):
+    """Weights packed on the device (iblnerf_upload_weights_device) == weights packed on the host, for both kernels."""
+    from ibl_nerf_amd import checkpoint as ck
+    g, sdc, _, _, _ = load_golden("plain_g16")                   # wide-range weights
+    host = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision=prec)
+    dev = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision=prec)
+    host.load_weights(0, sdc)
+    dev.load_weights(0, {k: torch.from_numpy(v).cuda() for k, v in sdc.items()})          # CUDA tensors -> device packer
+    pts, dirs = g["q_c_main_pts"], g["q_c_main_dirs"]
+    assert torch.equal(host.network_query(pts, dirs, 0), dev.network_query(pts, dirs, 0))
+    assert torch.equal(host.network_query(pts, None, 0), dev.network_query(pts, None, 0))
+    dev.load_weights(0, torch.from_numpy(ck.state_dict_to_blob(sdc)).cuda())              # flat device blob
+    assert torch.equal(host.network_query(pts, dirs, 0), dev.network_query(pts, dirs, 0))
+    with pytest.raises(ValueError):
+        dev.load_weights(0, {k: torch.from_numpy(v).cuda() for k, v in list(sdc.items())[:-1]})
+    if prec == "f16_mxfp6":                                      # an out-of-range weight is reported through the range flag
+        bad = {k: torch.from_numpy(v).cuda() for k, v in sdc.items()}
+        bad["positions_linears.3.weight"][7, 7] = 1.0e5
+        dev.load_weights(0, bad)
+        wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
+        wide.load_weights(0, {k: v.cpu().numpy() for k, v in bad.items()})
+        assert torch.equal(dev.network_query(pts, dirs, 0), wide.network_query(pts, dirs, 0)) and dev.range_fallbacks == 1
