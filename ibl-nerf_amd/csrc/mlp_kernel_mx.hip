@@ -77,6 +77,13 @@ __host__ __device__ constexpr int dma_piece(int cr) {
 // slice 3, k-step 3 + the fp6 forms at slice 7); that block's slots are the tile's last six, so slice 7 must
 // be done before the fourth-last slot issues.
 __host__ __device__ constexpr int slice_slot(int i, int ns) { return ns >= CHUNK_SLOTS ? 1 + (i * (ns - 5)) / 7 : 1 + (i * (ns - 1)) / 8; }
+// A slice is one dependency chain of ~11 VALU instructions; beside a single MFMA only about six are free and each
+// further one costs its full latency (a slot-level s_memtime trace showed slice slots 50-100 cycles longer than the
+// others).  So every slice runs as two stages in two consecutive slots: A = read the accumulators, block max, ReLU;
+// B = f16 pair, residuals, store, head dot products.  Stage q = 2*slice + stage of the previous tile runs after the
+// MFMA of slot stage_slot(q): 16 stages over the tile's first slots, the last one (slice 7, B) before slot ns - 5.
+constexpr int N_STAGES = 2;   // (three stages — reads+max / ReLU / rest — measured 3 % slower than two)
+__host__ __device__ constexpr int stage_slot(int q, int ns) { return ns >= CHUNK_SLOTS ? 1 + (q * (ns - 6)) / (8 * N_STAGES) : 1 + (q * (ns - 1)) / (8 * N_STAGES); }
 
 // ---------------------------------------------------------------------------------------------
 // weight-stream pipeline (cf. Pipe in mlp_kernel.hip): cyclic, never drained.  While chunk c is
@@ -268,8 +275,10 @@ struct Epi {
     u32x4 hq;
     int mxv;   // running block max as the int image of a non-negative float (ordering is the same; one v_max3_i32 per pair)
 
+    float sx0, sx1;   // the slice in flight between its two stages
+
     template <int T, int I>
-    __device__ __forceinline__ void slice(const f32x16& acc) {
+    __device__ __forceinline__ void stage_a(const f32x16& acc) {
         float x0 = acc[2 * I], x1 = acc[2 * I + 1];
         if constexpr (STORE) {
             // block max on the raw accumulator bits: with ReLU a negative value (negative int) never wins and the
@@ -282,6 +291,14 @@ struct Epi {
             x0 = relu_bits(x0);
             x1 = relu_bits(x1);
         }
+        sx0 = x0;
+        sx1 = x1;
+        pin(sx0);
+        pin(sx1);
+    }
+    template <int T, int I>
+    __device__ __forceinline__ void stage_b() {
+        const float x0 = sx0, x1 = sx1;
         if constexpr (STORE) {
             constexpr int j = 2 * (T & 1) + (I >> 2);   // f16 k-step of the block
             unsigned hb, lb;
@@ -300,6 +317,16 @@ struct Epi {
             *part[c] = fmaf(x1, w[1], fmaf(x0, w[0], *part[c]));
             if constexpr (I == 7) pin(*part[c]);
         }
+    }
+    template <int T, int I, int K>
+    __device__ __forceinline__ void stage(const f32x16& acc) {
+        if constexpr (K == 0) stage_a<T, I>(acc);
+        else stage_b<T, I>();
+    }
+    template <int T, int I>
+    __device__ __forceinline__ void slice(const f32x16& acc) {
+        stage_a<T, I>(acc);
+        stage_b<T, I>();
     }
 };
 
@@ -346,11 +373,11 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             if constexpr (g == NS / 2 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x16*>(bias_tab + (t + 1) * 32);
             if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
 #ifndef IBL_MX_ABLATE_NO_EPI     // timing ablation only: no epilogue work
-            static_for<0, 8>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                if constexpr (g == slice_slot(i, NS)) {
-                    if constexpr (t == 0) pend(I);
-                    else epi.template slice<(t > 0 ? t - 1 : 0), i>(prev);
+            static_for<0, 8 * N_STAGES>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if constexpr (g == stage_slot(q, NS)) {
+                    if constexpr (t == 0) pend(std::integral_constant<int, q / N_STAGES>{}, std::integral_constant<int, q % N_STAGES>{});
+                    else epi.template stage<(t > 0 ? t - 1 : 0), q / N_STAGES, q % N_STAGES>(prev);
                 }
             });
 #endif
@@ -459,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 #pragma unroll
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;
-        auto none = [](auto) {};
+        auto none = [](auto, auto) {};
         auto flush = [&](auto& e, auto T, const f32x16& acc) {
             static_for<0, 8>([&](auto I) { e.template slice<decltype(T)::value, decltype(I)::value>(acc); });
         };
@@ -472,16 +499,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         // positions_linears.1..4, two layers per trip (A -> B -> A)
         for (int l = 1; l <= 3; l += 2) {
             pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
-                                          [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+                                          [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
             pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
-                                          [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
+                                          [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
         }
         // positions_linears.5 : cat([x63, h]) (ibl_nerf.py:167-168) (A -> B)
         pacc = run_layer<8, true, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 40) * 32,
-                                     [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, eB);
+                                     [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
         // positions_linears.6 (B -> A)
         pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 48) * 32,
-                                      [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
+                                      [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
         // positions_linears.7 (A -> B); sigma_linear / roughness_linear on its fp32 activations
         auto e7 = [&] {
             if constexpr (VARIANT == VAR_FULL)
@@ -490,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}, &peak};
         }();
         pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 56) * 32,
-                                      [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, e7);
+                                      [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, e7);
 
         if constexpr (VARIANT == VAR_TRUNK) {
             flush(e7, T7{}, pacc);
@@ -498,22 +525,22 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             // feature_linear : no activation (B = h7 -> A = feature)
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}, &peak};
                 pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + BT_FEAT * 32,
-                                          [&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); }, eFeat);
+                                          [&](auto I, auto K) { e7.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eFeat);
             Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
                                      {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}, &peak};
             Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}, &peak};
             if constexpr (VARIANT == VAR_FULL) {
                 f32x16 qacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_ALB * 32,
-                                                     [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eAlb);
+                                                     [&](auto I, auto K) { eFeat.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eAlb);
                 pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_IRR * 32,
-                                              [&](auto I) { eAlb.template slice<3, decltype(I)::value>(qacc); }, eIrr);
+                                              [&](auto I, auto K) { eAlb.template stage<3, decltype(I)::value, decltype(K)::value>(qacc); }, eIrr);
             }
             // views_linears.0 : cat([feature, dir27]) (A -> B); radiance_linear
             Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]},
                                      {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}, &peak};
-                pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, [&](auto I) {
-                if constexpr (VARIANT == VAR_FULL) eIrr.template slice<3, decltype(I)::value>(pacc);
-                else eFeat.template slice<7, decltype(I)::value>(pacc);
+                pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, [&](auto I, auto K) {
+                if constexpr (VARIANT == VAR_FULL) eIrr.template stage<3, decltype(I)::value, decltype(K)::value>(pacc);
+                else eFeat.template stage<7, decltype(I)::value, decltype(K)::value>(pacc);
             }, eView);
             Epi<false, true, 3> eAr0{nullptr, {&part[9], &part[10], &part[11]},
                                      {ltab + TAB_AR, ltab + TAB_AR + 128, ltab + TAB_AR + 256}, &peak};
@@ -522,11 +549,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             Epi<false, true, 3> eAr2{nullptr, {&part[15], &part[16], &part[17]},
                                      {ltab + TAB_AR + 768, ltab + TAB_AR + 896, ltab + TAB_AR + 1024}, &peak};
             pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32,
-                                          [&](auto I) { eView.template slice<7, decltype(I)::value>(pacc); }, eAr0);
+                                          [&](auto I, auto K) { eView.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eAr0);
             pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 4) * 32,
-                                          [&](auto I) { eAr0.template slice<3, decltype(I)::value>(pacc); }, eAr1);
+                                          [&](auto I, auto K) { eAr0.template stage<3, decltype(I)::value, decltype(K)::value>(pacc); }, eAr1);
             pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 8) * 32,
-                                          [&](auto I) { eAr1.template slice<3, decltype(I)::value>(pacc); }, eAr2);
+                                          [&](auto I, auto K) { eAr1.template stage<3, decltype(I)::value, decltype(K)::value>(pacc); }, eAr2);
             flush(eAr2, T3{}, pacc);
         }
 
