@@ -122,6 +122,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         g_create_error = "unsupported sample counts: need 3 <= N_samples, N_samples + N_importance <= 256";
         return IBLNERF_ERR_INVALID;
     }
+    if (opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON && opts->normal_mode != IBLNERF_NORMAL_GROUND_TRUTH) {
+        g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0) or IBLNERF_NORMAL_GROUND_TRUTH (1)";
+        return IBLNERF_ERR_INVALID;
+    }
     if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6) {
         g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0) or IBLNERF_MLP_F16_MXFP6 (1)";
         return IBLNERF_ERR_INVALID;
@@ -383,10 +387,12 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
     int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw);
     if (rc) return rc;
-    // epsilon-normal: 4 offset copies, trunk only (normal_from_depth.py:139-158)
-    HIP_TRY(c, launch_make_points(1, ro, rd, z, z_stride, c->opt.epsilon, R, S, c->pts, s));
-    rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
-    if (rc) return rc;
+    // epsilon-normal: 4 offset copies, trunk only (normal_from_depth.py:139-158); none in the ground-truth normal mode
+    if (ov.gt_normal == nullptr) {
+        HIP_TRY(c, launch_make_points(1, ro, rd, z, z_stride, c->opt.epsilon, R, S, c->pts, s));
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
+        if (rc) return rc;
+    }
     PassAArgs a;
     a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
     a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = c->opt.epsilon;
@@ -439,6 +445,12 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         std::memcpy(ov.albedo_list, ovr->albedo_list, sizeof ov.albedo_list);
         std::memcpy(ov.irr_list, ovr->irradiance_list, sizeof ov.irr_list);
     }
+    const float* gt_normal = nullptr;
+    if (c->opt.normal_mode == IBLNERF_NORMAL_GROUND_TRUTH) {
+        if (!ovr || !ovr->d_gt_normal)
+            return c->fail(IBLNERF_ERR_INVALID, "normal_mode ground_truth needs overrides.d_gt_normal (gt_values[\"normal\"] rows)");
+        gt_normal = ovr->d_gt_normal;
+    }
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->opt.device));
     c->ev_used = 0;
@@ -453,6 +465,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         const float* ro = d_rays_o + 3 * r0;
         const float* rd = d_rays_d + 3 * r0;
         OverrideArgs o = ov;
+        o.gt_normal = gt_normal ? gt_normal + 3 * r0 : nullptr;
         if (o.mode) {
             o.mask = ovr->d_mask + 3 * r0;
             o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;

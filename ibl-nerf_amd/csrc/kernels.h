@@ -56,6 +56,7 @@ struct OverrideArgs {          // edit_intrinsic / insert_object branches, ibl_n
     int depth_stride;
     const float* normal_img;   // [R,3] in [0,1]
     const float* albedo_img;   // [R,3]
+    const float* gt_normal;    // [R,3] in [0,1] or null: target normal = normalize(2 v - 1) for every ray (:370-371), no eps-normal
     float rough_list[8];
     float albedo_list[24];
     float irr_list[8];

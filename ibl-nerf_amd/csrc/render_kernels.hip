@@ -228,9 +228,10 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     for (int c = 0; c < 17; ++c) ch[c] = wave_sum(ch[c]);
 
     // epsilon-normal depths (normal_from_depth.py:158-176): same z / dists, trunk-only sigma
-    float D[4];
+    float D[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
+        if (a.ov.gt_normal != nullptr) break;   // "ground_truth" normal mode: no offset queries were made
         float sv[NPL], wv[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -272,6 +273,11 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     }
     cross3(dxv, dyv, nrm);
     normalize3(nrm);
+    if (a.ov.gt_normal != nullptr) {   // target_normal_map_for_radiance_calculation == "ground_truth" (:370-371)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = 2.0f * a.ov.gt_normal[3 * r + c] - 1.0f;
+        normalize3(nrm);
+    }
 
     if (mask_all && ((ov.mode == 1 && ov.edit_normal) || ov.mode == 2)) {   // :380-382, :401-403
         float g[3];

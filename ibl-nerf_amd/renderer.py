@@ -53,7 +53,7 @@ class Renderer:
     def __init__(self, N_samples=64, N_importance=128, *, epsilon=0.01, gamma_correct=True, lut_coefficient="F",
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
-                 mlp_precision=None):
+                 mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon"):
         """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
         rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
         activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
@@ -62,6 +62,8 @@ class Renderer:
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
         if mlp_precision not in ("bf16x3", "f16_mxfp6"):
             raise ValueError("mlp_precision must be 'bf16x3' or 'f16_mxfp6'")
+        if normal_mode not in NORMAL_MODES:
+            raise ValueError(normal_mode)                                          # ibl_nerf_renderer.py:374-375
         if not torch.cuda.is_available():
             raise B.IblNerfError("no HIP device visible to torch: the render path has no CPU fallback")
         if lut_coefficient not in ("F", "F0"):
@@ -80,12 +82,14 @@ class Renderer:
         o.lindisp = int(bool(lindisp))
         o.use_radiance_linear = int(bool(use_radiance_linear))
         o.mlp_precision = B.MLP_F16_MXFP6 if mlp_precision == "f16_mxfp6" else B.MLP_BF16X3
+        o.normal_mode = NORMAL_MODES[normal_mode]
+        self.normal_mode = normal_mode
         self.mlp_precision = mlp_precision
         self._ctor = dict(N_samples=N_samples, N_importance=N_importance, epsilon=epsilon, gamma_correct=gamma_correct,
                           lut_coefficient=lut_coefficient,
                           correct_depth_for_prefiltered_radiance_infer=correct_depth_for_prefiltered_radiance_infer,
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
-                          lindisp=lindisp, use_radiance_linear=use_radiance_linear)
+                          lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode)
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
         self.range_fallbacks = 0
@@ -271,7 +275,8 @@ class Renderer:
         ei, io = bool(edit.get("edit_intrinsic", False)), bool(edit.get("insert_object", False))
         assert not (edit.get("load_edit_intrinsic_mask") and io), \
             "edit_intrinsic and insert_object cannot be True at the same time"          # ibl_nerf_renderer.py:218
-        if not ei and not io:
+        gt_normal_mode = self.normal_mode == "ground_truth"
+        if not ei and not io and not gt_normal_mode:
             return None, []
         ov, keep = B.Overrides(), []
 
@@ -285,6 +290,10 @@ class Renderer:
             keep.append(t)
             return t.data_ptr()
 
+        if gt_normal_mode:                                                              # :370-371
+            ov.d_gt_normal = rows("normal", 3)
+        if not ei and not io:
+            return ov, keep
         if ei:                                                                          # :219-228 (wins over insert, elif)
             nobj = int(edit.get("num_edit_objects") or 0)
             assert nobj > 0, "num_edit_objects must be greater than 0"
@@ -354,10 +363,10 @@ def _check_supported(kw):
     if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
         raise NotImplementedError("perturb / raw_noise_std > 0 are training-time options (SURVEY.md §8 f-3)")
     mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
-    if mode != "normal_map_from_depth_gradient_epsilon":
+    if mode not in NORMAL_MODES:
         if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
                     "normal_map_from_depth_gradient_direction", "normal_map_from_depth_gradient_direction_epsilon",
-                    "ground_truth", "inferred_normal_map"):
+                    "inferred_normal_map"):
             raise NotImplementedError("normal mode %r is not built (SURVEY.md §8 f-4)" % mode)
         raise ValueError(mode)                                                       # ibl_nerf_renderer.py:374-375
     if not kw.get("approximate_radiance", False):
@@ -367,6 +376,7 @@ def _check_supported(kw):
 
 
 _renderers = {}
+NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1}   # target_normal_map_for_radiance_calculation values built
 DEFAULT_MLP_PRECISION = "f16_mxfp6"
 
 
@@ -389,14 +399,15 @@ def renderer_for(kw):
            kw.get("lut_coefficient"), bool(kw.get("correct_depth_for_prefiltered_radiance_infer", False)),
            bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device(),
            bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)),
-           kw.get("mlp_precision") or DEFAULT_MLP_PRECISION)
+           kw.get("mlp_precision") or DEFAULT_MLP_PRECISION,
+           kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"))
     ent = _renderers.get(key)
     if ent is None:
         if kw.get("lut_coefficient") not in ("F", "F0"):
             raise ValueError(kw.get("lut_coefficient"))                               # ibl_nerf_renderer.py:437-438
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
-                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11])
+                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

@@ -52,6 +52,9 @@ typedef struct {
     int32_t device;                    /* HIP device ordinal */
     int32_t lindisp;                   /* 0 (shipped) | 1: sample linearly in inverse depth (ibl_nerf_renderer.py:673-674) */
     int32_t use_radiance_linear;       /* 0 (shipped, sigmoid radiance) | 1: ReLU radiance + Reinhard LDR map (:30-35, :480-483) */
+    int32_t normal_mode;               /* target_normal_map_for_radiance_calculation: IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON
+                                          (shipped; 4 offset queries per sample, normal_from_depth.py:139-183) or
+                                          IBLNERF_NORMAL_GROUND_TRUTH (gt_values["normal"] rows, :370-371; no offset queries) */
     int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
                                           1e-3 parity bar; no reference counterpart):
                                           IBLNERF_MLP_BF16X3    three bf16 products on hi/lo splits, fp32 range
@@ -61,6 +64,7 @@ typedef struct {
                                                                 beyond that runs on the bf16x3 kernel by itself) */
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
+enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1 };
 
 void iblnerf_default_options(iblnerf_options* o);
 
@@ -130,6 +134,8 @@ typedef struct {
     float roughness_list[8];           /* editing_/inserting_target_roughness_list */
     float albedo_list[24];             /* editing_/inserting_target_albedo_list */
     float irradiance_list[8];          /* inserting_target_irradiance_list */
+    const float* d_gt_normal;          /* gt_values["normal"] [n,3] in [0,1]; required when options.normal_mode is
+                                          IBLNERF_NORMAL_GROUND_TRUTH (mode may then be 0), ignored otherwise */
 } iblnerf_overrides;
 
 /* The 22 non-None maps raw2outputs returns per pass (ibl_nerf_renderer.py:494-525).  Device

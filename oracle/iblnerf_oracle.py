@@ -249,7 +249,8 @@ def decode_masks(mask_img, n_obj):
 def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None):
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
-    epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461)."""
+    epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
+    target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth', :348-375)."""
     gt = gt or {}
     edit = edit or {}
     flags = flags or {}
@@ -280,7 +281,13 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     irr = np.sum(w * radiance_f(raw[..., 5]), -1, dtype=F32)[:, None]                       # :287-288, :328
     rad = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
 
-    normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
+    nmode = flags.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
+    if nmode == "ground_truth":
+        normal = normalize(F32(2) * gt["normal"] - F32(1))                                  # :370-371
+    elif nmode == "normal_map_from_depth_gradient_epsilon":
+        normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
+    else:
+        raise ValueError(nmode)                                                             # :374-375
     if stages is not None:
         stages["normal_raw"] = normal.copy()
     if edit.get("edit_intrinsic"):                                                          # :378-398

@@ -51,7 +51,7 @@ def rel_linf(x, ref):
 
 
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
-                   "edit2_g10", "variant_small_g10"]
+                   "edit2_g10", "variant_small_g10", "gtnormal_g10"]
 
 
 def n_samples(g):
@@ -61,7 +61,7 @@ def n_samples(g):
 
 def golden_flags(g):
     """Flag variants recorded with a fixture (use_radiance_linear / lindisp / lut_coefficient / epsilon /
-    gamma_correct / correct_depth_for_prefiltered_radiance_infer)."""
+    gamma_correct / correct_depth_for_prefiltered_radiance_infer / target_normal_map_for_radiance_calculation)."""
     return {k[6:]: g[k].item() for k in g.files if k.startswith("flag__")}
 
 

@@ -201,6 +201,11 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
         gt["edit_depth"] = rng.uniform(1, 3, (n_rays, 1)).astype(np.float32)
         gt["edit_albedo"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    elif mode == "gtnormal":  # target_normal_map_for_radiance_calculation = "ground_truth" (the parser's default), one edit on top
+        edit.update(edit_intrinsic=True, num_edit_objects=1, edit_roughness=True, editing_target_roughness_list=[0.25])
+        level = rng.choice([0, 10], size=n_rays, p=[0.6, 0.4]).astype(np.float32) / np.float32(255)
+        gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
     elif mode == "insert":  # configs/IBL-NeRF/living-room-2/object_insert.txt:8-14
         edit.update(insert_object=True, num_insert_objects=4, inserting_target_roughness_list=[1, 1, 1, 1],
                     inserting_target_albedo_list=[0.870588, 0.3215686, 0.443137254, .05, .05, .05, .2, .2, .2, .05, .05, .05],
@@ -236,12 +241,17 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
     # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
     passes = ["c", "f"] if n_importance > 0 else ["c"]
+    gt_normals = (flags or {}).get("target_normal_map_for_radiance_calculation") == "ground_truth"
+    nq = 2 if gt_normals else 3                          # no eps-normal query in the ground-truth normal mode
     for pi, p in enumerate(passes):
-        main, eps, refl = rec.q[3 * pi:3 * pi + 3]
+        qs = rec.q[nq * pi:nq * pi + nq]
+        main, refl = qs[0], qs[-1]
         out["q_%s_main_pts" % p], out["q_%s_main_dirs" % p], out["q_%s_main_raw" % p] = main["pts"], main["dirs"], main["raw"]
-        out["q_%s_eps_pts" % p], out["q_%s_eps_sigma" % p] = eps["pts"], eps["raw"]
         out["q_%s_refl_pts" % p], out["q_%s_refl_dirs" % p], out["q_%s_refl_raw" % p] = refl["pts"], refl["dirs"], refl["raw"]
-        out["normal_raw_%s" % p] = rec.nrm[pi]          # before edit/insert overrides
+        if not gt_normals:
+            eps = qs[1]
+            out["q_%s_eps_pts" % p], out["q_%s_eps_sigma" % p] = eps["pts"], eps["raw"]
+            out["normal_raw_%s" % p] = rec.nrm[pi]      # before edit/insert overrides
         out["prefiltered_env_%s" % p] = rec.simple[pi]  # [N,4,3] linear (pre-gamma)
         out["lut_uv_%s" % p], out["lut_val_%s" % p] = rec.lut[pi]["uv"], rec.lut[pi]["val"]
     if n_importance > 0:
@@ -363,6 +373,9 @@ def main(only=None):
     run_fixture("variant_small_g10", torch, R, M, lut, n_rays=96, n_importance=48, gain=1.0, seed=6, n_samples=32,
                 near=1.0, far=5.0, posed=True,
                 flags=dict(epsilon=0.02, gamma_correct=False, correct_depth_for_prefiltered_radiance_infer=False))
+    # ground-truth normals instead of the eps-normal (no offset queries)
+    run_fixture("gtnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=7, mode="gtnormal",
+                flags=dict(target_normal_map_for_radiance_calculation="ground_truth"))
 
 
 if __name__ == "__main__":

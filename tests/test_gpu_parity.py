@@ -32,6 +32,8 @@ PRECISIONS = ["bf16x3", "f16_mxfp6"]   # the two product schemes of the fused ML
 
 def make_renderer(R, g, sdc, sdf, lut, **kw):
     kw = dict(golden_flags(g), **kw)
+    if "target_normal_map_for_radiance_calculation" in kw:
+        kw["normal_mode"] = kw.pop("target_normal_map_for_radiance_calculation")
     r = R.Renderer(n_samples(g), int(g["n_importance"]), **kw)
     r.load_weights(0, sdc)
     if int(g["n_importance"]) > 0:
@@ -98,8 +100,9 @@ def test_network_query_stagewise(R, name, lut, prec):
         raw = r.network_query(g["q_%s_main_pts" % p], g["q_%s_main_dirs" % p], which).cpu().numpy()
         assert raw.shape == g["q_%s_main_raw" % p].shape
         assert np.abs(raw - g["q_%s_main_raw" % p]).max() <= tol
-        sig = r.network_query(g["q_%s_eps_pts" % p], None, which).cpu().numpy()
-        assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= tol
+        if "q_%s_eps_pts" % p in g.files:
+            sig = r.network_query(g["q_%s_eps_pts" % p], None, which).cpu().numpy()
+            assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= tol
         refl = r.network_query(g["q_%s_refl_pts" % p], g["q_%s_refl_dirs" % p], which).cpu().numpy()
         assert np.abs(refl - g["q_%s_refl_raw" % p]).max() <= tol
     assert r.range_fallbacks == 0
@@ -393,3 +396,28 @@ def test_device_side_weight_upload_is_bit_identical(R, lut, prec):
         wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
         wide.load_weights(0, {k: v.cpu().numpy() for k, v in bad.items()})
         assert torch.equal(dev.network_query(pts, dirs, 0), wide.network_query(pts, dirs, 0)) and dev.range_fallbacks == 1
+
+
+def test_render_decomp_ground_truth_normal_mode(R, lut):
+    """The drop-in seam with target_normal_map_for_radiance_calculation="ground_truth" (the parser's default value):
+    normals come from gt_values["normal"], no offset queries are launched, results match the reference golden."""
+    from ibl_nerf_amd import model as M
+    g, sdc, sdf, gt, edit = load_golden("gtnormal_g10")
+    net_c, net_f = M.IBLNeRF(), M.IBLNeRF()
+    net_c.load_state_dict(sdc)
+    net_f.load_state_dict(sdf)
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, perturb=False, raw_noise_std=0, lindisp=False,
+              gamma_correct=True, lut_coefficient="F", epsilon=0.01, target_normal_map_for_radiance_calculation="ground_truth",
+              correct_depth_for_prefiltered_radiance_infer=True, near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut), max_rays_per_launch=64)
+    rays = torch.from_numpy(np.stack([g["rays_o"], g["rays_d"]], 0))
+    r = R.renderer_for(kw)
+    r.set_profiling(True)
+    ret = R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={k: torch.from_numpy(v) for k, v in gt.items()},
+                          approximate_radiance=True, **kw, **edit)
+    n_launch = r.last_mlp_time()[1]
+    r.set_profiling(False)
+    assert n_launch == 2 * 2 * 2                      # 2 launches x (coarse, fine) x (main + reflected): no TRUNK launches
+    assert rel_linf(ret["target_normal_map"].cpu().numpy(), g["out__target_normal_map"]) <= 1e-6
+    assert rel_linf(ret["color_map"].cpu().numpy(), g["out__color_map"]) <= 2e-4
+    with pytest.raises(KeyError):
+        R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)

@@ -55,8 +55,9 @@ def test_network_query_stagewise(name):
     for p, sd in passes:
         raw = O.network_query(sd, g["q_%s_main_pts" % p], g["q_%s_main_dirs" % p])
         assert np.abs(raw - g["q_%s_main_raw" % p]).max() <= 2e-6
-        sig = O.network_query(sd, g["q_%s_eps_pts" % p], None)
-        assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= 2e-6
+        if "q_%s_eps_pts" % p in g.files:                       # absent in the ground-truth normal mode
+            sig = O.network_query(sd, g["q_%s_eps_pts" % p], None)
+            assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= 2e-6
         refl = O.network_query(sd, g["q_%s_refl_pts" % p], g["q_%s_refl_dirs" % p])
         assert np.abs(refl - g["q_%s_refl_raw" % p]).max() <= 2e-6
 
@@ -88,7 +89,8 @@ def test_render_rays_end_to_end(name, lut):
         # stage-wise (teacher-forced) sample_pdf on the reference's own inputs
         assert np.abs(O.sample_pdf(g["pdf_bins"], g["pdf_weights"], int(g["n_importance"])) - g["pdf_samples"]).max() <= 2e-5  # 1 ulp of cdf / pdf(~2e-3) * bin width
     for p in (["c", "f"] if int(g["n_importance"]) > 0 else ["c"]):
-        assert rel_linf(st[p]["normal_raw"], g["normal_raw_%s" % p]) <= (5e-3 if wide else 6e-4)
+        if "normal_raw_%s" % p in g.files:
+            assert rel_linf(st[p]["normal_raw"], g["normal_raw_%s" % p]) <= (5e-3 if wide else 6e-4)
         lin = bool(flags.get("use_radiance_linear", False))
         # teacher-forced LUT fetch and reflected-ray composite on the reference's own inputs
         uv = g["lut_uv_%s" % p]
