@@ -5,6 +5,8 @@
 #include <cstdlib>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 template <int KIND, int N>
 __global__ __launch_bounds__(256, 1) void k(const float* seed, float* out, int iters) {
     f16x8 a, b;
@@ -15,6 +17,8 @@ __global__ __launch_bounds__(256, 1) void k(const float* seed, float* out, int i
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = seed[100 + threadIdx.x + i];
     unsigned pk = 0;
+    u32x16 hv; for (int i = 0; i < 16; ++i) hv[i] = __builtin_bit_cast(unsigned, seed[300 + threadIdx.x + i]) & 0x3fff3fffu;
+    unsigned sinkc = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -30,13 +34,16 @@ __global__ __launch_bounds__(256, 1) void k(const float* seed, float* out, int i
                 if (KIND == 5) asm volatile("s_nop 0");
                 if (KIND == 6) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x) : "v"(v[(n + 1) & 7]), "v"(v[(n + 2) & 7]));
                 if (KIND == 7) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(v[(n + 3) & 7]));
+                if (KIND == 8) { asm volatile("" : "+v"(hv)); auto r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), 1.0f); asm volatile("" :: "v"(r)); }
+                if (KIND == 9) { f32x16 a16, b16; for (int i = 0; i < 16; ++i) { a16[i] = v[i & 7]; b16[i] = v[(i + 3) & 7]; }
+                                 auto r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a16, b16, 1.0f); sinkc ^= (unsigned)r[n % 6]; v[n & 7] += 1.0f; }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     float s = 0; for (int r = 0; r < 16; ++r) s += acc[r];
     for (int i = 0; i < 8; ++i) s += v[i];
-    out[blockIdx.x * 256 + threadIdx.x] = s + (float)pk;
+    out[blockIdx.x * 256 + threadIdx.x] = s + (float)pk + (float)sinkc;
 }
 template <int KIND, int N> double run(const float* d_seed, float* d_out, int grid) {
     const int iters = 3000;
@@ -64,5 +71,7 @@ int main(int argc, char** argv) {
     row<5>(d_seed, d_out, grid, "s_nop 0");
     row<6>(d_seed, d_out, grid, "v_max3_i32");
     row<7>(d_seed, d_out, grid, "v_mov_b32");
+    printf("%-22s ns/MFMA with 0,1,2 fillers: %5.1f %5.1f %5.1f\n", "cvt_pk32_fp6_f16", run<8, 0>(d_seed, d_out, grid), run<8, 1>(d_seed, d_out, grid), run<8, 2>(d_seed, d_out, grid));
+    printf("%-22s ns/MFMA with 0,1,2 fillers: %5.1f %5.1f %5.1f\n", "cvt_2xpk16_fp6_f32", run<9, 0>(d_seed, d_out, grid), run<9, 1>(d_seed, d_out, grid), run<9, 2>(d_seed, d_out, grid));
     return 0;
 }
