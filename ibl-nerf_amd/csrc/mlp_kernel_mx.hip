@@ -36,7 +36,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // B operands of one K=64 block of this wave's 32 points: 4 f16 k-steps, fp6 of the f16 values, fp6 of
 // the f16 residuals, and the two e8m0 block scales (byte 0: x6, byte 1: l6).  29 registers.
 struct Blk {
-    u32x4 h[4];
+    u32x16 hv;        // the 4 f16 k-steps (4 dwords each) as ONE vector: the fp6 conversion reads all 16 registers, so they
+                      // are kept consecutive from the start; k-step S is quarter<S>(hv) (sub-vectors are cut in SSA)
     u32x4 x6a, l6a;   // fp6 bits 0..127   (6-wide vectors are kept out of the structs: they defeat SROA)
     u32x2 x6b, l6b;   // fp6 bits 128..191
     unsigned sc;
@@ -210,11 +211,22 @@ __device__ __forceinline__ i32x8 fp6_operand(const u32x4& q, const u32x2& d) {
     return v;
 }
 
+template <int S>
+__device__ __forceinline__ u32x4 quarter(const u32x16& v) { return __builtin_shufflevector(v, v, 4 * S, 4 * S + 1, 4 * S + 2, 4 * S + 3); }
+template <int S>
+__device__ __forceinline__ u32x16 with_quarter(const u32x16& v, const u32x4& q) {
+    const u32x16 w = __builtin_shufflevector(q, q, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    if constexpr (S == 0) return __builtin_shufflevector(v, w, 16, 17, 18, 19, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    else if constexpr (S == 1) return __builtin_shufflevector(v, w, 0, 1, 2, 3, 16, 17, 18, 19, 8, 9, 10, 11, 12, 13, 14, 15);
+    else if constexpr (S == 2) return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 12, 13, 14, 15);
+    else return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19);
+}
+
 // slot s of a block: accumulate one of the six products
 template <int S>
 __device__ __forceinline__ f32x16 slot_mfma(const u32x4& aq, const u32x2& ad, unsigned wsc, const Blk& b, f32x16 c) {
     if constexpr (S < 4) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq), __builtin_bit_cast(f16x8, b.h[S]), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq), __builtin_bit_cast(f16x8, quarter<S>(b.hv)), c, 0, 0, 0);
     } else if constexpr (S == 4) {   // fp6(W) [scale byte 0] x fp6(X - f16 X) [scale byte 1]
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(aq, ad), fp6_operand<true>(b.l6a, b.l6b), c, 2, 2, 0, (int)wsc, 1, (int)b.sc);
     } else {                         // fp6(W - f16 W) [scale byte 1] x fp6(f16 X) [scale byte 0]
@@ -248,9 +260,7 @@ __device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mx
     const unsigned e = mb >> 23;                        // biased exponent of the block max
     const float sh = __builtin_bit_cast(float, (e - 2) << 23);    // max / sh in [4, 8)
     const float sl = __builtin_bit_cast(float, (e - 14) << 23);   // |residual| <= 2^(e-11) -> / sl <= 8
-    u32x4 h0 = b.h[0], h1 = b.h[1], h2 = b.h[2], h3 = b.h[3];
-    asm("" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));   // (see fp6_operand: keeps the optimiser from fusing these into one 64-byte load)
-    const u32x16 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3], h2[0], h2[1], h2[2], h2[3], h3[0], h3[1], h3[2], h3[3]};
+    const u32x16 hv = b.hv;
     const auto x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, hv), sh);
     const auto l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, lres), sl);
     b.x6a = u32x4{(unsigned)x6[0], (unsigned)x6[1], (unsigned)x6[2], (unsigned)x6[3]};
@@ -307,7 +317,7 @@ struct Epi {
             lres[4 * j + (I & 3)] = lb;
             if constexpr ((I & 3) == 3) {
                 asm volatile("" : "+v"(hq));
-                dst->b[T >> 1].h[j] = hq;
+                dst->b[T >> 1].hv = with_quarter<j>(dst->b[T >> 1].hv, hq);
             }
             if constexpr (I == 7 && (T & 1) == 1) finish_block(dst->b[T >> 1], lres, mxv, *peak);
         }
@@ -422,7 +432,10 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& en
             lres[4 * j + e] = lb;
             mxv = max(mxv, max(__builtin_bit_cast(int, vals[8 * j + 2 * e]) & 0x7fffffff, __builtin_bit_cast(int, vals[8 * j + 2 * e + 1]) & 0x7fffffff));
         }
-        enc.h[j] = hv;
+        if (j == 0) enc.hv = with_quarter<0>(enc.hv, hv);
+        else if (j == 1) enc.hv = with_quarter<1>(enc.hv, hv);
+        else if (j == 2) enc.hv = with_quarter<2>(enc.hv, hv);
+        else enc.hv = with_quarter<3>(enc.hv, hv);
     }
     finish_block(enc, lres, mxv, peak);
 }
