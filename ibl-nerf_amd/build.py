@@ -27,6 +27,8 @@ SOURCES = [
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
+    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
+    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),
@@ -68,7 +70,7 @@ def build(verbose=True, force=False):
             subprocess.check_call(cmd)
             with open(stamp, "w") as f:
                 f.write(dg)
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as pool:
             list(pool.map(run, jobs))
         relink = True
     if relink:

@@ -24,6 +24,7 @@ std::string g_create_error;
 
 // algorithmic FLOPs per point (SURVEY.md §8 d): 2 * MACs of the nn.Linear layers on the path
 constexpr double FLOP_FULL = 1591552.0, FLOP_TRUNK = 982528.0, FLOP_REFL = 1458944.0;
+constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // what is_color_independent_to_direction skips
 }  // namespace
 
 struct iblnerf_ctx {
@@ -289,6 +290,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                    int pts_per_ray, long n_pts, float* out) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
+    if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
     const bool use_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6 && c->mx_ok[which];
     a.stream = use_mx ? c->d_stream_mx[which] : c->d_stream[which];
     a.range_flag = c->d_range_flag;
@@ -311,7 +313,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     }
     HIP_TRY(c, use_mx ? launch_mlp_mx(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
-    c->flop_alg += (double)n_pts * (variant == VAR_FULL ? FLOP_FULL : variant == VAR_TRUNK ? FLOP_TRUNK : FLOP_REFL);
+    c->flop_alg += (double)n_pts * (variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
 }
 

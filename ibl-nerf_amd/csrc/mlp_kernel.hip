@@ -64,7 +64,8 @@ __device__ long long g_trace[256];
 // ---------------------------------------------------------------------------------------------
 template <int VARIANT>
 struct Pipe {
-    static constexpr int N_PROG = VARIANT == VAR_FULL ? N_CHUNKS : (VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : N_CHUNKS - 8);
+    static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
+    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
     unsigned lds_ring;   // LDS byte address of the ring (for M0)
@@ -77,10 +78,14 @@ struct Pipe {
     long long* tr = nullptr;
 #endif
 
-    // program position -> stream chunk: the reflected-ray variant skips the 8 albedo / irradiance feature chunks
+    // program position -> stream chunk: a variant's program is the trunk followed by the head layers it evaluates
     __device__ __forceinline__ static int stream_chunk(int p) {
-        if (VARIANT == VAR_REFL) return p < CH_ALB ? p : p + 8;
-        return p;
+        if (p < N_CHUNKS_TRUNK) return p;
+        int q = p - N_CHUNKS_TRUNK;
+        if (!CI) { if (q < 8) return CH_FEAT + q; q -= 8; }
+        if (ALBIRR) { if (q < 8) return CH_ALB + q; q -= 8; }
+        if (!CI) { if (q < 9) return CH_VIEW + q; q -= 9; }
+        return CH_AR + q;
     }
     // One 32 KiB chunk = 8 LDS-DMA instructions per wave (wave w copies bytes [8192w, 8192w+8192),
     // piece i = 1 KiB).  Scalar base + one VGPR offset (saddr form) so no 64-bit VGPR address exists;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         }
         Enc pe, de;
         encode<PE_PAIRS_PER_HALF, PE_KSTEPS>(px, py, pz, h, pe);
-        if constexpr (VARIANT != VAR_TRUNK) {
+        if constexpr (VARIANT != VAR_TRUNK && !variant_ci(VARIANT)) {
             // direction encoding of this point's ray (run_network expands viewdirs over the samples,
             // ibl_nerf.py:244-247)
             float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -444,9 +449,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 48) * 32,
                                    [&](auto I) { eB.template slice<7, decltype(I)::value>(pacc); }, eA);
         // ---- positions_linears.7  (A -> B); sigma_linear / roughness_linear on its fp32 activations
+        constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
+        const float* rad[3] = {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512};
+        // with is_color_independent_to_direction the radiance_linear rows are dotted with h7 itself (ibl_nerf.py:192, :199)
         auto e7 = [&] {
             if constexpr (VARIANT == VAR_FULL)
                 return Epi<true, true, 2>{&B, {&part[0], &part[4]}, {ltab + TAB_SIG, ltab + TAB_ROUGH}};
+            else if constexpr (VARIANT == VAR_FULL_CI)
+                return Epi<true, true, 5>{&B, {&part[0], &part[4], &part[6], &part[7], &part[8]},
+                                          {ltab + TAB_SIG, ltab + TAB_ROUGH, rad[0], rad[1], rad[2]}};
+            else if constexpr (VARIANT == VAR_REFL_CI)
+                return Epi<true, true, 4>{&B, {&part[0], &part[6], &part[7], &part[8]}, {ltab + TAB_SIG, rad[0], rad[1], rad[2]}};
             else
                 return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}};
         }();
@@ -456,40 +469,40 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         if constexpr (VARIANT == VAR_TRUNK) {
             flush(e7, T7{}, pacc);
         } else {
-            // ---- feature_linear : 256 -> 256, no activation (B = h7 -> A = feature) ------------
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}};
-            pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32,
-                                       [&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); }, eFeat);
-            // ---- albedo_feature_linear (ReLU) -> albedo_linear ; irradiance_feature_linear -> irradiance_linear
             Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
                                      {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}};
             Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}};
-            if constexpr (VARIANT == VAR_FULL) {
-                Acc qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32,
-                                                  [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eAlb);
-                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_IRR * 32,
-                                           [&](auto I) { eAlb.template slice<3, decltype(I)::value>(qacc); }, eIrr);
-            }
-            // ---- views_linears.0 : cat([feature, dir27]) -> 256, ReLU (A -> B) ; radiance_linear -
-            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]},
-                                     {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}};
-            pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, [&](auto I) {
-                if constexpr (VARIANT == VAR_FULL) eIrr.template slice<3, decltype(I)::value>(pacc);
-                else eFeat.template slice<7, decltype(I)::value>(pacc);
-            }, eView);
-            // ---- additional_radiance_feature_linear.k (ReLU) -> additional_radiance_linear.k ----
+            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]}, {rad[0], rad[1], rad[2]}};
             Epi<false, true, 3> eAr0{nullptr, {&part[9], &part[10], &part[11]},
                                      {ltab + TAB_AR, ltab + TAB_AR + 128, ltab + TAB_AR + 256}};
             Epi<false, true, 3> eAr1{nullptr, {&part[12], &part[13], &part[14]},
                                      {ltab + TAB_AR + 384, ltab + TAB_AR + 512, ltab + TAB_AR + 640}};
             Epi<false, true, 3> eAr2{nullptr, {&part[15], &part[16], &part[17]},
                                      {ltab + TAB_AR + 768, ltab + TAB_AR + 896, ltab + TAB_AR + 1024}};
-            pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32,
-                                       [&](auto I) { eView.template slice<7, decltype(I)::value>(pacc); }, eAr0);
-            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 4) * 32,
-                                       [&](auto I) { eAr0.template slice<3, decltype(I)::value>(pacc); }, eAr1);
-            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 8) * 32,
-                                       [&](auto I) { eAr1.template slice<3, decltype(I)::value>(pacc); }, eAr2);
+            // the epilogue still owed by the previous layer, as the `pend` of the next one
+#define IBL_PEND(e, T, acc) [&](auto I) { (e).template slice<T, decltype(I)::value>(acc); }
+            // feature_linear : 256 -> 256, no activation (B = h7 -> A = feature)
+            if constexpr (!CI) pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32, IBL_PEND(e7, 7, pacc), eFeat);
+            // albedo_feature_linear (ReLU) -> albedo_linear ; irradiance_feature_linear -> irradiance_linear (both read h7 = B)
+            if constexpr (ALBIRR) {
+                Acc qacc;
+                if constexpr (CI) qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32, IBL_PEND(e7, 7, pacc), eAlb);
+                else qacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32, IBL_PEND(eFeat, 7, pacc), eAlb);
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_IRR * 32, IBL_PEND(eAlb, 3, qacc), eIrr);
+            }
+            // views_linears.0 : cat([feature, dir27]) -> 256, ReLU (A -> B) ; radiance_linear
+            if constexpr (!CI) {
+                if constexpr (ALBIRR) pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, IBL_PEND(eIrr, 3, pacc), eView);
+                else pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, IBL_PEND(eFeat, 7, pacc), eView);
+            }
+            // additional_radiance_feature_linear.k (ReLU) -> additional_radiance_linear.k, on B = views output, or h7 when colour-independent
+            if constexpr (!CI) pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32, IBL_PEND(eView, 7, pacc), eAr0);
+            else if constexpr (ALBIRR) pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32, IBL_PEND(eIrr, 3, pacc), eAr0);
+            else pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32, IBL_PEND(e7, 7, pacc), eAr0);
+            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 4) * 32, IBL_PEND(eAr0, 3, pacc), eAr1);
+            pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 8) * 32, IBL_PEND(eAr1, 3, pacc), eAr2);
+#undef IBL_PEND
             flush(eAr2, T3{}, pacc);
         }
 
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 #pragma unroll
             for (int c = 0; c < RAW_CH; ++c) tot[c] = part[c] + __shfl_xor(part[c], 32) + sc[c];
             if (valid) {
-                if constexpr (VARIANT == VAR_FULL) {
+                if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + p * RAW_CH;
                     if (h == 0) {
 #pragma unroll
@@ -538,6 +551,8 @@ hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t strea
         (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
         (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
         (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL_CI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL_CI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
         attr_set = true;
     }
 #ifdef IBL_TRACE
@@ -549,6 +564,8 @@ hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t strea
         case VAR_FULL: hipLaunchKernelGGL(mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
         case VAR_TRUNK: hipLaunchKernelGGL(mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
         case VAR_REFL: hipLaunchKernelGGL(mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
+        case VAR_FULL_CI: hipLaunchKernelGGL(mlp_kernel<VAR_FULL_CI>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
+        case VAR_REFL_CI: hipLaunchKernelGGL(mlp_kernel<VAR_REFL_CI>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
         default: return hipErrorInvalidValue;
     }
 #ifdef IBL_TRACE

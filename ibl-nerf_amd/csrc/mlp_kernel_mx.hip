@@ -94,7 +94,9 @@ __host__ __device__ constexpr int stage_slot(int q, int ns) { return ns >= CHUNK
 // ---------------------------------------------------------------------------------------------
 template <int VARIANT>
 struct Pipe {
-    static constexpr int N_PROG = VARIANT == VAR_FULL ? mx::N_CHUNKS : (VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK : mx::N_CHUNKS - 8);
+    static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
+    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
+                                                        : mx::N_CHUNKS_TRUNK + (CI ? 0 : 8 + 10) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;
     unsigned lds_ring;
@@ -104,8 +106,13 @@ struct Pipe {
     int prog2;                // program position of the chunk two ahead
 
     __device__ __forceinline__ static int stream_chunk(int p) {
-        if (VARIANT == VAR_REFL) return p < mx::CH_ALB ? p : p + 8;   // the reflected-ray variant skips albedo / irradiance features
-        return p;
+        // program position -> stream chunk: a variant's program is the trunk followed by the head layers it evaluates
+        if (p < mx::N_CHUNKS_TRUNK) return p;
+        int q = p - mx::N_CHUNKS_TRUNK;
+        if (!CI) { if (q < 8) return mx::CH_FEAT + q; q -= 8; }
+        if (ALBIRR) { if (q < 8) return mx::CH_ALB + q; q -= 8; }
+        if (!CI) { if (q < 10) return mx::CH_VIEW + q; q -= 10; }
+        return mx::CH_AR + q;
     }
     // Piece i of a chunk (wave w copies bytes [8192 w, 8192 w + 8192) in 8 pieces of 1 KiB).  The instruction's
     // immediate offset moves BOTH the global and the LDS address, so pieces 0..3 (and 4..7) share one M0 value
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         }
         Blk pe, de;
         encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak);
-        if constexpr (VARIANT != VAR_TRUNK) {
+        if constexpr (VARIANT != VAR_TRUNK && !variant_ci(VARIANT)) {
             float dx = 0.f, dy = 0.f, dz = 0.f;
             if (valid) {
                 const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;
@@ -523,9 +530,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 48) * 32,
                                       [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
         // positions_linears.7 (A -> B); sigma_linear / roughness_linear on its fp32 activations
+        constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
+        const float* rad[3] = {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512};
+        // with is_color_independent_to_direction the radiance_linear rows are dotted with h7 itself (ibl_nerf.py:192, :199)
         auto e7 = [&] {
             if constexpr (VARIANT == VAR_FULL)
                 return Epi<true, true, 2>{&B, {&part[0], &part[4]}, {ltab + TAB_SIG, ltab + TAB_ROUGH}, &peak};
+            else if constexpr (VARIANT == VAR_FULL_CI)
+                return Epi<true, true, 5>{&B, {&part[0], &part[4], &part[6], &part[7], &part[8]},
+                                          {ltab + TAB_SIG, ltab + TAB_ROUGH, rad[0], rad[1], rad[2]}, &peak};
+            else if constexpr (VARIANT == VAR_REFL_CI)
+                return Epi<true, true, 4>{&B, {&part[0], &part[6], &part[7], &part[8]}, {ltab + TAB_SIG, rad[0], rad[1], rad[2]}, &peak};
             else
                 return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}, &peak};
         }();
@@ -535,38 +550,40 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         if constexpr (VARIANT == VAR_TRUNK) {
             flush(e7, T7{}, pacc);
         } else {
-            // feature_linear : no activation (B = h7 -> A = feature)
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}, &peak};
-                pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + BT_FEAT * 32,
-                                          [&](auto I, auto K) { e7.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eFeat);
             Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
                                      {ltab + TAB_ALB, ltab + TAB_ALB + 128, ltab + TAB_ALB + 256}, &peak};
             Epi<false, true, 1> eIrr{nullptr, {&part[5]}, {ltab + TAB_IRR}, &peak};
-            if constexpr (VARIANT == VAR_FULL) {
-                f32x16 qacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_ALB * 32,
-                                                     [&](auto I, auto K) { eFeat.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eAlb);
-                pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_IRR * 32,
-                                              [&](auto I, auto K) { eAlb.template stage<3, decltype(I)::value, decltype(K)::value>(qacc); }, eIrr);
-            }
-            // views_linears.0 : cat([feature, dir27]) (A -> B); radiance_linear
-            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]},
-                                     {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}, &peak};
-                pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, [&](auto I, auto K) {
-                if constexpr (VARIANT == VAR_FULL) eIrr.template stage<3, decltype(I)::value, decltype(K)::value>(pacc);
-                else eFeat.template stage<7, decltype(I)::value, decltype(K)::value>(pacc);
-            }, eView);
+            Epi<true, true, 3> eView{&B, {&part[6], &part[7], &part[8]}, {rad[0], rad[1], rad[2]}, &peak};
             Epi<false, true, 3> eAr0{nullptr, {&part[9], &part[10], &part[11]},
                                      {ltab + TAB_AR, ltab + TAB_AR + 128, ltab + TAB_AR + 256}, &peak};
             Epi<false, true, 3> eAr1{nullptr, {&part[12], &part[13], &part[14]},
                                      {ltab + TAB_AR + 384, ltab + TAB_AR + 512, ltab + TAB_AR + 640}, &peak};
             Epi<false, true, 3> eAr2{nullptr, {&part[15], &part[16], &part[17]},
                                      {ltab + TAB_AR + 768, ltab + TAB_AR + 896, ltab + TAB_AR + 1024}, &peak};
-            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32,
-                                          [&](auto I, auto K) { eView.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eAr0);
-            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 4) * 32,
-                                          [&](auto I, auto K) { eAr0.template stage<3, decltype(I)::value, decltype(K)::value>(pacc); }, eAr1);
-            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 8) * 32,
-                                          [&](auto I, auto K) { eAr1.template stage<3, decltype(I)::value, decltype(K)::value>(pacc); }, eAr2);
+            // the epilogue still owed by the previous layer, as the `pend` of the next one
+#define IBL_PEND(e, T, acc) [&](auto I, auto K) { (e).template stage<T, decltype(I)::value, decltype(K)::value>(acc); }
+            // feature_linear : no activation (B = h7 -> A = feature)
+            if constexpr (!CI) pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + BT_FEAT * 32, IBL_PEND(e7, 7, pacc), eFeat);
+            // albedo_feature_linear -> albedo_linear ; irradiance_feature_linear -> irradiance_linear (both read h7 = B)
+            if constexpr (ALBIRR) {
+                f32x16 qacc;
+                if constexpr (CI) qacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_ALB * 32, IBL_PEND(e7, 7, pacc), eAlb);
+                else qacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_ALB * 32, IBL_PEND(eFeat, 7, pacc), eAlb);
+                pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_IRR * 32, IBL_PEND(eAlb, 3, qacc), eIrr);
+            }
+            // views_linears.0 : cat([feature, dir27]) (A -> B); radiance_linear
+            if constexpr (!CI) {
+                if constexpr (ALBIRR) pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, IBL_PEND(eIrr, 3, pacc), eView);
+                else pacc = run_layer<8, true, 4>(P, pf, wsc, A, de, bias + BT_VIEW * 32, IBL_PEND(eFeat, 7, pacc), eView);
+            }
+            // additional_radiance_feature_linear.k -> additional_radiance_linear.k, on B = views output, or h7 when colour-independent
+            if constexpr (!CI) pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32, IBL_PEND(eView, 7, pacc), eAr0);
+            else if constexpr (ALBIRR) pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32, IBL_PEND(eIrr, 3, pacc), eAr0);
+            else pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + BT_AR * 32, IBL_PEND(e7, 7, pacc), eAr0);
+            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 4) * 32, IBL_PEND(eAr0, 3, pacc), eAr1);
+            pacc = run_layer<4, false, 4>(P, pf, wsc, B, pe, bias + (BT_AR + 8) * 32, IBL_PEND(eAr1, 3, pacc), eAr2);
+#undef IBL_PEND
             flush(eAr2, T3{}, pacc);
         }
 
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 #pragma unroll
             for (int c = 0; c < RAW_CH; ++c) tot[c] = part[c] + __shfl_xor(part[c], 32) + sc[c];
             if (valid) {
-                if constexpr (VARIANT == VAR_FULL) {
+                if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + p * RAW_CH;
                     if (h == 0) {
 #pragma unroll
@@ -628,14 +645,20 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
 hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 1
 hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
-#else
+#elif IBL_MX_VARIANT == 2
 hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+#elif IBL_MX_VARIANT == 3
+hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
+#else
+hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
 #endif
 #else
 hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
 #ifndef IBL_MX_DEV_TRUNK_ONLY
 hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
+hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
 #endif
 #endif
 
@@ -643,6 +666,8 @@ hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { retur
 hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -651,6 +676,8 @@ hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t st
 #ifndef IBL_MX_DEV_TRUNK_ONLY
         case VAR_FULL: return launch_mlp_mx_full(a, grid, stream);
         case VAR_REFL: return launch_mlp_mx_refl(a, grid, stream);
+        case VAR_FULL_CI: return launch_mlp_mx_full_ci(a, grid, stream);
+        case VAR_REFL_CI: return launch_mlp_mx_refl_ci(a, grid, stream);
 #endif
         case VAR_TRUNK: return launch_mlp_mx_trunk(a, grid, stream);
         default: return hipErrorInvalidValue;

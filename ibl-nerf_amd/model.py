@@ -24,8 +24,7 @@ class IBLNeRF:
         if (D, W, input_ch, input_ch_views, tuple(skips), coarse_radiance_number) != (8, 256, 63, 27, (4,), 3):
             raise NotImplementedError("the HIP path is built for the shipped architecture: D=8, W=256, multires=10, "
                                       "multires_views=4, skips=[4], coarse_radiance_number=3")
-        if is_color_independent_to_direction:
-            raise NotImplementedError("color_independent_to_direction=True is not built (SURVEY.md §8 f-4)")
+        self.is_color_independent_to_direction = bool(is_color_independent_to_direction)   # ibl_nerf.py:75, :192
         self.coarse_radiance_number = coarse_radiance_number
         self._sd = ck.synthetic_state_dict(seed=0)       # placeholder values until load_state_dict
         self._version = 0
@@ -51,6 +50,10 @@ class IBLNeRF:
 _query_ctx = {}     # id(network) -> {"ref": weakref, "r": Renderer, "w": weights key}
 
 
+def _ci(network_fn):
+    return bool(getattr(network_fn, "is_color_independent_to_direction", False))
+
+
 def _query_renderer(network_fn):
     """A small cached context holding `network_fn`'s weights; they are re-uploaded whenever a parameter
     changed (load_state_dict, or an in-place optimizer step: torch bumps the tensors' `_version`)."""
@@ -58,7 +61,7 @@ def _query_renderer(network_fn):
     from . import renderer as R
     ent = _query_ctx.get(id(network_fn))
     if ent is None or ent["ref"]() is not network_fn:
-        ent = _query_ctx[id(network_fn)] = {"ref": weakref.ref(network_fn), "r": R.Renderer(64, 0, max_rays_per_launch=1), "w": None}
+        ent = _query_ctx[id(network_fn)] = {"ref": weakref.ref(network_fn), "r": R.Renderer(64, 0, max_rays_per_launch=1, color_independent_to_direction=_ci(network_fn)), "w": None}
         for k in [k for k, e in _query_ctx.items() if e["ref"]() is None]:
             del _query_ctx[k]
     key = R._weights_key(network_fn)

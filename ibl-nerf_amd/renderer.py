@@ -53,7 +53,7 @@ class Renderer:
     def __init__(self, N_samples=64, N_importance=128, *, epsilon=0.01, gamma_correct=True, lut_coefficient="F",
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
-                 mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon"):
+                 mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False):
         """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
         rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
         activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
@@ -83,13 +83,15 @@ class Renderer:
         o.use_radiance_linear = int(bool(use_radiance_linear))
         o.mlp_precision = B.MLP_F16_MXFP6 if mlp_precision == "f16_mxfp6" else B.MLP_BF16X3
         o.normal_mode = NORMAL_MODES[normal_mode]
+        o.color_independent_to_direction = int(bool(color_independent_to_direction))
         self.normal_mode = normal_mode
         self.mlp_precision = mlp_precision
         self._ctor = dict(N_samples=N_samples, N_importance=N_importance, epsilon=epsilon, gamma_correct=gamma_correct,
                           lut_coefficient=lut_coefficient,
                           correct_depth_for_prefiltered_radiance_infer=correct_depth_for_prefiltered_radiance_infer,
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
-                          lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode)
+                          lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode,
+                          color_independent_to_direction=color_independent_to_direction)
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
         self.range_fallbacks = 0
@@ -400,14 +402,18 @@ def renderer_for(kw):
            bool(kw.get("coarse_outputs", True)), int(kw.get("max_rays_per_launch", 65536)), torch.cuda.current_device(),
            bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)),
            kw.get("mlp_precision") or DEFAULT_MLP_PRECISION,
-           kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"))
+           kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"),
+           bool(getattr(net_c, "is_color_independent_to_direction", False)))
+    if net_f is not None and bool(getattr(net_f, "is_color_independent_to_direction", False)) != key[13]:
+        raise ValueError("network_fn and network_fine disagree on is_color_independent_to_direction")
     ent = _renderers.get(key)
     if ent is None:
         if kw.get("lut_coefficient") not in ("F", "F0"):
             raise ValueError(kw.get("lut_coefficient"))                               # ibl_nerf_renderer.py:437-438
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
-                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12])
+                     max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12],
+                     color_independent_to_direction=key[13])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

@@ -55,6 +55,8 @@ typedef struct {
     int32_t normal_mode;               /* target_normal_map_for_radiance_calculation: IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON
                                           (shipped; 4 offset queries per sample, normal_from_depth.py:139-183) or
                                           IBLNERF_NORMAL_GROUND_TRUTH (gt_values["normal"] rows, :370-371; no offset queries) */
+    int32_t color_independent_to_direction; /* 0 (shipped) | 1: networks built with is_color_independent_to_direction
+                                          (ibl_nerf.py:192): radiance heads read the trunk output, no feature / view layers */
     int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
                                           1e-3 parity bar; no reference counterpart):
                                           IBLNERF_MLP_BF16X3    three bf16 products on hi/lo splits, fp32 range

@@ -102,8 +102,13 @@ def _lin(sd, name, x):
     return (x @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(F32)
 
 
-def mlp_forward(sd, e_pts, e_dirs=None):
+COLOR_INDEPENDENT = False   # is_color_independent_to_direction (ibl_nerf.py:192): tests set it per fixture
+
+
+def mlp_forward(sd, e_pts, e_dirs=None, color_independent=None):
     """e_pts [P,63]; e_dirs [P,27] or None.  Returns [P,18], or [P,1] (sigma) if e_dirs is None."""
+    if color_independent is None:
+        color_independent = COLOR_INDEPENDENT
     h = e_pts
     for i in range(8):
         h = relu(_lin(sd, "positions_linears.%d" % i, h))
@@ -115,8 +120,11 @@ def mlp_forward(sd, e_pts, e_dirs=None):
     albedo = _lin(sd, "albedo_linear", relu(_lin(sd, "albedo_feature_linear", h)))
     rough = _lin(sd, "roughness_linear", h)
     irr = _lin(sd, "irradiance_linear", relu(_lin(sd, "irradiance_feature_linear", h)))
-    feat = _lin(sd, "feature_linear", h)                               # no activation (:193)
-    h2 = relu(_lin(sd, "views_linears.0", np.concatenate([feat, e_dirs], -1)))   # :194-197
+    if color_independent:                                              # :192: the radiance heads read the trunk output
+        h2 = h
+    else:
+        feat = _lin(sd, "feature_linear", h)                           # no activation (:193)
+        h2 = relu(_lin(sd, "views_linears.0", np.concatenate([feat, e_dirs], -1)))   # :194-197
     ret = [sigma, albedo, rough, irr, _lin(sd, "radiance_linear", h2)]
     for k in range(3):                                                 # taken from h2 (:202-206)
         f = relu(_lin(sd, "additional_radiance_feature_linear.%d" % k, h2))

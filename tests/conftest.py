@@ -51,7 +51,21 @@ def rel_linf(x, ref):
 
 
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
-                   "edit2_g10", "variant_small_g10", "gtnormal_g10"]
+                   "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10"]
+
+
+def color_independent(g):
+    """The fixture's networks were built with is_color_independent_to_direction (ibl_nerf.py:192)."""
+    return "model__color_independent_to_direction" in g.files
+
+
+@pytest.fixture(autouse=True)
+def _oracle_model_flags():
+    """The oracle takes the model flag from a module global; every test starts from the shipped value."""
+    import iblnerf_oracle as O
+    O.COLOR_INDEPENDENT = False
+    yield
+    O.COLOR_INDEPENDENT = False
 
 
 def n_samples(g):

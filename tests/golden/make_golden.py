@@ -51,13 +51,13 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance, n_samples=64):
+def reference_args(tmp, n_importance, n_samples=64, color_independent=False):
     """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
         multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=n_samples,
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
-        color_independent_to_direction=False, use_illumination_feature_layer=False,
+        color_independent_to_direction=color_independent, use_illumination_feature_layer=False,
         use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
         infer_normal=False, infer_normal_at_surface=False, infer_albedo_separate=False,
         infer_roughness_separate=False, infer_irradiance_separate=False, use_environment_map=False,
@@ -162,10 +162,10 @@ class Recorder:
 
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
-                n_samples=64, near=0.5, far=8.0, posed=False):
+                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
@@ -230,6 +230,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
                mode=np.array(mode))
     for k, v in (flags or {}).items():
         out["flag__" + k] = np.asarray(v)
+    if color_independent:
+        out["model__color_independent_to_direction"] = np.asarray(True)
     for k, v in gt.items():
         out["gt__" + k] = v
     for k, v in edit.items():
@@ -373,6 +375,8 @@ def main(only=None):
     run_fixture("variant_small_g10", torch, R, M, lut, n_rays=96, n_importance=48, gain=1.0, seed=6, n_samples=32,
                 near=1.0, far=5.0, posed=True,
                 flags=dict(epsilon=0.02, gamma_correct=False, correct_depth_for_prefiltered_radiance_infer=False))
+    # is_color_independent_to_direction (ibl_nerf.py:192): radiance heads on the trunk output, no feature / view layers
+    run_fixture("colorindep_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=8, color_independent=True)
     # ground-truth normals instead of the eps-normal (no offset queries)
     run_fixture("gtnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=7, mode="gtnormal",
                 flags=dict(target_normal_map_for_radiance_calculation="ground_truth"))

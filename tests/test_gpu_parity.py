@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, color_independent, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,8 @@ def make_renderer(R, g, sdc, sdf, lut, **kw):
     kw = dict(golden_flags(g), **kw)
     if "target_normal_map_for_radiance_calculation" in kw:
         kw["normal_mode"] = kw.pop("target_normal_map_for_radiance_calculation")
+    if color_independent(g):
+        kw["color_independent_to_direction"] = True
     r = R.Renderer(n_samples(g), int(g["n_importance"]), **kw)
     r.load_weights(0, sdc)
     if int(g["n_importance"]) > 0:
@@ -443,3 +445,20 @@ def test_repeated_launches_are_bit_identical(R, lut, prec):
     a = r.render_rays(ro, dirs - torch.tensor([0.0, 0.0, 2.0], device="cuda"), 0.5, 8.0)
     b = r.render_rays(ro, dirs - torch.tensor([0.0, 0.0, 2.0], device="cuda"), 0.5, 8.0)
     assert all(torch.equal(a[k], b[k]) for k in a) and bool(torch.isfinite(a["color_map"]).all())
+
+
+def test_create_iblnerf_color_independent_drop_in(R, lut, tmp_path):
+    """create_IBLNeRF(args.color_independent_to_direction=True) -> render_decomp picks the colour-independent kernels."""
+    import os
+    from ibl_nerf_amd import model as M
+    g, sdc, sdf, _, _ = load_golden("colorindep_g10")
+    os.makedirs(tmp_path / "exp")
+    _, kw, *_ = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), color_independent_to_direction=True))
+    assert kw["network_fn"].is_color_independent_to_direction
+    kw["network_fn"].load_state_dict(sdc)
+    kw["network_fine"].load_state_dict(sdf)
+    kw.update(near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut), max_rays_per_launch=64)
+    rays = torch.from_numpy(np.stack([g["rays_o"][:16], g["rays_d"][:16]], 0))
+    ret = R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    for k in ("radiance_map", "radiance_map_3", "albedo_map", "color_map"):
+        assert rel_linf(ret[k].cpu().numpy(), g["out__" + k][:16]) <= 2e-4, k

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, color_independent, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 # Channels that are smooth functions of the MLP outputs: the oracle must sit at fp32 round-off.
 DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
@@ -51,6 +51,7 @@ def test_sample_pdf(small):
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
 def test_network_query_stagewise(name):
     g, sdc, sdf, _, _ = load_golden(name)
+    O.COLOR_INDEPENDENT = color_independent(g)
     passes = [("c", sdc)] + ([("f", sdf)] if int(g["n_importance"]) > 0 else [])
     for p, sd in passes:
         raw = O.network_query(sd, g["q_%s_main_pts" % p], g["q_%s_main_dirs" % p])
@@ -65,6 +66,7 @@ def test_network_query_stagewise(name):
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
 def test_render_rays_end_to_end(name, lut):
     g, sdc, sdf, gt, edit = load_golden(name)
+    O.COLOR_INDEPENDENT = color_independent(g)
     st = {}
     flags = golden_flags(g)
     res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut,
