@@ -20,10 +20,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
-# (source, extra flags placed before -c[, object name]); the MX kernel's three instantiations are three objects so
-# that they compile side by side (each takes minutes)
+# (source, extra flags placed before -c[, object name]); every instantiation of the two MLP kernels is its own object
+# so that they compile side by side (each takes a minute or more)
 SOURCES = [
-    ("mlp_kernel.hip", []),
+    ("mlp_kernel.hip", ["-DIBL_VARIANT=0"], "mlp_kernel_full"),
+    ("mlp_kernel.hip", ["-DIBL_VARIANT=1"], "mlp_kernel_trunk"),
+    ("mlp_kernel.hip", ["-DIBL_VARIANT=2"], "mlp_kernel_refl"),
+    ("mlp_kernel.hip", ["-DIBL_VARIANT=3"], "mlp_kernel_full_ci"),
+    ("mlp_kernel.hip", ["-DIBL_VARIANT=4"], "mlp_kernel_refl_ci"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
     ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),

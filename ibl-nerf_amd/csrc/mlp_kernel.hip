@@ -542,32 +542,62 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     P.drain();   // the two chunks prefetched past the end are never consumed
 }
 
+// The five instantiations compile as five objects (build.py passes -DIBL_VARIANT=0..4) so that they build side by
+// side; the object of VAR_FULL also carries the dispatcher.  Without the macro everything lands in one object
+// (scratch/build_ablate.sh, trace builds).
+#ifdef IBL_TRACE
+constexpr int LDS_LAUNCH = LDS_BYTES + 2048;
+#else
+constexpr int LDS_LAUNCH = LDS_BYTES;
+#endif
+template <int VARIANT>
+static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a);
+    return hipGetLastError();
+}
+#define IBL_DEFINE_LAUNCH(V) hipError_t launch_mlp_v##V(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
+#if defined(IBL_VARIANT)
+#if IBL_VARIANT == 0
+IBL_DEFINE_LAUNCH(0)
+#elif IBL_VARIANT == 1
+IBL_DEFINE_LAUNCH(1)
+#elif IBL_VARIANT == 2
+IBL_DEFINE_LAUNCH(2)
+#elif IBL_VARIANT == 3
+IBL_DEFINE_LAUNCH(3)
+#else
+IBL_DEFINE_LAUNCH(4)
+#endif
+#else
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4)
+#endif
+#undef IBL_DEFINE_LAUNCH
+
+#if !defined(IBL_VARIANT) || IBL_VARIANT == 0
+hipError_t launch_mlp_v0(const MlpArgs&, int, hipStream_t);
+hipError_t launch_mlp_v1(const MlpArgs&, int, hipStream_t);
+hipError_t launch_mlp_v2(const MlpArgs&, int, hipStream_t);
+hipError_t launch_mlp_v3(const MlpArgs&, int, hipStream_t);
+hipError_t launch_mlp_v4(const MlpArgs&, int, hipStream_t);
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
     const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_TRUNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_FULL_CI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VAR_REFL_CI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        attr_set = true;
-    }
-#ifdef IBL_TRACE
-    constexpr int LDS_LAUNCH = LDS_BYTES + 2048;
-#else
-    constexpr int LDS_LAUNCH = LDS_BYTES;
-#endif
+    hipError_t rc;
     switch (variant) {
-        case VAR_FULL: hipLaunchKernelGGL(mlp_kernel<VAR_FULL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
-        case VAR_TRUNK: hipLaunchKernelGGL(mlp_kernel<VAR_TRUNK>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
-        case VAR_REFL: hipLaunchKernelGGL(mlp_kernel<VAR_REFL>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
-        case VAR_FULL_CI: hipLaunchKernelGGL(mlp_kernel<VAR_FULL_CI>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
-        case VAR_REFL_CI: hipLaunchKernelGGL(mlp_kernel<VAR_REFL_CI>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a); break;
+        case VAR_FULL: rc = launch_mlp_v0(a, grid, stream); break;
+        case VAR_TRUNK: rc = launch_mlp_v1(a, grid, stream); break;
+        case VAR_REFL: rc = launch_mlp_v2(a, grid, stream); break;
+        case VAR_FULL_CI: rc = launch_mlp_v3(a, grid, stream); break;
+        case VAR_REFL_CI: rc = launch_mlp_v4(a, grid, stream); break;
         default: return hipErrorInvalidValue;
     }
+    if (rc != hipSuccess) return rc;
 #ifdef IBL_TRACE
     if (variant == VAR_TRUNK) {
         (void)hipDeviceSynchronize();
@@ -583,5 +613,6 @@ hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t strea
 #endif
     return hipGetLastError();
 }
+#endif
 
 }  // namespace ibl

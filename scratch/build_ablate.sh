@@ -8,6 +8,6 @@ for v in ${ABL:-NO_LOADS NO_MFMA NO_BARRIER NO_FRAG NO_EPI}; do
 done
 wait
 for v in ${ABL:-NO_LOADS NO_MFMA NO_BARRIER NO_FRAG NO_EPI}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/lib_$v.so scratch/mlp_$v.o $B/render_kernels.hip.o $B/api.cpp.o $B/pack.cpp.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/lib_$v.so scratch/mlp_$v.o $B/mlp_kernel_mx_full.o $B/mlp_kernel_mx_trunk.o $B/mlp_kernel_mx_refl.o $B/mlp_kernel_mx_full_ci.o $B/mlp_kernel_mx_refl_ci.o $B/render_kernels.hip.o $B/pack_kernels.hip.o $B/api.cpp.o $B/pack.cpp.o
 done
 ls -la scratch/*.so
