@@ -44,7 +44,8 @@ class Overrides(C.Structure):
                 ("edit_roughness", C.c_int32), ("n_roughness_list", C.c_int32),
                 ("d_mask", FP), ("d_depth", FP), ("d_normal", FP), ("d_albedo", FP),
                 ("roughness_list", C.c_float * 8), ("albedo_list", C.c_float * 24),
-                ("irradiance_list", C.c_float * 8), ("d_gt_normal", FP)]
+                ("irradiance_list", C.c_float * 8), ("d_gt_normal", FP),
+                ("d_gt_albedo", FP), ("d_gt_roughness", FP), ("d_gt_irradiance", FP), ("d_gt_depth", FP)]
 
 
 class Maps(C.Structure):

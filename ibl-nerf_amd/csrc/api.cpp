@@ -354,7 +354,7 @@ int iblnerf_range_status(iblnerf_ctx* c, int* out_of_range) {
     return IBLNERF_OK;
 }
 
-static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S) {
+static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S, int irr_ch = 1) {
     auto off = [&](float* p, long w) { return p ? p + r0 * w : nullptr; };
     PassOutputs o;
     o.color = off(m.color_map, 3);
@@ -363,7 +363,7 @@ static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S) {
         o.radiance_k[k] = off(m.radiance_map_k[k], 3);
         o.refl_coarse_k[k] = off(m.reflected_coarse_radiance_map_k[k], 3);
     }
-    o.irradiance = off(m.irradiance_map, 1);
+    o.irradiance = off(m.irradiance_map, irr_ch);
     o.reflected_radiance = off(m.reflected_radiance_map, 3);
     o.prefiltered = off(m.prefiltered_reflected_map, 3);
     o.albedo = off(m.albedo_map, 3);
@@ -453,6 +453,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
             return c->fail(IBLNERF_ERR_INVALID, "normal_mode ground_truth needs overrides.d_gt_normal (gt_values[\"normal\"] rows)");
         gt_normal = ovr->d_gt_normal;
     }
+    const int irr_ch = (ovr && ovr->d_gt_irradiance) ? 3 : 1;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->opt.device));
     c->ev_used = 0;
@@ -468,6 +469,12 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         const float* rd = d_rays_d + 3 * r0;
         OverrideArgs o = ov;
         o.gt_normal = gt_normal ? gt_normal + 3 * r0 : nullptr;
+        if (ovr) {
+            o.gt_albedo = ovr->d_gt_albedo ? ovr->d_gt_albedo + 3 * r0 : nullptr;
+            o.gt_roughness = ovr->d_gt_roughness ? ovr->d_gt_roughness + r0 : nullptr;
+            o.gt_irradiance = ovr->d_gt_irradiance ? ovr->d_gt_irradiance + 3 * r0 : nullptr;
+            o.gt_depth = ovr->d_gt_depth ? ovr->d_gt_depth + r0 : nullptr;
+        }
         if (o.mode) {
             o.mask = ovr->d_mask + 3 * r0;
             o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;
@@ -476,12 +483,12 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         }
         int rc;
         if (!fine) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc));
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch));
             if (rc) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc));
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch));
             if (rc) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, c->zc, 0, 0.f, R, Sc, c->pts, s));
@@ -490,7 +497,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
             HIP_TRY(c, launch_sigma_weights(rd, c->zc, 0, c->sig4, R, Sc, c->w_c, s));
         }
         HIP_TRY(c, launch_fine_z(c->zc, Sc, c->w_c, R, c->opt.n_importance, c->z_fine, outs->z_std ? outs->z_std + r0 : nullptr, s));
-        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf));
+        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch));
         if (rc) return rc;
     }
     return IBLNERF_OK;

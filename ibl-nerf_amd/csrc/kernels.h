@@ -57,12 +57,17 @@ struct OverrideArgs {          // edit_intrinsic / insert_object branches, ibl_n
     const float* normal_img;   // [R,3] in [0,1]
     const float* albedo_img;   // [R,3]
     const float* gt_normal;    // [R,3] in [0,1] or null: target normal = normalize(2 v - 1) for every ray (:370-371), no eps-normal
+    // calculate_{albedo,roughness,irradiance}_from_gt / depth_map_from_ground_truth (:251-252, :320-330): null = network's value
+    const float* gt_albedo;      // [R,3]
+    const float* gt_roughness;   // [R] (channel 0 of gt_values["roughness"])
+    const float* gt_irradiance;  // [R,3]: the irradiance becomes a colour and the irradiance map has 3 channels
+    const float* gt_depth;       // [R]   (channel 0 of gt_values["depth"]); target depth only: depth_map / disp stay the network's
     float rough_list[8];
     float albedo_list[24];
     float irr_list[8];
 };
 
-constexpr int ST_FLOATS = 12;  // per-ray record handed from pass A to pass B (see render_kernels.hip)
+constexpr int ST_FLOATS = 14;  // per-ray record handed from pass A to pass B (see render_kernels.hip)
 
 struct PassOutputs {           // any pointer may be null (skipped).  Shapes per ray.
     float* color;              // 3

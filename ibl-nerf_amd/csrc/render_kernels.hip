@@ -180,7 +180,7 @@ __device__ __forceinline__ void store3(float* p, long r, const float (&v)[3], in
     if (p) { p[3 * r] = out_map(v[0], g); p[3 * r + 1] = out_map(v[1], g); p[3 * r + 2] = out_map(v[2], g); }
 }
 
-// State record handed from pass A to pass B (floats): 0-2 albedo, 3 rough, 4 irr, 5-7 fresnel,
+// State record handed from pass A to pass B (floats): 0-2 albedo, 3 rough, 4 / 12 / 13 irradiance (r, g, b), 5-7 fresnel,
 // 8-10 specular coefficient, 11 mip level.
 
 // Pass A: raw2outputs up to the reflected-ray set-up (ibl_nerf_renderer.py:200-440).
@@ -247,8 +247,13 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
 
     // ---- per-ray scalar section (all lanes compute, lane 0 stores) ---------------------------
     float albedo[3] = {ch[0], ch[1], ch[2]};
-    float rough = ch[3], irr = ch[4];
+    float rough = ch[3];
+    float irr[3] = {ch[4], ch[4], ch[4]};
     const OverrideArgs& ov = a.ov;
+    // *_from_gt substitutions come first; the edit / insert overrides then act on the substituted maps (:320-330, :378-410)
+    if (ov.gt_albedo != nullptr) for (int c = 0; c < 3; ++c) albedo[c] = ov.gt_albedo[3 * r + c];
+    if (ov.gt_roughness != nullptr) rough = ov.gt_roughness[r];
+    if (ov.gt_irradiance != nullptr) for (int c = 0; c < 3; ++c) irr[c] = ov.gt_irradiance[3 * r + c];
     float m = 0.0f;
     bool mask_all = false;
     if (ov.mode != 0) {   // ibl_nerf_renderer.py:223-228 / :233-238
@@ -257,11 +262,18 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     }
     // object q <=> 9(q+1)/255 < m < 11(q+1)/255
     auto in_obj = [&](int q) { return (float)(11 * (q + 1) / 255.) > m && m > (float)(9 * (q + 1) / 255.); };
-    if (mask_all && ((ov.mode == 1 && ov.edit_depth) || ov.mode == 2)) depth = ov.depth_img[(long)r * ov.depth_stride];   // :253-256
+    // target_depth_map IS depth_map (one tensor, :250) unless depth_map_from_ground_truth replaces it (:251-252): an edited
+    // depth shows in depth_map / disp / the mip level only in the aliased case
+    float tdepth = depth;
+    if (ov.gt_depth != nullptr) tdepth = ov.gt_depth[r];
+    if (mask_all && ((ov.mode == 1 && ov.edit_depth) || ov.mode == 2)) {   // :253-256
+        tdepth = ov.depth_img[(long)r * ov.depth_stride];
+        if (ov.gt_depth == nullptr) depth = tdepth;
+    }
     const float disp = 1.0f / fmaxf(1e-10f, depth / acc);   // :258
     float xs[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) xs[c] = o[c] + d[c] * depth;   // :262
+    for (int c = 0; c < 3; ++c) xs[c] = o[c] + d[c] * tdepth;   // :262
 
     float right[3], up[3], dxv[3], dyv[3], nrm[3];
     right_up(d, right, up);
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         for (int q = 0; q < ov.num_objects; ++q)
             if (in_obj(q)) {
                 rough = ov.rough_list[q];
-                if (ov.irr_list[q] > 0.0f) irr = ov.irr_list[q];
+                if (ov.irr_list[q] > 0.0f) irr[0] = irr[1] = irr[2] = ov.irr_list[q];
                 for (int c = 0; c < 3; ++c) albedo[c] = ov.albedo_list[3 * q + c];
             }
     }
@@ -324,16 +336,18 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         spec[c] = (a.lut_coefficient_F0 ? F0[c] : fres[c]) * e0 + e1;             // :433-436
         rdir[c] = d[c] - (2.0f * ndotd) * nrm[c];                                 // :439
     }
-    float level = rough;
+    // the mip level reads roughness_map, which is the edited tensor only while target_roughness_map aliases it (:324-326)
+    const float rough_net = ov.gt_roughness != nullptr ? ch[3] : rough;
+    float level = rough_net;
     if (a.correct_depth) {
         const float depth_0 = (a.far + a.near) * 0.5f;                            // :456-460
-        level = fminf(fmaxf(rough * depth / depth_0, 0.0f), 1.0f);
+        level = fminf(fmaxf(rough_net * depth / depth_0, 0.0f), 1.0f);
     }
 
     if (lane == 0) {
         float* st = a.state + r * ST_FLOATS;
         st[0] = albedo[0]; st[1] = albedo[1]; st[2] = albedo[2];
-        st[3] = rough; st[4] = irr;
+        st[3] = rough; st[4] = irr[0]; st[12] = irr[1]; st[13] = irr[2];
         st[5] = fres[0]; st[6] = fres[1]; st[7] = fres[2];
         st[8] = spec[0]; st[9] = spec[1]; st[10] = spec[2];
         st[11] = level;
@@ -348,7 +362,10 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
             const float rk[3] = {ch[8 + 3 * k], ch[9 + 3 * k], ch[10 + 3 * k]};
             store3(out.radiance_k[k], r, rk, gm);
         }
-        if (out.irradiance) out.irradiance[r] = out_map(irr, gm);
+        if (out.irradiance) {
+            if (ov.gt_irradiance != nullptr) store3(out.irradiance, r, irr, gm);   // [R,3] in this mode
+            else out.irradiance[r] = out_map(irr[0], gm);
+        }
         store3(out.albedo, r, albedo, gamma ? 1 : 0);     // albedo_f: gamma only (:488)
         if (out.roughness) out.roughness[r] = rough;
         if (out.n_dot_v) out.n_dot_v[r] = ndv;
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         if (out.disp) out.disp[r] = disp;
         if (out.acc) out.acc[r] = acc;
         if (out.depth) out.depth[r] = depth;
-        if (out.target_depth) out.target_depth[r] = depth;
+        if (out.target_depth) out.target_depth[r] = tdepth;
     }
 }
 
@@ -397,7 +414,8 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 
     const float* st = a.state + r * ST_FLOATS;
     const float albedo[3] = {st[0], st[1], st[2]};
-    const float rough = st[3], irr = st[4], level = st[11];
+    const float rough = st[3], level = st[11];
+    const float irr[3] = {st[4], st[12], st[13]};
     const float metal = 1.0f - rough;
     int i1 = (int)(level * 3.0f);                       // .long() truncation (:464)
     i1 = i1 < 0 ? 0 : (i1 > 3 ? 3 : i1);
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         pref[c] = (1.0f - rem) * maps[3 * i1 + c] + rem * maps[3 * i2 + c];
-        diffuse[c] = (1.0f - st[5 + c]) * (1.0f - metal) * albedo[c] * irr;
+        diffuse[c] = (1.0f - st[5 + c]) * (1.0f - metal) * albedo[c] * irr[c];
         specular[c] = st[8 + c] * pref[c];
         color[c] = diffuse[c] + specular[c];
     }

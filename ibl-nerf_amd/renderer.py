@@ -219,7 +219,7 @@ class Renderer:
                                                       bins.shape[0], bins.shape[1], int(N_samples), out.data_ptr()))
         return out
 
-    def _alloc_maps(self, n, S, want=True):
+    def _alloc_maps(self, n, S, want=True, irr_ch=1):
         torch = _torch()
         m, t = B.Maps(), {}
         if not want:
@@ -229,7 +229,7 @@ class Renderer:
             t[k] = e(n, 3)
         for k in MAP_KEYS_1:
             t[k] = e(n)
-        t["irradiance_map"] = e(n, 1)
+        t["irradiance_map"] = e(n, irr_ch)
         t["weights"] = e(n, S)
         for k in ("color_map", "radiance_map", "irradiance_map", "reflected_radiance_map", "prefiltered_reflected_map",
                   "albedo_map", "roughness_map", "specular_map", "diffuse_map", "n_dot_v_map", "target_normal_map",
@@ -250,10 +250,11 @@ class Renderer:
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
         fine = self.N_importance > 0
-        outs.fine, t_fine = self._alloc_maps(n, Sf if fine else Sc)
+        irr_ch = 3 if edit.get("calculate_irradiance_from_gt") else 1     # gt irradiance is RGB (:328-330, :501)
+        outs.fine, t_fine = self._alloc_maps(n, Sf if fine else Sc, irr_ch=irr_ch)
         t_coarse = {}
         if fine and self.coarse_outputs:
-            outs.coarse, t_coarse = self._alloc_maps(n, Sc)
+            outs.coarse, t_coarse = self._alloc_maps(n, Sc, irr_ch=irr_ch)
         z_std = None
         if fine:
             z_std = torch.empty((n,), dtype=torch.float32, device=self.device)
@@ -278,7 +279,8 @@ class Renderer:
         assert not (edit.get("load_edit_intrinsic_mask") and io), \
             "edit_intrinsic and insert_object cannot be True at the same time"          # ibl_nerf_renderer.py:218
         gt_normal_mode = self.normal_mode == "ground_truth"
-        if not ei and not io and not gt_normal_mode:
+        from_gt = [v for k, v in FROM_GT_FLAGS.items() if edit.get(k)]
+        if not ei and not io and not gt_normal_mode and not from_gt:
             return None, []
         ov, keep = B.Overrides(), []
 
@@ -294,6 +296,8 @@ class Renderer:
 
         if gt_normal_mode:                                                              # :370-371
             ov.d_gt_normal = rows("normal", 3)
+        for field, key, width in from_gt:
+            setattr(ov, field, rows(key, width))
         if not ei and not io:
             return ov, keep
         if ei:                                                                          # :219-228 (wins over insert, elif)
@@ -350,8 +354,12 @@ class Renderer:
 # reference-signature functions
 # ---------------------------------------------------------------------------------------------
 _UNSUPPORTED_TRUE = ["infer_normal", "infer_normal_at_surface", "infer_depth",
-                     "depth_map_from_ground_truth", "calculate_albedo_from_gt", "calculate_roughness_from_gt",
-                     "calculate_irradiance_from_gt", "use_environment_map", "white_bkgd", "retraw"]
+                     "use_environment_map", "white_bkgd", "retraw"]
+# raw2outputs flags that swap a network map for its gt_values row (ibl_nerf_renderer.py:251-252, :320-330)
+FROM_GT_FLAGS = {"calculate_albedo_from_gt": ("d_gt_albedo", "albedo", 3),
+                 "calculate_roughness_from_gt": ("d_gt_roughness", "roughness", 1),
+                 "calculate_irradiance_from_gt": ("d_gt_irradiance", "irradiance", 3),
+                 "depth_map_from_ground_truth": ("d_gt_depth", "depth", 1)}
 
 
 def _check_supported(kw):
@@ -454,7 +462,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
         rays_o, rays_d = rays
         rays_o, rays_d = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
     sh = rays_d.shape
-    edit = {k: kwargs[k] for k in kwargs if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit"))}
+    edit = {k: kwargs[k] for k in kwargs
+            if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
     ret = r.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), _scalar(near, "near"), _scalar(far, "far"),
                         kwargs.get("gt_values"), **edit)
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}

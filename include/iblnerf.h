@@ -138,6 +138,13 @@ typedef struct {
     float irradiance_list[8];          /* inserting_target_irradiance_list */
     const float* d_gt_normal;          /* gt_values["normal"] [n,3] in [0,1]; required when options.normal_mode is
                                           IBLNERF_NORMAL_GROUND_TRUTH (mode may then be 0), ignored otherwise */
+    /* calculate_albedo_from_gt / calculate_roughness_from_gt / calculate_irradiance_from_gt / depth_map_from_ground_truth
+     * (ibl_nerf_renderer.py:320-330, :251-252): non-NULL = shade with these rows instead of the network's maps (the edit /
+     * insert overrides then act on them).  With d_gt_irradiance the irradiance_map buffers are [n,3]. */
+    const float* d_gt_albedo;          /* gt_values["albedo"] [n,3] */
+    const float* d_gt_roughness;       /* gt_values["roughness"][..., 0] [n] */
+    const float* d_gt_irradiance;      /* gt_values["irradiance"] [n,3] */
+    const float* d_gt_depth;           /* gt_values["depth"][..., 0] [n] */
 } iblnerf_overrides;
 
 /* The 22 non-None maps raw2outputs returns per pass (ibl_nerf_renderer.py:494-525).  Device

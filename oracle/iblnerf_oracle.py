@@ -258,7 +258,9 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
     epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
-    target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth', :348-375)."""
+    target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth', :348-375),
+    depth_map_from_ground_truth / calculate_{albedo,roughness,irradiance}_from_gt (:251-252, :320-330): the target map is
+    the gt_values row and no longer aliases the network's map, so edits stop showing in depth_map / disp / the mip level."""
     gt = gt or {}
     edit = edit or {}
     flags = flags or {}
@@ -276,17 +278,27 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         masks, mask_all = decode_masks(gt["object_insert_mask"], edit["num_insert_objects"])
     w = alpha_weights(raw[..., 0], dists)                                                   # :241-245
     depth = np.sum(w * z_vals, -1, dtype=F32)                                               # :249
+    tdepth = depth                                                                          # :250 (one array: aliases depth_map)
+    if flags.get("depth_map_from_ground_truth", False):
+        tdepth = gt["depth"][:, 0].astype(F32).copy()                                       # :251-252
     if edit.get("edit_intrinsic") and edit.get("edit_depth"):
-        depth[mask_all] = gt["edit_depth"][:, 0][mask_all]                                  # :253-254 (aliases depth_map)
+        tdepth[mask_all] = gt["edit_depth"][:, 0][mask_all]                                 # :253-254
     if edit.get("insert_object"):
-        depth[mask_all] = gt["object_insert_depth"][:, 0][mask_all]                         # :255-256
+        tdepth[mask_all] = gt["object_insert_depth"][:, 0][mask_all]                        # :255-256
     acc = np.sum(w, -1, dtype=F32)
     with np.errstate(divide="ignore", invalid="ignore"):
         disp = (F32(1) / np.maximum(F32(1e-10), depth / acc)).astype(F32)                   # :258
-    x_surface = (rays_o + rays_d * depth[:, None]).astype(F32)                              # :262
+    x_surface = (rays_o + rays_d * tdepth[:, None]).astype(F32)                             # :262
     albedo = np.sum(w[..., None] * sigmoid(raw[..., 1:4]), -2, dtype=F32)                   # :281-282
     rough = np.sum(w * sigmoid(raw[..., 4]), -1, dtype=F32)                                 # :284-285
     irr = np.sum(w * radiance_f(raw[..., 5]), -1, dtype=F32)[:, None]                       # :287-288, :328
+    rough_net = rough                                                                       # :324 (aliases unless from gt)
+    if flags.get("calculate_albedo_from_gt", False):
+        albedo = gt["albedo"][:, :3].astype(F32).copy()                                     # :321-322
+    if flags.get("calculate_roughness_from_gt", False):
+        rough = gt["roughness"][:, 0].astype(F32).copy()                                    # :325-326
+    if flags.get("calculate_irradiance_from_gt", False):
+        irr = gt["irradiance"][:, :3].astype(F32).copy()                                    # :329-330
     rad = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
 
     nmode = flags.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
@@ -335,9 +347,9 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     pref_maps = composite_reflected(refl_raw, z_const, refl_d, radiance_f)                  # :446-448
     depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
     if flags.get("correct_depth_for_prefiltered_radiance_infer", True):
-        level = np.clip(rough * depth / depth_0, 0, 1).astype(F32)                          # :458-459
+        level = np.clip(rough_net * depth / depth_0, 0, 1).astype(F32)                      # :458-459 (roughness_map)
     else:
-        level = rough.astype(F32)                                                           # :461
+        level = rough_net.astype(F32)                                                       # :461
     i1 = np.clip((level * F32(3)).astype(np.int64), 0, 3)                                   # :464-465
     i2 = np.clip(i1 + 1, 0, 3)
     rem = ((level * F32(3)) - i1.astype(F32))[:, None].astype(F32)
@@ -362,7 +374,7 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         "prefiltered_reflected_map": g(pref), "albedo_map": gam(albedo), "roughness_map": rough,
         "specular_map": g(specular), "diffuse_map": g(diffuse), "n_dot_v_map": ndv,
         "target_normal_map": normal, "disp_map": disp, "acc_map": acc, "depth_map": depth,
-        "target_depth_map": depth, "weights": w})
+        "target_depth_map": tdepth, "weights": w})
     return res
 
 

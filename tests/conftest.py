@@ -51,7 +51,7 @@ def rel_linf(x, ref):
 
 
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
-                   "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10"]
+                   "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10"]
 
 
 def color_independent(g):
@@ -77,6 +77,15 @@ def golden_flags(g):
     """Flag variants recorded with a fixture (use_radiance_linear / lindisp / lut_coefficient / epsilon /
     gamma_correct / correct_depth_for_prefiltered_radiance_infer / target_normal_map_for_radiance_calculation)."""
     return {k[6:]: g[k].item() for k in g.files if k.startswith("flag__")}
+
+
+FROM_GT_FLAGS = ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt",
+                 "depth_map_from_ground_truth")
+
+
+def from_gt_flags(g):
+    """The per-call raw2outputs flags of a fixture (render kwargs, not renderer construction options)."""
+    return {k: v for k, v in golden_flags(g).items() if k in FROM_GT_FLAGS}
 
 
 def ill_conditioned(g):

@@ -206,6 +206,21 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         level = rng.choice([0, 10], size=n_rays, p=[0.6, 0.4]).astype(np.float32) / np.float32(255)
         gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
         gt["normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    elif mode == "fromgt":  # the four *_from_gt flags with an intrinsic edit on top: the target maps no longer alias the network's
+        edit.update(edit_intrinsic=True, num_edit_objects=2, edit_depth=True, edit_roughness=True,
+                    editing_target_roughness_list=[0.15, 0.7], edit_albedo=True,
+                    editing_target_albedo_list=[0.8, 0.1, 0.2, 0.3, 0.6, 0.9])
+        level = rng.choice([0, 10, 20], size=n_rays, p=[0.5, 0.25, 0.25]).astype(np.float32) / np.float32(255)
+        gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["edit_depth"] = rng.uniform(1, 3, (n_rays, 1)).astype(np.float32)
+    elif mode == "fromgt_insert":  # gt irradiance (RGB) under an object insertion: the scalar irradiance fills all channels
+        edit.update(insert_object=True, num_insert_objects=2, inserting_target_roughness_list=[0.9, 0.4],
+                    inserting_target_albedo_list=[0.870588, 0.3215686, 0.443137254, .05, .05, .05],
+                    inserting_target_irradiance_list=[0.5, 0.0])
+        level = rng.choice([0, 10, 20], size=n_rays, p=[0.4, 0.3, 0.3]).astype(np.float32) / np.float32(255)
+        gt["object_insert_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["object_insert_depth"] = rng.uniform(1, 2, (n_rays, 1)).astype(np.float32)
+        gt["object_insert_normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
     elif mode == "insert":  # configs/IBL-NeRF/living-room-2/object_insert.txt:8-14
         edit.update(insert_object=True, num_insert_objects=4, inserting_target_roughness_list=[1, 1, 1, 1],
                     inserting_target_albedo_list=[0.870588, 0.3215686, 0.443137254, .05, .05, .05, .2, .2, .2, .05, .05, .05],
@@ -214,6 +229,16 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         gt["object_insert_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
         gt["object_insert_depth"] = rng.uniform(1, 2, (n_rays, 1)).astype(np.float32)
         gt["object_insert_normal"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+
+    fl = flags or {}   # rows the *_from_gt flags read (3-channel images as load_mitsuba.py hands them over)
+    if fl.get("calculate_albedo_from_gt"):
+        gt["albedo"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    if fl.get("calculate_roughness_from_gt"):
+        gt["roughness"] = np.repeat(rng.uniform(0, 1, (n_rays, 1)), 3, 1).astype(np.float32)
+    if fl.get("calculate_irradiance_from_gt"):
+        gt["irradiance"] = rng.uniform(0, 2, (n_rays, 3)).astype(np.float32)
+    if fl.get("depth_map_from_ground_truth"):
+        gt["depth"] = np.repeat(rng.uniform(1, 4, (n_rays, 1)), 3, 1).astype(np.float32)
 
     rays = torch.from_numpy(np.stack([o, d], 0))
     gt_t = {k: torch.from_numpy(v.copy()) for k, v in gt.items()}
@@ -380,6 +405,12 @@ def main(only=None):
     # ground-truth normals instead of the eps-normal (no offset queries)
     run_fixture("gtnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=7, mode="gtnormal",
                 flags=dict(target_normal_map_for_radiance_calculation="ground_truth"))
+    # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
+    run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
+                flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,
+                           calculate_irradiance_from_gt=True, depth_map_from_ground_truth=True))
+    run_fixture("fromgt_insert_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=10, mode="fromgt_insert",
+                flags=dict(calculate_irradiance_from_gt=True, calculate_roughness_from_gt=True))
 
 
 if __name__ == "__main__":

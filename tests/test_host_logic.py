@@ -424,7 +424,9 @@ def test_unsupported_flags_raise():
     base = dict(approximate_radiance=True)
     R._check_supported(base)
     R._check_supported(dict(base, lindisp=True, use_radiance_linear=True))     # built flag variants
-    for k in ("infer_normal", "infer_depth", "calculate_albedo_from_gt", "depth_map_from_ground_truth"):
+    R._check_supported(dict(base, calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,
+                            calculate_irradiance_from_gt=True, depth_map_from_ground_truth=True))
+    for k in ("infer_normal", "infer_depth", "infer_normal_at_surface", "use_environment_map", "white_bkgd"):
         with pytest.raises(NotImplementedError):
             R._check_supported(dict(base, **{k: True}))
     with pytest.raises(ValueError):
