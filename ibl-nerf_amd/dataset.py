@@ -12,10 +12,20 @@ src/dataset/dataset_interface.py:12-300) that `test.py:36-73` and `render_decomp
     <basedir>/<split>/<n>_insert_mask.png, _insert_depth.npy, _insert_normal.png
     <basedir>/<split>/<n>_{normal,albedo,roughness,irradiance,diffuse,specular}.png, <n>_depth.npy
 
+and the two other layouts `load_dataset` knows (dataset_interface.py:316-331):
+
+    colmap        <basedir>/transforms.json {camera_angle_x, h, w, frames[i] = {file_path, transform_matrix}},
+                  <basedir>/images/<basename of file_path>; every 8th frame is the test split, the other seven of
+                  each group of eight the train split (dataset_colmap.py:36-41); poses are used as stored
+    mitsuba_eval  <basedir>/{rgb,diffuse,specular,irradiance,roughness,albedo}_%03d.png (dataset_mitsuba_eval.py:40-55):
+                  image sets for the metric scripts, no cameras
+
 Images are decoded with PIL as 8-bit RGB / 255 (the reference's cv2.imread + BGR->RGB yields the same
-array for 8-bit PNGs; alpha is dropped by both).  `image_scale != 1` (cv2.resize) and the prior
-images used only by the training losses are not built: they raise.  Nothing here touches the GPU
-until `to_tensor`."""
+array for 8-bit PNGs; alpha is dropped by both).  `image_scale`: 1 and 0.5 (the value of configs/real/) are
+built; 0.5 follows cv2.resize's documented INTER_LINEAR behaviour for an exact 2x reduction (a 2x2 box mean,
+rounded half up for 8-bit data) — cv2 is not in this image, so that one step is restated from OpenCV's source
+and NOT pinned by a run; other factors raise.  The prior images used only by the training losses are not
+built: they raise.  Nothing here touches the GPU until `to_tensor`."""
 from __future__ import annotations
 
 import json
@@ -25,19 +35,35 @@ import os
 import numpy as np
 
 
+def resize_half(a):
+    """cv2.resize(a, None, fx=0.5, fy=0.5) (default INTER_LINEAR): for an exact 2x reduction OpenCV switches to its
+    area filter, i.e. the mean of each 2x2 cell — (sum + 2) >> 2 for 8-bit data, sum * 0.25 for float."""
+    h, w = a.shape[:2]
+    if h % 2 or w % 2:
+        raise NotImplementedError("image_scale 0.5 is built for even image sizes only (got %dx%d)" % (w, h))
+    cells = a.reshape((h // 2, 2, w // 2, 2) + a.shape[2:])
+    if a.dtype == np.uint8:
+        return ((cells.astype(np.uint32).sum(axis=(1, 3)) + 2) >> 2).astype(np.uint8)
+    return (cells.astype(np.float32).sum(axis=(1, 3)) * np.float32(0.25)).astype(a.dtype)
+
+
+def _scaled(a, scale):
+    if scale == 1:
+        return a
+    if scale == 0.5:
+        return resize_half(a)
+    raise NotImplementedError("image_scale %r: only 1 and 0.5 (configs/real) are built" % (scale,))
+
+
 def load_image_from_path(path, scale=1):
-    """utils/image_utils.py:41-49."""
-    if scale != 1:
-        raise NotImplementedError("image_scale != 1 needs cv2.resize semantics, which are not built (shipped Mitsuba configs use 1)")
+    """utils/image_utils.py:39-47."""
     from PIL import Image
-    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / np.float32(255.0)
+    return _scaled(np.asarray(Image.open(path).convert("RGB")), scale).astype(np.float32) / np.float32(255.0)
 
 
 def load_numpy_from_path(path, scale=1):
-    """utils/image_utils.py:61-67."""
-    if scale != 1:
-        raise NotImplementedError("image_scale != 1 is not built")
-    return np.load(path).astype(np.float32)
+    """utils/image_utils.py:58-64."""
+    return _scaled(np.load(path), scale).astype(np.float32)
 
 
 # sample key -> (file suffix, loader kind, flag attribute, keep only channel 0)
@@ -68,10 +94,12 @@ _GT_KEYS = [("albedo", "load_albedo"), ("normal", "load_normal"), ("irradiance",
             ("object_insert_normal", "object_insert")]
 
 
-class MitsubaDataset:
-    def __init__(self, basedir, **kwargs):
+class NerfDataset:
+    """Shared part of the readers (dataset_interface.py:12-300): flags, bulk load, tensors, camera matrix, gt rows."""
+
+    def __init__(self, name, basedir, **kwargs):
         g = kwargs.get
-        self.name = "mitsuba"
+        self.name = name
         self.basedir = basedir
         self.scene_name = basedir.split("/")[-1]
         self.scale = g("image_scale", 1)
@@ -86,58 +114,16 @@ class MitsubaDataset:
             setattr(self, f, bool(g(f, False)))
         if self.load_priors:
             raise NotImplementedError("prior albedo/irradiance images feed the training losses only (SURVEY.md §8 f-3)")
-        if g("load_depth_range_from_file", False):                                # dataset_mitsuba.py:12-16
-            with open(os.path.join(basedir, "min_max_depth.json")) as fp:
-                f = json.load(fp)
-            self.near, self.far = f["min_depth"] * 0.9, f["max_depth"] * 1.1
-        with open(os.path.join(basedir, "transforms_{}.json".format(self.split))) as fp:
-            self.meta = json.load(fp)
-        self.skip = 1 if self.split == "train" else g("skip", 1)
-        self.camera_angle_x = float(self.meta["frames"][0]["fov_degree"]) / 180.0 * math.pi
-        from PIL import Image
-        with Image.open(os.path.join(basedir, "train/1.png")) as im:
-            self.original_width, self.original_height = im.size
-        self.height = int(self.original_height * self.scale)
-        self.width = int(self.original_width * self.scale)
-        self.focal = .5 * self.width / np.tan(0.5 * self.camera_angle_x)
+        self.prior_type = g("prior_type", "bell")
         self.full_data_loaded = False
         self._lists = {}
         self.poses = []
 
-    def __len__(self):
-        return len(self.meta["frames"][::self.skip]) if self.editing_idx is None else 1
-
-    def __getitem__(self, index):
-        if not 0 <= index < len(self):
-            raise IndexError(index)
-        n = (self.skip * index + 1) if self.editing_idx is None else self.editing_idx
-        frame = self.meta["frames"][self.editing_idx - 1] if self.editing_idx is not None else self.meta["frames"][::self.skip][index]
-        d = os.path.join(self.basedir, self.split)
-        sample = {}
-
-        def read(table):
-            for key, pat, kind, flag, ch0 in table:
-                if getattr(self, flag):
-                    p = os.path.join(d, pat % n)
-                    if kind == "img":
-                        a = load_image_from_path(p, self.scale)
-                        sample[key] = a[..., 0:1] if ch0 else a
-                    else:
-                        sample[key] = load_numpy_from_path(p, self.scale)[..., None]
-
-        read(_PER_VIEW)
-        if self.load_edit_intrinsic_mask:                                          # dataset_mitsuba.py:105-117
-            sample["edit_intrinsic_mask"] = load_image_from_path(os.path.join(d, "%d_edit_intrinsic_mask.png" % n), self.scale)
-            read(_EDIT)
-        if self.object_insert:                                                     # :119-122
-            sample["object_insert_mask"] = load_image_from_path(os.path.join(d, "%d_insert_mask.png" % n), self.scale)
-            sample["object_insert_normal"] = load_image_from_path(os.path.join(d, "%d_insert_normal.png" % n), self.scale)
-            sample["object_insert_depth"] = load_numpy_from_path(os.path.join(d, "%d_insert_depth.npy" % n), self.scale)[..., None]
-        pose = np.array(frame["transform"]).astype(np.float32)
-        pose[:3, 0] *= -1                                                          # Mitsuba: camera forward is +Z (:128-130)
-        pose[:3, 2] *= -1
-        sample["pose"] = pose
-        return sample
+    def _set_size(self, original_width, original_height):
+        self.original_width, self.original_height = original_width, original_height
+        self.height = int(self.original_height * self.scale)
+        self.width = int(self.original_width * self.scale)
+        self.focal = .5 * self.width / np.tan(0.5 * self.camera_angle_x)
 
     def load_all_data(self, num_of_workers=1, editing_idx=None):
         """dataset_interface.py:206-254 (sequential: the reference's DataLoader only parallelises I/O)."""
@@ -195,10 +181,123 @@ class MitsubaDataset:
                           "\t- size : %d x %d" % (self.width, self.height), "\t- image number : %d" % len(self)])
 
 
+class MitsubaDataset(NerfDataset):
+    def __init__(self, basedir, **kwargs):
+        super().__init__("mitsuba", basedir, **kwargs)
+        g = kwargs.get
+        if g("load_depth_range_from_file", False):                                # dataset_mitsuba.py:12-16
+            with open(os.path.join(basedir, "min_max_depth.json")) as fp:
+                f = json.load(fp)
+            self.near, self.far = f["min_depth"] * 0.9, f["max_depth"] * 1.1
+        with open(os.path.join(basedir, "transforms_{}.json".format(self.split))) as fp:
+            self.meta = json.load(fp)
+        self.skip = 1 if self.split == "train" else g("skip", 1)
+        self.camera_angle_x = float(self.meta["frames"][0]["fov_degree"]) / 180.0 * math.pi
+        from PIL import Image
+        with Image.open(os.path.join(basedir, "train/1.png")) as im:
+            self._set_size(*im.size)
+
+    def __len__(self):
+        return len(self.meta["frames"][::self.skip]) if self.editing_idx is None else 1
+
+    def __getitem__(self, index):
+        if not 0 <= index < len(self):
+            raise IndexError(index)
+        n = (self.skip * index + 1) if self.editing_idx is None else self.editing_idx
+        frame = self.meta["frames"][self.editing_idx - 1] if self.editing_idx is not None else self.meta["frames"][::self.skip][index]
+        d = os.path.join(self.basedir, self.split)
+        sample = {}
+
+        def read(table):
+            for key, pat, kind, flag, ch0 in table:
+                if getattr(self, flag):
+                    p = os.path.join(d, pat % n)
+                    if kind == "img":
+                        a = load_image_from_path(p, self.scale)
+                        sample[key] = a[..., 0:1] if ch0 else a
+                    else:
+                        sample[key] = load_numpy_from_path(p, self.scale)[..., None]
+
+        read(_PER_VIEW)
+        if self.load_edit_intrinsic_mask:                                          # dataset_mitsuba.py:105-117
+            sample["edit_intrinsic_mask"] = load_image_from_path(os.path.join(d, "%d_edit_intrinsic_mask.png" % n), self.scale)
+            read(_EDIT)
+        if self.object_insert:                                                     # :119-122
+            sample["object_insert_mask"] = load_image_from_path(os.path.join(d, "%d_insert_mask.png" % n), self.scale)
+            sample["object_insert_normal"] = load_image_from_path(os.path.join(d, "%d_insert_normal.png" % n), self.scale)
+            sample["object_insert_depth"] = load_numpy_from_path(os.path.join(d, "%d_insert_depth.npy" % n), self.scale)[..., None]
+        pose = np.array(frame["transform"]).astype(np.float32)
+        pose[:3, 0] *= -1                                                          # Mitsuba: camera forward is +Z (:128-130)
+        pose[:3, 2] *= -1
+        sample["pose"] = pose
+        return sample
+
+
+class ColmapDataset(NerfDataset):
+    """Real scenes reconstructed with COLMAP (configs/real/*, dataset_colmap.py:7-69)."""
+
+    def __init__(self, basedir, **kwargs):
+        super().__init__("colmap", basedir, **kwargs)
+        with open(os.path.join(basedir, "transforms.json")) as fp:
+            self.meta = json.load(fp)
+        self.skip = 1 if self.split == "train" else kwargs.get("skip", 1)
+        self.camera_angle_x = float(self.meta["camera_angle_x"])
+        self._set_size(self.meta["w"], self.meta["h"])
+        n = len(self.meta["frames"])
+        if self.split == "train":                                                   # frames 8i+1 .. 8i+7
+            idx = [8 * i + j + 1 for i in range(n // 8 + 1) for j in range(7)]
+        elif self.split in ("val", "test"):                                        # frames 8i
+            idx = [8 * i for i in range(n // 8 + 1)]
+        else:
+            raise AttributeError("split %r has no index list" % self.split)       # the reference never sets index_list
+        self.index_list = [i for i in idx if i < n]
+
+    def __len__(self):
+        return len(self.index_list)
+
+    def __getitem__(self, index):
+        if not 0 <= index < len(self):
+            raise IndexError(index)
+        frame = self.meta["frames"][::self.skip][self.index_list[index]]
+        sample = {}
+        if self.load_image:
+            sample["image"] = load_image_from_path(os.path.join(self.basedir, "images", os.path.split(frame["file_path"])[-1]),
+                                                   self.scale)
+        sample["pose"] = np.array(frame["transform_matrix"]).astype(np.float32)   # no axis flips (:62-63)
+        return sample
+
+
+class MitsubaEvalDataset(NerfDataset):
+    """Rendered image sets for the metric scripts (dataset_mitsuba_eval.py:20-59); there are no cameras."""
+    _KINDS = ("image", "diffuse", "specular", "irradiance", "roughness", "albedo")
+
+    def __init__(self, basedir, **kwargs):
+        super().__init__("mitsuba_eval", basedir, **kwargs)
+        import glob
+        self.load_diffuse_specular = True
+        self.file_n = len(glob.glob(os.path.join(basedir, "specular_*.png")))
+
+    def __len__(self):
+        return self.file_n
+
+    def __getitem__(self, index):
+        if not 0 <= index < len(self):
+            raise IndexError(index)
+        sample = {}
+        for key in self._KINDS:
+            stem = "rgb" if key == "image" else key
+            sample[key] = load_image_from_path(os.path.join(self.basedir, "%s_%03d.png" % (stem, index)), 1)
+        if "monte_carlo" in self.basedir:                                          # :52-53
+            sample["albedo"] = np.power(sample["albedo"], 1 / 2.2)
+        return sample
+
+
 def load_dataset(dataset_type, basedir, **kwargs):
     """dataset_interface.py:316-331."""
     if dataset_type == "mitsuba":
         return MitsubaDataset(basedir, **kwargs)
-    if dataset_type in ("mitsuba_eval", "colmap"):
-        raise NotImplementedError("dataset type %r is not built (SURVEY.md §8: Mitsuba scenes are the shipped path)" % dataset_type)
+    if dataset_type == "mitsuba_eval":
+        return MitsubaEvalDataset(basedir, **kwargs)
+    if dataset_type == "colmap":
+        return ColmapDataset(basedir, **kwargs)
     raise ValueError("Unknown dataset type: %s" % dataset_type)

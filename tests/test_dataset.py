@@ -98,9 +98,59 @@ def test_reader_plain(scene):
     with pytest.raises(ValueError):
         DS.load_dataset("blender", str(root))
     with pytest.raises(NotImplementedError):
-        DS.load_dataset("colmap", str(root))
+        DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.25)[0]
+    half = DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.5)        # configs/real use 0.5
+    assert (half.height, half.width) == (H // 2, W // 2) and abs(half.focal - f / 2) < 1e-12
+    a = truth[1][""].astype(np.uint32)                                                 # 2x2 cell mean, rounded half up
+    want = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.float32) / np.float32(255)
+    assert np.array_equal(half[0]["image"], want)
+
+
+def test_reader_colmap(tmp_path):
+    """dataset_colmap.py: one transforms.json for all splits, every 8th frame is the test view, the other seven of each
+    group of eight train views; poses are taken as stored (no axis flips); size and focal from h / w / camera_angle_x."""
+    from PIL import Image
+    root = tmp_path / "real" / "desk"
+    os.makedirs(root / "images")
+    n, hh, ww, ang = 19, 4, 6, 0.9
+    rs = np.random.RandomState(3)
+    imgs = [rs.randint(0, 256, (hh, ww, 3)).astype(np.uint8) for _ in range(n)]
+    frames = []
+    for i in range(n):
+        Image.fromarray(imgs[i]).save(root / "images" / ("frame_%03d.png" % i))
+        frames.append({"file_path": "./some/dir/frame_%03d.png" % i, "transform_matrix": look(i).tolist()})
+    json.dump({"camera_angle_x": ang, "h": hh, "w": ww, "frames": frames}, open(root / "transforms.json", "w"))
+    test = DS.load_dataset("colmap", str(root), split="test", skip=1, near_plane=0.5, far_plane=20)
+    train = DS.load_dataset("colmap", str(root), split="train", skip=4)
+    assert test.index_list == [0, 8, 16] and train.skip == 1                          # :25-26, :36-41
+    assert train.index_list == [i for i in range(n) if i % 8]
+    assert (test.height, test.width, test.scene_name) == (hh, ww, "desk")
+    assert abs(test.focal - 0.5 * ww / np.tan(0.5 * ang)) < 1e-12 and test.get_near_far_plane() == {"near": 0.5, "far": 20}
+    test.load_all_data()
+    assert len(test.poses) == 3 and np.array_equal(test.poses[1], look(8).astype(np.float32))
+    assert np.array_equal(test.images[2], imgs[16].astype(np.float32) / np.float32(255))   # basename under images/ (:47)
+    assert test.get_resized_normal_albedo(1, 0) == {}
+    half = DS.load_dataset("colmap", str(root), split="val", image_scale=0.5, load_image=False)
+    assert (half.height, half.width) == (2, 3) and "image" not in half[0] and len(half) == 3
     with pytest.raises(NotImplementedError):
-        DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.5)[0]
+        DS.load_dataset("colmap", str(root), load_priors=True)
+
+
+def test_reader_mitsuba_eval(tmp_path):
+    from PIL import Image
+    root = tmp_path / "eval" / "monte_carlo_run"
+    os.makedirs(root)
+    rs = np.random.RandomState(4)
+    truth = {}
+    for i in range(2):
+        for stem in ("rgb", "diffuse", "specular", "irradiance", "roughness", "albedo"):
+            truth[stem, i] = rs.randint(0, 256, (3, 5, 3)).astype(np.uint8)
+            Image.fromarray(truth[stem, i]).save(root / ("%s_%03d.png" % (stem, i)))
+    ds = DS.load_dataset("mitsuba_eval", str(root))
+    assert len(ds) == 2 and sorted(ds[1]) == ["albedo", "diffuse", "image", "irradiance", "roughness", "specular"]
+    assert np.array_equal(ds[1]["image"], truth["rgb", 1].astype(np.float32) / np.float32(255))
+    alb = truth["albedo", 0].astype(np.float32) / np.float32(255)
+    assert np.array_equal(ds[0]["albedo"], np.power(alb, 1 / 2.2))                    # "monte_carlo" in the path (:52-53)
 
 
 def test_reader_edit_and_insert(scene):
