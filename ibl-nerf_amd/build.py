@@ -22,17 +22,19 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # (source, extra flags placed before -c[, object name]); every instantiation of the two MLP kernels is its own object
 # so that they compile side by side (each takes a minute or more)
+# accumulator chains of the MX kernel in arch VGPRs (see run_layer in mlp_kernel_mx.hip)
+MX_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 SOURCES = [
     ("mlp_kernel.hip", ["-DIBL_VARIANT=0"], "mlp_kernel_full"),
     ("mlp_kernel.hip", ["-DIBL_VARIANT=1"], "mlp_kernel_trunk"),
     ("mlp_kernel.hip", ["-DIBL_VARIANT=2"], "mlp_kernel_refl"),
     ("mlp_kernel.hip", ["-DIBL_VARIANT=3"], "mlp_kernel_full_ci"),
     ("mlp_kernel.hip", ["-DIBL_VARIANT=4"], "mlp_kernel_refl_ci"),
-    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
-    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
-    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
-    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
-    ("mlp_kernel_mx.hip", ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),

@@ -301,7 +301,7 @@ struct Epi {
             // block max on the raw accumulator bits: with ReLU a negative value (negative int) never wins and the
             // max of the survivors is the max after ReLU; without it the sign bit is cleared first
             const int b0 = __builtin_bit_cast(int, x0), b1 = __builtin_bit_cast(int, x1);
-            if constexpr (RELU) mxv = max(mxv, max(b0, b1));
+            if constexpr (RELU) mxv = max(max(mxv, b0), b1);   // one v_max3_i32
             else mxv = max(mxv, max(b0 & 0x7fffffff, b1 & 0x7fffffff));
         }
         if constexpr (RELU) {
@@ -402,10 +402,16 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             if constexpr (cr == SYNC_SLOT) P.sync_next();
             if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
         });
-        // Keep the finished chain where it is (accumulator registers); its consumer is the deferred epilogue.
-        // Arch-VGPR accumulators would save the epilogue's v_accvgpr_reads, but "+v" sends them through scratch
-        // memory (4.5x slower) and an input-only "v" doubles the reads.
+        // Keep the finished chain where it is; its consumer is the deferred epilogue.  This file is built with
+        // -mllvm -amdgpu-mfma-vgpr-form (build.py): the accumulator chains live in arch VGPRs, so the epilogue reads them
+        // without v_accvgpr_read, and the register allocator parks finished fp6 operand forms in AGPRs (one
+        // v_accvgpr_write each; the MFMAs read them from there directly) - 575 accumulator-file moves per TRUNK evaluation
+        // instead of 896 with the chains pinned in AGPRs ("+a", -DIBL_MX_AGPR_CHAIN: the earlier form, 2 % slower).
+#ifdef IBL_MX_AGPR_CHAIN
         asm volatile("" : "+a"(acc));
+#else
+        asm volatile("" : "+v"(acc));
+#endif
         prev = acc;
     });
     return prev;

@@ -3,7 +3,7 @@
 set -e
 cd /root/repo
 B=ibl-nerf_amd/build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -DIBL_MX_DEV_TRUNK_ONLY ${MXFLAGS:-} -c ibl-nerf_amd/csrc/mlp_kernel_mx.hip -o scratch/mx_dev.o -save-temps=obj 2>&1 | grep -v warning || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -DIBL_MX_DEV_TRUNK_ONLY -mllvm -amdgpu-mfma-vgpr-form ${MXFLAGS:-} -c ibl-nerf_amd/csrc/mlp_kernel_mx.hip -o scratch/mx_dev.o -save-temps=obj 2>&1 | grep -v warning || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -x hip -c ibl-nerf_amd/csrc/pack.cpp -o scratch/pack_dev.o 2>&1 | grep -v warning || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/lib_mxdev.so scratch/mx_dev.o $B/mlp_kernel_full.o $B/mlp_kernel_trunk.o $B/mlp_kernel_refl.o $B/mlp_kernel_full_ci.o $B/mlp_kernel_refl_ci.o $B/render_kernels.hip.o $B/pack_kernels.hip.o $B/api.cpp.o scratch/pack_dev.o
 S=scratch/mlp_kernel_mx-hip-amdgcn-amd-amdhsa-gfx950.s
