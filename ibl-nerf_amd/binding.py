@@ -29,7 +29,8 @@ class Options(C.Structure):
                 ("gamma_correct", C.c_int32), ("lut_coefficient_f0", C.c_int32),
                 ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
                 ("max_rays_per_launch", C.c_int32), ("device", C.c_int32), ("lindisp", C.c_int32),
-                ("use_radiance_linear", C.c_int32), ("normal_mode", C.c_int32), ("color_independent_to_direction", C.c_int32), ("mlp_precision", C.c_int32)]
+                ("use_radiance_linear", C.c_int32), ("normal_mode", C.c_int32), ("color_independent_to_direction", C.c_int32), ("mlp_precision", C.c_int32),
+                ("epsilon_direction", C.c_float)]
 
 
 MLP_BF16X3, MLP_F16_MXFP6 = 0, 1

@@ -78,6 +78,7 @@ void iblnerf_default_options(iblnerf_options* o) {
     o->n_samples = 64;
     o->n_importance = 128;
     o->epsilon = 0.01f;
+    o->epsilon_direction = 0.005f;
     o->gamma_correct = 1;
     o->lut_coefficient_f0 = 0;
     o->correct_depth_for_prefiltered_radiance = 1;
@@ -123,8 +124,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         g_create_error = "unsupported sample counts: need 3 <= N_samples, N_samples + N_importance <= 256";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON && opts->normal_mode != IBLNERF_NORMAL_GROUND_TRUTH) {
-        g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0) or IBLNERF_NORMAL_GROUND_TRUTH (1)";
+    if (opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON && opts->normal_mode != IBLNERF_NORMAL_GROUND_TRUTH &&
+        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON) {
+        g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0), IBLNERF_NORMAL_GROUND_TRUTH (1) or "
+                         "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2)";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6) {
@@ -389,15 +392,18 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
     int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw);
     if (rc) return rc;
-    // epsilon-normal: 4 offset copies, trunk only (normal_from_depth.py:139-158); none in the ground-truth normal mode
+    // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
+    // (:55-75), trunk only; none in the ground-truth normal mode
+    const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
+    const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
     if (ov.gt_normal == nullptr) {
-        HIP_TRY(c, launch_make_points(1, ro, rd, z, z_stride, c->opt.epsilon, R, S, c->pts, s));
+        HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
         if (rc) return rc;
     }
     PassAArgs a;
     a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
-    a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = c->opt.epsilon;
+    a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = eps; a.tilted_rays = tilt ? 1 : 0;
     a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
     a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.radiance_linear = c->opt.use_radiance_linear;

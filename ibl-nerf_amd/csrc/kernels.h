@@ -41,6 +41,7 @@ hipError_t launch_coarse_z(float near, float far, int S, int lindisp, float* z, 
 // Point batches (rays x samples packed contiguously, [V][R][S][3]):
 //   mode 0: origin + dir * z                                  (ibl_nerf_renderer.py:200, :440)
 //   mode 1: V = 4 epsilon-offset copies (+-eps*right, +-eps*up) (normal_from_depth.py:143-156)
+//   mode 2: V = 4 rays from the same origin along normalize(dir +- eps*right), normalize(dir +- eps*up) (:64-73)
 // z_stride = 0 -> one z row shared by all rays, else per-ray rows of length z_stride.
 hipError_t launch_make_points(int mode, const float* origin, const float* dir, const float* z, int z_stride,
                               float eps, long R, int S, float* out, hipStream_t s);
@@ -98,6 +99,7 @@ struct PassAArgs {
     float* weights;                             // [R,S] (always written: sample_pdf input / output map)
     const float* lut;                           // [3,512,512]
     float near, far, eps;
+    int tilted_rays;                            // 0: offset-sample depths (normal_from_depth.py:139-183), 1: tilted-ray depths (:55-100)
     int lut_coefficient_F0;                     // 0 -> 'F' (shipped), 1 -> 'F0'
     int correct_depth;                          // correct_depth_for_prefiltered_radiance_infer
     int radiance_linear;                        // use_radiance_linear: radiance_f = ReLU, LDR map x/(1+x) before gamma

@@ -121,6 +121,20 @@ __global__ void k_coarse_z(float near, float far, int S, int lindisp, float* __r
                    : near * (1.0f - t) + far * t;                            // :672
 }
 
+// normal_from_depth.py:64-67: F.normalize(rays_d +- eps * right), F.normalize(rays_d +- eps * up)
+__device__ __forceinline__ void tilted_dirs(const float* d, const float* right, const float* up, float eps, float nd[4][3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float er = eps * right[c], eu = eps * up[c];
+        nd[0][c] = d[c] + er;
+        nd[1][c] = d[c] - er;
+        nd[2][c] = d[c] + eu;
+        nd[3][c] = d[c] - eu;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) normalize3(nd[v]);
+}
+
 __global__ void k_make_points(int mode, const float* __restrict__ origin, const float* __restrict__ dir,
                               const float* __restrict__ z, int z_stride, float eps, long R, int S,
                               float* __restrict__ out) {
@@ -141,6 +155,15 @@ __global__ void k_make_points(int mode, const float* __restrict__ origin, const 
     }
     float right[3], up[3];
     right_up(d, right, up);
+    if (mode == 2) {   // four rays from the same origin, directions tilted by +-eps*right / +-eps*up and normalised
+        float nd[4][3];
+        tilted_dirs(d, right, up, eps, nd);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[3 * (v * R * S + idx) + c] = o[c] + nd[v][c] * zz;
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float er = eps * right[c], eu = eps * up[c];
@@ -278,10 +301,20 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     float right[3], up[3], dxv[3], dyv[3], nrm[3];
     right_up(d, right, up);
     const float two_eps = 2.0f * a.eps;
+    if (a.tilted_rays) {   // end points of the four tilted rays (normal_from_depth.py:88-94)
+        float nd[4][3];
+        tilted_dirs(d, right, up, a.eps, nd);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        dxv[c] = two_eps * right[c] + (D[0] - D[1]) * d[c];
-        dyv[c] = two_eps * up[c] + (D[2] - D[3]) * d[c];
+        for (int c = 0; c < 3; ++c) {
+            dxv[c] = (o[c] + D[0] * nd[0][c]) - (o[c] + D[1] * nd[1][c]);
+            dyv[c] = (o[c] + D[2] * nd[2][c]) - (o[c] + D[3] * nd[3][c]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dxv[c] = two_eps * right[c] + (D[0] - D[1]) * d[c];
+            dyv[c] = two_eps * up[c] + (D[2] - D[3]) * d[c];
+        }
     }
     cross3(dxv, dyv, nrm);
     normalize3(nrm);

@@ -54,7 +54,9 @@ typedef struct {
     int32_t use_radiance_linear;       /* 0 (shipped, sigmoid radiance) | 1: ReLU radiance + Reinhard LDR map (:30-35, :480-483) */
     int32_t normal_mode;               /* target_normal_map_for_radiance_calculation: IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON
                                           (shipped; 4 offset queries per sample, normal_from_depth.py:139-183) or
-                                          IBLNERF_NORMAL_GROUND_TRUTH (gt_values["normal"] rows, :370-371; no offset queries) */
+                                          IBLNERF_NORMAL_GROUND_TRUTH (gt_values["normal"] rows, :370-371; no offset queries) or
+                                          IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (depths along four rays with tilted
+                                          directions, normal_from_depth.py:55-100; uses epsilon_direction) */
     int32_t color_independent_to_direction; /* 0 (shipped) | 1: networks built with is_color_independent_to_direction
                                           (ibl_nerf.py:192): radiance heads read the trunk output, no feature / view layers */
     int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
@@ -64,9 +66,11 @@ typedef struct {
                                                                 faster; inputs and activations must stay below 65504 —
                                                                 see iblnerf_range_status (a network with a weight
                                                                 beyond that runs on the bf16x3 kernel by itself) */
+    float epsilon_direction;           /* epsilon_direction_for_numerical_normal (0.005): tilt of the four rays of
+                                          IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
-enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1 };
+enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2 };
 
 void iblnerf_default_options(iblnerf_options* o);
 

@@ -205,6 +205,24 @@ def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=Fa
     return (n, np.stack(D, 0)) if return_depths else n
 
 
+def normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=0.005):
+    """nerf_models/normal_from_depth.py:55-100: depths along four rays whose (normalised) directions are tilted by
+    +-eps*right / +-eps*up, sampled at the centre ray's z values; normal from the four end points."""
+    eps = F32(eps)
+    up0 = np.broadcast_to(np.array([0, 1, 0], dtype=F32), rays_d.shape)
+    right = cross(rays_d, up0)
+    up = cross(right, rays_d)
+    new_d = [normalize((rays_d + eps * right).astype(F32)), normalize((rays_d - eps * right).astype(F32)),
+             normalize((rays_d + eps * up).astype(F32)), normalize((rays_d - eps * up).astype(F32))]       # :64-67
+    pts = np.concatenate([(rays_o[:, None, :] + d[:, None, :] * z_vals[:, :, None]).astype(F32) for d in new_d], 0)
+    raw = network_query(sd, pts, None)[..., 0]
+    dists = ray_dists(z_vals, rays_d)                                                                     # the centre ray's (:77-79)
+    N = rays_o.shape[0]
+    D = [np.sum(alpha_weights(raw[s * N:(s + 1) * N], dists) * z_vals, -1, dtype=F32) for s in range(4)]
+    pos = [(rays_o + D[s][:, None] * new_d[s]).astype(F32) for s in range(4)]                            # :88-91
+    return normalize(cross((pos[0] - pos[1]).astype(F32), (pos[2] - pos[3]).astype(F32)))
+
+
 # --------------------------------------------------------------------------------------------
 # A.9 pieces
 # --------------------------------------------------------------------------------------------
@@ -258,7 +276,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
     epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
-    target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth', :348-375),
+    target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth' |
+    'normal_map_from_depth_gradient_direction_epsilon' with epsilon_direction, default 0.005; :348-375),
     depth_map_from_ground_truth / calculate_{albedo,roughness,irradiance}_from_gt (:251-252, :320-330): the target map is
     the gt_values row and no longer aliases the network's map, so edits stop showing in depth_map / disp / the mip level."""
     gt = gt or {}
@@ -306,6 +325,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         normal = normalize(F32(2) * gt["normal"] - F32(1))                                  # :370-371
     elif nmode == "normal_map_from_depth_gradient_epsilon":
         normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
+    elif nmode == "normal_map_from_depth_gradient_direction_epsilon":
+        normal = normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon_direction", 0.005)))  # :366-369
     else:
         raise ValueError(nmode)                                                             # :374-375
     if stages is not None:

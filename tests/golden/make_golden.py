@@ -114,6 +114,7 @@ class Recorder:
         R, kw = self.R, self.kw
         self._q0, self._pdf0 = kw["network_query_fn"], R.sample_pdf
         self._n0, self._s0, self._g0 = R.get_normal_from_depth_gradient_epsilon, R.raw2outputs_simple, R.F.grid_sample
+        self._nd0 = R.get_normal_from_depth_gradient_direction_epsilon
         k = self.n_keep
 
         def q(inputs, viewdirs, fn):
@@ -139,6 +140,11 @@ class Recorder:
             self.nrm.append(out.numpy().copy())
             return out
 
+        def nrm_dir(*a, **k_):
+            out = self._nd0(*a, **k_)
+            self.nrm.append(out.numpy().copy())
+            return out
+
         def simple(*a, **k_):
             rad, coarse = self._s0(*a, **k_)
             self.simple.append(np.stack([rad.numpy()] + [c.numpy() for c in coarse], 1).copy())
@@ -151,6 +157,7 @@ class Recorder:
 
         kw["network_query_fn"] = q
         R.sample_pdf, R.get_normal_from_depth_gradient_epsilon = pdf, nrm
+        R.get_normal_from_depth_gradient_direction_epsilon = nrm_dir
         R.raw2outputs_simple, R.F.grid_sample = simple, grid
         return self
 
@@ -158,6 +165,7 @@ class Recorder:
         R, kw = self.R, self.kw
         kw["network_query_fn"] = self._q0
         R.sample_pdf, R.get_normal_from_depth_gradient_epsilon = self._pdf0, self._n0
+        R.get_normal_from_depth_gradient_direction_epsilon = self._nd0
         R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
 
 
@@ -405,6 +413,10 @@ def main(only=None):
     # ground-truth normals instead of the eps-normal (no offset queries)
     run_fixture("gtnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=7, mode="gtnormal",
                 flags=dict(target_normal_map_for_radiance_calculation="ground_truth"))
+    # the other finite-difference normal: four rays with tilted directions (normal_from_depth.py:55-100), posed camera
+    run_fixture("dirnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=11, posed=True,
+                flags=dict(target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_direction_epsilon",
+                           epsilon_direction=0.005))
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

@@ -426,7 +426,8 @@ def test_unsupported_flags_raise():
     R._check_supported(dict(base, lindisp=True, use_radiance_linear=True))     # built flag variants
     R._check_supported(dict(base, calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,
                             calculate_irradiance_from_gt=True, depth_map_from_ground_truth=True))
-    for k in ("infer_normal", "infer_depth", "infer_normal_at_surface", "use_environment_map", "white_bkgd"):
+    R._check_supported(dict(base, white_bkgd=True, retraw=True, use_environment_map=True))   # dead flags in the reference too
+    for k in ("infer_normal", "infer_depth", "infer_normal_at_surface"):
         with pytest.raises(NotImplementedError):
             R._check_supported(dict(base, **{k: True}))
     with pytest.raises(ValueError):
