@@ -17,6 +17,7 @@ EXPORTS = [
     "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
     "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
+    "iblnerf_upload_aux_weights", "iblnerf_clear_aux",
 ]
 
 
@@ -34,6 +35,7 @@ class Options(C.Structure):
 
 
 MLP_BF16X3, MLP_F16_MXFP6 = 0, 1
+AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
 FP = C.c_void_p  # device float*
@@ -90,6 +92,10 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.restype = C.c_int
+    lib.iblnerf_upload_aux_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.iblnerf_upload_aux_weights.restype = C.c_int
+    lib.iblnerf_clear_aux.argtypes = [C.c_void_p, C.c_int]
+    lib.iblnerf_clear_aux.restype = C.c_int
     lib.iblnerf_upload_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.iblnerf_pack_weights_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.iblnerf_encode_host.argtypes = [C.c_float, C.c_int, C.c_void_p]

@@ -57,6 +57,44 @@ def synthetic_state_dict(seed: int, gain: float = 1.0, sigma_bias: float = 0.3) 
     return sd
 
 
+# Auxiliary PositionMLPs (src/networks/MLP.py:6-30, ibl_nerf.py:312-326): the main network's trunk shape + out_linears
+AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1}
+TRUNK_SCHEMA = tuple(e for e in SCHEMA if e[0].startswith("positions_linears."))
+
+
+def synthetic_position_mlp(seed: int, out_ch: int, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """A seeded PositionMLP state dict (D=8, W=256, input_ch=63, skips=[4]) in nn.Module registration order."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name, o, i in TRUNK_SCHEMA + (("out_linears", out_ch, 256),):
+        sd[name + ".weight"] = (rs.randn(o, i) * gain * np.sqrt(2.0 / i)).astype(np.float32)
+        sd[name + ".bias"] = (rs.randn(o) * 0.1).astype(np.float32)
+    return sd
+
+
+def aux_channel_blob(aux_sd, channel: int) -> np.ndarray:
+    """One output channel of a PositionMLP as an IBLNeRF-schema blob for iblnerf_upload_aux_weights: its
+    positions_linears.*, row `channel` of out_linears in the place of sigma_linear, zeros elsewhere."""
+    want = [n + sfx for n, _, _ in TRUNK_SCHEMA for sfx in (".weight", ".bias")] + ["out_linears.weight", "out_linears.bias"]
+    if list(aux_sd.keys()) != want:
+        raise KeyError("not a PositionMLP state dict (D=8, W=256, skips=[4]): %s" % list(aux_sd.keys())[:4])
+    ow, ob = _to_numpy(aux_sd["out_linears.weight"]), _to_numpy(aux_sd["out_linears.bias"])
+    if ow.ndim != 2 or ow.shape[1] != 256 or not 0 <= channel < ow.shape[0] or ob.shape != (ow.shape[0],):
+        raise ValueError("out_linears %s / channel %d" % (ow.shape, channel))
+    full = OrderedDict()
+    for name, o, i in SCHEMA:
+        if name.startswith("positions_linears."):
+            w, b = _to_numpy(aux_sd[name + ".weight"]), _to_numpy(aux_sd[name + ".bias"])
+            if w.shape != (o, i) or b.shape != (o,):
+                raise ValueError("%s: expected [%d,%d], got %s" % (name, o, i, w.shape))
+        elif name == "sigma_linear":
+            w, b = ow[channel:channel + 1], ob[channel:channel + 1]
+        else:
+            w, b = np.zeros((o, i), np.float32), np.zeros((o,), np.float32)
+        full[name + ".weight"], full[name + ".bias"] = w, b
+    return state_dict_to_blob(full)
+
+
 def _to_numpy(v) -> np.ndarray:
     if isinstance(v, np.ndarray):
         return v
@@ -130,12 +168,22 @@ def load_checkpoint(path: str):
     return ckpt.get("global_step", 0), ckpt["network_fn_state_dict"], fine
 
 
-def save_checkpoint(path: str, global_step: int, coarse_sd, fine_sd=None, elapsed_time: float = 0.0):
-    """Write the same dict schema `train.py:180-191` writes (optimizer state left empty)."""
+def load_checkpoint_aux(path: str):
+    """The auxiliary networks a reference `.tar` may hold (ibl_nerf.py:369-374): {name: state dict} for the names present."""
+    import torch
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    return {k: ckpt[k] for k in AUX_OUT_CH if k in ckpt}
+
+
+def save_checkpoint(path: str, global_step: int, coarse_sd, fine_sd=None, elapsed_time: float = 0.0, aux=None):
+    """Write the same dict schema `train.py:180-191` writes (optimizer state left empty).  aux: {name: state dict} of
+    auxiliary networks, stored under the reference's keys ('albedo_mlp', ...)."""
     import torch
     to_t = lambda sd: OrderedDict((k, torch.from_numpy(np.array(_to_numpy(v)))) for k, v in sd.items())
     d = {"global_step": global_step, "network_fn_state_dict": to_t(coarse_sd),
          "optimizer_state_dict": {}, "elapsed_time": elapsed_time}
     if fine_sd is not None:
         d["network_fine_state_dict"] = to_t(fine_sd)
+    for k, sd in (aux or {}).items():
+        d[k] = to_t(sd)
     torch.save(d, path)

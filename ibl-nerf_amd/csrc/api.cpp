@@ -27,20 +27,26 @@ constexpr double FLOP_FULL = 1591552.0, FLOP_TRUNK = 982528.0, FLOP_REFL = 14589
 constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // what is_color_independent_to_direction skips
 }  // namespace
 
+constexpr int N_SLOTS = 7;
+constexpr int AUX_SLOT0[3] = {2, 5, 6}, AUX_CHANNELS[3] = {3, 1, 1}, AUX_RAW_COLUMN[3] = {1, 4, 5};   // albedo, roughness, irradiance
+
 struct iblnerf_ctx {
     iblnerf_options opt;
     std::string err;
     int n_cu = 256;
     // per network
-    char* d_stream[2] = {nullptr, nullptr};
-    char* d_stream_mx[2] = {nullptr, nullptr};   // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
+    // network slots: 0 coarse, 1 fine, 2.. one trunk-shaped stream per output channel of an auxiliary PositionMLP
+    // (albedo r, g, b, roughness, irradiance), allocated on first upload
+    char* d_stream[N_SLOTS] = {};
+    char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
     unsigned* d_range_flag = nullptr;
-    bool mx_ok[2] = {true, true};
+    bool mx_ok[N_SLOTS] = {true, true, true, true, true, true, true};
     unsigned short* d_map16 = nullptr;            // gather maps of the device packer (built on first use)
     int* d_map_mx = nullptr;
     int* d_map_tab = nullptr;                 // false: a weight is outside the f16 range -> that network runs on the bf16x3 kernel
-    float* d_tables[2] = {nullptr, nullptr};
-    bool have_net[2] = {false, false};
+    float* d_tables[N_SLOTS] = {};
+    bool have_net[N_SLOTS] = {};
+    bool aux_on[3] = {false, false, false};   // IBLNERF_AUX_ALBEDO / ROUGHNESS / IRRADIANCE enabled for render_rays
     float* d_lut = nullptr;
     bool have_lut = false;
     // workspace
@@ -200,10 +206,11 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
 void iblnerf_destroy(iblnerf_ctx* c) {
     if (!c) return;
     float* bufs[] = {c->zc, c->z_fine, c->pts, c->raw, c->sig4, c->w_c, c->w_f, c->state, c->refl_o, c->refl_d,
-                     c->refl_raw, c->d_lut, c->d_tables[0], c->d_tables[1]};
+                     c->refl_raw, c->d_lut};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < N_SLOTS; ++w) {
+        if (c->d_tables[w]) (void)hipFree(c->d_tables[w]);
         if (c->d_stream[w]) (void)hipFree(c->d_stream[w]);
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
     }
@@ -215,27 +222,55 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     delete c;
 }
 
-int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_t n_floats) {
-    if (!c) return IBLNERF_ERR_INVALID;
-    if (which < 0 || which > 1 || !h_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights: which must be 0/1, blob non-null");
+static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_floats, const char* who) {
     if (n_floats != blob_floats())
-        return c->fail(IBLNERF_ERR_INVALID, "upload_weights: blob has %zu floats, the IBLNeRF state dict has %zu", n_floats, blob_floats());
+        return c->fail(IBLNERF_ERR_INVALID, "%s: blob has %zu floats, the IBLNeRF state dict has %zu", who, n_floats, blob_floats());
     std::vector<char> stream((size_t)STREAM_BYTES);
     std::vector<float> tab((size_t)TAB_FLOATS);
     pack_network(h_blob, stream.data(), tab.data());
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, hipDeviceSynchronize());   // a previous render may still be reading the old stream
-    HIP_TRY(c, hipMemcpy(c->d_stream[which], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_tables[which], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
-    if (c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6) {
+    const bool want_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6;
+    if (!c->d_stream[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream[slot], STREAM_BYTES));          // auxiliary slots: first use
+    if (!c->d_tables[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_tables[slot], TAB_BYTES));
+    if (want_mx && !c->d_stream_mx[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream_mx[slot], mx::STREAM_BYTES));
+    HIP_TRY(c, hipMemcpy(c->d_stream[slot], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tables[slot], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
+    if (want_mx) {
         bool ok = true;                           // f16(W) must be finite: |w| < 65520 and not NaN
         for (size_t i = 0; i < n_floats && ok; ++i) ok = std::fabs(h_blob[i]) < 65504.0f;
-        c->mx_ok[which] = ok;
+        c->mx_ok[slot] = ok;
         std::vector<char> smx((size_t)mx::STREAM_BYTES);
         pack_network_mx(h_blob, smx.data(), tab.data());
-        HIP_TRY(c, hipMemcpy(c->d_stream_mx[which], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_stream_mx[slot], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
     }
-    c->have_net[which] = true;
+    c->have_net[slot] = true;
+    return IBLNERF_OK;
+}
+
+int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_t n_floats) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || !h_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights: which must be 0/1, blob non-null");
+    return upload_slot(c, which, h_blob, n_floats, "upload_weights");
+}
+
+int iblnerf_upload_aux_weights(iblnerf_ctx* c, int kind, int channel, const float* h_blob, size_t n_floats) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (kind < 0 || kind > 2 || channel < 0 || channel >= AUX_CHANNELS[kind < 0 || kind > 2 ? 0 : kind] || !h_blob)
+        return c->fail(IBLNERF_ERR_INVALID, "upload_aux_weights: kind must be IBLNERF_AUX_* and channel inside its out_ch, blob non-null");
+    const int rc = upload_slot(c, AUX_SLOT0[kind] + channel, h_blob, n_floats, "upload_aux_weights");
+    if (rc) return rc;
+    bool all = true;
+    for (int ch = 0; ch < AUX_CHANNELS[kind]; ++ch) all = all && c->have_net[AUX_SLOT0[kind] + ch];
+    c->aux_on[kind] = all;                       // takes effect once every output channel is there
+    return IBLNERF_OK;
+}
+
+int iblnerf_clear_aux(iblnerf_ctx* c, int kind) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (kind < 0 || kind > 2) return c->fail(IBLNERF_ERR_INVALID, "clear_aux: kind must be IBLNERF_AUX_*");
+    c->aux_on[kind] = false;
+    for (int ch = 0; ch < AUX_CHANNELS[kind]; ++ch) c->have_net[AUX_SLOT0[kind] + ch] = false;
     return IBLNERF_OK;
 }
 
@@ -290,7 +325,7 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
 }
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out) {
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
@@ -301,6 +336,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     a.pts = pts;
     a.dirs = dirs;
     a.out = out;
+    a.out_stride = out_stride;
     a.n_pts = n_pts;
     a.pts_per_ray = pts_per_ray;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -392,6 +428,13 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
     int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw);
     if (rc) return rc;
+    // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
+    // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
+    for (int kind = 0; kind < 3; ++kind)
+        for (int ch = 0; c->aux_on[kind] && ch < AUX_CHANNELS[kind]; ++ch) {
+            rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[kind] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[kind] + ch, RAW_CH);
+            if (rc) return rc;
+        }
     // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
     // (:55-75), trunk only; none in the ground-truth normal mode
     const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
@@ -404,6 +447,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     PassAArgs a;
     a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
     a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = eps; a.tilted_rays = tilt ? 1 : 0;
+    a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
     a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
     a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.radiance_linear = c->opt.use_radiance_linear;

@@ -13,6 +13,8 @@ struct MlpArgs {
     const float* pts;     // [n_pts,3]
     const float* dirs;    // [n_pts / pts_per_ray, 3] view directions (null for VAR_TRUNK)
     float* out;           // [n_pts,18] (FULL) | [n_pts] (TRUNK) | [n_pts,13] (REFL)
+    int out_stride = 1;   // VAR_TRUNK only: floats between consecutive points' outputs (an auxiliary network writes one
+                          // column of the main network's raw rows)
     long n_pts;
     int pts_per_ray;
     unsigned* range_flag; // f16 + MX-fp6 variant only: set to 1 if an input or activation left the f16 range (may be null)
@@ -99,6 +101,7 @@ struct PassAArgs {
     float* weights;                             // [R,S] (always written: sample_pdf input / output map)
     const float* lut;                           // [3,512,512]
     float near, far, eps;
+    int irradiance_sigmoid;                     // an irradiance_mlp's samples take sigmoid, whatever radiance_f is (:300-303)
     int tilted_rays;                            // 0: offset-sample depths (normal_from_depth.py:139-183), 1: tilted-ray depths (:55-100)
     int lut_coefficient_F0;                     // 0 -> 'F' (shipped), 1 -> 'F0'
     int correct_depth;                          // correct_depth_for_prefiltered_radiance_infer

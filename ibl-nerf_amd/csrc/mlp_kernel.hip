@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const float* sc = tabs + TAB_SCALAR;
         if constexpr (VARIANT == VAR_TRUNK) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
-            if (valid && h == 0) a.out[p] = s;
+            if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
         } else {
             float tot[RAW_CH];
 #pragma unroll

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
             const float* row = a.raw + ((long)r * S + s) * RAW_CH;
 #pragma unroll
             for (int c = 0; c < 17; ++c)   // albedo, roughness: sigmoid; irradiance, radiances: radiance_f (:281-318)
-                ch[c] += w[i] * (c < 4 ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], a.radiance_linear));
+                ch[c] += w[i] * ((c < 4 || (c == 4 && a.irradiance_sigmoid)) ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], a.radiance_linear));
         }
     }
     depth = wave_sum(depth);

@@ -47,6 +47,35 @@ class IBLNeRF:
         return iter(())          # a weight container: nothing here is trainable
 
 
+class PositionMLP:
+    """Weight container with the schema of src/networks/MLP.py:6-30 (albedo_mlp / roughness_mlp / irradiance_mlp)."""
+
+    def __init__(self, D=8, W=256, input_ch=63, out_ch=3, skips=(4,)):
+        if (D, W, input_ch, tuple(skips)) != (8, 256, 63, (4,)) or out_ch not in (1, 3):
+            raise NotImplementedError("auxiliary networks are built for D=8, W=256, multires=10, skips=[4], out_ch 1 or 3")
+        self.out_ch = out_ch
+        self._sd = ck.synthetic_position_mlp(0, out_ch)
+        self._version = 0
+
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd):
+        sd = OrderedDict((k, np.array(ck._to_numpy(v), dtype=np.float32)) for k, v in sd.items())
+        ck.aux_channel_blob(sd, 0)                      # validates names and shapes
+        if sd["out_linears.weight"].shape[0] != self.out_ch:
+            raise ValueError("out_linears has %d rows, this network %d" % (sd["out_linears.weight"].shape[0], self.out_ch))
+        self._sd = sd
+        self._version += 1
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+
 _query_ctx = {}     # id(network) -> {"ref": weakref, "r": Renderer, "w": weights key}
 
 
@@ -104,10 +133,12 @@ def create_IBLNeRF(args):
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
     if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
         raise NotImplementedError("embedders other than multires=10 / multires_views=4 are not built")
-    for flag in ("infer_depth", "infer_visibility", "infer_normal", "infer_albedo_separate", "infer_roughness_separate",
-                 "infer_irradiance_separate", "use_environment_map"):
+    for flag in ("infer_depth", "infer_visibility", "infer_normal"):
         if getattr(args, flag, False):
             raise NotImplementedError("%s is outside the shipped-config path (SURVEY.md §8 f-4)" % flag)
+    aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, out_ch=out_ch) if getattr(args, flag, False) else None)
+           for name, flag, out_ch in (("albedo_mlp", "infer_albedo_separate", 3), ("roughness_mlp", "infer_roughness_separate", 1),
+                                      ("irradiance_mlp", "infer_irradiance_separate", 1))}            # ibl_nerf.py:312-326
     mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, coarse_radiance_number=args.coarse_radiance_number,
                          is_color_independent_to_direction=args.color_independent_to_direction)
     model = mk()
@@ -120,13 +151,16 @@ def create_IBLNeRF(args):
         model.load_state_dict(sd_c)
         if model_fine is not None and sd_f is not None:
             model_fine.load_state_dict(sd_f)
+        for name, sd_a in ck.load_checkpoint_aux(path).items():                    # ibl_nerf.py:369-374
+            if aux[name] is not None:
+                aux[name].load_state_dict(sd_a)
     train = {
         "network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
         "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,
         "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
         "ndc": False, "lindisp": args.lindisp,
-        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": None, "albedo_mlp": None, "roughness_mlp": None,
-        "irradiance_mlp": None, "infer_depth": False, "infer_visibility": False, "infer_normal": False,
+        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": None, "albedo_mlp": aux["albedo_mlp"],
+        "roughness_mlp": aux["roughness_mlp"], "irradiance_mlp": aux["irradiance_mlp"], "infer_depth": False, "infer_visibility": False, "infer_normal": False,
         "infer_normal_at_surface": getattr(args, "infer_normal_at_surface", False),
         "coarse_radiance_number": args.coarse_radiance_number,
         "use_monte_carlo_integration": getattr(args, "use_monte_carlo_integration", False),

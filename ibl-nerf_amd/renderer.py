@@ -94,6 +94,7 @@ class Renderer:
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
                           lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode,
                           color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction)
+        self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
         self.range_fallbacks = 0
@@ -141,6 +142,23 @@ class Renderer:
             if self._wide is not None:
                 self._wide.load_weights(which, blob)
 
+    def load_aux(self, name, state_dict):
+        """name: 'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' (the render kwarg the reference passes it as,
+        ibl_nerf_renderer.py:291-303); state_dict: a PositionMLP's, or None to remove the network."""
+        kind, out_ch = B.AUX_KINDS[name]
+        if state_dict is None:
+            B.check(self.ctx, self.lib.iblnerf_clear_aux(self.ctx, kind))
+        else:
+            sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
+            if tuple(sd["out_linears.weight"].shape) != (out_ch, 256):
+                raise ValueError("%s.out_linears must be [%d,256]" % (name, out_ch))
+            for ch in range(out_ch):
+                blob = np.ascontiguousarray(ck.aux_channel_blob(sd, ch), dtype=np.float32)
+                B.check(self.ctx, self.lib.iblnerf_upload_aux_weights(self.ctx, kind, ch, blob.ctypes.data, blob.size))
+        self._aux[name] = state_dict
+        if self._wide is not None:
+            self._wide.load_aux(name, state_dict)
+
     def load_lut(self, lut):
         """lut: float [3,512,512] exactly as test.py:79-87 builds `brdf_lut`."""
         if not isinstance(lut, np.ndarray):
@@ -168,6 +186,9 @@ class Renderer:
             self._wide = Renderer(mlp_precision="bf16x3", **self._ctor)
             for which, blob in self._blobs.items():
                 self._wide.load_weights(which, blob)
+            for name, sd in self._aux.items():
+                if sd is not None:
+                    self._wide.load_aux(name, sd)
             if self._lut is not None:
                 self._wide.load_lut(self._lut)
         self.range_fallbacks += 1
@@ -370,7 +391,7 @@ def _check_supported(kw):
     for k in _UNSUPPORTED_TRUE:
         if kw.get(k):
             raise NotImplementedError("%s=True is outside the shipped-config forward path built here (SURVEY.md §8 f-4)" % k)
-    for k in ("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp", "depth_mlp"):
+    for k in ("normal_mlp", "depth_mlp", "visibility_mlp"):
         if kw.get(k) is not None:
             raise NotImplementedError("auxiliary %s (src/networks/MLP.py) is not built (SURVEY.md §8 f-4)" % k)
     if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
@@ -426,7 +447,7 @@ def renderer_for(kw):
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
                      max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12],
                      color_independent_to_direction=key[13], epsilon_direction=key[14])
-        ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None}
+        ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None, "aux": {}}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):
         if net is None:
@@ -435,6 +456,12 @@ def renderer_for(kw):
         if ent["w"][which] != wk:
             r.load_weights(which, net.state_dict())
             ent["w"][which] = wk
+    for name in B.AUX_KINDS:                          # albedo_mlp / roughness_mlp / irradiance_mlp (ibl_nerf_renderer.py:291-303)
+        net = kw.get(name)
+        wk = None if net is None else _weights_key(net)
+        if ent["aux"].get(name) != wk:
+            r.load_aux(name, None if net is None else net.state_dict())
+            ent["aux"][name] = wk
     lut = kw["brdf_lut"]
     lk = (id(lut), lut.data_ptr() if hasattr(lut, "data_ptr") else 0)
     if ent["lut"] != lk:

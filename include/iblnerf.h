@@ -95,6 +95,18 @@ int iblnerf_upload_weights(iblnerf_ctx* ctx, int which, const float* h_blob, siz
  * iblnerf_range_status flag instead of switching kernels. */
 int iblnerf_upload_weights_device(iblnerf_ctx* ctx, void* stream, int which, const float* d_blob, size_t n_floats);
 
+/* replaces: albedo_mlp / roughness_mlp / irradiance_mlp.load_state_dict (nerf_models/ibl_nerf.py:312-326, :369-374) and their
+ * use in raw2outputs (ibl_nerf_renderer.py:291-303): a PositionMLP (src/networks/MLP.py:6-30) has the main network's trunk
+ * shape plus out_linears [out_ch, 256]; its per-sample outputs replace the main network's albedo / roughness / irradiance
+ * samples before compositing (an irradiance_mlp's always through sigmoid).  One upload per output channel: h_blob is an
+ * IBLNeRF-schema blob whose positions_linears.* are the auxiliary network's and whose sigma_linear.{weight,bias} is row
+ * `channel` of its out_linears (the other tensors are not read).  kind: IBLNERF_AUX_ALBEDO (channels 0..2),
+ * IBLNERF_AUX_ROUGHNESS, IBLNERF_AUX_IRRADIANCE (channel 0).  The network takes effect in iblnerf_render_rays once all its
+ * channels are uploaded, for both passes, until iblnerf_clear_aux.  Cost: one trunk evaluation per sample and channel. */
+enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE = 2 };
+int iblnerf_upload_aux_weights(iblnerf_ctx* ctx, int kind, int channel, const float* h_blob, size_t n_floats);
+int iblnerf_clear_aux(iblnerf_ctx* ctx, int kind);
+
 /* replaces: brdf_lut tensor of test.py:79-87.  h_rgb = float [3,512,512] (R = scale, G = bias). */
 int iblnerf_upload_lut(iblnerf_ctx* ctx, const float* h_rgb);
 

@@ -144,6 +144,20 @@ def network_query(sd, pts, viewdirs):
     return mlp_forward(sd, e, embed(d, 4)).reshape(N, S, 18)
 
 
+def position_mlp_query(aux_sd, pts):
+    """network_query_fn(pts, None, <PositionMLP>) — src/networks/MLP.py:19-30: the trunk (ReLU after every layer, skip
+    after layer 4) then out_linears, no activation.  pts [N,S,3] -> [N,S,out_ch]."""
+    pts = np.asarray(pts, dtype=F32)
+    N, S, _ = pts.shape
+    e = embed(pts.reshape(-1, 3), 10)
+    h = e
+    for i in range(8):
+        h = relu(_lin(aux_sd, "positions_linears.%d" % i, h))
+        if i == 4:
+            h = np.concatenate([e, h], -1)
+    return _lin(aux_sd, "out_linears", h).reshape(N, S, -1).astype(F32)
+
+
 # --------------------------------------------------------------------------------------------
 # A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
 # --------------------------------------------------------------------------------------------
@@ -272,14 +286,16 @@ def decode_masks(mask_img, n_obj):
 # --------------------------------------------------------------------------------------------
 # one pass: raw2outputs, ibl_nerf_renderer.py:153-527 (approximate_radiance=True, shipped flags)
 # --------------------------------------------------------------------------------------------
-def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None):
+def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None, aux=None):
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
     epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
     target_normal_map_for_radiance_calculation ('normal_map_from_depth_gradient_epsilon' | 'ground_truth' |
     'normal_map_from_depth_gradient_direction_epsilon' with epsilon_direction, default 0.005; :348-375),
     depth_map_from_ground_truth / calculate_{albedo,roughness,irradiance}_from_gt (:251-252, :320-330): the target map is
-    the gt_values row and no longer aliases the network's map, so edits stop showing in depth_map / disp / the mip level."""
+    the gt_values row and no longer aliases the network's map, so edits stop showing in depth_map / disp / the mip level.
+    aux: {'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp': PositionMLP state dict} (:291-303): their samples replace the main
+    network's before compositing; an irradiance_mlp's go through sigmoid whatever radiance_f is."""
     gt = gt or {}
     edit = edit or {}
     flags = flags or {}
@@ -311,6 +327,13 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     albedo = np.sum(w[..., None] * sigmoid(raw[..., 1:4]), -2, dtype=F32)                   # :281-282
     rough = np.sum(w * sigmoid(raw[..., 4]), -1, dtype=F32)                                 # :284-285
     irr = np.sum(w * radiance_f(raw[..., 5]), -1, dtype=F32)[:, None]                       # :287-288, :328
+    aux = aux or {}
+    if aux.get("albedo_mlp") is not None:                                                   # :291-294
+        albedo = np.sum(w[..., None] * sigmoid(position_mlp_query(aux["albedo_mlp"], pts)[..., 0:3]), -2, dtype=F32)
+    if aux.get("roughness_mlp") is not None:                                                # :296-299
+        rough = np.sum(w * sigmoid(position_mlp_query(aux["roughness_mlp"], pts)[..., 0]), -1, dtype=F32)
+    if aux.get("irradiance_mlp") is not None:                                               # :301-304
+        irr = np.sum(w * sigmoid(position_mlp_query(aux["irradiance_mlp"], pts)[..., 0]), -1, dtype=F32)[:, None]
     rough_net = rough                                                                       # :324 (aliases unless from gt)
     if flags.get("calculate_albedo_from_gt", False):
         albedo = gt["albedo"][:, :3].astype(F32).copy()                                     # :321-322
@@ -412,21 +435,21 @@ def coarse_z(near, far, n_samples, n_rays, lindisp=False):
 
 
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64, n_importance=128,
-                gt=None, edit=None, stages=None, flags=None):
+                gt=None, edit=None, stages=None, flags=None, aux=None):
     rays_o = np.ascontiguousarray(rays_o, dtype=F32)
     rays_d = np.ascontiguousarray(rays_d, dtype=F32)
     N = rays_o.shape[0]
     flags = flags or {}
     z = coarse_z(near, far, n_samples, N, bool(flags.get("lindisp", False)))
     st_c = {} if stages is not None else None
-    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags)
+    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags, aux)
     if n_importance > 0:
         mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)                             # :701
         zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance)                       # :702-703
         zf = np.sort(np.concatenate([z, zs], -1), -1)                                      # :707
         st_f = {} if stages is not None else None
         fine = raw2outputs(sd_fine if sd_fine is not None else sd_coarse, rays_o, rays_d, zf, z,
-                           near, far, lut, gt, edit, st_f, flags)
+                           near, far, lut, gt, edit, st_f, flags, aux)
         for k, v in res.items():
             fine[k + "0"] = v                                                              # :712-713
         res = fine

@@ -44,6 +44,12 @@ def load_golden(name):
     return g, sdc, sdf, gt, edit
 
 
+def golden_aux(g):
+    """{'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp': PositionMLP state dict} of a fixture rendered with auxiliary networks."""
+    from ibl_nerf_amd import checkpoint as ck
+    return {k[5:]: ck.synthetic_position_mlp(int(g[k]), ck.AUX_OUT_CH[k[5:]], float(g["gain"])) for k in g.files if k.startswith("aux__")}
+
+
 def rel_linf(x, ref):
     """SURVEY.md §8 d: max|x - ref| / max|ref| (the per-channel parity metric of north_star)."""
     x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
@@ -51,7 +57,8 @@ def rel_linf(x, ref):
 
 
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
-                   "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10"]
+                   "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
+                   "auxmlp_lin_g10"]
 
 
 def color_independent(g):

@@ -51,7 +51,7 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance, n_samples=64, color_independent=False):
+def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False):
     """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
@@ -59,8 +59,8 @@ def reference_args(tmp, n_importance, n_samples=64, color_independent=False):
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
         color_independent_to_direction=color_independent, use_illumination_feature_layer=False,
         use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
-        infer_normal=False, infer_normal_at_surface=False, infer_albedo_separate=False,
-        infer_roughness_separate=False, infer_irradiance_separate=False, use_environment_map=False,
+        infer_normal=False, infer_normal_at_surface=False, infer_albedo_separate=aux,
+        infer_roughness_separate=aux, infer_irradiance_separate=aux, use_environment_map=False,
         N_envmap_size=16, lrate=5e-4, lrate_env_map=5e-4, basedir=tmp, expname="exp", ft_path=None,
         target_load_N_iter=-1, no_reload=True, perturb=1.0, use_viewdirs=True, white_bkgd=False,
         raw_noise_std=0.0, lindisp=False, use_monte_carlo_integration=False,
@@ -119,6 +119,8 @@ class Recorder:
 
         def q(inputs, viewdirs, fn):
             out = self._q0(inputs, viewdirs, fn)
+            if any(fn is kw.get(a) for a in ("albedo_mlp", "roughness_mlp", "irradiance_mlp")):
+                return out                       # auxiliary-network queries are not stage boundaries of the main network
             n = inputs.shape[0]
             if viewdirs is None:  # eps-normal query: 4 stacked copies of the ray set
                 nr = n // 4
@@ -170,10 +172,10 @@ class Recorder:
 
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
-                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False):
+                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
@@ -181,6 +183,12 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     if kw["network_fine"] is not None:
         kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    aux_seeds = {}
+    if aux:  # infer_{albedo,roughness,irradiance}_separate: seeded PositionMLPs (src/networks/MLP.py) beside the main networks
+        for j, aux_name in enumerate(("albedo_mlp", "roughness_mlp", "irradiance_mlp")):
+            aux_seeds[aux_name] = 100 * seed + j
+            sd_a = ck.synthetic_position_mlp(aux_seeds[aux_name], ck.AUX_OUT_CH[aux_name], gain)
+            kw[aux_name].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
     kw.update(flags or {})            # flag variants outside the shipped configs
@@ -265,6 +273,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         out["flag__" + k] = np.asarray(v)
     if color_independent:
         out["model__color_independent_to_direction"] = np.asarray(True)
+    for aux_name, sd_seed in aux_seeds.items():
+        out["aux__" + aux_name] = np.int64(sd_seed)
     for k, v in gt.items():
         out["gt__" + k] = v
     for k, v in edit.items():
@@ -417,6 +427,11 @@ def main(only=None):
     run_fixture("dirnormal_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=11, posed=True,
                 flags=dict(target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_direction_epsilon",
                            epsilon_direction=0.005))
+    # auxiliary PositionMLPs for albedo / roughness / irradiance (infer_*_separate), HDR radiance so that the irradiance_mlp's
+    # sigmoid differs from radiance_f
+    run_fixture("auxmlp_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=12, aux=True)
+    run_fixture("auxmlp_lin_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=13, aux=True,
+                flags=dict(use_radiance_linear=True))
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

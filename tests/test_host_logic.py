@@ -445,3 +445,30 @@ def test_tile_rows_partition():
             assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
     with pytest.raises(ValueError):
         D.tile_rows(10, 2, 2)
+
+
+def test_auxiliary_network_blob_and_checkpoint(tmp_path):
+    """PositionMLP (src/networks/MLP.py) -> one IBLNeRF-schema blob per output channel: trunk copied, out_linears row in the
+    place of sigma_linear, zeros elsewhere; the oracle's trunk + sigma head on that blob equals the PositionMLP's channel."""
+    aux = ck.synthetic_position_mlp(5, 3)
+    assert list(aux)[:2] == ["positions_linears.0.weight", "positions_linears.0.bias"] and list(aux)[-2:] == ["out_linears.weight", "out_linears.bias"]
+    pts = np.random.RandomState(0).uniform(-3, 3, (5, 7, 3)).astype(np.float32)
+    want = O.position_mlp_query(aux, pts)
+    for ch in range(3):
+        sd = ck.blob_to_state_dict(ck.aux_channel_blob(aux, ch))
+        assert np.array_equal(sd["positions_linears.5.weight"], aux["positions_linears.5.weight"])
+        assert np.array_equal(sd["sigma_linear.weight"][0], aux["out_linears.weight"][ch]) and not sd["radiance_linear.weight"].any()
+        assert np.abs(O.network_query(sd, pts, None)[..., 0] - want[..., ch]).max() <= 2e-6      # sgemv vs one column of sgemm
+    with pytest.raises(ValueError):
+        ck.aux_channel_blob(aux, 3)
+    with pytest.raises(KeyError):
+        ck.aux_channel_blob(ck.synthetic_state_dict(0), 0)
+    os.makedirs(tmp_path / "exp")
+    ck.save_checkpoint(str(tmp_path / "exp" / "000007.tar"), 7, ck.synthetic_state_dict(1), ck.synthetic_state_dict(2),
+                       aux={"albedo_mlp": aux})
+    _, kw, start, *_ = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), no_reload=False, infer_albedo_separate=True,
+                                                           infer_roughness_separate=True))
+    assert start == 7 and kw["irradiance_mlp"] is None and kw["roughness_mlp"].out_ch == 1     # built, not in the checkpoint
+    assert np.array_equal(kw["albedo_mlp"].state_dict()["out_linears.bias"], aux["out_linears.bias"])
+    with pytest.raises(ValueError):
+        kw["roughness_mlp"].load_state_dict(aux)                                               # 3 rows into a 1-channel network

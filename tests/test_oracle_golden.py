@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import GOLDEN, RENDER_FIXTURES, color_independent, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
+from conftest import GOLDEN, RENDER_FIXTURES, color_independent, golden_aux, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 # Channels that are smooth functions of the MLP outputs: the oracle must sit at fp32 round-off.
 DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
@@ -70,7 +70,7 @@ def test_render_rays_end_to_end(name, lut):
     st = {}
     flags = golden_flags(g)
     res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut,
-                        n_samples(g), int(g["n_importance"]), gt, edit, st, flags)
+                        n_samples(g), int(g["n_importance"]), gt, edit, st, flags, golden_aux(g))
     ref_keys = sorted(k[5:] for k in g.files if k.startswith("out__"))
     assert sorted(res.keys()) == ref_keys                       # 22 maps (+22 '0' maps + z_std)
     wide = ill_conditioned(g)
