@@ -35,7 +35,7 @@ class Options(C.Structure):
 
 
 MLP_BF16X3, MLP_F16_MXFP6 = 0, 1
-AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
+AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
 FP = C.c_void_p  # device float*
@@ -57,7 +57,7 @@ class Maps(C.Structure):
                 ("reflected_radiance_map", FP), ("prefiltered_reflected_map", FP), ("albedo_map", FP),
                 ("roughness_map", FP), ("specular_map", FP), ("diffuse_map", FP), ("n_dot_v_map", FP),
                 ("target_normal_map", FP), ("disp_map", FP), ("acc_map", FP), ("depth_map", FP),
-                ("target_depth_map", FP), ("weights", FP)]
+                ("target_depth_map", FP), ("weights", FP), ("inferred_normal_map", FP)]
 
 
 class Outputs(C.Structure):

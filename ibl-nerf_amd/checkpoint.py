@@ -58,7 +58,7 @@ def synthetic_state_dict(seed: int, gain: float = 1.0, sigma_bias: float = 0.3) 
 
 
 # Auxiliary PositionMLPs (src/networks/MLP.py:6-30, ibl_nerf.py:312-326): the main network's trunk shape + out_linears
-AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1}
+AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1, "normal_mlp": 3}
 TRUNK_SCHEMA = tuple(e for e in SCHEMA if e[0].startswith("positions_linears."))
 
 

@@ -27,8 +27,9 @@ constexpr double FLOP_FULL = 1591552.0, FLOP_TRUNK = 982528.0, FLOP_REFL = 14589
 constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // what is_color_independent_to_direction skips
 }  // namespace
 
-constexpr int N_SLOTS = 7;
-constexpr int AUX_SLOT0[3] = {2, 5, 6}, AUX_CHANNELS[3] = {3, 1, 1}, AUX_RAW_COLUMN[3] = {1, 4, 5};   // albedo, roughness, irradiance
+constexpr int N_SLOTS = 10, N_AUX = 4;
+// albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
+constexpr int AUX_SLOT0[N_AUX] = {2, 5, 6, 7}, AUX_CHANNELS[N_AUX] = {3, 1, 1, 3}, AUX_RAW_COLUMN[3] = {1, 4, 5};
 
 struct iblnerf_ctx {
     iblnerf_options opt;
@@ -40,13 +41,14 @@ struct iblnerf_ctx {
     char* d_stream[N_SLOTS] = {};
     char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
     unsigned* d_range_flag = nullptr;
-    bool mx_ok[N_SLOTS] = {true, true, true, true, true, true, true};
+    bool mx_ok[N_SLOTS] = {true, true, true, true, true, true, true, true, true, true};
     unsigned short* d_map16 = nullptr;            // gather maps of the device packer (built on first use)
     int* d_map_mx = nullptr;
     int* d_map_tab = nullptr;                 // false: a weight is outside the f16 range -> that network runs on the bf16x3 kernel
     float* d_tables[N_SLOTS] = {};
     bool have_net[N_SLOTS] = {};
-    bool aux_on[3] = {false, false, false};   // IBLNERF_AUX_ALBEDO / ROUGHNESS / IRRADIANCE enabled for render_rays
+    bool aux_on[N_AUX] = {};                  // IBLNERF_AUX_* enabled for render_rays
+    float* nrm_raw = nullptr;                 // [ws_rays, Smax, 3] normal_mlp samples (allocated with the first IBLNERF_AUX_NORMAL upload)
     float* d_lut = nullptr;
     bool have_lut = false;
     // workspace
@@ -131,9 +133,9 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         return IBLNERF_ERR_INVALID;
     }
     if (opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON && opts->normal_mode != IBLNERF_NORMAL_GROUND_TRUTH &&
-        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON) {
-        g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0), IBLNERF_NORMAL_GROUND_TRUTH (1) or "
-                         "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2)";
+        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON && opts->normal_mode != IBLNERF_NORMAL_INFERRED) {
+        g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0), IBLNERF_NORMAL_GROUND_TRUTH (1), "
+                         "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6) {
@@ -206,7 +208,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
 void iblnerf_destroy(iblnerf_ctx* c) {
     if (!c) return;
     float* bufs[] = {c->zc, c->z_fine, c->pts, c->raw, c->sig4, c->w_c, c->w_f, c->state, c->refl_o, c->refl_d,
-                     c->refl_raw, c->d_lut};
+                     c->refl_raw, c->d_lut, c->nrm_raw};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     for (int w = 0; w < N_SLOTS; ++w) {
@@ -256,10 +258,12 @@ int iblnerf_upload_weights(iblnerf_ctx* c, int which, const float* h_blob, size_
 
 int iblnerf_upload_aux_weights(iblnerf_ctx* c, int kind, int channel, const float* h_blob, size_t n_floats) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (kind < 0 || kind > 2 || channel < 0 || channel >= AUX_CHANNELS[kind < 0 || kind > 2 ? 0 : kind] || !h_blob)
+    if (kind < 0 || kind >= N_AUX || channel < 0 || channel >= AUX_CHANNELS[kind < 0 || kind >= N_AUX ? 0 : kind] || !h_blob)
         return c->fail(IBLNERF_ERR_INVALID, "upload_aux_weights: kind must be IBLNERF_AUX_* and channel inside its out_ch, blob non-null");
     const int rc = upload_slot(c, AUX_SLOT0[kind] + channel, h_blob, n_floats, "upload_aux_weights");
     if (rc) return rc;
+    if (kind == IBLNERF_AUX_NORMAL && !c->nrm_raw)
+        HIP_TRY(c, hipMalloc((void**)&c->nrm_raw, (size_t)c->ws_rays * c->Smax * 3 * sizeof(float)));
     bool all = true;
     for (int ch = 0; ch < AUX_CHANNELS[kind]; ++ch) all = all && c->have_net[AUX_SLOT0[kind] + ch];
     c->aux_on[kind] = all;                       // takes effect once every output channel is there
@@ -268,7 +272,7 @@ int iblnerf_upload_aux_weights(iblnerf_ctx* c, int kind, int channel, const floa
 
 int iblnerf_clear_aux(iblnerf_ctx* c, int kind) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (kind < 0 || kind > 2) return c->fail(IBLNERF_ERR_INVALID, "clear_aux: kind must be IBLNERF_AUX_*");
+    if (kind < 0 || kind >= N_AUX) return c->fail(IBLNERF_ERR_INVALID, "clear_aux: kind must be IBLNERF_AUX_*");
     c->aux_on[kind] = false;
     for (int ch = 0; ch < AUX_CHANNELS[kind]; ++ch) c->have_net[AUX_SLOT0[kind] + ch] = false;
     return IBLNERF_OK;
@@ -416,6 +420,7 @@ static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S, int irr_ch 
     o.depth = off(m.depth_map, 1);
     o.target_depth = off(m.target_depth_map, 1);
     o.weights = off(m.weights, S);
+    o.inferred_normal = off(m.inferred_normal_map, 3);
     return o;
 }
 
@@ -435,11 +440,16 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[kind] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[kind] + ch, RAW_CH);
             if (rc) return rc;
         }
+    const bool inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED;
+    for (int ch = 0; c->aux_on[IBLNERF_AUX_NORMAL] && ch < 3; ++ch) {   // normal_mlp at the same points (:273)
+        rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3);
+        if (rc) return rc;
+    }
     // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
     // (:55-75), trunk only; none in the ground-truth normal mode
     const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
     const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
-    if (ov.gt_normal == nullptr) {
+    if (ov.gt_normal == nullptr && !inferred) {
         HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
         if (rc) return rc;
@@ -448,6 +458,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
     a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = eps; a.tilted_rays = tilt ? 1 : 0;
     a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
+    a.nrm_raw = c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr;
+    a.normal_inferred = inferred ? 1 : 0;
     a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
     a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.radiance_linear = c->opt.use_radiance_linear;
@@ -503,6 +515,8 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
             return c->fail(IBLNERF_ERR_INVALID, "normal_mode ground_truth needs overrides.d_gt_normal (gt_values[\"normal\"] rows)");
         gt_normal = ovr->d_gt_normal;
     }
+    if (c->opt.normal_mode == IBLNERF_NORMAL_INFERRED && !c->aux_on[IBLNERF_AUX_NORMAL])
+        return c->fail(IBLNERF_ERR_STATE, "normal_mode inferred needs a normal_mlp (iblnerf_upload_aux_weights, IBLNERF_AUX_NORMAL)");
     const int irr_ch = (ovr && ovr->d_gt_irradiance) ? 3 : 1;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->opt.device));

@@ -91,6 +91,7 @@ struct PassOutputs {           // any pointer may be null (skipped).  Shapes per
     float* depth;              // 1
     float* target_depth;       // 1
     float* weights;            // S
+    float* inferred_normal;    // 3 (normal_mlp loaded)
 };
 
 struct PassAArgs {
@@ -98,6 +99,8 @@ struct PassAArgs {
     const float* z; int z_stride;               // see launch_make_points
     const float* raw;                           // [R,S,18]
     const float* sig4;                          // [4,R,S]
+    const float* nrm_raw;                       // [R,S,3] normal_mlp samples or null (ibl_nerf_renderer.py:273-276)
+    int normal_inferred;                        // target normal = the composited normal_mlp output, as it is (:372-373)
     float* weights;                             // [R,S] (always written: sample_pdf input / output map)
     const float* lut;                           // [3,512,512]
     float near, far, eps;

@@ -250,11 +250,27 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
 #pragma unroll
     for (int c = 0; c < 17; ++c) ch[c] = wave_sum(ch[c]);
 
+    // inferred normal (:273-276): sum_s w_s (2 sigmoid(normal_mlp(x_s)) - 1), not normalised
+    float inf[3] = {0.f, 0.f, 0.f};
+    if (a.nrm_raw != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int s = lane * NPL + i;
+            if (s < S) {
+                const float* row = a.nrm_raw + ((long)r * S + s) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) inf[c] += w[i] * (2.0f * sigmoidf_(row[c]) - 1.0f);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) inf[c] = wave_sum(inf[c]);
+    }
+
     // epsilon-normal depths (normal_from_depth.py:158-176): same z / dists, trunk-only sigma
     float D[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        if (a.ov.gt_normal != nullptr) break;   // "ground_truth" normal mode: no offset queries were made
+        if (a.ov.gt_normal != nullptr || a.normal_inferred) break;   // "ground_truth" / "inferred_normal_map": no offset queries were made
         float sv[NPL], wv[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -318,6 +334,10 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     }
     cross3(dxv, dyv, nrm);
     normalize3(nrm);
+    if (a.normal_inferred) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = inf[c];
+    }
     if (a.ov.gt_normal != nullptr) {   // target_normal_map_for_radiance_calculation == "ground_truth" (:370-371)
 #pragma unroll
         for (int c = 0; c < 3; ++c) nrm[c] = 2.0f * a.ov.gt_normal[3 * r + c] - 1.0f;
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         if (out.roughness) out.roughness[r] = rough;
         if (out.n_dot_v) out.n_dot_v[r] = ndv;
         store3(out.normal, r, nrm, 0);
+        if (a.nrm_raw != nullptr) store3(out.inferred_normal, r, inf, 0);
         if (out.disp) out.disp[r] = disp;
         if (out.acc) out.acc[r] = acc;
         if (out.depth) out.depth[r] = depth;

@@ -133,12 +133,12 @@ def create_IBLNeRF(args):
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
     if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
         raise NotImplementedError("embedders other than multires=10 / multires_views=4 are not built")
-    for flag in ("infer_depth", "infer_visibility", "infer_normal"):
+    for flag in ("infer_depth", "infer_visibility"):
         if getattr(args, flag, False):
             raise NotImplementedError("%s is outside the shipped-config path (SURVEY.md §8 f-4)" % flag)
     aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, out_ch=out_ch) if getattr(args, flag, False) else None)
            for name, flag, out_ch in (("albedo_mlp", "infer_albedo_separate", 3), ("roughness_mlp", "infer_roughness_separate", 1),
-                                      ("irradiance_mlp", "infer_irradiance_separate", 1))}            # ibl_nerf.py:312-326
+                                      ("irradiance_mlp", "infer_irradiance_separate", 1), ("normal_mlp", "infer_normal", 3))}   # ibl_nerf.py:307-326
     mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, coarse_radiance_number=args.coarse_radiance_number,
                          is_color_independent_to_direction=args.color_independent_to_direction)
     model = mk()
@@ -159,8 +159,8 @@ def create_IBLNeRF(args):
         "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,
         "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
         "ndc": False, "lindisp": args.lindisp,
-        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": None, "albedo_mlp": aux["albedo_mlp"],
-        "roughness_mlp": aux["roughness_mlp"], "irradiance_mlp": aux["irradiance_mlp"], "infer_depth": False, "infer_visibility": False, "infer_normal": False,
+        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": aux["normal_mlp"], "albedo_mlp": aux["albedo_mlp"],
+        "roughness_mlp": aux["roughness_mlp"], "irradiance_mlp": aux["irradiance_mlp"], "infer_depth": False, "infer_visibility": False, "infer_normal": bool(getattr(args, "infer_normal", False)),
         "infer_normal_at_surface": getattr(args, "infer_normal_at_surface", False),
         "coarse_radiance_number": args.coarse_radiance_number,
         "use_monte_carlo_integration": getattr(args, "use_monte_carlo_integration", False),

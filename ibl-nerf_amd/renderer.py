@@ -143,8 +143,8 @@ class Renderer:
                 self._wide.load_weights(which, blob)
 
     def load_aux(self, name, state_dict):
-        """name: 'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' (the render kwarg the reference passes it as,
-        ibl_nerf_renderer.py:291-303); state_dict: a PositionMLP's, or None to remove the network."""
+        """name: 'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' | 'normal_mlp' (the render kwarg the reference passes it as,
+        ibl_nerf_renderer.py:267-303); state_dict: a PositionMLP's, or None to remove the network."""
         kind, out_ch = B.AUX_KINDS[name]
         if state_dict is None:
             B.check(self.ctx, self.lib.iblnerf_clear_aux(self.ctx, kind))
@@ -242,7 +242,7 @@ class Renderer:
                                                       bins.shape[0], bins.shape[1], int(N_samples), out.data_ptr()))
         return out
 
-    def _alloc_maps(self, n, S, want=True, irr_ch=1):
+    def _alloc_maps(self, n, S, want=True, irr_ch=1, inferred_normal=False):
         torch = _torch()
         m, t = B.Maps(), {}
         if not want:
@@ -254,6 +254,9 @@ class Renderer:
             t[k] = e(n)
         t["irradiance_map"] = e(n, irr_ch)
         t["weights"] = e(n, S)
+        if inferred_normal:                      # infer_normal (ibl_nerf_renderer.py:267-276, :517)
+            t["inferred_normal_map"] = e(n, 3)
+            m.inferred_normal_map = t["inferred_normal_map"].data_ptr()
         for k in ("color_map", "radiance_map", "irradiance_map", "reflected_radiance_map", "prefiltered_reflected_map",
                   "albedo_map", "roughness_map", "specular_map", "diffuse_map", "n_dot_v_map", "target_normal_map",
                   "disp_map", "acc_map", "depth_map", "target_depth_map", "weights"):
@@ -274,10 +277,11 @@ class Renderer:
         outs = B.Outputs()
         fine = self.N_importance > 0
         irr_ch = 3 if edit.get("calculate_irradiance_from_gt") else 1     # gt irradiance is RGB (:328-330, :501)
-        outs.fine, t_fine = self._alloc_maps(n, Sf if fine else Sc, irr_ch=irr_ch)
+        inf = self._aux.get("normal_mlp") is not None
+        outs.fine, t_fine = self._alloc_maps(n, Sf if fine else Sc, irr_ch=irr_ch, inferred_normal=inf)
         t_coarse = {}
         if fine and self.coarse_outputs:
-            outs.coarse, t_coarse = self._alloc_maps(n, Sc, irr_ch=irr_ch)
+            outs.coarse, t_coarse = self._alloc_maps(n, Sc, irr_ch=irr_ch, inferred_normal=inf)
         z_std = None
         if fine:
             z_std = torch.empty((n,), dtype=torch.float32, device=self.device)
@@ -288,8 +292,9 @@ class Renderer:
         self._keep = keep   # override rows must outlive the asynchronous launch
         if self.out_of_range():
             return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, **edit)
-        res = {k: t_fine[k] for k in RESULT_ORDER}
-        for k in RESULT_ORDER:
+        order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
+        res = {k: t_fine[k] for k in order}
+        for k in order:
             if k in t_coarse:
                 res[k + "0"] = t_coarse[k]
         if z_std is not None:
@@ -376,7 +381,7 @@ class Renderer:
 # ---------------------------------------------------------------------------------------------
 # reference-signature functions
 # ---------------------------------------------------------------------------------------------
-_UNSUPPORTED_TRUE = ["infer_normal", "infer_normal_at_surface", "infer_depth"]
+_UNSUPPORTED_TRUE = ["infer_normal_at_surface", "infer_depth"]
 # white_bkgd, retraw and use_environment_map are accepted and ignored, as in the reference: render_rays takes the first two and
 # never reads them (ibl_nerf_renderer.py:629-630), and the environment map is created (ibl_nerf.py:331-334) but no renderer code uses it
 # raw2outputs flags that swap a network map for its gt_values row (ibl_nerf_renderer.py:251-252, :320-330)
@@ -391,16 +396,17 @@ def _check_supported(kw):
     for k in _UNSUPPORTED_TRUE:
         if kw.get(k):
             raise NotImplementedError("%s=True is outside the shipped-config forward path built here (SURVEY.md §8 f-4)" % k)
-    for k in ("normal_mlp", "depth_mlp", "visibility_mlp"):
+    for k in ("depth_mlp", "visibility_mlp"):
         if kw.get(k) is not None:
             raise NotImplementedError("auxiliary %s (src/networks/MLP.py) is not built (SURVEY.md §8 f-4)" % k)
+    if kw.get("infer_normal") and kw.get("normal_mlp") is None:
+        raise TypeError("infer_normal=True needs normal_mlp")                      # the reference calls run_network(..., None)
     if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
         raise NotImplementedError("perturb / raw_noise_std > 0 are training-time options (SURVEY.md §8 f-3)")
     mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
     if mode not in NORMAL_MODES:
         if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
-                    "normal_map_from_depth_gradient_direction",
-                    "inferred_normal_map"):
+                    "normal_map_from_depth_gradient_direction"):
             raise NotImplementedError("normal mode %r is not built (SURVEY.md §8 f-4)" % mode)
         raise ValueError(mode)                                                       # ibl_nerf_renderer.py:374-375
     if not kw.get("approximate_radiance", False):
@@ -411,7 +417,7 @@ def _check_supported(kw):
 
 _renderers = {}
 NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
-                "normal_map_from_depth_gradient_direction_epsilon": 2}   # target_normal_map_for_radiance_calculation values built
+                "normal_map_from_depth_gradient_direction_epsilon": 2, "inferred_normal_map": 3}   # target_normal_map_for_radiance_calculation values built
 DEFAULT_MLP_PRECISION = "f16_mxfp6"
 
 
@@ -458,6 +464,8 @@ def renderer_for(kw):
             ent["w"][which] = wk
     for name in B.AUX_KINDS:                          # albedo_mlp / roughness_mlp / irradiance_mlp (ibl_nerf_renderer.py:291-303)
         net = kw.get(name)
+        if name == "normal_mlp" and not kw.get("infer_normal"):
+            net = None                           # the reference only queries it under infer_normal (:267)
         wk = None if net is None else _weights_key(net)
         if ent["aux"].get(name) != wk:
             r.load_aux(name, None if net is None else net.state_dict())

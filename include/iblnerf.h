@@ -56,7 +56,9 @@ typedef struct {
                                           (shipped; 4 offset queries per sample, normal_from_depth.py:139-183) or
                                           IBLNERF_NORMAL_GROUND_TRUTH (gt_values["normal"] rows, :370-371; no offset queries) or
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (depths along four rays with tilted
-                                          directions, normal_from_depth.py:55-100; uses epsilon_direction) */
+                                          directions, normal_from_depth.py:55-100; uses epsilon_direction) or
+                                          IBLNERF_NORMAL_INFERRED ("inferred_normal_map", :372-373: the composited output of the
+                                          normal_mlp uploaded as IBLNERF_AUX_NORMAL, used as it is; no offset queries) */
     int32_t color_independent_to_direction; /* 0 (shipped) | 1: networks built with is_color_independent_to_direction
                                           (ibl_nerf.py:192): radiance heads read the trunk output, no feature / view layers */
     int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
@@ -70,7 +72,8 @@ typedef struct {
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
-enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2 };
+enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
+       IBLNERF_NORMAL_INFERRED = 3 };
 
 void iblnerf_default_options(iblnerf_options* o);
 
@@ -101,9 +104,11 @@ int iblnerf_upload_weights_device(iblnerf_ctx* ctx, void* stream, int which, con
  * samples before compositing (an irradiance_mlp's always through sigmoid).  One upload per output channel: h_blob is an
  * IBLNeRF-schema blob whose positions_linears.* are the auxiliary network's and whose sigma_linear.{weight,bias} is row
  * `channel` of its out_linears (the other tensors are not read).  kind: IBLNERF_AUX_ALBEDO (channels 0..2),
- * IBLNERF_AUX_ROUGHNESS, IBLNERF_AUX_IRRADIANCE (channel 0).  The network takes effect in iblnerf_render_rays once all its
+ * IBLNERF_AUX_ROUGHNESS, IBLNERF_AUX_IRRADIANCE (channel 0), IBLNERF_AUX_NORMAL (channels 0..2: the normal_mlp of infer_normal,
+ * ibl_nerf.py:307-310; its samples 2 sigmoid(.) - 1 are composited into maps.inferred_normal_map, ibl_nerf_renderer.py:267-276,
+ * the per-sample form only: infer_normal_at_surface is not built).  The network takes effect in iblnerf_render_rays once all its
  * channels are uploaded, for both passes, until iblnerf_clear_aux.  Cost: one trunk evaluation per sample and channel. */
-enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE = 2 };
+enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE = 2, IBLNERF_AUX_NORMAL = 3 };
 int iblnerf_upload_aux_weights(iblnerf_ctx* ctx, int kind, int channel, const float* h_blob, size_t n_floats);
 int iblnerf_clear_aux(iblnerf_ctx* ctx, int kind);
 
@@ -184,6 +189,7 @@ typedef struct {
     float* depth_map;                       /* [n] */
     float* target_depth_map;                /* [n] */
     float* weights;                         /* [n, S]  (S = n_samples coarse, n_samples+n_importance fine) */
+    float* inferred_normal_map;             /* [n,3]; written only while an IBLNERF_AUX_NORMAL network is loaded (infer_normal) */
 } iblnerf_maps;
 
 typedef struct {

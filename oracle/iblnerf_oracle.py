@@ -343,8 +343,15 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         irr = gt["irradiance"][:, :3].astype(F32).copy()                                    # :329-330
     rad = [np.sum(w[..., None] * radiance_f(raw[..., 6 + 3 * k:9 + 3 * k]), -2, dtype=F32) for k in range(4)]
 
+    inferred_normal = None
+    if flags.get("infer_normal", False):                                                    # :267-276 (per-sample form)
+        if flags.get("infer_normal_at_surface", False):
+            raise NotImplementedError("infer_normal_at_surface")
+        inferred_normal = np.sum(w[..., None] * (F32(2) * sigmoid(position_mlp_query(aux["normal_mlp"], pts)) - F32(1)), -2, dtype=F32)
     nmode = flags.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
-    if nmode == "ground_truth":
+    if nmode == "inferred_normal_map":
+        normal = inferred_normal.copy()                                                     # :372-373, used as it is
+    elif nmode == "ground_truth":
         normal = normalize(F32(2) * gt["normal"] - F32(1))                                  # :370-371
     elif nmode == "normal_map_from_depth_gradient_epsilon":
         normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
@@ -419,6 +426,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
         "specular_map": g(specular), "diffuse_map": g(diffuse), "n_dot_v_map": ndv,
         "target_normal_map": normal, "disp_map": disp, "acc_map": acc, "depth_map": depth,
         "target_depth_map": tdepth, "weights": w})
+    if inferred_normal is not None:
+        res["inferred_normal_map"] = inferred_normal                                        # :517
     return res
 
 

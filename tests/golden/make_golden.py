@@ -51,7 +51,7 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False):
+def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False, infer_normal=False):
     """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
@@ -59,7 +59,7 @@ def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
         color_independent_to_direction=color_independent, use_illumination_feature_layer=False,
         use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
-        infer_normal=False, infer_normal_at_surface=False, infer_albedo_separate=aux,
+        infer_normal=infer_normal, infer_normal_at_surface=False, infer_albedo_separate=aux,
         infer_roughness_separate=aux, infer_irradiance_separate=aux, use_environment_map=False,
         N_envmap_size=16, lrate=5e-4, lrate_env_map=5e-4, basedir=tmp, expname="exp", ft_path=None,
         target_load_N_iter=-1, no_reload=True, perturb=1.0, use_viewdirs=True, white_bkgd=False,
@@ -119,7 +119,7 @@ class Recorder:
 
         def q(inputs, viewdirs, fn):
             out = self._q0(inputs, viewdirs, fn)
-            if any(fn is kw.get(a) for a in ("albedo_mlp", "roughness_mlp", "irradiance_mlp")):
+            if any(fn is kw.get(a) for a in ("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp")):
                 return out                       # auxiliary-network queries are not stage boundaries of the main network
             n = inputs.shape[0]
             if viewdirs is None:  # eps-normal query: 4 stacked copies of the ray set
@@ -172,10 +172,10 @@ class Recorder:
 
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
-                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False):
+                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
@@ -189,6 +189,11 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
             aux_seeds[aux_name] = 100 * seed + j
             sd_a = ck.synthetic_position_mlp(aux_seeds[aux_name], ck.AUX_OUT_CH[aux_name], gain)
             kw[aux_name].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
+    if infer_normal:  # normal_mlp: a PositionMLP with three outputs (ibl_nerf.py:307-310)
+        aux_seeds["normal_mlp"] = 100 * seed + 3
+        sd_a = ck.synthetic_position_mlp(aux_seeds["normal_mlp"], 3, gain)
+        kw["normal_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
+        assert kw["infer_normal"] is True
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
     kw.update(flags or {})            # flag variants outside the shipped configs
@@ -271,6 +276,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
                mode=np.array(mode))
     for k, v in (flags or {}).items():
         out["flag__" + k] = np.asarray(v)
+    if infer_normal:
+        out["flag__infer_normal"] = np.asarray(True)
     if color_independent:
         out["model__color_independent_to_direction"] = np.asarray(True)
     for aux_name, sd_seed in aux_seeds.items():
@@ -286,7 +293,7 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
     # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
     passes = ["c", "f"] if n_importance > 0 else ["c"]
-    gt_normals = (flags or {}).get("target_normal_map_for_radiance_calculation") == "ground_truth"
+    gt_normals = (flags or {}).get("target_normal_map_for_radiance_calculation") in ("ground_truth", "inferred_normal_map")
     nq = 2 if gt_normals else 3                          # no eps-normal query in the ground-truth normal mode
     for pi, p in enumerate(passes):
         qs = rec.q[nq * pi:nq * pi + nq]
@@ -432,6 +439,10 @@ def main(only=None):
     run_fixture("auxmlp_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=12, aux=True)
     run_fixture("auxmlp_lin_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=13, aux=True,
                 flags=dict(use_radiance_linear=True))
+    # infer_normal: the normal_mlp's composited output as an extra map beside the eps-normal, and as the target normal
+    run_fixture("infernormal_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=14, infer_normal=True)
+    run_fixture("infernormal_target_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=15, infer_normal=True,
+                flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map"))
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

@@ -529,3 +529,32 @@ def test_create_iblnerf_auxiliary_networks_drop_in(R, lut, tmp_path):
                         aux={k: v for k, v in aux.items() if k != "albedo_mlp"})
     assert rel_linf(ret2["albedo_map"][:8], ref["albedo_map"]) <= 2e-4 and rel_linf(ret2["roughness_map"][:8], ref["roughness_map"]) <= 2e-4
     assert rel_linf(ret2["albedo_map"], g["out__albedo_map"]) > 1e-2 and n == 48
+
+
+def test_infer_normal_drop_in(R, lut, tmp_path):
+    """infer_normal: create_IBLNeRF builds the normal_mlp (ibl_nerf.py:307-310, checkpoint entry 'normal_mlp'), render_decomp
+    returns its composited output as inferred_normal_map (ibl_nerf_renderer.py:267-276) and, with
+    target_normal_map_for_radiance_calculation="inferred_normal_map", shades with it without any offset query."""
+    import os
+    from ibl_nerf_amd import checkpoint as ck, model as M
+    g, sdc, sdf, _, _ = load_golden("infernormal_target_g10")
+    os.makedirs(tmp_path / "exp")
+    ck.save_checkpoint(str(tmp_path / "exp" / "000001.tar"), 1, sdc, sdf, aux=golden_aux(g))
+    _, kw, *_ = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), no_reload=False, infer_normal=True,
+                                                 calculating_normal_type="inferred_normal_map"))
+    assert kw["infer_normal"] is True and kw["target_normal_map_for_radiance_calculation"] == "inferred_normal_map"
+    kw.update(near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut), max_rays_per_launch=32)
+    rays = torch.from_numpy(np.stack([g["rays_o"], g["rays_d"]], 0))
+    r = R.renderer_for(kw)
+    r.set_profiling(True)
+    ret = to_np(R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw))
+    n_launch = r.last_mlp_time()[1]
+    r.set_profiling(False)
+    assert n_launch == 2 * 2 * (1 + 3 + 1)            # 2 launches x (coarse, fine) x (main + 3 normal channels + reflected)
+    assert list(ret).index("inferred_normal_map") == list(ret).index("target_normal_map") - 1      # reference's key order
+    assert np.array_equal(ret["inferred_normal_map"], ret["target_normal_map"])
+    for k in ("inferred_normal_map", "inferred_normal_map0", "n_dot_v_map", "color_map"):
+        assert rel_linf(ret[k], g["out__" + k]) <= 2e-4, k
+    kw["infer_normal"] = False                          # the mode without its network: the reference dies on a None normal
+    with pytest.raises(Exception):
+        R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)

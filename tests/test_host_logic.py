@@ -414,7 +414,10 @@ def test_checkpoint_roundtrip_and_discovery():
                   "target_normal_map_for_radiance_calculation", "correct_depth_for_prefiltered_radiance_infer"):
             assert k in test
     with pytest.raises(NotImplementedError):
-        M.create_IBLNeRF(M.default_args(infer_normal=True))
+        M.create_IBLNeRF(M.default_args(infer_depth=True))                       # a PositionDirectionMLP: not built
+    with tempfile.TemporaryDirectory() as d2:
+        os.makedirs(os.path.join(d2, "exp"))
+        assert M.create_IBLNeRF(M.default_args(basedir=d2, infer_normal=True))[1]["normal_mlp"].out_ch == 3
     with pytest.raises(NotImplementedError):
         M.IBLNeRF(W=128)
 
@@ -427,7 +430,10 @@ def test_unsupported_flags_raise():
     R._check_supported(dict(base, calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,
                             calculate_irradiance_from_gt=True, depth_map_from_ground_truth=True))
     R._check_supported(dict(base, white_bkgd=True, retraw=True, use_environment_map=True))   # dead flags in the reference too
-    for k in ("infer_normal", "infer_depth", "infer_normal_at_surface"):
+    with pytest.raises(TypeError):
+        R._check_supported(dict(base, infer_normal=True))                          # needs the normal_mlp kwarg
+    R._check_supported(dict(base, infer_normal=True, normal_mlp=object(), target_normal_map_for_radiance_calculation="inferred_normal_map"))
+    for k in ("infer_depth", "infer_normal_at_surface"):
         with pytest.raises(NotImplementedError):
             R._check_supported(dict(base, **{k: True}))
     with pytest.raises(ValueError):
