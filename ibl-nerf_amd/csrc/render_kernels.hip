@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         tdepth = ov.depth_img[(long)r * ov.depth_stride];
         if (ov.gt_depth == nullptr) depth = tdepth;
     }
-    const float disp = 1.0f / fmaxf(1e-10f, depth / acc);   // :258
+    // :258 torch.max(1e-10, depth / acc): a NaN quotient (an empty ray: 0 / 0) stays NaN, unlike fmaxf
+    const float dq = depth / acc;
+    const float disp = 1.0f / (dq != dq ? dq : fmaxf(1e-10f, dq));
     float xs[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) xs[c] = o[c] + d[c] * tdepth;   // :262

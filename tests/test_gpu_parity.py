@@ -558,3 +558,31 @@ def test_infer_normal_drop_in(R, lut, tmp_path):
     kw["infer_normal"] = False                          # the mode without its network: the reference dies on a None normal
     with pytest.raises(Exception):
         R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_degenerate_density_rays_match_the_oracle(R, lut, prec):
+    """Rays the reference's arithmetic degenerates on: an empty volume (every sigma <= 0: weights 0, acc 0, depth/acc = 0/0, so
+    disp_map is NaN through torch.max, ibl_nerf_renderer.py:258; flat fine-sample pdf) and a wall at the first sample (sigma
+    huge: all weight on sample 0).  Same NaN pattern and the same finite values as the oracle."""
+    from ibl_nerf_amd import checkpoint as ck
+    g, _, _, _, _ = load_golden("plain_g10")
+    ro, rd = g["rays_o"][:24], g["rays_d"][:24]
+    for bias in (-60.0, 400.0):
+        sdc, sdf = ck.synthetic_state_dict(21, 1.0, sigma_bias=bias), ck.synthetic_state_dict(22, 1.0, sigma_bias=bias)
+        r = R.Renderer(64, 128, max_rays_per_launch=16, mlp_precision=prec)
+        r.load_weights(0, sdc)
+        r.load_weights(1, sdf)
+        r.load_lut(lut)
+        got = to_np(r.render_rays(ro, rd, 0.5, 8.0))
+        ref = O.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut)
+        for k in ref:
+            assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), (bias, k)
+            ok = ~np.isnan(ref[k])
+            if k in ("disp_map", "disp_map0"):
+                ok &= np.abs(ref[k]) < 1e9                      # 1 / max(1e-10, .) of a vanishing depth: compare where it is a depth
+            assert np.abs(got[k][ok] - ref[k][ok]).max(initial=0.0) <= 2e-4 * max(1.0, np.abs(ref[k][ok]).max(initial=0.0)), (bias, k)
+        if bias < 0:
+            assert np.isnan(ref["disp_map"]).all() and not ref["acc_map"].any()
+        else:
+            assert np.allclose(ref["weights"][:, 0], 1.0) and np.allclose(ref["depth_map"], 0.5)
