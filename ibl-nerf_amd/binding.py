@@ -31,7 +31,7 @@ class Options(C.Structure):
                 ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
                 ("max_rays_per_launch", C.c_int32), ("device", C.c_int32), ("lindisp", C.c_int32),
                 ("use_radiance_linear", C.c_int32), ("normal_mode", C.c_int32), ("color_independent_to_direction", C.c_int32), ("mlp_precision", C.c_int32),
-                ("epsilon_direction", C.c_float)]
+                ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32)]
 
 
 MLP_BF16X3, MLP_F16_MXFP6 = 0, 1

@@ -87,6 +87,7 @@ void iblnerf_default_options(iblnerf_options* o) {
     o->n_importance = 128;
     o->epsilon = 0.01f;
     o->epsilon_direction = 0.005f;
+    o->infer_normal_at_surface = 0;
     o->gamma_correct = 1;
     o->lut_coefficient_f0 = 0;
     o->correct_depth_for_prefiltered_radiance = 1;
@@ -441,8 +442,12 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             if (rc) return rc;
         }
     const bool inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED;
-    for (int ch = 0; c->aux_on[IBLNERF_AUX_NORMAL] && ch < 3; ++ch) {   // normal_mlp at the same points (:273)
-        rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3);
+    const bool at_surface = c->opt.infer_normal_at_surface != 0;
+    if (c->aux_on[IBLNERF_AUX_NORMAL] && at_surface)      // one point per ray: x_surface (:262, :268-271); refl_o is free until pass A
+        HIP_TRY(c, launch_surface_points(ro, rd, z, z_stride, c->raw, R, S, ov, c->refl_o, s));
+    for (int ch = 0; c->aux_on[IBLNERF_AUX_NORMAL] && ch < 3; ++ch) {   // normal_mlp at the surface point or at every sample (:273)
+        rc = at_surface ? run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->refl_o, nullptr, 1, R, c->nrm_raw + ch, 3)
+                        : run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3);
         if (rc) return rc;
     }
     // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
@@ -460,6 +465,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
     a.nrm_raw = c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr;
     a.normal_inferred = inferred ? 1 : 0;
+    a.nrm_at_surface = at_surface ? 1 : 0;
     a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
     a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.radiance_linear = c->opt.use_radiance_linear;

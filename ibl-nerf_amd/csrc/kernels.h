@@ -100,6 +100,7 @@ struct PassAArgs {
     const float* raw;                           // [R,S,18]
     const float* sig4;                          // [4,R,S]
     const float* nrm_raw;                       // [R,S,3] normal_mlp samples or null (ibl_nerf_renderer.py:273-276)
+    int nrm_at_surface;                         // nrm_raw is [R,3]: one evaluation per ray at the surface point (:268-271)
     int normal_inferred;                        // target normal = the composited normal_mlp output, as it is (:372-373)
     float* weights;                             // [R,S] (always written: sample_pdf input / output map)
     const float* lut;                           // [3,512,512]
@@ -117,6 +118,12 @@ struct PassAArgs {
 hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma_correct, hipStream_t s);
 
 // coarse pass of the inference-minimum mode: compositing weights only (ibl_nerf_renderer.py:203-206, 241-245)
+// Surface points x = o + d * target_depth of R rays from the main query's raw rows (ibl_nerf_renderer.py:249-262), the same
+// arithmetic as pass A: the input of a normal_mlp evaluated at the surface (:268-271).
+struct OverrideArgs;
+hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, long R, int S,
+                                 const OverrideArgs& ov, float* surf, hipStream_t s);
+
 hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, long R, int S,
                                 float* weights, hipStream_t s);
 

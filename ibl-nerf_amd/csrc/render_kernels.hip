@@ -203,6 +203,18 @@ __device__ __forceinline__ void store3(float* p, long r, const float (&v)[3], in
     if (p) { p[3 * r] = out_map(v[0], g); p[3 * r + 1] = out_map(v[1], g); p[3 * r + 2] = out_map(v[2], g); }
 }
 
+// target_depth_map IS depth_map (one tensor, ibl_nerf_renderer.py:250) unless depth_map_from_ground_truth replaces it
+// (:251-252): an edited depth (:253-256) shows in depth_map / disp / the mip level only in the aliased case.
+__device__ __forceinline__ float target_depth(const OverrideArgs& ov, long r, bool mask_all, float& depth) {
+    float tdepth = depth;
+    if (ov.gt_depth != nullptr) tdepth = ov.gt_depth[r];
+    if (mask_all && ((ov.mode == 1 && ov.edit_depth) || ov.mode == 2)) {
+        tdepth = ov.depth_img[(long)r * ov.depth_stride];
+        if (ov.gt_depth == nullptr) depth = tdepth;
+    }
+    return tdepth;
+}
+
 // State record handed from pass A to pass B (floats): 0-2 albedo, 3 rough, 4 / 12 / 13 irradiance (r, g, b), 5-7 fresnel,
 // 8-10 specular coefficient, 11 mip level.
 
@@ -252,7 +264,10 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
 
     // inferred normal (:273-276): sum_s w_s (2 sigmoid(normal_mlp(x_s)) - 1), not normalised
     float inf[3] = {0.f, 0.f, 0.f};
-    if (a.nrm_raw != nullptr) {
+    if (a.nrm_raw != nullptr && a.nrm_at_surface) {   // one evaluation at the surface point (:268-271)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) inf[c] = 2.0f * sigmoidf_(a.nrm_raw[3 * r + c]) - 1.0f;
+    } else if (a.nrm_raw != nullptr) {
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int s = lane * NPL + i;
@@ -301,14 +316,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     }
     // object q <=> 9(q+1)/255 < m < 11(q+1)/255
     auto in_obj = [&](int q) { return (float)(11 * (q + 1) / 255.) > m && m > (float)(9 * (q + 1) / 255.); };
-    // target_depth_map IS depth_map (one tensor, :250) unless depth_map_from_ground_truth replaces it (:251-252): an edited
-    // depth shows in depth_map / disp / the mip level only in the aliased case
-    float tdepth = depth;
-    if (ov.gt_depth != nullptr) tdepth = ov.gt_depth[r];
-    if (mask_all && ((ov.mode == 1 && ov.edit_depth) || ov.mode == 2)) {   // :253-256
-        tdepth = ov.depth_img[(long)r * ov.depth_stride];
-        if (ov.gt_depth == nullptr) depth = tdepth;
-    }
+    const float tdepth = target_depth(ov, r, mask_all, depth);
     // :258 torch.max(1e-10, depth / acc): a NaN quotient (an empty ray: 0 / 0) stays NaN, unlike fmaxf
     const float dq = depth / acc;
     const float disp = 1.0f / (dq != dq ? dq : fmaxf(1e-10f, dq));
@@ -526,6 +534,37 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
     }
 }
 
+template <int NPL>
+__global__ __launch_bounds__(256) void k_surface_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ zbase, int z_stride, const float* __restrict__ raw,
+                                                       long R, int S, OverrideArgs ov, float* __restrict__ surf) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zbase + (long)z_stride * r;
+    float z[NPL], zn[NPL], sig[NPL], w[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
+        sig[i] = s < S ? raw[(r * S + s) * RAW_CH] : 0.0f;
+    }
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+    float depth = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+        if (lane * NPL + i < S) depth += w[i] * z[i];
+    depth = wave_sum(depth);
+    const bool mask_all = ov.mode != 0 && ov.mask[r * ov.mask_stride] > 0.0f;
+    const float tdepth = target_depth(ov, r, mask_all, depth);
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) surf[3 * r + c] = rays_o[3 * r + c] + d[c] * tdepth;   // :262
+}
+
 // sample_pdf(det=True), nerf_renderer_helper.py:91-134, for one ray held by one wavefront.
 // cdf/bins live in LDS (nb <= 257).  Writes n_out samples to `dst` (LDS or global).
 template <class Dst>
@@ -687,6 +726,15 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
         hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, R, S, weights);
+    });
+}
+
+hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, long R, int S,
+                                 const OverrideArgs& ov, float* surf, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((R + 3) / 4));
+    return by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL(k_surface_points<decltype(N)::value>, grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, raw, R, S, ov, surf);
     });
 }
 

@@ -54,7 +54,7 @@ class Renderer:
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
-                 epsilon_direction=0.005):
+                 epsilon_direction=0.005, infer_normal_at_surface=False):
         """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
         rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
         activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
@@ -75,6 +75,7 @@ class Renderer:
         o.n_samples, o.n_importance = int(N_samples), int(N_importance)
         o.epsilon = float(epsilon)
         o.epsilon_direction = float(epsilon_direction)
+        o.infer_normal_at_surface = int(bool(infer_normal_at_surface))
         o.gamma_correct = int(bool(gamma_correct))
         o.lut_coefficient_f0 = int(lut_coefficient == "F0")
         o.correct_depth_for_prefiltered_radiance = int(bool(correct_depth_for_prefiltered_radiance_infer))
@@ -93,7 +94,8 @@ class Renderer:
                           correct_depth_for_prefiltered_radiance_infer=correct_depth_for_prefiltered_radiance_infer,
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
                           lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode,
-                          color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction)
+                          color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction,
+                          infer_normal_at_surface=infer_normal_at_surface)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
@@ -381,7 +383,7 @@ class Renderer:
 # ---------------------------------------------------------------------------------------------
 # reference-signature functions
 # ---------------------------------------------------------------------------------------------
-_UNSUPPORTED_TRUE = ["infer_normal_at_surface", "infer_depth"]
+_UNSUPPORTED_TRUE = ["infer_depth"]
 # white_bkgd, retraw and use_environment_map are accepted and ignored, as in the reference: render_rays takes the first two and
 # never reads them (ibl_nerf_renderer.py:629-630), and the environment map is created (ibl_nerf.py:331-334) but no renderer code uses it
 # raw2outputs flags that swap a network map for its gt_values row (ibl_nerf_renderer.py:251-252, :320-330)
@@ -442,7 +444,8 @@ def renderer_for(kw):
            bool(kw.get("lindisp", False)), bool(kw.get("use_radiance_linear", False)),
            kw.get("mlp_precision") or DEFAULT_MLP_PRECISION,
            kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"),
-           bool(getattr(net_c, "is_color_independent_to_direction", False)), float(kw.get("epsilon_direction", 0.005)))
+           bool(getattr(net_c, "is_color_independent_to_direction", False)), float(kw.get("epsilon_direction", 0.005)),
+           bool(kw.get("infer_normal") and kw.get("infer_normal_at_surface")))
     if net_f is not None and bool(getattr(net_f, "is_color_independent_to_direction", False)) != key[13]:
         raise ValueError("network_fn and network_fine disagree on is_color_independent_to_direction")
     ent = _renderers.get(key)
@@ -452,7 +455,7 @@ def renderer_for(kw):
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
                      max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12],
-                     color_independent_to_direction=key[13], epsilon_direction=key[14])
+                     color_independent_to_direction=key[13], epsilon_direction=key[14], infer_normal_at_surface=key[15])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None, "aux": {}}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

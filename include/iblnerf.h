@@ -70,6 +70,8 @@ typedef struct {
                                                                 beyond that runs on the bf16x3 kernel by itself) */
     float epsilon_direction;           /* epsilon_direction_for_numerical_normal (0.005): tilt of the four rays of
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
+    int32_t infer_normal_at_surface;   /* 0 | 1: the IBLNERF_AUX_NORMAL network is evaluated once per ray at the surface point
+                                          o + d * target_depth instead of at every sample (ibl_nerf_renderer.py:268-271) */
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
@@ -106,7 +108,7 @@ int iblnerf_upload_weights_device(iblnerf_ctx* ctx, void* stream, int which, con
  * `channel` of its out_linears (the other tensors are not read).  kind: IBLNERF_AUX_ALBEDO (channels 0..2),
  * IBLNERF_AUX_ROUGHNESS, IBLNERF_AUX_IRRADIANCE (channel 0), IBLNERF_AUX_NORMAL (channels 0..2: the normal_mlp of infer_normal,
  * ibl_nerf.py:307-310; its samples 2 sigmoid(.) - 1 are composited into maps.inferred_normal_map, ibl_nerf_renderer.py:267-276,
- * the per-sample form only: infer_normal_at_surface is not built).  The network takes effect in iblnerf_render_rays once all its
+ * or, with options.infer_normal_at_surface, evaluated at the surface point).  The network takes effect in iblnerf_render_rays once all its
  * channels are uploaded, for both passes, until iblnerf_clear_aux.  Cost: one trunk evaluation per sample and channel. */
 enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE = 2, IBLNERF_AUX_NORMAL = 3 };
 int iblnerf_upload_aux_weights(iblnerf_ctx* ctx, int kind, int channel, const float* h_blob, size_t n_floats);

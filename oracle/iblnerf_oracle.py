@@ -345,9 +345,10 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
 
     inferred_normal = None
     if flags.get("infer_normal", False):                                                    # :267-276 (per-sample form)
-        if flags.get("infer_normal_at_surface", False):
-            raise NotImplementedError("infer_normal_at_surface")
-        inferred_normal = np.sum(w[..., None] * (F32(2) * sigmoid(position_mlp_query(aux["normal_mlp"], pts)) - F32(1)), -2, dtype=F32)
+        if flags.get("infer_normal_at_surface", False):                                     # :268-271: one query at x_surface
+            inferred_normal = (F32(2) * sigmoid(position_mlp_query(aux["normal_mlp"], x_surface[:, None, :])[:, 0]) - F32(1)).astype(F32)
+        else:
+            inferred_normal = np.sum(w[..., None] * (F32(2) * sigmoid(position_mlp_query(aux["normal_mlp"], pts)) - F32(1)), -2, dtype=F32)
     nmode = flags.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
     if nmode == "inferred_normal_map":
         normal = inferred_normal.copy()                                                     # :372-373, used as it is

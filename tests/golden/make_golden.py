@@ -443,6 +443,9 @@ def main(only=None):
     run_fixture("infernormal_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=14, infer_normal=True)
     run_fixture("infernormal_target_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=15, infer_normal=True,
                 flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map"))
+    # ... evaluated once per ray at the surface point, under an edited depth (the surface point follows the edit)
+    run_fixture("infernormal_surface_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=16, infer_normal=True,
+                mode="edit2", flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map", infer_normal_at_surface=True))
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

@@ -433,7 +433,8 @@ def test_unsupported_flags_raise():
     with pytest.raises(TypeError):
         R._check_supported(dict(base, infer_normal=True))                          # needs the normal_mlp kwarg
     R._check_supported(dict(base, infer_normal=True, normal_mlp=object(), target_normal_map_for_radiance_calculation="inferred_normal_map"))
-    for k in ("infer_depth", "infer_normal_at_surface"):
+    R._check_supported(dict(base, infer_normal=True, infer_normal_at_surface=True, normal_mlp=object()))
+    for k in ("infer_depth",):
         with pytest.raises(NotImplementedError):
             R._check_supported(dict(base, **{k: True}))
     with pytest.raises(ValueError):
