@@ -122,6 +122,9 @@ struct Pipe {
 #ifdef IBL_MX_ABLATE_NO_LOADS   // timing ablation only (results are garbage): no weight traffic
         return;
 #endif
+#ifdef IBL_MX_ABLATE_HALF_LOADS  // timing ablation only (results are garbage): every other piece of the weight stream
+        if constexpr (I % 2 == 1) return;
+#endif
         const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
         const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + (I / 4) * 4096;
         const unsigned v = voff + (I / 4) * 4096;
@@ -155,6 +158,8 @@ struct Pipe {
         prog2 = 2;
 #ifdef IBL_MX_DOUBLE_DMA
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#elif defined(IBL_MX_ABLATE_HALF_LOADS)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 #else
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
 #endif
@@ -171,6 +176,8 @@ struct Pipe {
     // lgkmcnt(0) measured no faster: 12.78 vs 12.77 ms on the TRUNK benchmark.)
 #ifdef IBL_MX_DOUBLE_DMA
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#elif defined(IBL_MX_ABLATE_HALF_LOADS)
+    __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #elif defined(IBL_MX_ABLATE_NO_BARRIER)   // timing ablation only (racy)
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
 #else
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     __syncthreads();
     const float* ltab = tabs + h * 16;
 
-#ifdef IBL_MX_ABLATE_NO_LOADS
+#if defined(IBL_MX_ABLATE_NO_LOADS) || defined(IBL_MX_ABLATE_HALF_LOADS)
     for (int i = threadIdx.x; i < LDS_RING_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
 #endif
