@@ -97,6 +97,7 @@ def render_frame_sharded(render_tile: Callable[[int, int], Dict[str, "object"]],
         rank, world = 0, 1
     row0, n = tile_rows(H, rank, world)
     maps = render_tile(row0, n)
+    keys = list(keys) + [k for k in ("inferred_normal_map",) if k in maps and k not in keys]   # present under infer_normal only
     buf, layout = pack_maps(maps, keys, n, W)
     full = buf if world == 1 else all_gather_frame(buf, H, W, group)
     return unpack_maps(full, layout)
