@@ -586,3 +586,38 @@ def test_degenerate_density_rays_match_the_oracle(R, lut, prec):
             assert np.isnan(ref["disp_map"]).all() and not ref["acc_map"].any()
         else:
             assert np.allclose(ref["weights"][:, 0], 1.0) and np.allclose(ref["depth_map"], 0.5)
+
+
+def test_c_abi_rejects_misuse(R, lut):
+    """Error behaviour of the boundary: every misuse comes back as a negative status with a message, never a crash."""
+    import ctypes as C
+    from ibl_nerf_amd import binding as B, checkpoint as ck
+    lib = B.load_library()
+    o = B.default_options()
+    o.normal_mode = 7
+    ctx = C.c_void_p()
+    assert lib.iblnerf_create(C.byref(o), C.byref(ctx)) == -1 and b"normal_mode" in lib.iblnerf_last_error(None)
+    r = R.Renderer(64, 128, max_rays_per_launch=8, normal_mode="inferred_normal_map")
+    blob = ck.state_dict_to_blob(ck.synthetic_state_dict(0))
+    r.load_weights(0, blob)
+    r.load_weights(1, blob)
+    r.load_lut(lut)
+    with pytest.raises(B.IblNerfError, match="normal_mlp"):                    # the mode without its network
+        r.render_rays(np.zeros((2, 3), np.float32), np.array([[0, 0, -1.0]] * 2, np.float32), 0.5, 8.0)
+    assert lib.iblnerf_upload_aux_weights(r.ctx, 9, 0, blob.ctypes.data, blob.size) == -1
+    assert lib.iblnerf_upload_aux_weights(r.ctx, 1, 1, blob.ctypes.data, blob.size) == -1      # roughness_mlp has one channel
+    assert lib.iblnerf_upload_aux_weights(r.ctx, 0, 0, blob.ctypes.data, blob.size - 1) == -1  # wrong blob length
+    assert lib.iblnerf_clear_aux(r.ctx, -1) == -1
+    assert lib.iblnerf_upload_weights(r.ctx, 2, blob.ctypes.data, blob.size) == -1
+    fresh = R.Renderer(64, 0, max_rays_per_launch=8)
+    with pytest.raises(B.IblNerfError):                                         # weights / LUT not uploaded: IBLNERF_ERR_STATE
+        fresh.render_rays(np.zeros((1, 3), np.float32), np.array([[0, 0, -1.0]], np.float32), 0.5, 8.0)
+    ov = B.Overrides()
+    ov.mode = 3
+    outs = B.Outputs()
+    z = torch.zeros((1, 3), device="cuda")
+    r2 = R.Renderer(64, 0, max_rays_per_launch=8)
+    r2.load_weights(0, blob)
+    r2.load_lut(lut)
+    assert lib.iblnerf_render_rays(r2.ctx, None, z.data_ptr(), z.data_ptr(), 1, 0.5, 8.0, C.byref(ov), C.byref(outs)) == -1
+    assert b"mode" in lib.iblnerf_last_error(r2.ctx)
