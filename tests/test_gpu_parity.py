@@ -621,3 +621,30 @@ def test_c_abi_rejects_misuse(R, lut):
     r2.load_lut(lut)
     assert lib.iblnerf_render_rays(r2.ctx, None, z.data_ptr(), z.data_ptr(), 1, 0.5, 8.0, C.byref(ov), C.byref(outs)) == -1
     assert b"mode" in lib.iblnerf_last_error(r2.ctx)
+
+
+@pytest.mark.parametrize("seed,gain", [(31, 1.0), (32, 1.25)])
+def test_unseen_checkpoints_vs_oracle(R, lut, seed, gain):
+    """Checkpoints and rays that no fixture holds (guards against tuning to the committed vectors): a posed camera's rays
+    through seeded networks, default kernel, every map against the oracle at the fixture tolerances."""
+    from ibl_nerf_amd import checkpoint as ck
+    sdc, sdf = ck.synthetic_state_dict(2 * seed, gain), ck.synthetic_state_dict(2 * seed + 1, gain)
+    rs = np.random.RandomState(seed)
+    K = np.array([[692.82, 0, 400], [0, 692.82, 400], [0, 0, 1]], dtype=np.float32)
+    q, _ = np.linalg.qr(np.eye(3) + 0.2 * rs.randn(3, 3))
+    c2w = np.concatenate([q * np.sign(np.linalg.det(q)), rs.uniform(-0.3, 0.3, (3, 1))], 1).astype(np.float32)
+    ro, rd = O.get_rays(800, 800, K, c2w)
+    pix = rs.choice(640000, 40, replace=False)
+    ro, rd = ro.reshape(-1, 3)[pix], rd.reshape(-1, 3)[pix]
+    r = R.Renderer(64, 128, max_rays_per_launch=16)
+    r.load_weights(0, sdc)
+    r.load_weights(1, sdf)
+    r.load_lut(lut)
+    got = to_np(r.render_rays(ro, rd, 0.5, 8.0))
+    ref = O.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut)
+    assert sorted(got) == sorted(ref) and r.range_fallbacks == 0
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(got[k + sfx], ref[k + sfx]) <= 2e-4, (k + sfx, rel_linf(got[k + sfx], ref[k + sfx]))
+        for k in DERIVED:
+            assert rel_linf(got[k + sfx], ref[k + sfx]) <= (1e-3 if gain == 1.0 else 5e-2), (k + sfx, rel_linf(got[k + sfx], ref[k + sfx]))
