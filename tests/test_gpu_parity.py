@@ -648,3 +648,25 @@ def test_unseen_checkpoints_vs_oracle(R, lut, seed, gain):
             assert rel_linf(got[k + sfx], ref[k + sfx]) <= 2e-4, (k + sfx, rel_linf(got[k + sfx], ref[k + sfx]))
         for k in DERIVED:
             assert rel_linf(got[k + sfx], ref[k + sfx]) <= (1e-3 if gain == 1.0 else 5e-2), (k + sfx, rel_linf(got[k + sfx], ref[k + sfx]))
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys (one step of the real workload, no CPU baseline leg)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "rays/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 0.67
+    assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d                       # that leg (and its PSNR check against the oracle) was switched off
