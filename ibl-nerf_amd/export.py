@@ -89,9 +89,15 @@ def render_decomp_path(dataset_test, hwf, K, chunk, render_kwargs, savedir=None,
     `export_workers` threads while the next view renders; every file is on disk when this returns.
     `export_workers=0` writes inline like the reference.  `views` (iterable of view indices, default all)
     restricts the loop to this process's share of the views (`dist.view_indices`); file names keep the
-    global view index."""
+    global view index.  With the default `render_fn` the coarse pass only evaluates density (`coarse_outputs=False`): no
+    exported map comes from it and the exported ones do not change by a bit."""
     from concurrent.futures import ThreadPoolExecutor
-    render_fn = render_fn or R.render_decomp
+    if render_fn is None:
+        render_fn = R.render_decomp
+        # every exported map is a last-pass map (append_result reads un-suffixed keys only, :870-900), and those are
+        # bit-identical without the coarse pass's own maps: skip them (a quarter of a view's time) unless the caller says otherwise
+        if "coarse_outputs" not in render_kwargs and "coarse_outputs" not in kwargs:
+            kwargs = dict(kwargs, coarse_outputs=False)
     pool = ThreadPoolExecutor(max_workers=export_workers) if (savedir is not None and export_workers > 0) else None
     pending = []
     H, W, focal = hwf
