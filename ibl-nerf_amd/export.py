@@ -99,26 +99,28 @@ def render_decomp_path(dataset_test, hwf, K, chunk, render_kwargs, savedir=None,
         if "coarse_outputs" not in render_kwargs and "coarse_outputs" not in kwargs:
             kwargs = dict(kwargs, coarse_outputs=False)
     pool = ThreadPoolExecutor(max_workers=export_workers) if (savedir is not None and export_workers > 0) else None
-    pending = []
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]]).astype(np.float32)   # :832-836 (K argument is rebuilt)
     results = {}
 
+    def finish(key_name, out_name, index, img):
+        """append_result's host side (ibl_nerf_renderer.py:846-858): value mapping, 8-bit PNG."""
+        img = map_for_export(key_name, out_name, img, dataset_test.far)
+        if savedir is not None:
+            write_png(os.path.join(savedir, (out_name + "_{:03d}.png").format(index)), to8b(img))
+        return img
+
     def append_result(res_i, key_name, index, out_name):
         if key_name not in res_i or res_i[key_name] is None:
             return
         img = res_i[key_name]
         img = img.detach().cpu().numpy() if hasattr(img, "detach") else np.asarray(img)
-        img = map_for_export(key_name, out_name, img, dataset_test.far)
-        results.setdefault(out_name, []).append(img)
-        if savedir is not None:
-            path = os.path.join(savedir, (out_name + "_{:03d}.png").format(index))
-            if pool is not None:
-                pending.append(pool.submit(lambda p=path, a=img: write_png(p, to8b(a))))
-            else:
-                write_png(path, to8b(img))
+        if pool is not None:             # mapping and encoding overlap the next view's render
+            results.setdefault(out_name, []).append(pool.submit(finish, key_name, out_name, index, img))
+        else:
+            results.setdefault(out_name, []).append(finish(key_name, out_name, index, img))
 
     if savedir is not None:
         os.makedirs(savedir, exist_ok=True)
@@ -136,13 +138,17 @@ def render_decomp_path(dataset_test, hwf, K, chunk, render_kwargs, savedir=None,
                 d = res_i["depth_map"]
                 d = d.detach().cpu().numpy() if hasattr(d, "detach") else np.asarray(d)
                 c = c2w34.detach().cpu().numpy() if hasattr(c2w34, "detach") else np.asarray(c2w34)
-                res_i["normal_map_from_depth_map"] = depth_to_normal_image_space(d, c, K)
-                append_result(res_i, "normal_map_from_depth_map", i, "normal_from_depth")
+                if pool is not None:
+                    results.setdefault("normal_from_depth", []).append(pool.submit(
+                        lambda d=d, c=c, i=i: finish("normal_map_from_depth_map", "normal_from_depth", i, depth_to_normal_image_space(d, c, K))))
+                else:
+                    res_i["normal_map_from_depth_map"] = depth_to_normal_image_space(d, c, K)
+                    append_result(res_i, "normal_map_from_depth_map", i, "normal_from_depth")
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
-    for f in pending:
-        f.result()                       # re-raise a failed write
+    if pool is not None:                 # .result() re-raises a failed mapping / write
+        results = {k: [f.result() for f in v] for k, v in results.items()}
     return {k: np.stack(v, 0) for k, v in results.items()}
 
 
