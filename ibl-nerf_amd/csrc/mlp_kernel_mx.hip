@@ -336,7 +336,11 @@ struct Epi {
             if constexpr (I == 7 && (T & 1) == 1) finish_block(dst->b[T >> 1], lres, mxv, *peak);
         }
 #pragma unroll
+#ifdef IBL_MX_ABLATE_NO_HEADS   // timing ablation only (results are garbage): no head dot products
+        for (int c = 0; c < 0; ++c) {
+#else
         for (int c = 0; c < NCH; ++c) {
+#endif
             const f32x2 w = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
             *part[c] = fmaf(x1, w[1], fmaf(x0, w[0], *part[c]));
             if constexpr (I == 7) pin(*part[c]);
