@@ -292,7 +292,7 @@ __device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mx
 template <bool STORE, bool RELU, int NCH>
 struct Epi {
     Act* dst;
-    float* part[NCH > 0 ? NCH : 1];
+    f32x2* part[NCH > 0 ? NCH : 1];   // per head channel: two interleaved partial sums (even / odd element of each pair), one v_pk_fma_f32 per pair
     const float* tab[NCH > 0 ? NCH : 1];
     unsigned* peak;
     u32x16 lres;
@@ -300,6 +300,7 @@ struct Epi {
     int mxv;   // running block max as the int image of a non-negative float (ordering is the same; one v_max3_i32 per pair)
 
     float sx0, sx1;   // the slice in flight between its two stages
+    f32x2 hw[NCH > 0 ? NCH : 1];   // ... and its head weights: read from LDS in stage A so that stage B never waits for them
 
     template <int T, int I>
     __device__ __forceinline__ void stage_a(const f32x16& acc) {
@@ -319,6 +320,8 @@ struct Epi {
         sx1 = x1;
         pin(sx0);
         pin(sx1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) hw[c] = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
     }
     template <int T, int I>
     __device__ __forceinline__ void stage_b() {
@@ -341,9 +344,8 @@ struct Epi {
 #else
         for (int c = 0; c < NCH; ++c) {
 #endif
-            const f32x2 w = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
-            *part[c] = fmaf(x1, w[1], fmaf(x0, w[0], *part[c]));
-            if constexpr (I == 7) pin(*part[c]);
+            *part[c] = __builtin_elementwise_fma(f32x2{x0, x1}, hw[c], *part[c]);
+            if constexpr (I == 7) asm volatile("" : "+v"(*part[c]));
         }
     }
     template <int T, int I, int K>
@@ -519,9 +521,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         }
 
         Act A, B;
-        float part[RAW_CH];
+        f32x2 part[RAW_CH];
 #pragma unroll
-        for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
+        for (int c = 0; c < RAW_CH; ++c) part[c] = f32x2{0.0f, 0.0f};
         const float* bias = ltab + TAB_BIAS;
         auto none = [](auto, auto) {};
         auto flush = [&](auto& e, auto T, const f32x16& acc) {
@@ -606,12 +608,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 
         const float* sc = tabs + TAB_SCALAR;
         if constexpr (VARIANT == VAR_TRUNK) {
-            const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
+            const float p0 = part[0][0] + part[0][1];
+            const float s = p0 + __shfl_xor(p0, 32) + sc[0];
             if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
         } else {
             float tot[RAW_CH];
 #pragma unroll
-            for (int c = 0; c < RAW_CH; ++c) tot[c] = part[c] + __shfl_xor(part[c], 32) + sc[c];
+            for (int c = 0; c < RAW_CH; ++c) {
+                const float pc = part[c][0] + part[c][1];
+                tot[c] = pc + __shfl_xor(pc, 32) + sc[c];
+            }
             if (valid) {
                 if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + p * RAW_CH;
