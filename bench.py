@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mlp-precision", choices=["f16_mxfp6", "bf16x3"], default="f16_mxfp6",
+    ap.add_argument("--mlp-precision", choices=["f16_mxfp6", "f16_mixed", "bf16x3"], default="f16_mxfp6",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision)")
     args = ap.parse_args()
 
@@ -223,6 +223,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": ("f16 + 2x MX-fp6 residual products, fp32 accumulate (fp32 operands to ~2^-16)" if args.mlp_precision == "f16_mxfp6"
+                      else "f16 + 2x MX-fp6 residual products for the sample-placing and normal queries, plain f16 for the others, fp32 accumulate" if args.mlp_precision == "f16_mixed"
                       else "bf16x3 (bf16 hi/lo split, 3 MFMA products, fp32 accumulate)"),
             "data": "synthetic (seeded checkpoint in the reference state-dict schema, synthetic pinhole camera)",
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
@@ -233,11 +234,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch (reads x2-corrected + writes) from %s; points in + raw outputs out, weights stay in L2" % traffic_src,
-                         "kernel": ("ibl::mxk::mlp_kernel" if args.mlp_precision == "f16_mxfp6" else "ibl::mlp_kernel") + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
+                         "kernel": ("ibl::mxk::mlp_kernel" if args.mlp_precision == "f16_mxfp6" else "ibl::mxk::mlp_kernel + ibl::mxk16::mlp_kernel" if args.mlp_precision == "f16_mixed" else "ibl::mlp_kernel") + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
                          "range_fallbacks": r.range_fallbacks,
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues "
                                  + ("1 f16 + 2 block-scaled fp6 MFMA products (= 1.5 bf16-rate products)" if args.mlp_precision == "f16_mxfp6"
+                                    else "1 f16 + 2 block-scaled fp6 MFMA products in the coarse main and offset queries, 1 f16 product in the fine main and reflected queries" if args.mlp_precision == "f16_mixed"
                                     else "3 bf16 MFMA products")},
         }
         if value_min is not None:

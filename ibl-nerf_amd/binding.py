@@ -34,7 +34,7 @@ class Options(C.Structure):
                 ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32)]
 
 
-MLP_BF16X3, MLP_F16_MXFP6 = 0, 1
+MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED = 0, 1, 2
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 

@@ -35,6 +35,10 @@ SOURCES = [
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=0"], "mlp_kernel_mx16_full"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=2"], "mlp_kernel_mx16_refl"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=3"], "mlp_kernel_mx16_full_ci"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=4"], "mlp_kernel_mx16_refl_ci"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("api.cpp", ["-x", "hip"]),

@@ -139,8 +139,9 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6) {
-        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0) or IBLNERF_MLP_F16_MXFP6 (1)";
+    if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6 &&
+        opts->mlp_precision != IBLNERF_MLP_F16_MIXED) {
+        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), IBLNERF_MLP_F16_MXFP6 (1) or IBLNERF_MLP_F16_MIXED (2)";
         return IBLNERF_ERR_INVALID;
     }
     if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
@@ -185,7 +186,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             iblnerf_destroy(c);
             return IBLNERF_ERR_NOMEM;
         }
-    if (opts->mlp_precision == IBLNERF_MLP_F16_MXFP6) {
+    if (opts->mlp_precision != IBLNERF_MLP_BF16X3) {
         bool ok = hipMalloc((void**)&c->d_range_flag, sizeof(unsigned)) == hipSuccess &&
                   hipMemset(c->d_range_flag, 0, sizeof(unsigned)) == hipSuccess;
         for (int w = 0; w < 2 && ok; ++w)
@@ -233,7 +234,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     pack_network(h_blob, stream.data(), tab.data());
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, hipDeviceSynchronize());   // a previous render may still be reading the old stream
-    const bool want_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6;
+    const bool want_mx = c->opt.mlp_precision != IBLNERF_MLP_BF16X3;
     if (!c->d_stream[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream[slot], STREAM_BYTES));          // auxiliary slots: first use
     if (!c->d_tables[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_tables[slot], TAB_BYTES));
     if (want_mx && !c->d_stream_mx[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream_mx[slot], mx::STREAM_BYTES));
@@ -330,11 +331,16 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
 }
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out, int out_stride = 1) {
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, bool plain_f16 = false) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
-    const bool use_mx = c->opt.mlp_precision == IBLNERF_MLP_F16_MXFP6 && c->mx_ok[which];
+    const bool use_mx = c->opt.mlp_precision != IBLNERF_MLP_BF16X3 && c->mx_ok[which];
+    // IBLNERF_MLP_F16_MIXED: queries that neither place samples nor feed the finite-difference normal run in plain f16
+    // (not with HDR radiance, whose unbounded ReLU passes the raw error through, nor when the surface point of the main query is
+    // the input of a normal_mlp)
+    const bool use_mx16 = use_mx && plain_f16 && c->opt.mlp_precision == IBLNERF_MLP_F16_MIXED && variant != VAR_TRUNK &&
+                          !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface);
     a.stream = use_mx ? c->d_stream_mx[which] : c->d_stream[which];
     a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];
@@ -355,7 +361,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
-    HIP_TRY(c, use_mx ? launch_mlp_mx(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
+    HIP_TRY(c, use_mx16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : use_mx ? launch_mlp_mx(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     c->flop_alg += (double)n_pts * (variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
@@ -428,11 +434,12 @@ static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S, int irr_ch 
 // One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
-                     const PassOutputs& out) {
+                     const PassOutputs& out, bool places_samples) {
     const int Sc = c->Sc;
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
-    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw);
+    // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
+    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, !places_samples);
     if (rc) return rc;
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
     // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
@@ -473,7 +480,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, c->zc, 0, 0.f, R, Sc, c->pts, s));
-    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw);
+    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, true);
     if (rc) return rc;
     PassBArgs b;
     b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = Sc;
@@ -553,12 +560,12 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         }
         int rc;
         if (!fine) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch));
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false);
             if (rc) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch));
+            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true);
             if (rc) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, c->zc, 0, 0.f, R, Sc, c->pts, s));
@@ -567,7 +574,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
             HIP_TRY(c, launch_sigma_weights(rd, c->zc, 0, c->sig4, R, Sc, c->w_c, s));
         }
         HIP_TRY(c, launch_fine_z(c->zc, Sc, c->w_c, R, c->opt.n_importance, c->z_fine, outs->z_std ? outs->z_std + r0 : nullptr, s));
-        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch));
+        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false);
         if (rc) return rc;
     }
     return IBLNERF_OK;

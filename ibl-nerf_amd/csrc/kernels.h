@@ -21,6 +21,7 @@ struct MlpArgs {
 };
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
+hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
 
 // --- device-side weight packer (pack_kernels.hip): blob in HBM -> both weight streams + side tables ---------------
 struct PackMaps {                 // device copies of pack.cpp's build_pack_maps()

@@ -17,7 +17,18 @@
 #include "sincos_enc.h"
 
 namespace ibl {
-namespace mxk {
+// -DIBL_MX_F16ONLY builds the plain-f16 flavour of this kernel (namespace mxk16, launch_mlp_mx16): per block only the four f16
+// MFMAs, no residual forms in the epilogue, only the f16 half of the weight stream.  2^-11 per operand: enough for every query
+// that neither places samples nor feeds the finite-difference normal (the fine pass's main query, the reflected-ray queries;
+// scratch/prec_probe_f16f8.py, mode "f16+fp6|f16_only|keepcoarse"), not for the others.
+#ifdef IBL_MX_F16ONLY
+#define IBL_MXK mxk16
+constexpr bool F16O = true;
+#else
+#define IBL_MXK mxk
+constexpr bool F16O = false;
+#endif
+namespace IBL_MXK {
 
 using namespace ibl::mx;
 
@@ -125,6 +136,7 @@ struct Pipe {
 #ifdef IBL_MX_ABLATE_HALF_LOADS  // timing ablation only (results are garbage): every other piece of the weight stream
         if constexpr (I % 2 == 1) return;
 #endif
+        if constexpr (F16O && I >= 4) return;   // pieces 4..7 of a wave are the fp6 half of its block
         const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
         const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + (I / 4) * 4096;
         const unsigned v = voff + (I / 4) * 4096;
@@ -158,7 +170,7 @@ struct Pipe {
         prog2 = 2;
 #ifdef IBL_MX_DOUBLE_DMA
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-#elif defined(IBL_MX_ABLATE_HALF_LOADS)
+#elif defined(IBL_MX_ABLATE_HALF_LOADS) || defined(IBL_MX_F16ONLY)
         asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 #else
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
@@ -176,7 +188,7 @@ struct Pipe {
     // lgkmcnt(0) measured no faster: 12.78 vs 12.77 ms on the TRUNK benchmark.)
 #ifdef IBL_MX_DOUBLE_DMA
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#elif defined(IBL_MX_ABLATE_HALF_LOADS)
+#elif defined(IBL_MX_ABLATE_HALF_LOADS) || defined(IBL_MX_F16ONLY)
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #elif defined(IBL_MX_ABLATE_NO_BARRIER)   // timing ablation only (racy)
     __device__ __forceinline__ void sync_next() const { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
@@ -196,6 +208,7 @@ template <int KIND, int E>
 __device__ __forceinline__ void load_frag(Pre& pf, const char* blk, int lane) {
     if constexpr (KIND < 4) {
         pf.q[E] = *reinterpret_cast<const u32x4*>(blk + OFF_F16 + KIND * 1024 + lane * 16);
+    } else if constexpr (F16O) {
     } else if constexpr (KIND == 4) {
         pf.q[E] = *reinterpret_cast<const u32x4*>(blk + OFF_W6A + lane * 16);
         pf.d[E] = *reinterpret_cast<const u32x2*>(blk + OFF_W6B + lane * 8);
@@ -241,6 +254,8 @@ template <int S>
 __device__ __forceinline__ f32x16 slot_mfma(const u32x4& aq, const u32x2& ad, unsigned wsc, const Blk& b, f32x16 c) {
     if constexpr (S < 4) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq), __builtin_bit_cast(f16x8, quarter<S>(b.hv)), c, 0, 0, 0);
+    } else if constexpr (F16O) {     // plain-f16 flavour: the two residual slots are empty
+        return c;
     } else if constexpr (S == 4) {   // fp6(W) [scale byte 0] x fp6(X - f16 X) [scale byte 1]
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(aq, ad), fp6_operand<true>(b.l6a, b.l6b), c, 2, 2, 0, (int)wsc, 1, (int)b.sc);
     } else {                         // fp6(W - f16 W) [scale byte 1] x fp6(f16 X) [scale byte 0]
@@ -258,6 +273,10 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hb, unsigned& lb) {
     const f32x2 xv = {x0, x1};
     hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));
+    if constexpr (F16O) {
+        lb = 0;
+        return;
+    }
     // residuals x - (float)h, rounded to f16 and written straight into the low / high half of one register:
     // v_fma_mix{lo,hi}_f16 read the f16 half of h directly (plain C++ costs cvt + sub + cvt_pk per pair)
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(x0), "v"(hb));
@@ -270,6 +289,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hb, uns
 __device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mxv, unsigned& peak) {
     unsigned mb = (unsigned)mxv;
     peak = mb > peak ? mb : peak;
+    if constexpr (F16O) {       // plain-f16 flavour: only the range guard needs the block max
+        mxv = 0;
+        return;
+    }
     mb = mb > 0x0d800000u ? mb : 0x0d800000u;          // >= 2^-100: an all-zero block gets a harmless tiny scale
     const unsigned e = mb >> 23;                        // biased exponent of the block max
     const float sh = __builtin_bit_cast(float, (e - 2) << 23);    // max / sh in [4, 8)
@@ -382,7 +405,7 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             constexpr int G = t * NS + g;            // slot inside the layer
             constexpr int cr = G % CHUNK_SLOTS;      // slot inside the chunk
             constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
-            if constexpr (s == 4) wsc = pf.sc[G % 4];
+            if constexpr (s == 4 && !F16O) wsc = pf.sc[G % 4];
             if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
             else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
 #ifdef IBL_MX_DOUBLE_MFMA   // measurement only (results are garbage): every matrix instruction twice
@@ -647,7 +670,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     if (a.range_flag != nullptr && peak >= 0x477ff000u) atomicOr(a.range_flag, 1u);
 }
 
-}  // namespace mxk
+}  // namespace mxk / mxk16
 
 // The three instantiations are compiled as three objects (build.py passes -DIBL_MX_VARIANT=0|1|2) so that they
 // build side by side; the object for VAR_FULL also carries the dispatcher.  Without the macro (scratch/mxdev.sh
@@ -656,53 +679,62 @@ template <int VARIANT>
 static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mxk::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)IBL_MXK::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(mxk::mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(IBL_MXK::mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
+#ifdef IBL_MX_F16ONLY
+#define IBL_L(x) launch_mlp_mx16_##x
+#define IBL_DISPATCH launch_mlp_mx16
+#else
+#define IBL_L(x) launch_mlp_mx_##x
+#define IBL_DISPATCH launch_mlp_mx
+#endif
 #if defined(IBL_MX_VARIANT)
 #if IBL_MX_VARIANT == 0
-hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
+hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 1
-hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
 #elif IBL_MX_VARIANT == 2
-hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 3
-hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
+hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 #else
-hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
+hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
 #endif
 #else
-hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
 #ifndef IBL_MX_DEV_TRUNK_ONLY
-hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
-hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
-hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
-hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
+hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
+hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
+hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
 #endif
 #endif
 
 #if !defined(IBL_MX_VARIANT) || IBL_MX_VARIANT == 0
-hipError_t launch_mlp_mx_full(const MlpArgs& a, int grid, hipStream_t s);
-hipError_t launch_mlp_mx_trunk(const MlpArgs& a, int grid, hipStream_t s);
-hipError_t launch_mlp_mx_refl(const MlpArgs& a, int grid, hipStream_t s);
-hipError_t launch_mlp_mx_full_ci(const MlpArgs& a, int grid, hipStream_t s);
-hipError_t launch_mlp_mx_refl_ci(const MlpArgs& a, int grid, hipStream_t s);
-hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
+hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
     const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
     switch (variant) {
 #ifndef IBL_MX_DEV_TRUNK_ONLY
-        case VAR_FULL: return launch_mlp_mx_full(a, grid, stream);
-        case VAR_REFL: return launch_mlp_mx_refl(a, grid, stream);
-        case VAR_FULL_CI: return launch_mlp_mx_full_ci(a, grid, stream);
-        case VAR_REFL_CI: return launch_mlp_mx_refl_ci(a, grid, stream);
+        case VAR_FULL: return IBL_L(full)(a, grid, stream);
+        case VAR_REFL: return IBL_L(refl)(a, grid, stream);
+        case VAR_FULL_CI: return IBL_L(full_ci)(a, grid, stream);
+        case VAR_REFL_CI: return IBL_L(refl_ci)(a, grid, stream);
 #endif
-        case VAR_TRUNK: return launch_mlp_mx_trunk(a, grid, stream);
+#ifndef IBL_MX_F16ONLY          // the trunk-only evaluation feeds the finite-difference normal: never in plain f16
+        case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

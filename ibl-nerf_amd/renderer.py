@@ -61,8 +61,8 @@ class Renderer:
         repeat the call on a bf16x3 context, so results never depend on the choice beyond round-off."""
         torch = _torch()
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
-        if mlp_precision not in ("bf16x3", "f16_mxfp6"):
-            raise ValueError("mlp_precision must be 'bf16x3' or 'f16_mxfp6'")
+        if mlp_precision not in ("bf16x3", "f16_mxfp6", "f16_mixed"):
+            raise ValueError("mlp_precision must be 'bf16x3', 'f16_mxfp6' or 'f16_mixed'")
         if normal_mode not in NORMAL_MODES:
             raise ValueError(normal_mode)                                          # ibl_nerf_renderer.py:374-375
         if not torch.cuda.is_available():
@@ -84,7 +84,7 @@ class Renderer:
         o.device = self.device.index
         o.lindisp = int(bool(lindisp))
         o.use_radiance_linear = int(bool(use_radiance_linear))
-        o.mlp_precision = B.MLP_F16_MXFP6 if mlp_precision == "f16_mxfp6" else B.MLP_BF16X3
+        o.mlp_precision = {"bf16x3": B.MLP_BF16X3, "f16_mxfp6": B.MLP_F16_MXFP6, "f16_mixed": B.MLP_F16_MIXED}[mlp_precision]
         o.normal_mode = NORMAL_MODES[normal_mode]
         o.color_independent_to_direction = int(bool(color_independent_to_direction))
         self.normal_mode = normal_mode
@@ -139,7 +139,7 @@ class Renderer:
                 blob = ck.state_dict_to_blob(blob)
             blob = np.ascontiguousarray(blob, dtype=np.float32)
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
-        if self.mlp_precision == "f16_mxfp6":
+        if self.mlp_precision != "bf16x3":
             self._blobs[int(which)] = blob
             if self._wide is not None:
                 self._wide.load_weights(which, blob)
@@ -169,14 +169,14 @@ class Renderer:
         if lut.shape != (3, 512, 512):
             raise ValueError("brdf_lut must have shape [3,512,512], got %s" % (lut.shape,))
         B.check(self.ctx, self.lib.iblnerf_upload_lut(self.ctx, lut.ctypes.data))
-        if self.mlp_precision == "f16_mxfp6":
+        if self.mlp_precision != "bf16x3":
             self._lut = lut
             if self._wide is not None:
                 self._wide.load_lut(lut)
 
     def out_of_range(self):
         """f16_mxfp6 only: True if an MLP launch since the last check left the f16 range (synchronises)."""
-        if self.mlp_precision != "f16_mxfp6":
+        if self.mlp_precision == "bf16x3":
             return False
         flag = C.c_int()
         B.check(self.ctx, self.lib.iblnerf_range_status(self.ctx, C.byref(flag)))

@@ -67,13 +67,18 @@ typedef struct {
                                           IBLNERF_MLP_F16_MXFP6 one f16 product + two block-scaled fp6 residual products,
                                                                 faster; inputs and activations must stay below 65504 —
                                                                 see iblnerf_range_status (a network with a weight
-                                                                beyond that runs on the bf16x3 kernel by itself) */
+                                                                beyond that runs on the bf16x3 kernel by itself)
+                                          IBLNERF_MLP_F16_MIXED as F16_MXFP6 for the queries that place samples or feed the
+                                                                finite-difference normal (coarse main query, offset queries);
+                                                                one plain f16 product for the others (fine main query,
+                                                                reflected-ray queries), whose 2^-11 per operand stays below
+                                                                1e-4 on every map */
     float epsilon_direction;           /* epsilon_direction_for_numerical_normal (0.005): tilt of the four rays of
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
     int32_t infer_normal_at_surface;   /* 0 | 1: the IBLNERF_AUX_NORMAL network is evaluated once per ray at the surface point
                                           o + d * target_depth instead of at every sample (ibl_nerf_renderer.py:268-271) */
 } iblnerf_options;
-enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1 };
+enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3 };
 

@@ -1,4 +1,5 @@
-"""Precision probe for the fp16-main + fp8-correction product scheme (NOT shipped):
+"""Precision probe for the fp16-main + low-precision-correction product schemes (f16+fp6 is the shipped one; the two
+five-slot variants f16W+fp6X / fp6W+f16X drop one residual product):
   y = f16(W)·f16(X)  +  fp8(Wh)·fp8(Xl) + fp8(Wl)·fp8(Xh)      (fp32 accumulate)
 with Xh = f16(X), Xl = X - Xh (|Xl| <= 2^-12 |X|), fp8 = e4m3 with an MX-style power-of-two scale per
 block of 32 K-elements (per weight row / per point).  Emulated in numpy on the oracle."""
@@ -49,6 +50,12 @@ def lin(sd, name, x):
         return (main + b).astype(np.float32)
     if MODE == "f16x3":
         return (main + Xl.astype(np.float64) @ Wh.T + Xh.astype(np.float64) @ f16(Wl).T + b).astype(np.float32)
+    if MODE == "f16W+fp6X":        # five slots: f16(W) f16(X) + fp6(W) fp6(X - f16 X); the weights only to f16 (a fixed perturbation)
+        q6 = lambda a: fp8_block(a, sig=4, emin=0, top=2, vmax=7.5)
+        return (main + q6(Xl) @ q6(Wh).T + b).astype(np.float32)
+    if MODE == "fp6W+f16X":        # five slots the other way: activations only to f16 (per-point noise)
+        q6 = lambda a: fp8_block(a, sig=4, emin=0, top=2, vmax=7.5)
+        return (main + q6(Xh) @ q6(Wl).T + b).astype(np.float32)
     fmt = {"f16+fp8": dict(sig=4, emin=-6, top=7, vmax=448.0),       # e4m3
            "f16+bf8": dict(sig=3, emin=-14, top=14, vmax=57344.0),   # e5m2
            "f16+fp6": dict(sig=4, emin=0, top=2, vmax=7.5),          # e2m3: block max in [4, 8)
@@ -58,12 +65,31 @@ def lin(sd, name, x):
     return (main + corr + b).astype(np.float32)
 
 O._lin = lin
+# hybrid modes "A|B": trunk-only queries (the eps-normal's offset points) in scheme A, queries with view directions (main, reflected) in B
+_nq = O.network_query
+def network_query(sd, pts, viewdirs):
+    global MODE
+    if "|" not in HYBRID:
+        return _nq(sd, pts, viewdirs)
+    global N_VIEW_QUERIES
+    parts = HYBRID.split("|")
+    if viewdirs is None:
+        MODE = parts[0]
+    else:                       # "A|B|keepcoarse": the coarse pass's main query (the first one with directions: it places the fine samples) stays in A
+        MODE = parts[0] if (len(parts) > 2 and N_VIEW_QUERIES == 0) else parts[1]
+        N_VIEW_QUERIES += 1
+    return _nq(sd, pts, viewdirs)
+O.network_query = network_query
+HYBRID = ""
+N_VIEW_QUERIES = 0
 name = sys.argv[1] if len(sys.argv) > 1 else "plain_g10"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f16+fp8", "f16+bf8", "f16+fp6", "f16+fp4"]
 g, sdc, sdf, gt, edit = load_golden(name)
 keys = ["albedo_map", "roughness_map", "irradiance_map", "radiance_map", "depth_map", "target_normal_map", "prefiltered_reflected_map", "specular_map", "color_map", "weights"]
 for MODE in modes:
+    HYBRID = MODE
+    N_VIEW_QUERIES = 0
     res = O.render_rays(sdc, sdf, g["rays_o"][:n], g["rays_d"][:n], float(g["near"]), float(g["far"]), lut, 64, int(g["n_importance"]),
                         {k: v[:n] for k, v in gt.items()} if gt else gt, edit, {}, golden_flags(g))
-    print("%-10s" % MODE, " ".join("%s=%.1e" % (k.replace("_map", ""), rel_linf(res[k], g["out__" + k][:n])) for k in keys), flush=True)
+    print("%-18s" % HYBRID, " ".join("%s=%.1e" % (k.replace("_map", ""), rel_linf(res[k], g["out__" + k][:n])) for k in keys), flush=True)

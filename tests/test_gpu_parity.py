@@ -130,7 +130,7 @@ def test_network_query_ragged_sizes_vs_oracle(R, lut, prec):
         assert np.abs(got_s - ref_s).max() <= 6e-5, (n_rays, S)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("prec", PRECISIONS + ["f16_mixed"])   # + plain f16 for the fine main and reflected queries
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
 def test_render_rays_vs_reference_golden(R, name, lut, prec):
     g, sdc, sdf, gt, edit = load_golden(name)
