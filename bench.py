@@ -146,10 +146,11 @@ def main():
         else:
             dist.init_process_group(backend)
         # bring the RCCL communicator (rings over xGMI) up before anything is timed, even with --warmup 0
-        probe = torch.zeros(world * 256, device="cuda")
-        dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
+        if backend == "nccl":
+            probe = torch.zeros(world * 256, device="cuda")
+            dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
+            del probe
         dist.barrier()
-        del probe
 
     pkg = _pkg.load()
     from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R
@@ -186,7 +187,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -17,7 +17,7 @@ EXPORTS = [
     "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
     "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
-    "iblnerf_upload_aux_weights", "iblnerf_clear_aux",
+    "iblnerf_upload_aux_weights", "iblnerf_clear_aux", "iblnerf_composite_pass", "iblnerf_range_peek",
 ]
 
 
@@ -60,6 +60,11 @@ class Maps(C.Structure):
                 ("target_depth_map", FP), ("weights", FP), ("inferred_normal_map", FP)]
 
 
+class StageInputs(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("d_z", FP), ("d_raw", FP), ("d_sigma_offsets", FP), ("d_refl_raw", FP),
+                ("d_normal_raw", FP), ("d_stage", FP), ("d_refl_o", FP), ("d_refl_d", FP)]
+
+
 class Outputs(C.Structure):
     _fields_ = [("fine", Maps), ("coarse", Maps), ("z_std", FP)]
 
@@ -89,6 +94,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_stream_bytes_mx.restype = C.c_size_t
     lib.iblnerf_pack_weights_host_mx.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.iblnerf_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.iblnerf_range_peek.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.iblnerf_range_peek.restype = C.c_int
     lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.restype = C.c_int
@@ -106,6 +113,9 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_sample_pdf.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP]
     lib.iblnerf_render_rays.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
                                         C.POINTER(Overrides), C.POINTER(Outputs)]
+    lib.iblnerf_composite_pass.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
+                                           C.POINTER(Overrides), C.POINTER(StageInputs), C.POINTER(Maps)]
+    lib.iblnerf_composite_pass.restype = C.c_int
     lib.iblnerf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_last_mlp_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     for n in ("iblnerf_create", "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host",

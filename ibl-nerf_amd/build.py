@@ -44,7 +44,20 @@ SOURCES = [
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
 ]
-HEADERS = ["layout.h", "layout_mx.h", "kernels.h", "pack.h", "sincos_enc.h", os.path.join("..", "..", "include", "iblnerf.h")]
+
+
+def _deps(path, seen=None):
+    """The source plus every local header it includes, transitively (`#include "..."`, relative to the including file)."""
+    import re
+    seen = seen if seen is not None else []
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.append(path)
+    with open(path) as f:
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', f.read(), re.M):
+            _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
 def _digest(paths, extra):
@@ -58,14 +71,13 @@ def _digest(paths, extra):
 def build(verbose=True, force=False):
     """Compile every source whose inputs changed, then link.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, relink, jobs = [], force or not os.path.exists(LIB), []
     for entry in SOURCES:
         src, flags = entry[0], entry[1]
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, (entry[2] if len(entry) > 2 else src) + ".o")
         stamp = op + ".sha"
-        dg = _digest([sp] + hdrs, COMMON + flags)
+        dg = _digest(_deps(sp), COMMON + flags)
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or old != dg or not os.path.exists(op):
             jobs.append(([HIPCC] + COMMON + flags + ["-c", sp, "-o", op], stamp, dg))

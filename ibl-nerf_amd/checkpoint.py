@@ -158,6 +158,12 @@ def find_checkpoint(basedir: str, expname: str, ft_path=None, target_load_N_iter
     return ckpts[-1] if ckpts else None
 
 
+def read_checkpoint(path: str):
+    """The raw dict of a reference `.tar` (torch.save, `train.py:180-191`), tensors on the CPU."""
+    import torch
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_checkpoint(path: str):
     """Read a reference `.tar` (torch.save dict, `train.py:180-191`).
 

@@ -27,7 +27,7 @@ constexpr double FLOP_FULL = 1591552.0, FLOP_TRUNK = 982528.0, FLOP_REFL = 14589
 constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // what is_color_independent_to_direction skips
 }  // namespace
 
-constexpr int N_SLOTS = 10, N_AUX = 4;
+constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
 constexpr int AUX_SLOT0[N_AUX] = {2, 5, 6, 7}, AUX_CHANNELS[N_AUX] = {3, 1, 1, 3}, AUX_RAW_COLUMN[3] = {1, 4, 5};
 
@@ -40,7 +40,11 @@ struct iblnerf_ctx {
     // (albedo r, g, b, roughness, irradiance), allocated on first upload
     char* d_stream[N_SLOTS] = {};
     char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
+    // [0] activation / input range flag of the MX kernels, [1 + slot] "a weight of this slot is outside the f16 range" (device packer)
     unsigned* d_range_flag = nullptr;
+    unsigned* h_range_flag = nullptr;            // pinned snapshot for iblnerf_range_peek
+    hipEvent_t flag_ev = nullptr;
+    bool flag_armed = false;
     bool mx_ok[N_SLOTS] = {true, true, true, true, true, true, true, true, true, true};
     unsigned short* d_map16 = nullptr;            // gather maps of the device packer (built on first use)
     int* d_map_mx = nullptr;
@@ -187,8 +191,11 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             return IBLNERF_ERR_NOMEM;
         }
     if (opts->mlp_precision != IBLNERF_MLP_BF16X3) {
-        bool ok = hipMalloc((void**)&c->d_range_flag, sizeof(unsigned)) == hipSuccess &&
-                  hipMemset(c->d_range_flag, 0, sizeof(unsigned)) == hipSuccess;
+        bool ok = hipMalloc((void**)&c->d_range_flag, N_FLAGS * sizeof(unsigned)) == hipSuccess &&
+                  hipMemset(c->d_range_flag, 0, N_FLAGS * sizeof(unsigned)) == hipSuccess &&
+                  hipHostMalloc((void**)&c->h_range_flag, N_FLAGS * sizeof(unsigned)) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->flag_ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) std::memset(c->h_range_flag, 0, N_FLAGS * sizeof(unsigned));
         for (int w = 0; w < 2 && ok; ++w)
             ok = hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess &&
                  hipMemset(c->d_stream_mx[w], 0, mx::STREAM_BYTES) == hipSuccess;
@@ -219,6 +226,8 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
     }
     if (c->d_range_flag) (void)hipFree(c->d_range_flag);
+    if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
+    if (c->flag_ev) (void)hipEventDestroy(c->flag_ev);
     if (c->d_map16) (void)hipFree(c->d_map16);
     if (c->d_map_mx) (void)hipFree(c->d_map_mx);
     if (c->d_map_tab) (void)hipFree(c->d_map_tab);
@@ -280,6 +289,15 @@ int iblnerf_clear_aux(iblnerf_ctx* c, int kind) {
     return IBLNERF_OK;
 }
 
+// Enqueues a copy of the range-flag words into pinned host memory behind everything launched so far on `s`, for iblnerf_range_peek.
+static int arm_range_snapshot(iblnerf_ctx* c, hipStream_t s) {
+    if (!c->d_range_flag) return IBLNERF_OK;
+    HIP_TRY(c, hipMemcpyAsync(c->h_range_flag, c->d_range_flag, N_FLAGS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->flag_ev, s));
+    c->flag_armed = true;
+    return IBLNERF_OK;
+}
+
 int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const float* d_blob, size_t n_floats) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (which < 0 || which > 1 || !d_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights_device: which must be 0/1, blob non-null");
@@ -298,11 +316,15 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
         HIP_TRY(c, hipMemcpy(c->d_map_tab, mtab.data(), mtab.size() * 4, hipMemcpyHostToDevice));
     }
     PackMaps maps{c->d_map16, c->d_map_mx, c->d_map_tab};
-    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_tables[which], c->d_range_flag,
+    // an out-of-range weight raises this slot's own flag; iblnerf_range_status / _peek report it and pin the slot to the bf16x3
+    // kernel until its next upload (the activation flag alone cannot be relied on: inf * 0 or -inf through a ReLU can hide it)
+    unsigned* wflag = c->d_range_flag ? c->d_range_flag + 1 + which : nullptr;
+    if (wflag) HIP_TRY(c, hipMemsetAsync(wflag, 0, sizeof(unsigned), (hipStream_t)stream));
+    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_tables[which], wflag,
                                    (hipStream_t)stream));
-    c->mx_ok[which] = true;                       // an out-of-range weight is reported through the range flag here
+    c->mx_ok[which] = true;
     c->have_net[which] = true;
-    return IBLNERF_OK;
+    return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
 int iblnerf_upload_lut(iblnerf_ctx* c, const float* h_rgb) {
@@ -375,8 +397,10 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
     if (n_rays == 0) return IBLNERF_OK;
     if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "network_query: weights of network %d not uploaded", which);
     HIP_TRY(c, hipSetDevice(c->opt.device));
-    return run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
-                   (long)n_rays * n_samples, d_out);
+    if (int rc = run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
+                         (long)n_rays * n_samples, d_out))
+        return rc;
+    return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
@@ -391,16 +415,37 @@ int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const 
     return IBLNERF_OK;
 }
 
+// Folds a snapshot of the flag words into the context: a flagged slot runs on the bf16x3 kernel from now on.
+static int fold_flags(iblnerf_ctx* c, const unsigned* v) {
+    int any = v[0] ? 1 : 0;
+    for (int slot = 0; slot < N_SLOTS; ++slot)
+        if (v[1 + slot]) { c->mx_ok[slot] = false; any = 1; }
+    return any;
+}
+
 int iblnerf_range_status(iblnerf_ctx* c, int* out_of_range) {
     if (!c || !out_of_range) return IBLNERF_ERR_INVALID;
     *out_of_range = 0;
     if (!c->d_range_flag) return IBLNERF_OK;
-    unsigned v = 0;
+    unsigned v[N_FLAGS] = {};
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(&v, c->d_range_flag, sizeof v, hipMemcpyDeviceToHost));
-    if (v) HIP_TRY(c, hipMemset(c->d_range_flag, 0, sizeof v));
-    *out_of_range = v ? 1 : 0;
+    HIP_TRY(c, hipMemcpy(v, c->d_range_flag, sizeof v, hipMemcpyDeviceToHost));
+    *out_of_range = fold_flags(c, v);
+    if (*out_of_range) HIP_TRY(c, hipMemset(c->d_range_flag, 0, sizeof v));
+    c->flag_armed = false;
+    return IBLNERF_OK;
+}
+
+int iblnerf_range_peek(iblnerf_ctx* c, int* out_of_range, int* pending) {
+    if (!c || !out_of_range || !pending) return IBLNERF_ERR_INVALID;
+    *out_of_range = 0;
+    *pending = 0;
+    if (!c->d_range_flag || !c->flag_armed) return IBLNERF_OK;
+    const hipError_t q = hipEventQuery(c->flag_ev);
+    if (q == hipErrorNotReady) { *pending = 1; return IBLNERF_OK; }
+    if (q != hipSuccess) return c->fail(IBLNERF_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+    *out_of_range = fold_flags(c, c->h_range_flag);
     return IBLNERF_OK;
 }
 
@@ -429,6 +474,27 @@ static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S, int irr_ch 
     o.weights = off(m.weights, S);
     o.inferred_normal = off(m.inferred_normal_map, 3);
     return o;
+}
+
+// Arguments of pass A as the context's options set them (shared by the render path and the teacher-forced stage entry).
+static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, long R, const float* z, int z_stride, int S,
+                             const float* raw, const float* sig4, const float* nrm_raw, float* weights, float near_, float far_,
+                             const OverrideArgs& ov) {
+    const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
+    PassAArgs a;
+    a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = raw; a.sig4 = sig4;
+    a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_;
+    a.eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
+    a.tilted_rays = tilt ? 1 : 0;
+    a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
+    a.nrm_raw = nrm_raw;
+    a.normal_inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED ? 1 : 0;
+    a.nrm_at_surface = c->opt.infer_normal_at_surface != 0 ? 1 : 0;
+    a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
+    a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
+    a.radiance_linear = c->opt.use_radiance_linear;
+    a.ov = ov; a.state = c->state; a.refl_o = c->refl_o; a.refl_d = c->refl_d; a.R = R; a.S = S;
+    return a;
 }
 
 // One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
@@ -466,17 +532,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
         if (rc) return rc;
     }
-    PassAArgs a;
-    a.rays_o = ro; a.rays_d = rd; a.z = z; a.z_stride = z_stride; a.raw = c->raw; a.sig4 = c->sig4;
-    a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_; a.eps = eps; a.tilted_rays = tilt ? 1 : 0;
-    a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
-    a.nrm_raw = c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr;
-    a.normal_inferred = inferred ? 1 : 0;
-    a.nrm_at_surface = at_surface ? 1 : 0;
-    a.lut_coefficient_F0 = c->opt.lut_coefficient_f0;
-    a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
-    a.radiance_linear = c->opt.use_radiance_linear;
-    a.ov = ov; a.state = c->state; a.refl_o = c->refl_o; a.refl_d = c->refl_d; a.R = R; a.S = S;
+    const PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
+                                    weights, near_, far_, ov);
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, c->zc, 0, 0.f, R, Sc, c->pts, s));
@@ -489,18 +546,10 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     return IBLNERF_OK;
 }
 
-int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
-                        float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_outputs* outs) {
-    if (!c) return IBLNERF_ERR_INVALID;
-    if (n_rays < 0 || !outs) return c->fail(IBLNERF_ERR_INVALID, "render_rays: negative ray count / null outputs");
-    if (n_rays == 0) return IBLNERF_OK;   // empty batch: torch hands out null data pointers for zero-row tensors
-    if (!d_rays_o || !d_rays_d) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays");
-    const bool fine = c->opt.n_importance > 0;
-    if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
-    if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");
-    const int fine_net = c->have_net[1] ? 1 : 0;   // run_fn = network_fn if network_fine is None (:705)
-    OverrideArgs ov;
+// Validates the caller's overrides (the reference's asserts at ibl_nerf_renderer.py:222, :232) and copies the scalar part.
+static int parse_overrides(iblnerf_ctx* c, const iblnerf_overrides* ovr, OverrideArgs& ov, const float*& gt_normal) {
     std::memset(&ov, 0, sizeof ov);
+    gt_normal = nullptr;
     if (ovr && ovr->mode != 0) {
         if (ovr->mode != 1 && ovr->mode != 2) return c->fail(IBLNERF_ERR_INVALID, "overrides.mode must be 0, 1 or 2");
         if (ovr->num_objects <= 0 || ovr->num_objects > 8)   // reference: assert num_*_objects > 0 (:222, :232)
@@ -522,7 +571,6 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         std::memcpy(ov.albedo_list, ovr->albedo_list, sizeof ov.albedo_list);
         std::memcpy(ov.irr_list, ovr->irradiance_list, sizeof ov.irr_list);
     }
-    const float* gt_normal = nullptr;
     if (c->opt.normal_mode == IBLNERF_NORMAL_GROUND_TRUTH) {
         if (!ovr || !ovr->d_gt_normal)
             return c->fail(IBLNERF_ERR_INVALID, "normal_mode ground_truth needs overrides.d_gt_normal (gt_values[\"normal\"] rows)");
@@ -530,6 +578,41 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
     }
     if (c->opt.normal_mode == IBLNERF_NORMAL_INFERRED && !c->aux_on[IBLNERF_AUX_NORMAL])
         return c->fail(IBLNERF_ERR_STATE, "normal_mode inferred needs a normal_mlp (iblnerf_upload_aux_weights, IBLNERF_AUX_NORMAL)");
+    return IBLNERF_OK;
+}
+
+// The image-row pointers of the overrides, advanced to ray r0 of the call.
+static OverrideArgs rows_from(const OverrideArgs& ov, const iblnerf_overrides* ovr, const float* gt_normal, long r0) {
+    OverrideArgs o = ov;
+    o.gt_normal = gt_normal ? gt_normal + 3 * r0 : nullptr;
+    if (ovr) {
+        o.gt_albedo = ovr->d_gt_albedo ? ovr->d_gt_albedo + 3 * r0 : nullptr;
+        o.gt_roughness = ovr->d_gt_roughness ? ovr->d_gt_roughness + r0 : nullptr;
+        o.gt_irradiance = ovr->d_gt_irradiance ? ovr->d_gt_irradiance + 3 * r0 : nullptr;
+        o.gt_depth = ovr->d_gt_depth ? ovr->d_gt_depth + r0 : nullptr;
+    }
+    if (o.mode) {
+        o.mask = ovr->d_mask + 3 * r0;
+        o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;
+        o.normal_img = ovr->d_normal ? ovr->d_normal + 3 * r0 : nullptr;
+        o.albedo_img = ovr->d_albedo ? ovr->d_albedo + 3 * r0 : nullptr;
+    }
+    return o;
+}
+
+int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                        float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_outputs* outs) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || !outs) return c->fail(IBLNERF_ERR_INVALID, "render_rays: negative ray count / null outputs");
+    if (n_rays == 0) return IBLNERF_OK;   // empty batch: torch hands out null data pointers for zero-row tensors
+    if (!d_rays_o || !d_rays_d) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays");
+    const bool fine = c->opt.n_importance > 0;
+    if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
+    if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");
+    const int fine_net = c->have_net[1] ? 1 : 0;   // run_fn = network_fn if network_fine is None (:705)
+    OverrideArgs ov;
+    const float* gt_normal = nullptr;
+    if (int rc = parse_overrides(c, ovr, ov, gt_normal)) return rc;
     const int irr_ch = (ovr && ovr->d_gt_irradiance) ? 3 : 1;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(c, hipSetDevice(c->opt.device));
@@ -544,20 +627,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         const long R = (n_rays - r0 < per_launch) ? n_rays - r0 : per_launch;
         const float* ro = d_rays_o + 3 * r0;
         const float* rd = d_rays_d + 3 * r0;
-        OverrideArgs o = ov;
-        o.gt_normal = gt_normal ? gt_normal + 3 * r0 : nullptr;
-        if (ovr) {
-            o.gt_albedo = ovr->d_gt_albedo ? ovr->d_gt_albedo + 3 * r0 : nullptr;
-            o.gt_roughness = ovr->d_gt_roughness ? ovr->d_gt_roughness + r0 : nullptr;
-            o.gt_irradiance = ovr->d_gt_irradiance ? ovr->d_gt_irradiance + 3 * r0 : nullptr;
-            o.gt_depth = ovr->d_gt_depth ? ovr->d_gt_depth + r0 : nullptr;
-        }
-        if (o.mode) {
-            o.mask = ovr->d_mask + 3 * r0;
-            o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;
-            o.normal_img = ovr->d_normal ? ovr->d_normal + 3 * r0 : nullptr;
-            o.albedo_img = ovr->d_albedo ? ovr->d_albedo + 3 * r0 : nullptr;
-        }
+        const OverrideArgs o = rows_from(ov, ovr, gt_normal, r0);
         int rc;
         if (!fine) {
             rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false);
@@ -577,6 +647,43 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false);
         if (rc) return rc;
     }
+    return arm_range_snapshot(c, s);
+}
+
+int iblnerf_composite_pass(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                           float far_, const iblnerf_overrides* ovr, const iblnerf_stage_inputs* in, const iblnerf_maps* maps) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || !in || !maps) return c->fail(IBLNERF_ERR_INVALID, "composite_pass: negative ray count / null inputs / null maps");
+    if (n_rays == 0) return IBLNERF_OK;
+    if (n_rays > c->ws_rays) return c->fail(IBLNERF_ERR_INVALID, "composite_pass: at most max_rays_per_launch (%ld) rays per call", c->ws_rays);
+    const int S = in->n_samples;
+    if (S < 1 || S > c->Smax) return c->fail(IBLNERF_ERR_INVALID, "composite_pass: n_samples must be in 1..%d", c->Smax);
+    if (!d_rays_o || !d_rays_d || !in->d_z || !in->d_raw || !in->d_refl_raw)
+        return c->fail(IBLNERF_ERR_INVALID, "composite_pass: rays, d_z, d_raw and d_refl_raw are required");
+    if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "composite_pass: brdf_lut not uploaded");
+    OverrideArgs ov;
+    const float* gt_normal = nullptr;
+    if (int rc = parse_overrides(c, ovr, ov, gt_normal)) return rc;
+    const bool offsets = !gt_normal && c->opt.normal_mode != IBLNERF_NORMAL_INFERRED;
+    if (offsets && !in->d_sigma_offsets) return c->fail(IBLNERF_ERR_INVALID, "composite_pass: this normal mode needs d_sigma_offsets");
+    if (c->opt.normal_mode == IBLNERF_NORMAL_INFERRED && !in->d_normal_raw)
+        return c->fail(IBLNERF_ERR_INVALID, "composite_pass: normal_mode inferred needs d_normal_raw");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_coarse_z(near_, far_, c->Sc, c->opt.lindisp, c->zc, s));
+    const OverrideArgs o = rows_from(ov, ovr, gt_normal, 0);
+    const int irr_ch = (ovr && ovr->d_gt_irradiance) ? 3 : 1;
+    const PassOutputs out = slice_maps(*maps, 0, S, irr_ch);
+    PassAArgs a = pass_a_args(c, d_rays_o, d_rays_d, n_rays, in->d_z, S, S, in->d_raw, in->d_sigma_offsets, in->d_normal_raw, c->w_f,
+                              near_, far_, o);
+    a.stage = in->d_stage;
+    HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
+    if (in->d_refl_o) HIP_TRY(c, hipMemcpyAsync(in->d_refl_o, c->refl_o, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (in->d_refl_d) HIP_TRY(c, hipMemcpyAsync(in->d_refl_d, c->refl_d, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    PassBArgs b;
+    b.state = c->state; b.refl_raw = in->d_refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = c->Sc;
+    b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = n_rays;
+    HIP_TRY(c, launch_pass_b(b, s));
     return IBLNERF_OK;
 }
 

@@ -4,24 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include "layout.h"
+#include "mlp_args.h"
 
 namespace ibl {
-
-struct MlpArgs {
-    const char* stream;   // packed weight stream of one network (STREAM_BYTES)
-    const float* tables;  // TAB_FLOATS floats
-    const float* pts;     // [n_pts,3]
-    const float* dirs;    // [n_pts / pts_per_ray, 3] view directions (null for VAR_TRUNK)
-    float* out;           // [n_pts,18] (FULL) | [n_pts] (TRUNK) | [n_pts,13] (REFL)
-    int out_stride = 1;   // VAR_TRUNK only: floats between consecutive points' outputs (an auxiliary network writes one
-                          // column of the main network's raw rows)
-    long n_pts;
-    int pts_per_ray;
-    unsigned* range_flag; // f16 + MX-fp6 variant only: set to 1 if an input or activation left the f16 range (may be null)
-};
-hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
-hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
-hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
 
 // --- device-side weight packer (pack_kernels.hip): blob in HBM -> both weight streams + side tables ---------------
 struct PackMaps {                 // device copies of pack.cpp's build_pack_maps()
@@ -114,8 +99,11 @@ struct PassAArgs {
     OverrideArgs ov;
     float* state;                               // [R, ST_FLOATS]
     float* refl_o; float* refl_d;               // [R,3] reflected-ray origin / direction
+    float* stage = nullptr;                     // optional [R, STAGE_FLOATS] stage boundaries (iblnerf_composite_pass): normal before the
+                                                // edit / insert overrides (3), LUT coordinates n.v and roughness (2), LUT scale and bias (2), mip level
     long R; int S;
 };
+constexpr int STAGE_FLOATS = 8;
 hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma_correct, hipStream_t s);
 
 // coarse pass of the inference-minimum mode: compositing weights only (ibl_nerf_renderer.py:203-206, 241-245)

@@ -1,0 +1,26 @@
+// Launch interface of the fused MLP kernels (mlp_kernel.hip, mlp_kernel_mx.hip).  Kept apart from kernels.h so that a change
+// to the per-ray kernels' interface does not recompile the MLP instantiations (minutes each).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace ibl {
+
+struct MlpArgs {
+    const char* stream;   // packed weight stream of one network (STREAM_BYTES)
+    const float* tables;  // TAB_FLOATS floats
+    const float* pts;     // [n_pts,3]
+    const float* dirs;    // [n_pts / pts_per_ray, 3] view directions (null for VAR_TRUNK)
+    float* out;           // [n_pts,18] (FULL) | [n_pts] (TRUNK) | [n_pts,13] (REFL)
+    int out_stride = 1;   // VAR_TRUNK only: floats between consecutive points' outputs (an auxiliary network writes one
+                          // column of the main network's raw rows)
+    long n_pts;
+    int pts_per_ray;
+    unsigned* range_flag; // f16 + MX-fp6 variant only: set to 1 if an input or activation left the f16 range (may be null)
+};
+hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
+hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
+hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
+
+}  // namespace ibl

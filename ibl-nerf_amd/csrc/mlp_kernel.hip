@@ -15,7 +15,7 @@
 #include <type_traits>
 
 #include "layout.h"
-#include "kernels.h"
+#include "mlp_args.h"
 #include "sincos_enc.h"
 
 namespace ibl {

@@ -12,7 +12,7 @@
 
 #include <type_traits>
 
-#include "kernels.h"
+#include "mlp_args.h"
 #include "layout_mx.h"
 #include "sincos_enc.h"
 

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         for (int c = 0; c < 3; ++c) nrm[c] = 2.0f * a.ov.gt_normal[3 * r + c] - 1.0f;
         normalize3(nrm);
     }
+    const float nrm_before[3] = {nrm[0], nrm[1], nrm[2]};   // stage boundary: what get_normal_from_depth_gradient_epsilon returned
 
     if (mask_all && ((ov.mode == 1 && ov.edit_normal) || ov.mode == 2)) {   // :380-382, :401-403
         float g[3];
@@ -438,6 +439,11 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         if (out.acc) out.acc[r] = acc;
         if (out.depth) out.depth[r] = depth;
         if (out.target_depth) out.target_depth[r] = tdepth;
+        if (a.stage != nullptr) {
+            float* sg = a.stage + r * STAGE_FLOATS;
+            sg[0] = nrm_before[0]; sg[1] = nrm_before[1]; sg[2] = nrm_before[2];
+            sg[3] = ndv; sg[4] = rough; sg[5] = e0; sg[6] = e1; sg[7] = level;
+        }
     }
 }
 
@@ -612,7 +618,7 @@ __device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, i
         int lo = 0, hi = nb;   // searchsorted(right=True): number of cdf entries <= u
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+            if (!(cdf[mid] > u)) lo = mid + 1; else hi = mid;   // ATen's upper bound: a NaN cdf (NaN density) sends the search right, the sample is NaN
         }
         const int below = lo - 1 < 0 ? 0 : lo - 1;
         const int above = lo > nb - 1 ? nb - 1 : lo;
@@ -664,13 +670,17 @@ __global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc, in
     }
     s2 = wave_sum_d(s2);
     if (lane == 0 && z_std) z_std[r] = (float)sqrt(s2 / n_imp);
-    // rank sort (values only; ties keep index order)
+    // rank sort (values only; ties keep index order; NaNs order after everything, as torch.sort places them, so that a
+    // poisoned ray gives a visibly NaN row instead of stale slots)
     for (int e = lane; e < n; e += 64) {
         const float v = vals[wv][e];
+        const bool vn = v != v;
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             const float u = vals[wv][j];
-            rank += (u < v || (u == v && j < e)) ? 1 : 0;
+            const bool un = u != u;
+            const bool before = (un || vn) ? ((!un && vn) || (un && vn && j < e)) : (u < v || (u == v && j < e));
+            rank += before ? 1 : 0;
         }
         z_fine[r * n + rank] = v;
     }

@@ -78,8 +78,14 @@ def all_gather_frame(local, H: int, W: int, group=None):
     if n < max_rows:   # equal-size contributions let RCCL run one flat all-gather
         padded = torch.zeros((max_rows, W, C), dtype=local.dtype, device=local.device)
         padded[:n] = local
-    gathered = torch.empty((world * max_rows, W, C), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # test hook (several ranks sharing one GPU, which RCCL refuses): gloo exchanges host buffers
+        staged = torch.empty((world * max_rows, W, C), dtype=local.dtype)
+        dist.all_gather_into_tensor(staged, padded.contiguous().cpu(), group=group)
+        gathered = staged.to(local.device)
+    else:
+        gathered = torch.empty((world * max_rows, W, C), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
     if H % world == 0:
         return gathered
     parts = [gathered[r * max_rows: r * max_rows + tile_rows(H, r, world)[1]] for r in range(world)]

@@ -90,7 +90,7 @@ def _query_renderer(network_fn):
     from . import renderer as R
     ent = _query_ctx.get(id(network_fn))
     if ent is None or ent["ref"]() is not network_fn:
-        ent = _query_ctx[id(network_fn)] = {"ref": weakref.ref(network_fn), "r": R.Renderer(64, 0, max_rays_per_launch=1, color_independent_to_direction=_ci(network_fn)), "w": None}
+        ent = _query_ctx[id(network_fn)] = {"ref": weakref.ref(network_fn), "r": R.Renderer(64, 0, max_rays_per_launch=1, color_independent_to_direction=_ci(network_fn), range_check="lazy"), "w": None}
         for k in [k for k, e in _query_ctx.items() if e["ref"]() is None]:
             del _query_ctx[k]
     key = R._weights_key(network_fn)
@@ -147,13 +147,19 @@ def create_IBLNeRF(args):
     path = ck.find_checkpoint(args.basedir, args.expname, getattr(args, "ft_path", None),
                               getattr(args, "target_load_N_iter", -1))
     if path is not None and not getattr(args, "no_reload", False):
-        start, sd_c, sd_f = ck.load_checkpoint(path)
-        model.load_state_dict(sd_c)
-        if model_fine is not None and sd_f is not None:
-            model_fine.load_state_dict(sd_f)
-        for name, sd_a in ck.load_checkpoint_aux(path).items():                    # ibl_nerf.py:369-374
-            if aux[name] is not None:
-                aux[name].load_state_dict(sd_a)
+        # key accesses as ibl_nerf.py:355-376: a checkpoint without the fine network (N_importance > 0) or without the
+        # normal_mlp (infer_normal) is a KeyError there, never a render with placeholder weights
+        ckpt = ck.read_checkpoint(path)
+        start = ckpt["global_step"]
+        elapsed = ckpt.get("elapsed_time", 0)
+        model.load_state_dict(ckpt["network_fn_state_dict"])
+        if aux["normal_mlp"] is not None:
+            aux["normal_mlp"].load_state_dict(ckpt["normal_mlp"])
+        for name in ("albedo_mlp", "roughness_mlp", "irradiance_mlp"):             # lenient `in ckpt` only for these (:369-374)
+            if aux[name] is not None and name in ckpt:
+                aux[name].load_state_dict(ckpt[name])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt["network_fine_state_dict"])
     train = {
         "network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
         "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,

@@ -16,6 +16,8 @@ supported; anything else raises (see `_check_supported`).
 from __future__ import annotations
 
 import ctypes as C
+import itertools
+import weakref
 
 import numpy as np
 
@@ -54,15 +56,23 @@ class Renderer:
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
-                 epsilon_direction=0.005, infer_normal_at_surface=False):
+                 epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
         """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
         rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
         activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
-        repeat the call on a bf16x3 context, so results never depend on the choice beyond round-off."""
+        repeat the call on a bf16x3 context, so results never depend on the choice beyond round-off.
+        range_check: "eager" reads the kernel's range flag after every call (one device synchronisation per call: right
+        for frame-sized calls whose results are read back anyway); "lazy" never synchronises: each call looks at the
+        snapshot its predecessors left behind (iblnerf_range_peek), and on an out-of-range event warns that the flagged
+        call's results were invalid and moves every later call to the bf16x3 context (the training hook's mode: many
+        small queries per step; `check_range()` forces the question, e.g. once per step)."""
         torch = _torch()
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
         if mlp_precision not in ("bf16x3", "f16_mxfp6", "f16_mixed"):
             raise ValueError("mlp_precision must be 'bf16x3', 'f16_mxfp6' or 'f16_mixed'")
+        if range_check not in ("eager", "lazy"):
+            raise ValueError("range_check must be 'eager' or 'lazy'")
+        self.range_check, self._force_wide = range_check, False
         if normal_mode not in NORMAL_MODES:
             raise ValueError(normal_mode)                                          # ibl_nerf_renderer.py:374-375
         if not torch.cuda.is_available():
@@ -95,7 +105,7 @@ class Renderer:
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
                           lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode,
                           color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction,
-                          infer_normal_at_surface=infer_normal_at_surface)
+                          infer_normal_at_surface=infer_normal_at_surface, range_check=range_check)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
@@ -182,7 +192,7 @@ class Renderer:
         B.check(self.ctx, self.lib.iblnerf_range_status(self.ctx, C.byref(flag)))
         return bool(flag.value)
 
-    def _wide_twin(self):
+    def _wide_twin(self, count=True):
         """The bf16x3 context a call is repeated on after an out-of-range event."""
         if self._wide is None:
             self._wide = Renderer(mlp_precision="bf16x3", **self._ctor)
@@ -193,8 +203,32 @@ class Renderer:
                     self._wide.load_aux(name, sd)
             if self._lut is not None:
                 self._wide.load_lut(self._lut)
-        self.range_fallbacks += 1
+        self.range_fallbacks += int(count)
         return self._wide
+
+    def _lazy_poll(self):
+        """range_check="lazy": look at the flag snapshot of the calls issued so far, without synchronising."""
+        if self.mlp_precision == "bf16x3" or self._force_wide:
+            return
+        flag, pending = C.c_int(), C.c_int()
+        B.check(self.ctx, self.lib.iblnerf_range_peek(self.ctx, C.byref(flag), C.byref(pending)))
+        if flag.value:
+            self._went_out_of_range()
+
+    def _went_out_of_range(self):
+        import warnings
+        self.out_of_range()                     # clears the device flags (synchronises: once per event)
+        self._force_wide = True
+        self._wide_twin()
+        warnings.warn("IBL-NeRF HIP renderer: an earlier f16 + MX-fp6 MLP launch left the f16 range (range_check='lazy'): that "
+                      "call's results were invalid; this context now runs on the bf16x3 kernel", RuntimeWarning, stacklevel=3)
+
+    def check_range(self):
+        """range_check="lazy": synchronise and settle the question for everything issued so far.  True = an out-of-range
+        event happened (now or earlier) and the context runs on bf16x3."""
+        if not self._force_wide and self.out_of_range():
+            self._went_out_of_range()
+        return self._force_wide
 
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
@@ -227,10 +261,15 @@ class Renderer:
         inputs = _dev_f32(inputs, self.device)
         N, S = inputs.shape[0], inputs.shape[1]
         vd = None if viewdirs is None else _dev_f32(viewdirs, self.device)
+        lazy = self.range_check == "lazy"
+        if lazy:
+            self._lazy_poll()
+            if self._force_wide:
+                return self._wide_twin(count=False).network_query(inputs, vd, which)
         out = torch.empty((N, S, 18 if vd is not None else 1), dtype=torch.float32, device=self.device)
         B.check(self.ctx, self.lib.iblnerf_network_query(self.ctx, self._stream(), int(which), inputs.data_ptr(), N, S,
                                                          None if vd is None else vd.data_ptr(), out.data_ptr()))
-        if self.out_of_range():
+        if not lazy and self.out_of_range():
             return self._wide_twin().network_query(inputs, vd, which)
         return out
 
@@ -274,6 +313,11 @@ class Renderer:
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = rays_o.shape[0]
+        lazy = self.range_check == "lazy"
+        if lazy:
+            self._lazy_poll()
+            if self._force_wide:
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, **edit)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -292,7 +336,7 @@ class Renderer:
                                                        float(near), float(far), C.byref(ov) if ov is not None else None,
                                                        C.byref(outs)))
         self._keep = keep   # override rows must outlive the asynchronous launch
-        if self.out_of_range():
+        if not lazy and self.out_of_range():
             return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, **edit)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
@@ -302,6 +346,44 @@ class Renderer:
         if z_std is not None:
             res["z_std"] = z_std
         return res
+
+    def composite_pass(self, rays_o, rays_d, near, far, z_vals, raw, sigma_offsets, refl_raw, gt_values=None, normal_raw=None, **edit):
+        """Teacher-forced raw2outputs (iblnerf_composite_pass): one pass on caller-supplied network outputs, no MLP launch.
+        z_vals [n,S], raw [n,S,18], sigma_offsets [4,n,S] (or [4n,S,1] as the reference stacks them) or None, refl_raw
+        [n,N_samples,18] (the reflected query's raw rows; columns 0, 6..17 are read).  Returns the pass's maps plus
+        'stage' [n,8] (normal before overrides, n.v, roughness, LUT scale, LUT bias, mip level), 'refl_o', 'refl_d'."""
+        torch = _torch()
+        rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
+        n = rays_o.shape[0]
+        z = _dev_f32(z_vals, self.device).reshape(n, -1)
+        S = z.shape[1]
+        raw = _dev_f32(raw, self.device).reshape(n, S, 18)
+        refl = _dev_f32(refl_raw, self.device).reshape(n, self.N_samples, -1)
+        if refl.shape[-1] == 18:
+            refl = torch.cat([refl[..., :1], refl[..., 6:]], -1).contiguous()
+        si = B.StageInputs()
+        si.n_samples, si.d_z, si.d_raw, si.d_refl_raw = S, z.data_ptr(), raw.data_ptr(), refl.data_ptr()
+        keep = [z, raw, refl]
+        if sigma_offsets is not None:
+            so = _dev_f32(sigma_offsets, self.device).reshape(4, n, S)
+            si.d_sigma_offsets = so.data_ptr()
+            keep.append(so)
+        if normal_raw is not None:
+            nr = _dev_f32(normal_raw, self.device)
+            si.d_normal_raw = nr.data_ptr()
+            keep.append(nr)
+        extra = {"stage": torch.empty((n, 8), dtype=torch.float32, device=self.device),
+                 "refl_o": torch.empty((n, 3), dtype=torch.float32, device=self.device),
+                 "refl_d": torch.empty((n, 3), dtype=torch.float32, device=self.device)}
+        si.d_stage, si.d_refl_o, si.d_refl_d = (extra[k].data_ptr() for k in ("stage", "refl_o", "refl_d"))
+        ov, keep_ov = self._overrides(gt_values or {}, edit, n)
+        irr_ch = 3 if edit.get("calculate_irradiance_from_gt") else 1
+        maps, t = self._alloc_maps(n, S, irr_ch=irr_ch, inferred_normal=normal_raw is not None)
+        B.check(self.ctx, self.lib.iblnerf_composite_pass(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near),
+                                                          float(far), C.byref(ov) if ov is not None else None, C.byref(si), C.byref(maps)))
+        torch.cuda.synchronize(self.device)            # the inputs in `keep` may be freed on return
+        del keep, keep_ov
+        return dict(t, **extra)
 
     def _overrides(self, gt, edit, n):
         """gt_values rows + the edit/insert kwargs of test.py:115-139 -> iblnerf_overrides."""
@@ -423,14 +505,30 @@ NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
 DEFAULT_MLP_PRECISION = "f16_mxfp6"
 
 
+_tokens = itertools.count(1)
+
+
 def _weights_key(net):
+    """(identity token, content version) of a network object.  The token is a process-global counter value stamped on the
+    object the first time it is seen: unlike id() / a data pointer it cannot recur once the object is freed and another one
+    takes its address (a loop over checkpoints or scenes in one process).  The version is the container's load counter
+    (model.IBLNeRF / PositionMLP) or, for an nn.Module, the sum of its tensors' in-place `_version` counters plus their
+    storage addresses (optimizer steps and load_state_dict bump the former, `p.data = ...` changes the latter)."""
+    tok = getattr(net, "_iblnerf_token", None)
+    if tok is None:
+        tok = next(_tokens)
+        object.__setattr__(net, "_iblnerf_token", tok)
     sd = net.state_dict()
-    ver = 0
-    for v in sd.values():
-        ver += int(getattr(v, "_version", 0))
     first = next(iter(sd.values()))
-    ptr = first.data_ptr() if hasattr(first, "data_ptr") else first.ctypes.data
-    return (id(net), ptr, ver)
+    if hasattr(first, "data_ptr"):
+        ver = (sum(int(v._version) for v in sd.values()), hash(tuple(v.data_ptr() for v in sd.values())))
+    else:
+        ver = (int(getattr(net, "_version", 0)), first.ctypes.data if hasattr(first, "ctypes") else 0)
+    return (tok,) + ver
+
+
+def _same_object(ref, obj):
+    return ref is not None and ref() is obj
 
 
 def renderer_for(kw):
@@ -474,10 +572,10 @@ def renderer_for(kw):
             r.load_aux(name, None if net is None else net.state_dict())
             ent["aux"][name] = wk
     lut = kw["brdf_lut"]
-    lk = (id(lut), lut.data_ptr() if hasattr(lut, "data_ptr") else 0)
-    if ent["lut"] != lk:
+    lk = (lut.data_ptr(), int(lut._version)) if hasattr(lut, "data_ptr") else (lut.ctypes.data, 0)
+    if ent["lut"] is None or not _same_object(ent["lut"][0], lut) or ent["lut"][1] != lk:   # a dead referent = another LUT at a recycled address
         r.load_lut(lut)
-        ent["lut"] = lk
+        ent["lut"] = (weakref.ref(lut), lk)
     return r
 
 

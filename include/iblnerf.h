@@ -213,11 +213,41 @@ int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, c
                         int64_t n_rays, float near_, float far_, const iblnerf_overrides* overrides,
                         const iblnerf_outputs* outputs);
 
-/* IBLNERF_MLP_F16_MXFP6 only.  Synchronises the device and reports in *out_of_range whether any MLP launch on
- * this ctx since the last call saw an encoded input or activation at or beyond the f16 range (65504); the flag
- * is cleared.  When it is 1 the affected outputs are invalid: render again on a ctx created with
- * IBLNERF_MLP_BF16X3 (ibl-nerf_amd/renderer.py does this automatically).  Always 0 for IBLNERF_MLP_BF16X3. */
+/* Teacher-forced stage entry (parity tests): ONE raw2outputs pass (ibl_nerf_renderer.py:153-527, with
+ * raw2outputs_simple :38-68 for the reflected ray) on CALLER-SUPPLIED network outputs — no MLP launch.  Feeding the reference's
+ * recorded `raw` isolates the compositing / epsilon-normal / shading kernels from the MLP kernel's rounding, so that ill-conditioned
+ * checkpoints (sharp density, wide-range weights) can be held to fp32 round-off stage by stage.  n_rays <= max_rays_per_launch.
+ * The pass uses the context's options (normal mode, gamma, LUT coefficient, ...) and loaded LUT; overrides as in render_rays. */
+typedef struct {
+    int32_t n_samples;              /* S of this pass: N_samples (coarse) or N_samples + N_importance (fine) */
+    const float* d_z;               /* [n_rays, S] z_vals of this pass */
+    const float* d_raw;             /* [n_rays, S, 18] main query (network_query_fn output, :202) */
+    const float* d_sigma_offsets;   /* [4, n_rays, S] density of the four offset / tilted queries (normal_from_depth.py:158-160);
+                                       NULL in the ground-truth and inferred normal modes */
+    const float* d_refl_raw;        /* [n_rays, N_samples, 13] reflected-ray query (:445): columns 0 and 6..17 of its raw rows */
+    const float* d_normal_raw;      /* [n_rays, S, 3] normal_mlp samples ([n_rays, 3] with infer_normal_at_surface) or NULL */
+    float* d_stage;                 /* optional out [n_rays, 8]: normal before the edit / insert overrides (3), LUT coordinates n.v and
+                                       roughness (2), LUT scale and bias (2), mip level of the prefiltered radiance (1) */
+    float* d_refl_o;                /* optional out [n_rays, 3]: x_surface (:262) */
+    float* d_refl_d;                /* optional out [n_rays, 3]: reflected direction (:439) */
+} iblnerf_stage_inputs;
+int iblnerf_composite_pass(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                           float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_stage_inputs* in,
+                           const iblnerf_maps* maps);
+
+/* IBLNERF_MLP_F16_MXFP6 / _MIXED only.  Synchronises the device and reports in *out_of_range whether any MLP launch on
+ * this ctx since the last call saw an encoded input or activation at or beyond the f16 range (65504), or whether a network
+ * uploaded with iblnerf_upload_weights_device holds a weight beyond it; the flags are cleared.  When it is 1 the affected
+ * outputs are invalid: render again on a ctx created with IBLNERF_MLP_BF16X3 (ibl-nerf_amd/renderer.py does this
+ * automatically).  A network with an out-of-range weight runs on the bf16x3 kernel from this call on (until its next upload).
+ * Always 0 for IBLNERF_MLP_BF16X3. */
 int iblnerf_range_status(iblnerf_ctx* ctx, int* out_of_range);
+/* The same question without synchronising (for callers that issue many small queries per step, e.g. the training hook):
+ * iblnerf_render_rays / _network_query / _upload_weights_device leave a snapshot of the flags behind their launches; this
+ * call looks at the newest one.  *pending = 1: its launches have not finished yet (nothing is known; *out_of_range = 0).
+ * Otherwise *out_of_range tells whether anything up to and including the newest call went out of range.  Nothing is cleared:
+ * follow a positive answer with iblnerf_range_status. */
+int iblnerf_range_peek(iblnerf_ctx* ctx, int* out_of_range, int* pending);
 
 /* Host-only: the IBLNERF_MLP_F16_MXFP6 weight-stream format (csrc/layout_mx.h), for the CPU layout tests. */
 int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,

@@ -201,7 +201,7 @@ def sample_pdf(bins, weights, n_samples):
 # --------------------------------------------------------------------------------------------
 # A.7 epsilon normal — nerf_models/normal_from_depth.py:139-183
 # --------------------------------------------------------------------------------------------
-def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=False):
+def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=False, sigma=None):
     eps = F32(eps)
     up0 = np.broadcast_to(np.array([0, 1, 0], dtype=F32), rays_d.shape)
     right = cross(rays_d, up0)
@@ -209,7 +209,7 @@ def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=Fa
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)
     offs = [eps * right, -(eps * right), eps * up, -(eps * up)]        # pts +- eps*v (:151-154)
     new_pts = np.concatenate([(pts + o[:, None, :]).astype(F32) for o in offs], 0)
-    raw = network_query(sd, new_pts, None)[..., 0]
+    raw = network_query(sd, new_pts, None)[..., 0] if sigma is None else sigma   # sigma: teacher-forced query result [4N,S]
     dists = ray_dists(z_vals, rays_d)
     N = rays_o.shape[0]
     D = [np.sum(alpha_weights(raw[s * N:(s + 1) * N], dists) * z_vals, -1, dtype=F32) for s in range(4)]
@@ -219,7 +219,7 @@ def normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=0.01, return_depths=Fa
     return (n, np.stack(D, 0)) if return_depths else n
 
 
-def normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=0.005):
+def normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=0.005, sigma=None):
     """nerf_models/normal_from_depth.py:55-100: depths along four rays whose (normalised) directions are tilted by
     +-eps*right / +-eps*up, sampled at the centre ray's z values; normal from the four end points."""
     eps = F32(eps)
@@ -229,7 +229,7 @@ def normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=0.005):
     new_d = [normalize((rays_d + eps * right).astype(F32)), normalize((rays_d - eps * right).astype(F32)),
              normalize((rays_d + eps * up).astype(F32)), normalize((rays_d - eps * up).astype(F32))]       # :64-67
     pts = np.concatenate([(rays_o[:, None, :] + d[:, None, :] * z_vals[:, :, None]).astype(F32) for d in new_d], 0)
-    raw = network_query(sd, pts, None)[..., 0]
+    raw = network_query(sd, pts, None)[..., 0] if sigma is None else sigma
     dists = ray_dists(z_vals, rays_d)                                                                     # the centre ray's (:77-79)
     N = rays_o.shape[0]
     D = [np.sum(alpha_weights(raw[s * N:(s + 1) * N], dists) * z_vals, -1, dtype=F32) for s in range(4)]
@@ -286,7 +286,8 @@ def decode_masks(mask_img, n_obj):
 # --------------------------------------------------------------------------------------------
 # one pass: raw2outputs, ibl_nerf_renderer.py:153-527 (approximate_radiance=True, shipped flags)
 # --------------------------------------------------------------------------------------------
-def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None, aux=None):
+def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None, aux=None,
+                teacher=None):
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
     epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
@@ -295,14 +296,18 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     depth_map_from_ground_truth / calculate_{albedo,roughness,irradiance}_from_gt (:251-252, :320-330): the target map is
     the gt_values row and no longer aliases the network's map, so edits stop showing in depth_map / disp / the mip level.
     aux: {'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp': PositionMLP state dict} (:291-303): their samples replace the main
-    network's before compositing; an irradiance_mlp's go through sigmoid whatever radiance_f is."""
+    network's before compositing; an irradiance_mlp's go through sigmoid whatever radiance_f is.
+    teacher: {'raw' [N,S,18], 'sigma_offsets' [4N,S], 'refl_raw' [N,Sc,18]} — recorded results of the three network queries
+    (:201, normal_from_depth.py:158, :445) used INSTEAD of evaluating `sd` (teacher forcing: the pass downstream of the MLP
+    in isolation)."""
+    teacher = teacher or {}
     gt = gt or {}
     edit = edit or {}
     flags = flags or {}
     linear = bool(flags.get("use_radiance_linear", False))
     radiance_f = relu if linear else sigmoid
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)       # :200
-    raw = network_query(sd, pts, rays_d)                                                    # :201 (rays_d, not viewdirs)
+    raw = teacher["raw"] if "raw" in teacher else network_query(sd, pts, rays_d)            # :201 (rays_d, not viewdirs)
     dists = ray_dists(z_vals, rays_d)
     masks, mask_all = None, None
     if edit.get("edit_intrinsic"):
@@ -355,9 +360,11 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     elif nmode == "ground_truth":
         normal = normalize(F32(2) * gt["normal"] - F32(1))                                  # :370-371
     elif nmode == "normal_map_from_depth_gradient_epsilon":
-        normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)))   # :358-361
+        normal = normal_from_depth_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon", 0.01)),
+                                       sigma=teacher.get("sigma_offsets"))                  # :358-361
     elif nmode == "normal_map_from_depth_gradient_direction_epsilon":
-        normal = normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon_direction", 0.005)))  # :366-369
+        normal = normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon_direction", 0.005)),
+                                                 sigma=teacher.get("sigma_offsets"))        # :366-369
     else:
         raise ValueError(nmode)                                                             # :374-375
     if stages is not None:
@@ -395,7 +402,7 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     spec_coef = ((fres if lutc == "F" else F0) * env[:, 0:1] + env[:, 1:2]).astype(F32)     # :433-436
     refl_d = (rays_d - F32(2) * np.sum(normal * rays_d, -1, keepdims=True, dtype=F32) * normal).astype(F32)
     refl_pts = (x_surface[:, None, :] + refl_d[:, None, :] * z_const[:, :, None]).astype(F32)   # :440
-    refl_raw = network_query(sd, refl_pts, refl_d)                                          # :445
+    refl_raw = teacher["refl_raw"] if "refl_raw" in teacher else network_query(sd, refl_pts, refl_d)   # :445
     pref_maps = composite_reflected(refl_raw, z_const, refl_d, radiance_f)                  # :446-448
     depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
     if flags.get("correct_depth_for_prefiltered_radiance_infer", True):

@@ -35,8 +35,12 @@ def load_golden(name):
     """Returns (npz, coarse_sd, fine_sd, gt dict, edit dict) for a render fixture."""
     from ibl_nerf_amd import checkpoint as ck
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    sdc = ck.synthetic_state_dict(int(g["seed_coarse"]), float(g["gain"]))
-    sdf = ck.synthetic_state_dict(int(g["seed_fine"]), float(g["gain"]))
+    if "ckpt" in g.files and str(g["ckpt"]) == "fitted":       # the surface-bearing checkpoint (tests/golden/fit_checkpoint.py)
+        f = np.load(os.path.join(GOLDEN, "fitted_ckpt.npz"))
+        sdc, sdf = ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
+    else:
+        sdc = ck.synthetic_state_dict(int(g["seed_coarse"]), float(g["gain"]))
+        sdf = ck.synthetic_state_dict(int(g["seed_fine"]), float(g["gain"]))
     assert ck.blob_checksum(ck.state_dict_to_blob(sdc)) == str(g["ck_coarse"])
     assert ck.blob_checksum(ck.state_dict_to_blob(sdf)) == str(g["ck_fine"])
     edit = {k[6:]: g[k].tolist() for k in g.files if k.startswith("edit__")}
@@ -60,6 +64,7 @@ RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "ins
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
                    "infernormal_surface_g10"]
+FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert"]   # rendered by the reference from the fitted checkpoint
 
 
 def color_independent(g):
@@ -100,3 +105,23 @@ def ill_conditioned(g):
     """Fixtures whose DERIVED channels are chaotic even between two fp32 implementations: the
     wide-range checkpoint and HDR radiance (ReLU kinks + gamma of values near 0)."""
     return float(g["gain"]) > 1.0 or bool(golden_flags(g).get("use_radiance_linear", False))
+
+
+def teacher_pass(g, p):
+    """Recorded stage boundaries of pass p ('c' coarse | 'f' fine) of a fixture, for teacher forcing: the reference's own
+    network-query results for the first k rays (k = rays whose raw rows the fixture keeps) and the pass's z_vals, rebuilt exactly
+    as render_rays builds them (coarse grid; fine = sort(cat(coarse, recorded sample_pdf output)), ibl_nerf_renderer.py:701-707).
+    Returns dict(k, z, zc, raw [k,S,18], sigma_offsets [4k,S] | None, refl_raw [k,Sc,18])."""
+    import iblnerf_oracle as O
+    raw = g["q_%s_main_raw" % p]
+    k = raw.shape[0]
+    zc = O.coarse_z(float(g["near"]), float(g["far"]), n_samples(g), k, bool(golden_flags(g).get("lindisp", False)))
+    z = zc if p == "c" else np.sort(np.concatenate([zc, g["pdf_samples"][:k]], -1), -1)
+    sig = g["q_%s_eps_sigma" % p][..., 0] if "q_%s_eps_sigma" % p in g.files else None
+    assert raw.shape[1] == z.shape[1] and (sig is None or sig.shape == (4 * k, z.shape[1]))
+    return dict(k=k, z=z.astype(np.float32), zc=zc, raw=raw, sigma_offsets=sig, refl_raw=g["q_%s_refl_raw" % p])
+
+
+# fixtures whose recorded main-network raw rows are the whole input of raw2outputs (no auxiliary / normal network outputs, which the
+# recorder does not keep)
+TEACHER_FIXTURES = [n for n in RENDER_FIXTURES if not n.startswith(("auxmlp", "infernormal"))] + FITTED_FIXTURES

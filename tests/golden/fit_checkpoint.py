@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Fit the REFERENCE's own IBLNeRF modules to an analytic scene, so that parity is pinned on a checkpoint that has surfaces.
+
+Run from the repo root, only where /root/reference exists (never on the GPU box):
+
+    python tests/golden/fit_checkpoint.py [--steps1 N] [--steps2 N]
+
+Every other checkpoint in the tests is a random-init network (checkpoint.synthetic_state_dict): its density is fog and its
+weights are smooth.  A fitted network has sharp sigma steps, empty space with negative raw density, weights far from
+U(+-1/sqrt(fan_in)) — where the epsilon-normal's 1/(2 eps) amplification, the inverse-CDF sample placement and the f16 range
+guard of the MLP kernel are stressed.  This script produces such a checkpoint with the reference's code:
+
+  stage 1  the two `IBLNeRF` modules built by the reference's `create_IBLNeRF` are regressed point-wise (through the
+           reference's `network_query_fn`, i.e. its embedders and its forward) onto an analytic field: two spheres, a floor
+           and a back wall with constant albedo / roughness per object, Lambert irradiance and a Phong lobe for the
+           view-dependent radiance.  Plain torch.optim.Adam on CPU.
+  stage 2  a short optimisation THROUGH the reference's `render_decomp` with the train kwargs (stratified jitter, stochastic
+           fine sampling), photometric + intrinsic losses against the analytically rendered targets — the pattern of
+           train.py:286-297, :479-481.
+
+Output (data only): tests/golden/fitted_ckpt.npz — the two state-dict blobs (fp32, registration order, the format of
+checkpoint.state_dict_to_blob), their checksums, the scene constants and the loss history.  make_golden.py loads it for the
+`fitted_*` fixtures.
+"""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402  (reference import + args helper; also puts the repo root on sys.path)
+
+ck = MG.ck
+NEAR, FAR = 0.5, 8.0
+LIGHT = np.array([0.4, 0.8, 0.45], np.float32) / np.linalg.norm([0.4, 0.8, 0.45]).astype(np.float32)
+# object table: albedo RGB, roughness
+OBJ_ALBEDO = np.array([[0.80, 0.30, 0.20], [0.20, 0.50, 0.80], [0.60, 0.60, 0.55], [0.35, 0.40, 0.30]], np.float32)
+OBJ_ROUGH = np.array([0.20, 0.60, 0.80, 0.50], np.float32)
+SPH_C = np.array([[-0.7, -0.2, -3.2], [0.8, -0.45, -2.4]], np.float32)
+SPH_R = np.array([0.8, 0.5], np.float32)
+FLOOR_Y, WALL_Z = -1.0, -6.0
+SIGMA_IN, SIGMA_OUT, BAND = 60.0, -5.0, 0.02
+
+
+def scene(torch, x):
+    """Signed distance, object id and outward normal of the analytic scene at points x [...,3] (torch)."""
+    c = torch.from_numpy(SPH_C)
+    r = torch.from_numpy(SPH_R)
+    d0 = (x - c[0]).norm(dim=-1) - r[0]
+    d1 = (x - c[1]).norm(dim=-1) - r[1]
+    d2 = x[..., 1] - FLOOR_Y          # solid below the floor
+    d3 = x[..., 2] - WALL_Z           # solid behind the wall
+    sd = torch.stack([d0, d1, d2, d3], -1)
+    sdf, obj = sd.min(-1)
+    n0 = torch.nn.functional.normalize(x - c[0], dim=-1)
+    n1 = torch.nn.functional.normalize(x - c[1], dim=-1)
+    n2 = torch.tensor([0.0, 1.0, 0.0]).expand_as(x)
+    n3 = torch.tensor([0.0, 0.0, 1.0]).expand_as(x)
+    nrm = torch.stack([n0, n1, n2, n3], -2)
+    n = torch.gather(nrm, -2, obj[..., None, None].expand(*obj.shape, 1, 3))[..., 0, :]
+    return sdf, obj, n
+
+
+def field_targets(torch, x, d):
+    """Raw-output targets [...,18] of the analytic field at points x seen along (unnormalised) directions d."""
+    sdf, obj, n = scene(torch, x)
+    t = ((sdf + BAND) / (2 * BAND)).clamp(0, 1)                       # 0 inside .. 1 outside over the band
+    sigma = SIGMA_IN + (SIGMA_OUT - SIGMA_IN) * t
+    albedo = torch.from_numpy(OBJ_ALBEDO)[obj]
+    rough = torch.from_numpy(OBJ_ROUGH)[obj]
+    L = torch.from_numpy(LIGHT)
+    irr = 0.25 + 0.6 * (n * L).sum(-1).clamp(min=0)
+    dn = torch.nn.functional.normalize(d, dim=-1)
+    refl = dn - 2 * (dn * n).sum(-1, keepdim=True) * n
+    rl = (refl * L).sum(-1).clamp(min=0)
+    rads = []
+    for p in (8.0, 4.0, 2.0, 1.0):                                    # radiance and its three "prefiltered" versions
+        spec = (1 - rough) * 0.5 * rl ** p
+        rads.append((albedo * irr[..., None] + spec[..., None]).clamp(0.02, 0.98))
+    logit = lambda v: torch.log(v / (1 - v))  # noqa: E731
+    return torch.cat([sigma[..., None], logit(albedo.clamp(0.02, 0.98)), logit(rough.clamp(0.02, 0.98))[..., None],
+                      logit(irr.clamp(0.02, 0.98))[..., None]] + [logit(r) for r in rads], -1)
+
+
+def ray_hits(torch, o, d):
+    """Analytic first hit of rays o + t d (t in units of |d|, like z_vals): t, object id, hit normal."""
+    ts = []
+    for c, r in zip(SPH_C, SPH_R):
+        oc = o - torch.from_numpy(c)
+        a = (d * d).sum(-1)
+        b = 2 * (oc * d).sum(-1)
+        cc = (oc * oc).sum(-1) - float(r) ** 2
+        disc = b * b - 4 * a * cc
+        t = (-b - disc.clamp(min=0).sqrt()) / (2 * a)
+        ts.append(torch.where((disc > 0) & (t > 0), t, torch.full_like(t, 1e9)))
+    tf = (FLOOR_Y - o[..., 1]) / d[..., 1]
+    ts.append(torch.where((d[..., 1] < 0) & (tf > 0), tf, torch.full_like(tf, 1e9)))
+    tw = (WALL_Z - o[..., 2]) / d[..., 2]
+    ts.append(torch.where((d[..., 2] < 0) & (tw > 0), tw, torch.full_like(tw, 1e9)))
+    t, obj = torch.stack(ts, -1).min(-1)
+    return t, obj
+
+
+def camera_dirs(torch, rng, n, fov_deg=60.0):
+    f = 400.0 / np.tan(0.5 * np.deg2rad(fov_deg))
+    i = rng.uniform(0, 800, n)
+    j = rng.uniform(0, 800, n)
+    return torch.from_numpy(np.stack([(i - 400) / f, -(j - 400) / f, -np.ones(n)], -1).astype(np.float32))
+
+
+def sample_points(torch, rng, n):
+    """Training points: a third uniform along camera rays, two thirds within a few centimetres of the surfaces."""
+    d = camera_dirs(torch, rng, n)
+    o = torch.zeros_like(d)
+    t_hit, _ = ray_hits(torch, o, d)
+    t_uni = torch.from_numpy(rng.uniform(NEAR, FAR, n).astype(np.float32))
+    t_near = t_hit + torch.from_numpy((rng.standard_normal(n) * rng.choice([0.01, 0.04, 0.15], n)).astype(np.float32))
+    pick = torch.from_numpy(rng.uniform(size=n) < 1 / 3)
+    t = torch.where(pick, t_uni, t_near).clamp(0.3, 9.0)
+    x = o + d * t[:, None]
+    # view directions: the camera ray through the point, or (half of the time) a direction of comparable length, as the
+    # reflected-ray queries present (r = d - 2 (n.d) n has |r| = |d|)
+    rnd = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    rnd = rnd * d.norm(dim=-1, keepdim=True)
+    use_rnd = torch.from_numpy(rng.uniform(size=n) < 0.5)[:, None]
+    return x, torch.where(use_rnd, rnd, d)
+
+
+def render_targets(torch, o, d):
+    t, obj = ray_hits(torch, o, d)
+    x = o + d * t[:, None]
+    raw = field_targets(torch, x - 1e-4 * d, d)        # a hair in front of the surface; only the non-sigma channels are read
+    sg = torch.sigmoid
+    return dict(depth=t, albedo=sg(raw[:, 1:4]), roughness=sg(raw[:, 4]), irradiance=sg(raw[:, 5:6]), rgb=sg(raw[:, 6:9]),
+                rgb_k=[sg(raw[:, 9 + 3 * k:12 + 3 * k]) for k in range(3)])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps1", type=int, default=4000)
+    ap.add_argument("--batch1", type=int, default=8192)
+    ap.add_argument("--steps2", type=int, default=60)
+    ap.add_argument("--batch2", type=int, default=192)
+    ap.add_argument("--out", default=os.path.join(HERE, "fitted_ckpt.npz"))
+    a = ap.parse_args()
+    torch, R, M, Hh = MG.import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    rng = np.random.RandomState(20261002)
+    tmp = tempfile.mkdtemp()
+    try:
+        kw_train, kw_test, *_ = M.create_IBLNeRF(MG.reference_args(tmp, 128))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nets = [kw_train["network_fn"], kw_train["network_fine"]]
+    query = kw_train["network_query_fn"]
+    hist1, hist2 = [], []
+
+    # ---- stage 1: point-wise regression of both networks onto the analytic field
+    params = [p for n in nets for p in n.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    w = torch.tensor([0.02] + [1.0] * 17)              # the density target spans 65 units, the logits ~8
+    t0 = time.time()
+    for it in range(a.steps1):
+        x, d = sample_points(torch, rng, a.batch1)
+        tgt = field_targets(torch, x, d)
+        loss = 0.0
+        for net in nets:
+            out = query(x[:, None, :], d, net)[:, 0, :]
+            err = torch.nn.functional.smooth_l1_loss(out, tgt, reduction="none", beta=2.0)
+            loss = loss + (err * w).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:
+            g["lr"] = 1e-3 * 0.1 ** (it / max(a.steps1, 1))
+        if it % 50 == 0 or it == a.steps1 - 1:
+            hist1.append((it, float(loss.detach())))
+            print("stage1 %5d  loss %.5f  %.0fs" % (it, float(loss.detach()), time.time() - t0), flush=True)
+
+    # ---- stage 2: through the reference's render_decomp (train kwargs: perturb = 1, stochastic fine sampling)
+    lut = MG.load_lut(torch)
+    kw_train.update(near=NEAR, far=FAR)
+    kw_train["brdf_lut"] = lut
+    opt = torch.optim.Adam(params, lr=5e-5)
+    K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], np.float32)
+    mse = torch.nn.functional.mse_loss
+    for it in range(a.steps2):
+        d = camera_dirs(torch, rng, a.batch2)
+        o = torch.zeros_like(d)
+        tg = render_targets(torch, o, d)
+        res = R.render_decomp(800, 800, K, chunk=a.batch2, rays=torch.stack([o, d], 0), gt_values={},
+                              approximate_radiance=True, calculate_normal_from_depth_gradient_epsilon=True,
+                              **kw_train, **MG.EDIT_KEYS_OFF)
+        loss = 0.0
+        for s in ("", "0"):
+            loss = loss + mse(res["color_map" + s], tg["rgb"]) + mse(res["radiance_map" + s], tg["rgb"])
+            loss = loss + mse(res["albedo_map" + s], tg["albedo"]) + mse(res["roughness_map" + s], tg["roughness"])
+            loss = loss + mse(res["irradiance_map" + s], tg["irradiance"]) + 0.05 * mse(res["depth_map" + s], tg["depth"])
+            for k in range(3):
+                loss = loss + mse(res["radiance_map_%d%s" % (k + 1, s)], tg["rgb_k"][k])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        hist2.append((it, float(loss.detach())))
+        print("stage2 %4d  loss %.5f  %.0fs" % (it, float(loss.detach()), time.time() - t0), flush=True)
+
+    sd = [{k: v.detach().numpy().astype(np.float32) for k, v in n.state_dict().items()} for n in nets]
+    blobs = [ck.state_dict_to_blob(s) for s in sd]
+    np.savez_compressed(a.out, coarse=blobs[0], fine=blobs[1],
+                        ck_coarse=np.array(ck.blob_checksum(blobs[0])), ck_fine=np.array(ck.blob_checksum(blobs[1])),
+                        near=np.float32(NEAR), far=np.float32(FAR), hist1=np.array(hist1), hist2=np.array(hist2),
+                        sph_c=SPH_C, sph_r=SPH_R, floor_y=np.float32(FLOOR_Y), wall_z=np.float32(WALL_Z))
+    print("wrote", a.out, "%.2f MB" % (os.path.getsize(a.out) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -171,8 +171,15 @@ class Recorder:
         R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
 
 
+def fitted_state_dicts():
+    """The checkpoint fit_checkpoint.py produced with the reference's modules (tests/golden/fitted_ckpt.npz)."""
+    f = np.load(os.path.join(OUT, "fitted_ckpt.npz"))
+    return ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
+
+
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
-                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False):
+                n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False,
+                fitted=False, record_floor=False):
     tmp = tempfile.mkdtemp()
     try:
         _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal))
@@ -180,6 +187,9 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
     sd_f = ck.synthetic_state_dict(seed=2 * seed + 1, gain=gain)
+    if fitted:                                   # the surface-bearing checkpoint instead of a random-init one
+        sd_c, sd_f = fitted_state_dicts()
+    n_keep = min(n_keep, n_rays)
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     if kw["network_fine"] is not None:
         kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
@@ -268,6 +278,27 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         ret = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values=gt_t,
                               approximate_radiance=True, **kw, **edit)
 
+    floor = {}
+    if record_floor:
+        # the reference's own round-off sensitivity: the same render in float64 (modules, rays, gt rows, LUT) against the float32
+        # run, relative L-inf per map — the yardstick for channels whose conditioning depends on the checkpoint
+        nets = [n for n in (kw["network_fn"], kw["network_fine"]) if n is not None]
+        for n_ in nets:
+            n_.double()
+        kw["brdf_lut"] = lut.double()
+        q32 = kw["network_query_fn"]              # a few of the reference's intermediates are created as float32 whatever the inputs are
+        kw["network_query_fn"] = lambda inputs, viewdirs, fn: q32(inputs.double(), None if viewdirs is None else viewdirs.double(), fn)
+        with torch.no_grad():
+            ret64 = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays.double(), gt_values={k: v.double() for k, v in gt_t.items()},
+                                    approximate_radiance=True, **kw, **edit)
+        for n_ in nets:
+            n_.float()
+        kw["brdf_lut"] = lut
+        kw["network_query_fn"] = q32
+        for k, v in ret.items():
+            a, b = v.double().numpy(), ret64[k].double().numpy()
+            floor[k] = float(np.nanmax(np.abs(a - b)) / max(float(np.nanmax(np.abs(b))), 1e-30))
+
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(near), far=np.float32(far),
                gain=np.float64(gain), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1),
                n_importance=np.int64(n_importance), n_samples=np.int64(n_samples),
@@ -276,6 +307,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
                mode=np.array(mode))
     for k, v in (flags or {}).items():
         out["flag__" + k] = np.asarray(v)
+    if fitted:
+        out["ckpt"] = np.array("fitted")
     if infer_normal:
         out["flag__infer_normal"] = np.asarray(True)
     if color_independent:
@@ -291,6 +324,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
             out["edit__" + k] = np.asarray(v)
     for k, v in ret.items():
         out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+    for k, v in floor.items():
+        out["floor__" + k] = np.float64(v)
     # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
     passes = ["c", "f"] if n_importance > 0 else ["c"]
     gt_normals = (flags or {}).get("target_normal_map_for_radiance_calculation") in ("ground_truth", "inferred_normal_map")
@@ -412,7 +447,7 @@ def main(only=None):
     run_fixture("cfg1_coarse_g10", torch, R, M, lut, n_rays=128, n_importance=0, gain=1.0, seed=0)
     # configs 2/3 kernel mix: 64+128, well-conditioned and wide-range checkpoints
     run_fixture("plain_g10", torch, R, M, lut, n_rays=256, n_importance=128, gain=1.0, seed=0)
-    run_fixture("plain_g16", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.6, seed=1)
+    run_fixture("plain_g16", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.6, seed=1, n_keep=128, record_floor=True)
     # config 4 / config 5 override paths
     run_fixture("edit_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=2, mode="edit")
     run_fixture("insert_g10", torch, R, M, lut, n_rays=128, n_importance=128, gain=1.0, seed=3, mode="insert")
@@ -446,6 +481,10 @@ def main(only=None):
     # ... evaluated once per ray at the surface point, under an edited depth (the surface point follows the edit)
     run_fixture("infernormal_surface_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=16, infer_normal=True,
                 mode="edit2", flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map", infer_normal_at_surface=True))
+    # the fitted (surface-bearing) checkpoint of fit_checkpoint.py: plain, material edit, object insertion; raw recorded for all rays
+    run_fixture("fitted_plain", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=20, fitted=True, n_keep=96, record_floor=True)
+    run_fixture("fitted_edit", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=21, mode="edit", fitted=True, n_keep=64)
+    run_fixture("fitted_insert", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, mode="insert", fitted=True, n_keep=64)   # (the reference's masked assignments do not run in float64: the floor of fitted_plain stands for all three)
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

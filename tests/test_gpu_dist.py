@@ -1,0 +1,55 @@
+"""The sharded path (BASELINE configs 3 and 5) on a GPU: two ranks under torch.distributed.run.  On a one-GPU box both ranks
+share the device and exchange over gloo (RCCL refuses two ranks on one device; IBLNERF_BENCH_BACKEND=gloo); with two or more
+GPUs visible the same tests run one rank per GPU over RCCL.  The launcher is a fresh child process (nothing is exec'd from this
+GPU-initialised process other than through subprocess)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _launch(script_args, timeout=900):
+    n_gpu = torch.cuda.device_count()
+    assert n_gpu >= 1, "GPU tests need a HIP device"
+    env = dict(os.environ)
+    if n_gpu < 2:
+        env["IBLNERF_BENCH_BACKEND"] = "gloo"
+    else:
+        env.pop("IBLNERF_BENCH_BACKEND", None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env), env.get("IBLNERF_BENCH_BACKEND", "nccl")
+
+
+def test_two_rank_bench_step():
+    """bench.py --gpus 2: each rank renders its 400-row tile of the 800x800 frame on the HIP path, the ranks pack and all-gather
+    the export maps; rank 0 prints the one JSON line with n_gpus = 2."""
+    out, backend = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "rays/s" and d["steps"] == 1
+    assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert ("RCCL" if backend == "nccl" else backend) in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
+    assert d["roofline"]["range_fallbacks"] == 0 and d["roofline"]["launches_per_step"] > 0
+
+
+def test_two_rank_frame_with_overrides_is_bit_identical():
+    """dist.render_frame from two ranks under object-insertion and material-edit gt_values: the gathered frame equals the
+    frame one rank renders alone, bit for bit, on every rank (tests/dist_gpu_worker.py)."""
+    out, _ = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py")])
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "DIST_OK 0" in out.stdout and "DIST_OK 1" in out.stdout

@@ -479,3 +479,51 @@ def test_auxiliary_network_blob_and_checkpoint(tmp_path):
     assert np.array_equal(kw["albedo_mlp"].state_dict()["out_linears.bias"], aux["out_linears.bias"])
     with pytest.raises(ValueError):
         kw["roughness_mlp"].load_state_dict(aux)                                               # 3 rows into a 1-channel network
+
+
+def test_weights_key_cannot_recur():
+    """renderer_for's cache key: models built one after another from different seeds — each freed before the next
+    is built, so CPython hands out the same id() and array addresses again — must never share a key; a reload of the same
+    object must change its key."""
+    import torch
+    from ibl_nerf_amd import renderer as R
+    from torch_ref import RefShaped
+    keys = []
+    for seed in range(6):
+        m = M.IBLNeRF()
+        m.load_state_dict(ck.synthetic_state_dict(seed))
+        keys.append(R._weights_key(m))
+        del m
+    assert len(set(keys)) == 6 and len({k[0] for k in keys}) == 6
+    m = M.IBLNeRF()
+    k0 = R._weights_key(m)
+    assert R._weights_key(m) == k0
+    m.load_state_dict(ck.synthetic_state_dict(3))
+    assert R._weights_key(m) != k0 and R._weights_key(m)[0] == k0[0]
+    nets = []
+    for seed in range(3):                                  # nn.Modules rebuilt and reloaded: same version sums, other tokens
+        n = RefShaped(ck.synthetic_state_dict(seed))
+        nets.append(R._weights_key(n))
+        del n
+    assert len(set(nets)) == 3
+    n = RefShaped(ck.synthetic_state_dict(0))
+    k1 = R._weights_key(n)
+    with torch.no_grad():
+        n.sigma_linear.bias.add_(1.0)                      # an optimizer step
+    assert R._weights_key(n) != k1
+
+
+def test_create_iblnerf_checkpoint_key_errors(tmp_path):
+    """ibl_nerf.py:355-376: elapsed_time comes from the checkpoint; a checkpoint without network_fine_state_dict
+    (N_importance > 0) or without normal_mlp (infer_normal) is a KeyError, never a render with placeholder weights."""
+    os.makedirs(tmp_path / "a")
+    ck.save_checkpoint(str(tmp_path / "a" / "000003.tar"), 3, ck.synthetic_state_dict(1), ck.synthetic_state_dict(2), elapsed_time=12.5)
+    ret = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), expname="a", no_reload=False))
+    assert ret[2] == 3 and ret[3] == 12.5
+    with pytest.raises(KeyError):
+        M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), expname="a", no_reload=False, infer_normal=True))
+    os.makedirs(tmp_path / "b")
+    ck.save_checkpoint(str(tmp_path / "b" / "000003.tar"), 3, ck.synthetic_state_dict(1))          # coarse only
+    with pytest.raises(KeyError):
+        M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), expname="b", no_reload=False))
+    assert M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), expname="b", no_reload=False, N_importance=0))[1]["network_fine"] is None
