@@ -30,6 +30,19 @@ FOV_DEG = 60.0
 NEAR, FAR = 0.5, 8.0
 N_SAMPLES, N_IMPORTANCE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# per mlp_precision: (dtype string, kernels, matrix-core products per algorithmic MAC)
+MODES = {
+    "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for the main, auxiliary and coarse-grid offset queries; "
+                    "f16 + 2x MX-fp6 residual products (~2^-16) for the fine pass's offset queries and the reflected-ray queries; fp32 accumulate",
+                    "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products in the precise queries, 1 f16 + 2 block-scaled fp6 products in the others"),
+    "f16x3": ("f16x3 (f16 hi/lo split, 3 MFMA products, ~2^-22 per operand, fp32 accumulate)", "ibl::f16x3k::mlp_kernel", "3 f16 MFMA products"),
+    "f16_mxfp6": ("f16 + 2x MX-fp6 residual products, fp32 accumulate (fp32 operands to ~2^-16)", "ibl::mxk::mlp_kernel",
+                  "1 f16 + 2 block-scaled fp6 MFMA products (= 1.5 bf16-rate products)"),
+    "f16_mixed": ("f16 + 2x MX-fp6 residual products for the sample-placing and normal queries, plain f16 for the others, fp32 accumulate",
+                  "ibl::mxk::mlp_kernel + ibl::mxk16::mlp_kernel",
+                  "1 f16 + 2 block-scaled fp6 MFMA products in the coarse main and offset queries, 1 f16 product in the fine main and reflected queries"),
+    "bf16x3": ("bf16x3 (bf16 hi/lo split, 3 MFMA products, ~2^-17 per operand, fp32 accumulate)", "ibl::mlp_kernel", "3 bf16 MFMA products"),
+}
 
 
 def load_lut():
@@ -45,12 +58,19 @@ def camera():
     return K, c2w
 
 
-def pmc_traffic():
-    """HBM bytes per MLP launch from the committed rocprofv3 PMC pass (profiles/<round>/pmc.json,
-    written by profiles/summarize.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
-    runs), averaged over the launches of the three kernel variants.  None if no profile is committed."""
+def pmc_traffic(mode):
+    """HBM bytes per MLP launch from a COMMITTED rocprofv3 PMC pass (profiles/<round>_<tag>/pmc.json, written by
+    profiles/summarize.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs), averaged over the launches of
+    the kernel variants — not a counter read in this run.  The newest profile is the one named by profiles/LATEST (one line:
+    a directory name), else the most recently modified pmc.json.  None if no profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json")))
+    latest = os.path.join(ROOT, "profiles", "LATEST")
+    files = []
+    if os.path.exists(latest):
+        cand = os.path.join(ROOT, "profiles", open(latest).read().strip(), "pmc.json")
+        files = [cand] if os.path.exists(cand) else []
+    if not files:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json")), key=os.path.getmtime)
     if not files:
         return None, None
     d = json.load(open(files[-1]))["derived"]
@@ -122,8 +142,9 @@ def main():
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mlp-precision", choices=["f16_mxfp6", "f16_mixed", "bf16x3"], default="f16_mxfp6",
-                    help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision)")
+    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6", "f16x3", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6",
+                    help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
+                         "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
     args = ap.parse_args()
 
     import torch
@@ -208,6 +229,22 @@ def main():
         value_min = H * W / (time.perf_counter() - t1)
         del r2
 
+    # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
+    by_precision = {}
+    if world == 1 and args.mlp_precision == "f16x3_mxfp6" and not args.inference_min:
+        for mode in ("f16x3", "f16_mxfp6"):
+            r3 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=mode)
+            r3.load_weights(0, sdc)
+            r3.load_weights(1, sdf)
+            r3.load_lut(lut)
+            r3.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r3.render_rays(ro, rd, NEAR, FAR)
+            torch.cuda.synchronize()
+            by_precision[mode] = H * W / (time.perf_counter() - t1)
+            del r3
+
     # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
     r.set_profiling(True)
     step()
@@ -217,15 +254,13 @@ def main():
     achieved = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(args.mlp_precision)
         line = {
             "metric": "rays/sec (64c+128f samples) at 800x800 Kitchen; PSNR vs ref",
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f16 + 2x MX-fp6 residual products, fp32 accumulate (fp32 operands to ~2^-16)" if args.mlp_precision == "f16_mxfp6"
-                      else "f16 + 2x MX-fp6 residual products for the sample-placing and normal queries, plain f16 for the others, fp32 accumulate" if args.mlp_precision == "f16_mixed"
-                      else "bf16x3 (bf16 hi/lo split, 3 MFMA products, fp32 accumulate)"),
+            "dtype": MODES[args.mlp_precision][0],
             "data": "synthetic (seeded checkpoint in the reference state-dict schema, synthetic pinhole camera)",
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
@@ -234,17 +269,16 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch (reads x2-corrected + writes) from %s; points in + raw outputs out, weights stay in L2" % traffic_src,
-                         "kernel": ("ibl::mxk::mlp_kernel" if args.mlp_precision == "f16_mxfp6" else "ibl::mxk::mlp_kernel + ibl::mxk16::mlp_kernel" if args.mlp_precision == "f16_mixed" else "ibl::mlp_kernel") + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
+                         "traffic_note": "a committed figure, not a counter read in this run: HBM bytes per launch (reads x2-corrected + writes) of the rocprofv3 PMC pass %s; points in + raw outputs out, weights stay in L2" % traffic_src,
+                         "kernel": MODES[args.mlp_precision][1] + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
                          "range_fallbacks": r.range_fallbacks,
-                         "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues "
-                                 + ("1 f16 + 2 block-scaled fp6 MFMA products (= 1.5 bf16-rate products)" if args.mlp_precision == "f16_mxfp6"
-                                    else "1 f16 + 2 block-scaled fp6 MFMA products in the coarse main and offset queries, 1 f16 product in the fine main and reflected queries" if args.mlp_precision == "f16_mixed"
-                                    else "3 bf16 MFMA products")},
+                         "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues " + MODES[args.mlp_precision][2]},
         }
         if value_min is not None:
             line["value_inference_min"] = value_min
+        if by_precision:
+            line["value_by_mlp_precision"] = dict(by_precision, **{args.mlp_precision: line["value"]})
         if world == 1 and not args.no_cpu_baseline:
             color = maps["color_map"]
 

@@ -17,7 +17,7 @@ EXPORTS = [
     "iblnerf_table_floats", "iblnerf_encode_host", "iblnerf_get_rays", "iblnerf_network_query",
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
     "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
-    "iblnerf_upload_aux_weights", "iblnerf_clear_aux", "iblnerf_composite_pass", "iblnerf_range_peek",
+    "iblnerf_upload_aux_weights", "iblnerf_clear_aux", "iblnerf_composite_pass", "iblnerf_range_peek", "iblnerf_pack_weights_host_f16x3",
 ]
 
 
@@ -34,7 +34,9 @@ class Options(C.Structure):
                 ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32)]
 
 
-MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED = 0, 1, 2
+MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6 = 0, 1, 2, 3, 4
+MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
+                  "f16x3_mxfp6": MLP_F16X3_MXFP6}
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -105,6 +107,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_clear_aux.restype = C.c_int
     lib.iblnerf_upload_lut.argtypes = [C.c_void_p, C.c_void_p]
     lib.iblnerf_pack_weights_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.iblnerf_pack_weights_host_f16x3.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.iblnerf_pack_weights_host_f16x3.restype = C.c_int
     lib.iblnerf_encode_host.argtypes = [C.c_float, C.c_int, C.c_void_p]
     lib.iblnerf_encode_host.restype = None
     lib.iblnerf_get_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

@@ -28,6 +28,11 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 }  // namespace
 
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
+// which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
+static bool wants_mx(int prec) { return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6; }
+static bool wants_f16x3(int prec) { return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6; }
+// query classes of render_rays, for the per-class choice of the product scheme
+enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER };
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
 constexpr int AUX_SLOT0[N_AUX] = {2, 5, 6, 7}, AUX_CHANNELS[N_AUX] = {3, 1, 1, 3}, AUX_RAW_COLUMN[3] = {1, 4, 5};
 
@@ -39,7 +44,8 @@ struct iblnerf_ctx {
     // network slots: 0 coarse, 1 fine, 2.. one trunk-shaped stream per output channel of an auxiliary PositionMLP
     // (albedo r, g, b, roughness, irradiance), allocated on first upload
     char* d_stream[N_SLOTS] = {};
-    char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision == IBLNERF_MLP_F16_MXFP6)
+    char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision F16_MXFP6, F16_MIXED, F16X3_MXFP6)
+    char* d_stream_f16[N_SLOTS] = {};            // f16 (hi, lo) form of d_stream's layout (mlp_precision F16X3, F16X3_MXFP6)
     // [0] activation / input range flag of the MX kernels, [1 + slot] "a weight of this slot is outside the f16 range" (device packer)
     unsigned* d_range_flag = nullptr;
     unsigned* h_range_flag = nullptr;            // pinned snapshot for iblnerf_range_peek
@@ -114,6 +120,15 @@ int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_s
 }
 size_t iblnerf_table_floats(void) { return (size_t)TAB_FLOATS; }
 
+int iblnerf_pack_weights_host_f16x3(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                                    float* h_tables, size_t table_floats) {
+    if (!h_blob || !h_stream || !h_tables) return IBLNERF_ERR_INVALID;
+    if (n_floats != blob_floats() || stream_bytes != (size_t)STREAM_BYTES || table_floats != (size_t)TAB_FLOATS)
+        return IBLNERF_ERR_INVALID;
+    pack_network_f16x3(h_blob, h_stream, h_tables);
+    return IBLNERF_OK;
+}
+
 int iblnerf_pack_weights_host(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
                               float* h_tables, size_t table_floats) {
     if (!h_blob || !h_stream || !h_tables) return IBLNERF_ERR_INVALID;
@@ -143,9 +158,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->mlp_precision != IBLNERF_MLP_BF16X3 && opts->mlp_precision != IBLNERF_MLP_F16_MXFP6 &&
-        opts->mlp_precision != IBLNERF_MLP_F16_MIXED) {
-        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), IBLNERF_MLP_F16_MXFP6 (1) or IBLNERF_MLP_F16_MIXED (2)";
+    if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6) {
+        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3) or _F16X3_MXFP6 (4)";
         return IBLNERF_ERR_INVALID;
     }
     if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
@@ -196,11 +210,16 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                   hipHostMalloc((void**)&c->h_range_flag, N_FLAGS * sizeof(unsigned)) == hipSuccess &&
                   hipEventCreateWithFlags(&c->flag_ev, hipEventDisableTiming) == hipSuccess;
         if (ok) std::memset(c->h_range_flag, 0, N_FLAGS * sizeof(unsigned));
-        for (int w = 0; w < 2 && ok; ++w)
-            ok = hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess &&
-                 hipMemset(c->d_stream_mx[w], 0, mx::STREAM_BYTES) == hipSuccess;
+        for (int w = 0; w < 2 && ok; ++w) {
+            if (wants_mx(opts->mlp_precision))
+                ok = ok && hipMalloc((void**)&c->d_stream_mx[w], mx::STREAM_BYTES) == hipSuccess &&
+                     hipMemset(c->d_stream_mx[w], 0, mx::STREAM_BYTES) == hipSuccess;
+            if (wants_f16x3(opts->mlp_precision))
+                ok = ok && hipMalloc((void**)&c->d_stream_f16[w], STREAM_BYTES) == hipSuccess &&
+                     hipMemset(c->d_stream_f16[w], 0, STREAM_BYTES) == hipSuccess;
+        }
         if (!ok) {
-            g_create_error = "hipMalloc of the f16 + MX-fp6 weight stream failed";
+            g_create_error = "hipMalloc of the f16 weight streams failed";
             iblnerf_destroy(c);
             return IBLNERF_ERR_NOMEM;
         }
@@ -224,6 +243,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_tables[w]) (void)hipFree(c->d_tables[w]);
         if (c->d_stream[w]) (void)hipFree(c->d_stream[w]);
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
+        if (c->d_stream_f16[w]) (void)hipFree(c->d_stream_f16[w]);
     }
     if (c->d_range_flag) (void)hipFree(c->d_range_flag);
     if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
@@ -243,16 +263,23 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     pack_network(h_blob, stream.data(), tab.data());
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, hipDeviceSynchronize());   // a previous render may still be reading the old stream
-    const bool want_mx = c->opt.mlp_precision != IBLNERF_MLP_BF16X3;
+    const bool want_mx = wants_mx(c->opt.mlp_precision), want_f16 = wants_f16x3(c->opt.mlp_precision);
     if (!c->d_stream[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream[slot], STREAM_BYTES));          // auxiliary slots: first use
     if (!c->d_tables[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_tables[slot], TAB_BYTES));
     if (want_mx && !c->d_stream_mx[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream_mx[slot], mx::STREAM_BYTES));
+    if (want_f16 && !c->d_stream_f16[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream_f16[slot], STREAM_BYTES));
     HIP_TRY(c, hipMemcpy(c->d_stream[slot], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tables[slot], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
-    if (want_mx) {
+    if (want_mx || want_f16) {
         bool ok = true;                           // f16(W) must be finite: |w| < 65520 and not NaN
         for (size_t i = 0; i < n_floats && ok; ++i) ok = std::fabs(h_blob[i]) < 65504.0f;
         c->mx_ok[slot] = ok;
+    }
+    if (want_f16) {
+        pack_network_f16x3(h_blob, stream.data(), tab.data());
+        HIP_TRY(c, hipMemcpy(c->d_stream_f16[slot], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
+    }
+    if (want_mx) {
         std::vector<char> smx((size_t)mx::STREAM_BYTES);
         pack_network_mx(h_blob, smx.data(), tab.data());
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[slot], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
@@ -320,7 +347,7 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
     // kernel until its next upload (the activation flag alone cannot be relied on: inf * 0 or -inf through a ReLU can hide it)
     unsigned* wflag = c->d_range_flag ? c->d_range_flag + 1 + which : nullptr;
     if (wflag) HIP_TRY(c, hipMemsetAsync(wflag, 0, sizeof(unsigned), (hipStream_t)stream));
-    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_tables[which], wflag,
+    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_stream_f16[which], c->d_tables[which], wflag,
                                    (hipStream_t)stream));
     c->mx_ok[which] = true;
     c->have_net[which] = true;
@@ -353,17 +380,30 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
 }
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, bool plain_f16 = false) {
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
-    const bool use_mx = c->opt.mlp_precision != IBLNERF_MLP_BF16X3 && c->mx_ok[which];
-    // IBLNERF_MLP_F16_MIXED: queries that neither place samples nor feed the finite-difference normal run in plain f16
-    // (not with HDR radiance, whose unbounded ReLU passes the raw error through, nor when the surface point of the main query is
-    // the input of a normal_mlp)
-    const bool use_mx16 = use_mx && plain_f16 && c->opt.mlp_precision == IBLNERF_MLP_F16_MIXED && variant != VAR_TRUNK &&
-                          !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface);
-    a.stream = use_mx ? c->d_stream_mx[which] : c->d_stream[which];
+    // product scheme of this launch (include/iblnerf.h: mlp_precision).  A network with a weight outside the f16 range runs
+    // on the bf16x3 kernel whatever the mode.
+    const int prec = c->opt.mlp_precision;
+    enum { K_BF16X3, K_F16X3, K_MX, K_MX16 } kern = K_BF16X3;
+    if (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which]) {
+        if (prec == IBLNERF_MLP_F16X3) kern = K_F16X3;
+        else if (prec == IBLNERF_MLP_F16X3_MXFP6)
+            // f16 + fp6 where its 2^-16 is below the channel's own conditioning: the reflected-ray queries (the reference's own
+            // fp64-vs-fp32 runs differ by 1e-2 there on a checkpoint with surfaces) and the offset queries on the dense fine
+            // grid (normal 2e-4); on the coarse grid (spacing 0.12) the same offsets leave 1e-3 on the normal: f16x3
+            kern = (qclass == Q_OFFSET_FINE || qclass == Q_REFL) ? K_MX : K_F16X3;
+        else kern = K_MX;
+        // IBLNERF_MLP_F16_MIXED: queries that neither place samples nor feed the finite-difference normal run in plain f16
+        // (not with HDR radiance, whose unbounded ReLU passes the raw error through, nor when the surface point of the main
+        // query is the input of a normal_mlp)
+        if (prec == IBLNERF_MLP_F16_MIXED && (qclass == Q_MAIN_FINE || qclass == Q_REFL) && variant != VAR_TRUNK &&
+            !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface))
+            kern = K_MX16;
+    }
+    a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
     a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];
     a.pts = pts;
@@ -383,7 +423,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
-    HIP_TRY(c, use_mx16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : use_mx ? launch_mlp_mx(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
+    HIP_TRY(c, kern == K_MX16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : kern == K_MX ? launch_mlp_mx(variant, a, c->n_cu, s)
+               : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     c->flop_alg += (double)n_pts * (variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
@@ -505,13 +546,13 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
-    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, !places_samples);
+    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, places_samples ? Q_MAIN_COARSE : Q_MAIN_FINE);
     if (rc) return rc;
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
     // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
     for (int kind = 0; kind < 3; ++kind)
         for (int ch = 0; c->aux_on[kind] && ch < AUX_CHANNELS[kind]; ++ch) {
-            rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[kind] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[kind] + ch, RAW_CH);
+            rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[kind] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[kind] + ch, RAW_CH, Q_AUX);
             if (rc) return rc;
         }
     const bool inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED;
@@ -519,8 +560,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     if (c->aux_on[IBLNERF_AUX_NORMAL] && at_surface)      // one point per ray: x_surface (:262, :268-271); refl_o is free until pass A
         HIP_TRY(c, launch_surface_points(ro, rd, z, z_stride, c->raw, R, S, ov, c->refl_o, s));
     for (int ch = 0; c->aux_on[IBLNERF_AUX_NORMAL] && ch < 3; ++ch) {   // normal_mlp at the surface point or at every sample (:273)
-        rc = at_surface ? run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->refl_o, nullptr, 1, R, c->nrm_raw + ch, 3)
-                        : run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3);
+        rc = at_surface ? run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->refl_o, nullptr, 1, R, c->nrm_raw + ch, 3, Q_AUX)
+                        : run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3, Q_AUX);
         if (rc) return rc;
     }
     // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
@@ -529,7 +570,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
     if (ov.gt_normal == nullptr && !inferred) {
         HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4);
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, z_stride == 0 ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
         if (rc) return rc;
     }
     const PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
@@ -537,7 +578,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, c->zc, 0, 0.f, R, Sc, c->pts, s));
-    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, true);
+    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
     if (rc) return rc;
     PassBArgs b;
     b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = Sc;
@@ -639,7 +680,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
             if (rc) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, c->zc, 0, 0.f, R, Sc, c->pts, s));
-            rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4);
+            rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE);
             if (rc) return rc;
             HIP_TRY(c, launch_sigma_weights(rd, c->zc, 0, c->sig4, R, Sc, c->w_c, s));
         }

@@ -14,8 +14,8 @@ struct PackMaps {                 // device copies of pack.cpp's build_pack_maps
     const int* mx;
     const int* tab;
 };
-hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, float* d_tab,
-                               unsigned* d_range_flag, hipStream_t s);
+hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, char* d_stream_f16,
+                               float* d_tab, unsigned* d_range_flag, hipStream_t s);   // either fast stream may be null
 
 // --- per-ray kernels (render_kernels.hip) ------------------------------------------------------
 

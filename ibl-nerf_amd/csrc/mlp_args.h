@@ -17,9 +17,10 @@ struct MlpArgs {
                           // column of the main network's raw rows)
     long n_pts;
     int pts_per_ray;
-    unsigned* range_flag; // f16 + MX-fp6 variant only: set to 1 if an input or activation left the f16 range (may be null)
+    unsigned* range_flag; // f16 flavours only: set to 1 if an input or activation left the f16 range (may be null)
 };
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
+hipError_t launch_mlp_f16x3(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);  // three f16 products, same stream layout with f16 pairs
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
 hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
 

@@ -9,6 +9,16 @@
 // global_load_lds (LDS-DMA), one 32 KiB chunk = 48 MFMAs per wave.  Every GEMM runs as three
 // bf16 MFMA products on (hi, lo) splits with fp32 accumulation; the N=1/N=3 heads run on the
 // VALU in fp32 straight from the fp32 accumulators.
+//
+// Two flavours compile from this file:
+//   (default)     bf16 hi/lo splits: ~2^-17 per operand, the full fp32 exponent range — the wide-range fallback;
+//   -DIBL_F16X3   f16 hi/lo splits (namespace f16x3k): the same three products at the same matrix-core rate with ~2^-22 per
+//                 operand (11 + 11 significand bits; f16 denormals are honoured by the MFMA and by v_fma_mix, probed in
+//                 scratch/probe_f16_denorm.hip) — the precise mode.  On a checkpoint with surfaces the density head's
+//                 cancellation amplifies operand round-off ~100x: bf16x3 leaves 2e-3 on sigma (abs) and 2e-3 relative on the
+//                 depth of grazing rays, this flavour 1e-4 / 9e-5 (scratch/prec_probe_fitted.py).  Inputs, weights and
+//                 activations must stay below 65504: the kernel tracks the largest magnitude it converts and raises
+//                 MlpArgs::range_flag (the caller repeats the call on the bf16 flavour).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -19,8 +29,13 @@
 #include "sincos_enc.h"
 
 namespace ibl {
-
+#ifdef IBL_F16X3
+namespace f16x3k {
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (the fragment type keeps its name: 8 x 16-bit operands)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#else
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -44,6 +59,8 @@ __device__ __forceinline__ f32x16 mfma_stub(bf16x8 a, bf16x8 b, f32x16 c) {
     return c;
 }
 #define MFMA(a, b, c) mfma_stub((a), (b), (c))
+#elif defined(IBL_F16X3)
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #endif
@@ -155,6 +172,22 @@ __device__ __forceinline__ float relu_bits(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+#ifdef IBL_F16X3
+// (x0, x1) -> packed f16 pairs hi = rne(x), lo = rne(x - hi): v_cvt_pk_f16_f32, then the residuals in one v_fma_mix{lo,hi}_f16
+// each (they read the f16 half of hi directly and round x - hi, exact in fp32, to f16 — a denormal when |x| < 0.25)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 xv = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(hi));
+}
+// Range guard of this flavour: none in the hot loop (the kernel sits on the register cliff: one more long-lived value costs
+// hundreds of spills).  An activation or input at or beyond 65520 converts to hi = +inf, lo = rne(x - inf) = -inf; the next layer
+// accumulates Wh*(+inf) + Wh*(-inf) = NaN in EVERY output row (0 * inf for a zero weight).  This flavour's ReLU keeps a NaN of
+// either sign (relu_keepnan: compare + select instead of the integer max, free in the shadow of three MFMAs per k-step), so it
+// reaches at least one output channel of that point, and the kernel's tail checks the outputs.
+__device__ __forceinline__ float relu_keepnan(float x) { return !(x <= 0.0f) ? x : 0.0f; }
+#else
 // (x0, x1) -> packed bf16 pairs hi = rne(x), lo = rne(x - hi): cvt_pk, shift, and, packed sub, cvt_pk
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2 xv = {x0, x1};
@@ -162,6 +195,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
     const f32x2 hv = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(xv - hv, bf16x2));
 }
+#endif
 
 // Keeps a value materialised where it is computed (an empty asm the optimiser cannot see through):
 // the consumers of an epilogue's results are a whole layer (or the whole kernel) away, and
@@ -200,8 +234,13 @@ struct Epi {
         float x0 = acc[2 * I], x1 = acc[2 * I + 1];
 #endif
         if constexpr (RELU) {
+#ifdef IBL_F16X3
+            x0 = relu_keepnan(x0);
+            x1 = relu_keepnan(x1);
+#else
             x0 = relu_bits(x0);
             x1 = relu_bits(x1);
+#endif
         }
         if constexpr (STORE) {
             unsigned hh, ll;
@@ -511,10 +550,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         if constexpr (VARIANT == VAR_TRUNK) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
             if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
+#ifdef IBL_F16X3
+            if (valid && !(fabsf(s) < __builtin_inff()) && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);   // range guard (see split_pair)
+#endif
         } else {
             float tot[RAW_CH];
 #pragma unroll
             for (int c = 0; c < RAW_CH; ++c) tot[c] = part[c] + __shfl_xor(part[c], 32) + sc[c];
+#ifdef IBL_F16X3
+            {   // range guard (see split_pair): 0 * x is NaN exactly when x is inf or NaN
+                float chk = 0.0f;
+#pragma unroll
+                for (int c = 0; c < RAW_CH; ++c) chk = fmaf(tot[c], 0.0f, chk);
+                if (valid && chk != chk && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);
+            }
+#endif
             if (valid) {
                 if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + p * RAW_CH;
@@ -550,17 +600,29 @@ constexpr int LDS_LAUNCH = LDS_BYTES + 2048;
 #else
 constexpr int LDS_LAUNCH = LDS_BYTES;
 #endif
+#ifdef IBL_F16X3
+}  // namespace f16x3k
+#define IBL_KNS f16x3k::
+#define IBL_LAUNCH_NAME(V) launch_mlp_f16x3_v##V
+#define IBL_DISPATCH launch_mlp_f16x3
+#else
+#define IBL_KNS
+#define IBL_LAUNCH_NAME(V) launch_mlp_v##V
+#define IBL_DISPATCH launch_mlp
+#endif
 template <int VARIANT>
 static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
-        attr_set = true;
+    static bool attr_set[64] = {};   // per device: one process may hold contexts on several (iblnerf_options.device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
-#define IBL_DEFINE_LAUNCH(V) hipError_t launch_mlp_v##V(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
+#define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
 #if defined(IBL_VARIANT)
 #if IBL_VARIANT == 0
 IBL_DEFINE_LAUNCH(0)
@@ -579,26 +641,26 @@ IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH
 #undef IBL_DEFINE_LAUNCH
 
 #if !defined(IBL_VARIANT) || IBL_VARIANT == 0
-hipError_t launch_mlp_v0(const MlpArgs&, int, hipStream_t);
-hipError_t launch_mlp_v1(const MlpArgs&, int, hipStream_t);
-hipError_t launch_mlp_v2(const MlpArgs&, int, hipStream_t);
-hipError_t launch_mlp_v3(const MlpArgs&, int, hipStream_t);
-hipError_t launch_mlp_v4(const MlpArgs&, int, hipStream_t);
-hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
+hipError_t IBL_LAUNCH_NAME(0)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(1)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(2)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(3)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(4)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
     const int grid = (int)(n_groups < n_cu ? n_groups : n_cu);
     hipError_t rc;
     switch (variant) {
-        case VAR_FULL: rc = launch_mlp_v0(a, grid, stream); break;
-        case VAR_TRUNK: rc = launch_mlp_v1(a, grid, stream); break;
-        case VAR_REFL: rc = launch_mlp_v2(a, grid, stream); break;
-        case VAR_FULL_CI: rc = launch_mlp_v3(a, grid, stream); break;
-        case VAR_REFL_CI: rc = launch_mlp_v4(a, grid, stream); break;
+        case VAR_FULL: rc = IBL_LAUNCH_NAME(0)(a, grid, stream); break;
+        case VAR_TRUNK: rc = IBL_LAUNCH_NAME(1)(a, grid, stream); break;
+        case VAR_REFL: rc = IBL_LAUNCH_NAME(2)(a, grid, stream); break;
+        case VAR_FULL_CI: rc = IBL_LAUNCH_NAME(3)(a, grid, stream); break;
+        case VAR_REFL_CI: rc = IBL_LAUNCH_NAME(4)(a, grid, stream); break;
         default: return hipErrorInvalidValue;
     }
     if (rc != hipSuccess) return rc;
-#ifdef IBL_TRACE
+#if defined(IBL_TRACE) && !defined(IBL_F16X3)
     if (variant == VAR_TRUNK) {
         (void)hipDeviceSynchronize();
         long long h[32];

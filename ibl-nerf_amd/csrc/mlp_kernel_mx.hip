@@ -677,10 +677,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 // with -DIBL_MX_DEV_TRUNK_ONLY, or a plain compile) everything lands in one object.
 template <int VARIANT>
 static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device: one process may hold contexts on several (iblnerf_options.device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)IBL_MXK::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(IBL_MXK::mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
     return hipGetLastError();

@@ -50,6 +50,7 @@ inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; 
 // emitters record that index instead of converting a value, so the SAME traversal yields the gather maps the
 // device packer (pack_kernels.hip) uses.
 bool g_identity = false;
+bool g_split_f16 = false;   // pack_network_f16x3: the same stream with f16 (hi, lo) pairs instead of bf16 ones
 int32_t* g_map_mx = nullptr;
 const char* g_mx_base = nullptr;
 
@@ -58,6 +59,13 @@ inline void put_split(uint16_t* kstep_base, int lane, int e, float w) {
         const uint32_t idx = (uint32_t)w;
         kstep_base[lane * 8 + e] = (uint16_t)(idx & 0xffffu);
         kstep_base[512 + lane * 8 + e] = (uint16_t)(idx >> 16);
+        return;
+    }
+    if (g_split_f16) {                                      // hi = rne_f16(w), lo = rne_f16(w - hi) (exact in fp32; gradual underflow)
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)(w - (float)h);
+        std::memcpy(&kstep_base[lane * 8 + e], &h, 2);
+        std::memcpy(&kstep_base[512 + lane * 8 + e], &l, 2);
         return;
     }
     const uint16_t hi = bf16_rne(w);
@@ -109,6 +117,12 @@ size_t blob_floats() {
     size_t n = 0;
     for (int l = 0; l < N_LAYERS; ++l) n += (size_t)kLayers[l].out * kLayers[l].in + kLayers[l].out;
     return n;  // 798 994
+}
+
+void pack_network_f16x3(const float* blob, void* stream_out, float* tab) {
+    g_split_f16 = true;
+    pack_network(blob, stream_out, tab);
+    g_split_f16 = false;
 }
 
 void pack_network(const float* blob, void* stream_out, float* tab) {

@@ -9,6 +9,8 @@ namespace ibl {
 size_t blob_floats();  // 798 994: floats in one network's state-dict blob
 // blob -> stream_out (STREAM_BYTES) + tab (TAB_FLOATS floats), both host buffers
 void pack_network(const float* blob, void* stream_out, float* tab);
+// the same layout with f16 (hi, lo) pairs (mlp_kernel.hip -DIBL_F16X3); not thread-safe (shares the packer's mode flags)
+void pack_network_f16x3(const float* blob, void* stream_out, float* tab);
 // f16 + MX-fp6 variant (layout_mx.h): stream_out holds mx::STREAM_BYTES, tab as above
 void pack_network_mx(const float* blob, void* stream_out, float* tab);
 // Gather maps for the device packer: entry = 1 + flat blob index of the weight that lands at that position, 0 = zero.

@@ -49,8 +49,9 @@ __device__ __forceinline__ unsigned fp6_block(const float* v, unsigned out[6]) {
     return (unsigned)(se + 127);
 }
 
-// one thread per bf16x3 stream element (k-step, lane, slot)
-__global__ void k_pack_bf16(const float* blob, const unsigned short* id_stream, unsigned short* stream, long n_elems) {
+// one thread per bf16x3 stream element (k-step, lane, slot); the f16x3 stream has the same layout with f16 pairs
+__global__ void k_pack_bf16(const float* blob, const unsigned short* id_stream, unsigned short* stream, unsigned short* stream_f16,
+                            long n_elems, unsigned* range_flag) {
     const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (t >= n_elems) return;
     const long ks = t >> 9, r = t & 511;                       // 512 (lane, slot) pairs per k-step
@@ -61,6 +62,13 @@ __global__ void k_pack_bf16(const float* blob, const unsigned short* id_stream, 
     const float hf = __builtin_bit_cast(float, (unsigned)hi << 16);
     stream[at] = hi;
     stream[at + 512] = bf16_rne(w - hf);
+    if (stream_f16 != nullptr) {
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)(w - (float)h);
+        stream_f16[at] = __builtin_bit_cast(unsigned short, h);
+        stream_f16[at + 512] = __builtin_bit_cast(unsigned short, l);
+        if (!(fabsf(w) < 65504.0f) && range_flag) atomicOr(range_flag, 1u);
+    }
 }
 
 // one thread per (MX block, lane): 32 weights -> f16 fragments, fp6 forms of the weights and of their f16 residuals, scales
@@ -101,11 +109,11 @@ __global__ void k_pack_tab(const float* blob, const int* map, float* tab, int n)
 
 }  // namespace
 
-hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, float* d_tab,
-                               unsigned* d_range_flag, hipStream_t s) {
+hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, char* d_stream_f16,
+                               float* d_tab, unsigned* d_range_flag, hipStream_t s) {
     const long n16 = (long)N_CHUNKS * CHUNK_KSTEPS * 512;
     hipLaunchKernelGGL(k_pack_bf16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, d_blob, maps.id_stream,
-                       reinterpret_cast<unsigned short*>(d_stream_bf16), n16);
+                       reinterpret_cast<unsigned short*>(d_stream_bf16), reinterpret_cast<unsigned short*>(d_stream_f16), n16, d_range_flag);
     hipLaunchKernelGGL(k_pack_tab, dim3((TAB_FLOATS + 255) / 256), dim3(256), 0, s, d_blob, maps.tab, d_tab, TAB_FLOATS);
     if (d_stream_mx != nullptr) {
         const long nl = (long)mx::N_CHUNKS * mx::CHUNK_BLOCKS * 64;

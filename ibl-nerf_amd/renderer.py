@@ -57,10 +57,13 @@ class Renderer:
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
                  epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
-        """mlp_precision: "f16_mxfp6" (default; one f16 + two block-scaled fp6 MFMA products per GEMM, ~2x the
-        rate) or "bf16x3" (three bf16 products, full fp32 range).  The fast mode needs inputs, weights and
-        activations below 65504; the kernel detects anything beyond and `render_rays` / `network_query` then
-        repeat the call on a bf16x3 context, so results never depend on the choice beyond round-off.
+        """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6" (default: three f16 products on hi/lo splits, ~2^-22
+        per operand, for every query whose result is a direct channel and for the coarse grid's offset queries; one f16 + two
+        block-scaled fp6 products, ~2^-16, for the fine pass's offset queries and the reflected-ray queries), "f16x3" (precise
+        everywhere), "f16_mxfp6" (fast everywhere: 1e-3 on direct channels of grazing rays of a checkpoint with surfaces),
+        "f16_mixed" (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three bf16
+        products, 2^-17, the full fp32 range).  The f16 modes need inputs, weights and activations below 65504; the kernels
+        detect anything beyond and `render_rays` / `network_query` then repeat the call on a bf16x3 context.
         range_check: "eager" reads the kernel's range flag after every call (one device synchronisation per call: right
         for frame-sized calls whose results are read back anyway); "lazy" never synchronises: each call looks at the
         snapshot its predecessors left behind (iblnerf_range_peek), and on an out-of-range event warns that the flagged
@@ -68,8 +71,8 @@ class Renderer:
         small queries per step; `check_range()` forces the question, e.g. once per step)."""
         torch = _torch()
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
-        if mlp_precision not in ("bf16x3", "f16_mxfp6", "f16_mixed"):
-            raise ValueError("mlp_precision must be 'bf16x3', 'f16_mxfp6' or 'f16_mixed'")
+        if mlp_precision not in B.MLP_PRECISIONS:
+            raise ValueError("mlp_precision must be one of %s" % sorted(B.MLP_PRECISIONS))
         if range_check not in ("eager", "lazy"):
             raise ValueError("range_check must be 'eager' or 'lazy'")
         self.range_check, self._force_wide = range_check, False
@@ -94,7 +97,7 @@ class Renderer:
         o.device = self.device.index
         o.lindisp = int(bool(lindisp))
         o.use_radiance_linear = int(bool(use_radiance_linear))
-        o.mlp_precision = {"bf16x3": B.MLP_BF16X3, "f16_mxfp6": B.MLP_F16_MXFP6, "f16_mixed": B.MLP_F16_MIXED}[mlp_precision]
+        o.mlp_precision = B.MLP_PRECISIONS[mlp_precision]
         o.normal_mode = NORMAL_MODES[normal_mode]
         o.color_independent_to_direction = int(bool(color_independent_to_direction))
         self.normal_mode = normal_mode
@@ -502,7 +505,7 @@ def _check_supported(kw):
 _renderers = {}
 NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
                 "normal_map_from_depth_gradient_direction_epsilon": 2, "inferred_normal_map": 3}   # target_normal_map_for_radiance_calculation values built
-DEFAULT_MLP_PRECISION = "f16_mxfp6"
+DEFAULT_MLP_PRECISION = "f16x3_mxfp6"
 
 
 _tokens = itertools.count(1)

@@ -61,24 +61,30 @@ typedef struct {
                                           normal_mlp uploaded as IBLNERF_AUX_NORMAL, used as it is; no offset queries) */
     int32_t color_independent_to_direction; /* 0 (shipped) | 1: networks built with is_color_independent_to_direction
                                           (ibl_nerf.py:192): radiance heads read the trunk output, no feature / view layers */
-    int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (both meet the
-                                          1e-3 parity bar; no reference counterpart):
-                                          IBLNERF_MLP_BF16X3    three bf16 products on hi/lo splits, fp32 range
-                                          IBLNERF_MLP_F16_MXFP6 one f16 product + two block-scaled fp6 residual products,
-                                                                faster; inputs and activations must stay below 65504 —
-                                                                see iblnerf_range_status (a network with a weight
-                                                                beyond that runs on the bf16x3 kernel by itself)
-                                          IBLNERF_MLP_F16_MIXED as F16_MXFP6 for the queries that place samples or feed the
-                                                                finite-difference normal (coarse main query, offset queries);
-                                                                one plain f16 product for the others (fine main query,
-                                                                reflected-ray queries), whose 2^-11 per operand stays below
-                                                                1e-4 on every map */
+    int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (no reference counterpart).
+                                          Error per operand / matrix-core slots per 64 MACs of a 32x32 tile:
+                                          IBLNERF_MLP_BF16X3      2^-17 / 12  three bf16 products on hi/lo splits, fp32 range
+                                          IBLNERF_MLP_F16X3       2^-22 / 12  three f16 products on hi/lo splits: the precise mode —
+                                                                  on a checkpoint with surfaces the density head amplifies operand
+                                                                  round-off ~100x and only this mode keeps grazing rays at 1e-4
+                                          IBLNERF_MLP_F16_MXFP6   2^-16 /  6  one f16 product + two block-scaled fp6 residual products
+                                          IBLNERF_MLP_F16X3_MXFP6 (the Python default) F16X3 for the queries whose results are direct channels
+                                                                  (main query of both passes, auxiliary networks,
+                                                                  iblnerf_network_query) and for the coarse grid's offset queries;
+                                                                  F16_MXFP6 for the fine pass's offset queries of the
+                                                                  finite-difference normal (2e-4 on the normal) and for the
+                                                                  reflected-ray queries (ill-conditioned in the reference itself)
+                                          IBLNERF_MLP_F16_MIXED   F16_MXFP6 for the coarse main and offset queries, ONE plain f16
+                                                                  product (2^-11) for the fine main and reflected queries: fine on
+                                                                  random-init fog, 1e-2 on direct channels of a fitted checkpoint
+                                          The f16 modes need inputs, weights and activations below 65504 — see iblnerf_range_status (a
+                                          network with a weight beyond that runs on the bf16x3 kernel by itself) */
     float epsilon_direction;           /* epsilon_direction_for_numerical_normal (0.005): tilt of the four rays of
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
     int32_t infer_normal_at_surface;   /* 0 | 1: the IBLNERF_AUX_NORMAL network is evaluated once per ray at the surface point
                                           o + d * target_depth instead of at every sample (ibl_nerf_renderer.py:268-271) */
 } iblnerf_options;
-enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2 };
+enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3 };
 
@@ -249,6 +255,9 @@ int iblnerf_range_status(iblnerf_ctx* ctx, int* out_of_range);
  * follow a positive answer with iblnerf_range_status. */
 int iblnerf_range_peek(iblnerf_ctx* ctx, int* out_of_range, int* pending);
 
+/* Host-only: the f16 (hi, lo) form of iblnerf_pack_weights_host's stream (IBLNERF_MLP_F16X3), same sizes. */
+int iblnerf_pack_weights_host_f16x3(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
+                                    float* h_tables, size_t table_floats);
 /* Host-only: the IBLNERF_MLP_F16_MXFP6 weight-stream format (csrc/layout_mx.h), for the CPU layout tests. */
 int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
                                  float* h_tables, size_t table_floats);

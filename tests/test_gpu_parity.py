@@ -27,7 +27,10 @@ def R():
     return renderer
 
 
-PRECISIONS = ["bf16x3", "f16_mxfp6"]   # the two product schemes of the fused MLP kernel (include/iblnerf.h: mlp_precision)
+# product schemes of the fused MLP kernel (include/iblnerf.h: mlp_precision): the default mixes the precise f16x3 kernel with the
+# f16 + MX-fp6 one per query class; the others run one kernel for every query
+PRECISIONS = ["f16x3_mxfp6", "f16x3", "f16_mxfp6", "bf16x3"]
+F16_MODES = ["f16x3_mxfp6", "f16x3", "f16_mxfp6"]        # modes with the f16 range guard
 
 
 def make_renderer(R, g, sdc, sdf, lut, **kw):
@@ -338,14 +341,16 @@ def test_training_query_fn_dispatch(R, lut):
     assert M.network_query_fn(pts, dirs, RefShaped(sdc).cuda()).shape == (pts.shape[0], pts.shape[1], 18)
 
 
-def test_f16_range_fallback(R, lut):
-    """f16_mxfp6 on a checkpoint whose activations leave the f16 range: the kernel flags it and the call is
+@pytest.mark.parametrize("prec", F16_MODES)
+def test_f16_range_fallback(R, lut, prec):
+    """An f16 mode on a checkpoint whose activations leave the f16 range: the kernel flags it (f16 + MX-fp6: running maximum
+    of the converted values; f16x3: the overflow turns into NaN outputs, which the kernel's tail checks) and the call is
     repeated on the bf16x3 twin, so the caller gets exactly the bf16x3 result."""
     from ibl_nerf_amd import checkpoint as ck
     g, _, _, _, _ = load_golden("plain_g10")
     sd = {k: (v * np.float32(16.0) if k.endswith("weight") and k.startswith("positions_linears") else v)
           for k, v in ck.synthetic_state_dict(0).items()}          # 16^8 gain through the trunk: activations pass 65504
-    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
+    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision=prec)
     wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
     for r in (fast, wide):
         r.load_weights(0, sd)
@@ -359,8 +364,9 @@ def test_f16_range_fallback(R, lut):
     assert not wide.out_of_range()
 
 
-def test_f16_mode_with_out_of_range_weights(R, lut):
-    """A weight beyond the f16 range: the fast mode runs that network on the bf16x3 kernel from the start
+@pytest.mark.parametrize("prec", F16_MODES)
+def test_f16_mode_with_out_of_range_weights(R, lut, prec):
+    """A weight beyond the f16 range: an f16 mode runs that network on the bf16x3 kernel from the start
     (no device flag, no second render), with the same result as an explicit bf16x3 context."""
     from ibl_nerf_amd import checkpoint as ck
     g, _, _, _, _ = load_golden("plain_g10")
@@ -368,7 +374,7 @@ def test_f16_mode_with_out_of_range_weights(R, lut):
     w = sd["positions_linears.0.weight"].copy()
     w[3, 5] = np.float32(1.0e5)
     sd["positions_linears.0.weight"] = w
-    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
+    fast = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision=prec)
     wide = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision="bf16x3")
     for r in (fast, wide):
         r.load_weights(0, sd)
@@ -393,7 +399,7 @@ def test_device_side_weight_upload_is_bit_identical(R, lut, prec):
     assert torch.equal(host.network_query(pts, dirs, 0), dev.network_query(pts, dirs, 0))
     with pytest.raises(ValueError):
         dev.load_weights(0, {k: torch.from_numpy(v).cuda() for k, v in list(sdc.items())[:-1]})
-    if prec == "f16_mxfp6":                                      # an out-of-range weight is reported through the range flag
+    if prec != "bf16x3":                                         # an out-of-range weight is reported through the range flag
         bad = {k: torch.from_numpy(v).cuda() for k, v in sdc.items()}
         bad["positions_linears.3.weight"][7, 7] = 1.0e5
         dev.load_weights(0, bad)
