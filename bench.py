@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra frames (inference-minimum mode, other product schemes): profiling runs")
     ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6", "f16x3", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
@@ -215,7 +217,7 @@ def main():
     # the same frame with the coarse pass reduced to the density the fine sampling needs (no coarse
     # '...0' maps; SURVEY.md §8 d mode ii) — reported as an extra, never as `value`
     value_min = None
-    if world == 1 and not args.inference_min:
+    if world == 1 and not args.inference_min and not args.no_extras:
         r2 = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=False, max_rays_per_launch=args.rays_per_launch,
                         mlp_precision=args.mlp_precision)
         r2.load_weights(0, sdc)
@@ -231,7 +233,7 @@ def main():
 
     # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
     by_precision = {}
-    if world == 1 and args.mlp_precision == "f16x3_mxfp6" and not args.inference_min:
+    if world == 1 and args.mlp_precision == "f16x3_mxfp6" and not args.inference_min and not args.no_extras:
         for mode in ("f16x3", "f16_mxfp6"):
             r3 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=mode)
             r3.load_weights(0, sdc)
