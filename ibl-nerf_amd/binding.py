@@ -18,6 +18,7 @@ EXPORTS = [
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
     "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
     "iblnerf_upload_aux_weights", "iblnerf_clear_aux", "iblnerf_composite_pass", "iblnerf_range_peek", "iblnerf_pack_weights_host_f16x3",
+    "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query",
 ]
 
 
@@ -68,7 +69,7 @@ class StageInputs(C.Structure):
 
 
 class Outputs(C.Structure):
-    _fields_ = [("fine", Maps), ("coarse", Maps), ("z_std", FP)]
+    _fields_ = [("fine", Maps), ("coarse", Maps), ("z_std", FP), ("inferred_depth_map", FP)]
 
 
 _lib = None
@@ -120,6 +121,14 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_composite_pass.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
                                            C.POINTER(Overrides), C.POINTER(StageInputs), C.POINTER(Maps)]
     lib.iblnerf_composite_pass.restype = C.c_int
+    lib.iblnerf_posdir_floats.argtypes = [C.c_int]
+    lib.iblnerf_posdir_floats.restype = C.c_size_t
+    lib.iblnerf_upload_posdir_mlp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.iblnerf_upload_posdir_mlp.restype = C.c_int
+    lib.iblnerf_clear_posdir_mlp.argtypes = [C.c_void_p]
+    lib.iblnerf_clear_posdir_mlp.restype = C.c_int
+    lib.iblnerf_posdir_query.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, FP]
+    lib.iblnerf_posdir_query.restype = C.c_int
     lib.iblnerf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_last_mlp_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     for n in ("iblnerf_create", "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host",

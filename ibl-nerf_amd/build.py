@@ -46,6 +46,7 @@ SOURCES = [
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=4"], "mlp_kernel_mx16_refl_ci"),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
+    ("posdir_kernel.hip", []),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
 ]

@@ -72,6 +72,39 @@ def synthetic_position_mlp(seed: int, out_ch: int, gain: float = 1.0) -> "Ordere
     return sd
 
 
+def posdir_schema(out_ch: int = 1):
+    """(name, out, in) of the nn.Linear layers of a PositionDirectionMLP (src/networks/MLP.py:32-49; D=8, W=256, input_ch=63,
+    input_ch_views=27, skips=[4]) in registration order — the depth_mlp of infer_depth (ibl_nerf.py:293-297)."""
+    return TRUNK_SCHEMA + (("feature_linear", 256, 256), ("views_linears.0", 128, 283), ("views_linears.1", 128, 128),
+                           ("views_linears.2", 128, 128), ("views_linears.3", 128, 128), ("final_linear", out_ch, 128))
+
+
+def synthetic_position_direction_mlp(seed: int, out_ch: int = 1, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """A seeded PositionDirectionMLP state dict in nn.Module registration order."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name, o, i in posdir_schema(out_ch):
+        sd[name + ".weight"] = (rs.randn(o, i) * gain * np.sqrt(2.0 / i)).astype(np.float32)
+        sd[name + ".bias"] = (rs.randn(o) * 0.1).astype(np.float32)
+    return sd
+
+
+def posdir_blob(sd) -> np.ndarray:
+    """A PositionDirectionMLP state dict -> the flat fp32 blob of iblnerf_upload_posdir_mlp (weight [out,in] row-major, then bias,
+    layer after layer).  Validates names, order and shapes."""
+    out_ch = int(_to_numpy(sd["final_linear.bias"]).shape[0]) if "final_linear.bias" in sd else 1
+    want = [n + sfx for n, _, _ in posdir_schema(out_ch) for sfx in (".weight", ".bias")]
+    if list(sd.keys()) != want:
+        raise KeyError("not a PositionDirectionMLP state dict (D=8, W=256, skips=[4]): %s" % list(sd.keys())[:4])
+    parts = []
+    for name, o, i in posdir_schema(out_ch):
+        w, b = _to_numpy(sd[name + ".weight"]), _to_numpy(sd[name + ".bias"])
+        if w.shape != (o, i) or b.shape != (o,):
+            raise ValueError("%s: expected [%d,%d], got %s" % (name, o, i, w.shape))
+        parts += [np.ascontiguousarray(w, np.float32).ravel(), np.ascontiguousarray(b, np.float32).ravel()]
+    return np.concatenate(parts)
+
+
 def aux_channel_blob(aux_sd, channel: int) -> np.ndarray:
     """One output channel of a PositionMLP as an IBLNeRF-schema blob for iblnerf_upload_aux_weights: its
     positions_linears.*, row `channel` of out_linears in the place of sigma_linear, zeros elsewhere."""
@@ -178,7 +211,7 @@ def load_checkpoint_aux(path: str):
     """The auxiliary networks a reference `.tar` may hold (ibl_nerf.py:369-374): {name: state dict} for the names present."""
     import torch
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    return {k: ckpt[k] for k in AUX_OUT_CH if k in ckpt}
+    return {k: ckpt[k] for k in tuple(AUX_OUT_CH) + ("depth_mlp",) if k in ckpt}
 
 
 def save_checkpoint(path: str, global_step: int, coarse_sd, fine_sd=None, elapsed_time: float = 0.0, aux=None):

@@ -61,6 +61,8 @@ struct iblnerf_ctx {
     float* nrm_raw = nullptr;                 // [ws_rays, Smax, 3] normal_mlp samples (allocated with the first IBLNERF_AUX_NORMAL upload)
     float* d_lut = nullptr;
     bool have_lut = false;
+    float* d_posdir = nullptr;                // PositionDirectionMLP of infer_depth: per layer [Wt | bias] (posdir_kernel.hip)
+    int posdir_out_ch = 0;                    // 0 = none uploaded
     // workspace
     long ws_rays = 0;
     int Sc = 0, Sf = 0, Smax = 0;
@@ -245,6 +247,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
         if (c->d_stream_f16[w]) (void)hipFree(c->d_stream_f16[w]);
     }
+    if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->d_range_flag) (void)hipFree(c->d_range_flag);
     if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
     if (c->flag_ev) (void)hipEventDestroy(c->flag_ev);
@@ -352,6 +355,64 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
     c->mx_ok[which] = true;
     c->have_net[which] = true;
     return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+// (in, out) of the 14 nn.Linear layers of a PositionDirectionMLP in registration order (src/networks/MLP.py:41-49, D = 8, W = 256)
+static void posdir_layers(int out_ch, int (&dims)[14][2]) {
+    const int d[14][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256}, {256, 256}, {256, 256},
+                          {256, 256}, {283, 128}, {128, 128}, {128, 128}, {128, 128}, {128, out_ch}};
+    std::memcpy(dims, d, sizeof d);
+}
+
+size_t iblnerf_posdir_floats(int out_ch) {
+    int dims[14][2];
+    posdir_layers(out_ch, dims);
+    size_t n = 0;
+    for (auto& l : dims) n += (size_t)l[0] * l[1] + l[1];
+    return n;
+}
+
+int iblnerf_upload_posdir_mlp(iblnerf_ctx* c, const float* h_blob, size_t n_floats, int out_ch) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!h_blob || out_ch < 1 || out_ch > 16) return c->fail(IBLNERF_ERR_INVALID, "upload_posdir_mlp: blob non-null, 1 <= out_ch <= 16");
+    if (n_floats != iblnerf_posdir_floats(out_ch))
+        return c->fail(IBLNERF_ERR_INVALID, "upload_posdir_mlp: blob has %zu floats, a PositionDirectionMLP with %d output(s) has %zu", n_floats,
+                       out_ch, iblnerf_posdir_floats(out_ch));
+    int dims[14][2];
+    posdir_layers(out_ch, dims);
+    std::vector<float> packed(n_floats);
+    size_t off = 0;
+    for (auto& l : dims) {                        // weight [out,in] row-major -> [in][out], then the bias
+        const int n_in = l[0], n_out = l[1];
+        for (int o = 0; o < n_out; ++o)
+            for (int i = 0; i < n_in; ++i) packed[off + (size_t)i * n_out + o] = h_blob[off + (size_t)o * n_in + i];
+        std::memcpy(&packed[off + (size_t)n_in * n_out], &h_blob[off + (size_t)n_in * n_out], n_out * sizeof(float));
+        off += (size_t)n_in * n_out + n_out;
+    }
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->d_posdir && c->posdir_out_ch != out_ch) { (void)hipFree(c->d_posdir); c->d_posdir = nullptr; }
+    if (!c->d_posdir) HIP_TRY(c, hipMalloc((void**)&c->d_posdir, n_floats * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->d_posdir, packed.data(), n_floats * sizeof(float), hipMemcpyHostToDevice));
+    c->posdir_out_ch = out_ch;
+    return IBLNERF_OK;
+}
+
+int iblnerf_clear_posdir_mlp(iblnerf_ctx* c) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    c->posdir_out_ch = 0;
+    return IBLNERF_OK;
+}
+
+int iblnerf_posdir_query(iblnerf_ctx* c, void* stream, const float* d_pts, const float* d_viewdirs, int64_t n, float* d_out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!d_pts || !d_viewdirs || !d_out))) return c->fail(IBLNERF_ERR_INVALID, "posdir_query: bad arguments");
+    if (!c->posdir_out_ch) return c->fail(IBLNERF_ERR_STATE, "posdir_query: no PositionDirectionMLP uploaded");
+    if (n == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    PosDirArgs a{c->d_posdir, d_pts, d_viewdirs, d_out, (long)n, c->posdir_out_ch, 0, 0};
+    HIP_TRY(c, launch_posdir_mlp(a, (hipStream_t)stream));
+    return IBLNERF_OK;
 }
 
 int iblnerf_upload_lut(iblnerf_ctx* c, const float* h_rgb) {
@@ -687,6 +748,11 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         HIP_TRY(c, launch_fine_z(c->zc, Sc, c->w_c, R, c->opt.n_importance, c->z_fine, outs->z_std ? outs->z_std + r0 : nullptr, s));
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false);
         if (rc) return rc;
+    }
+    if (c->posdir_out_ch && outs->inferred_depth_map) {   // infer_depth (:722-726): depth_mlp(rays_o, viewdirs), relu of output 0
+        if (c->posdir_out_ch != 1) return c->fail(IBLNERF_ERR_STATE, "render_rays: the depth_mlp must have one output (ibl_nerf.py:294-296)");
+        PosDirArgs a{c->d_posdir, d_rays_o, d_rays_d, outs->inferred_depth_map, (long)n_rays, 1, 1, 1};
+        HIP_TRY(c, launch_posdir_mlp(a, s));
     }
     return arm_range_snapshot(c, s);
 }

@@ -137,4 +137,21 @@ hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* we
 hipError_t launch_fine_z(const float* zc, int Sc, const float* weights_c, long R, int n_imp, float* z_fine,
                          float* z_std, hipStream_t s);
 
+// PositionDirectionMLP (src/networks/MLP.py:32-74), one evaluation per row of pts / dirs (posdir_kernel.hip).
+// weights: per layer [Wt (n_in x n_out, transposed) | bias], layers in registration order (positions_linears.0-7, feature_linear,
+// views_linears.0-3, final_linear) — pack_posdir() in api.cpp.
+struct PosDirArgs {
+    const float* weights;
+    const float* pts;      // [n,3]
+    const float* dirs;     // [n,3]
+    float* out;            // [n,out_ch]
+    long n;
+    int out_ch;
+    int normalize_dirs;    // 1: dirs are rays_d, normalised here (ibl_nerf_renderer.py:795)
+    int relu_out;          // 1: F.relu on the output (:724)
+};
+constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (319L * 256 + 256) + 2 * (256L * 256 + 256) + (256L * 256 + 256) +
+                                    (283L * 128 + 128) + 3 * (128L * 128 + 128) + (128L * 1 + 1);
+hipError_t launch_posdir_mlp(const PosDirArgs& a, hipStream_t s);
+
 }  // namespace ibl

@@ -76,6 +76,35 @@ class PositionMLP:
         return iter(())
 
 
+class PositionDirectionMLP:
+    """Weight container with the schema of src/networks/MLP.py:32-74 (the depth_mlp of infer_depth, ibl_nerf.py:293-297)."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, out_ch=1, skips=(4,)):
+        if (D, W, input_ch, input_ch_views, tuple(skips)) != (8, 256, 63, 27, (4,)):
+            raise NotImplementedError("PositionDirectionMLP is built for D=8, W=256, multires=10, multires_views=4, skips=[4]")
+        self.out_ch = out_ch
+        self._sd = ck.synthetic_position_direction_mlp(0, out_ch)
+        self._version = 0
+
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd):
+        sd = OrderedDict((k, np.array(ck._to_numpy(v), dtype=np.float32)) for k, v in sd.items())
+        ck.posdir_blob(sd)                              # validates names and shapes
+        if sd["final_linear.weight"].shape[0] != self.out_ch:
+            raise ValueError("final_linear has %d rows, this network %d" % (sd["final_linear.weight"].shape[0], self.out_ch))
+        self._sd = sd
+        self._version += 1
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+
 _query_ctx = {}     # id(network) -> {"ref": weakref, "r": Renderer, "w": weights key}
 
 
@@ -133,9 +162,9 @@ def create_IBLNeRF(args):
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
     if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
         raise NotImplementedError("embedders other than multires=10 / multires_views=4 are not built")
-    for flag in ("infer_depth", "infer_visibility"):
-        if getattr(args, flag, False):
-            raise NotImplementedError("%s is outside the shipped-config path (SURVEY.md §8 f-4)" % flag)
+    # ibl_nerf.py:292-304: both are PositionDirectionMLPs; render_rays only ever evaluates the depth_mlp (:722-726)
+    depth_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_depth", False) else None
+    visibility_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_visibility", False) else None
     aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, out_ch=out_ch) if getattr(args, flag, False) else None)
            for name, flag, out_ch in (("albedo_mlp", "infer_albedo_separate", 3), ("roughness_mlp", "infer_roughness_separate", 1),
                                       ("irradiance_mlp", "infer_irradiance_separate", 1), ("normal_mlp", "infer_normal", 3))}   # ibl_nerf.py:307-326
@@ -153,6 +182,8 @@ def create_IBLNeRF(args):
         start = ckpt["global_step"]
         elapsed = ckpt.get("elapsed_time", 0)
         model.load_state_dict(ckpt["network_fn_state_dict"])
+        if depth_mlp is not None:
+            depth_mlp.load_state_dict(ckpt["depth_mlp"])                           # :365-366
         if aux["normal_mlp"] is not None:
             aux["normal_mlp"].load_state_dict(ckpt["normal_mlp"])
         for name in ("albedo_mlp", "roughness_mlp", "irradiance_mlp"):             # lenient `in ckpt` only for these (:369-374)
@@ -165,8 +196,9 @@ def create_IBLNeRF(args):
         "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,
         "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
         "ndc": False, "lindisp": args.lindisp,
-        "depth_mlp": None, "visibility_mlp": None, "normal_mlp": aux["normal_mlp"], "albedo_mlp": aux["albedo_mlp"],
-        "roughness_mlp": aux["roughness_mlp"], "irradiance_mlp": aux["irradiance_mlp"], "infer_depth": False, "infer_visibility": False, "infer_normal": bool(getattr(args, "infer_normal", False)),
+        "depth_mlp": depth_mlp, "visibility_mlp": visibility_mlp, "normal_mlp": aux["normal_mlp"], "albedo_mlp": aux["albedo_mlp"],
+        "roughness_mlp": aux["roughness_mlp"], "irradiance_mlp": aux["irradiance_mlp"], "infer_depth": bool(getattr(args, "infer_depth", False)),
+        "infer_visibility": bool(getattr(args, "infer_visibility", False)), "infer_normal": bool(getattr(args, "infer_normal", False)),
         "infer_normal_at_surface": getattr(args, "infer_normal_at_surface", False),
         "coarse_radiance_number": args.coarse_radiance_number,
         "use_monte_carlo_integration": getattr(args, "use_monte_carlo_integration", False),

@@ -110,6 +110,7 @@ class Renderer:
                           color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction,
                           infer_normal_at_surface=infer_normal_at_surface, range_check=range_check)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
+        self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
         self.range_fallbacks = 0
@@ -174,6 +175,31 @@ class Renderer:
         if self._wide is not None:
             self._wide.load_aux(name, state_dict)
 
+    def load_depth_mlp(self, state_dict):
+        """The depth_mlp of infer_depth (a PositionDirectionMLP, ibl_nerf.py:293-297), or None to remove it: render_rays then
+        returns inferred_depth_map = relu(depth_mlp(rays_o, viewdirs)[..., 0]) (ibl_nerf_renderer.py:722-726)."""
+        if state_dict is None:
+            B.check(self.ctx, self.lib.iblnerf_clear_posdir_mlp(self.ctx))
+        else:
+            blob = np.ascontiguousarray(ck.posdir_blob(state_dict), dtype=np.float32)
+            out_ch = int(ck._to_numpy(state_dict["final_linear.bias"]).shape[0])
+            B.check(self.ctx, self.lib.iblnerf_upload_posdir_mlp(self.ctx, blob.ctypes.data, blob.size, out_ch))
+        self._depth_mlp = state_dict
+        if self._wide is not None:
+            self._wide.load_depth_mlp(state_dict)
+
+    def posdir_query(self, inputs, viewdirs):
+        """network_query_fn(inputs [n,1,3] or [n,3], viewdirs [n,3], depth_mlp) (ibl_nerf.py:327-329): raw outputs [n,1,out_ch]."""
+        torch = _torch()
+        pts = _dev_f32(inputs, self.device).reshape(-1, 3)
+        vd = _dev_f32(viewdirs, self.device).reshape(-1, 3)
+        if vd.shape[0] != pts.shape[0]:
+            raise ValueError("posdir_query: one view direction per point")
+        out_ch = int(ck._to_numpy(self._depth_mlp["final_linear.bias"]).shape[0])
+        out = torch.empty((pts.shape[0], 1, out_ch), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_posdir_query(self.ctx, self._stream(), pts.data_ptr(), vd.data_ptr(), pts.shape[0], out.data_ptr()))
+        return out
+
     def load_lut(self, lut):
         """lut: float [3,512,512] exactly as test.py:79-87 builds `brdf_lut`."""
         if not isinstance(lut, np.ndarray):
@@ -204,6 +230,8 @@ class Renderer:
             for name, sd in self._aux.items():
                 if sd is not None:
                     self._wide.load_aux(name, sd)
+            if self._depth_mlp is not None:
+                self._wide.load_depth_mlp(self._depth_mlp)
             if self._lut is not None:
                 self._wide.load_lut(self._lut)
         self.range_fallbacks += int(count)
@@ -335,6 +363,10 @@ class Renderer:
         if fine:
             z_std = torch.empty((n,), dtype=torch.float32, device=self.device)
             outs.z_std = z_std.data_ptr()
+        inferred_depth = None
+        if self._depth_mlp is not None:
+            inferred_depth = torch.empty((n,), dtype=torch.float32, device=self.device)
+            outs.inferred_depth_map = inferred_depth.data_ptr()
         B.check(self.ctx, self.lib.iblnerf_render_rays(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
                                                        float(near), float(far), C.byref(ov) if ov is not None else None,
                                                        C.byref(outs)))
@@ -348,6 +380,8 @@ class Renderer:
                 res[k + "0"] = t_coarse[k]
         if z_std is not None:
             res["z_std"] = z_std
+        if inferred_depth is not None:
+            res["inferred_depth_map"] = inferred_depth                                 # appended last (:722-726)
         return res
 
     def composite_pass(self, rays_o, rays_d, near, far, z_vals, raw, sigma_offsets, refl_raw, gt_values=None, normal_raw=None, **edit):
@@ -468,7 +502,7 @@ class Renderer:
 # ---------------------------------------------------------------------------------------------
 # reference-signature functions
 # ---------------------------------------------------------------------------------------------
-_UNSUPPORTED_TRUE = ["infer_depth"]
+_UNSUPPORTED_TRUE = []
 # white_bkgd, retraw and use_environment_map are accepted and ignored, as in the reference: render_rays takes the first two and
 # never reads them (ibl_nerf_renderer.py:629-630), and the environment map is created (ibl_nerf.py:331-334) but no renderer code uses it
 # raw2outputs flags that swap a network map for its gt_values row (ibl_nerf_renderer.py:251-252, :320-330)
@@ -483,9 +517,8 @@ def _check_supported(kw):
     for k in _UNSUPPORTED_TRUE:
         if kw.get(k):
             raise NotImplementedError("%s=True is outside the shipped-config forward path built here (SURVEY.md §8 f-4)" % k)
-    for k in ("depth_mlp", "visibility_mlp"):
-        if kw.get(k) is not None:
-            raise NotImplementedError("auxiliary %s (src/networks/MLP.py) is not built (SURVEY.md §8 f-4)" % k)
+    if kw.get("infer_depth") and kw.get("depth_mlp") is None:
+        raise TypeError("infer_depth=True needs depth_mlp")                        # the reference calls run_network(..., None)
     if kw.get("infer_normal") and kw.get("normal_mlp") is None:
         raise TypeError("infer_normal=True needs normal_mlp")                      # the reference calls run_network(..., None)
     if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
@@ -574,6 +607,11 @@ def renderer_for(kw):
         if ent["aux"].get(name) != wk:
             r.load_aux(name, None if net is None else net.state_dict())
             ent["aux"][name] = wk
+    net = kw.get("depth_mlp") if kw.get("infer_depth") else None   # a visibility_mlp is never evaluated by the reference
+    wk = None if net is None else _weights_key(net)
+    if ent.get("depth") != wk:
+        r.load_depth_mlp(None if net is None else net.state_dict())
+        ent["depth"] = wk
     lut = kw["brdf_lut"]
     lk = (lut.data_ptr(), int(lut._version)) if hasattr(lut, "data_ptr") else (lut.ctypes.data, 0)
     if ent["lut"] is None or not _same_object(ent["lut"][0], lut) or ent["lut"][1] != lk:   # a dead referent = another LUT at a recycled address

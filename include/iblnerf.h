@@ -125,6 +125,19 @@ enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE
 int iblnerf_upload_aux_weights(iblnerf_ctx* ctx, int kind, int channel, const float* h_blob, size_t n_floats);
 int iblnerf_clear_aux(iblnerf_ctx* ctx, int kind);
 
+/* replaces: depth_mlp.load_state_dict(ckpt['depth_mlp']) (nerf_models/ibl_nerf.py:293-297, :365-366) and its use under infer_depth
+ * (ibl_nerf_renderer.py:722-726): a PositionDirectionMLP (src/networks/MLP.py:32-74: the trunk, feature_linear, four view layers of
+ * width 128, final_linear) evaluated once per ray at the ray origin with the normalised ray direction; relu of its first output is
+ * outputs.inferred_depth_map.  h_blob = every tensor of its state_dict() in registration order, weight [out,in] row-major then bias
+ * (iblnerf_posdir_floats(out_ch) floats).  Takes effect in iblnerf_render_rays until iblnerf_clear_posdir_mlp.  (The reference also
+ * builds a visibility_mlp of this class under infer_visibility, ibl_nerf.py:299-304, and never evaluates it: nothing to upload.) */
+size_t iblnerf_posdir_floats(int out_ch);
+int iblnerf_upload_posdir_mlp(iblnerf_ctx* ctx, const float* h_blob, size_t n_floats, int out_ch);
+int iblnerf_clear_posdir_mlp(iblnerf_ctx* ctx);
+/* replaces: network_query_fn(inputs, viewdirs, depth_mlp) (ibl_nerf.py:327-329) for the uploaded PositionDirectionMLP:
+ * d_pts [n,3], d_viewdirs [n,3] (one direction per point, used as given) -> d_out [n,out_ch] (no activation). */
+int iblnerf_posdir_query(iblnerf_ctx* ctx, void* stream, const float* d_pts, const float* d_viewdirs, int64_t n, float* d_out);
+
 /* replaces: brdf_lut tensor of test.py:79-87.  h_rgb = float [3,512,512] (R = scale, G = bias). */
 int iblnerf_upload_lut(iblnerf_ctx* ctx, const float* h_rgb);
 
@@ -209,6 +222,7 @@ typedef struct {
     iblnerf_maps fine;      /* un-suffixed keys (the only pass when n_importance == 0) */
     iblnerf_maps coarse;    /* "...0" keys; ignored unless options.coarse_outputs and n_importance > 0 */
     float* z_std;           /* [n] (n_importance > 0) */
+    float* inferred_depth_map; /* [n]; written while a PositionDirectionMLP is uploaded (infer_depth, ibl_nerf_renderer.py:722-726); may be NULL */
 } iblnerf_outputs;
 
 /* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,

@@ -158,6 +158,24 @@ def position_mlp_query(aux_sd, pts):
     return _lin(aux_sd, "out_linears", h).reshape(N, S, -1).astype(F32)
 
 
+def position_direction_mlp_query(sd, pts, viewdirs):
+    """network_query_fn(inputs, viewdirs, depth_mlp) for a PositionDirectionMLP (src/networks/MLP.py:32-74; run_network
+    ibl_nerf.py:236-252): pts [N,S,3], viewdirs [N,3] -> [N,S,out_ch].  Trunk as IBLNeRF's, feature_linear without activation,
+    cat([feature, embedded dirs]) through four ReLU view layers of width 128, final_linear."""
+    N, S = pts.shape[:2]
+    e_p = embed(pts.reshape(-1, 3), 10)
+    e_d = embed(np.repeat(viewdirs[:, None, :], S, 1).reshape(-1, 3), 4)
+    h = e_p
+    for i in range(8):
+        h = relu(_lin(sd, "positions_linears.%d" % i, h))
+        if i == 4:
+            h = np.concatenate([e_p, h], -1)
+    h = np.concatenate([_lin(sd, "feature_linear", h), e_d], -1)
+    for i in range(4):
+        h = relu(_lin(sd, "views_linears.%d" % i, h))
+    return _lin(sd, "final_linear", h).reshape(N, S, -1)
+
+
 # --------------------------------------------------------------------------------------------
 # A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
 # --------------------------------------------------------------------------------------------
@@ -475,6 +493,10 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
             stages.update(c=st_c, f=st_f, z_samples=zs, z_fine=zf)
     elif stages is not None:
         stages.update(c=st_c)
+    if (aux or {}).get("depth_mlp") is not None:                                           # infer_depth, :722-726
+        viewdirs = (rays_d / np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)   # :795
+        out = position_direction_mlp_query(aux["depth_mlp"], rays_o[:, None, :], viewdirs)
+        res["inferred_depth_map"] = relu(out[..., 0]).reshape(-1)
     return res
 
 

@@ -51,7 +51,8 @@ def load_golden(name):
 def golden_aux(g):
     """{'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp': PositionMLP state dict} of a fixture rendered with auxiliary networks."""
     from ibl_nerf_amd import checkpoint as ck
-    return {k[5:]: ck.synthetic_position_mlp(int(g[k]), ck.AUX_OUT_CH[k[5:]], float(g["gain"])) for k in g.files if k.startswith("aux__")}
+    return {k[5:]: (ck.synthetic_position_direction_mlp(int(g[k]), 1, float(g["gain"])) if k == "aux__depth_mlp"
+                    else ck.synthetic_position_mlp(int(g[k]), ck.AUX_OUT_CH[k[5:]], float(g["gain"]))) for k in g.files if k.startswith("aux__")}
 
 
 def rel_linf(x, ref):
@@ -63,7 +64,7 @@ def rel_linf(x, ref):
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
-                   "infernormal_surface_g10"]
+                   "infernormal_surface_g10", "inferdepth_g10"]
 FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert"]   # rendered by the reference from the fitted checkpoint
 
 
@@ -93,7 +94,7 @@ def golden_flags(g):
 
 
 FROM_GT_FLAGS = ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt",
-                 "depth_map_from_ground_truth", "infer_normal")   # per-call flags (render kwargs), not construction options
+                 "depth_map_from_ground_truth", "infer_normal", "infer_depth")   # per-call flags (render kwargs), not construction options
 
 
 def from_gt_flags(g):
@@ -124,4 +125,4 @@ def teacher_pass(g, p):
 
 # fixtures whose recorded main-network raw rows are the whole input of raw2outputs (no auxiliary / normal network outputs, which the
 # recorder does not keep)
-TEACHER_FIXTURES = [n for n in RENDER_FIXTURES if not n.startswith(("auxmlp", "infernormal"))] + FITTED_FIXTURES
+TEACHER_FIXTURES = [n for n in RENDER_FIXTURES if not n.startswith(("auxmlp", "infernormal", "inferdepth"))] + FITTED_FIXTURES

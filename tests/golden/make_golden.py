@@ -51,14 +51,14 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False, infer_normal=False):
+def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False, infer_normal=False, infer_depth=False):
     """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
         multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=n_samples,
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
         color_independent_to_direction=color_independent, use_illumination_feature_layer=False,
-        use_instance_feature_layer=False, device="cpu", infer_depth=False, infer_visibility=False,
+        use_instance_feature_layer=False, device="cpu", infer_depth=infer_depth, infer_visibility=False,
         infer_normal=infer_normal, infer_normal_at_surface=False, infer_albedo_separate=aux,
         infer_roughness_separate=aux, infer_irradiance_separate=aux, use_environment_map=False,
         N_envmap_size=16, lrate=5e-4, lrate_env_map=5e-4, basedir=tmp, expname="exp", ft_path=None,
@@ -109,6 +109,7 @@ class Recorder:
     def __init__(self, torch, R, kw, n_keep):
         self.torch, self.R, self.kw, self.n_keep = torch, R, kw, n_keep
         self.q, self.pdf, self.nrm, self.simple, self.lut = [], [], [], [], []
+        self.depth = None
 
     def __enter__(self):
         R, kw = self.R, self.kw
@@ -119,6 +120,9 @@ class Recorder:
 
         def q(inputs, viewdirs, fn):
             out = self._q0(inputs, viewdirs, fn)
+            if fn is kw.get("depth_mlp"):        # one query per chunk at the ray origins: kept whole (teacher-forced stage test)
+                self.depth = dict(pts=inputs.numpy().copy(), dirs=viewdirs.numpy().copy(), raw=out.numpy().copy())
+                return out
             if any(fn is kw.get(a) for a in ("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp")):
                 return out                       # auxiliary-network queries are not stage boundaries of the main network
             n = inputs.shape[0]
@@ -179,10 +183,10 @@ def fitted_state_dicts():
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
                 n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False,
-                fitted=False, record_floor=False):
+                fitted=False, record_floor=False, infer_depth=False):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal, infer_depth))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
@@ -204,6 +208,11 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         sd_a = ck.synthetic_position_mlp(aux_seeds["normal_mlp"], 3, gain)
         kw["normal_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
         assert kw["infer_normal"] is True
+    if infer_depth:   # depth_mlp: a PositionDirectionMLP evaluated once per ray at the origin (ibl_nerf_renderer.py:722-726)
+        aux_seeds["depth_mlp"] = 100 * seed + 1   # (a seed whose outputs straddle 0: the relu of :724 is exercised)
+        sd_a = ck.synthetic_position_direction_mlp(aux_seeds["depth_mlp"], 1, gain)
+        kw["depth_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
+        assert kw["infer_depth"] is True
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
     kw.update(flags or {})            # flag variants outside the shipped configs
@@ -311,6 +320,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         out["ckpt"] = np.array("fitted")
     if infer_normal:
         out["flag__infer_normal"] = np.asarray(True)
+    if infer_depth:
+        out["flag__infer_depth"] = np.asarray(True)
     if color_independent:
         out["model__color_independent_to_direction"] = np.asarray(True)
     for aux_name, sd_seed in aux_seeds.items():
@@ -341,6 +352,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
             out["normal_raw_%s" % p] = rec.nrm[pi]      # before edit/insert overrides
         out["prefiltered_env_%s" % p] = rec.simple[pi]  # [N,4,3] linear (pre-gamma)
         out["lut_uv_%s" % p], out["lut_val_%s" % p] = rec.lut[pi]["uv"], rec.lut[pi]["val"]
+    if rec.depth is not None:
+        out["q_depth_pts"], out["q_depth_dirs"], out["q_depth_raw"] = rec.depth["pts"], rec.depth["dirs"], rec.depth["raw"]
     if n_importance > 0:
         out["pdf_bins"], out["pdf_weights"], out["pdf_samples"] = rec.pdf[0]["bins"], rec.pdf[0]["weights"], rec.pdf[0]["samples"]
     path = os.path.join(OUT, name + ".npz")
@@ -481,6 +494,8 @@ def main(only=None):
     # ... evaluated once per ray at the surface point, under an edited depth (the surface point follows the edit)
     run_fixture("infernormal_surface_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=16, infer_normal=True,
                 mode="edit2", flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map", infer_normal_at_surface=True))
+    # infer_depth: the depth_mlp (PositionDirectionMLP) once per ray at the origin with the normalised direction; posed camera
+    run_fixture("inferdepth_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=17, infer_depth=True, posed=True)
     # the fitted (surface-bearing) checkpoint of fit_checkpoint.py: plain, material edit, object insertion; raw recorded for all rays
     run_fixture("fitted_plain", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=20, fitted=True, n_keep=96, record_floor=True)
     run_fixture("fitted_edit", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=21, mode="edit", fitted=True, n_keep=64)

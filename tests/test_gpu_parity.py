@@ -45,7 +45,10 @@ def make_renderer(R, g, sdc, sdf, lut, **kw):
         r.load_weights(1, sdf)
     r.load_lut(lut)
     for name, sd in golden_aux(g).items():
-        r.load_aux(name, sd)
+        if name == "depth_mlp":
+            r.load_depth_mlp(sd)
+        else:
+            r.load_aux(name, sd)
     return r
 
 
@@ -218,7 +221,7 @@ def test_render_decomp_dropin_surface(R, lut):
     with pytest.raises(AssertionError):
         R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, insert_object=True,
                         num_insert_objects=0, **kw)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                                              # infer_depth without its network
         R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, infer_depth=True))
     with pytest.raises(ValueError):
         R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, lut_coefficient="Q"))
@@ -535,6 +538,40 @@ def test_create_iblnerf_auxiliary_networks_drop_in(R, lut, tmp_path):
                         aux={k: v for k, v in aux.items() if k != "albedo_mlp"})
     assert rel_linf(ret2["albedo_map"][:8], ref["albedo_map"]) <= 2e-4 and rel_linf(ret2["roughness_map"][:8], ref["roughness_map"]) <= 2e-4
     assert rel_linf(ret2["albedo_map"], g["out__albedo_map"]) > 1e-2 and n == 48
+
+
+def test_infer_depth_drop_in(R, lut, tmp_path):
+    """infer_depth: create_IBLNeRF builds the depth_mlp (a PositionDirectionMLP, ibl_nerf.py:293-297; checkpoint entry 'depth_mlp'),
+    render_decomp appends inferred_depth_map = relu(depth_mlp(rays_o, viewdirs)[..., 0]) (ibl_nerf_renderer.py:722-726); the
+    network's raw query against the reference's recorded one (fp32 kernel: 1e-5)."""
+    import os
+    from ibl_nerf_amd import checkpoint as ck, model as M
+    g, sdc, sdf, _, _ = load_golden("inferdepth_g10")
+    aux = golden_aux(g)
+    os.makedirs(tmp_path / "exp")
+    ck.save_checkpoint(str(tmp_path / "exp" / "000002.tar"), 2, sdc, sdf, aux=aux)
+    _, kw, *_ = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), no_reload=False, infer_depth=True, infer_visibility=True))
+    assert kw["infer_depth"] is True and kw["depth_mlp"].out_ch == 1 and kw["visibility_mlp"] is not None
+    assert np.array_equal(kw["depth_mlp"].state_dict()["final_linear.weight"], aux["depth_mlp"]["final_linear.weight"])
+    kw.update(near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut), max_rays_per_launch=40)
+    rays = torch.from_numpy(np.stack([g["rays_o"], g["rays_d"]], 0))
+    ret = to_np(R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw))
+    assert list(ret)[-1] == "inferred_depth_map" and ret["inferred_depth_map"].shape == (64,)
+    assert np.abs(ret["inferred_depth_map"] - g["out__inferred_depth_map"]).max() <= 1e-5
+    assert (ret["inferred_depth_map"] == 0).any() and (ret["inferred_depth_map"] > 0).any()
+    assert rel_linf(ret["color_map"], g["out__color_map"]) <= 1e-3
+    r = R.renderer_for(kw)
+    raw = r.posdir_query(g["q_depth_pts"], g["q_depth_dirs"]).cpu().numpy()
+    assert raw.shape == g["q_depth_raw"].shape and np.abs(raw - g["q_depth_raw"]).max() <= 1e-5
+    for n in (1, 15, 16, 17, 33):                                               # ragged against the 16-ray workgroup tile
+        got = r.posdir_query(g["q_depth_pts"][:n], g["q_depth_dirs"][:n]).cpu().numpy()
+        assert np.array_equal(got, raw[:n])
+    kw["infer_depth"] = False                                                   # without the flag the map is gone
+    assert "inferred_depth_map" not in R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    from ibl_nerf_amd import binding as B
+    lib = B.load_library()
+    blob = ck.posdir_blob(aux["depth_mlp"])
+    assert lib.iblnerf_upload_posdir_mlp(r.ctx, blob.ctypes.data, blob.size - 1, 1) == -1 and b"floats" in lib.iblnerf_last_error(r.ctx)
 
 
 def test_infer_normal_drop_in(R, lut, tmp_path):

@@ -413,8 +413,12 @@ def test_checkpoint_roundtrip_and_discovery():
         for k in ("network_query_fn", "N_samples", "N_importance", "lut_coefficient", "gamma_correct", "epsilon",
                   "target_normal_map_for_radiance_calculation", "correct_depth_for_prefiltered_radiance_infer"):
             assert k in test
-    with pytest.raises(NotImplementedError):
-        M.create_IBLNeRF(M.default_args(infer_depth=True))                       # a PositionDirectionMLP: not built
+    with tempfile.TemporaryDirectory() as d3:
+        os.makedirs(os.path.join(d3, "exp"))
+        kw3 = M.create_IBLNeRF(M.default_args(basedir=d3, infer_depth=True))[1]       # a PositionDirectionMLP (ibl_nerf.py:293-297)
+        assert kw3["depth_mlp"].out_ch == 1 and kw3["infer_depth"] is True and kw3["visibility_mlp"] is None
+        assert list(kw3["depth_mlp"].state_dict())[-2:] == ["final_linear.weight", "final_linear.bias"]
+        assert ck.posdir_blob(kw3["depth_mlp"].state_dict()).size == 644865
     with tempfile.TemporaryDirectory() as d2:
         os.makedirs(os.path.join(d2, "exp"))
         assert M.create_IBLNeRF(M.default_args(basedir=d2, infer_normal=True))[1]["normal_mlp"].out_ch == 3
@@ -434,9 +438,9 @@ def test_unsupported_flags_raise():
         R._check_supported(dict(base, infer_normal=True))                          # needs the normal_mlp kwarg
     R._check_supported(dict(base, infer_normal=True, normal_mlp=object(), target_normal_map_for_radiance_calculation="inferred_normal_map"))
     R._check_supported(dict(base, infer_normal=True, infer_normal_at_surface=True, normal_mlp=object()))
-    for k in ("infer_depth",):
-        with pytest.raises(NotImplementedError):
-            R._check_supported(dict(base, **{k: True}))
+    with pytest.raises(TypeError):
+        R._check_supported(dict(base, infer_depth=True))                            # needs the depth_mlp kwarg
+    R._check_supported(dict(base, infer_depth=True, depth_mlp=object()))
     with pytest.raises(ValueError):
         R._check_supported(dict(base, target_normal_map_for_radiance_calculation="bogus"))   # ibl_nerf_renderer.py:375
     with pytest.raises(NotImplementedError):

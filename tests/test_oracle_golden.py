@@ -211,3 +211,17 @@ def test_fixture_regenerates_bit_identically(tmp_path):
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:
             assert np.array_equal(new[k], old[k], equal_nan=True) if old[k].dtype.kind == "f" else np.array_equal(new[k], old[k]), (name, k)
+
+
+def test_infer_depth_position_direction_mlp(lut):
+    """infer_depth (ibl_nerf_renderer.py:722-726): the PositionDirectionMLP (src/networks/MLP.py:32-74) once per ray at the ray origin
+    with the normalised direction, teacher-forced on the reference's recorded query and end to end."""
+    g, sdc, sdf, gt, edit = load_golden("inferdepth_g10")
+    aux = golden_aux(g)
+    raw = O.position_direction_mlp_query(aux["depth_mlp"], g["q_depth_pts"], g["q_depth_dirs"])
+    assert raw.shape == g["q_depth_raw"].shape and np.abs(raw - g["q_depth_raw"]).max() <= 1e-5
+    assert np.allclose(np.linalg.norm(g["q_depth_dirs"], axis=-1), 1, atol=1e-6)                  # viewdirs, not rays_d (:723)
+    res = O.render_rays(sdc, sdf, g["rays_o"][:16], g["rays_d"][:16], float(g["near"]), float(g["far"]), lut, aux=aux)
+    ref = g["out__inferred_depth_map"]
+    assert list(res)[-1] == "inferred_depth_map" and np.abs(res["inferred_depth_map"] - ref[:16]).max() <= 1e-5
+    assert (ref == 0).any() and (ref > 0).any()                                                     # both sides of the relu
