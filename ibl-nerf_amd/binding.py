@@ -18,7 +18,7 @@ EXPORTS = [
     "iblnerf_sample_pdf", "iblnerf_render_rays", "iblnerf_set_profiling", "iblnerf_last_mlp_time",
     "iblnerf_range_status", "iblnerf_pack_weights_host_mx", "iblnerf_stream_bytes_mx", "iblnerf_upload_weights_device",
     "iblnerf_upload_aux_weights", "iblnerf_clear_aux", "iblnerf_composite_pass", "iblnerf_range_peek", "iblnerf_pack_weights_host_f16x3",
-    "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query",
+    "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query", "iblnerf_render_rays_sampled", "iblnerf_sample_pdf_u",
 ]
 
 
@@ -66,6 +66,10 @@ class Maps(C.Structure):
 class StageInputs(C.Structure):
     _fields_ = [("n_samples", C.c_int32), ("d_z", FP), ("d_raw", FP), ("d_sigma_offsets", FP), ("d_refl_raw", FP),
                 ("d_normal_raw", FP), ("d_stage", FP), ("d_refl_o", FP), ("d_refl_d", FP)]
+
+
+class Sampling(C.Structure):
+    _fields_ = [("d_t_rand", FP), ("d_u", FP)]
 
 
 class Outputs(C.Structure):
@@ -129,6 +133,11 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_clear_posdir_mlp.restype = C.c_int
     lib.iblnerf_posdir_query.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, FP]
     lib.iblnerf_posdir_query.restype = C.c_int
+    lib.iblnerf_render_rays_sampled.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
+                                                C.POINTER(Overrides), C.POINTER(Sampling), C.POINTER(Outputs)]
+    lib.iblnerf_render_rays_sampled.restype = C.c_int
+    lib.iblnerf_sample_pdf_u.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP]
+    lib.iblnerf_sample_pdf_u.restype = C.c_int
     lib.iblnerf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_last_mlp_time.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     for n in ("iblnerf_create", "iblnerf_upload_weights", "iblnerf_upload_lut", "iblnerf_pack_weights_host",

@@ -66,6 +66,7 @@ struct iblnerf_ctx {
     // workspace
     long ws_rays = 0;
     int Sc = 0, Sf = 0, Smax = 0;
+    float* zc_ray = nullptr;                  // [ws_rays, Sc] jittered coarse grid (perturb > 0), allocated on first use
     float *zc = nullptr, *z_fine = nullptr, *pts = nullptr, *raw = nullptr, *sig4 = nullptr, *w_c = nullptr,
           *w_f = nullptr, *state = nullptr, *refl_o = nullptr, *refl_d = nullptr, *refl_raw = nullptr;
     // profiling
@@ -237,6 +238,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
 
 void iblnerf_destroy(iblnerf_ctx* c) {
     if (!c) return;
+    if (c->zc_ray) (void)hipFree(c->zc_ray);
     float* bufs[] = {c->zc, c->z_fine, c->pts, c->raw, c->sig4, c->w_c, c->w_f, c->state, c->refl_o, c->refl_d,
                      c->refl_raw, c->d_lut, c->nrm_raw};
     for (float* b : bufs)
@@ -507,12 +509,17 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
 
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
                        int n_bins, int n_out, float* d_samples) {
+    return iblnerf_sample_pdf_u(c, stream, d_bins, d_weights, n_rays, n_bins, n_out, nullptr, d_samples);
+}
+
+int iblnerf_sample_pdf_u(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
+                         int n_bins, int n_out, const float* d_u, float* d_samples) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (n_rays < 0 || n_bins < 2 || n_bins > 257 || n_out < 1 || (n_rays > 0 && (!d_bins || !d_weights || !d_samples)))
         return c->fail(IBLNERF_ERR_INVALID, "sample_pdf: need 2 <= n_bins <= 257, n_out >= 1");
     if (n_rays == 0) return IBLNERF_OK;
     HIP_TRY(c, hipSetDevice(c->opt.device));
-    HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_samples,
+    HIP_TRY(c, launch_sample_pdf(d_bins, n_bins, d_weights, n_bins - 1, (long)n_rays, n_bins, n_out, d_u, d_samples,
                                  (hipStream_t)stream));
     return IBLNERF_OK;
 }
@@ -600,9 +607,11 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 }
 
 // One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
+// zc / zc_stride: z_vals_constant, the coarse grid the reflected ray is sampled on (one shared row, or per-ray rows under perturb);
+// coarse_grid: this pass's own samples are that grid.
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
-                     const PassOutputs& out, bool places_samples) {
+                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid) {
     const int Sc = c->Sc;
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
@@ -631,18 +640,18 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
     if (ov.gt_normal == nullptr && !inferred) {
         HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, z_stride == 0 ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
         if (rc) return rc;
     }
     const PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
                                     weights, near_, far_, ov);
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
-    HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, c->zc, 0, 0.f, R, Sc, c->pts, s));
+    HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, Sc, c->pts, s));
     rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
     if (rc) return rc;
     PassBArgs b;
-    b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = Sc;
+    b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = zc; b.zc_stride = zc_stride; b.Sc = Sc;
     b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = R;
     HIP_TRY(c, launch_pass_b(b, s));
     return IBLNERF_OK;
@@ -704,11 +713,21 @@ static OverrideArgs rows_from(const OverrideArgs& ov, const iblnerf_overrides* o
 
 int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                         float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_outputs* outs) {
+    return iblnerf_render_rays_sampled(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, ovr, nullptr, outs);
+}
+
+int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                                float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_sampling* smp,
+                                const iblnerf_outputs* outs) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (n_rays < 0 || !outs) return c->fail(IBLNERF_ERR_INVALID, "render_rays: negative ray count / null outputs");
     if (n_rays == 0) return IBLNERF_OK;   // empty batch: torch hands out null data pointers for zero-row tensors
     if (!d_rays_o || !d_rays_d) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays");
     const bool fine = c->opt.n_importance > 0;
+    const float* t_rand = smp ? smp->d_t_rand : nullptr;
+    const float* u_rand = smp ? smp->d_u : nullptr;
+    if ((t_rand == nullptr) != (u_rand == nullptr) && fine)   // perturb > 0 switches both (det = (perturb == 0), :703)
+        return c->fail(IBLNERF_ERR_INVALID, "render_rays: d_t_rand and d_u go together (perturb > 0 jitters the grid and draws the fine samples)");
     if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
     if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");
     const int fine_net = c->have_net[1] ? 1 : 0;   // run_fn = network_fn if network_fine is None (:705)
@@ -722,6 +741,7 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
     c->flop_alg = 0.0;
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
+    if (t_rand && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
     // equal-sized launches (a short tail launch would leave most of the persistent grid idle)
     const long n_launch = (n_rays + c->ws_rays - 1) / c->ws_rays;
     const long per_launch = n_launch ? (n_rays + n_launch - 1) / n_launch : 0;
@@ -730,23 +750,32 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
         const float* ro = d_rays_o + 3 * r0;
         const float* rd = d_rays_d + 3 * r0;
         const OverrideArgs o = rows_from(ov, ovr, gt_normal, r0);
+        // the coarse grid of this launch: one shared row, or per-ray rows after the stratified jitter (:678-692)
+        const float* zc = c->zc;
+        int zcs = 0;
+        if (t_rand) {
+            HIP_TRY(c, launch_jitter_z(c->zc, Sc, t_rand + r0 * Sc, R, c->zc_ray, s));
+            zc = c->zc_ray;
+            zcs = Sc;
+        }
         int rc;
         if (!fine) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false);
+            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true);
             if (rc) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
-            rc = full_pass(c, s, 0, ro, rd, R, c->zc, 0, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true);
+            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true);
             if (rc) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
-            HIP_TRY(c, launch_make_points(0, ro, rd, c->zc, 0, 0.f, R, Sc, c->pts, s));
+            HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
             rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE);
             if (rc) return rc;
-            HIP_TRY(c, launch_sigma_weights(rd, c->zc, 0, c->sig4, R, Sc, c->w_c, s));
+            HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, R, Sc, c->w_c, s));
         }
-        HIP_TRY(c, launch_fine_z(c->zc, Sc, c->w_c, R, c->opt.n_importance, c->z_fine, outs->z_std ? outs->z_std + r0 : nullptr, s));
-        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false);
+        HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
+                                 outs->z_std ? outs->z_std + r0 : nullptr, s));
+        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false);
         if (rc) return rc;
     }
     if (c->posdir_out_ch && outs->inferred_depth_map) {   // infer_depth (:722-726): depth_mlp(rays_o, viewdirs), relu of output 0

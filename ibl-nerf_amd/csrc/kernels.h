@@ -120,7 +120,8 @@ struct PassBArgs {
     const float* state;        // [R, ST_FLOATS]
     const float* refl_raw;     // [R,64,13]
     const float* refl_d;       // [R,3]
-    const float* zc;           // [Sc] coarse z (z_vals_constant)
+    const float* zc;           // coarse z (z_vals_constant): [Sc], or per-ray rows [R, Sc] with zc_stride = Sc (perturb > 0)
+    int zc_stride = 0;
     int Sc;
     int gamma_correct;
     int radiance_linear;
@@ -130,12 +131,16 @@ struct PassBArgs {
 hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s);
 
 // nerf_renderer_helper.py:91-134 (det=True).  bins [R,nb], weights [R,nb-1] -> samples [R,n_out]
+// u: [R, n_out] uniform draws (det=False) or null (det=True: u = linspace(0, 1, n_out))
 hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, long R, int nb,
-                             int n_out, float* samples, hipStream_t s);
+                             int n_out, const float* u, float* samples, hipStream_t s);
 
 // ibl_nerf_renderer.py:701-707, :718: mids of zc, sample_pdf on weights[:,1:-1], sort(cat), z_std
-hipError_t launch_fine_z(const float* zc, int Sc, const float* weights_c, long R, int n_imp, float* z_fine,
+// zc: one shared row (zc_stride 0) or per-ray rows; u as in launch_sample_pdf
+hipError_t launch_fine_z(const float* zc, int zc_stride, int Sc, const float* weights_c, long R, int n_imp, const float* u, float* z_fine,
                          float* z_std, hipStream_t s);
+// ibl_nerf_renderer.py:678-692 (perturb > 0): z [S] shared base grid, t_rand [R,S] -> out [R,S]
+hipError_t launch_jitter_z(const float* z, int S, const float* t_rand, long R, float* out, hipStream_t s);
 
 // PositionDirectionMLP (src/networks/MLP.py:32-74), one evaluation per row of pts / dirs (posdir_kernel.hip).
 // weights: per layer [Wt (n_in x n_out, transposed) | bias], layers in registration order (positions_linears.0-7, feature_linear,

@@ -121,6 +121,17 @@ __global__ void k_coarse_z(float near, float far, int S, int lindisp, float* __r
                    : near * (1.0f - t) + far * t;                            // :672
 }
 
+// Stratified jitter of the coarse grid (ibl_nerf_renderer.py:678-692, perturb > 0): mids, upper = cat(mids, z[-1]),
+// lower = cat(z[0], mids), z' = lower + (upper - lower) * t_rand — per ray.
+__global__ void k_jitter_z(const float* __restrict__ z, int S, const float* __restrict__ t_rand, long R, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * S) return;
+    const int k = (int)(idx % S);
+    const float lower = k == 0 ? z[0] : 0.5f * (z[k] + z[k - 1]);
+    const float upper = k == S - 1 ? z[S - 1] : 0.5f * (z[k + 1] + z[k]);
+    out[idx] = lower + (upper - lower) * t_rand[idx];
+}
+
 // normal_from_depth.py:64-67: F.normalize(rays_d +- eps * right), F.normalize(rays_d +- eps * up)
 __device__ __forceinline__ void tilted_dirs(const float* d, const float* right, const float* up, float eps, float nd[4][3]) {
 #pragma unroll
@@ -461,8 +472,9 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
-        z[i] = s < S ? a.zc[s] : 0.0f;
-        zn[i] = s + 1 < S ? a.zc[s + 1] : 0.0f;
+        const float* zrow = a.zc + (long)a.zc_stride * r;      // z_vals_constant: one shared row, or per-ray rows under perturb
+        z[i] = s < S ? zrow[s] : 0.0f;
+        zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
         sig[i] = s < S ? a.refl_raw[((long)r * S + s) * REFL_CH] : 0.0f;
     }
     ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
@@ -573,9 +585,10 @@ __global__ __launch_bounds__(256) void k_surface_points(const float* __restrict_
 
 // sample_pdf(det=True), nerf_renderer_helper.py:91-134, for one ray held by one wavefront.
 // cdf/bins live in LDS (nb <= 257).  Writes n_out samples to `dst` (LDS or global).
+// u_row: this ray's n_out uniform draws (det=False, :103), or null for u = linspace(0, 1, n_out) (det=True, :100-101)
 template <class Dst>
 __device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, int nb, int n_out, int lane,
-                                                float* cdf /*LDS [nb]*/, const float* bins /*LDS [nb]*/, Dst&& put) {
+                                                float* cdf /*LDS [nb]*/, const float* bins /*LDS [nb]*/, const float* __restrict__ u_row, Dst&& put) {
     const int nw = nb - 1;
     // lane owns weights lane*NPL .. (contiguous) so the cumulative sum is lane-local + wave scan
     const int npl = (nw + 63) / 64;
@@ -614,7 +627,7 @@ __device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, i
     }
     __builtin_amdgcn_wave_barrier();   // same-wave LDS writes -> reads: in-order LDS queue, compiler inserts the lgkmcnt
     for (int j = lane; j < n_out; j += 64) {
-        const float u = linspace_at(0.0f, 1.0f, n_out, j);
+        const float u = u_row != nullptr ? u_row[j] : linspace_at(0.0f, 1.0f, n_out, j);
         int lo = 0, hi = nb;   // searchsorted(right=True): number of cdf entries <= u
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -632,20 +645,20 @@ __device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, i
 
 __global__ __launch_bounds__(256) void k_sample_pdf(const float* __restrict__ bins, int bins_stride,
                                                    const float* __restrict__ weights, int w_stride, long R, int nb,
-                                                   int n_out, float* __restrict__ samples) {
+                                                   int n_out, const float* __restrict__ u, float* __restrict__ samples) {
     __shared__ float lds[4][2][260];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long r = (long)blockIdx.x * 4 + wv;
     if (r >= R) return;
     for (int k = lane; k < nb; k += 64) lds[wv][1][k] = bins[r * bins_stride + k];
-    sample_pdf_wave(weights + r * w_stride, nb, n_out, lane, lds[wv][0], lds[wv][1],
+    sample_pdf_wave(weights + r * w_stride, nb, n_out, lane, lds[wv][0], lds[wv][1], u ? u + r * n_out : nullptr,
                     [&](int j, float v) { samples[r * n_out + j] = v; });
 }
 
 // z_vals_mid -> sample_pdf(weights[1:-1]) -> sort(cat([z, z_samples])) -> z_std
 // (ibl_nerf_renderer.py:701-707, :718).  Sc + n_imp <= 512.
-__global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc, int Sc, const float* __restrict__ wc,
-                                               long R, int n_imp, float* __restrict__ z_fine,
+__global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc_base, int zc_stride, int Sc, const float* __restrict__ wc,
+                                               long R, int n_imp, const float* __restrict__ u, float* __restrict__ z_fine,
                                                float* __restrict__ z_std) {
     __shared__ float lds[4][2][260];
     __shared__ float vals[4][512];
@@ -653,9 +666,10 @@ __global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc, in
     const long r = (long)blockIdx.x * 4 + wv;
     if (r >= R) return;
     const int nb = Sc - 1;
+    const float* zc = zc_base + (long)zc_stride * r;
     for (int k = lane; k < nb; k += 64) lds[wv][1][k] = 0.5f * (zc[k + 1] + zc[k]);
     for (int k = lane; k < Sc; k += 64) vals[wv][k] = zc[k];
-    sample_pdf_wave(wc + r * Sc + 1, nb, n_imp, lane, lds[wv][0], lds[wv][1],
+    sample_pdf_wave(wc + r * Sc + 1, nb, n_imp, lane, lds[wv][0], lds[wv][1], u ? u + r * n_imp : nullptr,
                     [&](int j, float v) { vals[wv][Sc + j] = v; });
     __builtin_amdgcn_wave_barrier();
     const int n = Sc + n_imp;
@@ -755,19 +769,26 @@ hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, long R, int nb,
-                             int n_out, float* samples, hipStream_t s) {
+                             int n_out, const float* u, float* samples, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     if (nb < 2 || nb > 257 || n_out < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, bins, bins_stride, weights, w_stride,
-                       R, nb, n_out, samples);
+                       R, nb, n_out, u, samples);
     return hipGetLastError();
 }
 
-hipError_t launch_fine_z(const float* zc, int Sc, const float* weights_c, long R, int n_imp, float* z_fine, float* z_std,
-                         hipStream_t s) {
+hipError_t launch_fine_z(const float* zc, int zc_stride, int Sc, const float* weights_c, long R, int n_imp, const float* u, float* z_fine,
+                         float* z_std, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     if (Sc < 3 || Sc > 256 || Sc + n_imp > 512 || n_imp < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fine_z, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, zc, Sc, weights_c, R, n_imp, z_fine, z_std);
+    hipLaunchKernelGGL(k_fine_z, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, zc, zc_stride, Sc, weights_c, R, n_imp, u, z_fine, z_std);
+    return hipGetLastError();
+}
+
+hipError_t launch_jitter_z(const float* z, int S, const float* t_rand, long R, float* out, hipStream_t s) {
+    const long n = R * S;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_jitter_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, S, t_rand, R, out);
     return hipGetLastError();
 }
 

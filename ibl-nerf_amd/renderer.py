@@ -42,6 +42,17 @@ def _torch():
     return torch
 
 
+def _pytest_uniform(n, m):
+    """np.random.seed(0); np.random.rand(n, m) -> float32, as the reference's `pytest` branches draw (ibl_nerf_renderer.py:686-690,
+    nerf_renderer_helper.py:106-113).  Restores the caller's numpy generator state."""
+    torch = _torch()
+    state = np.random.get_state()
+    np.random.seed(0)
+    a = np.random.rand(n, m)
+    np.random.set_state(state)
+    return torch.Tensor(a)
+
+
 def _dev_f32(x, device):
     torch = _torch()
     if isinstance(x, np.ndarray):
@@ -304,14 +315,25 @@ class Renderer:
             return self._wide_twin().network_query(inputs, vd, which)
         return out
 
-    def sample_pdf(self, bins, weights, N_samples):
+    def sample_pdf(self, bins, weights, N_samples, det=True, pytest=False, u=None):
+        """nerf_renderer_helper.py:91-134.  det=False draws u ~ U[0,1) on the device (or takes `u` [n, N_samples]); pytest=True
+        takes numpy's seed-0 stream as the reference's test path does (:106-113)."""
         torch = _torch()
         bins, weights = _dev_f32(bins, self.device), _dev_f32(weights, self.device)
         if weights.shape[-1] != bins.shape[-1] - 1:
             raise ValueError("sample_pdf: weights must have one entry fewer than bins")
-        out = torch.empty((bins.shape[0], N_samples), dtype=torch.float32, device=self.device)
-        B.check(self.ctx, self.lib.iblnerf_sample_pdf(self.ctx, self._stream(), bins.data_ptr(), weights.data_ptr(),
-                                                      bins.shape[0], bins.shape[1], int(N_samples), out.data_ptr()))
+        n = bins.shape[0]
+        if u is None and not det:
+            u = _pytest_uniform(n, int(N_samples)) if pytest else torch.rand((n, int(N_samples)), device=self.device)
+        up = None
+        if u is not None:
+            u = _dev_f32(u, self.device).reshape(n, int(N_samples))
+            up = u.data_ptr()
+        out = torch.empty((n, N_samples), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_sample_pdf_u(self.ctx, self._stream(), bins.data_ptr(), weights.data_ptr(),
+                                                        n, bins.shape[1], int(N_samples), up, out.data_ptr()))
+        if u is not None:
+            torch.cuda.current_stream(self.device).synchronize()       # `u` must outlive the launch
         return out
 
     def _alloc_maps(self, n, S, want=True, irr_ch=1, inferred_normal=False):
@@ -338,17 +360,34 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
-        (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std')."""
+        (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
+        perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
+        stochastic fine samples, from torch.rand on the device; pytest=True takes numpy's seed-0 stream instead, re-seeded for
+        every `chunk` rays exactly as batchify_rays / render_rays / sample_pdf do, so the reference's test path reproduces."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = rays_o.shape[0]
+        smp = None
+        if perturb and float(perturb) > 0.:
+            Sc, Ni = self.N_samples, max(self.N_importance, 1)
+            if pytest:
+                ch = int(chunk or n or 1)
+                t_rand = torch.cat([_pytest_uniform(min(ch, n - i), Sc) for i in range(0, n, ch)] or [torch.zeros((0, Sc))])
+                u = torch.cat([_pytest_uniform(min(ch, n - i), Ni) for i in range(0, n, ch)] or [torch.zeros((0, Ni))])
+                t_rand, u = _dev_f32(t_rand, self.device), _dev_f32(u, self.device)
+            else:
+                t_rand = torch.rand((n, Sc), device=self.device)
+                u = torch.rand((n, Ni), device=self.device)
+            smp = B.Sampling()
+            smp.d_t_rand, smp.d_u = t_rand.data_ptr(), u.data_ptr()
+            self._keep_smp = (t_rand, u)
         lazy = self.range_check == "lazy"
         if lazy:
             self._lazy_poll()
             if self._force_wide:
-                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, **edit)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -367,12 +406,12 @@ class Renderer:
         if self._depth_mlp is not None:
             inferred_depth = torch.empty((n,), dtype=torch.float32, device=self.device)
             outs.inferred_depth_map = inferred_depth.data_ptr()
-        B.check(self.ctx, self.lib.iblnerf_render_rays(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
-                                                       float(near), float(far), C.byref(ov) if ov is not None else None,
-                                                       C.byref(outs)))
+        B.check(self.ctx, self.lib.iblnerf_render_rays_sampled(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
+                                                               float(near), float(far), C.byref(ov) if ov is not None else None,
+                                                               C.byref(smp) if smp is not None else None, C.byref(outs)))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, **edit)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:
@@ -521,8 +560,8 @@ def _check_supported(kw):
         raise TypeError("infer_depth=True needs depth_mlp")                        # the reference calls run_network(..., None)
     if kw.get("infer_normal") and kw.get("normal_mlp") is None:
         raise TypeError("infer_normal=True needs normal_mlp")                      # the reference calls run_network(..., None)
-    if kw.get("perturb", 0.) and float(kw["perturb"]) > 0. or float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
-        raise NotImplementedError("perturb / raw_noise_std > 0 are training-time options (SURVEY.md §8 f-3)")
+    if float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
+        raise NotImplementedError("raw_noise_std > 0 (0 in every shipped config) is not built (SURVEY.md §8 f-3)")
     mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
     if mode not in NORMAL_MODES:
         if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
@@ -646,7 +685,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     edit = {k: kwargs[k] for k in kwargs
             if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
     ret = r.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), _scalar(near, "near"), _scalar(far, "far"),
-                        kwargs.get("gt_values"), **edit)
+                        kwargs.get("gt_values"), perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)),
+                        chunk=chunk, **edit)
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
 
 

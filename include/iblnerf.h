@@ -233,6 +233,22 @@ int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, c
                         int64_t n_rays, float near_, float far_, const iblnerf_overrides* overrides,
                         const iblnerf_outputs* outputs);
 
+/* Training-time sampling (perturb > 0; nerf_models/ibl_nerf_renderer.py:678-692, nerf_renderer_helper.py:98-113): the caller supplies
+ * the uniform [0,1) draws, so that any generator — torch's on the device, or numpy's seeded stream of the reference's `pytest` path —
+ * gives the reference's samples.  d_t_rand [n_rays, N_samples]: stratified jitter of the coarse grid (which then is per ray, also
+ * for the reflected-ray samples: z_vals_constant); d_u [n_rays, N_importance]: the draws sample_pdf(det=False) inverts.  Both or
+ * neither (det = (perturb == 0), :703); NULL struct = iblnerf_render_rays.  raw_noise_std stays 0 (its shipped value). */
+typedef struct {
+    const float* d_t_rand;
+    const float* d_u;
+} iblnerf_sampling;
+int iblnerf_render_rays_sampled(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                                float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_sampling* sampling,
+                                const iblnerf_outputs* outputs);
+/* sample_pdf(bins, weights, N_samples, det=False) with caller-supplied draws d_u [n_rays, n_out] (NULL = det=True). */
+int iblnerf_sample_pdf_u(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
+                         int n_bins, int n_out, const float* d_u, float* d_samples);
+
 /* Teacher-forced stage entry (parity tests): ONE raw2outputs pass (ibl_nerf_renderer.py:153-527, with
  * raw2outputs_simple :38-68 for the reflected ray) on CALLER-SUPPLIED network outputs — no MLP launch.  Feeding the reference's
  * recorded `raw` isolates the compositing / epsilon-normal / shading kernels from the MLP kernel's rounding, so that ill-conditioned

@@ -197,13 +197,14 @@ def alpha_weights(sigma_raw, dists):
 # --------------------------------------------------------------------------------------------
 # A.6 fine sampling — nerf_models/nerf_renderer_helper.py:91-134 with det=True
 # --------------------------------------------------------------------------------------------
-def sample_pdf(bins, weights, n_samples):
+def sample_pdf(bins, weights, n_samples, u=None):
+    """u: [N, n_samples] uniform draws of the det=False branch (:103), None = det=True (u = linspace)."""
     bins = np.asarray(bins, dtype=F32)
     w = (np.asarray(weights, dtype=F32) + F32(1e-5)).astype(F32)
     pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32)
     cdf = np.cumsum(pdf.astype(np.float64), -1).astype(F32)           # double accumulate (ATen CPU)
     cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)
-    u = np.broadcast_to(torch_linspace(0, 1, n_samples), cdf.shape[:-1] + (n_samples,))
+    u = np.broadcast_to(torch_linspace(0, 1, n_samples), cdf.shape[:-1] + (n_samples,)) if u is None else np.asarray(u, dtype=F32)
     nb = cdf.shape[-1]
     inds = np.stack([np.searchsorted(cdf[r], u[r], side="right") for r in range(cdf.shape[0])])
     below = np.maximum(inds - 1, 0)
@@ -469,18 +470,35 @@ def coarse_z(near, far, n_samples, n_rays, lindisp=False):
     return np.broadcast_to(z, (n_rays, n_samples)).copy()
 
 
+def pytest_uniform(n, m):
+    """np.random.seed(0); np.random.rand(n, m) -> float32: the draws of the reference's `pytest` branches
+    (ibl_nerf_renderer.py:686-690, nerf_renderer_helper.py:106-113)."""
+    state = np.random.get_state()
+    np.random.seed(0)
+    a = np.random.rand(n, m).astype(F32)
+    np.random.set_state(state)
+    return a
+
+
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64, n_importance=128,
-                gt=None, edit=None, stages=None, flags=None, aux=None):
+                gt=None, edit=None, stages=None, flags=None, aux=None, t_rand=None, u=None):
+    """t_rand [N, n_samples] / u [N, n_importance]: the uniform draws of perturb > 0 (:678-692 stratified jitter, :703 stochastic
+    fine samples); None = the deterministic test-time path."""
     rays_o = np.ascontiguousarray(rays_o, dtype=F32)
     rays_d = np.ascontiguousarray(rays_d, dtype=F32)
     N = rays_o.shape[0]
     flags = flags or {}
     z = coarse_z(near, far, n_samples, N, bool(flags.get("lindisp", False)))
+    if t_rand is not None:                                                                 # :678-692
+        mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+        upper = np.concatenate([mids, z[:, -1:]], -1)
+        lower = np.concatenate([z[:, :1], mids], -1)
+        z = (lower + (upper - lower) * np.asarray(t_rand, dtype=F32)).astype(F32)
     st_c = {} if stages is not None else None
     res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags, aux)
     if n_importance > 0:
         mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)                             # :701
-        zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance)                       # :702-703
+        zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance, u)                    # :702-703
         zf = np.sort(np.concatenate([z, zs], -1), -1)                                      # :707
         st_f = {} if stages is not None else None
         fine = raw2outputs(sd_fine if sd_fine is not None else sd_coarse, rays_o, rays_d, zf, z,

@@ -207,3 +207,45 @@ def test_lazy_range_check_never_synchronises_and_falls_back(R, lut):
         b = lazy.network_query(pts, dirs, 0)                          # the snapshot of the first call is in: falls back
     assert lazy.range_fallbacks == 1 and torch.equal(b, wide.network_query(pts, dirs, 0))
     assert lazy.check_range() is True and torch.equal(lazy.network_query(pts, None, 0), wide.network_query(pts, None, 0))
+
+
+def test_perturb_pytest_seed_path_vs_reference(R, lut):
+    """perturb = 1 on the HIP path (iblnerf_render_rays_sampled: stratified jitter of the coarse grid, per-ray z_vals_constant for
+    the reflected ray, stochastic inverse-CDF draws) against the reference's run of its own pytest seed path, and chunked as
+    batchify_rays re-seeds it."""
+    g, sdc, sdf, gt, edit = load_golden("perturb_g10")
+    n = g["rays_o"].shape[0]
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=24)            # three launches: the draws are indexed per ray
+    res = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0, perturb=1.0, pytest=True, chunk=n))
+    assert sorted(res) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 2e-4, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 1e-3, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+    assert rel_linf(res["z_std"], g["out__z_std"]) <= 1e-4
+    # the drop-in seam with the reference's kwargs, in chunks of 20 rays: every chunk restarts numpy's seed-0 stream
+    from ibl_nerf_amd import model as M
+    net_c, net_f = M.IBLNeRF(), M.IBLNeRF()
+    net_c.load_state_dict(sdc)
+    net_f.load_state_dict(sdf)
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, perturb=1.0, pytest=True, raw_noise_std=0., lindisp=False,
+              gamma_correct=True, lut_coefficient="F", epsilon=0.01, target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_epsilon",
+              correct_depth_for_prefiltered_radiance_infer=True, near=0.5, far=8.0, brdf_lut=torch.from_numpy(lut), max_rays_per_launch=64)
+    rays = torch.from_numpy(np.stack([g["rays_o"], g["rays_d"]], 0))
+    ch = to_np(R.render_decomp(800, 800, np.eye(3, dtype=np.float32), chunk=20, rays=rays, gt_values={}, approximate_radiance=True, **kw))
+    t20 = np.concatenate([O.pytest_uniform(min(20, n - i), 64) for i in range(0, n, 20)])
+    u20 = np.concatenate([O.pytest_uniform(min(20, n - i), 128) for i in range(0, n, 20)])
+    ora = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut, t_rand=t20, u=u20)
+    for k in ("depth_map", "albedo_map", "weights", "depth_map0", "z_std"):
+        assert rel_linf(ch[k], ora[k]) <= 2e-4, k
+    assert np.array_equal(ch["depth_map"][:20], res["depth_map"][:20]) and not np.array_equal(ch["depth_map"][20:40], res["depth_map"][20:40])
+    # device generator (training): another quadrature every call, finite, weights still sum to the opacity
+    a = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0, perturb=1.0))
+    b = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0, perturb=1.0))
+    assert not np.array_equal(a["depth_map"], b["depth_map"]) and all(np.isfinite(v).all() for v in a.values())
+    assert np.allclose(a["weights"].sum(-1), a["acc_map"], rtol=1e-5) and rel_linf(a["depth_map"], b["depth_map"]) < 5e-2
+    s = r.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128, det=False, pytest=True).cpu().numpy()
+    assert np.abs(s - g["pdf_samples"]).max() <= 5e-5                             # teacher-forced: the reference's bins, weights and draws
+    with pytest.raises(NotImplementedError):
+        R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, raw_noise_std=1.0))

@@ -225,3 +225,27 @@ def test_infer_depth_position_direction_mlp(lut):
     ref = g["out__inferred_depth_map"]
     assert list(res)[-1] == "inferred_depth_map" and np.abs(res["inferred_depth_map"] - ref[:16]).max() <= 1e-5
     assert (ref == 0).any() and (ref > 0).any()                                                     # both sides of the relu
+
+
+def test_perturb_through_the_reference_pytest_seed_path(lut):
+    """perturb = 1 (ibl_nerf_renderer.py:678-692 stratified jitter, :703 sample_pdf(det=False)) pinned through the reference's own
+    deterministic hook: with pytest=True it draws np.random.seed(0); np.random.rand(...) per chunk in both places."""
+    g, sdc, sdf, gt, edit = load_golden("perturb_g10")
+    n = g["rays_o"].shape[0]
+    assert float(g["perturb"]) == 1.0 and int(g["chunk"]) == n
+    t_rand, u = O.pytest_uniform(n, 64), O.pytest_uniform(n, 128)
+    assert np.array_equal(t_rand.ravel()[:128], u.ravel()[:128])                  # both restart the same stream
+    st = {}
+    res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut, stages=st, t_rand=t_rand, u=u)
+    z0 = (g["q_c_main_pts"][:, :, 2] - g["rays_o"][:6, None, 2]) / g["rays_d"][:6, None, 2]      # the jittered coarse grid the reference used
+    zj = O.coarse_z(0.5, 8.0, 64, 1)[0]
+    assert np.abs(z0 - zj).max() > 0.01 and np.all(np.diff(z0, axis=-1) > 0)
+    assert np.abs(st["z_samples"] - g["pdf_samples"]).max() <= 5e-5
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 2e-5, k + sfx
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 6e-4, k + sfx
+    assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
+    det = O.render_rays(sdc, sdf, g["rays_o"][:8], g["rays_d"][:8], 0.5, 8.0, lut)
+    assert rel_linf(det["depth_map"], g["out__depth_map"][:8]) > 1e-4              # it is another quadrature
