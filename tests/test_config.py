@@ -113,3 +113,54 @@ def test_reference_config_files():
     assert e.edit_intrinsic and e.editing_target_roughness_list == [0.0]
     o = Cfg.load_config("/root/reference/configs/IBL-NeRF/living-room-2/object_insert.txt")
     assert o.insert_object and o.num_insert_objects == 4 and len(o.inserting_target_albedo_list) == 12
+
+
+def _same(ours, ref, key):
+    if key.endswith("_list"):
+        return [float(x) for x in (ours or [])] == [float(x) for x in (ref or [])]     # the reference keeps an unset list as None
+    if isinstance(ref, (int, float)) and not isinstance(ref, bool):
+        return float(ours) == float(ref)
+    return ours == ref
+
+
+def test_values_match_the_reference_parser(cfgdir):
+    """The effective values the REFERENCE's recursive_config_parser gives for the config texts above (tests/golden/
+    io_config_expected.json, produced by tests/golden/make_io_golden.py with a configargparse stand-in: pinned as far as that
+    stand-in is faithful), key by key for every flag this reader types."""
+    import json
+    from conftest import GOLDEN
+    expected = json.load(open(os.path.join(GOLDEN, "io_config_expected.json")))
+    assert sorted(expected) == sorted(FILES)
+    for rel, ref in expected.items():
+        ours = vars(Cfg.load_config(str(cfgdir / rel)))
+        for key, want in ref.items():
+            if key == "expname" and want is None:
+                assert ours[key] == os.path.basename(rel).split(".")[0]              # test.py:160-163 fills it from the file name
+                continue
+            assert _same(ours[key], want, key), (rel, key, ours[key], want)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="needs the reference checkout (build container only)")
+def test_shipped_configs_against_the_reference_parser_live():
+    """Every config file the reference ships for the IBL-NeRF scenes, read by the reference's own parser (fresh process, stand-in
+    for configargparse) and by this reader."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    files = sorted(glob.glob("/root/reference/configs/IBL-NeRF/*/*.txt"))
+    assert len(files) >= 10
+    checked = 0
+    for path in files:
+        out = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_io_golden.py"), "--dump-config", path], capture_output=True, text=True,
+                             timeout=120, cwd=os.path.dirname(path))
+        assert out.returncode == 0, (path, out.stderr[-800:])
+        ref = json.loads(out.stdout.strip().splitlines()[-1])
+        ours = vars(Cfg.load_config(path))
+        for key in Cfg.DEFAULTS:
+            if key not in ref or (key == "expname" and ref[key] is None):
+                continue
+            assert _same(ours[key], ref[key], key), (path, key, ours[key], ref[key])
+            checked += 1
+    assert checked > 700

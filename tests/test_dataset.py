@@ -250,3 +250,33 @@ def test_render_test_cli_on_gpu(scene, tmp_path, lut, extra):
         b = np.asarray(Image.open(os.path.join(ref_dir, name))).astype(int)
         assert a.shape == b.shape, name
         assert np.abs(a - b).max() <= (3 if "normal" in name else 1), name             # to8b truncation flips LSBs at 1e-6
+
+
+def test_reader_matches_the_reference_reader(scene):
+    """The same scene through the REFERENCE's MitsubaDataset / NerfDataset (tests/golden/io_dataset_expected.npz, produced by
+    tests/golden/make_io_golden.py with PIL-backed stand-ins for cv2 / imageio and torch's antialiased bilinear filter for
+    torchvision's Resize: pinned as far as those stand-ins are faithful; image_scale 1 only) with test.py's four load-parameter
+    sets — every array bit for bit."""
+    from conftest import GOLDEN
+    root, _ = scene
+    g = np.load(os.path.join(GOLDEN, "io_dataset_expected.npz"))
+    base = dict(image_scale=1, coarse_radiance_number=0, near_plane=1.0, far_plane=20.0, load_depth_range_from_file=True, gamma_correct=True,
+                load_priors=False)
+    modes = {"plain": dict(skip=2), "all": dict(skip=1),
+             "edit": dict(skip=1, load_edit_intrinsic_mask=True, load_edit_albedo=True, load_edit_normal=True, load_edit_depth=True, editing_idx=2),
+             "insert": dict(skip=1, object_insert=True, editing_idx=3)}
+    seen = set()
+    for mode, kw in modes.items():
+        ds = DS.load_dataset("mitsuba", str(root), split="test", **dict(base, **kw))
+        ds.load_all_data(num_of_workers=1)
+        ds.to_tensor("cpu")
+        got = {"hwf": np.array([ds.height, ds.width, ds.focal], np.float64), "near_far": np.array([ds.near, ds.far], np.float64),
+               "len": np.int64(len(ds)), "K": ds.get_focal_matrix(), "poses": ds.poses.numpy(), "images": ds.images.numpy()}
+        for i in range(len(ds)):
+            for k, v in ds.get_resized_normal_albedo(1, i).items():
+                got["gt%d__%s" % (i, k)] = v.numpy() if hasattr(v, "numpy") else np.asarray(v)
+        for k, v in got.items():
+            want = g["%s__%s" % (mode, k)]
+            assert np.asarray(v).shape == want.shape and np.array_equal(np.asarray(v), want), (mode, k)
+            seen.add("%s__%s" % (mode, k))
+    assert seen == set(g.files)
