@@ -32,9 +32,12 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # per mlp_precision: (dtype string, kernels, matrix-core products per algorithmic MAC)
 MODES = {
-    "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for the main, auxiliary and coarse-grid offset queries; "
-                    "f16 + 2x MX-fp6 residual products (~2^-16) for the fine pass's offset queries and the reflected-ray queries; fp32 accumulate",
-                    "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products in the precise queries, 1 f16 + 2 block-scaled fp6 products in the others"),
+    "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
+                    "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
+                    "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in the reflected-ray queries"),
+    "f16x3_main": ("f16 hi/lo splits x3 products for the main, auxiliary and coarse-grid offset queries; f16 + 2x MX-fp6 residual products "
+                   "for the fine pass's offset queries and the reflected-ray queries; fp32 accumulate",
+                   "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products in the precise queries, 1 f16 + 2 block-scaled fp6 products in the others"),
     "f16x3": ("f16x3 (f16 hi/lo split, 3 MFMA products, ~2^-22 per operand, fp32 accumulate)", "ibl::f16x3k::mlp_kernel", "3 f16 MFMA products"),
     "f16_mxfp6": ("f16 + 2x MX-fp6 residual products, fp32 accumulate (fp32 operands to ~2^-16)", "ibl::mxk::mlp_kernel",
                   "1 f16 + 2 block-scaled fp6 MFMA products (= 1.5 bf16-rate products)"),
@@ -144,7 +147,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra frames (inference-minimum mode, other product schemes): profiling runs")
-    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6", "f16x3", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6",
+    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
     args = ap.parse_args()
@@ -234,7 +237,7 @@ def main():
     # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
     by_precision = {}
     if world == 1 and args.mlp_precision == "f16x3_mxfp6" and not args.inference_min and not args.no_extras:
-        for mode in ("f16x3", "f16_mxfp6"):
+        for mode in ("f16x3_main", "f16_mxfp6"):
             r3 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=mode)
             r3.load_weights(0, sdc)
             r3.load_weights(1, sdf)

@@ -29,8 +29,10 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
-static bool wants_mx(int prec) { return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6; }
-static bool wants_f16x3(int prec) { return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6; }
+static bool wants_mx(int prec) {
+    return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN;
+}
+static bool wants_f16x3(int prec) { return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN; }
 // query classes of render_rays, for the per-class choice of the product scheme
 enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER };
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
@@ -161,8 +163,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6) {
-        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3) or _F16X3_MXFP6 (4)";
+    if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MAIN) {
+        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3), _F16X3_MXFP6 (4) or _F16X3_MAIN (5)";
         return IBLNERF_ERR_INVALID;
     }
     if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
@@ -454,9 +456,12 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     if (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which]) {
         if (prec == IBLNERF_MLP_F16X3) kern = K_F16X3;
         else if (prec == IBLNERF_MLP_F16X3_MXFP6)
-            // f16 + fp6 where its 2^-16 is below the channel's own conditioning: the reflected-ray queries (the reference's own
-            // fp64-vs-fp32 runs differ by 1e-2 there on a checkpoint with surfaces) and the offset queries on the dense fine
-            // grid (normal 2e-4); on the coarse grid (spacing 0.12) the same offsets leave 1e-3 on the normal: f16x3
+            // f16 + fp6 only where its 2^-16 is below the channel's own conditioning: the reflected-ray queries (the reference's
+            // own fp64-vs-fp32 runs differ by 2e-2 .. 6e-2 there on a checkpoint with surfaces)
+            kern = qclass == Q_REFL ? K_MX : K_F16X3;
+        else if (prec == IBLNERF_MLP_F16X3_MAIN)
+            // ... and also for the offset queries on the dense fine grid: the normal's worst ray of 1024 goes from 1.9e-4 to
+            // 1.5e-3 (99.9th percentile 3e-4); on the coarse grid (spacing 0.12) the same offsets would leave 1e-3 at 96 rays
             kern = (qclass == Q_OFFSET_FINE || qclass == Q_REFL) ? K_MX : K_F16X3;
         else kern = K_MX;
         // IBLNERF_MLP_F16_MIXED: queries that neither place samples nor feed the finite-difference normal run in plain f16

@@ -234,7 +234,7 @@ struct Epi {
         float x0 = acc[2 * I], x1 = acc[2 * I + 1];
 #endif
         if constexpr (RELU) {
-#ifdef IBL_F16X3
+#if defined(IBL_F16X3) && !defined(IBL_ABLATE_RELU_BITS)   // (timing ablation: the integer-max ReLU, which loses the range guard)
             x0 = relu_keepnan(x0);
             x1 = relu_keepnan(x1);
 #else

@@ -69,12 +69,12 @@ class Renderer:
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
                  epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
         """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6" (default: three f16 products on hi/lo splits, ~2^-22
-        per operand, for every query whose result is a direct channel and for the coarse grid's offset queries; one f16 + two
-        block-scaled fp6 products, ~2^-16, for the fine pass's offset queries and the reflected-ray queries), "f16x3" (precise
-        everywhere), "f16_mxfp6" (fast everywhere: 1e-3 on direct channels of grazing rays of a checkpoint with surfaces),
-        "f16_mixed" (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three bf16
-        products, 2^-17, the full fp32 range).  The f16 modes need inputs, weights and activations below 65504; the kernels
-        detect anything beyond and `render_rays` / `network_query` then repeat the call on a bf16x3 context.
+        per operand, for every query except the reflected-ray ones, which run one f16 + two block-scaled fp6 products, ~2^-16),
+        "f16x3" (precise everywhere), "f16x3_main" (f16 + fp6 also for the fine pass's offset queries: 16 % faster, the normal's
+        worst ray at 1.5e-3 on a checkpoint with surfaces), "f16_mxfp6" (fast everywhere: 1e-2 on direct channels of grazing
+        rays there), "f16_mixed" (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three
+        bf16 products, 2^-17, the full fp32 range).  The f16 modes need inputs, weights and activations below 65504; the
+        kernels detect anything beyond and `render_rays` / `network_query` then repeat the call on a bf16x3 context.
         range_check: "eager" reads the kernel's range flag after every call (one device synchronisation per call: right
         for frame-sized calls whose results are read back anyway); "lazy" never synchronises: each call looks at the
         snapshot its predecessors left behind (iblnerf_range_peek), and on an out-of-range event warns that the flagged

@@ -65,7 +65,17 @@ RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "ins
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
                    "infernormal_surface_g10", "inferdepth_g10"]
-FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert"]   # rendered by the reference from the fitted checkpoint
+FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert", "fitted_wide"]   # rendered by the reference from the fitted checkpoint (fitted_wide: 1 024 rays, maps only)
+
+
+def reference_floor(key, name="fitted_plain"):
+    """The reference's own float64-vs-float32 relative L-inf on map `key` for the fitted checkpoint, as make_golden.py recorded it with
+    fixture `name` (fixtures rendered with edits have none — the reference's masked assignments do not run in float64 — and take
+    fitted_plain's)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if "floor__" + key not in g.files:
+        g = np.load(os.path.join(GOLDEN, "fitted_plain.npz"))
+    return float(g["floor__" + key])
 
 
 def color_independent(g):

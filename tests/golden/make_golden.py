@@ -507,6 +507,8 @@ def main(only=None):
     run_fixture("fitted_plain", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=20, fitted=True, n_keep=96, record_floor=True)
     run_fixture("fitted_edit", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=21, mode="edit", fitted=True, n_keep=64)
     run_fixture("fitted_insert", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, mode="insert", fitted=True, n_keep=64)   # (the reference's masked assignments do not run in float64: the floor of fitted_plain stands for all three)
+    # the same checkpoint on 1 024 rays (maps only): how the worst ray grows with the sample, and the reference's own fp64-vs-fp32 run on it
+    run_fixture("fitted_wide", torch, R, M, lut, n_rays=1024, n_importance=128, gain=1.0, seed=23, fitted=True, n_keep=2, record_floor=True)
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

@@ -14,7 +14,7 @@ import pytest
 
 import iblnerf_oracle as O
 from conftest import (FITTED_FIXTURES, FROM_GT_FLAGS, GOLDEN, TEACHER_FIXTURES, color_independent, from_gt_flags, golden_flags,
-                      load_golden, n_samples, rel_linf, teacher_pass)
+                      load_golden, n_samples, reference_floor, rel_linf, teacher_pass)
 from test_gpu_parity import DERIVED, DIRECT, make_renderer, to_np
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +23,7 @@ torch = pytest.importorskip("torch")
 
 PRECISE = ["f16x3_mxfp6", "f16x3"]                 # the default and the precise-everywhere mode: held to the fixture tolerances
 COARSER = ["bf16x3", "f16_mxfp6", "f16_mixed"]     # 2^-17 / 2^-16 / 2^-11 operands: their error class on this checkpoint is recorded
+# (f16x3_main: the direct channels of f16x3, f16 + fp6 offsets on the fine grid: its normal is recorded on the 1 024-ray fixture)
 REFLECTED = ["specular_map", "color_map", "reflected_radiance_map", "prefiltered_reflected_map",
              "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3"]
 
@@ -35,16 +36,12 @@ def R():
     return renderer
 
 
-def reference_floor(key):
-    return float(np.load(GOLDEN + "/fitted_plain.npz")["floor__" + key])
-
-
 # MLP stage bound per product scheme, relative to each output channel's range over the fixture (density spans -8 .. 100):
 # measured 3.9e-6 / 8.6e-5 / 3.0e-4; the fp32 oracle sits at 4e-7.  iblnerf_network_query is a precise-class query in the default mode.
-STAGE_TOL = {"f16x3_mxfp6": 1e-5, "f16x3": 1e-5, "bf16x3": 2e-4, "f16_mxfp6": 6e-4, "f16_mixed": 6e-4}
+STAGE_TOL = {"f16x3_mxfp6": 1e-5, "f16x3": 1e-5, "f16x3_main": 1e-5, "bf16x3": 2e-4, "f16_mxfp6": 6e-4, "f16_mixed": 6e-4}
 
 
-@pytest.mark.parametrize("prec", PRECISE + COARSER)
+@pytest.mark.parametrize("prec", PRECISE + ["f16x3_main"] + COARSER)
 def test_fitted_network_query_stagewise(R, lut, prec):
     """Teacher-forced MLP on the reference's own query inputs of the fitted checkpoint (all rays of the fixture)."""
     g, sdc, sdf, _, _ = load_golden("fitted_plain")
@@ -65,10 +62,14 @@ def test_fitted_network_query_stagewise(R, lut, prec):
 @pytest.mark.parametrize("prec", PRECISE)
 @pytest.mark.parametrize("name", FITTED_FIXTURES)
 def test_fitted_render_vs_reference_golden(R, name, lut, prec):
-    """End to end on the checkpoint with surfaces, default and precise modes.  Direct channels: the fixture tolerance 2e-4, or
-    8x the reference's own float64-vs-float32 difference on that map where that is larger (one grazing ray of fitted_plain, on
-    which the fp32 oracle itself is 400x its median error: weights 3.9e-5 x 8) — never above the north-star 1e-3.  The normal
-    and what follows from it alone: 1e-3, unchanged.  Reflected-ray channels: 4x the reference's own difference (1.6e-2)."""
+    """End to end on the checkpoint with surfaces, default and precise modes, 96 / 64 / 64 / 1 024 rays.  The yardstick is the
+    reference's own float64-vs-float32 difference on the same rays (fixture keys floor__*): its worst ray grows with the sample
+    (depth 1.9e-5 on 96 rays, 1.8e-4 on 1 024), because rays that graze a surface amplify round-off without bound.
+      maps that are direct channels: 2e-4, or 8x that difference where larger (2^-22 operands against fp32's 2^-24, three products),
+      never above the north-star 1e-3 (measured: 6.5x on the one grazing ray of 96, 2.7x on 1 024 rays);
+      weights (per sample, not a map): 2e-4 or 8x that difference (measured 2.5e-4 on 96 rays, 9.8e-4 on 1 024);
+      the normal and what follows from it alone: 1e-3, unchanged (measured 2.1e-4; 1.4x the reference's own difference);
+      reflected-ray channels: 4x the reference's own difference (1.6e-2 .. 6.4e-2): ill-conditioned in the reference itself."""
     g, sdc, sdf, gt, edit = load_golden(name)
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec)
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
@@ -77,15 +78,17 @@ def test_fitted_render_vs_reference_golden(R, name, lut, prec):
     report = {k: rel_linf(res[k], g["out__" + k]) for k in res}
     for sfx in ("", "0"):
         for k in DIRECT:
-            tol = min(1e-3, max(2e-4, 8 * reference_floor(k)))
+            tol = max(2e-4, 8 * reference_floor(k + sfx, name))
+            if k != "weights":
+                tol = min(1e-3, tol)
             assert report[k + sfx] <= tol, (k + sfx, report[k + sfx], tol)
         for k in DERIVED:
-            tol = max(1e-3, 4 * reference_floor(k)) if k in REFLECTED else 1e-3
+            tol = max(1e-3, 4 * reference_floor(k + sfx, name)) if k in REFLECTED else 1e-3
             assert report[k + sfx] <= tol, (k + sfx, report[k + sfx], tol)
-    assert report["z_std"] <= max(1e-4, 4 * reference_floor("z_std"))
+    assert report["z_std"] <= max(1e-4, 4 * reference_floor("z_std", name))
     # the bulk of the rays sits at fp32 round-off: the bounds above are set by the worst ray
     per_ray = np.abs(res["depth_map"] - g["out__depth_map"]) / np.abs(g["out__depth_map"]).max()
-    assert np.median(per_ray) <= 2e-7 and np.percentile(per_ray, 90) <= 2e-6
+    assert np.median(per_ray) <= 2e-7 and np.percentile(per_ray, 90) <= 2e-6 and np.percentile(per_ray, 99) <= 2e-5
     psnr = 10 * np.log10(1.0 / max(np.mean((res["color_map"].astype(np.float64) - g["out__color_map"]) ** 2), 1e-30))
     assert psnr > 55, psnr
 
@@ -105,6 +108,22 @@ def test_fitted_render_error_class_of_the_coarser_modes(R, lut, prec):
     per_ray = np.abs(res["depth_map"] - g["out__depth_map"]) / np.abs(g["out__depth_map"]).max()
     assert np.median(per_ray) <= (2e-4 if prec == "f16_mixed" else 2e-6)
     assert r.range_fallbacks == 0
+
+
+def test_fitted_wide_error_class_of_f16x3_main(R, lut):
+    """f16x3_main on 1 024 rays of the fitted checkpoint: direct channels exactly those of f16x3 (the same kernels produce them),
+    the normal's worst ray an order above (1.5e-3 against 1.9e-4; 99.9th percentile 3e-4) — why its f16 + fp6 offset queries
+    on the fine grid are an opt-in and not the default.  Bounds: the measured class x2."""
+    g, sdc, sdf, gt, edit = load_golden("fitted_wide")
+    out = {}
+    for prec in ("f16x3_main", "f16x3"):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec)
+        out[prec] = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0))
+    for k in ("depth_map", "albedo_map", "weights", "depth_map0", "target_normal_map0"):
+        assert np.array_equal(out["f16x3_main"][k], out["f16x3"][k]), k
+    e = lambda p: np.abs(out[p]["target_normal_map"] - g["out__target_normal_map"]).max(-1)
+    assert e("f16x3").max() <= 4e-4 and e("f16x3_main").max() <= 3e-3 and np.percentile(e("f16x3_main"), 99.9) <= 6e-4
+    assert e("f16x3_main").max() > 2 * e("f16x3").max()
 
 
 @pytest.mark.parametrize("name", TEACHER_FIXTURES)

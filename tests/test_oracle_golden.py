@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import iblnerf_oracle as O
-from conftest import FITTED_FIXTURES, GOLDEN, RENDER_FIXTURES, TEACHER_FIXTURES, teacher_pass, color_independent, golden_aux, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
+from conftest import FITTED_FIXTURES, GOLDEN, RENDER_FIXTURES, TEACHER_FIXTURES, reference_floor, teacher_pass, color_independent, golden_aux, golden_flags, ill_conditioned, load_golden, n_samples, rel_linf
 
 # Channels that are smooth functions of the MLP outputs: the oracle must sit at fp32 round-off.
 DIRECT = ["weights", "depth_map", "acc_map", "disp_map", "albedo_map", "roughness_map", "irradiance_map",
@@ -143,12 +143,6 @@ REFLECTED = ["specular_map", "color_map", "reflected_radiance_map", "prefiltered
              "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3"]
 
 
-def reference_floor(key):
-    """The reference's own fp64-vs-fp32 relative L-inf on `key` for the fitted checkpoint (recorded by make_golden.py)."""
-    g = np.load(GOLDEN + "/fitted_plain.npz")
-    return float(g["floor__" + key])
-
-
 @pytest.mark.parametrize("name", FITTED_FIXTURES)
 def test_fitted_checkpoint_end_to_end(name, lut):
     """The oracle against the reference on a checkpoint with surfaces (tests/golden/fit_checkpoint.py): direct channels, the
@@ -161,11 +155,15 @@ def test_fitted_checkpoint_end_to_end(name, lut):
     assert float(g["out__weights0"].max()) > 0.9 and float(g["out__acc_map"].min()) > 0.999          # surfaces, not fog
     for sfx in ("", "0"):
         for k in DIRECT:
-            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 1e-4, k + sfx
+            # fp32 against fp32: the oracle's worst ray sits where the reference's own float64-vs-float32 difference does
+            tol = max(1e-4, 2 * reference_floor(k + sfx, name))
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]), tol)
         for k in DERIVED:
-            tol = 4 * reference_floor(k) if k in REFLECTED else 6e-4
+            tol = 4 * reference_floor(k + sfx, name) if k in REFLECTED else max(6e-4, 2 * reference_floor(k + sfx, name))
             assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]), tol)
     assert reference_floor("prefiltered_reflected_map") > 5e-3 > reference_floor("target_normal_map")   # the fact the tolerances rest on
+    # the worst ray grows with the sample: 96 rays 1.9e-5 on depth, 1 024 rays 1.8e-4 — in the reference's own arithmetic
+    assert reference_floor("depth_map", "fitted_wide") > 5 * reference_floor("depth_map", "fitted_plain")
 
 
 @pytest.mark.parametrize("name", TEACHER_FIXTURES)
