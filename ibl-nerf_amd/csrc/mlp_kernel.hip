@@ -183,10 +183,11 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 }
 // Range guard of this flavour: none in the hot loop (the kernel sits on the register cliff: one more long-lived value costs
 // hundreds of spills).  An activation or input at or beyond 65520 converts to hi = +inf, lo = rne(x - inf) = -inf; the next layer
-// accumulates Wh*(+inf) + Wh*(-inf) = NaN in EVERY output row (0 * inf for a zero weight).  This flavour's ReLU keeps a NaN of
-// either sign (relu_keepnan: compare + select instead of the integer max, free in the shadow of three MFMAs per k-step), so it
-// reaches at least one output channel of that point, and the kernel's tail checks the outputs.
-__device__ __forceinline__ float relu_keepnan(float x) { return !(x <= 0.0f) ? x : 0.0f; }
+// accumulates Wh*(+inf) + Wh*(-inf) = NaN in EVERY output row (0 * inf for a zero weight) — the NEGATIVE quiet NaN 0xffc00000
+// (scratch/probe_mfma_nan.hip), which the integer-max ReLU of the bf16 flavour would turn into 0.  This flavour's ReLU is gfx950's
+// v_maximum3_f32 (IEEE 754-2019 maximum: a NaN operand of either sign propagates; one instruction, like the integer max), so the
+// NaN reaches at least one output channel of that point, and the kernel's tail checks the outputs.
+__device__ __forceinline__ float relu_keepnan(float x) { return __builtin_elementwise_maximum(x, 0.0f); }
 #else
 // (x0, x1) -> packed bf16 pairs hi = rne(x), lo = rne(x - hi): cvt_pk, shift, and, packed sub, cvt_pk
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
