@@ -85,15 +85,26 @@ def pmc_traffic(mode):
     return (num / den if den else None), os.path.relpath(files[-1], ROOT)
 
 
+def load_checkpoint(kind):
+    """The two networks of the benchmark: "fitted" = the checkpoint with surfaces that tests/golden/fit_checkpoint.py fitted with the
+    reference's own modules (tests/golden/fitted_ckpt.npz: the stand-in for BASELINE configs[1]'s "pretrained checkpoint"; no real one
+    ships with the reference), "synthetic" = round 1's seeded random-init networks (fog).  The work per ray is the same either way
+    (fixed sample counts, no early termination); the operand statistics the matrix cores see are not."""
+    from ibl_nerf_amd import checkpoint as ck
+    if kind == "fitted":
+        f = np.load(os.path.join(ROOT, "tests", "golden", "fitted_ckpt.npz"))
+        return ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
+    return ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
+
+
 def _cpu_worker(job):
     """One oracle process: renders its batches of seeded pixels with `threads` OpenBLAS threads."""
-    seeds, sels, threads = job
+    kind, sels, threads = job
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import iblnerf_oracle as O
     from threadpoolctl import threadpool_limits
     _pkg.load()
-    from ibl_nerf_amd import checkpoint as ck
-    sdc, sdf = ck.synthetic_state_dict(seeds[0], 1.0), ck.synthetic_state_dict(seeds[1], 1.0)
+    sdc, sdf = load_checkpoint(kind)
     lut = load_lut()
     K, c2w = camera()
     ro, rd = O.get_rays(H, W, K, c2w)
@@ -108,7 +119,7 @@ def _cpu_worker(job):
     return dt, np.concatenate(out) if out else np.zeros((0, 3), np.float32)
 
 
-def cpu_baseline(gpu_color_fn, batch=256, batches_per_worker=3, threads=16):
+def cpu_baseline(gpu_color_fn, kind, batch=256, batches_per_worker=3, threads=16):
     """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view, on as many of the host's
     cores as it scales to: independent processes of `threads` OpenBLAS threads each (the oracle's many small sgemms run
     2.6x SLOWER with one 64-thread pool than with 16 threads: 57 vs 150 rays/s), at most 8 processes.  Workers are
@@ -121,7 +132,7 @@ def cpu_baseline(gpu_color_fn, batch=256, batches_per_worker=3, threads=16):
     jobs = []
     for w in range(workers):
         sels = [pix[(w * batches_per_worker + b) * batch:(w * batches_per_worker + b + 1) * batch] for b in range(batches_per_worker)]
-        jobs.append(((0, 1), sels, threads))
+        jobs.append((kind, sels, threads))
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_cpu_worker, jobs)
     t = max(r[0] for r in res)
@@ -144,6 +155,8 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=65536)
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
+    ap.add_argument("--checkpoint", choices=["fitted", "synthetic"], default="fitted",
+                    help="fitted: the checkpoint with surfaces (tests/golden/fitted_ckpt.npz); synthetic: round 1's random-init networks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra frames (inference-minimum mode, other product schemes): profiling runs")
@@ -180,7 +193,7 @@ def main():
 
     pkg = _pkg.load()
     from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R
-    sdc, sdf = ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
+    sdc, sdf = load_checkpoint(args.checkpoint)
     lut = load_lut()
     K, c2w = camera()
     r = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=not args.inference_min,
@@ -266,10 +279,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": MODES[args.mlp_precision][0],
-            "data": "synthetic (seeded checkpoint in the reference state-dict schema, synthetic pinhole camera)",
+            "data": ("synthetic (checkpoint fitted to an analytic scene with the reference's own modules, reference state-dict schema; synthetic pinhole camera)"
+                     if args.checkpoint == "fitted" else "synthetic (seeded random-init checkpoint in the reference state-dict schema, synthetic pinhole camera)"),
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
-                       "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
+                       "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -290,7 +304,7 @@ def main():
             def gpu_color(idx):
                 return color[torch.as_tensor(idx, device=color.device)].cpu().numpy()
 
-            line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color)
+            line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color, args.checkpoint)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
