@@ -268,3 +268,33 @@ def test_perturb_pytest_seed_path_vs_reference(R, lut):
     assert np.abs(s - g["pdf_samples"]).max() <= 5e-5                             # teacher-forced: the reference's bins, weights and draws
     with pytest.raises(NotImplementedError):
         R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, raw_noise_std=1.0))
+
+
+def test_full_frame_of_the_fitted_checkpoint(R, lut):
+    """BASELINE configs[1] at full size on the checkpoint with surfaces: 640 000 rays, 64 + 128 samples, default mode, no range fallback;
+    the 1 024 pixels of the frame that fixture fitted_wide holds (rendered by the reference) at that fixture's tolerances, and
+    size-independent properties of the whole frame."""
+    g, sdc, sdf, _, _ = load_golden("fitted_wide")
+    r = R.Renderer(64, 128)
+    r.load_weights(0, sdc)
+    r.load_weights(1, sdf)
+    r.load_lut(lut)
+    f = np.float32(0.5 * 800 / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[f, 0, 400], [0, f, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    ro, rd = r.get_rays(800, 800, K, c2w)
+    m = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
+    torch.cuda.synchronize()
+    assert r.range_fallbacks == 0 and all(bool(torch.isfinite(v).all()) for v in m.values())
+    assert float((m["target_normal_map"].norm(dim=-1) - 1).abs().max()) <= 1e-5
+    assert float(m["acc_map"].min()) > 0.999                                      # every ray ends on a surface in this scene
+    assert float((m["weights"].sum(-1) - m["acc_map"]).abs().max()) <= 5e-6
+    assert float(m["depth_map"].min()) > 1.5 and float(m["depth_map"].max()) < 8.0
+    pix = torch.as_tensor(g["pix"], device=m["depth_map"].device)
+    assert np.abs(rd.reshape(-1, 3)[pix].cpu().numpy() - g["rays_d"]).max() <= 2e-7
+    for k in DIRECT:
+        tol = max(2e-4, 8 * reference_floor(k, "fitted_wide"))
+        if k != "weights":
+            tol = min(1e-3, tol)
+        assert rel_linf(m[k][pix].cpu().numpy(), g["out__" + k]) <= tol, (k, rel_linf(m[k][pix].cpu().numpy(), g["out__" + k]), tol)
+    assert rel_linf(m["target_normal_map"][pix].cpu().numpy(), g["out__target_normal_map"]) <= 1e-3
