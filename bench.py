@@ -143,6 +143,9 @@ def cpu_baseline(gpu_color_fn, kind, batch=256, batches_per_worker=3, threads=16
     mse = float(np.mean((got - ref) ** 2))
     psnr = float(10 * np.log10(1.0 / max(mse, 1e-30)))
     return {"value": n / t, "unit": "rays/s", "cores": int(workers * threads), "kind": "port",
+            "reference_in_build_container": {"value": 131.8 if kind == "fitted" else 144.2, "unit": "rays/s", "cores": 8,
+                                             "note": "the reference's own PyTorch-CPU render_decomp on the same weights, 1 024 rays, 8 threads of an 8-vCPU Xeon 2.1 GHz "
+                                                     "(tests/golden/time_reference_cpu.py, BASELINE.md section 2b); a recorded figure: the reference cannot travel to the GPU box"},
             "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm), %d processes x %d threads"
                       % (n, workers, threads)}, psnr
 

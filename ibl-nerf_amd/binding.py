@@ -69,7 +69,7 @@ class StageInputs(C.Structure):
 
 
 class Sampling(C.Structure):
-    _fields_ = [("d_t_rand", FP), ("d_u", FP)]
+    _fields_ = [("d_t_rand", FP), ("d_u", FP), ("d_noise_coarse", FP), ("d_noise_fine", FP)]
 
 
 class Outputs(C.Structure):

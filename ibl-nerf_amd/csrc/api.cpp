@@ -616,7 +616,7 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 // coarse_grid: this pass's own samples are that grid.
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
-                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid) {
+                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise) {
     const int Sc = c->Sc;
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
@@ -633,7 +633,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const bool inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED;
     const bool at_surface = c->opt.infer_normal_at_surface != 0;
     if (c->aux_on[IBLNERF_AUX_NORMAL] && at_surface)      // one point per ray: x_surface (:262, :268-271); refl_o is free until pass A
-        HIP_TRY(c, launch_surface_points(ro, rd, z, z_stride, c->raw, R, S, ov, c->refl_o, s));
+        HIP_TRY(c, launch_surface_points(ro, rd, z, z_stride, c->raw, noise, R, S, ov, c->refl_o, s));
     for (int ch = 0; c->aux_on[IBLNERF_AUX_NORMAL] && ch < 3; ++ch) {   // normal_mlp at the surface point or at every sample (:273)
         rc = at_surface ? run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->refl_o, nullptr, 1, R, c->nrm_raw + ch, 3, Q_AUX)
                         : run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[IBLNERF_AUX_NORMAL] + ch, c->pts, nullptr, S, R * S, c->nrm_raw + ch, 3, Q_AUX);
@@ -648,8 +648,9 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
         if (rc) return rc;
     }
-    const PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
-                                    weights, near_, far_, ov);
+    PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
+                              weights, near_, far_, ov);
+    a.noise = noise;
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, Sc, c->pts, s));
@@ -731,6 +732,8 @@ int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_ray
     const bool fine = c->opt.n_importance > 0;
     const float* t_rand = smp ? smp->d_t_rand : nullptr;
     const float* u_rand = smp ? smp->d_u : nullptr;
+    const float* noise_c = smp ? smp->d_noise_coarse : nullptr;      // raw_noise_std > 0: per-sample density noise of each pass
+    const float* noise_f = smp ? smp->d_noise_fine : nullptr;
     if ((t_rand == nullptr) != (u_rand == nullptr) && fine)   // perturb > 0 switches both (det = (perturb == 0), :703)
         return c->fail(IBLNERF_ERR_INVALID, "render_rays: d_t_rand and d_u go together (perturb > 0 jitters the grid and draws the fine samples)");
     if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
@@ -765,22 +768,25 @@ int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_ray
         }
         int rc;
         if (!fine) {
-            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true);
+            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
+                           noise_c ? noise_c + r0 * Sc : nullptr);
             if (rc) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
-            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true);
+            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
+                           noise_c ? noise_c + r0 * Sc : nullptr);
             if (rc) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
             rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE);
             if (rc) return rc;
-            HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, R, Sc, c->w_c, s));
+            HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, noise_c ? noise_c + r0 * Sc : nullptr, R, Sc, c->w_c, s));
         }
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
-        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false);
+        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
+                       noise_f ? noise_f + r0 * Sf : nullptr);
         if (rc) return rc;
     }
     if (c->posdir_out_ch && outs->inferred_depth_map) {   // infer_depth (:722-726): depth_mlp(rays_o, viewdirs), relu of output 0

@@ -85,6 +85,7 @@ struct PassAArgs {
     const float* z; int z_stride;               // see launch_make_points
     const float* raw;                           // [R,S,18]
     const float* sig4;                          // [4,R,S]
+    const float* noise = nullptr;               // [R,S] added to the density before compositing (raw_noise_std > 0, :208-216, :242) or null
     const float* nrm_raw;                       // [R,S,3] normal_mlp samples or null (ibl_nerf_renderer.py:273-276)
     int nrm_at_surface;                         // nrm_raw is [R,3]: one evaluation per ray at the surface point (:268-271)
     int normal_inferred;                        // target normal = the composited normal_mlp output, as it is (:372-373)
@@ -110,11 +111,11 @@ hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma_c
 // Surface points x = o + d * target_depth of R rays from the main query's raw rows (ibl_nerf_renderer.py:249-262), the same
 // arithmetic as pass A: the input of a normal_mlp evaluated at the surface (:268-271).
 struct OverrideArgs;
-hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, long R, int S,
-                                 const OverrideArgs& ov, float* surf, hipStream_t s);
+hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, const float* noise,
+                                 long R, int S, const OverrideArgs& ov, float* surf, hipStream_t s);
 
-hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, long R, int S,
-                                float* weights, hipStream_t s);
+hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,
+                                float* weights, hipStream_t s);   // noise: [R,S] or null
 
 struct PassBArgs {
     const float* state;        // [R, ST_FLOATS]

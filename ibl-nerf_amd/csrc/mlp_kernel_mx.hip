@@ -315,7 +315,7 @@ __device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mx
 template <bool STORE, bool RELU, int NCH>
 struct Epi {
     Act* dst;
-    f32x2* part[NCH > 0 ? NCH : 1];   // per head channel: two interleaved partial sums (even / odd element of each pair), one v_pk_fma_f32 per pair
+    f32x2* part[NCH > 0 ? NCH : 1];   // per head channel: two interleaved partial sums (even / odd element of each pair), two v_fma_f32 per pair
     const float* tab[NCH > 0 ? NCH : 1];
     unsigned* peak;
     u32x16 lres;
@@ -367,7 +367,13 @@ struct Epi {
 #else
         for (int c = 0; c < NCH; ++c) {
 #endif
+#ifdef IBL_MX_HEADS_PK_FMA   // A/B build (scratch/mx_heads_ab.sh): one v_pk_fma_f32 per pair — round 1's form, 0.8 % slower (FULL, 65 536 x 128 points:
+                             // 21.79 against 21.60 ms, same box, head-weight prefetch kept in both): packed f32 VALU beside MFMAs is an anti-lever
             *part[c] = __builtin_elementwise_fma(f32x2{x0, x1}, hw[c], *part[c]);
+#else
+            (*part[c])[0] = fmaf(x0, hw[c][0], (*part[c])[0]);
+            (*part[c])[1] = fmaf(x1, hw[c][1], (*part[c])[1]);
+#endif
             if constexpr (I == 7) asm volatile("" : "+v"(*part[c]));
         }
     }

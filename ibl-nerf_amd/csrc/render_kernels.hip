@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
         z[i] = s < S ? zrow[s] : 0.0f;
         zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
         sig[i] = s < S ? a.raw[((long)r * S + s) * RAW_CH] : 0.0f;
+        if (a.noise != nullptr && s < S) sig[i] = sig[i] + a.noise[(long)r * S + s];   // raw[..., 0] + noise (:242)
     }
     ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
 
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 
 template <int NPL>
 __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__ rays_d, const float* __restrict__ zbase,
-                                                      int z_stride, const float* __restrict__ sigma, long R, int S,
+                                                      int z_stride, const float* __restrict__ sigma, const float* __restrict__ noise, long R, int S,
                                                       float* __restrict__ weights) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
         z[i] = s < S ? zrow[s] : 0.0f;
         zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
         sig[i] = s < S ? sigma[r * S + s] : 0.0f;
+        if (noise != nullptr && s < S) sig[i] = sig[i] + noise[r * S + s];
     }
     ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
 #pragma unroll
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
 template <int NPL>
 __global__ __launch_bounds__(256) void k_surface_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const float* __restrict__ zbase, int z_stride, const float* __restrict__ raw,
-                                                       long R, int S, OverrideArgs ov, float* __restrict__ surf) {
+                                                       const float* __restrict__ noise, long R, int S, OverrideArgs ov, float* __restrict__ surf) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(256) void k_surface_points(const float* __restrict_
         z[i] = s < S ? zrow[s] : 0.0f;
         zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
         sig[i] = s < S ? raw[(r * S + s) * RAW_CH] : 0.0f;
+        if (noise != nullptr && s < S) sig[i] = sig[i] + noise[r * S + s];
     }
     ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
     float depth = 0.f;
@@ -744,21 +747,21 @@ hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma, 
     });
 }
 
-hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, long R, int S,
+hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,
                                 float* weights, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
-        hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, R, S, weights);
+        hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, noise, R, S, weights);
     });
 }
 
-hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, long R, int S,
-                                 const OverrideArgs& ov, float* surf, hipStream_t s) {
+hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, const float* noise,
+                                 long R, int S, const OverrideArgs& ov, float* surf, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
-        hipLaunchKernelGGL(k_surface_points<decltype(N)::value>, grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, raw, R, S, ov, surf);
+        hipLaunchKernelGGL(k_surface_points<decltype(N)::value>, grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, raw, noise, R, S, ov, surf);
     });
 }
 

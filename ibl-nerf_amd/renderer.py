@@ -360,16 +360,33 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
         (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
         perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
         stochastic fine samples, from torch.rand on the device; pytest=True takes numpy's seed-0 stream instead, re-seeded for
-        every `chunk` rays exactly as batchify_rays / render_rays / sample_pdf do, so the reference's test path reproduces."""
+        every `chunk` rays exactly as batchify_rays / render_rays / sample_pdf do, so the reference's test path reproduces.
+        raw_noise_std > 0 (:208-216): noise on the main query's density before compositing, N(0, std) from the device generator, or
+        — pytest=True — std * numpy's seed-0 UNIFORM stream, which is what the reference's test hook draws."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = rays_o.shape[0]
         smp = None
+        std = float(raw_noise_std or 0.)
+        if std > 0.:
+            smp = B.Sampling()
+            Sc, Sf = self.N_samples, self.N_samples + self.N_importance
+            ch = int(chunk or n or 1)
+            keep = []
+            for S, field in ((Sc, "d_noise_coarse"), (Sf, "d_noise_fine")):
+                if pytest:
+                    nz = torch.cat([_pytest_uniform(min(ch, n - i), S) for i in range(0, n, ch)] or [torch.zeros((0, S))])
+                    nz = _dev_f32(nz * np.float32(std), self.device)
+                else:
+                    nz = torch.randn((n, S), device=self.device) * std
+                setattr(smp, field, nz.data_ptr())
+                keep.append(nz)
+            self._keep_noise = keep
         if perturb and float(perturb) > 0.:
             Sc, Ni = self.N_samples, max(self.N_importance, 1)
             if pytest:
@@ -380,14 +397,14 @@ class Renderer:
             else:
                 t_rand = torch.rand((n, Sc), device=self.device)
                 u = torch.rand((n, Ni), device=self.device)
-            smp = B.Sampling()
+            smp = smp or B.Sampling()
             smp.d_t_rand, smp.d_u = t_rand.data_ptr(), u.data_ptr()
             self._keep_smp = (t_rand, u)
         lazy = self.range_check == "lazy"
         if lazy:
             self._lazy_poll()
             if self._force_wide:
-                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, **edit)
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, **edit)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -411,7 +428,7 @@ class Renderer:
                                                                C.byref(smp) if smp is not None else None, C.byref(outs)))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, **edit)
+            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, **edit)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:
@@ -560,8 +577,6 @@ def _check_supported(kw):
         raise TypeError("infer_depth=True needs depth_mlp")                        # the reference calls run_network(..., None)
     if kw.get("infer_normal") and kw.get("normal_mlp") is None:
         raise TypeError("infer_normal=True needs normal_mlp")                      # the reference calls run_network(..., None)
-    if float(kw.get("raw_noise_std", 0.) or 0.) > 0.:
-        raise NotImplementedError("raw_noise_std > 0 (0 in every shipped config) is not built (SURVEY.md §8 f-3)")
     mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
     if mode not in NORMAL_MODES:
         if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
@@ -686,7 +701,7 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
             if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
     ret = r.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), _scalar(near, "near"), _scalar(far, "far"),
                         kwargs.get("gt_values"), perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)),
-                        chunk=chunk, **edit)
+                        chunk=chunk, raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **edit)
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
 
 

@@ -240,10 +240,15 @@ int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, c
  * the uniform [0,1) draws, so that any generator — torch's on the device, or numpy's seeded stream of the reference's `pytest` path —
  * gives the reference's samples.  d_t_rand [n_rays, N_samples]: stratified jitter of the coarse grid (which then is per ray, also
  * for the reflected-ray samples: z_vals_constant); d_u [n_rays, N_importance]: the draws sample_pdf(det=False) inverts.  Both or
- * neither (det = (perturb == 0), :703); NULL struct = iblnerf_render_rays.  raw_noise_std stays 0 (its shipped value). */
+ * neither (det = (perturb == 0), :703); NULL struct = iblnerf_render_rays.
+ * raw_noise_std > 0 (:208-216, :242; 0 in every shipped config): d_noise_coarse [n_rays, N_samples] / d_noise_fine [n_rays, N_samples +
+ * N_importance] = the noise values already multiplied by raw_noise_std, added to the main query's density before compositing in
+ * the respective pass (the reflected ray and the offset queries take none, as in the reference); NULL = none. */
 typedef struct {
     const float* d_t_rand;
     const float* d_u;
+    const float* d_noise_coarse;
+    const float* d_noise_fine;
 } iblnerf_sampling;
 int iblnerf_render_rays_sampled(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                                 float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_sampling* sampling,

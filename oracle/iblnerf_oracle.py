@@ -306,7 +306,7 @@ def decode_masks(mask_img, n_obj):
 # one pass: raw2outputs, ibl_nerf_renderer.py:153-527 (approximate_radiance=True, shipped flags)
 # --------------------------------------------------------------------------------------------
 def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, edit=None, stages=None, flags=None, aux=None,
-                teacher=None):
+                teacher=None, noise=None):
     """flags: use_radiance_linear (radiance_f = ReLU + Reinhard LDR map, :30-35, :192-197, :480-483),
     lut_coefficient ('F' | 'F0', :433-438), gamma_correct (default True as in the shipped configs),
     epsilon (default 0.01, :358-361), correct_depth_for_prefiltered_radiance_infer (default True, :455-461),
@@ -318,7 +318,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     network's before compositing; an irradiance_mlp's go through sigmoid whatever radiance_f is.
     teacher: {'raw' [N,S,18], 'sigma_offsets' [4N,S], 'refl_raw' [N,Sc,18]} — recorded results of the three network queries
     (:201, normal_from_depth.py:158, :445) used INSTEAD of evaluating `sd` (teacher forcing: the pass downstream of the MLP
-    in isolation)."""
+    in isolation).
+    noise: [N,S] added to the density before compositing (raw_noise_std > 0, :208-216, :242), already multiplied by the std."""
     teacher = teacher or {}
     gt = gt or {}
     edit = edit or {}
@@ -335,7 +336,8 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     elif edit.get("insert_object"):
         assert edit["num_insert_objects"] > 0
         masks, mask_all = decode_masks(gt["object_insert_mask"], edit["num_insert_objects"])
-    w = alpha_weights(raw[..., 0], dists)                                                   # :241-245
+    sig_raw = raw[..., 0] if noise is None else (raw[..., 0] + np.asarray(noise, dtype=F32)).astype(F32)
+    w = alpha_weights(sig_raw, dists)                                                       # :241-245
     depth = np.sum(w * z_vals, -1, dtype=F32)                                               # :249
     tdepth = depth                                                                          # :250 (one array: aliases depth_map)
     if flags.get("depth_map_from_ground_truth", False):
@@ -481,9 +483,10 @@ def pytest_uniform(n, m):
 
 
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64, n_importance=128,
-                gt=None, edit=None, stages=None, flags=None, aux=None, t_rand=None, u=None):
+                gt=None, edit=None, stages=None, flags=None, aux=None, t_rand=None, u=None, noise_c=None, noise_f=None):
     """t_rand [N, n_samples] / u [N, n_importance]: the uniform draws of perturb > 0 (:678-692 stratified jitter, :703 stochastic
-    fine samples); None = the deterministic test-time path."""
+    fine samples); None = the deterministic test-time path.  noise_c [N, n_samples] / noise_f [N, n_samples + n_importance]: the
+    density noise of raw_noise_std > 0 per pass (already multiplied by the std)."""
     rays_o = np.ascontiguousarray(rays_o, dtype=F32)
     rays_d = np.ascontiguousarray(rays_d, dtype=F32)
     N = rays_o.shape[0]
@@ -495,14 +498,14 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
         lower = np.concatenate([z[:, :1], mids], -1)
         z = (lower + (upper - lower) * np.asarray(t_rand, dtype=F32)).astype(F32)
     st_c = {} if stages is not None else None
-    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags, aux)
+    res = raw2outputs(sd_coarse, rays_o, rays_d, z, z, near, far, lut, gt, edit, st_c, flags, aux, noise=noise_c)
     if n_importance > 0:
         mids = (F32(0.5) * (z[:, 1:] + z[:, :-1])).astype(F32)                             # :701
         zs = sample_pdf(mids, res["weights"][:, 1:-1], n_importance, u)                    # :702-703
         zf = np.sort(np.concatenate([z, zs], -1), -1)                                      # :707
         st_f = {} if stages is not None else None
         fine = raw2outputs(sd_fine if sd_fine is not None else sd_coarse, rays_o, rays_d, zf, z,
-                           near, far, lut, gt, edit, st_f, flags, aux)
+                           near, far, lut, gt, edit, st_f, flags, aux, noise=noise_f)
         for k, v in res.items():
             fine[k + "0"] = v                                                              # :712-713
         res = fine

@@ -183,7 +183,7 @@ def fitted_state_dicts():
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
                 n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False,
-                fitted=False, record_floor=False, infer_depth=False, perturb=False):
+                fitted=False, record_floor=False, infer_depth=False, perturb=False, raw_noise_std=0.0):
     tmp = tempfile.mkdtemp()
     try:
         _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal, infer_depth))
@@ -216,7 +216,7 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     kw.update(near=near, far=far)
     kw["brdf_lut"] = lut
     if perturb:   # training-time sampling through the reference's own deterministic test hook (pytest=True: numpy seed 0 per chunk)
-        kw.update(perturb=1.0, pytest=True)
+        kw.update(perturb=1.0, pytest=True, raw_noise_std=raw_noise_std)
     kw.update(flags or {})            # flag variants outside the shipped configs
 
     rng = np.random.RandomState(1000 + seed)
@@ -327,6 +327,7 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     if perturb:
         out["perturb"] = np.float32(1.0)
         out["chunk"] = np.int64(n_rays)
+        out["raw_noise_std"] = np.float32(raw_noise_std)
     if color_independent:
         out["model__color_independent_to_direction"] = np.asarray(True)
     for aux_name, sd_seed in aux_seeds.items():
@@ -501,6 +502,8 @@ def main(only=None):
                 mode="edit2", flags=dict(target_normal_map_for_radiance_calculation="inferred_normal_map", infer_normal_at_surface=True))
     # perturb = 1 (stratified jitter + stochastic fine samples) through the reference's pytest seed path
     run_fixture("perturb_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=18, perturb=True)
+    # ... with density noise on top (raw_noise_std = 1; the pytest hook draws it uniform)
+    run_fixture("perturb_noise_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=19, perturb=True, raw_noise_std=1.0)
     # infer_depth: the depth_mlp (PositionDirectionMLP) once per ray at the origin with the normalised direction; posed camera
     run_fixture("inferdepth_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=17, infer_depth=True, posed=True)
     # the fitted (surface-bearing) checkpoint of fit_checkpoint.py: plain, material edit, object insertion; raw recorded for all rays

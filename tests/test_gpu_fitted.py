@@ -266,8 +266,20 @@ def test_perturb_pytest_seed_path_vs_reference(R, lut):
     assert np.allclose(a["weights"].sum(-1), a["acc_map"], rtol=1e-5) and rel_linf(a["depth_map"], b["depth_map"]) < 5e-2
     s = r.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128, det=False, pytest=True).cpu().numpy()
     assert np.abs(s - g["pdf_samples"]).max() <= 5e-5                             # teacher-forced: the reference's bins, weights and draws
-    with pytest.raises(NotImplementedError):
-        R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, raw_noise_std=1.0))
+    # raw_noise_std = 1 on top (fixture perturb_noise_g10: the reference's pytest hook draws the noise uniform)
+    gn, sdcn, sdfn, _, _ = load_golden("perturb_noise_g10")
+    rn = make_renderer(R, gn, sdcn, sdfn, lut, max_rays_per_launch=20)
+    nz = to_np(rn.render_rays(gn["rays_o"], gn["rays_d"], 0.5, 8.0, perturb=1.0, pytest=True, chunk=gn["rays_o"].shape[0], raw_noise_std=1.0))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(nz[k + sfx], gn["out__" + k + sfx]) <= 2e-4, (k + sfx, rel_linf(nz[k + sfx], gn["out__" + k + sfx]))
+        for k in DERIVED:
+            assert rel_linf(nz[k + sfx], gn["out__" + k + sfx]) <= 1e-3, (k + sfx, rel_linf(nz[k + sfx], gn["out__" + k + sfx]))
+    lean = make_renderer(R, gn, sdcn, sdfn, lut, max_rays_per_launch=20, coarse_outputs=False)    # density-only coarse pass takes the noise too
+    nl = to_np(lean.render_rays(gn["rays_o"], gn["rays_d"], 0.5, 8.0, perturb=1.0, pytest=True, chunk=gn["rays_o"].shape[0], raw_noise_std=1.0))
+    assert all(np.array_equal(nl[k], nz[k]) for k in nl)
+    c = to_np(rn.render_rays(gn["rays_o"], gn["rays_d"], 0.5, 8.0, raw_noise_std=0.5))             # device generator, no jitter
+    assert all(np.isfinite(v).all() for v in c.values()) and np.allclose(c["weights"].sum(-1), c["acc_map"], rtol=1e-5)
 
 
 def test_full_frame_of_the_fitted_checkpoint(R, lut):

@@ -444,8 +444,7 @@ def test_unsupported_flags_raise():
     with pytest.raises(ValueError):
         R._check_supported(dict(base, target_normal_map_for_radiance_calculation="bogus"))   # ibl_nerf_renderer.py:375
     R._check_supported(dict(base, perturb=1.0, pytest=True))                         # training-time sampling: built
-    with pytest.raises(NotImplementedError):
-        R._check_supported(dict(base, raw_noise_std=1.0))
+    R._check_supported(dict(base, raw_noise_std=1.0))                                  # density noise: built
 
 
 def test_tile_rows_partition():

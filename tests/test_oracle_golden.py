@@ -247,3 +247,20 @@ def test_perturb_through_the_reference_pytest_seed_path(lut):
     assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
     det = O.render_rays(sdc, sdf, g["rays_o"][:8], g["rays_d"][:8], 0.5, 8.0, lut)
     assert rel_linf(det["depth_map"], g["out__depth_map"][:8]) > 1e-4              # it is another quadrature
+
+
+def test_raw_noise_std_through_the_pytest_seed_path(lut):
+    """raw_noise_std = 1 on top of perturb = 1 (ibl_nerf_renderer.py:208-216, :242): under pytest=True the reference adds
+    raw_noise_std * np.random.rand(...) (seed 0, uniform) to the main query's density of each pass."""
+    g, sdc, sdf, gt, edit = load_golden("perturb_noise_g10")
+    n = g["rays_o"].shape[0]
+    assert float(g["raw_noise_std"]) == 1.0
+    res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut, t_rand=O.pytest_uniform(n, 64), u=O.pytest_uniform(n, 128),
+                        noise_c=O.pytest_uniform(n, 64), noise_f=O.pytest_uniform(n, 192))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 2e-5, k + sfx
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 6e-4, k + sfx
+    quiet = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut, t_rand=O.pytest_uniform(n, 64), u=O.pytest_uniform(n, 128))
+    assert rel_linf(quiet["depth_map0"], g["out__depth_map0"]) > 1e-3                # the noise matters
