@@ -1,0 +1,57 @@
+"""End-to-end normal error on the 1 024-ray fitted fixture when the FINE grid's offset queries run the fast scheme with their first k
+layers in f16x3 (emulation, CPU, numpy; everything else f16x3).  python scratch/prec_probe_mixed.py [n_rays]"""
+import sys, numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+import _pkg; _pkg.load()
+import iblnerf_oracle as O
+from conftest import load_golden, load_lut_rgb
+
+def f16(a): return a.astype(np.float16).astype(np.float32)
+def q6(a, block=32):
+    sh = a.shape; K = sh[-1]; pad = (-K) % block
+    x = np.pad(a.astype(np.float64), [(0, 0)] * (a.ndim - 1) + [(0, pad)]).reshape(sh[:-1] + (-1, block))
+    mx = np.abs(x).max(-1, keepdims=True)
+    s = 2.0 ** np.where(mx > 0, np.floor(np.log2(np.maximum(mx, 1e-300))) - 2, 0.0)
+    v = x / s
+    m, e = np.frexp(v); normal = np.ldexp(np.rint(m * 16) / 16, e)
+    q = np.where(np.abs(v) >= 1.0, normal, np.rint(v * 8) / 8)
+    return (np.clip(q, -7.5, 7.5) * s).reshape(sh[:-1] + (-1,))[..., :K]
+
+HEADS = ("sigma_linear", "roughness_linear", "albedo_linear", "irradiance_linear", "radiance_linear", "additional_radiance_linear")
+FAST = False          # the current query runs the fast scheme ...
+PRECISE = set()       # ... except these layers
+def lin(sd, name, x):
+    W, b = sd[name + ".weight"], sd[name + ".bias"]
+    if name.startswith(HEADS): return (x @ W.T + b).astype(np.float32)
+    x64 = lambda a: a.astype(np.float64)
+    Wh, Xh = f16(W), f16(x)
+    if not FAST or name in PRECISE:
+        Wl, Xl = f16(W - Wh), f16(x - Xh)
+        return (x64(Xh) @ x64(Wh).T + x64(Xl) @ x64(Wh).T + x64(Xh) @ x64(Wl).T + b).astype(np.float32)
+    Wl, Xl = W - Wh, x - Xh
+    return (x64(Xh) @ x64(Wh).T + q6(Xl) @ q6(Wh).T + q6(Xh) @ q6(Wl).T + b).astype(np.float32)
+O._lin = lin
+_nq = O.network_query
+N_OFFSET = [0]
+def network_query(sd, pts, viewdirs):
+    global FAST
+    if viewdirs is None:
+        N_OFFSET[0] += 1
+        FAST = N_OFFSET[0] % 2 == 0      # render_rays issues the coarse pass's offset query first, then the fine pass's: only the fine one is fast
+    else:
+        FAST = False
+    out = _nq(sd, pts, viewdirs)
+    FAST = False
+    return out
+O.network_query = network_query
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+g, sdc, sdf, gt, edit = load_golden("fitted_wide")
+lut = load_lut_rgb()
+L = ["positions_linears.%d" % i for i in range(8)]
+for label, sel in (("fine offsets fast", []), ("+ layer 0 precise", L[:1]), ("+ layers 0-1", L[:2]), ("+ layers 0-2", L[:3]), ("+ layers 0-3", L[:4]), ("all precise", L)):
+    PRECISE = set(sel); N_OFFSET[0] = 0
+    res = O.render_rays(sdc, sdf, g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0, lut)
+    e = np.abs(res["target_normal_map"] - g["out__target_normal_map"][:n]).max(-1)
+    d = np.abs(res["depth_map"] - g["out__depth_map"][:n]) / np.abs(g["out__depth_map"]).max()
+    print("%-22s normal: max %.2e  p99.9 %.2e  p99 %.2e   depth max %.1e" % (label, e.max(), np.percentile(e, 99.9), np.percentile(e, 99), d.max()), flush=True)
