@@ -35,6 +35,9 @@ MODES = {
     "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
                     "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in the reflected-ray queries"),
+    "f16x3_mxfp6x": ("f16 hi/lo splits x3 products for the main, auxiliary and coarse-grid offset queries; the fine pass's offset queries on the fast kernel's mixed "
+                     "trunk form (layers 0-1 as three f16 products, layers 2-7 as f16 + 2x MX-fp6); f16 + 2x MX-fp6 for the reflected-ray queries; fp32 accumulate",
+                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel<TRUNK_X>", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in layers 2-7 of the fine offsets and in the reflected-ray queries"),
     "f16x3_main": ("f16 hi/lo splits x3 products for the main, auxiliary and coarse-grid offset queries; f16 + 2x MX-fp6 residual products "
                    "for the fine pass's offset queries and the reflected-ray queries; fp32 accumulate",
                    "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products in the precise queries, 1 f16 + 2 block-scaled fp6 products in the others"),
@@ -163,7 +166,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra frames (inference-minimum mode, other product schemes): profiling runs")
-    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6",
+    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6x",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
     args = ap.parse_args()
@@ -252,8 +255,8 @@ def main():
 
     # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
     by_precision = {}
-    if world == 1 and args.mlp_precision == "f16x3_mxfp6" and not args.inference_min and not args.no_extras:
-        for mode in ("f16x3_main", "f16_mxfp6"):
+    if world == 1 and args.mlp_precision == "f16x3_mxfp6x" and not args.inference_min and not args.no_extras:
+        for mode in ("f16x3_mxfp6", "f16_mxfp6"):
             r3 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=mode)
             r3.load_weights(0, sdc)
             r3.load_weights(1, sdf)

@@ -35,9 +35,9 @@ class Options(C.Structure):
                 ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32)]
 
 
-MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_MAIN = 0, 1, 2, 3, 4, 5
+MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_MAIN, MLP_F16X3_MXFP6X = 0, 1, 2, 3, 4, 5, 6
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
-                  "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN}
+                  "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 

@@ -30,9 +30,12 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
 static bool wants_mx(int prec) {
-    return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN;
+    return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN ||
+           prec == IBLNERF_MLP_F16X3_MXFP6X;
 }
-static bool wants_f16x3(int prec) { return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN; }
+static bool wants_f16x3(int prec) {
+    return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN || prec == IBLNERF_MLP_F16X3_MXFP6X;
+}
 // query classes of render_rays, for the per-class choice of the product scheme
 enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER };
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
@@ -63,6 +66,9 @@ struct iblnerf_ctx {
     float* nrm_raw = nullptr;                 // [ws_rays, Smax, 3] normal_mlp samples (allocated with the first IBLNERF_AUX_NORMAL upload)
     float* d_lut = nullptr;
     bool have_lut = false;
+    // measurement / test aids, read from the environment at iblnerf_create: IBLNERF_X_COARSE routes the coarse grid's offset queries,
+    // IBLNERF_X_USER the trunk-only form of iblnerf_network_query, to the mixed TRUNK form (mode IBLNERF_MLP_F16X3_MXFP6X only)
+    bool x_coarse = false, x_user = false;
     float* d_posdir = nullptr;                // PositionDirectionMLP of infer_depth: per layer [Wt | bias] (posdir_kernel.hip)
     int posdir_out_ch = 0;                    // 0 = none uploaded
     // workspace
@@ -163,8 +169,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MAIN) {
-        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3), _F16X3_MXFP6 (4) or _F16X3_MAIN (5)";
+    if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
+        g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3), _F16X3_MXFP6 (4), _F16X3_MAIN (5) or _F16X3_MXFP6X (6)";
         return IBLNERF_ERR_INVALID;
     }
     if ((long)opts->max_rays_per_launch * 4 * (opts->n_samples + opts->n_importance) >= (1L << 31)) {
@@ -187,6 +193,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         const int g = std::atoi(e);
         if (g > 0) c->n_cu = g;
     }
+    c->x_coarse = std::getenv("IBLNERF_X_COARSE") != nullptr;
+    c->x_user = std::getenv("IBLNERF_X_USER") != nullptr;
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -452,14 +460,19 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     // product scheme of this launch (include/iblnerf.h: mlp_precision).  A network with a weight outside the f16 range runs
     // on the bf16x3 kernel whatever the mode.
     const int prec = c->opt.mlp_precision;
-    enum { K_BF16X3, K_F16X3, K_MX, K_MX16 } kern = K_BF16X3;
+    enum { K_BF16X3, K_F16X3, K_MX, K_MX16, K_MXX } kern = K_BF16X3;   // K_MXX: the fast kernel's TRUNK form with its first two layers as three f16 products
     if (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which]) {
         if (prec == IBLNERF_MLP_F16X3) kern = K_F16X3;
         else if (prec == IBLNERF_MLP_F16X3_MXFP6)
             // f16 + fp6 only where its 2^-16 is below the channel's own conditioning: the reflected-ray queries (the reference's
             // own fp64-vs-fp32 runs differ by 2e-2 .. 6e-2 there on a checkpoint with surfaces)
             kern = qclass == Q_REFL ? K_MX : K_F16X3;
-        else if (prec == IBLNERF_MLP_F16X3_MAIN)
+        else if (prec == IBLNERF_MLP_F16X3_MXFP6X) {
+            // ... and the offset queries on the fast kernel's mixed TRUNK form (layers 0-1 as three f16 products): the first layers set
+            // the density's error, so the normal stays that of the f16x3 kernel for +17 % matrix instructions over the fast kernel
+            const bool x = qclass == Q_OFFSET_FINE || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
+            kern = qclass == Q_REFL ? K_MX : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
+        } else if (prec == IBLNERF_MLP_F16X3_MAIN)
             // ... and also for the offset queries on the dense fine grid: the normal's worst ray of 1024 goes from 1.9e-4 to
             // 1.5e-3 (99.9th percentile 3e-4); on the coarse grid (spacing 0.12) the same offsets would leave 1e-3 at 96 rays
             kern = (qclass == Q_OFFSET_FINE || qclass == Q_REFL) ? K_MX : K_F16X3;
@@ -492,6 +505,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
     HIP_TRY(c, kern == K_MX16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : kern == K_MX ? launch_mlp_mx(variant, a, c->n_cu, s)
+               : kern == K_MXX ? launch_mlp_mx(VAR_TRUNK_X, a, c->n_cu, s)
                : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     c->flop_alg += (double)n_pts * (variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));

@@ -104,7 +104,8 @@ constexpr int REFL_CH = 13;   // sigma + channels 6..17 (what raw2outputs_simple
 // FULL: all 18 channels; TRUNK: sigma only (ibl_nerf.py:175-176); REFL: sigma + the 12 radiance channels (what
 // raw2outputs_simple reads).  *_CI: the same for a network built with is_color_independent_to_direction (ibl_nerf.py:192):
 // the radiance heads read the trunk output, feature_linear and views_linears are not evaluated.
-enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_REFL_CI = 4 };
+enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_REFL_CI = 4,
+               VAR_TRUNK_X = 5 };   // fast kernel only: TRUNK with its first two layers as three f16 products (layout_mx.h)
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

@@ -58,8 +58,16 @@ constexpr int CH_ALB = 68;   // albedo_feature_linear      4              4     
 constexpr int CH_IRR = 72;   // irradiance_feature_linear  4              4       4
 constexpr int CH_VIEW = 76;  // views_linears.0            1 (DE) + 4     8       10
 constexpr int CH_AR = 86;    // additional_radiance_feature_linear.{0,1,2}  4   4 each   12
-constexpr int N_CHUNKS = 98;
+constexpr int N_CHUNKS_NET = 98;   // the network's blocks
+// Residual blocks for the mixed TRUNK form (VAR_TRUNK_X, mlp_kernel_mx.hip): positions_linears.0 and .1 evaluated as THREE f16 products
+// (Wh Xh + Wh Xl + Wl Xh) inside the fast kernel.  Block r holds, in its f16 area only, f16(W - f16 W) of network block
+// L0 tile t (r = t) / L1 tile t, block b (r = 8 + 4 t + b), slot for slot.  (Errors injected in the first layers dominate the
+// density's error on a fitted network, DESIGN.md 4.0: with these two layers at 2^-22 the offset queries' normal is that of the f16x3 kernel.)
+constexpr int CH_RES = 98;
+constexpr int N_RES_BLOCKS = 8 + 32;
+constexpr int N_CHUNKS = CH_RES + N_RES_BLOCKS / 4;   // 108
 constexpr int N_CHUNKS_TRUNK = 60;
+constexpr int N_CHUNKS_TRUNK_X = 4 + 16 + 50;         // program of VAR_TRUNK_X: L0 and L1 as (network block, residual block) pairs
 constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;
 
 // e2m3 (bias 1): value of a 6-bit code, and round-to-nearest-even encoding with saturation at 7.5

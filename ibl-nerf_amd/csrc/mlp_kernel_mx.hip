@@ -21,6 +21,15 @@ namespace ibl {
 // MFMAs, no residual forms in the epilogue, only the f16 half of the weight stream.  2^-11 per operand: enough for every query
 // that neither places samples nor feeds the finite-difference normal (the fine pass's main query, the reflected-ray queries;
 // scratch/prec_probe_f16f8.py, mode "f16+fp6|f16_only|keepcoarse"), not for the others.
+//
+// VAR_TRUNK_X (this kernel only): the trunk-only form with positions_linears.0 and .1 evaluated as THREE f16 products on hi/lo splits
+// (Wh Xh + Wh Xl + Wl Xh, 2^-22 per operand) inside the same pipeline; the other six layers as above.  On a network with surfaces the
+// density's error is set by the first layers (an error injected early is amplified by every later layer; scratch/prec_probe_layers.py,
+// prec_probe_mixed.py): with these two at 2^-22 the finite-difference normal of the offset queries is that of the f16x3 kernel
+// (1.9e-4 against 2.6e-3 on the worst of 1 024 rays, emulated) for +17 % matrix instructions instead of +100 %.  A logical block of
+// those layers is a PAIR of stream blocks: the network's block (its f16 area = Wh) and a residual block (its f16 area = f16(W - Wh),
+// layout_mx.h CH_RES); a chunk of four blocks is assembled by the four waves' LDS-DMA from the two places.  Per pair: slots 0-3 of
+// the first block issue Wh Xh and Wh Xl (one operand read, two MFMAs), slots 0-3 of the second Wl Xh; their fp6 slots are idle.
 #ifdef IBL_MX_F16ONLY
 #define IBL_MXK mxk16
 constexpr bool F16O = true;
@@ -96,6 +105,9 @@ __host__ __device__ constexpr int slice_slot(int i, int ns) { return ns >= CHUNK
 // MFMA of slot stage_slot(q): 16 stages over the tile's first slots, the last one (slice 7, B) before slot ns - 5.
 constexpr int N_STAGES = 2;   // (three stages — reads+max / ReLU / rest — measured 3 % slower than two)
 __host__ __device__ constexpr int stage_slot(int q, int ns) { return ns >= CHUNK_SLOTS ? 1 + (q * (ns - 6)) / (8 * N_STAGES) : 1 + (q * (ns - 1)) / (8 * N_STAGES); }
+// ... in a three-product layer (run_layer_x3) the last logical block of the input is the tile's last TWELVE slots (a pair of stream
+// blocks), so the pending epilogue that completes it must be through before slot ns - 12
+__host__ __device__ constexpr int stage_slot_x3(int q, int ns) { return ns >= 2 * CHUNK_SLOTS ? 1 + (q * (ns - 14)) / (8 * N_STAGES) : 1 + (q * (ns - 1)) / (8 * N_STAGES); }
 
 // ---------------------------------------------------------------------------------------------
 // weight-stream pipeline (cf. Pipe in mlp_kernel.hip): cyclic, never drained.  While chunk c is
@@ -106,7 +118,8 @@ __host__ __device__ constexpr int stage_slot(int q, int ns) { return ns >= CHUNK
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
+    static constexpr bool X = VARIANT == VAR_TRUNK_X;
+    static constexpr int N_PROG = X ? mx::N_CHUNKS_TRUNK_X : VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
                                                         : mx::N_CHUNKS_TRUNK + (CI ? 0 : 8 + 10) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;
@@ -116,6 +129,18 @@ struct Pipe {
     int slot, slot1, slot2;   // ring slots of the chunk being consumed, the next one, the one two ahead
     int prog2;                // program position of the chunk two ahead
 
+    // VAR_TRUNK_X: stream block that wave w copies for program position p (layers 0 and 1: network block / residual block pairs)
+    __device__ __forceinline__ static int x_block(int p, int w) {
+        if (p < 4) {                                   // L0: chunk p = tiles 2p, 2p+1, each as [network, residual]
+            const int tile = 2 * p + (w >> 1);
+            return (w & 1) ? mx::CH_RES * 4 + tile : mx::CH_L0 * 4 + tile;
+        }
+        if (p < 20) {                                  // L1: chunk c = tile c/2, logical blocks 2(c&1), 2(c&1)+1
+            const int c = p - 4, lb = 4 * (c >> 1) + 2 * (c & 1) + (w >> 1);
+            return (w & 1) ? mx::CH_RES * 4 + 8 + lb : mx::CH_L1 * 4 + lb;
+        }
+        return (mx::CH_L1 + 8 + (p - 20)) * 4 + w;     // positions_linears.2 .. 7 as they are
+    }
     __device__ __forceinline__ static int stream_chunk(int p) {
         // program position -> stream chunk: a variant's program is the trunk followed by the head layers it evaluates
         if (p < mx::N_CHUNKS_TRUNK) return p;
@@ -137,9 +162,10 @@ struct Pipe {
         if constexpr (I % 2 == 1) return;
 #endif
         if constexpr (F16O && I >= 4) return;   // pieces 4..7 of a wave are the fp6 half of its block
-        const char* src = stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
+        // (VAR_TRUNK_X: the wave's block comes from its own place in the stream, so the wave term moves from the offset register to the base)
+        const char* src = X ? stream + (size_t)x_block(prog, wave) * BLOCK_BYTES : stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
         const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + (I / 4) * 4096;
-        const unsigned v = voff + (I / 4) * 4096;
+        const unsigned v = (X ? voff - wave * 8192 : voff) + (I / 4) * 4096;
         if constexpr (I % 4 != 0) {
             asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(v), "s"(src), "n"((I % 4) * 1024) : "memory");
 #ifdef IBL_MX_DOUBLE_DMA   // measurement only: every piece twice (same bytes to the same place) prices one LDS-DMA instruction
@@ -312,12 +338,14 @@ __device__ __forceinline__ void finish_block(Blk& b, const u32x16& lres, int& mx
 // mlp_kernel.hip).  STORE: v = [ReLU](acc) -> f16 k-steps 2(T&1), 2(T&1)+1 of block T>>1 of `dst`, residuals
 // staged in `lres`; after the odd tile of a pair the block is finished (scales + fp6 forms).
 // NCH: running fp32 dot products with N=1/3 head rows.
-template <bool STORE, bool RELU, int NCH>
+template <bool STORE, bool RELU, int NCH, bool KEEP_LO = false>
 struct Epi {
     Act* dst;
     f32x2* part[NCH > 0 ? NCH : 1];   // per head channel: two interleaved partial sums (even / odd element of each pair), two v_fma_f32 per pair
     const float* tab[NCH > 0 ? NCH : 1];
     unsigned* peak;
+    u32x16* lo_dst = nullptr;   // KEEP_LO (VAR_TRUNK_X, layer 0): where the f16 residuals of each finished block go (input of a three-product
+                                // layer); set once at construction — a pointer that changes at run time would keep the array out of registers
     u32x16 lres;
     u32x4 hq;
     int mxv;   // running block max as the int image of a non-negative float (ordering is the same; one v_max3_i32 per pair)
@@ -359,7 +387,10 @@ struct Epi {
                 asm volatile("" : "+v"(hq));
                 dst->b[T >> 1].hv = with_quarter<j>(dst->b[T >> 1].hv, hq);
             }
-            if constexpr (I == 7 && (T & 1) == 1) finish_block(dst->b[T >> 1], lres, mxv, *peak);
+            if constexpr (I == 7 && (T & 1) == 1) {
+                if constexpr (KEEP_LO) lo_dst[T >> 1] = lres;
+                finish_block(dst->b[T >> 1], lres, mxv, *peak);
+            }
         }
 #pragma unroll
 #ifdef IBL_MX_ABLATE_NO_HEADS   // timing ablation only (results are garbage): no head dot products
@@ -459,9 +490,72 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
     return prev;
 }
 
+
+// A layer as THREE f16 products (VAR_TRUNK_X, layers 0 and 1): every logical block is a pair of stream blocks, the network's (its
+// f16 area = Wh) then a residual block (f16 area = f16(W - Wh)).  The slot machinery (operand prefetch PF slots ahead, DMA pieces,
+// chunk synchronisation, epilogue stages) is run_layer's; what a slot issues differs:
+//   first block of a pair,  slots 0-3:  acc += Wh_k Xh_k ; acc += Wh_k Xl_k     (one operand read, two MFMAs)
+//   second block of a pair, slots 0-3:  acc += Wl_k Xh_k
+//   slots 4, 5 of both: nothing (the prefetched fp6 operands are not used)
+// `lo`: the f16 residuals of the input blocks (encode / Epi::lo_dst), same element order as Blk::hv.
+template <int NT, bool HAS_ENC, int NH, int VARIANT, class PEND, class EPI>
+__device__ __forceinline__ f32x16 run_layer_x3(Pipe<VARIANT>& P, Pre& pf, unsigned& wsc, const Act& in, const u32x16* lo, const Blk& enc,
+                                               const u32x16& enc_lo, const float* bias_tab, PEND&& pend, EPI& epi) {
+    constexpr int NL = (HAS_ENC ? 1 : 0) + NH;   // logical blocks per tile
+    constexpr int NB = 2 * NL;                   // stream blocks per tile
+    constexpr int NS = NB * SLOTS_PER_BLOCK;     // slots per tile
+    static_assert((NT * NS) % CHUNK_SLOTS == 0, "a layer is a whole number of chunks");
+    f32x16 prev = {0};
+    f32x16 bias_next = *reinterpret_cast<const f32x16*>(bias_tab);
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc = bias_next;
+        static_for<0, NS>([&](auto GS) {
+            constexpr int g = decltype(GS)::value;
+            constexpr int G = t * NS + g;
+            constexpr int cr = G % CHUNK_SLOTS;
+            constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
+            constexpr int lb = bb >> 1;          // logical block, and which of its two stream blocks
+            constexpr bool resid = (bb & 1) != 0;
+            if constexpr (s < 4) {
+                const f16x8 aw = __builtin_bit_cast(f16x8, pf.q[G % 4]);
+                if constexpr (HAS_ENC && lb == 0) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(enc.hv)), acc, 0, 0, 0);
+                    if constexpr (!resid) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(enc_lo)), acc, 0, 0, 0);
+                } else {
+                    constexpr int ib = lb - (HAS_ENC ? 1 : 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(in.b[ib].hv)), acc, 0, 0, 0);
+                    if constexpr (!resid) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(lo[ib])), acc, 0, 0, 0);
+                }
+            }
+            {
+                constexpr int Gp = G + PF;
+                constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
+                constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+            }
+            if constexpr (g == NS / 2 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x16*>(bias_tab + (t + 1) * 32);
+            if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
+            static_for<0, 8 * N_STAGES>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if constexpr (g == stage_slot_x3(q, NS)) {
+                    if constexpr (t == 0) pend(std::integral_constant<int, q / N_STAGES>{}, std::integral_constant<int, q % N_STAGES>{});
+                    else epi.template stage<(t > 0 ? t - 1 : 0), q / N_STAGES, q % N_STAGES>(prev);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (cr == SYNC_SLOT) P.sync_next();
+            if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
+        });
+        asm volatile("" : "+v"(acc));
+        prev = acc;
+    });
+    return prev;
+}
+
 // [x, sin(2^k x), cos(2^k x)] in the slot order of layout.h::enc_ref_index -> one block
 template <int PAIRS>
-__device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& enc, unsigned& peak) {
+__device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& enc, unsigned& peak, u32x16* lo_out = nullptr) {
     float vals[32];
     const float mul = h ? (float)(1 << (PAIRS / 3)) : 1.0f;
     const TurnPair tx = to_turns(x), ty = to_turns(y), tz = to_turns(z);
@@ -492,6 +586,7 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& en
         else if (j == 2) enc.hv = with_quarter<2>(enc.hv, hv);
         else enc.hv = with_quarter<3>(enc.hv, hv);
     }
+    if (lo_out != nullptr) *lo_out = lres;   // the f16 residuals themselves (three-product layers)
     finish_block(enc, lres, mxv, peak);
 }
 
@@ -536,9 +631,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
         }
+        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X;
         Blk pe, de;
-        encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak);
-        if constexpr (VARIANT != VAR_TRUNK && !variant_ci(VARIANT)) {
+        u32x16 pe_lo, loA[4];   // VAR_TRUNK_X: f16 residuals of the encoding and of layer 0's output
+        encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak, VARIANT == VAR_TRUNK_X ? &pe_lo : nullptr);
+        if constexpr (!TRUNKV && !variant_ci(VARIANT)) {
             float dx = 0.f, dy = 0.f, dz = 0.f;
             if (valid) {
                 const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;
@@ -562,10 +659,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         using T3 = std::integral_constant<int, 3>;
         Epi<true, true, 0> eA{&A, {nullptr}, {nullptr}, &peak}, eB{&B, {nullptr}, {nullptr}, &peak};
 
-        // positions_linears.0 : 63 -> 256, ReLU (-> A)
-        f32x16 pacc = run_layer<8, true, 0>(P, pf, wsc, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
-        // positions_linears.1..4, two layers per trip (A -> B -> A)
-        for (int l = 1; l <= 3; l += 2) {
+        f32x16 pacc;
+        if constexpr (VARIANT == VAR_TRUNK_X) {
+            // positions_linears.0 and .1 as three f16 products (-> A with its f16 residuals in loA, -> B), then .2 (B -> A)
+            Epi<true, true, 0, true> eA0{&A, {nullptr}, {nullptr}, &peak, loA};
+            pacc = run_layer_x3<8, true, 0>(P, pf, wsc, A /*unused*/, loA /*unused*/, pe, pe_lo, bias + BT_L0 * 32, none, eA0);
+            pacc = run_layer_x3<8, false, 4>(P, pf, wsc, A, loA, pe, pe_lo, bias + (BT_L0 + 8) * 32,
+                                             [&](auto I, auto K) { eA0.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
+            pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 16) * 32,
+                                          [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
+        } else {
+            // positions_linears.0 : 63 -> 256, ReLU (-> A)
+            pacc = run_layer<8, true, 0>(P, pf, wsc, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
+        }
+        // positions_linears.1..4, two layers per trip (A -> B -> A)   (VAR_TRUNK_X: .3 and .4 only)
+        for (int l = (VARIANT == VAR_TRUNK_X ? 3 : 1); l <= 3; l += 2) {
             pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
                                           [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
             pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
@@ -590,12 +698,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             else if constexpr (VARIANT == VAR_REFL_CI)
                 return Epi<true, true, 4>{&B, {&part[0], &part[6], &part[7], &part[8]}, {ltab + TAB_SIG, rad[0], rad[1], rad[2]}, &peak};
             else
-                return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}, &peak};
+                return Epi<!TRUNKV, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}, &peak};
         }();
         pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 56) * 32,
                                       [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, e7);
 
-        if constexpr (VARIANT == VAR_TRUNK) {
+        if constexpr (TRUNKV) {
             flush(e7, T7{}, pacc);
         } else {
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}, &peak};
@@ -636,7 +744,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         }
 
         const float* sc = tabs + TAB_SCALAR;
-        if constexpr (VARIANT == VAR_TRUNK) {
+        if constexpr (TRUNKV) {
             const float p0 = part[0][0] + part[0][1];
             const float s = p0 + __shfl_xor(p0, 32) + sc[0];
             if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
@@ -708,6 +816,8 @@ hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launc
 hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
 #elif IBL_MX_VARIANT == 2
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+#elif IBL_MX_VARIANT == 5
+hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
 #elif IBL_MX_VARIANT == 3
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 #else
@@ -715,6 +825,9 @@ hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s) { return la
 #endif
 #else
 hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+#ifndef IBL_MX_F16ONLY
+hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
+#endif
 #ifndef IBL_MX_DEV_TRUNK_ONLY
 hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
@@ -729,6 +842,7 @@ hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -742,6 +856,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
 #endif
 #ifndef IBL_MX_F16ONLY          // the trunk-only evaluation feeds the finite-difference normal: never in plain f16
         case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);
+        case VAR_TRUNK_X: return IBL_L(trunk_x)(a, grid, stream);
 #endif
         default: return hipErrorInvalidValue;
     }

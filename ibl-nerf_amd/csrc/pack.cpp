@@ -225,14 +225,19 @@ inline uint8_t fp6_block(const float* v, uint32_t out[6]) {
     return (uint8_t)(se + 127);
 }
 
-// one 8 KiB block: w(i, h, jj) = weight of tile row i for k-slot jj (0..31) of lane half h
+// one 8 KiB block: w(i, h, jj) = weight of tile row i for k-slot jj (0..31) of lane half h.  res_blk (layers 0 and 1): the
+// residual block that takes f16(w - f16 w) in its f16 area, slot for slot (layout_mx.h: CH_RES)
 template <class WF>
-void pack_block(char* blk, WF&& w) {
+void pack_block(char* blk, WF&& w, char* res_blk = nullptr) {
     for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 31, h = lane >> 5;
         if (g_identity) {
             int32_t* m = g_map_mx + ((size_t)((blk - g_mx_base) / mx::BLOCK_BYTES) * 64 + lane) * 32;
             for (int jj = 0; jj < 32; ++jj) m[jj] = (int32_t)w(i, h, jj);
+            if (res_blk != nullptr) {
+                int32_t* m2 = g_map_mx + ((size_t)((res_blk - g_mx_base) / mx::BLOCK_BYTES) * 64 + lane) * 32;
+                for (int jj = 0; jj < 32; ++jj) m2[jj] = m[jj];
+            }
             continue;
         }
         float full[32], res[32];
@@ -242,6 +247,10 @@ void pack_block(char* blk, WF&& w) {
             std::memcpy(blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2, &hb, 2);
             full[jj] = x;
             res[jj] = x - f16_round(x);
+            if (res_blk != nullptr) {
+                const uint16_t rb = f16_bits(res[jj]);
+                std::memcpy(res_blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2, &rb, 2);
+            }
         }
         uint32_t c6[6], r6[6];
         const uint32_t sw = fp6_block(full, c6), sr = fp6_block(res, r6);
@@ -255,19 +264,19 @@ void pack_block(char* blk, WF&& w) {
 }
 
 // the 4 blocks of rows [row0, row0+32) of layer l over a 256-feature activation (columns from col_base)
-void pack_h_mx(char* blk0, const Net& n, int l, int row0, int col_base) {
+void pack_h_mx(char* blk0, const Net& n, int l, int row0, int col_base, char* res0 = nullptr) {
     for (int b = 0; b < 4; ++b)
         pack_block(blk0 + (size_t)b * mx::BLOCK_BYTES, [&](int i, int h, int jj) {
             const int j = jj >> 3, e = jj & 7;
             return n.W(l, row0 + i, col_base + 32 * (2 * b + (j >> 1)) + acc_feature(8 * (j & 1) + e, h));
-        });
+        }, res0 ? res0 + (size_t)b * mx::BLOCK_BYTES : nullptr);
 }
 // the one encoding block of rows [row0, row0+32)
-void pack_enc_mx(char* blk, const Net& n, int l, int row0, int col_base, int pairs_per_half) {
+void pack_enc_mx(char* blk, const Net& n, int l, int row0, int col_base, int pairs_per_half, char* res = nullptr) {
     pack_block(blk, [&](int i, int h, int jj) {
         const int ref = enc_ref_index(jj, h, pairs_per_half);
         return ref < 0 ? 0.0f : n.W(l, row0 + i, col_base + ref);
-    });
+    }, res);
 }
 
 }  // namespace
@@ -282,9 +291,11 @@ void pack_network_mx(const float* blob, void* stream_out, float* tab) {
     if (g_identity) g_mx_base = s;
     else std::memset(s, 0, mx::STREAM_BYTES);
     auto at = [&](int chunk, int block = 0) { return s + (size_t)chunk * CHUNK_BYTES + (size_t)block * mx::BLOCK_BYTES; };
-    for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF);
+    // layers 0 and 1 also fill their residual blocks (the mixed TRUNK form runs them as three f16 products)
+    for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF, at(mx::CH_RES, t));
     for (int l = 1; l <= 4; ++l)
-        for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L1 + 8 * (l - 1) + t), n, L_POS0 + l, 32 * t, 0);
+        for (int t = 0; t < 8; ++t)
+            pack_h_mx(at(mx::CH_L1 + 8 * (l - 1) + t), n, L_POS0 + l, 32 * t, 0, l == 1 ? at(mx::CH_RES, 8 + 4 * t) : nullptr);
     for (int t = 0; t < 8; ++t) {                     // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
         pack_enc_mx(at(mx::CH_L5, 5 * t), n, L_POS5, 32 * t, 0, PE_PAIRS_PER_HALF);
         pack_h_mx(at(mx::CH_L5, 5 * t + 1), n, L_POS5, 32 * t, 63);

@@ -79,6 +79,15 @@ __global__ void k_pack_mx(const float* blob, const int* map, char* stream, long 
     const int lane = (int)(t & 63);
     char* blk = stream + blk_i * mx::BLOCK_BYTES;
     const int* m = map + t * 32;
+    if (blk_i >= (long)mx::CH_RES * mx::CHUNK_BLOCKS) {   // residual block of layer 0 / 1 (layout_mx.h): f16(w - f16 w) in the f16 area only
+        for (int jj = 0; jj < 32; ++jj) {
+            const int idx = m[jj];
+            const float x = idx ? blob[idx - 1] : 0.0f;
+            const _Float16 r = (_Float16)(x - (float)(_Float16)x);
+            *reinterpret_cast<_Float16*>(blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2) = r;
+        }
+        return;
+    }
     float full[32], res[32];
     bool bad = false;
     for (int jj = 0; jj < 32; ++jj) {

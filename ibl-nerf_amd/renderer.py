@@ -68,13 +68,15 @@ class Renderer:
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
                  epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
-        """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6" (default: three f16 products on hi/lo splits, ~2^-22
-        per operand, for every query except the reflected-ray ones, which run one f16 + two block-scaled fp6 products, ~2^-16),
-        "f16x3" (precise everywhere), "f16x3_main" (f16 + fp6 also for the fine pass's offset queries: 16 % faster, the normal's
-        worst ray at 1.5e-3 on a checkpoint with surfaces), "f16_mxfp6" (fast everywhere: 1e-2 on direct channels of grazing
-        rays there), "f16_mixed" (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three
-        bf16 products, 2^-17, the full fp32 range).  The f16 modes need inputs, weights and activations below 65504; the
-        kernels detect anything beyond and `render_rays` / `network_query` then repeat the call on a bf16x3 context.
+        """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6x" (default: three f16 products on hi/lo splits, ~2^-22
+        per operand, for the main, auxiliary and coarse-grid offset queries; the fine pass's offset queries on the fast kernel's
+        mixed trunk form — its first two layers as three f16 products, the others as one f16 + two block-scaled fp6 products;
+        the reflected-ray queries on the fast kernel), "f16x3_mxfp6" (all offset queries on the precise kernel), "f16x3" (precise
+        everywhere), "f16x3_main" (the plain fast kernel for the fine pass's offset queries: the normal's worst ray at 1.5e-3 on
+        a checkpoint with surfaces), "f16_mxfp6" (fast everywhere: 1e-2 on direct channels of grazing rays there), "f16_mixed"
+        (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three bf16 products, 2^-17, the
+        full fp32 range).  The f16 modes need inputs, weights and activations below 65504; the kernels detect anything beyond
+        and `render_rays` / `network_query` then repeat the call on a bf16x3 context.
         range_check: "eager" reads the kernel's range flag after every call (one device synchronisation per call: right
         for frame-sized calls whose results are read back anyway); "lazy" never synchronises: each call looks at the
         snapshot its predecessors left behind (iblnerf_range_peek), and on an out-of-range event warns that the flagged
@@ -592,7 +594,7 @@ def _check_supported(kw):
 _renderers = {}
 NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
                 "normal_map_from_depth_gradient_direction_epsilon": 2, "inferred_normal_map": 3}   # target_normal_map_for_radiance_calculation values built
-DEFAULT_MLP_PRECISION = "f16x3_mxfp6"
+DEFAULT_MLP_PRECISION = "f16x3_mxfp6x"
 
 
 _tokens = itertools.count(1)

@@ -68,10 +68,14 @@ typedef struct {
                                                                   on a checkpoint with surfaces the density head amplifies operand
                                                                   round-off ~100x and only this mode keeps grazing rays at 1e-4
                                           IBLNERF_MLP_F16_MXFP6   2^-16 /  6  one f16 product + two block-scaled fp6 residual products
-                                          IBLNERF_MLP_F16X3_MXFP6 (the Python default) F16X3 for every query except the reflected-ray
+                                          IBLNERF_MLP_F16X3_MXFP6 F16X3 for every query except the reflected-ray
                                                                   queries, which run F16_MXFP6: they only feed maps that are
                                                                   ill-conditioned in the reference itself (its fp64 and fp32 runs
                                                                   differ by 2e-2 .. 6e-2 there on a checkpoint with surfaces)
+                                          IBLNERF_MLP_F16X3_MXFP6X (the Python default) as F16X3_MXFP6, with the fine pass's offset queries on the fast kernel's
+                                                                  mixed trunk form: positions_linears.0 and .1 as three f16 products,
+                                                                  the other six layers as F16_MXFP6 (the first layers set the density's
+                                                                  error on a network with surfaces)
                                           IBLNERF_MLP_F16X3_MAIN  F16X3 for the queries whose results are direct channels (main query
                                                                   of both passes, auxiliary networks, iblnerf_network_query) and for
                                                                   the coarse grid's offset queries; F16_MXFP6 also for the fine
@@ -87,7 +91,7 @@ typedef struct {
     int32_t infer_normal_at_surface;   /* 0 | 1: the IBLNERF_AUX_NORMAL network is evaluated once per ray at the surface point
                                           o + d * target_depth instead of at every sample (ibl_nerf_renderer.py:268-271) */
 } iblnerf_options;
-enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5 };
+enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3 };
 

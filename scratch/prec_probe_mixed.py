@@ -45,13 +45,16 @@ def network_query(sd, pts, viewdirs):
     return out
 O.network_query = network_query
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 g, sdc, sdf, gt, edit = load_golden("fitted_wide")
+# the 96 rays whose normal is worst on the GPU under the coarser modes (scratch/worst_rays.py) + 96 others: the full 1 024 take 25 min per row
+import os
+rsel = np.load("gpurun_out/worst_rays.npy") if os.path.exists("gpurun_out/worst_rays.npy") else np.arange(96)
+rsel = np.concatenate([rsel, np.setdiff1d(np.arange(1024), rsel)[:96]])
 lut = load_lut_rgb()
 L = ["positions_linears.%d" % i for i in range(8)]
 for label, sel in (("fine offsets fast", []), ("+ layer 0 precise", L[:1]), ("+ layers 0-1", L[:2]), ("+ layers 0-2", L[:3]), ("+ layers 0-3", L[:4]), ("all precise", L)):
     PRECISE = set(sel); N_OFFSET[0] = 0
-    res = O.render_rays(sdc, sdf, g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0, lut)
-    e = np.abs(res["target_normal_map"] - g["out__target_normal_map"][:n]).max(-1)
-    d = np.abs(res["depth_map"] - g["out__depth_map"][:n]) / np.abs(g["out__depth_map"]).max()
-    print("%-22s normal: max %.2e  p99.9 %.2e  p99 %.2e   depth max %.1e" % (label, e.max(), np.percentile(e, 99.9), np.percentile(e, 99), d.max()), flush=True)
+    res = O.render_rays(sdc, sdf, g["rays_o"][rsel], g["rays_d"][rsel], 0.5, 8.0, lut)
+    e = np.abs(res["target_normal_map"] - g["out__target_normal_map"][rsel]).max(-1)
+    d = np.abs(res["depth_map"] - g["out__depth_map"][rsel]) / np.abs(g["out__depth_map"]).max()
+    print("%-22s normal: max %.2e  2nd %.2e  10th %.2e  median %.2e   depth max %.1e" % (label, e.max(), np.sort(e)[-2], np.sort(e)[-10], np.median(e), d.max()), flush=True)

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-PRECISE = ["f16x3_mxfp6", "f16x3"]                 # the default and the precise-everywhere mode: held to the fixture tolerances
+PRECISE = ["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3"]                 # the default and the precise-everywhere mode: held to the fixture tolerances
 COARSER = ["bf16x3", "f16_mxfp6", "f16_mixed"]     # 2^-17 / 2^-16 / 2^-11 operands: their error class on this checkpoint is recorded
 # (f16x3_main: the direct channels of f16x3, f16 + fp6 offsets on the fine grid: its normal is recorded on the 1 024-ray fixture)
 REFLECTED = ["specular_map", "color_map", "reflected_radiance_map", "prefiltered_reflected_map",
@@ -38,7 +38,7 @@ def R():
 
 # MLP stage bound per product scheme, relative to each output channel's range over the fixture (density spans -8 .. 100):
 # measured 3.9e-6 / 8.6e-5 / 3.0e-4; the fp32 oracle sits at 4e-7.  iblnerf_network_query is a precise-class query in the default mode.
-STAGE_TOL = {"f16x3_mxfp6": 1e-5, "f16x3": 1e-5, "f16x3_main": 1e-5, "bf16x3": 2e-4, "f16_mxfp6": 6e-4, "f16_mixed": 6e-4}
+STAGE_TOL = {"f16x3_mxfp6x": 1e-5, "f16x3_mxfp6": 1e-5, "f16x3": 1e-5, "f16x3_main": 1e-5, "bf16x3": 2e-4, "f16_mxfp6": 6e-4, "f16_mixed": 6e-4}
 
 
 @pytest.mark.parametrize("prec", PRECISE + ["f16x3_main"] + COARSER)
@@ -108,6 +108,34 @@ def test_fitted_render_error_class_of_the_coarser_modes(R, lut, prec):
     per_ray = np.abs(res["depth_map"] - g["out__depth_map"]) / np.abs(g["out__depth_map"]).max()
     assert np.median(per_ray) <= (2e-4 if prec == "f16_mixed" else 2e-6)
     assert r.range_fallbacks == 0
+
+
+def test_mixed_trunk_form_of_the_fast_kernel(R, lut, monkeypatch):
+    """VAR_TRUNK_X (the fast kernel's trunk form with positions_linears.0 / .1 as three f16 products; the default mode's fine-grid
+    offset queries) on its own, through iblnerf_network_query (IBLNERF_X_USER routes the trunk-only form of that entry to it):
+    density of the fitted checkpoint's recorded offset points between the fast kernel's and the precise kernel's error (measured
+    2.1e-3 against 7.4e-3 and 2.0e-4 abs), ragged point counts, bit-repeatability (the LDS-DMA of its chunks gathers network and
+    residual blocks from two places per wave), device-side packing bit-identical to the host's."""
+    monkeypatch.setenv("IBLNERF_X_USER", "1")          # read by iblnerf_create
+    g, sdc, sdf, _, _ = load_golden("fitted_plain")
+    rx = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x")
+    fast = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
+    prec = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16x3")
+    err = {}
+    for name, r in (("x", rx), ("fast", fast), ("precise", prec)):
+        err[name] = max(float(np.abs(r.network_query(g["q_%s_eps_pts" % p], None, w).cpu().numpy() - g["q_%s_eps_sigma" % p]).max())
+                        for p, w in (("c", 0), ("f", 1)))
+    assert err["precise"] < 5e-4 < err["x"] < 4e-3 < err["fast"] < 2e-2, err
+    pts = torch.rand((8192, 96, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 8 - 4
+    a = rx.network_query(pts, None, 1)
+    for _ in range(3):
+        assert torch.equal(rx.network_query(pts, None, 1), a)
+    for n in (1, 31, 33, 127, 129):
+        assert float((rx.network_query(pts[:n, :7], None, 1) - prec.network_query(pts[:n, :7], None, 1)).abs().max()) <= 5e-3
+    monkeypatch.setenv("IBLNERF_X_USER", "1")
+    dev = R.Renderer(64, 128, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x")
+    dev.load_weights(1, {k: torch.from_numpy(v).cuda() for k, v in sdf.items()})
+    assert torch.equal(dev.network_query(pts[:64], None, 1), rx.network_query(pts[:64], None, 1))
 
 
 def test_fitted_wide_error_class_of_f16x3_main(R, lut):

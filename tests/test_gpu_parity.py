@@ -29,8 +29,8 @@ def R():
 
 # product schemes of the fused MLP kernel (include/iblnerf.h: mlp_precision): the default mixes the precise f16x3 kernel with the
 # f16 + MX-fp6 one per query class; the others run one kernel for every query
-PRECISIONS = ["f16x3_mxfp6", "f16x3_main", "f16x3", "f16_mxfp6", "bf16x3"]
-F16_MODES = ["f16x3_mxfp6", "f16x3_main", "f16x3", "f16_mxfp6"]        # modes with the f16 range guard
+PRECISIONS = ["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3_main", "f16x3", "f16_mxfp6", "bf16x3"]
+F16_MODES = ["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3_main", "f16x3", "f16_mxfp6"]        # modes with the f16 range guard
 
 
 def make_renderer(R, g, sdc, sdf, lut, **kw):

@@ -354,7 +354,7 @@ def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
     blob = ck.state_dict_to_blob(sd)
     stream = np.zeros(lib.iblnerf_stream_bytes_mx(), dtype=np.uint8)
     tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
-    assert stream.size == 98 * 32768
+    assert stream.size == (98 + 10) * 32768            # the network's 98 chunks + 40 residual blocks of layers 0 and 1 (layout_mx.h: CH_RES)
     assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == 0
     assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size - 1, tab.ctypes.data, tab.size) == -1
     emu = EmuMX(stream.tobytes(), tab)
@@ -366,6 +366,20 @@ def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
             feat = 32 * (2 + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h)
             assert np.array_equal(emu.A16[blk, jj >> 3, h, :, jj & 7], W[96:128, feat].astype(np.float16).astype(np.float64))
             assert np.abs(emu.W6[blk, h, :, jj] - W[96:128, feat]).max() <= 0.07 * np.abs(W[96:128]).max()   # 4 significant bits, block-scaled
+    # residual blocks (the mixed TRUNK form's third product): f16(W - f16 W) of layer 1, tile 3, block 1 and of layer 0, tile 5, slot for slot
+    W1, W0 = sd["positions_linears.1.weight"], sd["positions_linears.0.weight"]
+    rb1, rb0 = 98 * 4 + 8 + 4 * 3 + 1, 98 * 4 + 5
+    for h in range(2):
+        for jj in (0, 9, 31):
+            feat = 32 * (2 + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h)
+            w = W1[96:128, feat]
+            want = (w - w.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float64)
+            assert np.array_equal(emu.A16[rb1, jj >> 3, h, :, jj & 7], want) and np.abs(want).max() > 0
+            ref_i = enc_ref_index(jj, h, 15)
+            w0 = W0[160:192, ref_i] if ref_i >= 0 else np.zeros(32, np.float32)
+            assert np.array_equal(emu.A16[rb0, jj >> 3, h, :, jj & 7], (w0 - w0.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float64))
+    raw_blocks = np.frombuffer(stream.tobytes(), dtype=np.uint8).reshape(-1, 8192)
+    assert not raw_blocks[98 * 4:, 4096:].any()         # nothing but the f16 area is used in a residual block
     rng = np.random.RandomState(3)
     pts = rng.uniform(-8, 8, (24, 3)).astype(np.float32)
     dirs = rng.uniform(-1.2, 1.2, (24, 3)).astype(np.float32)

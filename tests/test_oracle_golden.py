@@ -149,9 +149,11 @@ def test_fitted_checkpoint_end_to_end(name, lut):
     eps-normal and what follows from it alone at the tolerances of the random-init fixtures; the reflected-ray channels at a small
     multiple of the reference's own float64-vs-float32 difference."""
     g, sdc, sdf, gt, edit = load_golden(name)
-    res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, n_samples(g),
-                        int(g["n_importance"]), gt, edit, {}, golden_flags(g))
-    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    n = min(g["rays_o"].shape[0], 256)              # (fitted_wide: its first 256 rays keep the CPU suite short; the GPU tests take all 1 024)
+    g = {k: (g[k][:n] if k.startswith("out__") else g[k]) for k in g.files}
+    res = O.render_rays(sdc, sdf, g["rays_o"][:n], g["rays_d"][:n], float(g["near"]), float(g["far"]), lut, 64,
+                        int(g["n_importance"]), gt, edit, {}, {})
+    assert sorted(res.keys()) == sorted(k[5:] for k in g if k.startswith("out__"))
     assert float(g["out__weights0"].max()) > 0.9 and float(g["out__acc_map"].min()) > 0.999          # surfaces, not fog
     for sfx in ("", "0"):
         for k in DIRECT:
