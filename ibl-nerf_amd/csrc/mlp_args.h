@@ -21,7 +21,7 @@ struct MlpArgs {
 };
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
 hipError_t launch_mlp_f16x3(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);  // three f16 products, same stream layout with f16 pairs
-hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h)
+hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h); also VAR_TRUNK_X, its mixed trunk form
 hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
 
 }  // namespace ibl
