@@ -164,9 +164,11 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         return IBLNERF_ERR_INVALID;
     }
     if (opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON && opts->normal_mode != IBLNERF_NORMAL_GROUND_TRUTH &&
-        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON && opts->normal_mode != IBLNERF_NORMAL_INFERRED) {
+        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON && opts->normal_mode != IBLNERF_NORMAL_INFERRED &&
+        opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT && opts->normal_mode != IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION) {
         g_create_error = "normal_mode must be IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON (0), IBLNERF_NORMAL_GROUND_TRUTH (1), "
-                         "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2) or IBLNERF_NORMAL_INFERRED (3)";
+                         "IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (2), IBLNERF_NORMAL_INFERRED (3), "
+                         "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -484,6 +486,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface))
             kern = K_MX16;
     }
+    // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
+    if (variant == VAR_TRUNK_GRAD) kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3;
     a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
     a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];
@@ -508,7 +512,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                : kern == K_MXX ? launch_mlp_mx(VAR_TRUNK_X, a, c->n_cu, s)
                : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
-    c->flop_alg += (double)n_pts * (variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
+    c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
 }
 
@@ -523,6 +527,17 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
     if (int rc = run_mlp(c, (hipStream_t)stream, d_viewdirs ? VAR_FULL : VAR_TRUNK, which, d_pts, d_viewdirs, n_samples,
                          (long)n_rays * n_samples, d_out))
         return rc;
+    return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+int iblnerf_density_gradient(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)))
+        return c->fail(IBLNERF_ERR_INVALID, "density_gradient: bad arguments");
+    if (n_pts == 0) return IBLNERF_OK;
+    if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "density_gradient: weights of network %d not uploaded", which);
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    if (int rc = run_mlp(c, (hipStream_t)stream, VAR_TRUNK_GRAD, which, d_pts, nullptr, 1, (long)n_pts, d_out, 4)) return rc;
     return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
@@ -614,6 +629,7 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
     a.weights = weights; a.lut = c->d_lut; a.near = near_; a.far = far_;
     a.eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
     a.tilted_rays = tilt ? 1 : 0;
+    a.grad_normal = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT ? 1 : c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION ? 2 : 0;
     a.irradiance_sigmoid = c->aux_on[2] ? 1 : 0;
     a.nrm_raw = nrm_raw;
     a.normal_inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED ? 1 : 0;
@@ -657,7 +673,13 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // (:55-75), trunk only; none in the ground-truth normal mode
     const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
     const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
-    if (ov.gt_normal == nullptr && !inferred) {
+    const bool by_gradient = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT || c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION;
+    if (by_gradient) {
+        // the autograd normal modes (normal_from_depth.py:16-52, :102-137): density and its position gradient at the main query's own
+        // points (c->pts still holds them), rows [sigma, d sigma / d x, y, z]; pass A applies the chain rule through the compositing
+        rc = run_mlp(c, s, VAR_TRUNK_GRAD, which, c->pts, nullptr, S, R * S, c->sig4, 4, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
+        if (rc) return rc;
+    } else if (ov.gt_normal == nullptr && !inferred) {
         HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
         if (rc) return rc;

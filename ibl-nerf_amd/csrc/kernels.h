@@ -84,7 +84,7 @@ struct PassAArgs {
     const float* rays_o; const float* rays_d;   // [R,3]
     const float* z; int z_stride;               // see launch_make_points
     const float* raw;                           // [R,S,18]
-    const float* sig4;                          // [4,R,S]
+    const float* sig4;                          // [4,R,S]; with grad_normal: [R,S,4] rows (sigma, d sigma / d x, y, z) of the density-gradient query
     const float* noise = nullptr;               // [R,S] added to the density before compositing (raw_noise_std > 0, :208-216, :242) or null
     const float* nrm_raw;                       // [R,S,3] normal_mlp samples or null (ibl_nerf_renderer.py:273-276)
     int nrm_at_surface;                         // nrm_raw is [R,3]: one evaluation per ray at the surface point (:268-271)
@@ -94,6 +94,7 @@ struct PassAArgs {
     float near, far, eps;
     int irradiance_sigmoid;                     // an irradiance_mlp's samples take sigmoid, whatever radiance_f is (:300-303)
     int tilted_rays;                            // 0: offset-sample depths (normal_from_depth.py:139-183), 1: tilted-ray depths (:55-100)
+    int grad_normal = 0;                        // 1: normal from d depth / d ray origin (normal_from_depth.py:102-137), 2: d depth / d ray direction (:16-52)
     int lut_coefficient_F0;                     // 0 -> 'F' (shipped), 1 -> 'F0'
     int correct_depth;                          // correct_depth_for_prefiltered_radiance_infer
     int radiance_linear;                        // use_radiance_linear: radiance_f = ReLU, LDR map x/(1+x) before gamma

@@ -45,11 +45,25 @@ constexpr int CH_ALB = 68;   // albedo_feature_linear      16              4    
 constexpr int CH_IRR = 72;   // irradiance_feature_linear  16              4       4
 constexpr int CH_VIEW = 76;  // views_linears.0            2 (DE) + 16     8       9
 constexpr int CH_AR = 85;    // additional_radiance_feature_linear.{0,1,2}  16   4 each   12
-constexpr int N_CHUNKS = 97;
+constexpr int N_CHUNKS_NET = 97;   // the network's forward layers
 constexpr int N_CHUNKS_TRUNK = 60;
+// Backward stream of the trunk (the density-gradient query, VAR_TRUNK_GRAD: d sigma / d position): the same tile format
+// with TRANSPOSED matrices, layers in reverse order.  Rows of a tile = 32 INPUT features of the layer, K = its 256 output
+// features in accumulator order, so the backward chain dZ(l-1) = (W(l)^T dZ(l)) * [Z(l-1) > 0] is the forward loop run on
+// these chunks.  positions_linears.5 has 10 row tiles (8 hidden + 2 for its 63 encoding columns), .0 has the 2 encoding
+// tiles only; an encoding tile's row (r&3) + 8*(r>>2) + 4h is encoding slot 16*tile + r of lane half h (enc_ref_index), so
+// that the gradient of a slot lands in the lane half that computed the slot's sine / cosine.
+//   layer                          row tiles   chunks   first chunk
+constexpr int CH_G7 = 97;    // positions_linears.7^T      8           8
+constexpr int CH_G6 = 105;   // positions_linears.6^T      8           8
+constexpr int CH_G5 = 113;   // positions_linears.5^T      8 + 2       10
+constexpr int CH_G4 = 123;   // positions_linears.4..1^T   8           8 each (123..154)
+constexpr int CH_G0 = 155;   // positions_linears.0^T      2           2
+constexpr int N_CHUNKS_GRAD = 60;
+constexpr int N_CHUNKS = N_CHUNKS_NET + N_CHUNKS_GRAD;   // 157
 constexpr int PE_KSTEPS = 4;   // 64 slots, 63 used
 constexpr int DE_KSTEPS = 2;   // 32 slots, 27 used
-constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 3.06 MiB per network
+constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 4.9 MiB per network
 
 // fp32 side tables (biases in accumulator-lane layout + the tiny N=1/3 heads that run on the VALU)
 // Lane-layout entry [tile][h][r] holds the value for feature 32*tile_local + (r&3) + 8*(r>>2) + 4h.
@@ -105,7 +119,8 @@ constexpr int REFL_CH = 13;   // sigma + channels 6..17 (what raw2outputs_simple
 // raw2outputs_simple reads).  *_CI: the same for a network built with is_color_independent_to_direction (ibl_nerf.py:192):
 // the radiance heads read the trunk output, feature_linear and views_linears are not evaluated.
 enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_REFL_CI = 4,
-               VAR_TRUNK_X = 5 };   // fast kernel only: TRUNK with its first two layers as three f16 products (layout_mx.h)
+               VAR_TRUNK_X = 5,     // fast kernel only: TRUNK with its first two layers as three f16 products (layout_mx.h)
+               VAR_TRUNK_GRAD = 6 };  // three-product kernels only: TRUNK forward + its backward chain, out = [sigma, d sigma / d x, y, z]
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

@@ -82,7 +82,8 @@ __device__ long long g_trace[256];
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
+    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : VARIANT == VAR_TRUNK_GRAD ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
+                                  : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
     unsigned lds_ring;   // LDS byte address of the ring (for M0)
@@ -99,6 +100,7 @@ struct Pipe {
     __device__ __forceinline__ static int stream_chunk(int p) {
         if (p < N_CHUNKS_TRUNK) return p;
         int q = p - N_CHUNKS_TRUNK;
+        if (VARIANT == VAR_TRUNK_GRAD) return CH_G7 + q;   // the backward stream follows the trunk
         if (!CI) { if (q < 8) return CH_FEAT + q; q -= 8; }
         if (ALBIRR) { if (q < 8) return CH_ALB + q; q -= 8; }
         if (!CI) { if (q < 9) return CH_VIEW + q; q -= 9; }
@@ -219,12 +221,16 @@ struct Acc {
 //   NCH  : running fp32 dot products of v with N=1/3 head weight rows (sigma, roughness, albedo,
 //          irradiance, radiance heads) held in lane layout in LDS.
 // The layer bias is already in the accumulator (it is the MFMA chain's initial C).
-template <bool STORE, bool RELU, int NCH>
+//   MASK : (density-gradient variant) the ReLU's pass bits of this tile, 16 per lane, go to the wave's mask area in LDS:
+//          u16 at mrow + 128 * T (mrow = this lane's slot in the layer's row, see MASK_* below)
+template <bool STORE, bool RELU, int NCH, bool MASK = false>
 struct Epi {
     Act* dst;
     float* part[NCH > 0 ? NCH : 1];
     const float* tab[NCH > 0 ? NCH : 1];   // this lane-half's row of tile 0 of each head table ([tile][2][16])
+    char* mrow;
     u32x4 h, l;
+    unsigned mb;
 
     template <int T, int I>
     __device__ __forceinline__ void slice(const Acc& a) {
@@ -242,6 +248,11 @@ struct Epi {
             x0 = relu_bits(x0);
             x1 = relu_bits(x1);
 #endif
+        }
+        if constexpr (MASK) {
+            const unsigned bits = (x0 > 0.0f ? 1u << (2 * I) : 0u) | (x1 > 0.0f ? 2u << (2 * I) : 0u);
+            mb = I == 0 ? bits : (mb | bits);
+            if constexpr (I == 7) *reinterpret_cast<unsigned short*>(mrow + 128 * T) = (unsigned short)mb;
         }
         if constexpr (STORE) {
             unsigned hh, ll;
@@ -263,6 +274,50 @@ struct Epi {
     }
 };
 
+// Epilogue of a tile of the BACKWARD chain (density-gradient variant).  Tiles 0..7 are the gradient with respect to the previous
+// layer's 256 post-ReLU features: times the recorded pass bits, then (hi, lo) fragments of `dst` as in the forward.  Tiles 8, 9
+// (positions_linears.5^T) / all tiles with ENC_ACC (positions_linears.0^T) are the gradient with respect to the 64 encoding
+// slots: kept in fp32, genc[16 * tile + r].
+template <bool ENC_ACC>
+struct EpiG {
+    Act* dst;
+    const char* mrow;
+    float* genc;
+    u32x4 h, l;
+    unsigned mw;
+
+    template <int T, int I>
+    __device__ __forceinline__ void slice(const Acc& a) {
+        float x0 = a.main[2 * I], x1 = a.main[2 * I + 1];
+        if constexpr (ENC_ACC) {
+            genc[16 * T + 2 * I] += x0;
+            genc[16 * T + 2 * I + 1] += x1;
+            if constexpr (I == 7) { pin(genc[16 * T]); }
+        } else if constexpr (T >= 8) {
+            genc[16 * (T - 8) + 2 * I] = x0;
+            genc[16 * (T - 8) + 2 * I + 1] = x1;
+        } else {
+            if constexpr (I == 0) mw = *reinterpret_cast<const unsigned short*>(mrow + 128 * T);
+            x0 = (mw & (1u << (2 * I))) ? x0 : 0.0f;
+            x1 = (mw & (2u << (2 * I))) ? x1 : 0.0f;
+            unsigned hh, ll;
+            split_pair(x0, x1, hh, ll);
+            h[I & 3] = hh;
+            l[I & 3] = ll;
+            if constexpr ((I & 3) == 3) {
+                asm volatile("" : "+v"(h), "+v"(l));
+                dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
+                dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+            }
+        }
+    }
+};
+// LDS of the density-gradient variant behind the side tables: 16 zero floats per lane half (the backward layers' "bias"), then per
+// wave 8 KiB of pass bits [layer 8][tile 8][lane 64] u16
+constexpr int MASK_ZERO_OFF = LDS_BYTES;
+constexpr int MASK_OFF = LDS_BYTES + 128;
+constexpr int LDS_BYTES_GRAD = MASK_OFF + 4 * 8192;   // 155 904 of 163 840
+
 // One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then NKH
 // (16, or 0 for the first layer) k-steps over the 256-feature activation `in`; three MFMA products
 // per k-step.  Chunk boundaries (every 16 k-steps of the flat stream) are compile-time positions.
@@ -277,7 +332,7 @@ struct Epi {
 constexpr int DMA_K0 = 2;   // chunk-relative k-step after which the first DMA piece of the chunk two ahead is issued
 template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI>
 __device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
-                                         PEND&& pend, EPI& epi) {
+                                         PEND&& pend, EPI& epi, int bias_stride = 32) {
     constexpr int N = NKE + NKH;                       // k-steps per tile
     Acc prev;
     prev.main = f32x16{0};
@@ -291,7 +346,7 @@ __device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const 
         constexpr int t = decltype(T)::value;
         // the accumulator starts at the layer bias (lane layout [tile][h][16]): no add in the epilogue
         Acc acc;
-        acc.main = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+        acc.main = *reinterpret_cast<const f32x16*>(bias_tab + t * bias_stride);   // (0 for the backward layers: one row of zeros)
 #ifdef IBL_DUAL_ACC
         acc.cross = f32x16{0};
 #define ACC_X acc.cross
@@ -367,8 +422,7 @@ __device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const 
 // [x, sin(2^k x), cos(2^k x)] in the slot order of layout.h::enc_ref_index (sincos_enc.h: one
 // extended-precision range reduction per coordinate, exact 2^k scaling per frequency).
 template <int PAIRS, int NK>
-__device__ __forceinline__ void encode(float x, float y, float z, int h, Enc& enc) {
-    float vals[8 * NK];
+__device__ __forceinline__ void enc_values(float x, float y, float z, int h, float (&vals)[8 * NK]) {
     const float mul = h ? (float)(1 << (PAIRS / 3)) : 1.0f;   // half h starts at frequency index h * PAIRS/3
     const TurnPair tx = to_turns(x), ty = to_turns(y), tz = to_turns(z);
 #pragma unroll
@@ -380,6 +434,11 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Enc& en
     vals[2 * PAIRS + 1] = h ? 0.0f : y;
 #pragma unroll
     for (int i = 2 * PAIRS + 2; i < 8 * NK; ++i) vals[i] = 0.0f;
+}
+template <int PAIRS, int NK>
+__device__ __forceinline__ void encode(float x, float y, float z, int h, Enc& enc) {
+    float vals[8 * NK];
+    enc_values<PAIRS, NK>(x, y, z, h, vals);
 #pragma unroll
     for (int jj = 0; jj < NK; ++jj) {
         u32x4 hv, lv;
@@ -406,6 +465,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     // side tables -> LDS once per workgroup
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
+    if constexpr (VARIANT == VAR_TRUNK_GRAD)
+        if (threadIdx.x < 32) reinterpret_cast<float*>(smem + MASK_ZERO_OFF)[threadIdx.x] = 0.0f;
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
 
@@ -452,6 +513,102 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
+        if constexpr (VARIANT == VAR_TRUNK_GRAD) {
+            // ---- density and its gradient with respect to the position: the trunk forward with every ReLU's pass bits
+            // recorded, then the backward chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on the transposed stream (what autograd
+            // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts) ----
+            char* mbase = smem + MASK_OFF + wave * 8192 + lane * 2;   // + 1024 * layer + 128 * tile
+            const float* zero = reinterpret_cast<const float*>(smem + MASK_ZERO_OFF) + h * 16;
+            using EM = Epi<true, true, 0, true>;
+            EM eA{&A, {nullptr}, {nullptr}, mbase}, eB{&B, {nullptr}, {nullptr}, mbase + 1024};
+#define IBL_PEND(e, T, acc) [&](auto I) { (e).template slice<T, decltype(I)::value>(acc); }
+            Acc pacc = run_layer<8, PE_KSTEPS, 0>(P, A, pe, bias + BT_L0 * 32, none, eA);                    // layer 0 -> A
+            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 8) * 32, IBL_PEND(eA, 7, pacc), eB);         // 1 -> B
+            eA.mrow = mbase + 2 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 16) * 32, IBL_PEND(eB, 7, pacc), eA);        // 2 -> A
+            eB.mrow = mbase + 3 * 1024;
+            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 24) * 32, IBL_PEND(eA, 7, pacc), eB);        // 3 -> B
+            eA.mrow = mbase + 4 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 32) * 32, IBL_PEND(eB, 7, pacc), eA);        // 4 -> A
+            eB.mrow = mbase + 5 * 1024;
+            pacc = run_layer<8, PE_KSTEPS, 16>(P, A, pe, bias + (BT_L0 + 40) * 32, IBL_PEND(eA, 7, pacc), eB);  // 5 (skip) -> B
+            eA.mrow = mbase + 6 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 48) * 32, IBL_PEND(eB, 7, pacc), eA);        // 6 -> A
+            Epi<false, true, 1, true> e7{nullptr, {&part[0]}, {ltab + TAB_SIG}, mbase + 7 * 1024};
+            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 56) * 32, IBL_PEND(eA, 7, pacc), e7);        // 7: sigma head + bits
+            static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
+            const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
+
+            // dZ(7) = sigma_linear.weight * bits(7) -> A
+            static_for<0, 8>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const unsigned mw = *reinterpret_cast<const unsigned short*>(mbase + 7 * 1024 + 128 * t);
+                static_for<0, 2>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    u32x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q + e;
+                        const f32x2 w = *reinterpret_cast<const f32x2*>(ltab + TAB_SIG + t * 32 + 2 * i);
+                        unsigned hh, ll;
+                        split_pair((mw & (1u << (2 * i))) ? w[0] : 0.0f, (mw & (2u << (2 * i))) ? w[1] : 0.0f, hh, ll);
+                        hv[e] = hh;
+                        lv[e] = ll;
+                    }
+                    A.hi[2 * t + q] = __builtin_bit_cast(bf16x8, hv);
+                    A.lo[2 * t + q] = __builtin_bit_cast(bf16x8, lv);
+                });
+            });
+            float genc[32];
+            EpiG<false> gA{&A, mbase, genc}, gB{&B, mbase + 6 * 1024, genc};
+            pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gB, 0);                                           // W7^T: dZ7 (A) -> dZ6 (B)
+            gA.mrow = mbase + 5 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W6^T -> dZ5 (A)
+            gB.mrow = mbase + 4 * 1024;
+            pacc = run_layer<10, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                         // W5^T -> dZ4 (B), encoding gradient
+            gA.mrow = mbase + 3 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 9, pacc), gA, 0);                          // W4^T -> dZ3 (A)
+            gB.mrow = mbase + 2 * 1024;
+            pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W3^T -> dZ2 (B)
+            gA.mrow = mbase + 1 * 1024;
+            pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W2^T -> dZ1 (A)
+            gB.mrow = mbase;
+            pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W1^T -> dZ0 (B)
+            EpiG<true> g0{nullptr, nullptr, genc};
+            pacc = run_layer<2, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), g0, 0);                          // W0^T: + encoding gradient
+            static_for<0, 8>([&](auto I) { g0.template slice<1, decltype(I)::value>(pacc); });
+#undef IBL_PEND
+            // chain rule through the encoding: slot 2u = sin(f x_c), 2u+1 = cos(f x_c) of pair u (c = u % 3, f = 2^(u/3) [* 32 in half 1]),
+            // slots 30, 31 = (x, y) | (z, pad)
+            float vals[8 * PE_KSTEPS];
+            if (valid) {   // (re-read: three registers less across the sixteen layers)
+                px = a.pts[3 * p + 0];
+                py = a.pts[3 * p + 1];
+                pz = a.pts[3 * p + 2];
+            }
+            enc_values<PE_PAIRS_PER_HALF, PE_KSTEPS>(px, py, pz, h, vals);
+            float g3[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < PE_PAIRS_PER_HALF; ++u) {
+                const float f = (float)(1 << (u / 3)) * (h ? (float)(1 << (PE_PAIRS_PER_HALF / 3)) : 1.0f);
+                g3[u % 3] += f * (genc[2 * u] * vals[2 * u + 1] - genc[2 * u + 1] * vals[2 * u]);
+            }
+            g3[h ? 2 : 0] += genc[2 * PE_PAIRS_PER_HALF];
+            if (!h) g3[1] += genc[2 * PE_PAIRS_PER_HALF + 1];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g3[c] += __shfl_xor(g3[c], 32);
+            if (valid && h == 0) {
+                f32x4 o = {sigma, g3[0], g3[1], g3[2]};
+                *reinterpret_cast<f32x4*>(a.out + 4 * p) = o;
+            }
+#ifdef IBL_F16X3
+            {   // range guard (see split_pair)
+                const float chk = fmaf(sigma, 0.0f, fmaf(g3[0], 0.0f, fmaf(g3[1], 0.0f, g3[2] * 0.0f)));
+                if (valid && chk != chk && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);
+            }
+#endif
+            continue;
+        }
         // whole epilogue of a layer's last tile, run before anything else may read its results
         auto flush = [&](auto& e, auto T, const Acc& acc) {
             static_for<0, 8>([&](auto I) { e.template slice<decltype(T)::value, decltype(I)::value>(acc); });
@@ -617,10 +774,11 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 2048);
+        (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  VARIANT == VAR_TRUNK_GRAD ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), IBL_KNS LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), VARIANT == VAR_TRUNK_GRAD ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
 #define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
@@ -633,11 +791,13 @@ IBL_DEFINE_LAUNCH(1)
 IBL_DEFINE_LAUNCH(2)
 #elif IBL_VARIANT == 3
 IBL_DEFINE_LAUNCH(3)
+#elif IBL_VARIANT == 6
+IBL_DEFINE_LAUNCH(6)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -647,6 +807,7 @@ hipError_t IBL_LAUNCH_NAME(1)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(2)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(3)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(4)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(6)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -658,6 +819,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_REFL: rc = IBL_LAUNCH_NAME(2)(a, grid, stream); break;
         case VAR_FULL_CI: rc = IBL_LAUNCH_NAME(3)(a, grid, stream); break;
         case VAR_REFL_CI: rc = IBL_LAUNCH_NAME(4)(a, grid, stream); break;
+        case VAR_TRUNK_GRAD: rc = IBL_LAUNCH_NAME(6)(a, grid, stream); break;
         default: return hipErrorInvalidValue;
     }
     if (rc != hipSuccess) return rc;

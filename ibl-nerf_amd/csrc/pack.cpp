@@ -104,6 +104,33 @@ void pack_enc(uint16_t* ks0, const Net& n, int l, int row0, int col_base, int pa
     }
 }
 
+// Backward stream (layout.h: CH_G7..): 16 k-steps of the tile whose rows are INPUT features [in0, in0+32) of layer l
+// (reference columns col_base + in0 ..), K = the layer's 256 output features in accumulator order
+void pack_hT(uint16_t* ks0, const Net& n, int l, int in0, int col_base) {
+    for (int j = 0; j < 16; ++j) {
+        uint16_t* ks = ks0 + (size_t)j * (KSTEP_BYTES / 2);
+        const int t = j >> 1, s = j & 1;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5;
+            for (int e = 0; e < 8; ++e)
+                put_split(ks, lane, e, n.W(l, 32 * t + acc_feature(8 * s + e, h), col_base + in0 + i));
+        }
+    }
+}
+// ... and of encoding tile `tile` (0, 1): row i = accumulator register r = (i&3) + 4*(i>>3) of lane half (i>>2)&1 <-> slot 16*tile + r
+void pack_encT(uint16_t* ks0, const Net& n, int l, int tile, int pairs_per_half) {
+    for (int j = 0; j < 16; ++j) {
+        uint16_t* ks = ks0 + (size_t)j * (KSTEP_BYTES / 2);
+        const int t = j >> 1, s = j & 1;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5;
+            const int ref = enc_ref_index(16 * tile + (i & 3) + 4 * (i >> 3), (i >> 2) & 1, pairs_per_half);
+            for (int e = 0; e < 8; ++e)
+                put_split(ks, lane, e, ref < 0 ? 0.0f : n.W(l, 32 * t + acc_feature(8 * s + e, h), ref));
+        }
+    }
+}
+
 // lane-layout table of a length-(32*ntiles) vector
 void lane_table(float* dst, const float* src, int ntiles) {
     for (int t = 0; t < ntiles; ++t)
@@ -157,6 +184,15 @@ void pack_network(const float* blob, void* stream_out, float* tab) {
     }
     for (int k = 0; k < 3; ++k)
         for (int t = 0; t < 4; ++t) pack_h(at(CH_AR + 4 * k + t), n, L_AR_F0 + k, 32 * t, 0);
+
+    // backward stream of the trunk (density-gradient query)
+    for (int t = 0; t < 8; ++t) pack_hT(at(CH_G7 + t), n, L_POS7, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) pack_hT(at(CH_G6 + t), n, L_POS6, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) pack_hT(at(CH_G5 + t), n, L_POS5, 32 * t, 63);
+    for (int t = 0; t < 2; ++t) pack_encT(at(CH_G5 + 8 + t), n, L_POS5, t, PE_PAIRS_PER_HALF);
+    for (int l = 4; l >= 1; --l)
+        for (int t = 0; t < 8; ++t) pack_hT(at(CH_G4 + 8 * (4 - l) + t), n, L_POS0 + l, 32 * t, 0);
+    for (int t = 0; t < 2; ++t) pack_encT(at(CH_G0 + t), n, L_POS0, t, PE_PAIRS_PER_HALF);
 
     // biases
     for (int l = 0; l < 8; ++l) lane_table(tab + TAB_BIAS + (BT_L0 + 8 * l) * 32, n.b[L_POS0 + l], 8);

@@ -82,6 +82,56 @@ __device__ __forceinline__ void ray_weights(const float (&sigma)[NPL], const flo
     }
 }
 
+// d depth / d raw_s of depth = sum_s w_s z_s — what autograd returns through relu, exp, cumprod and the sum in
+// get_normal_from_depth_gradient(_direction) (normal_from_depth.py:39-47, :124-132):
+//   d depth / d alpha_s = T_s z_s - (sum_{i>s} w_i z_i) / (1 - alpha_s + 1e-10);   d alpha_s / d raw_s = dist_s exp(-raw_s dist_s) [raw_s > 0]
+// in double (the reference's float32 backward differs from it by its own rounding).
+template <int NPL>
+__device__ __forceinline__ void ray_depth_grad(const float (&sigma)[NPL], const float (&z)[NPL], const float (&zn)[NPL],
+                                               float norm, int S, int lane, double (&G)[NPL]) {
+    double alpha[NPL], om[NPL], da[NPL], T[NPL];
+    double lane_prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        const double dist = (double)((s == S - 1 ? 1e10f : (zn[i] - z[i])) * norm);
+        const double sr = sigma[i] > 0.0f ? (double)sigma[i] : 0.0;
+        const double e = exp(-sr * dist);
+        alpha[i] = s < S ? 1.0 - e : 0.0;
+        om[i] = s < S ? (1.0 - alpha[i]) + 1e-10 : 1.0;
+        da[i] = (s < S && sigma[i] > 0.0f) ? dist * e : 0.0;
+        lane_prod *= om[i];
+    }
+    double incl = lane_prod;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(incl, d);
+        if (lane >= d) incl *= o;
+    }
+    double t = __shfl_up(incl, 1);
+    if (lane == 0) t = 1.0;
+    double lane_wz = 0.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        T[i] = t;
+        lane_wz += alpha[i] * t * (double)z[i];
+        t *= om[i];
+    }
+    double sfx = lane_wz;                      // inclusive suffix sum over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_down(sfx, d);
+        if (lane + d < 64) sfx += o;
+    }
+    double after = __shfl_down(sfx, 1);        // samples of the lanes behind this one
+    if (lane == 63) after = 0.0;
+#pragma unroll
+    for (int i = NPL - 1; i >= 0; --i) {
+        G[i] = (T[i] * (double)z[i] - after / om[i]) * da[i];
+        after += alpha[i] * T[i] * (double)z[i];
+    }
+}
+
 __device__ __forceinline__ void cross3(const float (&a)[3], const float (&b)[3], float (&c)[3]) {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
@@ -297,7 +347,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     float D[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        if (a.ov.gt_normal != nullptr || a.normal_inferred) break;   // "ground_truth" / "inferred_normal_map": no offset queries were made
+        if (a.ov.gt_normal != nullptr || a.normal_inferred || a.grad_normal) break;   // "ground_truth" / "inferred_normal_map" / the gradient modes: no offset queries were made
         float sv[NPL], wv[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -309,6 +359,34 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
 #pragma unroll
         for (int i = 0; i < NPL; ++i) dv += wv[i] * z[i];
         D[v] = wave_sum(dv);
+    }
+
+    // the autograd normal modes (normal_from_depth.py:102-137 position, :16-52 direction): d depth / d (a, b) at a = b = 0, where the
+    // sample points move by a*right + b*up (position) or by z*(a*right + b*up) (direction); sig4 = [sigma, grad sigma] rows of the
+    // density-gradient query at the unshifted points
+    double gda = 0.0, gdb = 0.0;
+    if (a.grad_normal && a.ov.gt_normal == nullptr && !a.normal_inferred) {
+        float sv[NPL], gr[NPL][3];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int s = lane * NPL + i;
+            const float* row = a.sig4 + ((long)r * S + (s < S ? s : 0)) * 4;
+            sv[i] = s < S ? row[0] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gr[i][c] = s < S ? row[1 + c] : 0.0f;
+        }
+        double G[NPL];
+        ray_depth_grad<NPL>(sv, z, zn, norm, S, lane, G);
+        float rt[3], upv[3];
+        right_up(d, rt, upv);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const double g = a.grad_normal == 2 ? G[i] * (double)z[i] : G[i];
+            gda += g * ((double)gr[i][0] * rt[0] + (double)gr[i][1] * rt[1] + (double)gr[i][2] * rt[2]);
+            gdb += g * ((double)gr[i][0] * upv[0] + (double)gr[i][1] * upv[1] + (double)gr[i][2] * upv[2]);
+        }
+        gda = wave_sum_d(gda);
+        gdb = wave_sum_d(gdb);
     }
 
     // ---- per-ray scalar section (all lanes compute, lane 0 stores) ---------------------------
@@ -356,6 +434,11 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     }
     cross3(dxv, dyv, nrm);
     normalize3(nrm);
+    if (a.grad_normal) {   // grad = right * dx + up * dy;  normal = F.normalize(grad - rays_d)   (:48-51, :133-136)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = (right[c] * (float)gda + up[c] * (float)gdb) - d[c];
+        normalize3(nrm);
+    }
     if (a.normal_inferred) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) nrm[c] = inf[c];

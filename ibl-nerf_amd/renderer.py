@@ -317,6 +317,23 @@ class Renderer:
             return self._wide_twin().network_query(inputs, vd, which)
         return out
 
+    def density_gradient(self, pts, which=0):
+        """(sigma, d sigma / d pts) of network `which` at pts [..., 3]: what autograd gives the reference for raw[..., 0] through
+        network_query_fn(pts, None, fn) (normal_from_depth.py:36-47, :121-132), in one fused forward + backward launch."""
+        torch = _torch()
+        pts = _dev_f32(pts, self.device)
+        flat = pts.reshape(-1, 3)
+        lazy = self.range_check == "lazy"
+        if lazy:
+            self._lazy_poll()
+            if self._force_wide:
+                return self._wide_twin(count=False).density_gradient(pts, which)
+        out = torch.empty((flat.shape[0], 4), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_density_gradient(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], out.data_ptr()))
+        if not lazy and self.out_of_range():
+            return self._wide_twin().density_gradient(pts, which)
+        return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape)
+
     def sample_pdf(self, bins, weights, N_samples, det=True, pytest=False, u=None):
         """nerf_renderer_helper.py:91-134.  det=False draws u ~ U[0,1) on the device (or takes `u` [n, N_samples]); pytest=True
         takes numpy's seed-0 stream as the reference's test path does (:106-113)."""
@@ -581,9 +598,9 @@ def _check_supported(kw):
         raise TypeError("infer_normal=True needs normal_mlp")                      # the reference calls run_network(..., None)
     mode = kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon")
     if mode not in NORMAL_MODES:
-        if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface", "normal_map_from_depth_gradient",
-                    "normal_map_from_depth_gradient_direction"):
-            raise NotImplementedError("normal mode %r is not built (SURVEY.md §8 f-4)" % mode)
+        if mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface"):
+            # ibl_nerf_renderer.py:349-353 call functions whose import is commented out (:15): the reference raises NameError here
+            raise NameError("name 'get_normal_from_sigma_gradient%s' is not defined" % ("_surface" if mode.endswith("surface") else ""))
         raise ValueError(mode)                                                       # ibl_nerf_renderer.py:374-375
     if not kw.get("approximate_radiance", False):
         raise NotImplementedError("approximate_radiance=False (training warm-up) is not built")
@@ -593,7 +610,10 @@ def _check_supported(kw):
 
 _renderers = {}
 NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
-                "normal_map_from_depth_gradient_direction_epsilon": 2, "inferred_normal_map": 3}   # target_normal_map_for_radiance_calculation values built
+                "normal_map_from_depth_gradient_direction_epsilon": 2, "inferred_normal_map": 3,
+                # the two autograd modes (normal_from_depth.py:102-137, :16-52): chain rule on the density-gradient query, no autograd —
+                # so they also run under no_grad, where the reference's depth_map.backward() raises
+                "normal_map_from_depth_gradient": 4, "normal_map_from_depth_gradient_direction": 5}   # target_normal_map_for_radiance_calculation values built
 DEFAULT_MLP_PRECISION = "f16x3_mxfp6x"
 
 

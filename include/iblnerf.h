@@ -58,7 +58,13 @@ typedef struct {
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON (depths along four rays with tilted
                                           directions, normal_from_depth.py:55-100; uses epsilon_direction) or
                                           IBLNERF_NORMAL_INFERRED ("inferred_normal_map", :372-373: the composited output of the
-                                          normal_mlp uploaded as IBLNERF_AUX_NORMAL, used as it is; no offset queries) */
+                                          normal_mlp uploaded as IBLNERF_AUX_NORMAL, used as it is; no offset queries) or
+                                          IBLNERF_NORMAL_DEPTH_GRADIENT / _DIRECTION ("normal_map_from_depth_gradient",
+                                          "..._direction": normal_from_depth.py:102-137 / :16-52, the derivative of the rendered
+                                          depth with respect to a shift of the ray origin / a tilt of the ray direction, which the
+                                          reference takes by autograd and can therefore only run with gradients enabled; here one
+                                          density-gradient query per sample (iblnerf_density_gradient) and the chain rule through
+                                          the compositing, no autograd) */
     int32_t color_independent_to_direction; /* 0 (shipped) | 1: networks built with is_color_independent_to_direction
                                           (ibl_nerf.py:192): radiance heads read the trunk output, no feature / view layers */
     int32_t mlp_precision;             /* how the fp32 nn.Linear products are mapped onto the matrix cores (no reference counterpart).
@@ -93,7 +99,7 @@ typedef struct {
 } iblnerf_options;
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
-       IBLNERF_NORMAL_INFERRED = 3 };
+       IBLNERF_NORMAL_INFERRED = 3, IBLNERF_NORMAL_DEPTH_GRADIENT = 4, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION = 5 };
 
 void iblnerf_default_options(iblnerf_options* o);
 
@@ -169,6 +175,14 @@ int iblnerf_get_rays(iblnerf_ctx* ctx, void* stream, int H, int W, const float* 
  * IBLNeRF.forward early return :175-176). */
 int iblnerf_network_query(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays,
                           int n_samples, const float* d_viewdirs, float* d_out);
+
+/* replaces: torch.autograd through network_query_fn(pts, None, network_fn) for d raw[..., 0] / d pts — what
+ * get_normal_from_depth_gradient / _direction (nerf_models/normal_from_depth.py:102-137, :16-52) obtain from
+ * depth_map.backward(), and the dgrad half of a training step's backward through the trunk (train.py:479-481).
+ * One fused launch: the trunk forward keeping every ReLU's pass bits, then the chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on a
+ * transposed weight stream, the skip layer's encoding columns, and the derivative of the positional encoding.
+ * d_pts [n_pts, 3] -> d_out [n_pts, 4] = (sigma, d sigma / d x, d sigma / d y, d sigma / d z). */
+int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out);
 
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
@@ -271,6 +285,7 @@ typedef struct {
     const float* d_z;               /* [n_rays, S] z_vals of this pass */
     const float* d_raw;             /* [n_rays, S, 18] main query (network_query_fn output, :202) */
     const float* d_sigma_offsets;   /* [4, n_rays, S] density of the four offset / tilted queries (normal_from_depth.py:158-160);
+                                       in the two depth-gradient modes [n_rays, S, 4] rows of iblnerf_density_gradient;
                                        NULL in the ground-truth and inferred normal modes */
     const float* d_refl_raw;        /* [n_rays, N_samples, 13] reflected-ray query (:445): columns 0 and 6..17 of its raw rows */
     const float* d_normal_raw;      /* [n_rays, S, 3] normal_mlp samples ([n_rays, 3] with infer_normal_at_surface) or NULL */

@@ -177,6 +177,38 @@ def position_direction_mlp_query(sd, pts, viewdirs):
 
 
 # --------------------------------------------------------------------------------------------
+def density_gradient(sd, pts):
+    """What autograd returns for d raw[..., 0] / d pts through run_network with viewdirs=None (ibl_nerf.py:236-252 -> positional_embedder.py:4-52
+    -> ibl_nerf.py:154-176), written out: the trunk forward keeping every ReLU's pass mask, then the chain
+    dZ(l-1) = (dZ(l) W(l)) * [Z(l-1) > 0], the skip layer's encoding columns, and d sin(f x) = f cos(f x), d cos(f x) = -f sin(f x).
+    pts [P,3] -> (sigma [P], grad [P,3]), float32 like the reference's backward."""
+    pts = np.asarray(pts, dtype=F32).reshape(-1, 3)
+    e = embed(pts, 10)
+    h, masks = e, []
+    for i in range(8):
+        z = _lin(sd, "positions_linears.%d" % i, h)
+        masks.append(z > 0)
+        h = relu(z)
+        if i == 4:
+            h = np.concatenate([e, h], -1)
+    sigma = _lin(sd, "sigma_linear", h)[:, 0]
+    g = np.broadcast_to(sd["sigma_linear.weight"].astype(F32), (pts.shape[0], 256)) * masks[7]     # dZ(7)
+    g_enc = np.zeros_like(e)
+    for i in range(7, 0, -1):
+        g = (g.astype(F32) @ sd["positions_linears.%d.weight" % i]).astype(F32)                      # d / d input of layer i
+        if i == 5:                                                                                    # input = [x63, h4] (:168)
+            g_enc = g_enc + g[:, :63]
+            g = g[:, 63:]
+        g = g * masks[i - 1]
+    g_enc = (g_enc + (g.astype(F32) @ sd["positions_linears.0.weight"]).astype(F32)).astype(F32)
+    grad = g_enc[:, 0:3].copy()
+    for k in range(10):
+        f = F32(2.0 ** k)
+        s_, c_ = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
+        grad = grad + f * (g_enc[:, 3 + 6 * k:6 + 6 * k] * c_ - g_enc[:, 6 + 6 * k:9 + 6 * k] * s_)
+    return sigma.astype(F32), grad.astype(F32)
+
+
 # A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
 # --------------------------------------------------------------------------------------------
 def ray_dists(z_vals, rays_d):
@@ -254,6 +286,45 @@ def normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=0.005, sigma
     D = [np.sum(alpha_weights(raw[s * N:(s + 1) * N], dists) * z_vals, -1, dtype=F32) for s in range(4)]
     pos = [(rays_o + D[s][:, None] * new_d[s]).astype(F32) for s in range(4)]                            # :88-91
     return normalize(cross((pos[0] - pos[1]).astype(F32), (pos[2] - pos[3]).astype(F32)))
+
+
+def depth_gradient_wrt_density(sigma_raw, dists, z_vals):
+    """d depth_map / d raw[..., 0] of depth = sum_s w_s z_s (normal_from_depth.py:39-45 / :124-130), i.e. autograd through relu, exp,
+    cumprod and the sum:  d depth / d alpha_s = T_s z_s - (sum_{i>s} w_i z_i) / (1 - alpha_s + 1e-10);  d alpha / d raw = dist exp(-raw dist) [raw > 0].
+    float64 inside (the reference's float32 backward differs from it by its own rounding)."""
+    sr = np.maximum(np.asarray(sigma_raw, dtype=np.float64), 0.0)
+    di = np.asarray(dists, dtype=np.float64)
+    alpha = 1.0 - np.exp(-sr * di)
+    om = 1.0 - alpha + 1e-10
+    T = np.cumprod(np.concatenate([np.ones_like(om[:, :1]), om], -1), -1)[:, :-1]
+    wz = alpha * T * np.asarray(z_vals, dtype=np.float64)
+    suffix = np.concatenate([np.cumsum(wz[:, ::-1], -1)[:, ::-1][:, 1:], np.zeros_like(wz[:, :1])], -1)   # sum over i > s
+    d_alpha = T * z_vals - suffix / om
+    return d_alpha * di * np.exp(-sr * di) * (np.asarray(sigma_raw) > 0)
+
+
+def normal_from_depth_gradient(sd, rays_o, rays_d, z_vals, direction=False, sigma_grad=None):
+    """nerf_models/normal_from_depth.py:102-137 (position: the ray origin moves by a*right + b*up) and :16-52 (direction: the ray
+    direction becomes a*right + b*up + sqrt(1 - a^2 - b^2) d), autograd of depth_map with respect to (a, b) at 0:
+        d depth / d a = sum_s (d depth / d raw_s) (grad raw_s . right) [z_s],     normal = normalize(right dx + up dy - d).
+    sigma_grad: teacher-forced (sigma [N,S], grad [N,S,3]) of the density-gradient query."""
+    up0 = np.broadcast_to(np.array([0, 1, 0], dtype=F32), rays_d.shape)
+    right = cross(rays_d, up0)
+    up = cross(right, rays_d)
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)
+    N, S = z_vals.shape
+    if sigma_grad is None:
+        sigma, grad = density_gradient(sd, pts.reshape(-1, 3))
+        sigma, grad = sigma.reshape(N, S), grad.reshape(N, S, 3)
+    else:
+        sigma, grad = sigma_grad
+    G = depth_gradient_wrt_density(sigma, ray_dists(z_vals, rays_d), z_vals)
+    if direction:
+        G = G * z_vals
+    dx = np.sum(G * np.sum(grad.astype(np.float64) * right[:, None, :], -1), -1)
+    dy = np.sum(G * np.sum(grad.astype(np.float64) * up[:, None, :], -1), -1)
+    g = right * dx[:, None] + up * dy[:, None]
+    return normalize((g - rays_d).astype(F32))
 
 
 # --------------------------------------------------------------------------------------------
@@ -386,6 +457,11 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     elif nmode == "normal_map_from_depth_gradient_direction_epsilon":
         normal = normal_from_depth_direction_eps(sd, rays_o, rays_d, z_vals, eps=float(flags.get("epsilon_direction", 0.005)),
                                                  sigma=teacher.get("sigma_offsets"))        # :366-369
+    elif nmode in ("normal_map_from_depth_gradient", "normal_map_from_depth_gradient_direction"):   # :354-357, :362-365 (gradients enabled)
+        normal = normal_from_depth_gradient(sd, rays_o, rays_d, z_vals, direction=nmode.endswith("direction"),
+                                            sigma_grad=teacher.get("sigma_grad"))
+    elif nmode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface"):
+        raise NameError("get_normal_from_sigma_gradient")                                   # :349-353: the import is commented out (:15)
     else:
         raise ValueError(nmode)                                                             # :374-375
     if stages is not None:

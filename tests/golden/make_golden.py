@@ -175,6 +175,47 @@ class Recorder:
         R.raw2outputs_simple, R.F.grid_sample = self._s0, self._g0
 
 
+class GradRecorder:
+    """The two autograd normal modes (normal_from_depth.py:16-52, :102-137) run with gradients enabled: records what they return."""
+
+    def __init__(self, R):
+        self.R, self.nrm = R, []
+
+    def __enter__(self):
+        R = self.R
+        self._p0, self._d0 = R.get_normal_from_depth_gradient, R.get_normal_from_depth_gradient_direction
+
+        def wrap(f):
+            def g(*a, **k):
+                out = f(*a, **k)
+                self.nrm.append(out.detach().numpy().copy())
+                return out
+            return g
+        R.get_normal_from_depth_gradient, R.get_normal_from_depth_gradient_direction = wrap(self._p0), wrap(self._d0)
+        return self
+
+    def __exit__(self, *exc):
+        self.R.get_normal_from_depth_gradient, self.R.get_normal_from_depth_gradient_direction = self._p0, self._d0
+
+
+def density_gradient_samples(torch, kw, o, d, near, far, n_rays, n_samples):
+    """d raw[..., 0] / d pts by autograd through the reference's own query path (run_network -> embed -> IBLNeRF.forward), both networks."""
+    z = torch.linspace(0., 1., n_samples) * (far - near) + near
+    out = {}
+    pts0 = torch.from_numpy(o[:n_rays, None, :] + d[:n_rays, None, :] * z.numpy()[None, :, None]).float()
+    out["dg_pts"] = pts0.numpy().reshape(-1, 3).copy()
+    for tag, net in (("c", kw["network_fn"]), ("f", kw["network_fine"])):
+        if net is None:
+            continue
+        pts = pts0.clone().requires_grad_(True)
+        with torch.enable_grad():
+            raw = kw["network_query_fn"](pts, None, net)
+            raw[..., 0].sum().backward()
+        out["dg_sigma_" + tag] = raw[..., 0].detach().numpy().reshape(-1).copy()
+        out["dg_grad_" + tag] = pts.grad.numpy().reshape(-1, 3).copy()
+    return out
+
+
 def fitted_state_dicts():
     """The checkpoint fit_checkpoint.py produced with the reference's modules (tests/golden/fitted_ckpt.npz)."""
     f = np.load(os.path.join(OUT, "fitted_ckpt.npz"))
@@ -183,7 +224,7 @@ def fitted_state_dicts():
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
                 n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False,
-                fitted=False, record_floor=False, infer_depth=False, perturb=False, raw_noise_std=0.0):
+                fitted=False, record_floor=False, infer_depth=False, perturb=False, raw_noise_std=0.0, autograd=False):
     tmp = tempfile.mkdtemp()
     try:
         _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal, infer_depth))
@@ -285,9 +326,15 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     rays = torch.from_numpy(np.stack([o, d], 0))
     gt_t = {k: torch.from_numpy(v.copy()) for k, v in gt.items()}
     K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
-    with torch.no_grad(), Recorder(torch, R, kw, n_keep) as rec:
-        ret = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values=gt_t,
-                              approximate_radiance=True, **kw, **edit)
+    if autograd:   # the autograd normal modes only run with gradients enabled (train.py:286-297; test.py's no_grad makes .backward() raise)
+        with torch.enable_grad(), GradRecorder(R) as rec:
+            ret = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values=gt_t,
+                                  approximate_radiance=True, **kw, **edit)
+        ret = {k: v.detach() for k, v in ret.items()}
+    else:
+        with torch.no_grad(), Recorder(torch, R, kw, n_keep) as rec:
+            ret = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values=gt_t,
+                                  approximate_radiance=True, **kw, **edit)
 
     floor = {}
     if record_floor:
@@ -299,9 +346,10 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         kw["brdf_lut"] = lut.double()
         q32 = kw["network_query_fn"]              # a few of the reference's intermediates are created as float32 whatever the inputs are
         kw["network_query_fn"] = lambda inputs, viewdirs, fn: q32(inputs.double(), None if viewdirs is None else viewdirs.double(), fn)
-        with torch.no_grad():
+        with (torch.enable_grad() if autograd else torch.no_grad()):
             ret64 = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays.double(), gt_values={k: v.double() for k, v in gt_t.items()},
                                     approximate_radiance=True, **kw, **edit)
+        ret64 = {k: v.detach() for k, v in ret64.items()}
         for n_ in nets:
             n_.float()
         kw["brdf_lut"] = lut
@@ -343,8 +391,16 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
     for k, v in floor.items():
         out["floor__" + k] = np.float64(v)
-    # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
     passes = ["c", "f"] if n_importance > 0 else ["c"]
+    if autograd:
+        for pi, p_ in enumerate(passes):
+            out["normal_raw_%s" % p_] = rec.nrm[pi]
+        out.update(density_gradient_samples(torch, kw, o, d, near, far, n_keep, n_samples))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-28s %4d rays  %s (autograd normal)  %.2f MB" % (name, n_rays, mode, os.path.getsize(path) / 1e6))
+        return
+    # stage boundaries; query order inside one raw2outputs: main, eps-normal(4x), reflected
     gt_normals = (flags or {}).get("target_normal_map_for_radiance_calculation") in ("ground_truth", "inferred_normal_map")
     nq = 2 if gt_normals else 3                          # no eps-normal query in the ground-truth normal mode
     for pi, p in enumerate(passes):
@@ -512,6 +568,14 @@ def main(only=None):
     run_fixture("fitted_insert", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, mode="insert", fitted=True, n_keep=64)   # (the reference's masked assignments do not run in float64: the floor of fitted_plain stands for all three)
     # the same checkpoint on 1 024 rays (maps only): how the worst ray grows with the sample, and the reference's own fp64-vs-fp32 run on it
     run_fixture("fitted_wide", torch, R, M, lut, n_rays=1024, n_importance=128, gain=1.0, seed=23, fitted=True, n_keep=2, record_floor=True)
+    # the autograd normal modes (normal_from_depth.py:16-52 direction, :102-137 position), run with gradients enabled as in training;
+    # posed cameras; one on the fitted checkpoint
+    run_fixture("gradnormal_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=24, posed=True, autograd=True, n_keep=4, record_floor=True,
+                flags=dict(target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient"))
+    run_fixture("graddir_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=25, posed=True, autograd=True, n_keep=4, record_floor=True,
+                flags=dict(target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_direction"))
+    run_fixture("fitted_gradnormal", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=26, fitted=True, autograd=True, n_keep=8, record_floor=True,
+                flags=dict(target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient"))
     # *_from_gt: shade with ground-truth intrinsics (config_parser.py's calculate_*_from_gt, depth_map_from_ground_truth)
     run_fixture("fromgt_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=9, mode="fromgt",
                 flags=dict(calculate_albedo_from_gt=True, calculate_roughness_from_gt=True,

@@ -1,0 +1,135 @@
+"""GPU parity of the density-gradient query (the trunk's forward + backward chain in one launch) and of the two normal modes built
+on it, against the reference's own autograd.
+
+`normal_map_from_depth_gradient` / `..._direction` (normal_from_depth.py:102-137, :16-52) differentiate the rendered depth with
+respect to a shift of the ray origin / a tilt of the ray direction by `depth_map.backward()`; the reference can only run them with
+gradients enabled (training).  Fixtures gradnormal_g10 / graddir_g10 / fitted_gradnormal are the reference's render_decomp under
+`torch.enable_grad()`, plus `dg_*`: d raw[..., 0] / d pts from autograd through the reference's own query path for both networks.
+On the random-init (fog) fixtures the FINE pass's normal is ill-conditioned in the reference itself — its float64 and float32 runs
+differ by 2.4e-2 / 3.3e-2 (the depth of a fog ray barely depends on any one sample, so the gradient is a difference of nearly
+equal terms) — so that map is held to 2x that difference; the coarse pass and the fitted checkpoint are held to 1e-3 / 2e-4.
+"""
+import numpy as np
+import pytest
+
+import iblnerf_oracle as O
+from conftest import GOLDEN, golden_flags, load_golden, rel_linf
+from test_gpu_parity import DERIVED, DIRECT, make_renderer, to_np
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+GRAD_FIXTURES = ["gradnormal_g10", "graddir_g10", "fitted_gradnormal"]
+REFLECTED = ["specular_map", "color_map", "reflected_radiance_map", "prefiltered_reflected_map",
+             "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3"]
+
+
+@pytest.fixture(scope="module")
+def R():
+    from ibl_nerf_amd import binding as B, renderer
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    B.load_library()
+    return renderer
+
+
+def floor(g, key):
+    return float(g["floor__" + key])
+
+
+# sigma abs / gradient relative to the largest component over the fixture's points: f16 pairs (2^-22 operands) and bf16 pairs (2^-17)
+DG_TOL = {"f16x3_mxfp6x": (2e-5, 2e-5), "f16x3": (2e-5, 2e-5), "bf16x3": (5e-4, 5e-4)}
+
+
+@pytest.mark.parametrize("prec", ["f16x3_mxfp6x", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("name", GRAD_FIXTURES)
+def test_density_gradient_vs_reference_autograd(R, name, lut, prec):
+    g, sdc, sdf, _, _ = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision=prec)
+    for tag, which in (("c", 0), ("f", 1)):
+        sigma, grad = r.density_gradient(g["dg_pts"], which)
+        sigma, grad = sigma.cpu().numpy(), grad.cpu().numpy()
+        ref_s, ref_g = g["dg_sigma_" + tag], g["dg_grad_" + tag]
+        assert rel_linf(sigma, ref_s) <= DG_TOL[prec][0] * (10 if name.startswith("fitted") else 1), (tag, rel_linf(sigma, ref_s))
+        assert rel_linf(grad, ref_g) <= DG_TOL[prec][1] * (10 if name.startswith("fitted") else 1), (tag, rel_linf(grad, ref_g))
+        # the density of this launch is the trunk-only query's
+        alone = r.network_query(torch.from_numpy(g["dg_pts"])[None], None, which).cpu().numpy().reshape(-1)
+        assert np.abs(alone - sigma).max() <= (0 if prec != "f16x3_mxfp6x" else 1e-6)   # (same kernel arithmetic; the default mode's user query is also f16x3)
+    assert r.range_fallbacks == 0
+
+
+def test_density_gradient_ragged_and_against_the_oracle(R, lut):
+    """Point counts that do not fill a 128-point group, points outside the fitted scene, an empty batch; against the numpy chain."""
+    g, sdc, sdf, _, _ = load_golden("fitted_gradnormal")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64)
+    rng = np.random.RandomState(5)
+    for n in (1, 127, 129, 1000):
+        pts = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+        sigma, grad = r.density_gradient(pts, 1)
+        so, go = O.density_gradient(sdf, pts)
+        assert sigma.shape == (n,) and grad.shape == (n, 3)
+        assert np.abs(sigma.cpu().numpy() - so).max() <= 2e-4 * max(1.0, np.abs(so).max())
+        # the gradient of a ReLU network is piecewise constant in the encoding: a pre-activation within round-off of zero flips a
+        # pass bit and moves the gradient by a finite step, so the worst of 1 000 off-scene points is loose, the bulk is not
+        err = np.abs(grad.cpu().numpy() - go).max(-1) / np.abs(go).max()
+        assert err.max() <= 2e-2 and np.percentile(err, 95) <= 1e-4, (err.max(), np.percentile(err, 95))
+    s0, g0 = r.density_gradient(np.zeros((0, 3), np.float32), 0)
+    assert s0.shape == (0,) and g0.shape == (0, 3)
+    # the launch is deterministic and independent of how the points are batched
+    pts = rng.uniform(-2, 2, (300, 3)).astype(np.float32)
+    a = r.density_gradient(pts, 0)[1]
+    b = torch.cat([r.density_gradient(pts[:77], 0)[1], r.density_gradient(pts[77:], 0)[1]], 0)
+    assert torch.equal(a, b)
+
+
+def per_ray(x, ref):
+    """Per-ray error relative to the map's range (the rows of rel_linf)."""
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    return np.abs(x.reshape(ref.shape) - ref).reshape(ref.shape[0], -1).max(-1) / max(float(np.abs(ref).max()), 1e-30)
+
+
+@pytest.mark.parametrize("prec", ["f16x3_mxfp6x", "bf16x3"])
+@pytest.mark.parametrize("name", GRAD_FIXTURES)
+def test_render_with_the_autograd_normal_modes(R, name, lut, prec):
+    """End to end against the reference's render with gradients enabled — here under no_grad, where the reference cannot run.
+    The gradient of a ReLU network is piecewise constant: a pre-activation within round-off of zero flips one pass bit and moves that
+    sample's gradient by a finite step (scratch/gradnormal_probe.py: one of 4 096 coarse samples of gradnormal_g10 differs by 9e-3 of
+    the largest gradient with 2^-22 operands, three with 2^-17; the same happens between the reference's float32 and float64 runs,
+    less often).  So the normal and what follows from it are held per ray: all but a few rays at the bound, the few at 0.1 (0.3 for
+    the bf16 pairs, the wide-range fallback)."""
+    g, sdc, sdf, gt, edit = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec)
+    assert r.normal_mode == golden_flags(g)["target_normal_map_for_radiance_calculation"]
+    with torch.no_grad():
+        res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
+    assert r.range_fallbacks == 0
+    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    fitted, wide = name.startswith("fitted"), prec == "bf16x3"
+    n_rays = g["rays_o"].shape[0]
+    flips = 2 if not wide else 8                       # rays of 64 allowed beyond the bound
+    for sfx in ("", "0"):
+        for k in DIRECT:                               # do not depend on the normal
+            tol = (8e-3 if wide else max(2e-4, 8 * floor(g, k + sfx))) if fitted else (1e-3 if wide else 2e-4)
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+        for k in DERIVED:
+            # ... and what does inherits the reference's own float64-vs-float32 difference of the normal
+            tol = max(2e-3 if wide else 1e-3, (4 if k in REFLECTED else 2) * floor(g, k + sfx))
+            e = per_ray(res[k + sfx], g["out__" + k + sfx])
+            assert (e > tol).sum() <= flips and e.max() <= max(0.3 if wide else 0.1, tol), (k + sfx, np.sort(e)[-4:], tol)
+    # where the reference is well conditioned, so is this: the coarse pass everywhere, both passes on the checkpoint with surfaces
+    e0 = per_ray(res["target_normal_map0"], g["out__target_normal_map0"])
+    assert np.percentile(e0, 90) <= (2e-4 if not wide else 2e-3), np.sort(e0)[-4:]
+    if fitted:
+        assert floor(g, "target_normal_map") < 1e-4
+        e1 = per_ray(res["target_normal_map"], g["out__target_normal_map"])
+        assert np.percentile(e1, 90) <= (2e-4 if not wide else 2e-3), np.sort(e1)[-4:]
+    else:
+        assert floor(g, "target_normal_map") > 1e-2      # the fact the fine-pass tolerance rests on
+    assert n_rays == 64
+
+
+def test_sigma_gradient_modes_raise_as_in_the_reference(R):
+    """ibl_nerf_renderer.py:349-353 call functions whose import is commented out (:15)."""
+    for mode in ("normal_map_from_sigma_gradient", "normal_map_from_sigma_gradient_surface"):
+        with pytest.raises(NameError):
+            R._check_supported(dict(approximate_radiance=True, target_normal_map_for_radiance_calculation=mode))

@@ -102,6 +102,7 @@ def test_encoder_sincos_error_bound(lib):
 # --------------------------------------------------------------------------------------------
 KS_BYTES, CH = 2048, 16
 CH_L0, CH_L1, CH_L5, CH_L6, CH_L7, CH_FEAT, CH_ALB, CH_IRR, CH_VIEW, CH_AR = 0, 2, 34, 44, 52, 60, 68, 72, 76, 85
+CH_G7, CH_G6, CH_G5, CH_G4, CH_G0 = 97, 105, 113, 123, 155      # backward stream of the trunk (layout.h)
 TAB_BIAS, TAB_SIG, TAB_ROUGH, TAB_ALB, TAB_IRR, TAB_RAD, TAB_AR, TAB_SCALAR = 0, 3200, 3456, 3712, 4096, 4224, 4992, 6144
 
 
@@ -185,6 +186,47 @@ class Emu:
         out = out.astype(np.float32)
         return np.maximum(out, 0) if relu else out
 
+    def back(self, chunk0, ntiles, dz):    # one backward layer: rows = the layer's input features, K = dZ of its 256 outputs, no bias
+        a = self.frag_act(dz.astype(np.float32))
+        return np.concatenate([self.ksteps((chunk0 + t) * CH, *a) for t in range(ntiles)], 1).astype(np.float32)
+
+    def density_gradient(self, pts):
+        """The VAR_TRUNK_GRAD program on the packed stream: forward keeping the pass masks, dZ(l-1) = (W(l)^T dZ(l)) * mask(l-1) on the
+        transposed chunks, encoding tiles in slot order (row (r&3) + 8(r>>2) + 4h of tile t = slot 16t + r of half h), chain rule of the encoding."""
+        emb = O.embed(pts, 10)
+        pe = self.frag_enc(emb, 15, 4)
+        hs = [self.layer(CH_L0, 8, None, pe, 0)]
+        for l in range(1, 5):
+            hs.append(self.layer(CH_L1 + 8 * (l - 1), 8, self.frag_act(hs[-1]), None, 8 * l))
+        hs.append(self.layer(CH_L5, 8, self.frag_act(hs[-1]), pe, 40))
+        hs.append(self.layer(CH_L6, 8, self.frag_act(hs[-1]), None, 48))
+        hs.append(self.layer(CH_L7, 8, self.frag_act(hs[-1]), None, 56))
+        dz = self.lane_vec(TAB_SIG, 8)[None, :] * (hs[7] > 0)
+        dz = self.back(CH_G7, 8, dz) * (hs[6] > 0)
+        dz = self.back(CH_G6, 8, dz) * (hs[5] > 0)
+        full = self.back(CH_G5, 10, dz)
+        genc = full[:, 256:].copy()
+        dz = full[:, :256] * (hs[4] > 0)
+        for l in range(4, 0, -1):
+            dz = self.back(CH_G4 + 8 * (4 - l), 8, dz) * (hs[l - 1] > 0)
+        genc = genc + self.back(CH_G0, 2, dz)
+        grad = np.zeros((pts.shape[0], 3))
+        for t in range(2):
+            for row in range(32):
+                h, r = (row >> 2) & 1, (row & 3) + 4 * (row >> 3)
+                ref = enc_ref_index(16 * t + r, h, 15)
+                if ref < 0:
+                    assert np.all(genc[:, 32 * t + row] == 0)          # pad slot: a zero row of the stream
+                    continue
+                gcol = genc[:, 32 * t + row].astype(np.float64)
+                if ref < 3:
+                    grad[:, ref] += gcol
+                    continue
+                k, rem = divmod(ref - 3, 6)                             # [sin(2^k x) x3, cos(2^k x) x3]
+                c, f = rem % 3, 2.0 ** k
+                grad[:, c] += gcol * (f * emb[:, ref + 3] if rem < 3 else -f * emb[:, ref - 3])
+        return grad.astype(np.float32)
+
     def forward(self, pts, dirs):
         pe = self.frag_enc(O.embed(pts, 10), 15, 4)
         h = self.layer(CH_L0, 8, None, pe, 0)
@@ -220,7 +262,7 @@ def test_packed_stream_reproduces_oracle_mlp(lib, gain):
     blob = ck.state_dict_to_blob(sd)
     stream = np.zeros(lib.iblnerf_stream_bytes(), dtype=np.uint8)
     tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
-    assert stream.size == 97 * 32768 and tab.size == 6176
+    assert stream.size == (97 + 60) * 32768 and tab.size == 6176     # the network's layers + the trunk's backward stream
     rc = lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size)
     assert rc == 0
     assert lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size - 1, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == -1
@@ -236,6 +278,13 @@ def test_packed_stream_reproduces_oracle_mlp(lib, gain):
     assert np.abs(emu.forward(pts, None) - ref_s).max() <= (2e-5 if gain == 1.0 else 2e-4)
     # transpose / permutation detector: a wrong K order or row map gives O(0.1) errors, not 1e-5
     assert np.abs(ref).max() > 0.05
+    # the backward stream (density-gradient query): the chain on the packed transposed chunks against the oracle's written-out backward
+    # (itself pinned on the reference's autograd, test_autograd_normal_modes)
+    sg, gg = O.density_gradient(sd, pts)
+    ge = emu.density_gradient(pts)
+    err = np.abs(ge - gg).max(-1) / np.abs(gg).max()
+    assert np.median(err) <= (2e-5 if gain == 1.0 else 2e-4) and err.max() <= 1e-2, (np.median(err), err.max())   # (a pass bit may flip at 2^-17 operands)
+    assert np.abs(gg).max() > 0.5
 
 
 # --------------------------------------------------------------------------------------------

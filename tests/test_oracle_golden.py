@@ -266,3 +266,35 @@ def test_raw_noise_std_through_the_pytest_seed_path(lut):
             assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 6e-4, k + sfx
     quiet = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut, t_rand=O.pytest_uniform(n, 64), u=O.pytest_uniform(n, 128))
     assert rel_linf(quiet["depth_map0"], g["out__depth_map0"]) > 1e-3                # the noise matters
+
+
+@pytest.mark.parametrize("name", ["gradnormal_g10", "graddir_g10", "fitted_gradnormal"])
+def test_autograd_normal_modes(name, lut):
+    """normal_map_from_depth_gradient(_direction): the oracle's written-out chain rule (density_gradient, depth_gradient_wrt_density)
+    against the reference's autograd — per point (d raw[..., 0] / d pts of both networks, 1e-6), per pass (the normal each mode
+    returned) and end to end.  The fine pass of the fog fixtures is ill-conditioned in the reference (its float64-vs-float32
+    difference is recorded with the fixture: 2.4e-2 / 3.3e-2); the coarse pass and the fitted checkpoint are not."""
+    g, sdc, sdf, gt, edit = load_golden(name)
+    for tag, sd in (("c", sdc), ("f", sdf)):
+        s, gr = O.density_gradient(sd, g["dg_pts"])
+        assert np.abs(s - g["dg_sigma_" + tag]).max() <= 2e-6 * max(1.0, np.abs(g["dg_sigma_" + tag]).max())
+        assert rel_linf(gr, g["dg_grad_" + tag]) <= 2e-6
+    st = {}
+    res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, 64, int(g["n_importance"]),
+                        gt, edit, st, golden_flags(g), {})
+    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    fl = lambda k: float(g["floor__" + k])
+    assert rel_linf(st["c"]["normal_raw"], g["normal_raw_c"]) <= 2e-5
+    assert rel_linf(st["f"]["normal_raw"], g["normal_raw_f"]) <= max(1e-4, 2 * fl("target_normal_map"))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= max(2e-5, 2 * fl(k + sfx)), k + sfx
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= max(6e-4, 4 * fl(k + sfx)), k + sfx
+    if name.startswith("fitted"):
+        assert fl("target_normal_map") < 1e-4 and rel_linf(res["target_normal_map"], g["out__target_normal_map"]) <= 1e-4
+    else:
+        assert fl("target_normal_map") > 1e-2
+    with pytest.raises(NameError):                      # the two sigma-gradient modes: the reference's NameError (:349-353, import commented out :15)
+        O.render_rays(sdc, sdf, g["rays_o"][:2], g["rays_d"][:2], float(g["near"]), float(g["far"]), lut, 64, 0, {}, {}, {},
+                      dict(target_normal_map_for_radiance_calculation="normal_map_from_sigma_gradient"), {})
