@@ -35,9 +35,11 @@ MODES = {
     "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
                     "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in the reflected-ray queries"),
-    "f16x3_mxfp6x": ("f16 hi/lo splits x3 products for the main, auxiliary and coarse-grid offset queries; the fine pass's offset queries on the fast kernel's mixed "
-                     "trunk form (layers 0-1 as three f16 products, layers 2-7 as f16 + 2x MX-fp6); f16 + 2x MX-fp6 for the reflected-ray queries; fp32 accumulate",
-                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel<TRUNK_X>", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in layers 2-7 of the fine offsets and in the reflected-ray queries"),
+    "f16x3_mxfp6x": ("f16 hi/lo splits x3 products (~2^-22 per operand) where errors are amplified — the coarse pass's main query (it places the fine samples), "
+                     "auxiliary networks, the coarse grid's offset queries; the fine pass's offset queries on the fast kernel's mixed trunk form (layers 0-1 as three "
+                     "f16 products, layers 2-7 as f16 + 2x MX-fp6); f16 + 2x MX-fp6 (~2^-16) for the fine pass's main query and the reflected-ray queries; fp32 accumulate",
+                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel<TRUNK_X>", "3 f16 MFMA products in the coarse pass; 1 f16 + 2 block-scaled fp6 products in layers 2-7 of the fine "
+                     "offsets, in the fine main query and in the reflected-ray queries"),
     "f16x3_main": ("f16 hi/lo splits x3 products for the main, auxiliary and coarse-grid offset queries; f16 + 2x MX-fp6 residual products "
                    "for the fine pass's offset queries and the reflected-ray queries; fp32 accumulate",
                    "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products in the precise queries, 1 f16 + 2 block-scaled fp6 products in the others"),

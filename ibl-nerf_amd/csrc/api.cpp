@@ -68,7 +68,7 @@ struct iblnerf_ctx {
     bool have_lut = false;
     // measurement / test aids, read from the environment at iblnerf_create: IBLNERF_X_COARSE routes the coarse grid's offset queries,
     // IBLNERF_X_USER the trunk-only form of iblnerf_network_query, to the mixed TRUNK form (mode IBLNERF_MLP_F16X3_MXFP6X only)
-    bool x_coarse = false, x_user = false;
+    bool x_coarse = false, x_user = false, fine_main_precise = false;
     float* d_posdir = nullptr;                // PositionDirectionMLP of infer_depth: per layer [Wt | bias] (posdir_kernel.hip)
     int posdir_out_ch = 0;                    // 0 = none uploaded
     // workspace
@@ -197,6 +197,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     }
     c->x_coarse = std::getenv("IBLNERF_X_COARSE") != nullptr;
     c->x_user = std::getenv("IBLNERF_X_USER") != nullptr;
+    c->fine_main_precise = std::getenv("IBLNERF_FINE_MAIN_PRECISE") != nullptr;   // measurement aid: the fine main query back on f16x3
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -471,9 +472,12 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             kern = qclass == Q_REFL ? K_MX : K_F16X3;
         else if (prec == IBLNERF_MLP_F16X3_MXFP6X) {
             // ... and the offset queries on the fast kernel's mixed TRUNK form (layers 0-1 as three f16 products): the first layers set
-            // the density's error, so the normal stays that of the f16x3 kernel for +17 % matrix instructions over the fast kernel
+            // the density's error, so the normal stays that of the f16x3 kernel for +17 % matrix instructions over the fast kernel;
+            // ... and the FINE pass's main query on the fast kernel: its raw rows enter the maps as weighted sums (2^-16 per operand, no
+            // amplification: it places no samples and no depth difference is taken of it) — on 1 024 rays of the fitted checkpoint the
+            // worst ray of every direct channel is set by the coarse pass's sample placement, with or without it
             const bool x = qclass == Q_OFFSET_FINE || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
-            kern = qclass == Q_REFL ? K_MX : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
+            kern = (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise)) ? K_MX : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
         } else if (prec == IBLNERF_MLP_F16X3_MAIN)
             // ... and also for the offset queries on the dense fine grid: the normal's worst ray of 1024 goes from 1.9e-4 to
             // 1.5e-3 (99.9th percentile 3e-4); on the coarse grid (spacing 0.12) the same offsets would leave 1e-3 at 96 rays

@@ -69,9 +69,10 @@ class Renderer:
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
                  epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
         """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6x" (default: three f16 products on hi/lo splits, ~2^-22
-        per operand, for the main, auxiliary and coarse-grid offset queries; the fine pass's offset queries on the fast kernel's
-        mixed trunk form — its first two layers as three f16 products, the others as one f16 + two block-scaled fp6 products;
-        the reflected-ray queries on the fast kernel), "f16x3_mxfp6" (all offset queries on the precise kernel), "f16x3" (precise
+        per operand, for the coarse pass's main query, auxiliary networks and the coarse grid's offset queries; the fine pass's
+        offset queries on the fast kernel's mixed trunk form — its first two layers as three f16 products, the others as one f16 +
+        two block-scaled fp6 products; the fine pass's main query and the reflected-ray queries on the fast kernel),
+        "f16x3_mxfp6" (the fine main query and all offset queries on the precise kernel), "f16x3" (precise
         everywhere), "f16x3_main" (the plain fast kernel for the fine pass's offset queries: the normal's worst ray at 1.5e-3 on
         a checkpoint with surfaces), "f16_mxfp6" (fast everywhere: 1e-2 on direct channels of grazing rays there), "f16_mixed"
         (plain f16 for the fine main and reflected queries: random-init networks only), "bf16x3" (three bf16 products, 2^-17, the

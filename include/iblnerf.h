@@ -81,7 +81,10 @@ typedef struct {
                                           IBLNERF_MLP_F16X3_MXFP6X (the Python default) as F16X3_MXFP6, with the fine pass's offset queries on the fast kernel's
                                                                   mixed trunk form: positions_linears.0 and .1 as three f16 products,
                                                                   the other six layers as F16_MXFP6 (the first layers set the density's
-                                                                  error on a network with surfaces)
+                                                                  error on a network with surfaces), and the fine pass's MAIN query
+                                                                  on F16_MXFP6 (it places no samples and no difference is taken of it:
+                                                                  its 2^-16 reaches the maps unamplified; the worst ray of every direct
+                                                                  channel is set by the coarse pass's sample placement)
                                           IBLNERF_MLP_F16X3_MAIN  F16X3 for the queries whose results are direct channels (main query
                                                                   of both passes, auxiliary networks, iblnerf_network_query) and for
                                                                   the coarse grid's offset queries; F16_MXFP6 also for the fine
