@@ -37,6 +37,7 @@ SOURCES = [
     ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=4"], "mlp_kernel_f16x3_refl_ci"),
     ("mlp_kernel.hip", ["-DIBL_VARIANT=6"], "mlp_kernel_trunk_grad"),
     ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=6"], "mlp_kernel_f16x3_trunk_grad"),
+    ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=7"], "mlp_kernel_f16x3_trunk_bwd"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),
@@ -50,6 +51,7 @@ SOURCES = [
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("posdir_kernel.hip", []),
+    ("wgrad_kernel.hip", []),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),
 ]

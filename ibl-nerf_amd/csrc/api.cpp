@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -69,6 +70,10 @@ struct iblnerf_ctx {
     // measurement / test aids, read from the environment at iblnerf_create: IBLNERF_X_COARSE routes the coarse grid's offset queries,
     // IBLNERF_X_USER the trunk-only form of iblnerf_network_query, to the mixed TRUNK form (mode IBLNERF_MLP_F16X3_MXFP6X only)
     bool x_coarse = false, x_user = false, fine_main_precise = false;
+    char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
+    size_t bwd_stash_bytes = 0;
+    float* bwd_partial = nullptr;
+    size_t bwd_partial_floats = 0;
     float* d_posdir = nullptr;                // PositionDirectionMLP of infer_depth: per layer [Wt | bias] (posdir_kernel.hip)
     int posdir_out_ch = 0;                    // 0 = none uploaded
     // workspace
@@ -263,6 +268,8 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream_f16[w]) (void)hipFree(c->d_stream_f16[w]);
     }
     if (c->d_posdir) (void)hipFree(c->d_posdir);
+    if (c->bwd_stash) (void)hipFree(c->bwd_stash);
+    if (c->bwd_partial) (void)hipFree(c->bwd_partial);
     if (c->d_range_flag) (void)hipFree(c->d_range_flag);
     if (c->h_range_flag) (void)hipHostFree(c->h_range_flag);
     if (c->flag_ev) (void)hipEventDestroy(c->flag_ev);
@@ -543,6 +550,68 @@ int iblnerf_density_gradient(iblnerf_ctx* c, void* stream, int which, const floa
     HIP_TRY(c, hipSetDevice(c->opt.device));
     if (int rc = run_mlp(c, (hipStream_t)stream, VAR_TRUNK_GRAD, which, d_pts, nullptr, 1, (long)n_pts, d_out, 4)) return rc;
     return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
+                           float grad_scale, float* d_out, float* d_grad) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_dsigma || !d_out)) || !d_grad)
+        return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
+    int gs_exp = 0;
+    if (!(grad_scale > 0.0f) || std::frexp(grad_scale, &gs_exp) != 0.5f)
+        return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: grad_scale must be a positive power of two");
+    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: more than 2^31 points");
+    if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "trunk_backward: weights of network %d not uploaded", which);
+    if (!c->d_stream_f16[which] || !c->mx_ok[which])
+        return c->fail(IBLNERF_ERR_STATE, "trunk_backward: needs an mlp_precision that keeps the f16x3 stream (f16x3*) and weights inside the f16 range");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipMemsetAsync(d_grad, 0, blob_floats() * sizeof(float), s));
+    if (n_pts == 0) return IBLNERF_OK;
+    const long groups = (n_pts + 127) / 128, wgs = groups * 4;
+    const size_t need = (size_t)stash_bytes(wgs);
+    WgradArgs w;
+    w.n_split = (int)std::min<long>(28, std::max<long>(1, wgs / 8));
+    if (need > c->bwd_stash_bytes) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->bwd_stash) (void)hipFree(c->bwd_stash);
+        c->bwd_stash = nullptr; c->bwd_stash_bytes = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->bwd_stash, need));
+        c->bwd_stash_bytes = need;
+    }
+    const size_t pneed = (size_t)w.n_split * WGRAD_PARTIAL_FLOATS;
+    if (pneed > c->bwd_partial_floats) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->bwd_partial) (void)hipFree(c->bwd_partial);
+        c->bwd_partial = nullptr; c->bwd_partial_floats = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->bwd_partial, pneed * sizeof(float)));
+        c->bwd_partial_floats = pneed;
+    }
+    MlpArgs a;
+    a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
+    a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
+    HIP_TRY(c, launch_mlp_f16x3(VAR_TRUNK_BWD, a, c->n_cu, s));
+    c->flop_alg += (double)n_pts * 3.0 * FLOP_TRUNK;
+    w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
+    w.n_gemm = 9;
+    w.unscale = 1.0f / grad_scale;
+    size_t wo[11], bo[11];
+    for (int l = 0; l < 11; ++l) blob_offsets(l, &wo[l], &bo[l]);
+    long part = 0;
+    auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
+        w.gemm[k] = WgradGemm{STASH_DZ + layer, x_what, in_dim, col_base, (long)wo[layer], part};
+        part += x_what == STASH_ENC ? 16384 : 65536;
+    };
+    gemm(0, 0, STASH_ENC, 63, 0);
+    for (int l = 1; l <= 4; ++l) gemm(l, l, STASH_X + l - 1, 256, 0);
+    gemm(5, 5, STASH_ENC, 319, 0);            // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
+    gemm(6, 5, STASH_X + 4, 319, 63);
+    gemm(7, 6, STASH_X + 5, 256, 0);
+    gemm(8, 7, STASH_X + 6, 256, 0);
+    for (int l = 0; l < 8; ++l) w.bias_off[l] = (long)bo[l];
+    w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
+    HIP_TRY(c, launch_wgrad(w, d_dsigma, (long)n_pts, s));
+    return arm_range_snapshot(c, s);
 }
 
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,

@@ -161,4 +161,25 @@ constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (
                                     (283L * 128 + 128) + 3 * (128L * 128 + 128) + (128L * 1 + 1);
 hipError_t launch_posdir_mlp(const PosDirArgs& a, hipStream_t s);
 
+// Weight gradient of the trunk from the backward kernel's operand stash (wgrad_kernel.hip; layout.h: STASH_*).
+struct WgradGemm {
+    int dz_what, x_what;     // stash activations: dZ of the layer, its input (STASH_X + l - 1, or STASH_ENC)
+    int in_dim, col_base;    // row length of the reference's [out][in] weight, first column this GEMM fills
+    long blob_off;           // the weight inside the state-dict blob
+    long part_off;           // this GEMM inside one split's partial sums
+};
+struct WgradArgs {
+    const char* stash;
+    float* partial;          // [n_split][partial_stride]
+    float* grad;             // the reference's state-dict layout (blob_floats() floats), zeroed by the caller
+    long wave_groups, partial_stride;
+    int n_split, n_gemm;
+    WgradGemm gemm[9];
+    long bias_off[8];        // positions_linears.l.bias
+    long sigma_w_off, sigma_b_off;
+    float unscale;           // 1 / MlpArgs::grad_scale
+};
+constexpr long WGRAD_PARTIAL_FLOATS = 7 * 65536L + 2 * 16384L;
+hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s);
+
 }  // namespace ibl

@@ -88,6 +88,20 @@ constexpr int TAB_BYTES = TAB_FLOATS * 4;           // 24 704 B
 constexpr int LDS_RING_BYTES = RING_SLOTS * CHUNK_BYTES;   // 96 KiB
 constexpr int LDS_BYTES = LDS_RING_BYTES + TAB_BYTES;      // 123 008 B
 
+// Operand stash of VAR_TRUNK_BWD for the weight-gradient kernel (wgrad_kernel.hip), per WAVE GROUP of 32 points (wave w of point
+// group g: 4 g + w), in the kernel's own fragment layout so that every store is one coalesced 16-byte piece per lane: the f16 `hi`
+// fragment of k-step j (8 features 32(j>>1) + acc_feature(8(j&1) + e, h) of point lane&31) at  j * 1024 + lane * 16.
+//   [STASH_X  + layer l][wave group]  post-ReLU output of positions_linears.l   (16 KiB each)
+//   [STASH_DZ + layer l][wave group]  dL / d pre-activation of positions_linears.l
+//   [STASH_ENC][wave group]           the encoding's 4 k-steps (4 KiB each; slot order of enc_ref_index)
+constexpr int STASH_X = 0, STASH_DZ = 8, STASH_ENC = 16;
+constexpr long STASH_ACT_BYTES = 16 * 1024;   // per wave group and activation
+constexpr long STASH_ENC_BYTES = 4 * 1024;
+__host__ __device__ constexpr long stash_bytes(long wave_groups) { return wave_groups * (16 * STASH_ACT_BYTES + STASH_ENC_BYTES); }
+__host__ __device__ constexpr long stash_offset(int what, long wave_groups, long wg) {
+    return what < STASH_ENC ? (what * wave_groups + wg) * STASH_ACT_BYTES : 16 * wave_groups * STASH_ACT_BYTES + wg * STASH_ENC_BYTES;
+}
+
 // feature held by accumulator register r of lane-half h (tile-local, 0..31)
 __host__ __device__ constexpr int acc_feature(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -120,7 +134,8 @@ constexpr int REFL_CH = 13;   // sigma + channels 6..17 (what raw2outputs_simple
 // the radiance heads read the trunk output, feature_linear and views_linears are not evaluated.
 enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_REFL_CI = 4,
                VAR_TRUNK_X = 5,     // fast kernel only: TRUNK with its first two layers as three f16 products (layout_mx.h)
-               VAR_TRUNK_GRAD = 6 };  // three-product kernels only: TRUNK forward + its backward chain, out = [sigma, d sigma / d x, y, z]
+               VAR_TRUNK_GRAD = 6,    // three-product kernels only: TRUNK forward + its backward chain, out = [sigma, d sigma / d x, y, z]
+               VAR_TRUNK_BWD = 7 };   // ... with an upstream gradient per point, and the operands of the weight gradient stashed (STASH_*)
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

@@ -18,6 +18,12 @@ struct MlpArgs {
     long n_pts;
     int pts_per_ray;
     unsigned* range_flag; // f16 flavours only: set to 1 if an input or activation left the f16 range (may be null)
+    // VAR_TRUNK_BWD only (the trunk's backward for a training step): upstream gradient per point and the operand stash the
+    // weight-gradient kernel reads (layout.h: STASH_*)
+    const float* dsigma = nullptr;   // [n_pts] dL / d sigma
+    char* stash = nullptr;
+    float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
+                                     // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels
 };
 hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);      // three bf16 products (layout.h)
 hipError_t launch_mlp_f16x3(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);  // three f16 products, same stream layout with f16 pairs

@@ -82,7 +82,7 @@ __device__ long long g_trace[256];
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : VARIANT == VAR_TRUNK_GRAD ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
+    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
                                   : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
@@ -100,7 +100,7 @@ struct Pipe {
     __device__ __forceinline__ static int stream_chunk(int p) {
         if (p < N_CHUNKS_TRUNK) return p;
         int q = p - N_CHUNKS_TRUNK;
-        if (VARIANT == VAR_TRUNK_GRAD) return CH_G7 + q;   // the backward stream follows the trunk
+        if (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) return CH_G7 + q;   // the backward stream follows the trunk
         if (!CI) { if (q < 8) return CH_FEAT + q; q -= 8; }
         if (ALBIRR) { if (q < 8) return CH_ALB + q; q -= 8; }
         if (!CI) { if (q < 9) return CH_VIEW + q; q -= 9; }
@@ -223,12 +223,14 @@ struct Acc {
 // The layer bias is already in the accumulator (it is the MFMA chain's initial C).
 //   MASK : (density-gradient variant) the ReLU's pass bits of this tile, 16 per lane, go to the wave's mask area in LDS:
 //          u16 at mrow + 128 * T (mrow = this lane's slot in the layer's row, see MASK_* below)
-template <bool STORE, bool RELU, int NCH, bool MASK = false>
+//          MASK = 2 (VAR_TRUNK_BWD): the hi fragments also go to the operand stash (layout.h: STASH_X), srow + 1024 * k-step
+template <bool STORE, bool RELU, int NCH, int MASK = 0>
 struct Epi {
     Act* dst;
     float* part[NCH > 0 ? NCH : 1];
     const float* tab[NCH > 0 ? NCH : 1];   // this lane-half's row of tile 0 of each head table ([tile][2][16])
     char* mrow;
+    char* srow;
     u32x4 h, l;
     unsigned mb;
 
@@ -263,6 +265,7 @@ struct Epi {
                 asm volatile("" : "+v"(h), "+v"(l));
                 dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
                 dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+                if constexpr (MASK == 2) *reinterpret_cast<u32x4*>(srow + 1024 * (2 * T + (I >> 2))) = h;
             }
         }
 #pragma unroll
@@ -278,11 +281,12 @@ struct Epi {
 // layer's 256 post-ReLU features: times the recorded pass bits, then (hi, lo) fragments of `dst` as in the forward.  Tiles 8, 9
 // (positions_linears.5^T) / all tiles with ENC_ACC (positions_linears.0^T) are the gradient with respect to the 64 encoding
 // slots: kept in fp32, genc[16 * tile + r].
-template <bool ENC_ACC>
+template <bool ENC_ACC, bool STASH = false>
 struct EpiG {
     Act* dst;
     const char* mrow;
     float* genc;
+    char* srow;        // STASH: this layer's dZ stash row of the wave group (+ lane * 16)
     u32x4 h, l;
     unsigned mw;
 
@@ -308,6 +312,7 @@ struct EpiG {
                 asm volatile("" : "+v"(h), "+v"(l));
                 dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
                 dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+                if constexpr (STASH) *reinterpret_cast<u32x4*>(srow + 1024 * (2 * T + (I >> 2))) = h;
             }
         }
     }
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     // side tables -> LDS once per workgroup
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
-    if constexpr (VARIANT == VAR_TRUNK_GRAD)
+    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD)
         if (threadIdx.x < 32) reinterpret_cast<float*>(smem + MASK_ZERO_OFF)[threadIdx.x] = 0.0f;
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
@@ -513,33 +518,46 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
-        if constexpr (VARIANT == VAR_TRUNK_GRAD) {
+        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) {
             // ---- density and its gradient with respect to the position: the trunk forward with every ReLU's pass bits
             // recorded, then the backward chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on the transposed stream (what autograd
-            // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts) ----
+            // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts).
+            // VAR_TRUNK_BWD: dZ(7) carries the caller's dL / d sigma, and every layer's input and dZ fragments go to the stash
+            // the weight-gradient kernel reads (train.py:479-481's backward through the trunk) ----
+            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD;
+            constexpr int MK = BWD ? 2 : 1;
             char* mbase = smem + MASK_OFF + wave * 8192 + lane * 2;   // + 1024 * layer + 128 * tile
             const float* zero = reinterpret_cast<const float*>(smem + MASK_ZERO_OFF) + h * 16;
-            using EM = Epi<true, true, 0, true>;
-            EM eA{&A, {nullptr}, {nullptr}, mbase}, eB{&B, {nullptr}, {nullptr}, mbase + 1024};
+            const long wgs = n_groups * 4, wgi = g * 4 + wave;          // wave groups of 32 points (layout.h: STASH_*)
+            auto srow = [&](int what) -> char* { return BWD ? a.stash + stash_offset(what, wgs, wgi) + lane * 16 : nullptr; };
+            if constexpr (BWD) {
+#pragma unroll
+                for (int jj = 0; jj < PE_KSTEPS; ++jj) *reinterpret_cast<bf16x8*>(srow(STASH_ENC) + 1024 * jj) = pe.hi[jj];
+            }
+            using EM = Epi<true, true, 0, MK>;
+            EM eA{&A, {nullptr}, {nullptr}, mbase, srow(STASH_X + 0)}, eB{&B, {nullptr}, {nullptr}, mbase + 1024, srow(STASH_X + 1)};
 #define IBL_PEND(e, T, acc) [&](auto I) { (e).template slice<T, decltype(I)::value>(acc); }
             Acc pacc = run_layer<8, PE_KSTEPS, 0>(P, A, pe, bias + BT_L0 * 32, none, eA);                    // layer 0 -> A
             pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 8) * 32, IBL_PEND(eA, 7, pacc), eB);         // 1 -> B
-            eA.mrow = mbase + 2 * 1024;
+            eA.mrow = mbase + 2 * 1024; eA.srow = srow(STASH_X + 2);
             pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 16) * 32, IBL_PEND(eB, 7, pacc), eA);        // 2 -> A
-            eB.mrow = mbase + 3 * 1024;
+            eB.mrow = mbase + 3 * 1024; eB.srow = srow(STASH_X + 3);
             pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 24) * 32, IBL_PEND(eA, 7, pacc), eB);        // 3 -> B
-            eA.mrow = mbase + 4 * 1024;
+            eA.mrow = mbase + 4 * 1024; eA.srow = srow(STASH_X + 4);
             pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 32) * 32, IBL_PEND(eB, 7, pacc), eA);        // 4 -> A
-            eB.mrow = mbase + 5 * 1024;
+            eB.mrow = mbase + 5 * 1024; eB.srow = srow(STASH_X + 5);
             pacc = run_layer<8, PE_KSTEPS, 16>(P, A, pe, bias + (BT_L0 + 40) * 32, IBL_PEND(eA, 7, pacc), eB);  // 5 (skip) -> B
-            eA.mrow = mbase + 6 * 1024;
+            eA.mrow = mbase + 6 * 1024; eA.srow = srow(STASH_X + 6);
             pacc = run_layer<8, 0, 16>(P, B, pe, bias + (BT_L0 + 48) * 32, IBL_PEND(eB, 7, pacc), eA);        // 6 -> A
-            Epi<false, true, 1, true> e7{nullptr, {&part[0]}, {ltab + TAB_SIG}, mbase + 7 * 1024};
-            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 56) * 32, IBL_PEND(eA, 7, pacc), e7);        // 7: sigma head + bits
+            // layer 7: sigma head + bits (its fragments are formed only for the stash: the head's weight gradient reads them)
+            Epi<BWD, true, 1, MK> e7{&B, {&part[0]}, {ltab + TAB_SIG}, mbase + 7 * 1024, srow(STASH_X + 7)};
+            pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 56) * 32, IBL_PEND(eA, 7, pacc), e7);
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
+            float up = 1.0f;                                   // dL / d sigma of this point (invalid points: 0, they add nothing to any gradient)
+            if constexpr (BWD) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
 
-            // dZ(7) = sigma_linear.weight * bits(7) -> A
+            // dZ(7) = dL/dsigma * sigma_linear.weight * bits(7) -> A
             static_for<0, 8>([&](auto T) {
                 constexpr int t = decltype(T)::value;
                 const unsigned mw = *reinterpret_cast<const unsigned short*>(mbase + 7 * 1024 + 128 * t);
@@ -551,30 +569,31 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                         const int i = 4 * q + e;
                         const f32x2 w = *reinterpret_cast<const f32x2*>(ltab + TAB_SIG + t * 32 + 2 * i);
                         unsigned hh, ll;
-                        split_pair((mw & (1u << (2 * i))) ? w[0] : 0.0f, (mw & (2u << (2 * i))) ? w[1] : 0.0f, hh, ll);
+                        split_pair((mw & (1u << (2 * i))) ? w[0] * up : 0.0f, (mw & (2u << (2 * i))) ? w[1] * up : 0.0f, hh, ll);
                         hv[e] = hh;
                         lv[e] = ll;
                     }
                     A.hi[2 * t + q] = __builtin_bit_cast(bf16x8, hv);
                     A.lo[2 * t + q] = __builtin_bit_cast(bf16x8, lv);
+                    if constexpr (BWD) *reinterpret_cast<u32x4*>(srow(STASH_DZ + 7) + 1024 * (2 * t + q)) = hv;
                 });
             });
             float genc[32];
-            EpiG<false> gA{&A, mbase, genc}, gB{&B, mbase + 6 * 1024, genc};
+            EpiG<false, BWD> gA{&A, mbase, genc, nullptr}, gB{&B, mbase + 6 * 1024, genc, srow(STASH_DZ + 6)};
             pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gB, 0);                                           // W7^T: dZ7 (A) -> dZ6 (B)
-            gA.mrow = mbase + 5 * 1024;
+            gA.mrow = mbase + 5 * 1024; gA.srow = srow(STASH_DZ + 5);
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W6^T -> dZ5 (A)
-            gB.mrow = mbase + 4 * 1024;
+            gB.mrow = mbase + 4 * 1024; gB.srow = srow(STASH_DZ + 4);
             pacc = run_layer<10, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                         // W5^T -> dZ4 (B), encoding gradient
-            gA.mrow = mbase + 3 * 1024;
+            gA.mrow = mbase + 3 * 1024; gA.srow = srow(STASH_DZ + 3);
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 9, pacc), gA, 0);                          // W4^T -> dZ3 (A)
-            gB.mrow = mbase + 2 * 1024;
+            gB.mrow = mbase + 2 * 1024; gB.srow = srow(STASH_DZ + 2);
             pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W3^T -> dZ2 (B)
-            gA.mrow = mbase + 1 * 1024;
+            gA.mrow = mbase + 1 * 1024; gA.srow = srow(STASH_DZ + 1);
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W2^T -> dZ1 (A)
-            gB.mrow = mbase;
+            gB.mrow = mbase; gB.srow = srow(STASH_DZ + 0);
             pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W1^T -> dZ0 (B)
-            EpiG<true> g0{nullptr, nullptr, genc};
+            EpiG<true> g0{nullptr, nullptr, genc, nullptr};
             pacc = run_layer<2, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), g0, 0);                          // W0^T: + encoding gradient
             static_for<0, 8>([&](auto I) { g0.template slice<1, decltype(I)::value>(pacc); });
 #undef IBL_PEND
@@ -597,6 +616,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             if (!h) g3[1] += genc[2 * PE_PAIRS_PER_HALF + 1];
 #pragma unroll
             for (int c = 0; c < 3; ++c) g3[c] += __shfl_xor(g3[c], 32);
+            if constexpr (VARIANT == VAR_TRUNK_BWD) {
+                const float inv = 1.0f / a.grad_scale;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g3[c] *= inv;
+            }
             if (valid && h == 0) {
                 f32x4 o = {sigma, g3[0], g3[1], g3[2]};
                 *reinterpret_cast<f32x4*>(a.out + 4 * p) = o;
@@ -775,10 +799,10 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  VARIANT == VAR_TRUNK_GRAD ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
+                                  (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), VARIANT == VAR_TRUNK_GRAD ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
 #define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
@@ -793,11 +817,13 @@ IBL_DEFINE_LAUNCH(2)
 IBL_DEFINE_LAUNCH(3)
 #elif IBL_VARIANT == 6
 IBL_DEFINE_LAUNCH(6)
+#elif IBL_VARIANT == 7
+IBL_DEFINE_LAUNCH(7)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -808,6 +834,9 @@ hipError_t IBL_LAUNCH_NAME(2)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(3)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(4)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(6)(const MlpArgs&, int, hipStream_t);
+#ifdef IBL_F16X3
+hipError_t IBL_LAUNCH_NAME(7)(const MlpArgs&, int, hipStream_t);   // (the stash is f16: this flavour only)
+#endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -820,6 +849,9 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_FULL_CI: rc = IBL_LAUNCH_NAME(3)(a, grid, stream); break;
         case VAR_REFL_CI: rc = IBL_LAUNCH_NAME(4)(a, grid, stream); break;
         case VAR_TRUNK_GRAD: rc = IBL_LAUNCH_NAME(6)(a, grid, stream); break;
+#ifdef IBL_F16X3
+        case VAR_TRUNK_BWD: rc = IBL_LAUNCH_NAME(7)(a, grid, stream); break;
+#endif
         default: return hipErrorInvalidValue;
     }
     if (rc != hipSuccess) return rc;

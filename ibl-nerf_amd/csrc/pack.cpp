@@ -146,6 +146,17 @@ size_t blob_floats() {
     return n;  // 798 994
 }
 
+void blob_offsets(int layer, size_t* weight, size_t* bias) {
+    size_t off = 0;
+    for (int l = 0; l < N_LAYERS; ++l) {
+        const size_t w = off;
+        off += (size_t)kLayers[l].out * kLayers[l].in;
+        if (l == layer) { *weight = w; *bias = off; return; }
+        off += (size_t)kLayers[l].out;
+    }
+    *weight = *bias = 0;
+}
+
 void pack_network_f16x3(const float* blob, void* stream_out, float* tab) {
     g_split_f16 = true;
     pack_network(blob, stream_out, tab);

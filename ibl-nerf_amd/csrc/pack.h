@@ -7,6 +7,9 @@
 
 namespace ibl {
 size_t blob_floats();  // 798 994: floats in one network's state-dict blob
+// offsets (floats) of layer `layer`'s weight and bias inside the blob; layers in registration order: 0..7 positions_linears,
+// 8 views_linears.0, 9 feature_linear, 10 sigma_linear, ... (pack.cpp: LayerId)
+void blob_offsets(int layer, size_t* weight, size_t* bias);
 // blob -> stream_out (STREAM_BYTES) + tab (TAB_FLOATS floats), both host buffers
 void pack_network(const float* blob, void* stream_out, float* tab);
 // the same layout with f16 (hi, lo) pairs (mlp_kernel.hip -DIBL_F16X3); not thread-safe (shares the packer's mode flags)

@@ -335,6 +335,43 @@ class Renderer:
             return self._wide_twin().density_gradient(pts, which)
         return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape)
 
+    def trunk_backward(self, pts, dsigma, which=0, grad_scale=None):
+        """The backward of the trunk-only query of a training step (train.py:479-481 through network_query_fn(pts, None, fn)):
+        given dL/dsigma per point, returns (sigma, dL/dpts, grads) with grads = {parameter name: gradient} for positions_linears.0-7 and
+        sigma_linear in the reference's state-dict shapes — what autograd would leave in `.grad`.
+        grad_scale: the power-of-two loss scale of the f16 gradient stash (include/iblnerf.h).  None = dynamic, as in f16 training:
+        start where the largest upstream gradient sits at 2^10 and step down by 2^6 while the kernels report an overflow.  No bf16x3
+        repeat: a range event at every scale raises FloatingPointError."""
+        torch = _torch()
+        from . import checkpoint as ck
+        pts = _dev_f32(pts, self.device)
+        flat = pts.reshape(-1, 3)
+        ds = _dev_f32(dsigma, self.device).reshape(-1)
+        if ds.shape[0] != flat.shape[0]:
+            raise ValueError("trunk_backward: one dL/dsigma per point")
+        out = torch.empty((flat.shape[0], 4), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
+        if grad_scale is None:
+            top = float(ds.abs().max()) if ds.numel() else 1.0
+            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
+        else:
+            scales = [float(grad_scale)]
+        for sc in scales:
+            B.check(self.ctx, self.lib.iblnerf_trunk_backward(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], ds.data_ptr(),
+                                                             sc, out.data_ptr(), grad.data_ptr()))
+            if not self.out_of_range():
+                break
+        else:
+            raise FloatingPointError("trunk_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
+        self.last_grad_scale = sc
+        grads, off = {}, 0
+        for name, o, i in ck.SCHEMA:                         # views into the device blob, reference shapes
+            if name.startswith(("positions_linears.", "sigma_linear")):
+                grads[name + ".weight"] = grad[off:off + o * i].view(o, i)
+                grads[name + ".bias"] = grad[off + o * i:off + o * i + o]
+            off += o * i + o
+        return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape), grads
+
     def sample_pdf(self, bins, weights, N_samples, det=True, pytest=False, u=None):
         """nerf_renderer_helper.py:91-134.  det=False draws u ~ U[0,1) on the device (or takes `u` [n, N_samples]); pytest=True
         takes numpy's seed-0 stream as the reference's test path does (:106-113)."""

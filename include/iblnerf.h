@@ -187,6 +187,21 @@ int iblnerf_network_query(iblnerf_ctx* ctx, void* stream, int which, const float
  * d_pts [n_pts, 3] -> d_out [n_pts, 4] = (sigma, d sigma / d x, d sigma / d y, d sigma / d z). */
 int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out);
 
+/* replaces: loss.backward() through the trunk-only query network_query_fn(pts, None, fn) of a training step (train.py:479-481;
+ * ibl_nerf.py:236-252, 154-176): given dL / d sigma per point, the gradient with respect to the points AND to the trunk's
+ * parameters (positions_linears.0-7 and sigma_linear, weights and biases).
+ * d_pts [n_pts, 3], d_dsigma [n_pts]  ->  d_out [n_pts, 4] = (sigma, dL/dx, dL/dy, dL/dz);
+ * d_grad: iblnerf_blob_floats() floats in the state-dict layout of iblnerf_upload_weights (zeroed here; entries of the other layers stay 0).
+ * Two stages: the fused forward + backward chain of iblnerf_density_gradient, which also stashes every layer's input and dZ
+ * fragments (8.1 KiB per point of workspace, grown on demand), then the weight-gradient GEMMs over the points (f16 operands,
+ * fp32 accumulation; the operand transposition is done by the matrix core).  Needs an mlp_precision with the f16x3 stream.
+ * grad_scale: a power of two applied to dL/dsigma inside the kernels and taken out of every result — the loss scaling of f16
+ * training: gradients are stashed as f16, so small ones must be lifted out of the denormals (|dZ| < 6e-5) without the largest
+ * reaching 65504; an overflow raises the range flag (iblnerf_range_status) and the results are then invalid: repeat with a
+ * smaller scale (ibl-nerf_amd/renderer.py: trunk_backward does that). */
+int iblnerf_trunk_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
+                           float grad_scale, float* d_out, float* d_grad);
+
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
 int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,

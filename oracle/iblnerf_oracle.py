@@ -209,6 +209,44 @@ def density_gradient(sd, pts):
     return sigma.astype(F32), grad.astype(F32)
 
 
+def trunk_backward(sd, pts, dsigma):
+    """What loss.backward() leaves in .grad of the trunk's parameters for L with dL/d sigma_p = dsigma_p on the trunk-only query
+    (train.py:479-481 through ibl_nerf.py:236-252, 154-176), written out: dW(l) = dZ(l)^T X(l-1), db(l) = sum_p dZ(l).
+    Returns (sigma [P], dL/dpts [P,3], {name: gradient})."""
+    pts = np.asarray(pts, dtype=F32).reshape(-1, 3)
+    up = np.asarray(dsigma, dtype=np.float64).reshape(-1, 1)
+    e = embed(pts, 10)
+    h, masks, ins = e, [], []
+    for i in range(8):
+        ins.append(h)
+        z = _lin(sd, "positions_linears.%d" % i, h)
+        masks.append(z > 0)
+        h = relu(z)
+        if i == 4:
+            h = np.concatenate([e, h], -1)
+    sigma = _lin(sd, "sigma_linear", h)[:, 0]
+    grads = {"sigma_linear.weight": (up * h).sum(0, keepdims=True).astype(F32), "sigma_linear.bias": up.sum(0).astype(F32)}
+    g = up * sd["sigma_linear.weight"].astype(np.float64) * masks[7]
+    g_enc = np.zeros(e.shape)
+    for i in range(7, -1, -1):
+        grads["positions_linears.%d.weight" % i] = (g.T @ ins[i].astype(np.float64)).astype(F32)
+        grads["positions_linears.%d.bias" % i] = g.sum(0).astype(F32)
+        gi = g @ sd["positions_linears.%d.weight" % i].astype(np.float64)
+        if i == 5:
+            g_enc = g_enc + gi[:, :63]
+            gi = gi[:, 63:]
+        if i == 0:
+            g_enc = g_enc + gi
+        else:
+            g = gi * masks[i - 1]
+    grad = g_enc[:, 0:3].copy()
+    for k in range(10):
+        f = 2.0 ** k
+        s_, c_ = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
+        grad = grad + f * (g_enc[:, 3 + 6 * k:6 + 6 * k] * c_ - g_enc[:, 6 + 6 * k:9 + 6 * k] * s_)
+    return sigma.astype(F32), grad.astype(F32), grads
+
+
 # A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
 # --------------------------------------------------------------------------------------------
 def ray_dists(z_vals, rays_d):

@@ -216,6 +216,41 @@ def density_gradient_samples(torch, kw, o, d, near, far, n_rays, n_samples):
     return out
 
 
+def trunk_backward_fixture(torch, M):
+    """loss.backward() through the reference's own trunk-only query path (run_network -> embed -> IBLNeRF.forward, viewdirs=None) for
+    L = sum_p c_p sigma_p, c seeded: the parameter gradients of positions_linears.0-7 and sigma_linear and dL/dpts — the known answer of
+    iblnerf_trunk_backward.  Random-init network (seed 60) and the fitted coarse network, 384 points each."""
+    out = {}
+    for tag, sd in (("g10", ck.synthetic_state_dict(seed=60, gain=1.0)), ("fit", fitted_state_dicts()[0])):
+        tmp = tempfile.mkdtemp()
+        try:
+            _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 0))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        net = kw["network_fn"]
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        rng = np.random.RandomState(61)
+        pts = rng.uniform(-1.5, 1.5, (3, 128, 3)).astype(np.float32)
+        c = rng.uniform(-1, 1, (3, 128)).astype(np.float32)
+        p = torch.from_numpy(pts).requires_grad_(True)
+        net.zero_grad()
+        with torch.enable_grad():
+            raw = kw["network_query_fn"](p, None, net)
+            (raw[..., 0] * torch.from_numpy(c)).sum().backward()
+        out[tag + "__pts"], out[tag + "__dsigma"] = pts.reshape(-1, 3), c.reshape(-1)
+        out[tag + "__sigma"] = raw[..., 0].detach().numpy().reshape(-1).copy()
+        out[tag + "__dpts"] = p.grad.numpy().reshape(-1, 3).copy()
+        for name, prm in net.named_parameters():
+            if name.startswith(("positions_linears.", "sigma_linear.")):
+                out[tag + "__grad__" + name] = prm.grad.numpy().copy()
+            else:
+                assert prm.grad is None or float(prm.grad.abs().max()) == 0.0      # the trunk-only query touches nothing else
+        out[tag + "__ck"] = np.array(ck.blob_checksum(ck.state_dict_to_blob(sd)))
+    path = os.path.join(OUT, "trunk_backward.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s parameter gradients of the trunk by the reference's autograd  %.2f MB" % ("trunk_backward", os.path.getsize(path) / 1e6))
+
+
 def fitted_state_dicts():
     """The checkpoint fit_checkpoint.py produced with the reference's modules (tests/golden/fitted_ckpt.npz)."""
     f = np.load(os.path.join(OUT, "fitted_ckpt.npz"))
@@ -513,6 +548,8 @@ def main(only=None):
         small_vectors(torch, R, Hh)
     if not only or "export_path" in only:
         export_fixture(torch, R, M, lut)
+    if not only or "trunk_backward" in only:
+        trunk_backward_fixture(torch, M)
 
     def run_fixture(name, *a, **k):
         if not only or name in only:

@@ -298,3 +298,18 @@ def test_autograd_normal_modes(name, lut):
     with pytest.raises(NameError):                      # the two sigma-gradient modes: the reference's NameError (:349-353, import commented out :15)
         O.render_rays(sdc, sdf, g["rays_o"][:2], g["rays_d"][:2], float(g["near"]), float(g["far"]), lut, 64, 0, {}, {}, {},
                       dict(target_normal_map_for_radiance_calculation="normal_map_from_sigma_gradient"), {})
+
+
+@pytest.mark.parametrize("tag", ["g10", "fit"])
+def test_trunk_backward_against_reference_autograd(tag):
+    """oracle.trunk_backward (the written-out backward of the trunk-only query) against the reference's loss.backward(): every parameter
+    gradient of positions_linears.0-7 / sigma_linear and dL/dpts at float32 round-off."""
+    from ibl_nerf_amd import checkpoint as ck
+    g = np.load(GOLDEN + "/trunk_backward.npz")
+    sd = ck.synthetic_state_dict(60, 1.0) if tag == "g10" else ck.blob_to_state_dict(np.load(GOLDEN + "/fitted_ckpt.npz")["coarse"])
+    assert ck.blob_checksum(ck.state_dict_to_blob(sd)) == str(g[tag + "__ck"])
+    s, dp, grads = O.trunk_backward(sd, g[tag + "__pts"], g[tag + "__dsigma"])
+    assert rel_linf(s, g[tag + "__sigma"]) <= 2e-6 and rel_linf(dp, g[tag + "__dpts"]) <= 5e-6
+    assert len(grads) == 18
+    for k, v in grads.items():
+        assert v.shape == g[tag + "__grad__" + k].shape and rel_linf(v, g[tag + "__grad__" + k]) <= 5e-6, k
