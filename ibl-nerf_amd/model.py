@@ -138,19 +138,52 @@ def network_query_fn(inputs, viewdirs, network_fn, renderer=None, which=0):
     return _query_renderer(network_fn).network_query(inputs, viewdirs, 0)
 
 
-def training_network_query_fn(grad_query_fn):
+TRUNK_PARAMS = tuple("positions_linears.%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")) + ("sigma_linear.weight", "sigma_linear.bias")
+
+
+def fused_trunk_query(inputs, network_fn):
+    """`network_query_fn(inputs, None, network_fn)` (the trunk-only query, ibl_nerf.py:175-176) WITH autograd, both directions on the
+    fused kernels: forward = the trunk query, backward = iblnerf_trunk_backward (the forward is recomputed there with the pass bits
+    kept, as under activation checkpointing), which hands dL/dinputs and the gradients of positions_linears.0-7 / sigma_linear back
+    to torch.  `network_fn` is the torch module whose parameters carry those names (the reference's IBLNeRF).  First derivatives only."""
+    import torch
+    named = dict(network_fn.named_parameters())
+    params = [named[k] for k in TRUNK_PARAMS]
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, pts, *ps):
+            ctx.save_for_backward(pts)
+            return _query_renderer(network_fn).network_query(pts, None, 0)
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            (pts,) = ctx.saved_tensors
+            r = _query_renderer(network_fn)
+            _, dpts, grads = r.trunk_backward(pts, grad_out.contiguous()[..., 0], 0)
+            return (dpts if ctx.needs_input_grad[0] else None,) + tuple(
+                grads[k].reshape(p.shape) if ctx.needs_input_grad[1 + i] else None for i, (k, p) in enumerate(zip(TRUNK_PARAMS, params)))
+
+    return _Fn.apply(inputs, *params)
+
+
+def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):
     """`network_query_fn` for `render_kwargs_train` (train.py:286-297).  In the shipped training
     configuration the eps-normal queries (ibl_nerf_renderer.py:358-361) and the reflected-ray query
     (:442-448) run under `torch.no_grad()`: 1024 trunk + 128 full evaluations per ray, 59 % of the forward
     FLOPs of a training step.  Those go to the fused kernel; a query that must carry gradients (the main
     query of each pass) is handed to `grad_query_fn`, the reference's own autograd path
-    (`lambda inputs, viewdirs, network_fn: run_network(...)`, ibl_nerf.py:327-329), unchanged."""
+    (`lambda inputs, viewdirs, network_fn: run_network(...)`, ibl_nerf.py:327-329), unchanged — except, with
+    `fused_trunk_backward`, a gradient-carrying TRUNK-ONLY query (viewdirs None: what the depth-gradient normal modes issue,
+    normal_from_depth.py:36, :121), which then runs forward and backward on the fused kernels (`fused_trunk_query`)."""
     import torch
 
     def fn(inputs, viewdirs, network_fn):
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in network_fn.parameters()) or getattr(inputs, "requires_grad", False)
             or getattr(viewdirs, "requires_grad", False))
+        if needs_grad and fused_trunk_backward and viewdirs is None:
+            return fused_trunk_query(inputs, network_fn)
         if needs_grad:
             return grad_query_fn(inputs, viewdirs, network_fn)
         return network_query_fn(inputs, viewdirs, network_fn)

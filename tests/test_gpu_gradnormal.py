@@ -196,3 +196,45 @@ def test_trunk_backward_accumulates_over_many_points_and_ragged_sizes(R, lut):
     from ibl_nerf_amd.binding import IblNerfError
     with pytest.raises(IblNerfError):
         rb.trunk_backward(pts[:10], c[:10], 0)
+
+
+def test_fused_trunk_query_in_a_torch_training_loop(R, lut):
+    """model.fused_trunk_query: the trunk-only query as a torch.autograd.Function (forward and backward on the fused kernels) inside a
+    plain torch training loop — gradients against torch's own autograd through the same module, then ten Adam steps on both paths from the
+    same start: the fused path follows the weights the optimizer writes (device-side repack per step) and the loss curves agree."""
+    from ibl_nerf_amd import model as M
+    from torch_ref import RefShaped, torch_query
+    g, sdc, _, _, _ = load_golden("plain_g10")
+    rng = np.random.RandomState(11)
+    pts = torch.from_numpy(rng.uniform(-1.5, 1.5, (8, 64, 3)).astype(np.float32)).cuda()
+    target = torch.from_numpy(rng.uniform(0, 2, (8, 64, 1)).astype(np.float32)).cuda()
+    nets = [RefShaped(sdc).cuda(), RefShaped(sdc).cuda()]
+    calls = []
+    q = M.training_network_query_fn(lambda i, v, n: calls.append(1) or torch_query(i, v, n), fused_trunk_backward=True)
+    # one backward: every trunk gradient and the input gradient against torch autograd
+    p0, p1 = pts.clone().requires_grad_(True), pts.clone().requires_grad_(True)
+    (q(p0, None, nets[0]) - target).square().sum().backward()
+    (torch_query(p1, None, nets[1]) - target).square().sum().backward()
+    assert not calls                                                          # the trunk-only query never reached the autograd path
+    assert rel_linf(p0.grad.cpu().numpy(), p1.grad.cpu().numpy()) <= 2e-3
+    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if k in M.TRUNK_PARAMS:
+            assert rel_linf(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= 1e-3, k
+        else:
+            assert a.grad is None and b.grad is None
+    # a gradient-carrying query WITH view directions still goes to the autograd path
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (8, 3)).astype(np.float32)).cuda()
+    assert q(pts, dirs, nets[0]).requires_grad and len(calls) == 1
+    # ten optimizer steps on each path
+    opts = [torch.optim.Adam(n.parameters(), lr=5e-4) for n in nets]
+    losses = [[], []]
+    for step in range(10):
+        for j, (net, opt) in enumerate(zip(nets, opts)):
+            opt.zero_grad()
+            out = q(pts, None, net) if j == 0 else torch_query(pts, None, net)
+            loss = (out - target).square().mean()
+            loss.backward()
+            opt.step()
+            losses[j].append(float(loss.detach()))
+    assert losses[0][-1] < 0.7 * losses[0][0]                                # it trains
+    assert np.abs(np.array(losses[0]) - np.array(losses[1])).max() <= 2e-2 * losses[1][0], (losses[0], losses[1])
