@@ -552,10 +552,43 @@ int iblnerf_density_gradient(iblnerf_ctx* c, void* stream, int which, const floa
     return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
+int iblnerf_trunk_features(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_h7) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_h7))) return c->fail(IBLNERF_ERR_INVALID, "trunk_features: bad arguments");
+    if (n_pts == 0) return IBLNERF_OK;
+    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "trunk_features: more than 2^31 points");
+    if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "trunk_features: weights of network %d not uploaded", which);
+    if (!c->d_stream_f16[which] || !c->mx_ok[which])
+        return c->fail(IBLNERF_ERR_STATE, "trunk_features: needs an mlp_precision that keeps the f16x3 stream (f16x3*) and weights inside the f16 range");
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    MlpArgs a;
+    a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_h7; a.out_stride = 256;
+    a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag;
+    HIP_TRY(c, launch_mlp_f16x3(VAR_TRUNK_FEAT, a, c->n_cu, (hipStream_t)stream));
+    c->flop_alg += (double)n_pts * FLOP_TRUNK;
+    return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
+                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad);
+
 int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                            float grad_scale, float* d_out, float* d_grad) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_dsigma || !d_out)) || !d_grad)
+    if (n_pts > 0 && !d_dsigma) return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
+    return trunk_backward_impl(c, stream, which, d_pts, n_pts, d_dsigma, nullptr, grad_scale, d_out, d_grad);
+}
+
+int iblnerf_trunk_features_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dh7,
+                                    float grad_scale, float* d_out, float* d_grad) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_pts > 0 && !d_dh7) return c->fail(IBLNERF_ERR_INVALID, "trunk_features_backward: bad arguments");
+    return trunk_backward_impl(c, stream, which, d_pts, n_pts, nullptr, d_dh7, grad_scale, d_out, d_grad);
+}
+
+static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
+                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad) {
+    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)) || !d_grad)
         return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
     int gs_exp = 0;
     if (!(grad_scale > 0.0f) || std::frexp(grad_scale, &gs_exp) != 0.5f)
@@ -589,7 +622,7 @@ int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float*
     }
     MlpArgs a;
     a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
-    a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
+    a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
     HIP_TRY(c, launch_mlp_f16x3(VAR_TRUNK_BWD, a, c->n_cu, s));
     c->flop_alg += (double)n_pts * 3.0 * FLOP_TRUNK;
     w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;

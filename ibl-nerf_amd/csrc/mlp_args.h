@@ -21,6 +21,7 @@ struct MlpArgs {
     // VAR_TRUNK_BWD only (the trunk's backward for a training step): upstream gradient per point and the operand stash the
     // weight-gradient kernel reads (layout.h: STASH_*)
     const float* dsigma = nullptr;   // [n_pts] dL / d sigma
+    const float* dh7 = nullptr;      // or [n_pts, 256] dL / d trunk features (then dsigma is not read: the heads live with the caller)
     char* stash = nullptr;
     float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
                                      // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels

@@ -82,7 +82,7 @@ __device__ long long g_trace[256];
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr int N_PROG = VARIANT == VAR_TRUNK ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
+    static constexpr int N_PROG = (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
                                   : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
@@ -224,15 +224,18 @@ struct Acc {
 //   MASK : (density-gradient variant) the ReLU's pass bits of this tile, 16 per lane, go to the wave's mask area in LDS:
 //          u16 at mrow + 128 * T (mrow = this lane's slot in the layer's row, see MASK_* below)
 //          MASK = 2 (VAR_TRUNK_BWD): the hi fragments also go to the operand stash (layout.h: STASH_X), srow + 1024 * k-step
-template <bool STORE, bool RELU, int NCH, int MASK = 0>
+//   FOUT : (VAR_TRUNK_FEAT) the fp32 values themselves go to the caller: frow = this point's 256-float row + 4h, four floats per two slices
+template <bool STORE, bool RELU, int NCH, int MASK = 0, bool FOUT = false>
 struct Epi {
     Act* dst;
     float* part[NCH > 0 ? NCH : 1];
     const float* tab[NCH > 0 ? NCH : 1];   // this lane-half's row of tile 0 of each head table ([tile][2][16])
     char* mrow;
     char* srow;
+    float* frow;
     u32x4 h, l;
     unsigned mb;
+    f32x2 keep;
 
     template <int T, int I>
     __device__ __forceinline__ void slice(const Acc& a) {
@@ -250,6 +253,10 @@ struct Epi {
             x0 = relu_bits(x0);
             x1 = relu_bits(x1);
 #endif
+        }
+        if constexpr (FOUT) {
+            if constexpr ((I & 1) == 0) keep = f32x2{x0, x1};
+            else if (frow != nullptr) *reinterpret_cast<f32x4*>(frow + 32 * T + 8 * (I >> 1)) = f32x4{keep[0], keep[1], x0, x1};
         }
         if constexpr (MASK) {
             const unsigned bits = (x0 > 0.0f ? 1u << (2 * I) : 0u) | (x1 > 0.0f ? 2u << (2 * I) : 0u);
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
             float up = 1.0f;                                   // dL / d sigma of this point (invalid points: 0, they add nothing to any gradient)
-            if constexpr (BWD) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
+            if constexpr (BWD) up = (valid && a.dsigma != nullptr) ? a.dsigma[p] * a.grad_scale : 0.0f;
 
             // dZ(7) = dL/dsigma * sigma_linear.weight * bits(7) -> A
             static_for<0, 8>([&](auto T) {
@@ -564,12 +571,24 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 static_for<0, 2>([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
                     u32x4 hv, lv;
+                    float wv[8];   // dL / d h7 of accumulator registers 8q .. 8q+7 = features 32t + 16q + 4h + {0..3, 8..11}
+                    bool from_rows = false;
+                    if constexpr (BWD) from_rows = a.dh7 != nullptr;
+                    if (from_rows) {
+                        const float* row = a.dh7 + (size_t)(valid ? p : 0) * 256 + 32 * t + 16 * q + 4 * h;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(row), r1 = *reinterpret_cast<const f32x4*>(row + 8);
+                        const float sc_ = valid ? a.grad_scale : 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { wv[e] = r0[e] * sc_; wv[4 + e] = r1[e] * sc_; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) wv[e] = ltab[TAB_SIG + t * 32 + 8 * q + e] * up;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * q + e;
-                        const f32x2 w = *reinterpret_cast<const f32x2*>(ltab + TAB_SIG + t * 32 + 2 * i);
                         unsigned hh, ll;
-                        split_pair((mw & (1u << (2 * i))) ? w[0] * up : 0.0f, (mw & (2u << (2 * i))) ? w[1] * up : 0.0f, hh, ll);
+                        split_pair((mw & (1u << (2 * i))) ? wv[2 * e] : 0.0f, (mw & (2u << (2 * i))) ? wv[2 * e + 1] : 0.0f, hh, ll);
                         hv[e] = hh;
                         lv[e] = ll;
                     }
@@ -681,13 +700,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                                           {ltab + TAB_SIG, ltab + TAB_ROUGH, rad[0], rad[1], rad[2]}};
             else if constexpr (VARIANT == VAR_REFL_CI)
                 return Epi<true, true, 4>{&B, {&part[0], &part[6], &part[7], &part[8]}, {ltab + TAB_SIG, rad[0], rad[1], rad[2]}};
+            else if constexpr (VARIANT == VAR_TRUNK_FEAT)   // h7 itself is the output (sigma is still formed: it carries the range guard's NaN)
+                return Epi<false, true, 1, 0, true>{&B, {&part[0]}, {ltab + TAB_SIG}, nullptr, nullptr, valid ? a.out + (size_t)p * 256 + 4 * h : nullptr};
             else
                 return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}};
         }();
         pacc = run_layer<8, 0, 16>(P, A, pe, bias + (BT_L0 + 56) * 32,
                                    [&](auto I) { eA.template slice<7, decltype(I)::value>(pacc); }, e7);
 
-        if constexpr (VARIANT == VAR_TRUNK) {
+        if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) {
             flush(e7, T7{}, pacc);
         } else {
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}};
@@ -729,9 +750,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 
         // ---- combine the two lane halves, add head biases, store ------------------------------
         const float* sc = tabs + TAB_SCALAR;
-        if constexpr (VARIANT == VAR_TRUNK) {
+        if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
-            if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
+            if (VARIANT == VAR_TRUNK && valid && h == 0) a.out[(long)p * a.out_stride] = s;
 #ifdef IBL_F16X3
             if (valid && !(fabsf(s) < __builtin_inff()) && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);   // range guard (see split_pair)
 #endif
@@ -819,11 +840,13 @@ IBL_DEFINE_LAUNCH(3)
 IBL_DEFINE_LAUNCH(6)
 #elif IBL_VARIANT == 7
 IBL_DEFINE_LAUNCH(7)
+#elif IBL_VARIANT == 8
+IBL_DEFINE_LAUNCH(8)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -836,6 +859,7 @@ hipError_t IBL_LAUNCH_NAME(4)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(6)(const MlpArgs&, int, hipStream_t);
 #ifdef IBL_F16X3
 hipError_t IBL_LAUNCH_NAME(7)(const MlpArgs&, int, hipStream_t);   // (the stash is f16: this flavour only)
+hipError_t IBL_LAUNCH_NAME(8)(const MlpArgs&, int, hipStream_t);
 #endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
@@ -851,6 +875,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_TRUNK_GRAD: rc = IBL_LAUNCH_NAME(6)(a, grid, stream); break;
 #ifdef IBL_F16X3
         case VAR_TRUNK_BWD: rc = IBL_LAUNCH_NAME(7)(a, grid, stream); break;
+        case VAR_TRUNK_FEAT: rc = IBL_LAUNCH_NAME(8)(a, grid, stream); break;
 #endif
         default: return hipErrorInvalidValue;
     }

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_bias_grad(WgradArgs a, const float* __r
     const int lane = threadIdx.x & 63, j = 4 * jq + (threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
     const bool head = what == 8;
+    if (head && dsigma == nullptr) return;      // the caller keeps sigma_linear (upstream gradient given on the trunk features)
     const char* base = a.stash + stash_offset(head ? STASH_X + 7 : STASH_DZ + what, a.wave_groups, 0) + j * 1024 + lane * 16;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float accb = 0.0f;

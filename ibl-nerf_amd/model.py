@@ -167,23 +167,74 @@ def fused_trunk_query(inputs, network_fn):
     return _Fn.apply(inputs, *params)
 
 
+def fused_trunk_features(inputs, network_fn):
+    """positions_linears.0-7 of IBLNeRF.forward (ibl_nerf.py:160-170) as a torch.autograd.Function on the fused kernels: [..., 3] points ->
+    [..., 256] post-ReLU trunk features; backward = iblnerf_trunk_features_backward (dL/dinputs and the 16 trunk parameter gradients)."""
+    import torch
+    named = dict(network_fn.named_parameters())
+    names = TRUNK_PARAMS[:16]
+    params = [named[k] for k in names]
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, pts, *ps):
+            ctx.save_for_backward(pts)
+            return _query_renderer(network_fn).trunk_features(pts, 0)
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            (pts,) = ctx.saved_tensors
+            _, dpts, grads = _query_renderer(network_fn).trunk_backward(pts, grad_out.contiguous(), 0, features=True)
+            return (dpts if ctx.needs_input_grad[0] else None,) + tuple(
+                grads[k].reshape(p.shape) if ctx.needs_input_grad[1 + i] else None for i, (k, p) in enumerate(zip(names, params)))
+
+    return _Fn.apply(inputs, *params)
+
+
+def fused_query(inputs, viewdirs, network_fn):
+    """`network_query_fn(inputs, viewdirs, network_fn)` WITH autograd for a training step's gradient-carrying main query: the trunk
+    (62 % of the network's FLOPs) forward and backward on the fused kernels (`fused_trunk_features`), the head layers — what
+    IBLNeRF.forward does after the trunk, ibl_nerf.py:171-208 — in torch on the module's own parameters."""
+    import torch
+    import torch.nn.functional as F
+    n = network_fn
+    h = fused_trunk_features(inputs, n)
+    sigma = n.sigma_linear(h)
+    if viewdirs is None:
+        return sigma                                                                   # :175-176
+    albedo = n.albedo_linear(F.relu(n.albedo_feature_linear(h)))
+    rough = n.roughness_linear(h)
+    irr = n.irradiance_linear(F.relu(n.irradiance_feature_linear(h)))
+    if not _ci(n):
+        d = viewdirs[:, None].expand(inputs.shape)                                     # run_network expands the directions over the samples (:244-247)
+        e = torch.cat([d] + [f(d * 2.0 ** k) for k in range(4) for f in (torch.sin, torch.cos)], -1)
+        h = torch.cat([n.feature_linear(h), e], -1)
+        for l in n.views_linears:
+            h = F.relu(l(h))
+    ret = [sigma, albedo, rough, irr, n.radiance_linear(h)]
+    for fl, ol in zip(n.additional_radiance_feature_linear, n.additional_radiance_linear):
+        ret.append(ol(F.relu(fl(h))))
+    return torch.cat(ret, -1)
+
+
 def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):
     """`network_query_fn` for `render_kwargs_train` (train.py:286-297).  In the shipped training
     configuration the eps-normal queries (ibl_nerf_renderer.py:358-361) and the reflected-ray query
     (:442-448) run under `torch.no_grad()`: 1024 trunk + 128 full evaluations per ray, 59 % of the forward
     FLOPs of a training step.  Those go to the fused kernel; a query that must carry gradients (the main
     query of each pass) is handed to `grad_query_fn`, the reference's own autograd path
-    (`lambda inputs, viewdirs, network_fn: run_network(...)`, ibl_nerf.py:327-329), unchanged — except, with
-    `fused_trunk_backward`, a gradient-carrying TRUNK-ONLY query (viewdirs None: what the depth-gradient normal modes issue,
-    normal_from_depth.py:36, :121), which then runs forward and backward on the fused kernels (`fused_trunk_query`)."""
+    (`lambda inputs, viewdirs, network_fn: run_network(...)`, ibl_nerf.py:327-329), unchanged — except with
+    `fused_trunk_backward`: then the trunk of every gradient-carrying query runs forward and backward on the fused kernels — the
+    trunk-only query (viewdirs None: what the depth-gradient normal modes issue, normal_from_depth.py:36, :121) entirely
+    (`fused_trunk_query`), the main query with its head layers in torch (`fused_query`)."""
     import torch
 
     def fn(inputs, viewdirs, network_fn):
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in network_fn.parameters()) or getattr(inputs, "requires_grad", False)
             or getattr(viewdirs, "requires_grad", False))
-        if needs_grad and fused_trunk_backward and viewdirs is None:
-            return fused_trunk_query(inputs, network_fn)
+        if needs_grad and fused_trunk_backward:
+            return fused_trunk_query(inputs, network_fn) if viewdirs is None else fused_query(inputs, viewdirs, network_fn)
         if needs_grad:
             return grad_query_fn(inputs, viewdirs, network_fn)
         return network_query_fn(inputs, viewdirs, network_fn)

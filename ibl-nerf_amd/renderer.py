@@ -335,10 +335,22 @@ class Renderer:
             return self._wide_twin().density_gradient(pts, which)
         return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape)
 
-    def trunk_backward(self, pts, dsigma, which=0, grad_scale=None):
+    def trunk_features(self, pts, which=0):
+        """positions_linears.0-7 (ibl_nerf.py:160-170): the 256 post-ReLU trunk features every head of IBLNeRF.forward reads, [..., 256]."""
+        torch = _torch()
+        pts = _dev_f32(pts, self.device)
+        flat = pts.reshape(-1, 3)
+        out = torch.empty((flat.shape[0], 256), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_trunk_features(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], out.data_ptr()))
+        if self.out_of_range():
+            raise FloatingPointError("trunk_features: an activation left the f16 range")
+        return out.reshape(pts.shape[:-1] + (256,))
+
+    def trunk_backward(self, pts, dsigma, which=0, grad_scale=None, features=False):
         """The backward of the trunk-only query of a training step (train.py:479-481 through network_query_fn(pts, None, fn)):
         given dL/dsigma per point, returns (sigma, dL/dpts, grads) with grads = {parameter name: gradient} for positions_linears.0-7 and
         sigma_linear in the reference's state-dict shapes — what autograd would leave in `.grad`.
+        features=True: `dsigma` is dL/dh7 [..., 256], the gradient on trunk_features' output (the heads, sigma_linear included, are the caller's).
         grad_scale: the power-of-two loss scale of the f16 gradient stash (include/iblnerf.h).  None = dynamic, as in f16 training:
         start where the largest upstream gradient sits at 2^10 and step down by 2^6 while the kernels report an overflow.  No bf16x3
         repeat: a range event at every scale raises FloatingPointError."""
@@ -346,9 +358,10 @@ class Renderer:
         from . import checkpoint as ck
         pts = _dev_f32(pts, self.device)
         flat = pts.reshape(-1, 3)
-        ds = _dev_f32(dsigma, self.device).reshape(-1)
+        ds = _dev_f32(dsigma, self.device).reshape(-1, 256) if features else _dev_f32(dsigma, self.device).reshape(-1)
         if ds.shape[0] != flat.shape[0]:
-            raise ValueError("trunk_backward: one dL/dsigma per point")
+            raise ValueError("trunk_backward: one upstream gradient row per point")
+        entry = self.lib.iblnerf_trunk_features_backward if features else self.lib.iblnerf_trunk_backward
         out = torch.empty((flat.shape[0], 4), dtype=torch.float32, device=self.device)
         grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
         if grad_scale is None:
@@ -357,8 +370,7 @@ class Renderer:
         else:
             scales = [float(grad_scale)]
         for sc in scales:
-            B.check(self.ctx, self.lib.iblnerf_trunk_backward(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], ds.data_ptr(),
-                                                             sc, out.data_ptr(), grad.data_ptr()))
+            B.check(self.ctx, entry(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], ds.data_ptr(), sc, out.data_ptr(), grad.data_ptr()))
             if not self.out_of_range():
                 break
         else:
@@ -366,7 +378,7 @@ class Renderer:
         self.last_grad_scale = sc
         grads, off = {}, 0
         for name, o, i in ck.SCHEMA:                         # views into the device blob, reference shapes
-            if name.startswith(("positions_linears.", "sigma_linear")):
+            if name.startswith("positions_linears.") or (name.startswith("sigma_linear") and not features):
                 grads[name + ".weight"] = grad[off:off + o * i].view(o, i)
                 grads[name + ".bias"] = grad[off + o * i:off + o * i + o]
             off += o * i + o

@@ -202,6 +202,14 @@ int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const fl
 int iblnerf_trunk_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                            float grad_scale, float* d_out, float* d_grad);
 
+/* The same split one layer earlier, for callers that keep the head layers (a training step's main query, whose heads run in the
+ * caller's autograd): iblnerf_trunk_features = positions_linears.0-7 of IBLNeRF.forward (ibl_nerf.py:160-170) -> d_h7 [n_pts, 256],
+ * the post-ReLU trunk features every head reads; iblnerf_trunk_features_backward takes dL/dh7 [n_pts, 256] and returns d_out
+ * [n_pts, 4] = (sigma, dL/dpts) and the gradients of positions_linears.0-7 (sigma_linear's stay 0: that layer is the caller's). */
+int iblnerf_trunk_features(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_h7);
+int iblnerf_trunk_features_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dh7,
+                                    float grad_scale, float* d_out, float* d_grad);
+
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
 int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,

@@ -28,4 +28,6 @@ def timeit(q, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 a = timeit(torch_query)
 b = timeit(M.training_network_query_fn(torch_query))
-print("queries of one training step: all PyTorch fp32 %.1f ms; no-grad queries on the fused kernel %.1f ms (%.2fx)" % (a, b, a / b))
+c = timeit(M.training_network_query_fn(torch_query, fused_trunk_backward=True))
+print("queries of one training step: all PyTorch fp32 %.1f ms; no-grad queries on the fused kernel %.1f ms (%.2fx); "
+      "+ the trunk of the gradient-carrying queries fused, forward and backward %.1f ms (%.2fx)" % (a, b, a / b, c, a / c))

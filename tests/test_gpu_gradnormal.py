@@ -222,9 +222,28 @@ def test_fused_trunk_query_in_a_torch_training_loop(R, lut):
             assert rel_linf(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= 1e-3, k
         else:
             assert a.grad is None and b.grad is None
-    # a gradient-carrying query WITH view directions still goes to the autograd path
+    # a gradient-carrying query WITH view directions: trunk on the fused kernels, heads in torch — all 46 parameter gradients and the
+    # input gradient against torch autograd through the whole module
     dirs = torch.from_numpy(rng.uniform(-1, 1, (8, 3)).astype(np.float32)).cuda()
-    assert q(pts, dirs, nets[0]).requires_grad and len(calls) == 1
+    wts = torch.from_numpy(rng.uniform(-1, 1, (8, 64, 18)).astype(np.float32)).cuda()
+    for n in nets:
+        n.zero_grad()
+    p0, p1 = pts.clone().requires_grad_(True), pts.clone().requires_grad_(True)
+    out0, out1 = q(p0, dirs, nets[0]), torch_query(p1, dirs, nets[1])
+    assert not calls and out0.shape == out1.shape == (8, 64, 18)
+    assert float((out0 - out1).detach().abs().max()) <= 2e-5 * max(1.0, float(out1.detach().abs().max()))
+    (out0 * wts).sum().backward()
+    (out1 * wts).sum().backward()
+    assert rel_linf(p0.grad.cpu().numpy(), p1.grad.cpu().numpy()) <= 2e-3
+    n_checked = 0
+    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert rel_linf(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= 1e-3, k
+        n_checked += 1
+    assert n_checked == 46
+    plain = M.training_network_query_fn(lambda i, v, n: calls.append(1) or torch_query(i, v, n))     # without the switch: the autograd path, as before
+    assert plain(pts, dirs, nets[0]).requires_grad and len(calls) == 1
+    for n in nets:
+        n.zero_grad()
     # ten optimizer steps on each path
     opts = [torch.optim.Adam(n.parameters(), lr=5e-4) for n in nets]
     losses = [[], []]
