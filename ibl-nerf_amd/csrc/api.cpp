@@ -623,7 +623,7 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     MlpArgs a;
     a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
     a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
-    HIP_TRY(c, launch_mlp_f16x3(VAR_TRUNK_BWD, a, c->n_cu, s));
+    HIP_TRY(c, launch_mlp_f16x3(d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
     c->flop_alg += (double)n_pts * 3.0 * FLOP_TRUNK;
     w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
     w.n_gemm = 9;
@@ -631,8 +631,11 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     size_t wo[11], bo[11];
     for (int l = 0; l < 11; ++l) blob_offsets(l, &wo[l], &bo[l]);
     long part = 0;
+    const long bias_part0 = 7 * 65536L + 2 * 16384L;
     auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
-        w.gemm[k] = WgradGemm{STASH_DZ + layer, x_what, in_dim, col_base, (long)wo[layer], part};
+        const bool first_of_layer = !(layer == 5 && x_what != STASH_ENC);   // positions_linears.5 has two GEMMs: its encoding block keeps the bias
+        w.gemm[k] = WgradGemm{STASH_DZ + layer, x_what, in_dim, col_base, (long)wo[layer], part,
+                              first_of_layer ? bias_part0 + 512L * layer : -1L, (long)bo[layer]};
         part += x_what == STASH_ENC ? 16384 : 65536;
     };
     gemm(0, 0, STASH_ENC, 63, 0);
@@ -641,7 +644,6 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     gemm(6, 5, STASH_X + 4, 319, 63);
     gemm(7, 6, STASH_X + 5, 256, 0);
     gemm(8, 7, STASH_X + 6, 256, 0);
-    for (int l = 0; l < 8; ++l) w.bias_off[l] = (long)bo[l];
     w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
     HIP_TRY(c, launch_wgrad(w, d_dsigma, (long)n_pts, s));
     return arm_range_snapshot(c, s);

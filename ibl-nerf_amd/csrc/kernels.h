@@ -167,6 +167,8 @@ struct WgradGemm {
     int in_dim, col_base;    // row length of the reference's [out][in] weight, first column this GEMM fills
     long blob_off;           // the weight inside the state-dict blob
     long part_off;           // this GEMM inside one split's partial sums
+    long bias_part;          // >= 0: this GEMM also sums dZ for the layer's bias gradient: [2 lane halves][256] floats inside the split's partial sums
+    long bias_off;           // ... and where that bias sits in the blob
 };
 struct WgradArgs {
     const char* stash;
@@ -175,11 +177,10 @@ struct WgradArgs {
     long wave_groups, partial_stride;
     int n_split, n_gemm;
     WgradGemm gemm[9];
-    long bias_off[8];        // positions_linears.l.bias
     long sigma_w_off, sigma_b_off;
     float unscale;           // 1 / MlpArgs::grad_scale
 };
-constexpr long WGRAD_PARTIAL_FLOATS = 7 * 65536L + 2 * 16384L;
+constexpr long WGRAD_PARTIAL_FLOATS = 7 * 65536L + 2 * 16384L + 8 * 512L;
 hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s);
 
 }  // namespace ibl

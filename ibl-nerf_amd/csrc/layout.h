@@ -136,7 +136,8 @@ enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_R
                VAR_TRUNK_X = 5,     // fast kernel only: TRUNK with its first two layers as three f16 products (layout_mx.h)
                VAR_TRUNK_GRAD = 6,    // three-product kernels only: TRUNK forward + its backward chain, out = [sigma, d sigma / d x, y, z]
                VAR_TRUNK_BWD = 7,     // ... with an upstream gradient per point, and the operands of the weight gradient stashed (STASH_*)
-               VAR_TRUNK_FEAT = 8 };  // f16x3 kernel only: TRUNK forward whose output is the 256 trunk features h7 (fp32 rows), not sigma
+               VAR_TRUNK_FEAT = 8,    // f16x3 kernel only: TRUNK forward whose output is the 256 trunk features h7 (fp32 rows), not sigma
+               VAR_TRUNK_BWD_FEAT = 9 };  // VAR_TRUNK_BWD with the upstream gradient given on those features (dL/dh7 rows) instead of on sigma
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

@@ -82,7 +82,7 @@ __device__ long long g_trace[256];
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr int N_PROG = (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
+    static constexpr int N_PROG = (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
                                   : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
@@ -100,7 +100,7 @@ struct Pipe {
     __device__ __forceinline__ static int stream_chunk(int p) {
         if (p < N_CHUNKS_TRUNK) return p;
         int q = p - N_CHUNKS_TRUNK;
-        if (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) return CH_G7 + q;   // the backward stream follows the trunk
+        if (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) return CH_G7 + q;   // the backward stream follows the trunk
         if (!CI) { if (q < 8) return CH_FEAT + q; q -= 8; }
         if (ALBIRR) { if (q < 8) return CH_ALB + q; q -= 8; }
         if (!CI) { if (q < 9) return CH_VIEW + q; q -= 9; }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     // side tables -> LDS once per workgroup
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
-    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD)
+    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT)
         if (threadIdx.x < 32) reinterpret_cast<float*>(smem + MASK_ZERO_OFF)[threadIdx.x] = 0.0f;
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
@@ -525,13 +525,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
-        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) {
+        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) {
             // ---- density and its gradient with respect to the position: the trunk forward with every ReLU's pass bits
             // recorded, then the backward chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on the transposed stream (what autograd
             // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts).
             // VAR_TRUNK_BWD: dZ(7) carries the caller's dL / d sigma, and every layer's input and dZ fragments go to the stash
             // the weight-gradient kernel reads (train.py:479-481's backward through the trunk) ----
-            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD;
+            constexpr bool ROWS = VARIANT == VAR_TRUNK_BWD_FEAT;   // upstream gradient = dL/dh7 rows
+            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD || ROWS;
             constexpr int MK = BWD ? 2 : 1;
             char* mbase = smem + MASK_OFF + wave * 8192 + lane * 2;   // + 1024 * layer + 128 * tile
             const float* zero = reinterpret_cast<const float*>(smem + MASK_ZERO_OFF) + h * 16;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
             float up = 1.0f;                                   // dL / d sigma of this point (invalid points: 0, they add nothing to any gradient)
-            if constexpr (BWD) up = (valid && a.dsigma != nullptr) ? a.dsigma[p] * a.grad_scale : 0.0f;
+            if constexpr (BWD && !ROWS) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
 
             // dZ(7) = dL/dsigma * sigma_linear.weight * bits(7) -> A
             static_for<0, 8>([&](auto T) {
@@ -572,9 +573,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                     constexpr int q = decltype(Q)::value;
                     u32x4 hv, lv;
                     float wv[8];   // dL / d h7 of accumulator registers 8q .. 8q+7 = features 32t + 16q + 4h + {0..3, 8..11}
-                    bool from_rows = false;
-                    if constexpr (BWD) from_rows = a.dh7 != nullptr;
-                    if (from_rows) {
+                    if constexpr (ROWS) {
                         const float* row = a.dh7 + (size_t)(valid ? p : 0) * 256 + 32 * t + 16 * q + 4 * h;
                         const f32x4 r0 = *reinterpret_cast<const f32x4*>(row), r1 = *reinterpret_cast<const f32x4*>(row + 8);
                         const float sc_ = valid ? a.grad_scale : 0.0f;
@@ -635,7 +634,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             if (!h) g3[1] += genc[2 * PE_PAIRS_PER_HALF + 1];
 #pragma unroll
             for (int c = 0; c < 3; ++c) g3[c] += __shfl_xor(g3[c], 32);
-            if constexpr (VARIANT == VAR_TRUNK_BWD) {
+            if constexpr (BWD) {
                 const float inv = 1.0f / a.grad_scale;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) g3[c] *= inv;
@@ -820,10 +819,10 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
+                                  (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
 #define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
@@ -842,11 +841,13 @@ IBL_DEFINE_LAUNCH(6)
 IBL_DEFINE_LAUNCH(7)
 #elif IBL_VARIANT == 8
 IBL_DEFINE_LAUNCH(8)
+#elif IBL_VARIANT == 9
+IBL_DEFINE_LAUNCH(9)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8) IBL_DEFINE_LAUNCH(9)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -860,6 +861,7 @@ hipError_t IBL_LAUNCH_NAME(6)(const MlpArgs&, int, hipStream_t);
 #ifdef IBL_F16X3
 hipError_t IBL_LAUNCH_NAME(7)(const MlpArgs&, int, hipStream_t);   // (the stash is f16: this flavour only)
 hipError_t IBL_LAUNCH_NAME(8)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(9)(const MlpArgs&, int, hipStream_t);
 #endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
@@ -876,6 +878,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
 #ifdef IBL_F16X3
         case VAR_TRUNK_BWD: rc = IBL_LAUNCH_NAME(7)(a, grid, stream); break;
         case VAR_TRUNK_FEAT: rc = IBL_LAUNCH_NAME(8)(a, grid, stream); break;
+        case VAR_TRUNK_BWD_FEAT: rc = IBL_LAUNCH_NAME(9)(a, grid, stream); break;
 #endif
         default: return hipErrorInvalidValue;
     }

@@ -79,6 +79,12 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm&
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) C[m][n] = f32x16{0};
+    // db(l) = sum_p dZ(l)[p]: the transposed dZ tiles have feature m in lane m and 16 of the 32 points in its registers, so the bias
+    // gradient is a by-product (one wave column per layer keeps it: gm.bias_part >= 0 and this wave's first column tile is 0)
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bsum[m] = 0.0f;
+    const bool keeps_bias = gm.bias_part >= 0 && nt0 == 0;
 
     const long per = (a.wave_groups + a.n_split - 1) / a.n_split;
     const long g0 = split * per, g1 = g0 + per < a.wave_groups ? g0 + per : a.wave_groups;
@@ -112,6 +118,15 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm&
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) to_operands(d[m], A[m]);
+            if (keeps_bias) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += d[m][r];
+                    bsum[m] += t;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -131,6 +146,10 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm&
         for (int m = 0; m < MT; ++m) { fz[m][0] = nz[m][0]; fz[m][1] = nz[m][1]; }
 #pragma unroll
         for (int n = 0; n < NT; ++n) { fx[n][0] = nx[n][0]; fx[n][1] = nx[n][1]; }
+    }
+    if (keeps_bias) {   // lane (i, h) holds feature 32(mt0 + m) + i for the points of its half: the halves are added by the reduce kernel
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a.partial[(size_t)split * a.partial_stride + gm.bias_part + h * 256 + 32 * (mt0 + m) + i] = bsum[m];
     }
     // partial[split][gemm]: [256 rows][ncols]; accumulator register r of lane (i, h) = row (r&3) + 8(r>>2) + 4h, column i of its tile
     float* part = a.partial + (size_t)split * a.partial_stride + gm.part_off;
@@ -170,12 +189,20 @@ __global__ void k_wgrad_reduce(WgradArgs a) {
     float acc = 0.0f;
     for (int s = 0; s < a.n_split; ++s) acc += a.partial[(size_t)s * a.partial_stride + gm.part_off + idx];
     a.grad[gm.blob_off + (size_t)m * gm.in_dim + gm.col_base + col] = acc * a.unscale;
+    if (gm.bias_part >= 0 && n == 0) {      // the layer's bias gradient: both lane halves of every split
+        float b = 0.0f;
+        for (int s = 0; s < a.n_split; ++s) {
+            const float* bp = a.partial + (size_t)s * a.partial_stride + gm.bias_part;
+            b += bp[m] + bp[256 + m];
+        }
+        a.grad[gm.bias_off + m] = b * a.unscale;
+    }
 }
 
-// db(l) = sum_p dZ(l)[p], d sigma_linear.weight = sum_p dL/dsigma[p] X(7)[p], d sigma_linear.bias = sum_p dL/dsigma[p].
-// block = (what: 8 dZ layers + the head, quarter of the 16 k-steps); thread = (k-step, lane) of the fragment layout; grid.y splits the groups.
-__global__ __launch_bounds__(256) void k_bias_grad(WgradArgs a, const float* __restrict__ dsigma, long n_pts) {
-    const int what = blockIdx.x >> 2, jq = blockIdx.x & 3;
+// d sigma_linear.weight = sum_p dL/dsigma[p] X(7)[p], d sigma_linear.bias = sum_p dL/dsigma[p]  (the biases of the trunk layers come out of
+// k_wgrad).  block = quarter of the 16 k-steps; thread = (k-step, lane) of the fragment layout; grid.y splits the groups.
+__global__ __launch_bounds__(256) void k_head_grad(WgradArgs a, const float* __restrict__ dsigma, long n_pts) {
+    const int what = 8, jq = blockIdx.x & 3;
     const int lane = threadIdx.x & 63, j = 4 * jq + (threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
     const bool head = what == 8;
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(256) void k_bias_grad(WgradArgs a, const float* __r
         accb += __shfl_xor(accb, m);
     }
     if (i == 0) {
-        float* dst = a.grad + (head ? a.sigma_w_off : a.bias_off[what]);
+        float* dst = a.grad + a.sigma_w_off;
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(dst + 32 * (j >> 1) + acc_feature(8 * (j & 1) + e, h), acc[e]);
         if (head && j == 0 && h == 0) atomicAdd(a.grad + a.sigma_b_off, accb);
@@ -213,7 +240,7 @@ __global__ __launch_bounds__(256) void k_bias_grad(WgradArgs a, const float* __r
 hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_gemm, a.n_split), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(256, a.n_gemm), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bias_grad, dim3(9 * 4, 64), dim3(256), 0, s, a, dsigma, n_pts);
+    if (dsigma != nullptr) hipLaunchKernelGGL(k_head_grad, dim3(4, 64), dim3(256), 0, s, a, dsigma, n_pts);
     return hipGetLastError();
 }
 
