@@ -21,6 +21,7 @@ def q6(a, block=32):
 HEADS = ("sigma_linear", "roughness_linear", "albedo_linear", "irradiance_linear", "radiance_linear", "additional_radiance_linear")
 FAST = False
 PRECISE = set()
+PLAIN_ALL = False     # the fast query runs the f16 main product alone (2^-11): what a 4-slot f16 block would compute
 def lin(sd, name, x):
     W, b = sd[name + ".weight"], sd[name + ".bias"]
     if name.startswith(HEADS): return (x @ W.T + b).astype(np.float32)
@@ -29,12 +30,15 @@ def lin(sd, name, x):
     if not FAST or name in PRECISE:
         Wl, Xl = f16(W - Wh), f16(x - Xh)
         return (x64(Xh) @ x64(Wh).T + x64(Xl) @ x64(Wh).T + x64(Xh) @ x64(Wl).T + b).astype(np.float32)
+    if PLAIN_ALL and CURRENT_IS_FINE_MAIN[0]:
+        return (x64(Xh) @ x64(Wh).T + b).astype(np.float32)
     Wl, Xl = W - Wh, x - Xh
     return (x64(Xh) @ x64(Wh).T + q6(Xl) @ q6(Wh).T + q6(Xh) @ q6(Wl).T + b).astype(np.float32)
 O._lin = lin
 _nq = O.network_query
 L = ["positions_linears.%d" % i for i in range(8)]
 N_DIR, N_OFF = [0], [0]
+CURRENT_IS_FINE_MAIN = [False]
 MAIN_PRECISE = None      # None: fine main query in f16x3; else the set of its precise layers
 def network_query(sd, pts, viewdirs):
     global FAST, PRECISE
@@ -44,20 +48,23 @@ def network_query(sd, pts, viewdirs):
     else:
         N_DIR[0] += 1
         q = (N_DIR[0] - 1) % 4                                   # 0 coarse main, 1 coarse reflected, 2 fine main, 3 fine reflected
+        CURRENT_IS_FINE_MAIN[0] = q == 2
         if q in (1, 3): FAST, PRECISE = True, set()
         elif q == 2 and MAIN_PRECISE is not None: FAST, PRECISE = True, MAIN_PRECISE
         else: FAST = False
     out = _nq(sd, pts, viewdirs)
     FAST = False
+    CURRENT_IS_FINE_MAIN[0] = False
     return out
 O.network_query = network_query
 
 g, sdc, sdf, gt, edit = load_golden("fitted_wide")
-rsel = np.load("gpurun_out/worst_rays_direct.npy")[:int(sys.argv[1]) if len(sys.argv) > 1 else 64]
+rsel = np.load("gpurun_out/worst_rays_direct.npy")[:int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64]
 lut = load_lut_rgb()
 KEYS = ["depth_map", "weights", "albedo_map", "roughness_map", "irradiance_map", "radiance_map", "radiance_map_3", "target_normal_map"]
-for label, sel in (("fine main f16x3 (default)", None), ("fine main fast, L0-1 precise", set(L[:2])), ("L0-2", set(L[:3])), ("L0-3", set(L[:4])), ("all fast", set())):
-    MAIN_PRECISE = sel; N_DIR[0] = 0; N_OFF[0] = 0
+for label, sel, plain in (("fine main all fast (shipped)", set(), False), ("fine main plain f16 (2^-11)", set(), True)) if "--plain" in sys.argv else \
+        tuple((a, b, False) for a, b in (("fine main f16x3", None), ("fine main fast, L0-1 precise", set(L[:2])), ("L0-2", set(L[:3])), ("L0-3", set(L[:4])), ("all fast (shipped)", set()))):
+    MAIN_PRECISE = sel; PLAIN_ALL = plain; N_DIR[0] = 0; N_OFF[0] = 0
     res = O.render_rays(sdc, sdf, g["rays_o"][rsel], g["rays_d"][rsel], 0.5, 8.0, lut)
     out = []
     for k in KEYS:
