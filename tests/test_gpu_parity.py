@@ -469,7 +469,7 @@ def test_render_decomp_from_gt_flags(R, lut):
                         calculate_albedo_from_gt=True)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("prec", PRECISIONS + ["f16_mixed"])
 def test_repeated_launches_are_bit_identical(R, lut, prec):
     """Race detector for the hand-counted LDS-DMA pipeline (ring slots are reused every third chunk, guarded only by
     vmcnt arithmetic and one barrier per chunk): the same 1.6 M points through all 256 persistent workgroups five times
@@ -603,7 +603,7 @@ def test_infer_normal_drop_in(R, lut, tmp_path):
         R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("prec", PRECISIONS + ["f16_mixed"])
 def test_degenerate_density_rays_match_the_oracle(R, lut, prec):
     """Rays the reference's arithmetic degenerates on: an empty volume (every sigma <= 0: weights 0, acc 0, depth/acc = 0/0, so
     disp_map is NaN through torch.max, ibl_nerf_renderer.py:258; flat fine-sample pdf) and a wall at the first sample (sigma
