@@ -21,10 +21,11 @@ and the two other layouts `load_dataset` knows (dataset_interface.py:316-331):
                   image sets for the metric scripts, no cameras
 
 Images are decoded with PIL as 8-bit RGB / 255 (the reference's cv2.imread + BGR->RGB yields the same
-array for 8-bit PNGs; alpha is dropped by both).  `image_scale`: 1 and 0.5 (the value of configs/real/) are
-built; 0.5 follows cv2.resize's documented INTER_LINEAR behaviour for an exact 2x reduction (a 2x2 box mean,
+array for 8-bit PNGs; alpha is dropped by both).  `image_scale`: 1 and 0.5 (the value of configs/real/) follow the shipped configs; any
+other scale goes through `resize_linear`, OpenCV's general bilinear path restated from its published algorithm (unpinned: no cv2 here);
+0.5 follows cv2.resize's documented INTER_LINEAR behaviour for an exact 2x reduction (a 2x2 box mean,
 rounded half up for 8-bit data) — cv2 is not in this image, so that one step is restated from OpenCV's source
-and NOT pinned by a run; other factors raise.  The prior images used only by the training losses are not
+and NOT pinned by a run.  The prior images used only by the training losses are not
 built: they raise.  Nothing here touches the GPU until `to_tensor`."""
 from __future__ import annotations
 
@@ -47,12 +48,59 @@ def resize_half(a):
     return (cells.astype(np.float32).sum(axis=(1, 3)) * np.float32(0.25)).astype(a.dtype)
 
 
+def _round_half_even(x):
+    return int(np.rint(x))
+
+
+def resize_linear(a, scale):
+    """cv2.resize(a, None, fx=scale, fy=scale) with the default INTER_LINEAR for any other scale, restated from OpenCV's published
+    algorithm (imgproc/resize.cpp: dsize = round(size * scale); source coordinate (d + 0.5) / scale - 0.5 in float, floor + fraction,
+    the fraction zeroed where the tap leaves the image on the x axis, rows replicated on the y axis; 8-bit images in fixed point:
+    coefficients rounded to 1/2048, horizontal pass in int32, vertical pass ((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2;
+    float images in float).  UNPINNED: the build image has no cv2 to run against — no shipped config uses such a scale
+    (all use 1, configs/real 0.5)."""
+    h, w = a.shape[:2]
+    dw, dh = _round_half_even(w * scale), _round_half_even(h * scale)
+    if dw < 1 or dh < 1:
+        raise ValueError("image_scale %r leaves no pixels of a %dx%d image" % (scale, w, h))
+    inv = 1.0 / scale
+
+    def taps(n_dst, n_src, zero_frac_at_border):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * inv - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if zero_frac_at_border:
+            lo, hi = s < 0, s >= n_src - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+        return s, f
+
+    sx, fx = taps(dw, w, True)
+    sy, fy = taps(dh, h, False)
+    clip = lambda v, n: np.clip(v, 0, n - 1)
+    x0, x1 = sx, clip(sx + 1, w)
+    y0, y1 = clip(sy, h), clip(sy + 1, h)
+    src = a.reshape(h, w, -1)
+    if a.dtype == np.uint8:
+        q = lambda c: np.clip(np.rint(c.astype(np.float32) * np.float32(2048)), -32768, 32767).astype(np.int64)
+        a0, a1, b0, b1 = q(1 - fx), q(fx), q(1 - fy), q(fy)
+        s64 = src.astype(np.int64)
+        rows = s64[:, x0] * a0[None, :, None] + s64[:, x1] * a1[None, :, None]              # [h, dw, c], scaled by 2048
+        out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+        out = np.clip(out, 0, 255).astype(np.uint8)
+    else:
+        s32 = src.astype(np.float32)
+        rows = s32[:, x0] * (1 - fx)[None, :, None] + s32[:, x1] * fx[None, :, None]
+        out = (rows[y0] * (1 - fy)[:, None, None] + rows[y1] * fy[:, None, None]).astype(a.dtype)
+    return out.reshape((dh, dw) + a.shape[2:])
+
+
 def _scaled(a, scale):
     if scale == 1:
         return a
-    if scale == 0.5:
-        return resize_half(a)
-    raise NotImplementedError("image_scale %r: only 1 and 0.5 (configs/real) are built" % (scale,))
+    if scale == 0.5 and a.shape[0] % 2 == 0 and a.shape[1] % 2 == 0:
+        return resize_half(a)                    # the exact 2x reduction: OpenCV's area fast path
+    return resize_linear(a, scale)
 
 
 def load_image_from_path(path, scale=1):

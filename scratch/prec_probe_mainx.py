@@ -24,7 +24,7 @@ PRECISE = set()
 PLAIN_ALL = False     # the fast query runs the f16 main product alone (2^-11): what a 4-slot f16 block would compute
 def lin(sd, name, x):
     W, b = sd[name + ".weight"], sd[name + ".bias"]
-    if name.startswith(HEADS): return (x @ W.T + b).astype(np.float32)
+    if name.startswith(HEADS) and not (HEADS_FAST and (CURRENT_IS_FINE_MAIN[0] or CURRENT_IS_REFL[0])): return (x @ W.T + b).astype(np.float32)
     x64 = lambda a: a.astype(np.float64)
     Wh, Xh = f16(W), f16(x)
     if not FAST or name in PRECISE:
@@ -39,6 +39,8 @@ _nq = O.network_query
 L = ["positions_linears.%d" % i for i in range(8)]
 N_DIR, N_OFF = [0], [0]
 CURRENT_IS_FINE_MAIN = [False]
+CURRENT_IS_REFL = [False]
+HEADS_FAST = "--heads" in sys.argv      # the N = 1/3 head products of the fast queries on the matrix core too (f16 + fp6 forms of their input)
 MAIN_PRECISE = None      # None: fine main query in f16x3; else the set of its precise layers
 def network_query(sd, pts, viewdirs):
     global FAST, PRECISE
@@ -49,12 +51,14 @@ def network_query(sd, pts, viewdirs):
         N_DIR[0] += 1
         q = (N_DIR[0] - 1) % 4                                   # 0 coarse main, 1 coarse reflected, 2 fine main, 3 fine reflected
         CURRENT_IS_FINE_MAIN[0] = q == 2
+        CURRENT_IS_REFL[0] = q in (1, 3)
         if q in (1, 3): FAST, PRECISE = True, set()
         elif q == 2 and MAIN_PRECISE is not None: FAST, PRECISE = True, MAIN_PRECISE
         else: FAST = False
     out = _nq(sd, pts, viewdirs)
     FAST = False
     CURRENT_IS_FINE_MAIN[0] = False
+    CURRENT_IS_REFL[0] = False
     return out
 O.network_query = network_query
 
@@ -63,6 +67,7 @@ rsel = np.load("gpurun_out/worst_rays_direct.npy")[:int(sys.argv[1]) if len(sys.
 lut = load_lut_rgb()
 KEYS = ["depth_map", "weights", "albedo_map", "roughness_map", "irradiance_map", "radiance_map", "radiance_map_3", "target_normal_map"]
 for label, sel, plain in (("fine main all fast (shipped)", set(), False), ("fine main plain f16 (2^-11)", set(), True)) if "--plain" in sys.argv else \
+        (("fine main + reflected: heads on the matrix core too", set(), False),) if HEADS_FAST else \
         tuple((a, b, False) for a, b in (("fine main f16x3", None), ("fine main fast, L0-1 precise", set(L[:2])), ("L0-2", set(L[:3])), ("L0-3", set(L[:4])), ("all fast (shipped)", set()))):
     MAIN_PRECISE = sel; PLAIN_ALL = plain; N_DIR[0] = 0; N_OFF[0] = 0
     res = O.render_rays(sdc, sdf, g["rays_o"][rsel], g["rays_d"][rsel], 0.5, 8.0, lut)

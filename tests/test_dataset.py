@@ -97,8 +97,8 @@ def test_reader_plain(scene):
     assert DS.load_dataset("mitsuba", str(root), split="train", skip=5).skip == 1     # :30-32
     with pytest.raises(ValueError):
         DS.load_dataset("blender", str(root))
-    with pytest.raises(NotImplementedError):
-        DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.25)[0]
+    quarter = DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.25)    # any other scale: OpenCV's general bilinear path
+    assert quarter[0]["image"].shape == (int(np.rint(H * 0.25)), int(np.rint(W * 0.25)), 3) and abs(quarter.focal - f / 4) < 1e-12
     half = DS.load_dataset("mitsuba", str(root), split="test", image_scale=0.5)        # configs/real use 0.5
     assert (half.height, half.width) == (H // 2, W // 2) and abs(half.focal - f / 2) < 1e-12
     a = truth[1][""].astype(np.uint32)                                                 # 2x2 cell mean, rounded half up
@@ -280,3 +280,31 @@ def test_reader_matches_the_reference_reader(scene):
             assert np.asarray(v).shape == want.shape and np.array_equal(np.asarray(v), want), (mode, k)
             seen.add("%s__%s" % (mode, k))
     assert seen == set(g.files)
+
+
+def test_resize_linear_known_answers():
+    """dataset.resize_linear = cv2.resize(..., INTER_LINEAR) for scales other than 1 and an exact 1/2, restated from OpenCV's algorithm
+    (no cv2 in this image: UNPINNED by a run; these are the algorithm's own invariants and two hand-computed cases)."""
+    from ibl_nerf_amd import dataset as DS
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (12, 16, 3)).astype(np.uint8)
+    const = np.full((9, 7, 3), 173, np.uint8)
+    for scale in (0.25, 0.75, 1.5, 2.0, 3.0):
+        out = DS.resize_linear(img, scale)
+        assert out.dtype == np.uint8 and out.shape == (int(np.rint(12 * scale)), int(np.rint(16 * scale)), 3)
+        assert np.array_equal(DS.resize_linear(const, scale), np.full((int(np.rint(9 * scale)), int(np.rint(7 * scale)), 3), 173, np.uint8))
+        f32 = DS.resize_linear(img[..., 0].astype(np.float32), scale)                  # depth maps: float arithmetic
+        assert f32.dtype == np.float32 and f32.shape == out.shape[:2]
+        assert np.abs(f32 - out[..., 0]).max() <= 1.0                                  # fixed point against float: within one level
+        assert f32.min() >= img[..., 0].min() and f32.max() <= img[..., 0].max()       # a convex combination of the source
+    # 2x upscale of one row [0, 255]: destination centres 0.25 / 0.75 pixel apart from the source centres; the first and last tap leave
+    # the image (fraction zeroed): [0, 0.25*255, 0.75*255, 255] -> fixed point: (0*1536 + 255*512)/2048 = 63.75 -> 64, 191.25 -> 191
+    row = np.array([[0, 255]], np.uint8)
+    assert DS.resize_linear(row, 2.0).tolist() == [[0, 64, 191, 255], [0, 64, 191, 255]]
+    assert np.allclose(DS.resize_linear(row.astype(np.float32), 2.0), [[0, 63.75, 191.25, 255]] * 2)
+    # 4x reduction samples between source pixels 1 and 2 of every four (centre (d + 0.5) * 4 - 0.5 = 4d + 1.5): their mean
+    ramp = np.arange(16, dtype=np.float32)[None, :].repeat(4, 0)
+    assert np.allclose(DS.resize_linear(ramp, 0.25), [[1.5, 5.5, 9.5, 13.5]])
+    assert DS.resize_linear(ramp.astype(np.uint8), 0.25).tolist() == [[2, 6, 10, 14]]     # x.5 -> (.. + 2) >> 2 rounds half up
+    with pytest.raises(ValueError):
+        DS.resize_linear(row, 0.1)
