@@ -569,8 +569,39 @@ int iblnerf_trunk_features(iblnerf_ctx* c, void* stream, int which, const float*
     return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
+int iblnerf_trunk_features2(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples, const float* d_viewdirs,
+                            float* d_h7, float* d_h2) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_pts || !d_viewdirs || !d_h7 || !d_h2)))
+        return c->fail(IBLNERF_ERR_INVALID, "trunk_features2: bad arguments");
+    if (n_rays == 0) return IBLNERF_OK;
+    const long n_pts = (long)n_rays * n_samples;
+    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "trunk_features2: more than 2^31 points");
+    if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "trunk_features2: a colour-independent network has no feature / view layers");
+    if (!c->have_net[which]) return c->fail(IBLNERF_ERR_STATE, "trunk_features2: weights of network %d not uploaded", which);
+    if (!c->d_stream_f16[which] || !c->mx_ok[which])
+        return c->fail(IBLNERF_ERR_STATE, "trunk_features2: needs an mlp_precision that keeps the f16x3 stream (f16x3*) and weights inside the f16 range");
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    MlpArgs a;
+    a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = d_viewdirs; a.out = d_h7; a.out2 = d_h2; a.out_stride = 256;
+    a.n_pts = n_pts; a.pts_per_ray = n_samples; a.range_flag = c->d_range_flag;
+    HIP_TRY(c, launch_mlp_f16x3(VAR_TRUNK_FEAT2, a, c->n_cu, (hipStream_t)stream));
+    c->flop_alg += (double)n_pts * (FLOP_TRUNK + FLOP_FEAT_VIEW);
+    return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
 static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
-                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad);
+                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad, const float* d_dirs = nullptr,
+                               int pts_per_ray = 1, const float* d_dh2 = nullptr);
+
+int iblnerf_trunk_features2_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                                     const float* d_viewdirs, const float* d_dh7, const float* d_dh2, float grad_scale, float* d_out, float* d_grad) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_viewdirs || !d_dh7 || !d_dh2)))
+        return c->fail(IBLNERF_ERR_INVALID, "trunk_features2_backward: bad arguments");
+    if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "trunk_features2_backward: a colour-independent network has no feature / view layers");
+    return trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, d_dh7, grad_scale, d_out, d_grad, d_viewdirs, n_samples, d_dh2);
+}
 
 int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                            float grad_scale, float* d_out, float* d_grad) {
@@ -587,7 +618,8 @@ int iblnerf_trunk_features_backward(iblnerf_ctx* c, void* stream, int which, con
 }
 
 static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
-                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad) {
+                               const float* d_dh7, float grad_scale, float* d_out, float* d_grad, const float* d_dirs, int pts_per_ray,
+                               const float* d_dh2) {
     if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)) || !d_grad)
         return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
     int gs_exp = 0;
@@ -622,21 +654,29 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     }
     MlpArgs a;
     a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
-    a.n_pts = n_pts; a.pts_per_ray = 1; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
-    HIP_TRY(c, launch_mlp_f16x3(d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
-    c->flop_alg += (double)n_pts * 3.0 * FLOP_TRUNK;
+    a.n_pts = n_pts; a.pts_per_ray = pts_per_ray; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
+    a.dirs = d_dirs; a.dh2 = d_dh2;
+    const bool feat2 = d_dh2 != nullptr;
+    HIP_TRY(c, launch_mlp_f16x3(feat2 ? VAR_TRUNK_BWD_FEAT2 : d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
+    c->flop_alg += (double)n_pts * 3.0 * (FLOP_TRUNK + (feat2 ? FLOP_FEAT_VIEW : 0.0));
     w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
-    w.n_gemm = 9;
+    w.n_gemm = feat2 ? 12 : 9;
     w.unscale = 1.0f / grad_scale;
     size_t wo[11], bo[11];
     for (int l = 0; l < 11; ++l) blob_offsets(l, &wo[l], &bo[l]);
     long part = 0;
-    const long bias_part0 = 7 * 65536L + 2 * 16384L;
+    const long bias_part0 = 9 * 65536L + 2 * 16384L + 8192L;
+    int n_bias = 0;
+    // (k, blob layer, dZ stash, input stash, row length, first column, keeps the layer's bias)
+    auto gemm_ = [&](int k, int layer, int dz_what, int x_what, int in_dim, int col_base, bool bias) {
+        const int ncols = x_what == STASH_ENC ? 64 : x_what == STASH_DENC ? 32 : 256;
+        w.gemm[k] = WgradGemm{dz_what, x_what, ncols, x_what == STASH_ENC ? PE_PAIRS_PER_HALF : x_what == STASH_DENC ? DE_PAIRS_PER_HALF : 0, in_dim, col_base,
+                              (long)wo[layer], part, bias ? bias_part0 + 512L * n_bias : -1L, (long)bo[layer]};
+        if (bias) ++n_bias;
+        part += 256L * ncols;
+    };
     auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
-        const bool first_of_layer = !(layer == 5 && x_what != STASH_ENC);   // positions_linears.5 has two GEMMs: its encoding block keeps the bias
-        w.gemm[k] = WgradGemm{STASH_DZ + layer, x_what, in_dim, col_base, (long)wo[layer], part,
-                              first_of_layer ? bias_part0 + 512L * layer : -1L, (long)bo[layer]};
-        part += x_what == STASH_ENC ? 16384 : 65536;
+        gemm_(k, layer, STASH_DZ + layer, x_what, in_dim, col_base, !(layer == 5 && x_what != STASH_ENC));   // positions_linears.5: its encoding block keeps the bias
     };
     gemm(0, 0, STASH_ENC, 63, 0);
     for (int l = 1; l <= 4; ++l) gemm(l, l, STASH_X + l - 1, 256, 0);
@@ -644,6 +684,11 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     gemm(6, 5, STASH_X + 4, 319, 63);
     gemm(7, 6, STASH_X + 5, 256, 0);
     gemm(8, 7, STASH_X + 6, 256, 0);
+    if (feat2) {   // blob layers 8 = views_linears.0 ([feature256 | dir27], ibl_nerf.py:194), 9 = feature_linear
+        gemm_(9, 9, STASH_DZF, STASH_X + 7, 256, 0, true);
+        gemm_(10, 8, STASH_DZV, STASH_XF, 283, 0, true);
+        gemm_(11, 8, STASH_DZV, STASH_DENC, 283, 256, false);
+    }
     w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
     HIP_TRY(c, launch_wgrad(w, d_dsigma, (long)n_pts, s));
     return arm_range_snapshot(c, s);

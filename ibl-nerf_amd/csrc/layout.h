@@ -60,10 +60,14 @@ constexpr int CH_G5 = 113;   // positions_linears.5^T      8 + 2       10
 constexpr int CH_G4 = 123;   // positions_linears.4..1^T   8           8 each (123..154)
 constexpr int CH_G0 = 155;   // positions_linears.0^T      2           2
 constexpr int N_CHUNKS_GRAD = 60;
-constexpr int N_CHUNKS = N_CHUNKS_NET + N_CHUNKS_GRAD;   // 157
+// ... and of the two 256-wide head layers between the trunk and the view-dependent heads (VAR_TRUNK_BWD_FEAT2):
+constexpr int CH_GV = 157;   // views_linears.0^T, its 256 feature columns (the direction columns carry no gradient)   8   8
+constexpr int CH_GF = 165;   // feature_linear^T                                                                     8   8
+constexpr int N_CHUNKS_GRAD2 = 16;
+constexpr int N_CHUNKS = N_CHUNKS_NET + N_CHUNKS_GRAD + N_CHUNKS_GRAD2;   // 173
 constexpr int PE_KSTEPS = 4;   // 64 slots, 63 used
 constexpr int DE_KSTEPS = 2;   // 32 slots, 27 used
-constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 4.9 MiB per network
+constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 5.4 MiB per network
 
 // fp32 side tables (biases in accumulator-lane layout + the tiny N=1/3 heads that run on the VALU)
 // Lane-layout entry [tile][h][r] holds the value for feature 32*tile_local + (r&3) + 8*(r>>2) + 4h.
@@ -94,12 +98,17 @@ constexpr int LDS_BYTES = LDS_RING_BYTES + TAB_BYTES;      // 123 008 B
 //   [STASH_X  + layer l][wave group]  post-ReLU output of positions_linears.l   (16 KiB each)
 //   [STASH_DZ + layer l][wave group]  dL / d pre-activation of positions_linears.l
 //   [STASH_ENC][wave group]           the encoding's 4 k-steps (4 KiB each; slot order of enc_ref_index)
-constexpr int STASH_X = 0, STASH_DZ = 8, STASH_ENC = 16;
+//   VAR_TRUNK_BWD_FEAT2 adds  [STASH_XF] feature_linear's output (views_linears.0's input), [STASH_DZV] / [STASH_DZF] dL / d pre-activation
+//   of views_linears.0 / feature_linear, and [STASH_DENC] the direction encoding's 2 k-steps (2 KiB each)
+constexpr int STASH_X = 0, STASH_DZ = 8, STASH_XF = 16, STASH_DZV = 17, STASH_DZF = 18, STASH_N_ACT = 19, STASH_ENC = 19, STASH_DENC = 20;
 constexpr long STASH_ACT_BYTES = 16 * 1024;   // per wave group and activation
 constexpr long STASH_ENC_BYTES = 4 * 1024;
-__host__ __device__ constexpr long stash_bytes(long wave_groups) { return wave_groups * (16 * STASH_ACT_BYTES + STASH_ENC_BYTES); }
+constexpr long STASH_DENC_BYTES = 2 * 1024;
+__host__ __device__ constexpr long stash_bytes(long wave_groups) { return wave_groups * (STASH_N_ACT * STASH_ACT_BYTES + STASH_ENC_BYTES + STASH_DENC_BYTES); }
 __host__ __device__ constexpr long stash_offset(int what, long wave_groups, long wg) {
-    return what < STASH_ENC ? (what * wave_groups + wg) * STASH_ACT_BYTES : 16 * wave_groups * STASH_ACT_BYTES + wg * STASH_ENC_BYTES;
+    return what < STASH_N_ACT ? (what * wave_groups + wg) * STASH_ACT_BYTES
+           : what == STASH_ENC ? STASH_N_ACT * wave_groups * STASH_ACT_BYTES + wg * STASH_ENC_BYTES
+                               : wave_groups * (STASH_N_ACT * STASH_ACT_BYTES + STASH_ENC_BYTES) + wg * STASH_DENC_BYTES;
 }
 
 // feature held by accumulator register r of lane-half h (tile-local, 0..31)
@@ -137,7 +146,9 @@ enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_R
                VAR_TRUNK_GRAD = 6,    // three-product kernels only: TRUNK forward + its backward chain, out = [sigma, d sigma / d x, y, z]
                VAR_TRUNK_BWD = 7,     // ... with an upstream gradient per point, and the operands of the weight gradient stashed (STASH_*)
                VAR_TRUNK_FEAT = 8,    // f16x3 kernel only: TRUNK forward whose output is the 256 trunk features h7 (fp32 rows), not sigma
-               VAR_TRUNK_BWD_FEAT = 9 };  // VAR_TRUNK_BWD with the upstream gradient given on those features (dL/dh7 rows) instead of on sigma
+               VAR_TRUNK_BWD_FEAT = 9,    // VAR_TRUNK_BWD with the upstream gradient given on those features (dL/dh7 rows) instead of on sigma
+               VAR_TRUNK_FEAT2 = 10,      // ... one layer pair further: outputs h7 AND h2 = relu(views_linears.0([feature_linear(h7), dir27])) rows
+               VAR_TRUNK_BWD_FEAT2 = 11 };  // its backward: dL/dh7 and dL/dh2 rows in; also stashes for feature_linear's and views_linears.0's weight gradients
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

@@ -83,6 +83,7 @@ template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
     static constexpr int N_PROG = (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
+                                  : VARIANT == VAR_TRUNK_FEAT2 ? N_CHUNKS_TRUNK + 8 + 9 : VARIANT == VAR_TRUNK_BWD_FEAT2 ? N_CHUNKS_TRUNK + 8 + 9 + N_CHUNKS_GRAD2 + N_CHUNKS_GRAD
                                   : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
@@ -101,6 +102,12 @@ struct Pipe {
         if (p < N_CHUNKS_TRUNK) return p;
         int q = p - N_CHUNKS_TRUNK;
         if (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) return CH_G7 + q;   // the backward stream follows the trunk
+        if (VARIANT == VAR_TRUNK_FEAT2 || VARIANT == VAR_TRUNK_BWD_FEAT2) {   // trunk, feature_linear, views_linears.0 [, their transposes, the trunk's]
+            if (q < 8) return CH_FEAT + q;
+            if (q < 17) return CH_VIEW + (q - 8);
+            q -= 17;
+            return q < N_CHUNKS_GRAD2 ? CH_GV + q : CH_G7 + (q - N_CHUNKS_GRAD2);
+        }
         if (!CI) { if (q < 8) return CH_FEAT + q; q -= 8; }
         if (ALBIRR) { if (q < 8) return CH_ALB + q; q -= 8; }
         if (!CI) { if (q < 9) return CH_VIEW + q; q -= 9; }
@@ -223,7 +230,8 @@ struct Acc {
 // The layer bias is already in the accumulator (it is the MFMA chain's initial C).
 //   MASK : (density-gradient variant) the ReLU's pass bits of this tile, 16 per lane, go to the wave's mask area in LDS:
 //          u16 at mrow + 128 * T (mrow = this lane's slot in the layer's row, see MASK_* below)
-//          MASK = 2 (VAR_TRUNK_BWD): the hi fragments also go to the operand stash (layout.h: STASH_X), srow + 1024 * k-step
+//          MASK = 2 (VAR_TRUNK_BWD): the hi fragments also go to the operand stash (layout.h: STASH_X), srow + 1024 * k-step;
+//          MASK = 3: the stash only (a layer without ReLU)
 //   FOUT : (VAR_TRUNK_FEAT) the fp32 values themselves go to the caller: frow = this point's 256-float row + 4h, four floats per two slices
 template <bool STORE, bool RELU, int NCH, int MASK = 0, bool FOUT = false>
 struct Epi {
@@ -258,7 +266,7 @@ struct Epi {
             if constexpr ((I & 1) == 0) keep = f32x2{x0, x1};
             else if (frow != nullptr) *reinterpret_cast<f32x4*>(frow + 32 * T + 8 * (I >> 1)) = f32x4{keep[0], keep[1], x0, x1};
         }
-        if constexpr (MASK) {
+        if constexpr (MASK == 1 || MASK == 2) {
             const unsigned bits = (x0 > 0.0f ? 1u << (2 * I) : 0u) | (x1 > 0.0f ? 2u << (2 * I) : 0u);
             mb = I == 0 ? bits : (mb | bits);
             if constexpr (I == 7) *reinterpret_cast<unsigned short*>(mrow + 128 * T) = (unsigned short)mb;
@@ -272,7 +280,7 @@ struct Epi {
                 asm volatile("" : "+v"(h), "+v"(l));
                 dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
                 dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
-                if constexpr (MASK == 2) *reinterpret_cast<u32x4*>(srow + 1024 * (2 * T + (I >> 2))) = h;
+                if constexpr (MASK >= 2) *reinterpret_cast<u32x4*>(srow + 1024 * (2 * T + (I >> 2))) = h;
             }
         }
 #pragma unroll
@@ -288,12 +296,16 @@ struct Epi {
 // layer's 256 post-ReLU features: times the recorded pass bits, then (hi, lo) fragments of `dst` as in the forward.  Tiles 8, 9
 // (positions_linears.5^T) / all tiles with ENC_ACC (positions_linears.0^T) are the gradient with respect to the 64 encoding
 // slots: kept in fp32, genc[16 * tile + r].
-template <bool ENC_ACC, bool STASH = false>
+// MODE 1: no pass bits (the layer in front has no ReLU: feature_linear).  MODE 2: the caller's gradient rows are added first
+// (dL/dh7 arrives both through feature_linear and directly from the heads the caller keeps): addrow = this point's row + 4h, or null.
+template <bool ENC_ACC, bool STASH = false, int MODE = 0>
 struct EpiG {
     Act* dst;
     const char* mrow;
     float* genc;
     char* srow;        // STASH: this layer's dZ stash row of the wave group (+ lane * 16)
+    const float* addrow;
+    float addscale;
     u32x4 h, l;
     unsigned mw;
 
@@ -308,9 +320,18 @@ struct EpiG {
             genc[16 * (T - 8) + 2 * I] = x0;
             genc[16 * (T - 8) + 2 * I + 1] = x1;
         } else {
-            if constexpr (I == 0) mw = *reinterpret_cast<const unsigned short*>(mrow + 128 * T);
-            x0 = (mw & (1u << (2 * I))) ? x0 : 0.0f;
-            x1 = (mw & (2u << (2 * I))) ? x1 : 0.0f;
+            if constexpr (MODE == 2) {
+                if (addrow != nullptr) {   // accumulator registers 2I, 2I+1 = features 32T + (2I & 3) + 8 (I >> 1) + 4h, +1
+                    const f32x2 r = *reinterpret_cast<const f32x2*>(addrow + 32 * T + ((2 * I) & 3) + 8 * (I >> 1));
+                    x0 = fmaf(r[0], addscale, x0);
+                    x1 = fmaf(r[1], addscale, x1);
+                }
+            }
+            if constexpr (MODE != 1) {
+                if constexpr (I == 0) mw = *reinterpret_cast<const unsigned short*>(mrow + 128 * T);
+                x0 = (mw & (1u << (2 * I))) ? x0 : 0.0f;
+                x1 = (mw & (2u << (2 * I))) ? x1 : 0.0f;
+            }
             unsigned hh, ll;
             split_pair(x0, x1, hh, ll);
             h[I & 3] = hh;
@@ -329,6 +350,7 @@ struct EpiG {
 constexpr int MASK_ZERO_OFF = LDS_BYTES;
 constexpr int MASK_OFF = LDS_BYTES + 128;
 constexpr int LDS_BYTES_GRAD = MASK_OFF + 4 * 8192;   // 155 904 of 163 840
+constexpr int LDS_BYTES_GRAD2 = MASK_OFF + 4 * 9216;  // VAR_TRUNK_BWD_FEAT2: a ninth row of pass bits (views_linears.0): 160 000
 
 // One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then NKH
 // (16, or 0 for the first layer) k-steps over the 256-feature activation `in`; three MFMA products
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     // side tables -> LDS once per workgroup
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
-    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT)
+    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2)
         if (threadIdx.x < 32) reinterpret_cast<float*>(smem + MASK_ZERO_OFF)[threadIdx.x] = 0.0f;
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
@@ -506,7 +528,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         }
         Enc pe, de;
         encode<PE_PAIRS_PER_HALF, PE_KSTEPS>(px, py, pz, h, pe);
-        if constexpr (VARIANT != VAR_TRUNK && !variant_ci(VARIANT)) {
+        if constexpr (VARIANT != VAR_TRUNK && VARIANT != VAR_TRUNK_FEAT && VARIANT != VAR_TRUNK_GRAD && VARIANT != VAR_TRUNK_BWD &&
+                      VARIANT != VAR_TRUNK_BWD_FEAT && !variant_ci(VARIANT)) {
             // direction encoding of this point's ray (run_network expands viewdirs over the samples,
             // ibl_nerf.py:244-247)
             float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -525,16 +548,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
-        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) {
+        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2) {
             // ---- density and its gradient with respect to the position: the trunk forward with every ReLU's pass bits
             // recorded, then the backward chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on the transposed stream (what autograd
             // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts).
             // VAR_TRUNK_BWD: dZ(7) carries the caller's dL / d sigma, and every layer's input and dZ fragments go to the stash
             // the weight-gradient kernel reads (train.py:479-481's backward through the trunk) ----
+            constexpr bool FEAT2 = VARIANT == VAR_TRUNK_BWD_FEAT2;   // ... and dL/dh2 rows: feature_linear and views_linears.0 are differentiated here too
             constexpr bool ROWS = VARIANT == VAR_TRUNK_BWD_FEAT;   // upstream gradient = dL/dh7 rows
-            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD || ROWS;
+            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD || ROWS || FEAT2;
             constexpr int MK = BWD ? 2 : 1;
-            char* mbase = smem + MASK_OFF + wave * 8192 + lane * 2;   // + 1024 * layer + 128 * tile
+            char* mbase = smem + MASK_OFF + wave * (FEAT2 ? 9216 : 8192) + lane * 2;   // + 1024 * layer + 128 * tile
             const float* zero = reinterpret_cast<const float*>(smem + MASK_ZERO_OFF) + h * 16;
             const long wgs = n_groups * 4, wgi = g * 4 + wave;          // wave groups of 32 points (layout.h: STASH_*)
             auto srow = [&](int what) -> char* { return BWD ? a.stash + stash_offset(what, wgs, wgi) + lane * 16 : nullptr; };
@@ -563,42 +587,86 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
             float up = 1.0f;                                   // dL / d sigma of this point (invalid points: 0, they add nothing to any gradient)
-            if constexpr (BWD && !ROWS) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
-
-            // dZ(7) = dL/dsigma * sigma_linear.weight * bits(7) -> A
-            static_for<0, 8>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                const unsigned mw = *reinterpret_cast<const unsigned short*>(mbase + 7 * 1024 + 128 * t);
-                static_for<0, 2>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value;
-                    u32x4 hv, lv;
-                    float wv[8];   // dL / d h7 of accumulator registers 8q .. 8q+7 = features 32t + 16q + 4h + {0..3, 8..11}
-                    if constexpr (ROWS) {
-                        const float* row = a.dh7 + (size_t)(valid ? p : 0) * 256 + 32 * t + 16 * q + 4 * h;
+            if constexpr (BWD && !ROWS && !FEAT2) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
+            if constexpr (FEAT2) {
+                // feature_linear (no activation: B = h7 -> A) and views_linears.0 ([feature, dir27] -> ReLU: only its pass bits are kept),
+                // ibl_nerf.py:193-197; then their backward: dZv = dL/dh2 * bits -> A, dFeat = Wv^T dZv -> B, dZ(7) = (Wf^T dFeat + dL/dh7) * bits(7) -> A
+#pragma unroll
+                for (int jj = 0; jj < DE_KSTEPS; ++jj) *reinterpret_cast<bf16x8*>(srow(STASH_DENC) + 1024 * jj) = de.hi[jj];
+                Epi<true, false, 0, 3> eF{&A, {nullptr}, {nullptr}, nullptr, srow(STASH_XF)};
+                pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32, none, eF);
+                Epi<false, true, 0, 1> eV{nullptr, {nullptr}, {nullptr}, mbase + 8 * 1024, nullptr};
+                pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, IBL_PEND(eF, 7, pacc), eV);
+                static_for<0, 8>([&](auto I) { eV.template slice<7, decltype(I)::value>(pacc); });
+                const float sc_ = valid ? a.grad_scale : 0.0f;
+                static_for<0, 8>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const unsigned mw = *reinterpret_cast<const unsigned short*>(mbase + 8 * 1024 + 128 * t);
+                    static_for<0, 2>([&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        const float* row = a.dh2 + (size_t)(valid ? p : 0) * 256 + 32 * t + 16 * q + 4 * h;
                         const f32x4 r0 = *reinterpret_cast<const f32x4*>(row), r1 = *reinterpret_cast<const f32x4*>(row + 8);
-                        const float sc_ = valid ? a.grad_scale : 0.0f;
+                        const float wv[8] = {r0[0] * sc_, r0[1] * sc_, r0[2] * sc_, r0[3] * sc_, r1[0] * sc_, r1[1] * sc_, r1[2] * sc_, r1[3] * sc_};
+                        u32x4 hv, lv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { wv[e] = r0[e] * sc_; wv[4 + e] = r1[e] * sc_; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) wv[e] = ltab[TAB_SIG + t * 32 + 8 * q + e] * up;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q + e;
-                        unsigned hh, ll;
-                        split_pair((mw & (1u << (2 * i))) ? wv[2 * e] : 0.0f, (mw & (2u << (2 * i))) ? wv[2 * e + 1] : 0.0f, hh, ll);
-                        hv[e] = hh;
-                        lv[e] = ll;
-                    }
-                    A.hi[2 * t + q] = __builtin_bit_cast(bf16x8, hv);
-                    A.lo[2 * t + q] = __builtin_bit_cast(bf16x8, lv);
-                    if constexpr (BWD) *reinterpret_cast<u32x4*>(srow(STASH_DZ + 7) + 1024 * (2 * t + q)) = hv;
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * q + e;
+                            unsigned hh, ll;
+                            split_pair((mw & (1u << (2 * i))) ? wv[2 * e] : 0.0f, (mw & (2u << (2 * i))) ? wv[2 * e + 1] : 0.0f, hh, ll);
+                            hv[e] = hh;
+                            lv[e] = ll;
+                        }
+                        A.hi[2 * t + q] = __builtin_bit_cast(bf16x8, hv);
+                        A.lo[2 * t + q] = __builtin_bit_cast(bf16x8, lv);
+                        *reinterpret_cast<u32x4*>(srow(STASH_DZV) + 1024 * (2 * t + q)) = hv;
+                    });
                 });
-            });
+            }
+
+            // (declared here: the FEAT2 form's last head layer hands its pending tile to the trunk's first backward layer)
+            EpiG<false, true, 1> gF{&B, nullptr, nullptr, FEAT2 ? srow(STASH_DZF) : nullptr, nullptr, 0.0f};
+            EpiG<false, true, 2> g7{&A, mbase + 7 * 1024, nullptr, FEAT2 ? srow(STASH_DZ + 7) : nullptr,
+                                    (FEAT2 && valid) ? a.dh7 + (size_t)p * 256 + 4 * h : nullptr, a.grad_scale};
+            if constexpr (FEAT2) {
+                pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gF, 0);                                       // Wv^T (feature columns): dZv (A) -> dFeat (B)
+                pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gF, 7, pacc), g7, 0);                      // Wf^T: dFeat (B) [+ dL/dh7] -> dZ7 (A)
+            } else {
+                // dZ(7) = dL/dsigma * sigma_linear.weight * bits(7) -> A
+                static_for<0, 8>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const unsigned mw = *reinterpret_cast<const unsigned short*>(mbase + 7 * 1024 + 128 * t);
+                    static_for<0, 2>([&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        u32x4 hv, lv;
+                        float wv[8];   // dL / d h7 of accumulator registers 8q .. 8q+7 = features 32t + 16q + 4h + {0..3, 8..11}
+                        if constexpr (ROWS) {
+                            const float* row = a.dh7 + (size_t)(valid ? p : 0) * 256 + 32 * t + 16 * q + 4 * h;
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(row), r1 = *reinterpret_cast<const f32x4*>(row + 8);
+                            const float sc_ = valid ? a.grad_scale : 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { wv[e] = r0[e] * sc_; wv[4 + e] = r1[e] * sc_; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) wv[e] = ltab[TAB_SIG + t * 32 + 8 * q + e] * up;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * q + e;
+                            unsigned hh, ll;
+                            split_pair((mw & (1u << (2 * i))) ? wv[2 * e] : 0.0f, (mw & (2u << (2 * i))) ? wv[2 * e + 1] : 0.0f, hh, ll);
+                            hv[e] = hh;
+                            lv[e] = ll;
+                        }
+                        A.hi[2 * t + q] = __builtin_bit_cast(bf16x8, hv);
+                        A.lo[2 * t + q] = __builtin_bit_cast(bf16x8, lv);
+                        if constexpr (BWD) *reinterpret_cast<u32x4*>(srow(STASH_DZ + 7) + 1024 * (2 * t + q)) = hv;
+                    });
+                });
+            }
             float genc[32];
-            EpiG<false, BWD> gA{&A, mbase, genc, nullptr}, gB{&B, mbase + 6 * 1024, genc, srow(STASH_DZ + 6)};
-            pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gB, 0);                                           // W7^T: dZ7 (A) -> dZ6 (B)
+            EpiG<false, BWD> gA{&A, mbase, genc, nullptr, nullptr, 0.0f}, gB{&B, mbase + 6 * 1024, genc, srow(STASH_DZ + 6), nullptr, 0.0f};
+            if constexpr (FEAT2) pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(g7, 7, pacc), gB, 0);     // W7^T: dZ7 (A) -> dZ6 (B)
+            else pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gB, 0);
             gA.mrow = mbase + 5 * 1024; gA.srow = srow(STASH_DZ + 5);
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W6^T -> dZ5 (A)
             gB.mrow = mbase + 4 * 1024; gB.srow = srow(STASH_DZ + 4);
@@ -611,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W2^T -> dZ1 (A)
             gB.mrow = mbase; gB.srow = srow(STASH_DZ + 0);
             pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W1^T -> dZ0 (B)
-            EpiG<true> g0{nullptr, nullptr, genc, nullptr};
+            EpiG<true> g0{nullptr, nullptr, genc, nullptr, nullptr, 0.0f};
             pacc = run_layer<2, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), g0, 0);                          // W0^T: + encoding gradient
             static_for<0, 8>([&](auto I) { g0.template slice<1, decltype(I)::value>(pacc); });
 #undef IBL_PEND
@@ -701,6 +769,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 return Epi<true, true, 4>{&B, {&part[0], &part[6], &part[7], &part[8]}, {ltab + TAB_SIG, rad[0], rad[1], rad[2]}};
             else if constexpr (VARIANT == VAR_TRUNK_FEAT)   // h7 itself is the output (sigma is still formed: it carries the range guard's NaN)
                 return Epi<false, true, 1, 0, true>{&B, {&part[0]}, {ltab + TAB_SIG}, nullptr, nullptr, valid ? a.out + (size_t)p * 256 + 4 * h : nullptr};
+            else if constexpr (VARIANT == VAR_TRUNK_FEAT2)  // ... and the operand of feature_linear
+                return Epi<true, true, 1, 0, true>{&B, {&part[0]}, {ltab + TAB_SIG}, nullptr, nullptr, valid ? a.out + (size_t)p * 256 + 4 * h : nullptr};
             else
                 return Epi<VARIANT != VAR_TRUNK, true, 1>{&B, {&part[0]}, {ltab + TAB_SIG}};
         }();
@@ -709,6 +779,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 
         if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) {
             flush(e7, T7{}, pacc);
+        } else if constexpr (VARIANT == VAR_TRUNK_FEAT2) {
+            // feature_linear (no activation) and views_linears.0 ([feature, dir27], ReLU) — ibl_nerf.py:193-197; its output rows go to out2
+            Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}};
+            pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32, [&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); }, eFeat);
+            Epi<false, true, 0, 0, true> eV{nullptr, {nullptr}, {nullptr}, nullptr, nullptr, valid ? a.out2 + (size_t)p * 256 + 4 * h : nullptr};
+            pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, [&](auto I) { eFeat.template slice<7, decltype(I)::value>(pacc); }, eV);
+            flush(eV, T7{}, pacc);
         } else {
             Epi<true, false, 0> eFeat{&A, {nullptr}, {nullptr}};
             Epi<false, true, 3> eAlb{nullptr, {&part[1], &part[2], &part[3]},
@@ -749,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
 
         // ---- combine the two lane halves, add head biases, store ------------------------------
         const float* sc = tabs + TAB_SCALAR;
-        if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) {
+        if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT || VARIANT == VAR_TRUNK_FEAT2) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
             if (VARIANT == VAR_TRUNK && valid && h == 0) a.out[(long)p * a.out_stride] = s;
 #ifdef IBL_F16X3
@@ -819,10 +896,10 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
+                                  VARIANT == VAR_TRUNK_BWD_FEAT2 ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), VARIANT == VAR_TRUNK_BWD_FEAT2 ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
 #define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
@@ -843,11 +920,15 @@ IBL_DEFINE_LAUNCH(7)
 IBL_DEFINE_LAUNCH(8)
 #elif IBL_VARIANT == 9
 IBL_DEFINE_LAUNCH(9)
+#elif IBL_VARIANT == 10
+IBL_DEFINE_LAUNCH(10)
+#elif IBL_VARIANT == 11
+IBL_DEFINE_LAUNCH(11)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8) IBL_DEFINE_LAUNCH(9)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8) IBL_DEFINE_LAUNCH(9) IBL_DEFINE_LAUNCH(10) IBL_DEFINE_LAUNCH(11)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -862,6 +943,8 @@ hipError_t IBL_LAUNCH_NAME(6)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(7)(const MlpArgs&, int, hipStream_t);   // (the stash is f16: this flavour only)
 hipError_t IBL_LAUNCH_NAME(8)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(9)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(10)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(11)(const MlpArgs&, int, hipStream_t);
 #endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
@@ -879,6 +962,8 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_TRUNK_BWD: rc = IBL_LAUNCH_NAME(7)(a, grid, stream); break;
         case VAR_TRUNK_FEAT: rc = IBL_LAUNCH_NAME(8)(a, grid, stream); break;
         case VAR_TRUNK_BWD_FEAT: rc = IBL_LAUNCH_NAME(9)(a, grid, stream); break;
+        case VAR_TRUNK_FEAT2: rc = IBL_LAUNCH_NAME(10)(a, grid, stream); break;
+        case VAR_TRUNK_BWD_FEAT2: rc = IBL_LAUNCH_NAME(11)(a, grid, stream); break;
 #endif
         default: return hipErrorInvalidValue;
     }

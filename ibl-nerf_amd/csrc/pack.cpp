@@ -204,6 +204,8 @@ void pack_network(const float* blob, void* stream_out, float* tab) {
     for (int l = 4; l >= 1; --l)
         for (int t = 0; t < 8; ++t) pack_hT(at(CH_G4 + 8 * (4 - l) + t), n, L_POS0 + l, 32 * t, 0);
     for (int t = 0; t < 2; ++t) pack_encT(at(CH_G0 + t), n, L_POS0, t, PE_PAIRS_PER_HALF);
+    for (int t = 0; t < 8; ++t) pack_hT(at(CH_GV + t), n, L_VIEWS, 32 * t, 0);      // views_linears.0: columns 0..255 = feature (ibl_nerf.py:194)
+    for (int t = 0; t < 8; ++t) pack_hT(at(CH_GF + t), n, L_FEATURE, 32 * t, 0);
 
     // biases
     for (int l = 0; l < 8; ++l) lane_table(tab + TAB_BIAS + (BT_L0 + 8 * l) * 32, n.b[L_POS0 + l], 8);

@@ -90,9 +90,8 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm&
     const long g0 = split * per, g1 = g0 + per < a.wave_groups ? g0 + per : a.wave_groups;
     const char* zbase = a.stash + stash_offset(gm.dz_what, a.wave_groups, 0) + (size_t)(2 * mt0) * 1024 + lane * 16;
     const long zstride = STASH_ACT_BYTES;
-    const bool enc = gm.x_what == STASH_ENC;
     const char* xbase = a.stash + stash_offset(gm.x_what, a.wave_groups, 0) + (size_t)(2 * nt0) * 1024 + lane * 16;
-    const long xstride = enc ? STASH_ENC_BYTES : STASH_ACT_BYTES;
+    const long xstride = gm.x_what == STASH_ENC ? STASH_ENC_BYTES : gm.x_what == STASH_DENC ? STASH_DENC_BYTES : STASH_ACT_BYTES;
 
     f16x8 fz[MT][2], fx[NT][2], nz[MT][2], nx[NT][2];
     auto load = [&](long g, f16x8 (&z)[MT][2], f16x8 (&x)[NT][2]) {
@@ -153,7 +152,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm&
     }
     // partial[split][gemm]: [256 rows][ncols]; accumulator register r of lane (i, h) = row (r&3) + 8(r>>2) + 4h, column i of its tile
     float* part = a.partial + (size_t)split * a.partial_stride + gm.part_off;
-    const int ncols = enc ? 64 : 256;
+    const int ncols = gm.ncols;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -167,15 +166,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WgradGemm gm = a.gemm[blockIdx.x];
-    if (gm.x_what == STASH_ENC) wgrad_block<2, 2>(a, gm, wave, lane, blockIdx.y);
+    if (gm.ncols == 64) wgrad_block<2, 2>(a, gm, wave, lane, blockIdx.y);
+    else if (gm.ncols == 32) wgrad_block<2, 1>(a, gm, wave, lane, blockIdx.y);
     else wgrad_block<4, 4>(a, gm, wave, lane, blockIdx.y);
 }
 
 // sum of the splits -> the reference's [out][in] row-major weight gradient inside the state-dict blob
 __global__ void k_wgrad_reduce(WgradArgs a) {
     const WgradGemm gm = a.gemm[blockIdx.y];
-    const bool enc = gm.x_what == STASH_ENC;
-    const int ncols = enc ? 64 : 256;
+    const bool enc = gm.enc_pairs > 0;
+    const int ncols = gm.ncols;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 256 * ncols) return;
     const int m = idx / ncols, n = idx - m * ncols;
@@ -183,7 +183,7 @@ __global__ void k_wgrad_reduce(WgradArgs a) {
     if (enc) {   // tile-local feature -> encoding slot -> embedder column (layout.h: enc_ref_index); pad slots have no column
         const int t = n >> 5, nl = n & 31;
         const int h = (nl >> 2) & 1, s = nl >> 4, e = (nl & 3) + 4 * ((nl >> 3) & 1);
-        col = enc_ref_index(8 * (2 * t + s) + e, h, PE_PAIRS_PER_HALF);
+        col = enc_ref_index(8 * (2 * t + s) + e, h, gm.enc_pairs);
         if (col < 0) return;
     }
     float acc = 0.0f;

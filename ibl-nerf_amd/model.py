@@ -191,21 +191,53 @@ def fused_trunk_features(inputs, network_fn):
     return _Fn.apply(inputs, *params)
 
 
+FEAT2_PARAMS = TRUNK_PARAMS[:16] + ("feature_linear.weight", "feature_linear.bias", "views_linears.0.weight", "views_linears.0.bias")
+
+
+def fused_trunk_features2(inputs, viewdirs, network_fn):
+    """positions_linears.0-7, feature_linear and views_linears.0 (ibl_nerf.py:160-170, 193-197) as one torch.autograd.Function on the fused
+    kernels: -> (h7, h2), the operands of every remaining head; backward = iblnerf_trunk_features2_backward."""
+    import torch
+    named = dict(network_fn.named_parameters())
+    params = [named[k] for k in FEAT2_PARAMS]
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, pts, vd, *ps):
+            ctx.save_for_backward(pts, vd)
+            return _query_renderer(network_fn).trunk_features2(pts, vd, 0)
+
+        @staticmethod
+        def backward(ctx, g7, g2):
+            pts, vd = ctx.saved_tensors
+            dpts, grads = _query_renderer(network_fn).trunk_features2_backward(pts, vd, g7.contiguous(), g2.contiguous(), 0)
+            return (dpts if ctx.needs_input_grad[0] else None, None) + tuple(
+                grads[k].reshape(p.shape) if ctx.needs_input_grad[2 + i] else None for i, (k, p) in enumerate(zip(FEAT2_PARAMS, params)))
+
+    return _Fn.apply(inputs, viewdirs, *params)
+
+
 def fused_query(inputs, viewdirs, network_fn):
     """`network_query_fn(inputs, viewdirs, network_fn)` WITH autograd for a training step's gradient-carrying main query: the trunk
-    (62 % of the network's FLOPs) forward and backward on the fused kernels (`fused_trunk_features`), the head layers — what
-    IBLNeRF.forward does after the trunk, ibl_nerf.py:171-208 — in torch on the module's own parameters."""
+    and the two 256-wide layers behind it (feature_linear, views_linears.0: together 79 % of the network's FLOPs) forward and backward
+    on the fused kernels (`fused_trunk_features2`), the remaining head layers — ibl_nerf.py:171-191, 199-208 — in torch on the module's own parameters."""
     import torch
     import torch.nn.functional as F
     n = network_fn
-    h = fused_trunk_features(inputs, n)
+    if viewdirs is not None and not _ci(n) and len(n.views_linears) == 1 and inputs.dim() == 3:
+        # feature_linear and views_linears.0 too (79 % of the FLOPs): the heads below read h7 and h2 = relu(views_linears.0([feature, dir27]))
+        h, h2 = fused_trunk_features2(inputs, viewdirs, n)
+    else:
+        h, h2 = fused_trunk_features(inputs, n), None
     sigma = n.sigma_linear(h)
     if viewdirs is None:
         return sigma                                                                   # :175-176
     albedo = n.albedo_linear(F.relu(n.albedo_feature_linear(h)))
     rough = n.roughness_linear(h)
     irr = n.irradiance_linear(F.relu(n.irradiance_feature_linear(h)))
-    if not _ci(n):
+    if h2 is not None:
+        h = h2
+    elif not _ci(n):
         d = viewdirs[:, None].expand(inputs.shape)                                     # run_network expands the directions over the samples (:244-247)
         e = torch.cat([d] + [f(d * 2.0 ** k) for k in range(4) for f in (torch.sin, torch.cos)], -1)
         h = torch.cat([n.feature_linear(h), e], -1)

@@ -346,6 +346,49 @@ class Renderer:
             raise FloatingPointError("trunk_features: an activation left the f16 range")
         return out.reshape(pts.shape[:-1] + (256,))
 
+    def trunk_features2(self, pts, viewdirs, which=0):
+        """trunk_features one layer pair further (ibl_nerf.py:193-197): (h7, h2) with h2 = relu(views_linears.0([feature_linear(h7), dir27])),
+        both [n_rays, n_samples, 256]; pts [n_rays, n_samples, 3], viewdirs [n_rays, 3]."""
+        torch = _torch()
+        pts, vd = _dev_f32(pts, self.device), _dev_f32(viewdirs, self.device)
+        N, S = pts.shape[0], pts.shape[1]
+        h7 = torch.empty((N, S, 256), dtype=torch.float32, device=self.device)
+        h2 = torch.empty((N, S, 256), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_trunk_features2(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), h7.data_ptr(), h2.data_ptr()))
+        if self.out_of_range():
+            raise FloatingPointError("trunk_features2: an activation left the f16 range")
+        return h7, h2
+
+    def trunk_features2_backward(self, pts, viewdirs, dh7, dh2, which=0, grad_scale=None):
+        """Backward of trunk_features2: dL/dh7 (what does not flow through feature_linear) and dL/dh2 -> (dL/dpts, grads) with the gradients
+        of positions_linears.0-7, feature_linear and views_linears.0.  Loss scaling as trunk_backward."""
+        torch = _torch()
+        pts, vd = _dev_f32(pts, self.device), _dev_f32(viewdirs, self.device)
+        N, S = pts.shape[0], pts.shape[1]
+        g7, g2 = _dev_f32(dh7, self.device).reshape(N * S, 256), _dev_f32(dh2, self.device).reshape(N * S, 256)
+        out = torch.empty((N * S, 4), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
+        if grad_scale is None:
+            top = max(float(g7.abs().max()), float(g2.abs().max())) if N * S else 1.0
+            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
+        else:
+            scales = [float(grad_scale)]
+        for sc in scales:
+            B.check(self.ctx, self.lib.iblnerf_trunk_features2_backward(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(),
+                                                                        g7.data_ptr(), g2.data_ptr(), sc, out.data_ptr(), grad.data_ptr()))
+            if not self.out_of_range():
+                break
+        else:
+            raise FloatingPointError("trunk_features2_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
+        self.last_grad_scale = sc
+        grads, off = {}, 0
+        for name, o, i in ck.SCHEMA:
+            if name.startswith(("positions_linears.", "feature_linear", "views_linears.0")):
+                grads[name + ".weight"] = grad[off:off + o * i].view(o, i)
+                grads[name + ".bias"] = grad[off + o * i:off + o * i + o]
+            off += o * i + o
+        return out[:, 1:].reshape(pts.shape), grads
+
     def trunk_backward(self, pts, dsigma, which=0, grad_scale=None, features=False):
         """The backward of the trunk-only query of a training step (train.py:479-481 through network_query_fn(pts, None, fn)):
         given dL/dsigma per point, returns (sigma, dL/dpts, grads) with grads = {parameter name: gradient} for positions_linears.0-7 and

@@ -210,6 +210,17 @@ int iblnerf_trunk_features(iblnerf_ctx* ctx, void* stream, int which, const floa
 int iblnerf_trunk_features_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dh7,
                                     float grad_scale, float* d_out, float* d_grad);
 
+/* ... and one layer pair further (not for colour-independent networks): iblnerf_trunk_features2 also evaluates feature_linear and
+ * views_linears.0 (ibl_nerf.py:193-197; the direction encoding of d_viewdirs [n_rays, 3], expanded over the n_samples points of a ray as
+ * run_network does) and returns both operands of the remaining heads: d_h7 [n, 256] and d_h2 = relu(views_linears.0(...)) [n, 256],
+ * n = n_rays * n_samples.  Its backward takes dL/dh7 (the part that does NOT flow through feature_linear) and dL/dh2 and adds
+ * feature_linear's and views_linears.0's gradients to d_grad (79 % of the network's FLOPs differentiated on the fused kernels). */
+int iblnerf_trunk_features2(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                            const float* d_viewdirs, float* d_h7, float* d_h2);
+int iblnerf_trunk_features2_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                                     const float* d_viewdirs, const float* d_dh7, const float* d_dh2, float grad_scale, float* d_out,
+                                     float* d_grad);
+
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
 int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,

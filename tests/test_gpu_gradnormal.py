@@ -257,3 +257,46 @@ def test_fused_trunk_query_in_a_torch_training_loop(R, lut):
             losses[j].append(float(loss.detach()))
     assert losses[0][-1] < 0.7 * losses[0][0]                                # it trains
     assert np.abs(np.array(losses[0]) - np.array(losses[1])).max() <= 2e-2 * losses[1][0], (losses[0], losses[1])
+
+
+def test_trunk_features2_stagewise(R, lut):
+    """iblnerf_trunk_features2 / _backward on their own: h7 and h2 against torch through the same module; the backward against torch autograd
+    for a loss on both outputs (the gradients of the 20 tensors of positions_linears.0-7, feature_linear, views_linears.0 — the direction
+    columns of the latter included — and of the points); a colour-independent network is refused."""
+    from torch_ref import RefShaped, embed
+    import torch.nn.functional as F
+    g, sdc, _, _, _ = load_golden("plain_g10")
+    net = RefShaped(sdc).cuda()
+    rng = np.random.RandomState(3)
+    pts = torch.from_numpy(rng.uniform(-1.5, 1.5, (5, 37, 3)).astype(np.float32)).cuda()        # 185 points: ragged against the 128-point groups
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (5, 3)).astype(np.float32)).cuda()
+    w7 = torch.from_numpy(rng.uniform(-1, 1, (5, 37, 256)).astype(np.float32)).cuda()
+    w2 = torch.from_numpy(rng.uniform(-1, 1, (5, 37, 256)).astype(np.float32)).cuda()
+    r = R.Renderer(64, 0, max_rays_per_launch=64)
+    r.load_weights(0, sdc)
+    h7, h2 = r.trunk_features2(pts, dirs, 0)
+    p = pts.clone().requires_grad_(True)
+    h = embed(p.reshape(-1, 3), 10)
+    e = h
+    for i, l in enumerate(net.positions_linears):
+        h = F.relu(l(h))
+        if i == 4:
+            h = torch.cat([e, h], -1)
+    t7 = h.reshape(5, 37, 256)
+    t2 = F.relu(net.views_linears[0](torch.cat([net.feature_linear(t7), embed(dirs[:, None].expand(5, 37, 3), 4)], -1)))
+    t7d, t2d = t7.detach(), t2.detach()
+    assert float((h7 - t7d).abs().max()) <= 2e-5 * float(t7d.abs().max()) and float((h2 - t2d).abs().max()) <= 2e-5 * float(t2d.abs().max())
+    assert torch.equal(h7, r.trunk_features(pts, 0))                       # the same trunk arithmetic as the one-output form
+    ((t7 * w7).sum() + (t2 * w2).sum()).backward()
+    dpts, grads = r.trunk_features2_backward(pts, dirs, w7, w2, 0)
+    assert rel_linf(dpts.cpu().numpy(), p.grad.cpu().numpy()) <= 2e-3
+    named = dict(net.named_parameters())
+    assert len(grads) == 20
+    for k, v in grads.items():
+        assert rel_linf(v.cpu().numpy(), named[k].grad.cpu().numpy()) <= 1e-3, k
+    assert float(named["views_linears.0.weight"].grad[:, 256:].abs().max()) > 0        # the direction columns are exercised
+    ci = R.Renderer(64, 0, max_rays_per_launch=64, color_independent_to_direction=True)
+    ci.load_weights(0, sdc)
+    from ibl_nerf_amd.binding import IblNerfError
+    with pytest.raises(IblNerfError):
+        ci.trunk_features2(pts, dirs, 0)
