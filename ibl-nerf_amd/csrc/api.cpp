@@ -592,7 +592,17 @@ int iblnerf_trunk_features2(iblnerf_ctx* c, void* stream, int which, const float
 
 static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                                const float* d_dh7, float grad_scale, float* d_out, float* d_grad, const float* d_dirs = nullptr,
-                               int pts_per_ray = 1, const float* d_dh2 = nullptr);
+                               int pts_per_ray = 1, const float* d_dh2 = nullptr, const float* d_draw = nullptr);
+
+int iblnerf_network_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                             const float* d_viewdirs, const float* d_draw, float grad_scale, float* d_out, float* d_grad) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_viewdirs || !d_draw)))
+        return c->fail(IBLNERF_ERR_INVALID, "network_backward: bad arguments");
+    if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "network_backward: not built for colour-independent networks");
+    return trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, nullptr, grad_scale, d_out, d_grad, d_viewdirs, n_samples,
+                               nullptr, d_draw);
+}
 
 int iblnerf_trunk_features2_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
                                      const float* d_viewdirs, const float* d_dh7, const float* d_dh2, float grad_scale, float* d_out, float* d_grad) {
@@ -619,7 +629,7 @@ int iblnerf_trunk_features_backward(iblnerf_ctx* c, void* stream, int which, con
 
 static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                                const float* d_dh7, float grad_scale, float* d_out, float* d_grad, const float* d_dirs, int pts_per_ray,
-                               const float* d_dh2) {
+                               const float* d_dh2, const float* d_draw) {
     if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)) || !d_grad)
         return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
     int gs_exp = 0;
@@ -655,25 +665,27 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     MlpArgs a;
     a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
     a.n_pts = n_pts; a.pts_per_ray = pts_per_ray; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
-    a.dirs = d_dirs; a.dh2 = d_dh2;
-    const bool feat2 = d_dh2 != nullptr;
-    HIP_TRY(c, launch_mlp_f16x3(feat2 ? VAR_TRUNK_BWD_FEAT2 : d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
-    c->flop_alg += (double)n_pts * 3.0 * (FLOP_TRUNK + (feat2 ? FLOP_FEAT_VIEW : 0.0));
+    a.dirs = d_dirs; a.dh2 = d_dh2; a.draw = d_draw;
+    const bool net = d_draw != nullptr;
+    const bool feat2 = d_dh2 != nullptr || net;
+    HIP_TRY(c, launch_mlp_f16x3(net ? VAR_NET_BWD : feat2 ? VAR_TRUNK_BWD_FEAT2 : d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
+    c->flop_alg += (double)n_pts * 3.0 * (net ? FLOP_FULL : FLOP_TRUNK + (feat2 ? FLOP_FEAT_VIEW : 0.0));
     w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
-    w.n_gemm = feat2 ? 12 : 9;
+    w.n_gemm = net ? 17 : feat2 ? 12 : 9;
+    w.n_head = 0;
     w.unscale = 1.0f / grad_scale;
-    size_t wo[11], bo[11];
-    for (int l = 0; l < 11; ++l) blob_offsets(l, &wo[l], &bo[l]);
+    size_t wo[23], bo[23];
+    for (int l = 0; l < 23; ++l) blob_offsets(l, &wo[l], &bo[l]);
     long part = 0;
-    const long bias_part0 = 9 * 65536L + 2 * 16384L + 8192L;
+    const long bias_part0 = 9 * 65536L + 2 * 16384L + 8192L + 5 * 32768L;
     int n_bias = 0;
-    // (k, blob layer, dZ stash, input stash, row length, first column, keeps the layer's bias)
-    auto gemm_ = [&](int k, int layer, int dz_what, int x_what, int in_dim, int col_base, bool bias) {
+    // (k, blob layer, dZ stash, input stash, row length, first column, keeps the layer's bias, output rows)
+    auto gemm_ = [&](int k, int layer, int dz_what, int x_what, int in_dim, int col_base, bool bias, int nrows = 256) {
         const int ncols = x_what == STASH_ENC ? 64 : x_what == STASH_DENC ? 32 : 256;
-        w.gemm[k] = WgradGemm{dz_what, x_what, ncols, x_what == STASH_ENC ? PE_PAIRS_PER_HALF : x_what == STASH_DENC ? DE_PAIRS_PER_HALF : 0, in_dim, col_base,
+        w.gemm[k] = WgradGemm{dz_what, x_what, nrows, ncols, x_what == STASH_ENC ? PE_PAIRS_PER_HALF : x_what == STASH_DENC ? DE_PAIRS_PER_HALF : 0, in_dim, col_base,
                               (long)wo[layer], part, bias ? bias_part0 + 512L * n_bias : -1L, (long)bo[layer]};
         if (bias) ++n_bias;
-        part += 256L * ncols;
+        part += (long)nrows * ncols;
     };
     auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
         gemm_(k, layer, STASH_DZ + layer, x_what, in_dim, col_base, !(layer == 5 && x_what != STASH_ENC));   // positions_linears.5: its encoding block keeps the bias
@@ -689,8 +701,23 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
         gemm_(10, 8, STASH_DZV, STASH_XF, 283, 0, true);
         gemm_(11, 8, STASH_DZV, STASH_DENC, 283, 256, false);
     }
+    if (net) {     // blob layers 11 / 14 = albedo / irradiance feature layers, 17..19 = additional_radiance_feature_linear.k; then the N = 1/3 heads
+        for (int k = 0; k < 3; ++k) gemm_(12 + k, 17 + k, STASH_DF0 + k, STASH_XH2, 256, 0, true, 128);
+        gemm_(15, 11, STASH_DFA, STASH_X + 7, 256, 0, true, 128);
+        gemm_(16, 14, STASH_DFI, STASH_X + 7, 256, 0, true, 128);
+        auto head = [&](int k, int layer, int x_what, int n_ksteps, int nc, int ch0) {
+            w.head[k] = WgradArgs::Head{x_what, n_ksteps, nc, ch0, (long)wo[layer], (long)bo[layer]};
+        };
+        head(0, 10, STASH_X + 7, 16, 1, 0);            // sigma_linear
+        head(1, 13, STASH_X + 7, 16, 1, 4);            // roughness_linear
+        head(2, 12, STASH_FA, 8, 3, 1);                // albedo_linear
+        head(3, 15, STASH_FI, 8, 1, 5);                // irradiance_linear
+        head(4, 16, STASH_XH2, 16, 3, 6);              // radiance_linear
+        for (int k = 0; k < 3; ++k) head(5 + k, 20 + k, STASH_F0 + k, 8, 3, 9 + 3 * k);   // additional_radiance_linear.k
+        w.n_head = 8;
+    }
     w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
-    HIP_TRY(c, launch_wgrad(w, d_dsigma, (long)n_pts, s));
+    HIP_TRY(c, launch_wgrad(w, net ? d_draw : d_dsigma, (long)n_pts, s));
     return arm_range_snapshot(c, s);
 }
 

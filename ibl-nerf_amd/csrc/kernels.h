@@ -164,6 +164,7 @@ hipError_t launch_posdir_mlp(const PosDirArgs& a, hipStream_t s);
 // Weight gradient of the trunk from the backward kernel's operand stash (wgrad_kernel.hip; layout.h: STASH_*).
 struct WgradGemm {
     int dz_what, x_what;     // stash activations: dZ of the layer, its input (STASH_X + l - 1 / STASH_XF, or an encoding: STASH_ENC / STASH_DENC)
+    int nrows;               // 256, or 128 (a 128-wide feature layer: its dZ stash entry uses k-steps 0..7)
     int ncols, enc_pairs;    // columns of this GEMM: 256 (an activation), 64 (the 63 position-encoding columns, enc_pairs 15), 32 (the 27 direction columns, 6)
     int in_dim, col_base;    // row length of the reference's [out][in] weight, first column this GEMM fills
     long blob_off;           // the weight inside the state-dict blob
@@ -177,11 +178,14 @@ struct WgradArgs {
     float* grad;             // the reference's state-dict layout (blob_floats() floats), zeroed by the caller
     long wave_groups, partial_stride;
     int n_split, n_gemm;
-    WgradGemm gemm[12];
+    WgradGemm gemm[17];
     long sigma_w_off, sigma_b_off;
     float unscale;           // 1 / MlpArgs::grad_scale
+    // the N = 1/3 heads: d weight[c][j] = sum_p up[p][ch0 + c] * x[p][j], d bias[c] = sum_p up[p][ch0 + c]; x = a stashed activation
+    struct Head { int x_what, n_ksteps, nc, ch0; long w_off, b_off; } head[8];
+    int n_head;
 };
-constexpr long WGRAD_PARTIAL_FLOATS = 9 * 65536L + 2 * 16384L + 8192L + 10 * 512L;   // 9 hidden + 2 position-encoding + 1 direction-encoding GEMMs, 10 bias rows
-hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s);
+constexpr long WGRAD_PARTIAL_FLOATS = 9 * 65536L + 2 * 16384L + 8192L + 5 * 32768L + 15 * 512L;   // 9 hidden + 2 position-encoding + 1 direction-encoding + 5 128-row GEMMs, 15 bias rows
+hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s);   // dsigma: [n] (or null), or with a.n_head > 0 the [n, 18] dL/d raw rows
 
 }  // namespace ibl

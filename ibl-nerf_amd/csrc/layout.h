@@ -64,10 +64,15 @@ constexpr int N_CHUNKS_GRAD = 60;
 constexpr int CH_GV = 157;   // views_linears.0^T, its 256 feature columns (the direction columns carry no gradient)   8   8
 constexpr int CH_GF = 165;   // feature_linear^T                                                                     8   8
 constexpr int N_CHUNKS_GRAD2 = 16;
-constexpr int N_CHUNKS = N_CHUNKS_NET + N_CHUNKS_GRAD + N_CHUNKS_GRAD2;   // 173
+// ... and of the whole network (VAR_NET_BWD): the three additional_radiance_feature layers meet in dL/dh2 and feature_linear meets the
+// albedo / irradiance feature layers in dL/dh7, so their transposes are packed K-concatenated, one tile = all k-steps of its 32 rows:
+constexpr int CH_GA = 173;   // [ARF.2^T (8 k-steps) | ARF.0^T (8) | ARF.1^T (8)] per tile: 8 tiles x 24 k-steps   12 chunks
+constexpr int CH_GH = 185;   // [albedo_feature^T (8) | irradiance_feature^T (8) | feature_linear^T (16)] per tile: 8 x 32   16 chunks
+constexpr int N_CHUNKS_GRAD3 = 28;
+constexpr int N_CHUNKS = N_CHUNKS_NET + N_CHUNKS_GRAD + N_CHUNKS_GRAD2 + N_CHUNKS_GRAD3;   // 201
 constexpr int PE_KSTEPS = 4;   // 64 slots, 63 used
 constexpr int DE_KSTEPS = 2;   // 32 slots, 27 used
-constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 5.4 MiB per network
+constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;  // 6.3 MiB per network
 
 // fp32 side tables (biases in accumulator-lane layout + the tiny N=1/3 heads that run on the VALU)
 // Lane-layout entry [tile][h][r] holds the value for feature 32*tile_local + (r&3) + 8*(r>>2) + 4h.
@@ -100,7 +105,10 @@ constexpr int LDS_BYTES = LDS_RING_BYTES + TAB_BYTES;      // 123 008 B
 //   [STASH_ENC][wave group]           the encoding's 4 k-steps (4 KiB each; slot order of enc_ref_index)
 //   VAR_TRUNK_BWD_FEAT2 adds  [STASH_XF] feature_linear's output (views_linears.0's input), [STASH_DZV] / [STASH_DZF] dL / d pre-activation
 //   of views_linears.0 / feature_linear, and [STASH_DENC] the direction encoding's 2 k-steps (2 KiB each)
-constexpr int STASH_X = 0, STASH_DZ = 8, STASH_XF = 16, STASH_DZV = 17, STASH_DZF = 18, STASH_N_ACT = 19, STASH_ENC = 19, STASH_DENC = 20;
+//   VAR_NET_BWD adds  [STASH_XH2] relu(views_linears.0), [STASH_F0 + k] relu(additional_radiance_feature_linear.k), [STASH_FA] / [STASH_FI] relu of the
+//   albedo / irradiance feature layers, and [STASH_DF0 + k], [STASH_DFA], [STASH_DFI] their dL / d pre-activation (128 wide: k-steps 0..7 of an entry)
+constexpr int STASH_X = 0, STASH_DZ = 8, STASH_XF = 16, STASH_DZV = 17, STASH_DZF = 18, STASH_XH2 = 19, STASH_F0 = 20, STASH_FA = 23, STASH_FI = 24,
+              STASH_DF0 = 25, STASH_DFA = 28, STASH_DFI = 29, STASH_N_ACT = 30, STASH_ENC = 30, STASH_DENC = 31;
 constexpr long STASH_ACT_BYTES = 16 * 1024;   // per wave group and activation
 constexpr long STASH_ENC_BYTES = 4 * 1024;
 constexpr long STASH_DENC_BYTES = 2 * 1024;
@@ -148,7 +156,8 @@ enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_R
                VAR_TRUNK_FEAT = 8,    // f16x3 kernel only: TRUNK forward whose output is the 256 trunk features h7 (fp32 rows), not sigma
                VAR_TRUNK_BWD_FEAT = 9,    // VAR_TRUNK_BWD with the upstream gradient given on those features (dL/dh7 rows) instead of on sigma
                VAR_TRUNK_FEAT2 = 10,      // ... one layer pair further: outputs h7 AND h2 = relu(views_linears.0([feature_linear(h7), dir27])) rows
-               VAR_TRUNK_BWD_FEAT2 = 11 };  // its backward: dL/dh7 and dL/dh2 rows in; also stashes for feature_linear's and views_linears.0's weight gradients
+               VAR_TRUNK_BWD_FEAT2 = 11,  // its backward: dL/dh7 and dL/dh2 rows in; also stashes for feature_linear's and views_linears.0's weight gradients
+               VAR_NET_BWD = 12 };        // the whole network's backward: dL/d raw rows [n, 18] in, every layer differentiated
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
 

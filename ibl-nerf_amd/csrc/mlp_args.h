@@ -24,6 +24,7 @@ struct MlpArgs {
     const float* dh7 = nullptr;      // or [n_pts, 256] dL / d trunk features (then dsigma is not read: the heads live with the caller)
     const float* dh2 = nullptr;      // VAR_TRUNK_BWD_FEAT2: [n_pts, 256] dL / d relu(views_linears.0) output
     float* out2 = nullptr;           // VAR_TRUNK_FEAT2: [n_pts, 256] that output (out = the trunk features)
+    const float* draw = nullptr;     // VAR_NET_BWD: [n_pts, 18] dL / d raw (the network's 18 output channels, ibl_nerf.py:200-208)
     char* stash = nullptr;
     float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
                                      // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels

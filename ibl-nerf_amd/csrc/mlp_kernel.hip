@@ -44,6 +44,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Act { bf16x8 hi[16]; bf16x8 lo[16]; };  // 256 features = 16 k-steps of B fragments
 struct Enc { bf16x8 hi[4]; bf16x8 lo[4]; };    // up to 64 encoding slots = 4 k-steps
+struct Half { bf16x8 hi[8]; bf16x8 lo[8]; };   // 128 features = 8 k-steps (the gradient of one 128-wide feature layer)
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -84,6 +85,7 @@ struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
     static constexpr int N_PROG = (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT) ? N_CHUNKS_TRUNK : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? N_CHUNKS_TRUNK + N_CHUNKS_GRAD
                                   : VARIANT == VAR_TRUNK_FEAT2 ? N_CHUNKS_TRUNK + 8 + 9 : VARIANT == VAR_TRUNK_BWD_FEAT2 ? N_CHUNKS_TRUNK + 8 + 9 + N_CHUNKS_GRAD2 + N_CHUNKS_GRAD
+                                  : VARIANT == VAR_NET_BWD ? N_CHUNKS_NET + 12 + 8 + 16 + N_CHUNKS_GRAD
                                   : N_CHUNKS_TRUNK + (CI ? 0 : 8 + 9) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;          // generic pointer to the ring (for ds_read)
@@ -102,6 +104,14 @@ struct Pipe {
         if (p < N_CHUNKS_TRUNK) return p;
         int q = p - N_CHUNKS_TRUNK;
         if (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) return CH_G7 + q;   // the backward stream follows the trunk
+        if (VARIANT == VAR_NET_BWD) {   // the whole forward (FULL's chunks), then dL/dh2, dFeat, dL/dh7, the trunk
+            if (q < N_CHUNKS_NET - N_CHUNKS_TRUNK) return p;
+            q -= N_CHUNKS_NET - N_CHUNKS_TRUNK;
+            if (q < 12) return CH_GA + q;
+            if (q < 20) return CH_GV + (q - 12);
+            if (q < 36) return CH_GH + (q - 20);
+            return CH_G7 + (q - 36);
+        }
         if (VARIANT == VAR_TRUNK_FEAT2 || VARIANT == VAR_TRUNK_BWD_FEAT2) {   // trunk, feature_linear, views_linears.0 [, their transposes, the trunk's]
             if (q < 8) return CH_FEAT + q;
             if (q < 17) return CH_VIEW + (q - 8);
@@ -231,7 +241,8 @@ struct Acc {
 //   MASK : (density-gradient variant) the ReLU's pass bits of this tile, 16 per lane, go to the wave's mask area in LDS:
 //          u16 at mrow + 128 * T (mrow = this lane's slot in the layer's row, see MASK_* below)
 //          MASK = 2 (VAR_TRUNK_BWD): the hi fragments also go to the operand stash (layout.h: STASH_X), srow + 1024 * k-step;
-//          MASK = 3: the stash only (a layer without ReLU)
+//          MASK = 3: the stash only (a layer without ReLU); MASK = 4: the stash only and no `dst` (a 128-wide feature layer: its pass bits are
+//          read back from the stashed values)
 //   FOUT : (VAR_TRUNK_FEAT) the fp32 values themselves go to the caller: frow = this point's 256-float row + 4h, four floats per two slices
 template <bool STORE, bool RELU, int NCH, int MASK = 0, bool FOUT = false>
 struct Epi {
@@ -271,15 +282,17 @@ struct Epi {
             mb = I == 0 ? bits : (mb | bits);
             if constexpr (I == 7) *reinterpret_cast<unsigned short*>(mrow + 128 * T) = (unsigned short)mb;
         }
-        if constexpr (STORE) {
+        if constexpr (STORE || MASK == 4) {
             unsigned hh, ll;
             split_pair(x0, x1, hh, ll);
             h[I & 3] = hh;
             l[I & 3] = ll;
             if constexpr ((I & 3) == 3) {
                 asm volatile("" : "+v"(h), "+v"(l));
-                dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
-                dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+                if constexpr (STORE) {
+                    dst->hi[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, h);
+                    dst->lo[2 * T + (I >> 2)] = __builtin_bit_cast(bf16x8, l);
+                }
                 if constexpr (MASK >= 2) *reinterpret_cast<u32x4*>(srow + 1024 * (2 * T + (I >> 2))) = h;
             }
         }
@@ -296,7 +309,7 @@ struct Epi {
 // layer's 256 post-ReLU features: times the recorded pass bits, then (hi, lo) fragments of `dst` as in the forward.  Tiles 8, 9
 // (positions_linears.5^T) / all tiles with ENC_ACC (positions_linears.0^T) are the gradient with respect to the 64 encoding
 // slots: kept in fp32, genc[16 * tile + r].
-// MODE 1: no pass bits (the layer in front has no ReLU: feature_linear).  MODE 2: the caller's gradient rows are added first
+// MODE 1: no pass bits (the layer in front has no ReLU: feature_linear).  MODE 3: see rtab.  MODE 2: the caller's gradient rows are added first
 // (dL/dh7 arrives both through feature_linear and directly from the heads the caller keeps): addrow = this point's row + 4h, or null.
 template <bool ENC_ACC, bool STASH = false, int MODE = 0>
 struct EpiG {
@@ -306,6 +319,8 @@ struct EpiG {
     char* srow;        // STASH: this layer's dZ stash row of the wave group (+ lane * 16)
     const float* addrow;
     float addscale;
+    const float* rtab[3];   // MODE 3: the N = 1/3 heads that read this activation directly add their rank-1 terms: head-weight tables in lane
+    float rch[3];           // layout (as the forward's), times the point's upstream gradient of that channel
     u32x4 h, l;
     unsigned mw;
 
@@ -325,6 +340,14 @@ struct EpiG {
                     const f32x2 r = *reinterpret_cast<const f32x2*>(addrow + 32 * T + ((2 * I) & 3) + 8 * (I >> 1));
                     x0 = fmaf(r[0], addscale, x0);
                     x1 = fmaf(r[1], addscale, x1);
+                }
+            }
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x2 w = *reinterpret_cast<const f32x2*>(rtab[c] + T * 32 + 2 * I);
+                    x0 = fmaf(w[0], rch[c], x0);
+                    x1 = fmaf(w[1], rch[c], x1);
                 }
             }
             if constexpr (MODE != 1) {
@@ -350,7 +373,7 @@ struct EpiG {
 constexpr int MASK_ZERO_OFF = LDS_BYTES;
 constexpr int MASK_OFF = LDS_BYTES + 128;
 constexpr int LDS_BYTES_GRAD = MASK_OFF + 4 * 8192;   // 155 904 of 163 840
-constexpr int LDS_BYTES_GRAD2 = MASK_OFF + 4 * 9216;  // VAR_TRUNK_BWD_FEAT2: a ninth row of pass bits (views_linears.0): 160 000
+constexpr int LDS_BYTES_GRAD2 = MASK_OFF + 4 * 9216;  // VAR_TRUNK_BWD_FEAT2, VAR_NET_BWD: a ninth row of pass bits (views_linears.0): 160 000
 
 // One layer of the k-step stream: NT output tiles; per tile NKE encoding k-steps (B = enc) then NKH
 // (16, or 0 for the first layer) k-steps over the 256-feature activation `in`; three MFMA products
@@ -364,8 +387,8 @@ constexpr int LDS_BYTES_GRAD2 = MASK_OFF + 4 * 9216;  // VAR_TRUNK_BWD_FEAT2: a 
 //     still interleaves the three MFMAs with the slice's VALU work).
 // The last tile's accumulator is returned for the next layer's `pend`.
 constexpr int DMA_K0 = 2;   // chunk-relative k-step after which the first DMA piece of the chunk two ahead is issued
-template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI>
-__device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const Enc& enc, const float* bias_tab,
+template <int NT, int NKE, int NKH, int VARIANT, class PEND, class EPI, class ENC>
+__device__ __forceinline__ Acc run_layer(Pipe<VARIANT>& P, const Act& in, const ENC& enc, const float* bias_tab,
                                          PEND&& pend, EPI& epi, int bias_stride = 32) {
     constexpr int N = NKE + NKH;                       // k-steps per tile
     Acc prev;
@@ -499,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     // side tables -> LDS once per workgroup
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
-    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2)
+    if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2 || VARIANT == VAR_NET_BWD)
         if (threadIdx.x < 32) reinterpret_cast<float*>(smem + MASK_ZERO_OFF)[threadIdx.x] = 0.0f;
     __syncthreads();
     const float* ltab = tabs + h * 16;   // this lane-half's 16-float row inside every [2][16] entry
@@ -548,17 +571,18 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         for (int c = 0; c < RAW_CH; ++c) part[c] = 0.0f;
         const float* bias = ltab + TAB_BIAS;   // + tile*32: this lane-half's 16 biases of a tile
         auto none = [](auto) {};
-        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2) {
+        if constexpr (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT || VARIANT == VAR_TRUNK_BWD_FEAT2 || VARIANT == VAR_NET_BWD) {
             // ---- density and its gradient with respect to the position: the trunk forward with every ReLU's pass bits
             // recorded, then the backward chain dZ(l-1) = (W(l)^T dZ(l)) * bits(l-1) on the transposed stream (what autograd
             // does for normal_from_depth.py:16-52, :102-137 through run_network, restricted to d raw[..., 0] / d pts).
             // VAR_TRUNK_BWD: dZ(7) carries the caller's dL / d sigma, and every layer's input and dZ fragments go to the stash
             // the weight-gradient kernel reads (train.py:479-481's backward through the trunk) ----
+            constexpr bool NET = VARIANT == VAR_NET_BWD;             // the whole network: upstream gradient = dL/d raw rows
             constexpr bool FEAT2 = VARIANT == VAR_TRUNK_BWD_FEAT2;   // ... and dL/dh2 rows: feature_linear and views_linears.0 are differentiated here too
             constexpr bool ROWS = VARIANT == VAR_TRUNK_BWD_FEAT;   // upstream gradient = dL/dh7 rows
-            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD || ROWS || FEAT2;
+            constexpr bool BWD = VARIANT == VAR_TRUNK_BWD || ROWS || FEAT2 || NET;
             constexpr int MK = BWD ? 2 : 1;
-            char* mbase = smem + MASK_OFF + wave * (FEAT2 ? 9216 : 8192) + lane * 2;   // + 1024 * layer + 128 * tile
+            char* mbase = smem + MASK_OFF + wave * ((FEAT2 || NET) ? 9216 : 8192) + lane * 2;   // + 1024 * layer + 128 * tile
             const float* zero = reinterpret_cast<const float*>(smem + MASK_ZERO_OFF) + h * 16;
             const long wgs = n_groups * 4, wgi = g * 4 + wave;          // wave groups of 32 points (layout.h: STASH_*)
             auto srow = [&](int what) -> char* { return BWD ? a.stash + stash_offset(what, wgs, wgi) + lane * 16 : nullptr; };
@@ -587,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float sigma = part[0] + __shfl_xor(part[0], 32) + tabs[TAB_SCALAR];
             float up = 1.0f;                                   // dL / d sigma of this point (invalid points: 0, they add nothing to any gradient)
-            if constexpr (BWD && !ROWS && !FEAT2) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
+            if constexpr (BWD && !ROWS && !FEAT2 && !NET) up = valid ? a.dsigma[p] * a.grad_scale : 0.0f;
             if constexpr (FEAT2) {
                 // feature_linear (no activation: B = h7 -> A) and views_linears.0 ([feature, dir27] -> ReLU: only its pass bits are kept),
                 // ibl_nerf.py:193-197; then their backward: dZv = dL/dh2 * bits -> A, dFeat = Wv^T dZv -> B, dZ(7) = (Wf^T dFeat + dL/dh7) * bits(7) -> A
@@ -623,11 +647,88 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 });
             }
 
-            // (declared here: the FEAT2 form's last head layer hands its pending tile to the trunk's first backward layer)
-            EpiG<false, true, 1> gF{&B, nullptr, nullptr, FEAT2 ? srow(STASH_DZF) : nullptr, nullptr, 0.0f};
-            EpiG<false, true, 2> g7{&A, mbase + 7 * 1024, nullptr, FEAT2 ? srow(STASH_DZ + 7) : nullptr,
-                                    (FEAT2 && valid) ? a.dh7 + (size_t)p * 256 + 4 * h : nullptr, a.grad_scale};
-            if constexpr (FEAT2) {
+            // (declared here: the FEAT2 / NET forms' last head layer hands its pending tile to the trunk's first backward layer)
+            float dr[RAW_CH];   // NET: this point's dL / d raw, times the gradient scale
+            if constexpr (NET) {
+#pragma unroll
+                for (int c = 0; c < RAW_CH; ++c) dr[c] = valid ? a.draw[(size_t)p * RAW_CH + c] * a.grad_scale : 0.0f;
+            }
+            EpiG<false, true, 1> gF{&B, nullptr, nullptr, (FEAT2 || NET) ? srow(STASH_DZF) : nullptr, nullptr, 0.0f, {nullptr, nullptr, nullptr}, {0.f, 0.f, 0.f}};
+            EpiG<false, true, NET ? 3 : 2> g7{&A, mbase + 7 * 1024, nullptr, (FEAT2 || NET) ? srow(STASH_DZ + 7) : nullptr,
+                                             (FEAT2 && valid) ? a.dh7 + (size_t)p * 256 + 4 * h : nullptr, a.grad_scale,
+                                             {ltab + TAB_SIG, ltab + TAB_ROUGH, ltab + TAB_ROUGH}, {NET ? dr[0] : 0.f, NET ? dr[4] : 0.f, 0.f}};
+            if constexpr (NET) {
+                // ---- the head layers, forward in FULL's order (chunks 60..96), keeping what the backward needs: feature_linear's output and
+                // h2 as fragments + stash, the five 128-wide feature layers' outputs in the stash only ----
+#pragma unroll
+                for (int jj = 0; jj < DE_KSTEPS; ++jj) *reinterpret_cast<bf16x8*>(srow(STASH_DENC) + 1024 * jj) = de.hi[jj];
+                Epi<true, false, 0, 3> eF{&A, {nullptr}, {nullptr}, nullptr, srow(STASH_XF)};
+                pacc = run_layer<8, 0, 16>(P, B, pe, bias + BT_FEAT * 32, none, eF);                                   // feature_linear: h7 (B) -> A
+                Epi<false, true, 0, 4> eAl{nullptr, {nullptr}, {nullptr}, nullptr, srow(STASH_FA)};
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_ALB * 32, IBL_PEND(eF, 7, pacc), eAl);                  // albedo_feature_linear
+                Epi<false, true, 0, 4> eIr{nullptr, {nullptr}, {nullptr}, nullptr, srow(STASH_FI)};
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_IRR * 32, IBL_PEND(eAl, 3, pacc), eIr);                 // irradiance_feature_linear
+                Epi<true, true, 0, 2> eV{&B, {nullptr}, {nullptr}, mbase + 8 * 1024, srow(STASH_XH2)};
+                pacc = run_layer<8, DE_KSTEPS, 16>(P, A, de, bias + BT_VIEW * 32, IBL_PEND(eIr, 3, pacc), eV);         // views_linears.0 -> h2 (B)
+                Epi<false, true, 0, 4> eA0{nullptr, {nullptr}, {nullptr}, nullptr, srow(STASH_F0)}, eA1{nullptr, {nullptr}, {nullptr}, nullptr, srow(STASH_F0 + 1)},
+                    eA2{nullptr, {nullptr}, {nullptr}, nullptr, srow(STASH_F0 + 2)};
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + BT_AR * 32, IBL_PEND(eV, 7, pacc), eA0);                   // additional_radiance_feature_linear.0-2
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 4) * 32, IBL_PEND(eA0, 3, pacc), eA1);
+                pacc = run_layer<4, 0, 16>(P, B, pe, bias + (BT_AR + 8) * 32, IBL_PEND(eA1, 3, pacc), eA2);
+                static_for<0, 8>([&](auto I) { eA2.template slice<3, decltype(I)::value>(pacc); });
+                // dL/d pre-activation of a 128-wide feature layer = [its stashed output > 0] * (its N = 1/3 head's weights . upstream channels):
+                // 8 k-steps of fragments, formed on the VALU from the head tables (lane layout, channel c at tab + 128 c)
+                auto form = [&](auto NC, const char* fstash, const float* tab, const float* dch, bf16x8* hi, bf16x8* lo, char* dstash) {
+                    constexpr int nc = decltype(NC)::value;
+                    static_for<0, 8>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        const bf16x8 f = *reinterpret_cast<const bf16x8*>(fstash + 1024 * j);
+                        u32x4 hv, lv;
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            float v[2];
+#pragma unroll
+                            for (int o = 0; o < 2; ++o) {
+                                const int e = 2 * e2 + o;
+                                float acc = 0.0f;
+#pragma unroll
+                                for (int c = 0; c < nc; ++c) acc = fmaf(tab[128 * c + (j >> 1) * 32 + 8 * (j & 1) + e], dch[c], acc);
+                                v[o] = (float)f[e] != 0.0f ? acc : 0.0f;
+                            }
+                            unsigned hh, ll;
+                            split_pair(v[0], v[1], hh, ll);
+                            hv[e2] = hh;
+                            lv[e2] = ll;
+                        }
+                        hi[j] = __builtin_bit_cast(bf16x8, hv);
+                        lo[j] = __builtin_bit_cast(bf16x8, lv);
+                        *reinterpret_cast<u32x4*>(dstash + 1024 * j) = hv;
+                    });
+                };
+                using N1 = std::integral_constant<int, 1>;
+                using N3 = std::integral_constant<int, 3>;
+                {
+                    Act DF01;      // dF.0 | dF.1
+                    Half DF2;
+                    form(N3{}, srow(STASH_F0), ltab + TAB_AR, &dr[9], &DF01.hi[0], &DF01.lo[0], srow(STASH_DF0));
+                    form(N3{}, srow(STASH_F0 + 1), ltab + TAB_AR + 384, &dr[12], &DF01.hi[8], &DF01.lo[8], srow(STASH_DF0 + 1));
+                    form(N3{}, srow(STASH_F0 + 2), ltab + TAB_AR + 768, &dr[15], &DF2.hi[0], &DF2.lo[0], srow(STASH_DF0 + 2));
+                    // dL/dh2 = sum_k ARF.k^T dF.k + radiance_linear^T dRad;  dZv = that * bits(views) -> A
+                    EpiG<false, true, 3> gV{&A, mbase + 8 * 1024, nullptr, srow(STASH_DZV), nullptr, 0.0f,
+                                            {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512}, {dr[6], dr[7], dr[8]}};
+                    pacc = run_layer<8, 8, 16>(P, DF01, DF2, zero, none, gV, 0);
+                    pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gV, 7, pacc), gF, 0);                          // Wv^T (feature columns): dZv (A) -> dFeat (B)
+                }
+                {
+                    Act DFAI;      // dFa | dFi
+                    form(N3{}, srow(STASH_FA), ltab + TAB_ALB, &dr[1], &DFAI.hi[0], &DFAI.lo[0], srow(STASH_DFA));
+                    form(N1{}, srow(STASH_FI), ltab + TAB_IRR, &dr[5], &DFAI.hi[8], &DFAI.lo[8], srow(STASH_DFI));
+                    // dL/dh7 = Wf^T dFeat + ALBF^T dFa + IRRF^T dFi + sigma_linear^T dsigma + roughness_linear^T drough;  dZ7 = that * bits(7) -> A
+                    // (dFeat is the SECOND operand: its last k-steps are completed by the pending epilogue during this layer's first tile, whose
+                    // slices are spread over all 32 k-steps — as the first operand it would be read at k-steps 14, 15, before slice 7 at k-step 28)
+                    pacc = run_layer<8, 16, 16>(P, B, DFAI, zero, IBL_PEND(gF, 7, pacc), g7, 0);
+                }
+            } else if constexpr (FEAT2) {
                 pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gF, 0);                                       // Wv^T (feature columns): dZv (A) -> dFeat (B)
                 pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gF, 7, pacc), g7, 0);                      // Wf^T: dFeat (B) [+ dL/dh7] -> dZ7 (A)
             } else {
@@ -664,8 +765,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 });
             }
             float genc[32];
-            EpiG<false, BWD> gA{&A, mbase, genc, nullptr, nullptr, 0.0f}, gB{&B, mbase + 6 * 1024, genc, srow(STASH_DZ + 6), nullptr, 0.0f};
-            if constexpr (FEAT2) pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(g7, 7, pacc), gB, 0);     // W7^T: dZ7 (A) -> dZ6 (B)
+            EpiG<false, BWD> gA{&A, mbase, genc, nullptr, nullptr, 0.0f, {nullptr, nullptr, nullptr}, {0.f, 0.f, 0.f}}, gB{&B, mbase + 6 * 1024, genc, srow(STASH_DZ + 6), nullptr, 0.0f, {nullptr, nullptr, nullptr}, {0.f, 0.f, 0.f}};
+            if constexpr (FEAT2 || NET) pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(g7, 7, pacc), gB, 0);     // W7^T: dZ7 (A) -> dZ6 (B)
             else pacc = run_layer<8, 0, 16>(P, A, pe, zero, none, gB, 0);
             gA.mrow = mbase + 5 * 1024; gA.srow = srow(STASH_DZ + 5);
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W6^T -> dZ5 (A)
@@ -679,7 +780,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             pacc = run_layer<8, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), gA, 0);                          // W2^T -> dZ1 (A)
             gB.mrow = mbase; gB.srow = srow(STASH_DZ + 0);
             pacc = run_layer<8, 0, 16>(P, A, pe, zero, IBL_PEND(gA, 7, pacc), gB, 0);                          // W1^T -> dZ0 (B)
-            EpiG<true> g0{nullptr, nullptr, genc, nullptr, nullptr, 0.0f};
+            EpiG<true> g0{nullptr, nullptr, genc, nullptr, nullptr, 0.0f, {nullptr, nullptr, nullptr}, {0.f, 0.f, 0.f}};
             pacc = run_layer<2, 0, 16>(P, B, pe, zero, IBL_PEND(gB, 7, pacc), g0, 0);                          // W0^T: + encoding gradient
             static_for<0, 8>([&](auto I) { g0.template slice<1, decltype(I)::value>(pacc); });
 #undef IBL_PEND
@@ -896,10 +997,10 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)IBL_KNS mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  VARIANT == VAR_TRUNK_BWD_FEAT2 ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
+                                  (VARIANT == VAR_TRUNK_BWD_FEAT2 || VARIANT == VAR_NET_BWD) ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : LDS_BYTES + 2048);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), VARIANT == VAR_TRUNK_BWD_FEAT2 ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
+    hipLaunchKernelGGL(IBL_KNS mlp_kernel<VARIANT>, dim3(grid), dim3(256), (VARIANT == VAR_TRUNK_BWD_FEAT2 || VARIANT == VAR_NET_BWD) ? IBL_KNS LDS_BYTES_GRAD2 : (VARIANT == VAR_TRUNK_GRAD || VARIANT == VAR_TRUNK_BWD || VARIANT == VAR_TRUNK_BWD_FEAT) ? IBL_KNS LDS_BYTES_GRAD : IBL_KNS LDS_LAUNCH, stream, a);
     return hipGetLastError();
 }
 #define IBL_DEFINE_LAUNCH(V) hipError_t IBL_LAUNCH_NAME(V)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<V>(a, grid, s); }
@@ -924,11 +1025,13 @@ IBL_DEFINE_LAUNCH(9)
 IBL_DEFINE_LAUNCH(10)
 #elif IBL_VARIANT == 11
 IBL_DEFINE_LAUNCH(11)
+#elif IBL_VARIANT == 12
+IBL_DEFINE_LAUNCH(12)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
 #else
-IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8) IBL_DEFINE_LAUNCH(9) IBL_DEFINE_LAUNCH(10) IBL_DEFINE_LAUNCH(11)
+IBL_DEFINE_LAUNCH(0) IBL_DEFINE_LAUNCH(1) IBL_DEFINE_LAUNCH(2) IBL_DEFINE_LAUNCH(3) IBL_DEFINE_LAUNCH(4) IBL_DEFINE_LAUNCH(6) IBL_DEFINE_LAUNCH(7) IBL_DEFINE_LAUNCH(8) IBL_DEFINE_LAUNCH(9) IBL_DEFINE_LAUNCH(10) IBL_DEFINE_LAUNCH(11) IBL_DEFINE_LAUNCH(12)
 #endif
 #undef IBL_DEFINE_LAUNCH
 
@@ -945,6 +1048,7 @@ hipError_t IBL_LAUNCH_NAME(8)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(9)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(10)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(11)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(12)(const MlpArgs&, int, hipStream_t);
 #endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
@@ -964,6 +1068,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_TRUNK_BWD_FEAT: rc = IBL_LAUNCH_NAME(9)(a, grid, stream); break;
         case VAR_TRUNK_FEAT2: rc = IBL_LAUNCH_NAME(10)(a, grid, stream); break;
         case VAR_TRUNK_BWD_FEAT2: rc = IBL_LAUNCH_NAME(11)(a, grid, stream); break;
+        case VAR_NET_BWD: rc = IBL_LAUNCH_NAME(12)(a, grid, stream); break;
 #endif
         default: return hipErrorInvalidValue;
     }

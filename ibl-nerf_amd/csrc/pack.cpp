@@ -117,6 +117,18 @@ void pack_hT(uint16_t* ks0, const Net& n, int l, int in0, int col_base) {
         }
     }
 }
+// ... nk k-steps (8: a 128-output layer) of the same tile
+void pack_hT_k(uint16_t* ks0, const Net& n, int l, int in0, int nk) {
+    for (int j = 0; j < nk; ++j) {
+        uint16_t* ks = ks0 + (size_t)j * (KSTEP_BYTES / 2);
+        const int t = j >> 1, s = j & 1;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5;
+            for (int e = 0; e < 8; ++e)
+                put_split(ks, lane, e, n.W(l, 32 * t + acc_feature(8 * s + e, h), in0 + i));
+        }
+    }
+}
 // ... and of encoding tile `tile` (0, 1): row i = accumulator register r = (i&3) + 4*(i>>3) of lane half (i>>2)&1 <-> slot 16*tile + r
 void pack_encT(uint16_t* ks0, const Net& n, int l, int tile, int pairs_per_half) {
     for (int j = 0; j < 16; ++j) {
@@ -206,6 +218,18 @@ void pack_network(const float* blob, void* stream_out, float* tab) {
     for (int t = 0; t < 2; ++t) pack_encT(at(CH_G0 + t), n, L_POS0, t, PE_PAIRS_PER_HALF);
     for (int t = 0; t < 8; ++t) pack_hT(at(CH_GV + t), n, L_VIEWS, 32 * t, 0);      // views_linears.0: columns 0..255 = feature (ibl_nerf.py:194)
     for (int t = 0; t < 8; ++t) pack_hT(at(CH_GF + t), n, L_FEATURE, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) {   // dL/dh2 = sum_k ARF.k^T dF.k: the kernel's "encoding" operand (first) carries dF.2, its activation dF.0 | dF.1
+        uint16_t* tile = at(CH_GA) + (size_t)t * 24 * KS;
+        pack_hT_k(tile, n, L_AR_F2, 32 * t, 8);
+        pack_hT_k(tile + 8 * KS, n, L_AR_F0, 32 * t, 8);
+        pack_hT_k(tile + 16 * KS, n, L_AR_F1, 32 * t, 8);
+    }
+    for (int t = 0; t < 8; ++t) {   // dL/dh7 = Wf^T dFeat + ALBF^T dFa + IRRF^T dFi (+ the N = 1 heads' rank-1 terms, in the epilogue)
+        uint16_t* tile = at(CH_GH) + (size_t)t * 32 * KS;    // (the feature layer's k-steps last: see the kernel)
+        pack_hT_k(tile, n, L_ALB_F, 32 * t, 8);
+        pack_hT_k(tile + 8 * KS, n, L_IRR_F, 32 * t, 8);
+        pack_hT(tile + 16 * KS, n, L_FEATURE, 32 * t, 0);
+    }
 
     // biases
     for (int l = 0; l < 8; ++l) lane_table(tab + TAB_BIAS + (BT_L0 + 8 * l) * 32, n.b[L_POS0 + l], 8);

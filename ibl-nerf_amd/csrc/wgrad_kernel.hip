@@ -64,7 +64,7 @@ __device__ __forceinline__ void to_operands(const f32x16& d, f16x8 (&op)[2]) {
 // alone, the compiler batches all transpositions first and spills the prefetched fragments).
 template <int MT, int NT>
 __device__ __forceinline__ void wgrad_block(const WgradArgs& a, const WgradGemm& gm, int wave, int lane, int split) {
-    const int mt0 = (NT == 4) ? 4 * (wave >> 1) : 2 * wave;
+    const int mt0 = (NT == 4) ? MT * (wave >> 1) : 2 * wave;     // NT == 4: waves 2 x 2 over (2 MT) x 8 tiles; else 4 x 1
     const int nt0 = (NT == 4) ? 4 * (wave & 1) : 0;
     const int h = lane >> 5, i = lane & 31;
     // selection fragments: B[k = (h, e)][col i] = 1 where the tile-local feature of slot (s, h, e) is i
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WgradGemm gm = a.gemm[blockIdx.x];
-    if (gm.ncols == 64) wgrad_block<2, 2>(a, gm, wave, lane, blockIdx.y);
+    if (gm.nrows == 128) wgrad_block<2, 4>(a, gm, wave, lane, blockIdx.y);
+    else if (gm.ncols == 64) wgrad_block<2, 2>(a, gm, wave, lane, blockIdx.y);
     else if (gm.ncols == 32) wgrad_block<2, 1>(a, gm, wave, lane, blockIdx.y);
     else wgrad_block<4, 4>(a, gm, wave, lane, blockIdx.y);
 }
@@ -177,7 +178,7 @@ __global__ void k_wgrad_reduce(WgradArgs a) {
     const bool enc = gm.enc_pairs > 0;
     const int ncols = gm.ncols;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 256 * ncols) return;
+    if (idx >= gm.nrows * ncols) return;
     const int m = idx / ncols, n = idx - m * ncols;
     int col = n;
     if (enc) {   // tile-local feature -> encoding slot -> embedder column (layout.h: enc_ref_index); pad slots have no column
@@ -237,10 +238,55 @@ __global__ __launch_bounds__(256) void k_head_grad(WgradArgs a, const float* __r
 
 }  // namespace
 
+// the N = 1/3 heads of the whole-network backward (WgradArgs::head): block = (head, quarter of the 16 k-steps), thread = (k-step, lane)
+__global__ __launch_bounds__(256) void k_heads_grad(WgradArgs a, const float* __restrict__ up, long n_pts) {
+    const WgradArgs::Head hd = a.head[blockIdx.x >> 2];
+    const int jq = blockIdx.x & 3;
+    const int lane = threadIdx.x & 63, j = 4 * jq + (threadIdx.x >> 6);
+    if (j >= hd.n_ksteps) return;
+    const int h = lane >> 5, i = lane & 31;
+    const char* base = a.stash + stash_offset(hd.x_what, a.wave_groups, 0) + j * 1024 + lane * 16;
+    float acc[3][8], accb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.0f;
+    for (long g = blockIdx.y; g < a.wave_groups; g += gridDim.y) {
+        const f16x8 f = *reinterpret_cast<const f16x8*>(base + g * STASH_ACT_BYTES);
+        const long p = g * 32 + i;
+        float w[3] = {0.f, 0.f, 0.f};
+        if (p < n_pts)
+            for (int c = 0; c < hd.nc; ++c) w[c] = up[p * RAW_CH + hd.ch0 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            accb[c] += w[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c][e] += w[c] * (float)f[e];
+        }
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c][e] += __shfl_xor(acc[c][e], m);
+            accb[c] += __shfl_xor(accb[c], m);
+        }
+    if (i == 0) {
+        const int width = 16 * hd.n_ksteps;          // 256 or 128 input features
+        for (int c = 0; c < hd.nc; ++c) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(a.grad + hd.w_off + (long)c * width + 32 * (j >> 1) + acc_feature(8 * (j & 1) + e, h), acc[c][e]);
+            if (j == 0 && h == 0) atomicAdd(a.grad + hd.b_off + c, accb[c]);
+        }
+    }
+}
+
 hipError_t launch_wgrad(const WgradArgs& a, const float* dsigma, long n_pts, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_gemm, a.n_split), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(256, a.n_gemm), dim3(256), 0, s, a);
-    if (dsigma != nullptr) hipLaunchKernelGGL(k_head_grad, dim3(4, 64), dim3(256), 0, s, a, dsigma, n_pts);
+    if (a.n_head > 0) hipLaunchKernelGGL(k_heads_grad, dim3(4 * a.n_head, 64), dim3(256), 0, s, a, dsigma, n_pts);
+    else if (dsigma != nullptr) hipLaunchKernelGGL(k_head_grad, dim3(4, 64), dim3(256), 0, s, a, dsigma, n_pts);
     return hipGetLastError();
 }
 

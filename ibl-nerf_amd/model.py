@@ -217,6 +217,32 @@ def fused_trunk_features2(inputs, viewdirs, network_fn):
     return _Fn.apply(inputs, viewdirs, *params)
 
 
+ALL_PARAMS = tuple(n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias"))
+
+
+def fused_network_query(inputs, viewdirs, network_fn):
+    """`network_query_fn(inputs, viewdirs, network_fn)` WITH autograd, the whole network on the fused kernels in both directions: forward =
+    the precise network query, backward = iblnerf_network_backward (dL/d raw rows in; dL/dinputs and all 46 parameter gradients out)."""
+    import torch
+    named = dict(network_fn.named_parameters())
+    params = [named[k] for k in ALL_PARAMS]
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, pts, vd, *ps):
+            ctx.save_for_backward(pts, vd)
+            return _query_renderer(network_fn).network_query(pts, vd, 0)
+
+        @staticmethod
+        def backward(ctx, graw):
+            pts, vd = ctx.saved_tensors
+            dpts, grads = _query_renderer(network_fn).network_backward(pts, vd, graw.contiguous(), 0)
+            return (dpts if ctx.needs_input_grad[0] else None, None) + tuple(
+                grads[k].reshape(p.shape) if ctx.needs_input_grad[2 + i] else None for i, (k, p) in enumerate(zip(ALL_PARAMS, params)))
+
+    return _Fn.apply(inputs, viewdirs, *params)
+
+
 def fused_query(inputs, viewdirs, network_fn):
     """`network_query_fn(inputs, viewdirs, network_fn)` WITH autograd for a training step's gradient-carrying main query: the trunk
     and the two 256-wide layers behind it (feature_linear, views_linears.0: together 79 % of the network's FLOPs) forward and backward
@@ -224,6 +250,8 @@ def fused_query(inputs, viewdirs, network_fn):
     import torch
     import torch.nn.functional as F
     n = network_fn
+    if viewdirs is not None and not _ci(n) and len(n.views_linears) == 1 and inputs.dim() == 3 and set(ALL_PARAMS) == set(dict(n.named_parameters())):
+        return fused_network_query(inputs, viewdirs, n)                                # every layer, both directions
     if viewdirs is not None and not _ci(n) and len(n.views_linears) == 1 and inputs.dim() == 3:
         # feature_linear and views_linears.0 too (79 % of the FLOPs): the heads below read h7 and h2 = relu(views_linears.0([feature, dir27]))
         h, h2 = fused_trunk_features2(inputs, viewdirs, n)

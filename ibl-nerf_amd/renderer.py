@@ -389,6 +389,35 @@ class Renderer:
             off += o * i + o
         return out[:, 1:].reshape(pts.shape), grads
 
+    def network_backward(self, pts, viewdirs, draw, which=0, grad_scale=None):
+        """Backward of network_query(pts, viewdirs): dL/d raw [n_rays, n_samples, 18] -> (dL/dpts, grads) with the gradients of ALL the network's
+        parameters in the reference's state-dict shapes (iblnerf_network_backward).  Loss scaling as trunk_backward."""
+        torch = _torch()
+        pts, vd = _dev_f32(pts, self.device), _dev_f32(viewdirs, self.device)
+        N, S = pts.shape[0], pts.shape[1]
+        dr = _dev_f32(draw, self.device).reshape(N * S, 18)
+        out = torch.empty((N * S, 4), dtype=torch.float32, device=self.device)
+        grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
+        if grad_scale is None:
+            top = float(dr.abs().max()) if N * S else 1.0
+            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
+        else:
+            scales = [float(grad_scale)]
+        for sc in scales:
+            B.check(self.ctx, self.lib.iblnerf_network_backward(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), dr.data_ptr(),
+                                                                sc, out.data_ptr(), grad.data_ptr()))
+            if not self.out_of_range():
+                break
+        else:
+            raise FloatingPointError("network_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
+        self.last_grad_scale = sc
+        grads, off = {}, 0
+        for name, o, i in ck.SCHEMA:
+            grads[name + ".weight"] = grad[off:off + o * i].view(o, i)
+            grads[name + ".bias"] = grad[off + o * i:off + o * i + o]
+            off += o * i + o
+        return out[:, 1:].reshape(pts.shape), grads
+
     def trunk_backward(self, pts, dsigma, which=0, grad_scale=None, features=False):
         """The backward of the trunk-only query of a training step (train.py:479-481 through network_query_fn(pts, None, fn)):
         given dL/dsigma per point, returns (sigma, dL/dpts, grads) with grads = {parameter name: gradient} for positions_linears.0-7 and

@@ -221,6 +221,15 @@ int iblnerf_trunk_features2_backward(iblnerf_ctx* ctx, void* stream, int which, 
                                      const float* d_viewdirs, const float* d_dh7, const float* d_dh2, float grad_scale, float* d_out,
                                      float* d_grad);
 
+/* replaces: loss.backward() through a training step's main query network_query_fn(pts, viewdirs, fn) (train.py:479-481; ibl_nerf.py:236-252,
+ * 154-210): the WHOLE network.  d_draw [n, 18] = dL / d raw (n = n_rays * n_samples, channel order of IBLNeRF.forward) -> d_out [n, 4] =
+ * (sigma, dL/dpts) and d_grad = the gradients of all 23 layers in state-dict layout.  One fused launch (forward with the ReLU pass bits and
+ * an operand stash, then the backward chain: the 128-wide feature layers' gradients are formed from their heads' weights, the transposed
+ * layers that meet in dL/dh2 and dL/dh7 are packed K-concatenated, the N = 1 heads on those activations enter as rank-1 terms) + the
+ * weight-gradient GEMMs and head reductions.  Not for colour-independent networks.  15 KiB of workspace per point. */
+int iblnerf_network_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
+                             const float* d_viewdirs, const float* d_draw, float grad_scale, float* d_out, float* d_grad);
+
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
 int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,

@@ -247,6 +247,69 @@ def trunk_backward(sd, pts, dsigma):
     return sigma.astype(F32), grad.astype(F32), grads
 
 
+def network_backward(sd, pts, viewdirs, draw):
+    """What loss.backward() leaves in .grad of EVERY parameter for L with dL/d raw = draw on the full query network_query_fn(pts, viewdirs, fn)
+    (train.py:479-481 through ibl_nerf.py:236-252, 154-210), written out layer by layer.  pts [N,S,3], viewdirs [N,3], draw [N,S,18]
+    -> (dL/dpts [N,S,3], {name: gradient}).  float64 inside."""
+    pts = np.asarray(pts, dtype=F32)
+    N, S, _ = pts.shape
+    d = np.asarray(draw, dtype=np.float64).reshape(N * S, 18)
+    e = embed(pts.reshape(-1, 3), 10)
+    ed = embed(np.broadcast_to(np.asarray(viewdirs, dtype=F32)[:, None, :], pts.shape).reshape(-1, 3), 4)
+    W = lambda n: sd[n + ".weight"].astype(np.float64)
+    grads = {}
+
+    def lin_bwd(name, x, dz):                         # dz = dL/d output of the layer (after its activation's mask) -> dL/d input
+        grads[name + ".weight"] = (dz.T @ x.astype(np.float64)).astype(F32)
+        grads[name + ".bias"] = dz.sum(0).astype(F32)
+        return dz @ W(name)
+
+    # forward, keeping inputs and masks
+    h, ins, masks = e, [], []
+    for i in range(8):
+        ins.append(h)
+        z = _lin(sd, "positions_linears.%d" % i, h)
+        masks.append(z > 0)
+        h = relu(z)
+        if i == 4:
+            h = np.concatenate([e, h], -1)
+    h7 = h
+    fa, fi = _lin(sd, "albedo_feature_linear", h7), _lin(sd, "irradiance_feature_linear", h7)
+    feat = _lin(sd, "feature_linear", h7)
+    xin = np.concatenate([feat, ed], -1)
+    zv = _lin(sd, "views_linears.0", xin)
+    h2 = relu(zv)
+    fk = [_lin(sd, "additional_radiance_feature_linear.%d" % k, h2) for k in range(3)]
+    # backward of the heads
+    dh2 = lin_bwd("radiance_linear", h2, d[:, 6:9])
+    for k in range(3):
+        df = lin_bwd("additional_radiance_linear.%d" % k, relu(fk[k]), d[:, 9 + 3 * k:12 + 3 * k]) * (fk[k] > 0)
+        dh2 = dh2 + lin_bwd("additional_radiance_feature_linear.%d" % k, h2, df)
+    dxin = lin_bwd("views_linears.0", xin, dh2 * (zv > 0))
+    dh7 = lin_bwd("feature_linear", h7, dxin[:, :256])
+    dh7 = dh7 + lin_bwd("sigma_linear", h7, d[:, 0:1]) + lin_bwd("roughness_linear", h7, d[:, 4:5])
+    dh7 = dh7 + lin_bwd("albedo_feature_linear", h7, lin_bwd("albedo_linear", relu(fa), d[:, 1:4]) * (fa > 0))
+    dh7 = dh7 + lin_bwd("irradiance_feature_linear", h7, lin_bwd("irradiance_linear", relu(fi), d[:, 5:6]) * (fi > 0))
+    # the trunk
+    g = dh7 * masks[7]
+    g_enc = np.zeros(e.shape)
+    for i in range(7, -1, -1):
+        gi = lin_bwd("positions_linears.%d" % i, ins[i], g)
+        if i == 5:
+            g_enc = g_enc + gi[:, :63]
+            gi = gi[:, 63:]
+        if i == 0:
+            g_enc = g_enc + gi
+        else:
+            g = gi * masks[i - 1]
+    grad = g_enc[:, 0:3].copy()
+    for k in range(10):
+        f = 2.0 ** k
+        s_, c_ = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
+        grad = grad + f * (g_enc[:, 3 + 6 * k:6 + 6 * k] * c_ - g_enc[:, 6 + 6 * k:9 + 6 * k] * s_)
+    return grad.reshape(N, S, 3).astype(F32), grads
+
+
 # A.5 compositing — ibl_nerf_renderer.py:203-206, 241-245 (and :44-52, normal_from_depth.py:160-170)
 # --------------------------------------------------------------------------------------------
 def ray_dists(z_vals, rays_d):

@@ -251,6 +251,37 @@ def trunk_backward_fixture(torch, M):
     print("%-28s parameter gradients of the trunk by the reference's autograd  %.2f MB" % ("trunk_backward", os.path.getsize(path) / 1e6))
 
 
+def network_backward_fixture(torch, M):
+    """loss.backward() through the reference's own FULL query path (run_network with view directions -> IBLNeRF.forward) for
+    L = sum (draw * raw), draw seeded: every parameter gradient and dL/dpts — the known answer of iblnerf_network_backward.  Random-init
+    network (seed 62), 4 rays x 48 points (a set without a ReLU pass-bit flip on the device, scratch/netbwd_seeds.py)."""
+    out = {}
+    sd = ck.synthetic_state_dict(seed=62, gain=1.0)
+    tmp = tempfile.mkdtemp()
+    try:
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 0))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    net = kw["network_fn"]
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rng = np.random.RandomState(63)
+    pts = rng.uniform(-1.5, 1.5, (4, 48, 3)).astype(np.float32)
+    dirs = rng.uniform(-1, 1, (4, 3)).astype(np.float32)
+    draw = rng.uniform(-1, 1, (4, 48, 18)).astype(np.float32)
+    p = torch.from_numpy(pts).requires_grad_(True)
+    net.zero_grad()
+    with torch.enable_grad():
+        raw = kw["network_query_fn"](p, torch.from_numpy(dirs), net)
+        (raw * torch.from_numpy(draw)).sum().backward()
+    out.update(pts=pts, dirs=dirs, draw=draw, raw=raw.detach().numpy().copy(), dpts=p.grad.numpy().copy(),
+               ck=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd))))
+    for name, prm in net.named_parameters():
+        out["grad__" + name] = prm.grad.numpy().copy()
+    path = os.path.join(OUT, "network_backward.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s every parameter gradient of the network by the reference's autograd  %.2f MB" % ("network_backward", os.path.getsize(path) / 1e6))
+
+
 def fitted_state_dicts():
     """The checkpoint fit_checkpoint.py produced with the reference's modules (tests/golden/fitted_ckpt.npz)."""
     f = np.load(os.path.join(OUT, "fitted_ckpt.npz"))
@@ -550,6 +581,8 @@ def main(only=None):
         export_fixture(torch, R, M, lut)
     if not only or "trunk_backward" in only:
         trunk_backward_fixture(torch, M)
+    if not only or "network_backward" in only:
+        network_backward_fixture(torch, M)
 
     def run_fixture(name, *a, **k):
         if not only or name in only:

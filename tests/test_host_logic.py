@@ -262,7 +262,7 @@ def test_packed_stream_reproduces_oracle_mlp(lib, gain):
     blob = ck.state_dict_to_blob(sd)
     stream = np.zeros(lib.iblnerf_stream_bytes(), dtype=np.uint8)
     tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
-    assert stream.size == (97 + 60 + 16) * 32768 and tab.size == 6176     # the network's layers + the backward streams (trunk; feature / views layers)
+    assert stream.size == (97 + 60 + 16 + 28) * 32768 and tab.size == 6176     # the network's layers + the backward streams (trunk; feature / views layers)
     rc = lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size)
     assert rc == 0
     assert lib.iblnerf_pack_weights_host(blob.ctypes.data, blob.size - 1, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == -1

@@ -313,3 +313,17 @@ def test_trunk_backward_against_reference_autograd(tag):
     assert len(grads) == 18
     for k, v in grads.items():
         assert v.shape == g[tag + "__grad__" + k].shape and rel_linf(v, g[tag + "__grad__" + k]) <= 5e-6, k
+
+
+def test_network_backward_against_reference_autograd():
+    """oracle.network_backward (the written-out backward of the full query) against the reference's loss.backward() through run_network with
+    view directions: all 46 parameter gradients and dL/dpts at float32 round-off."""
+    from ibl_nerf_amd import checkpoint as ck
+    g = np.load(GOLDEN + "/network_backward.npz")
+    sd = ck.synthetic_state_dict(62, 1.0)
+    assert ck.blob_checksum(ck.state_dict_to_blob(sd)) == str(g["ck"])
+    assert rel_linf(O.network_query(sd, g["pts"], g["dirs"]), g["raw"]) <= 2e-6
+    dp, grads = O.network_backward(sd, g["pts"], g["dirs"], g["draw"])
+    assert rel_linf(dp, g["dpts"]) <= 5e-6 and len(grads) == 46
+    for k, v in grads.items():
+        assert v.shape == g["grad__" + k].shape and rel_linf(v, g["grad__" + k]) <= 5e-6, k
