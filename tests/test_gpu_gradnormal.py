@@ -359,3 +359,33 @@ def test_network_backward_vs_reference_autograd(R, lut):
     for k, e in report.items():
         small_head = grads[k].dim() == 2 and grads[k].shape[0] <= 3
         assert e <= (2e-3 if small_head else 1e-3), {k: "%.1e" % v for k, v in report.items()}
+
+
+def test_network_backward_on_the_fitted_checkpoint_and_ragged_sizes(R, lut):
+    """The checkpoint with surfaces (gradients two orders of magnitude larger than on a random-init network: the dynamic loss scale has to step
+    down), ray / sample counts that fill no 128-point group, against the numpy chain (oracle.network_backward, pinned on the reference's
+    autograd); an all-zero upstream gradient gives exactly zero; a colour-independent context is refused."""
+    from ibl_nerf_amd import checkpoint as ck
+    sd = ck.blob_to_state_dict(np.load(GOLDEN + "/fitted_ckpt.npz")["fine"])
+    r = R.Renderer(64, 0, max_rays_per_launch=64)
+    r.load_weights(0, sd)
+    rng = np.random.RandomState(40)
+    for n_rays, n_s in ((3, 37), (1, 1), (9, 64)):
+        pts = rng.uniform(-1.2, 1.2, (n_rays, n_s, 3)).astype(np.float32)
+        dirs = rng.uniform(-1, 1, (n_rays, 3)).astype(np.float32)
+        draw = rng.uniform(-1, 1, (n_rays, n_s, 18)).astype(np.float32)
+        dpo, go = O.network_backward(sd, pts, dirs, draw)
+        dp, grads = r.network_backward(pts, dirs, draw, 0)
+        assert dp.shape == pts.shape and len(grads) == 46
+        e = np.abs(dp.cpu().numpy() - dpo).reshape(-1, 3).max(-1) / max(np.abs(dpo).max(), 1e-30)
+        assert np.percentile(e, 90) <= 2e-3 and e.max() <= 5e-2, (n_rays, n_s, np.percentile(e, 90), e.max())
+        if n_rays * n_s >= 100:       # (sums over a handful of points are dominated by single products' f16 rounding)
+            report = {k: rel_linf(v.cpu().numpy(), go[k]) for k, v in grads.items() if np.abs(go[k]).max() > 0}
+            assert np.median(list(report.values())) <= 1e-3 and max(report.values()) <= 2e-2, {k: "%.1e" % v for k, v in report.items() if v > 1e-3}
+    dz, gz = r.network_backward(pts, dirs, np.zeros_like(draw), 0)
+    assert float(dz.abs().max()) == 0.0 and all(float(v.abs().max()) == 0.0 for v in gz.values())
+    ci = R.Renderer(64, 0, max_rays_per_launch=64, color_independent_to_direction=True)
+    ci.load_weights(0, sd)
+    from ibl_nerf_amd.binding import IblNerfError
+    with pytest.raises(IblNerfError):
+        ci.network_backward(pts, dirs, draw, 0)
