@@ -9,7 +9,7 @@ from torch_ref import RefShaped, torch_query
 torch.manual_seed(0)
 nets = [RefShaped(ck.synthetic_state_dict(i)).cuda() for i in (0, 1)]
 opt = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=5e-4)
-N = 512
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 def step(q):
     loss = 0.0
     for net, S in ((nets[0], 64), (nets[1], 192)):
@@ -30,4 +30,4 @@ a = timeit(torch_query)
 b = timeit(M.training_network_query_fn(torch_query))
 c = timeit(M.training_network_query_fn(torch_query, fused_trunk_backward=True))
 print("queries of one training step: all PyTorch fp32 %.1f ms; no-grad queries on the fused kernel %.1f ms (%.2fx); "
-      "+ the trunk of the gradient-carrying queries fused, forward and backward %.1f ms (%.2fx)" % (a, b, a / b, c, a / c))
+      "+ the gradient-carrying queries fused in both directions (the whole network) %.1f ms (%.2fx)" % (a, b, a / b, c, a / c))
