@@ -740,9 +740,9 @@ int iblnerf_sample_pdf_u(iblnerf_ctx* c, void* stream, const float* d_bins, cons
 
 // Folds a snapshot of the flag words into the context: a flagged slot runs on the bf16x3 kernel from now on.
 static int fold_flags(iblnerf_ctx* c, const unsigned* v) {
-    int any = v[0] ? 1 : 0;
+    int any = (int)(v[0] & 3u);      // bit 0: an activation / input left the f16 range; bit 1: only a backward's gradients did (mlp_kernel.hip)
     for (int slot = 0; slot < N_SLOTS; ++slot)
-        if (v[1 + slot]) { c->mx_ok[slot] = false; any = 1; }
+        if (v[1 + slot]) { c->mx_ok[slot] = false; any |= 1; }
     return any;
 }
 

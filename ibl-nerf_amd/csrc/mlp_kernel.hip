@@ -813,9 +813,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 *reinterpret_cast<f32x4*>(a.out + 4 * p) = o;
             }
 #ifdef IBL_F16X3
-            {   // range guard (see split_pair)
-                const float chk = fmaf(sigma, 0.0f, fmaf(g3[0], 0.0f, fmaf(g3[1], 0.0f, g3[2] * 0.0f)));
-                if (valid && chk != chk && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);
+            {   // range guard (see split_pair).  Bit 0: the forward left the f16 range (sigma is not finite); bit 1: only the backward did —
+                // a loss scale too large for this batch, which the caller answers with a smaller scale, not with the bf16 kernels
+                const float chk = fmaf(g3[0], 0.0f, fmaf(g3[1], 0.0f, g3[2] * 0.0f));
+                const bool fwd_bad = !(fabsf(sigma) < __builtin_inff());
+                if (valid && (fwd_bad || chk != chk) && a.range_flag != nullptr) atomicOr(a.range_flag, fwd_bad ? 1u : 2u);
             }
 #endif
             continue;

@@ -231,9 +231,16 @@ class Renderer:
         """f16_mxfp6 only: True if an MLP launch since the last check left the f16 range (synchronises)."""
         if self.mlp_precision == "bf16x3":
             return False
+        return bool(self.range_bits())
+
+    def range_bits(self):
+        """Synchronises, reads and clears the range flags: bit 0 = a forward activation / input / weight left the f16 range, bit 1 = only the
+        gradients of a fused backward did (a loss scale too large for that batch)."""
+        if self.mlp_precision == "bf16x3":
+            return 0
         flag = C.c_int()
         B.check(self.ctx, self.lib.iblnerf_range_status(self.ctx, C.byref(flag)))
-        return bool(flag.value)
+        return int(flag.value)
 
     def _wide_twin(self, count=True):
         """The bf16x3 context a call is repeated on after an out-of-range event."""
@@ -257,8 +264,18 @@ class Renderer:
             return
         flag, pending = C.c_int(), C.c_int()
         B.check(self.ctx, self.lib.iblnerf_range_peek(self.ctx, C.byref(flag), C.byref(pending)))
-        if flag.value:
+        if flag.value & 1:
             self._went_out_of_range()
+        elif flag.value & 2:                    # only a backward's gradients overflowed: the loss scale was too large for that batch
+            self.out_of_range()                 # clears the device flags (synchronises: once per event)
+            self._grad_overflowed()
+
+    def _grad_overflowed(self):
+        import warnings
+        self._grad_scale = getattr(self, "_grad_scale", 2.0 ** 10) / 64.0
+        warnings.warn("IBL-NeRF HIP renderer: the gradients of an earlier fused backward left the f16 range (range_check='lazy'): that "
+                      "call returned zero gradients (a skipped step); the loss scale is now 2^%d" % int(np.log2(self._grad_scale)),
+                      RuntimeWarning, stacklevel=3)
 
     def _went_out_of_range(self):
         import warnings
@@ -271,8 +288,12 @@ class Renderer:
     def check_range(self):
         """range_check="lazy": synchronise and settle the question for everything issued so far.  True = an out-of-range
         event happened (now or earlier) and the context runs on bf16x3."""
-        if not self._force_wide and self.out_of_range():
-            self._went_out_of_range()
+        if not self._force_wide:
+            bits = self.range_bits()
+            if bits & 1:
+                self._went_out_of_range()
+            elif bits & 2:
+                self._grad_overflowed()
         return self._force_wide
 
     def set_profiling(self, on):
@@ -389,6 +410,38 @@ class Renderer:
             off += o * i + o
         return out[:, 1:].reshape(pts.shape), grads
 
+    def _run_backward(self, up, launch, out, grad, grad_scale, who):
+        """Loss-scale policy around one fused backward.  `launch(up_rows, scale)` issues the kernels.  Eager contexts (and an explicit scale): start
+        where the largest upstream gradient sits at 2^10, step down by 2^6 while the kernels report an overflow (one synchronisation per try).
+        range_check="lazy" contexts (the training hook's) never synchronise: the upstream gradient is normalised to [0.5, 1] by a power of two
+        ON THE DEVICE, the kernels run at the context's persistent scale, a call whose gradients overflowed returns all-zero gradients (a skipped
+        step, as under torch.cuda.amp) and the scale steps down when a later call sees the flag."""
+        torch = _torch()
+        if self.range_check == "lazy" and grad_scale is None and up.numel():
+            self._lazy_poll()
+            if self._force_wide:
+                raise FloatingPointError(who + ": the forward left the f16 range on this context; the fused backward has no bf16x3 form")
+            inv = torch.exp2(torch.ceil(torch.log2(up.abs().amax().clamp_min(1e-30))))          # device scalar, a power of two
+            self.last_grad_scale = getattr(self, "_grad_scale", 2.0 ** 10)
+            launch(up / inv, self.last_grad_scale)
+            ok = torch.isfinite(grad).all() & torch.isfinite(out).all()
+            zero = torch.zeros((), dtype=torch.float32, device=self.device)
+            grad.copy_(torch.where(ok, grad * inv, zero))
+            out[:, 1:] = torch.where(ok, out[:, 1:] * inv, zero)          # (column 0 is sigma)
+            return
+        if grad_scale is None:
+            top = float(up.abs().max()) if up.numel() else 1.0
+            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
+        else:
+            scales = [float(grad_scale)]
+        for sc in scales:
+            launch(up, sc)
+            if not self.out_of_range():
+                break
+        else:
+            raise FloatingPointError("%s: an activation or gradient left the f16 range at every gradient scale tried (%s)" % (who, scales))
+        self.last_grad_scale = sc
+
     def network_backward(self, pts, viewdirs, draw, which=0, grad_scale=None):
         """Backward of network_query(pts, viewdirs): dL/d raw [n_rays, n_samples, 18] -> (dL/dpts, grads) with the gradients of ALL the network's
         parameters in the reference's state-dict shapes (iblnerf_network_backward).  Loss scaling as trunk_backward."""
@@ -398,19 +451,9 @@ class Renderer:
         dr = _dev_f32(draw, self.device).reshape(N * S, 18)
         out = torch.empty((N * S, 4), dtype=torch.float32, device=self.device)
         grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
-        if grad_scale is None:
-            top = float(dr.abs().max()) if N * S else 1.0
-            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
-        else:
-            scales = [float(grad_scale)]
-        for sc in scales:
-            B.check(self.ctx, self.lib.iblnerf_network_backward(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), dr.data_ptr(),
-                                                                sc, out.data_ptr(), grad.data_ptr()))
-            if not self.out_of_range():
-                break
-        else:
-            raise FloatingPointError("network_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
-        self.last_grad_scale = sc
+        self._run_backward(dr, lambda up, sc: B.check(self.ctx, self.lib.iblnerf_network_backward(
+            self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), up.data_ptr(), sc, out.data_ptr(), grad.data_ptr())),
+            out, grad, grad_scale, "network_backward")
         grads, off = {}, 0
         for name, o, i in ck.SCHEMA:
             grads[name + ".weight"] = grad[off:off + o * i].view(o, i)
@@ -436,18 +479,8 @@ class Renderer:
         entry = self.lib.iblnerf_trunk_features_backward if features else self.lib.iblnerf_trunk_backward
         out = torch.empty((flat.shape[0], 4), dtype=torch.float32, device=self.device)
         grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
-        if grad_scale is None:
-            top = float(ds.abs().max()) if ds.numel() else 1.0
-            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
-        else:
-            scales = [float(grad_scale)]
-        for sc in scales:
-            B.check(self.ctx, entry(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], ds.data_ptr(), sc, out.data_ptr(), grad.data_ptr()))
-            if not self.out_of_range():
-                break
-        else:
-            raise FloatingPointError("trunk_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
-        self.last_grad_scale = sc
+        self._run_backward(ds, lambda up, sc: B.check(self.ctx, entry(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], up.data_ptr(), sc,
+                                                                        out.data_ptr(), grad.data_ptr())), out, grad, grad_scale, "trunk_backward")
         grads, off = {}, 0
         for name, o, i in ck.SCHEMA:                         # views into the device blob, reference shapes
             if name.startswith("positions_linears.") or (name.startswith("sigma_linear") and not features):

@@ -198,7 +198,8 @@ int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const fl
  * grad_scale: a power of two applied to dL/dsigma inside the kernels and taken out of every result — the loss scaling of f16
  * training: gradients are stashed as f16, so small ones must be lifted out of the denormals (|dZ| < 6e-5) without the largest
  * reaching 65504; an overflow raises the range flag (iblnerf_range_status) and the results are then invalid: repeat with a
- * smaller scale (ibl-nerf_amd/renderer.py: trunk_backward does that). */
+ * smaller scale (ibl-nerf_amd/renderer.py: trunk_backward does that).  The range entries report WHICH: *out_of_range bit 0 = a forward
+ * activation left the range (the bf16x3 answer), bit 1 = only the gradients of a backward did (the smaller-scale answer). */
 int iblnerf_trunk_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                            float grad_scale, float* d_out, float* d_grad);
 

@@ -389,3 +389,36 @@ def test_network_backward_on_the_fitted_checkpoint_and_ragged_sizes(R, lut):
     from ibl_nerf_amd.binding import IblNerfError
     with pytest.raises(IblNerfError):
         ci.network_backward(pts, dirs, draw, 0)
+
+
+def test_lazy_loss_scaling_never_synchronises_and_skips_an_overflowed_step(R, lut):
+    """range_check="lazy" contexts (the training hook's): the fused backward normalises the upstream gradient on the device and runs at the
+    context's persistent scale — same gradients as the eager path; a scale that overflows the f16 stash gives all-zero gradients for that call
+    (a skipped step), and the next call sees the flag (bit 1: gradients only), warns and steps the scale down; the forward flag (bit 0) is not raised."""
+    from ibl_nerf_amd import checkpoint as ck
+    g = np.load(GOLDEN + "/network_backward.npz")
+    sd = ck.synthetic_state_dict(62, 1.0)
+    eager = R.Renderer(64, 0, max_rays_per_launch=64)
+    lazy = R.Renderer(64, 0, max_rays_per_launch=64, range_check="lazy")
+    for r in (eager, lazy):
+        r.load_weights(0, sd)
+    draw = g["draw"] * np.float32(37.0)                          # any magnitude: the normalisation is by a power of two, exact
+    dp0, g0 = eager.network_backward(g["pts"], g["dirs"], draw, 0)
+    dp1, g1 = lazy.network_backward(g["pts"], g["dirs"], draw, 0)
+    assert rel_linf(dp1.cpu().numpy(), dp0.cpu().numpy()) <= 1e-3
+    for k in g0:
+        assert rel_linf(g1[k].cpu().numpy(), g0[k].cpu().numpy()) <= 1e-3, k
+    lazy._grad_scale = 2.0 ** 40                                 # far too large: the stash overflows
+    dp2, g2 = lazy.network_backward(g["pts"], g["dirs"], draw, 0)
+    assert float(dp2.abs().max()) == 0.0 and all(float(v.abs().max()) == 0.0 for v in g2.values())
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="loss scale"):
+        dp3, g3 = lazy.network_backward(g["pts"], g["dirs"], draw, 0)      # polls, steps the scale down by 2^6 ...
+    assert lazy._grad_scale == 2.0 ** 34 and not lazy._force_wide            # ... and stays on the f16 kernels
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="loss scale"):
+        assert lazy.check_range() is False                                   # (the third call overflowed too, at 2^34: settles it, clears the flags)
+    lazy._grad_scale = 2.0 ** 10
+    dp4, g4 = lazy.network_backward(g["pts"], g["dirs"], draw, 0)
+    for k in g0:
+        assert rel_linf(g4[k].cpu().numpy(), g0[k].cpu().numpy()) <= 1e-3, k
