@@ -259,6 +259,19 @@ def test_fused_trunk_query_in_a_torch_training_loop(R, lut):
             losses[j].append(float(loss.detach()))
     assert losses[0][-1] < 0.7 * losses[0][0]                                # it trains
     assert np.abs(np.array(losses[0]) - np.array(losses[1])).max() <= 2e-2 * losses[1][0], (losses[0], losses[1])
+    # ... and ten more on the MAIN query (view directions: the whole network fused in both directions), a loss on all 18 channels
+    target18 = torch.from_numpy(rng.uniform(-1, 1, (8, 64, 18)).astype(np.float32)).cuda()
+    losses = [[], []]
+    for step in range(10):
+        for j, (net, opt) in enumerate(zip(nets, opts)):
+            opt.zero_grad()
+            out = q(pts, dirs, net) if j == 0 else torch_query(pts, dirs, net)
+            loss = (out - target18).square().mean()
+            loss.backward()
+            opt.step()
+            losses[j].append(float(loss.detach()))
+    assert losses[0][-1] < 0.97 * losses[0][0]
+    assert np.abs(np.array(losses[0]) - np.array(losses[1])).max() <= 2e-2 * losses[1][0], (losses[0], losses[1])
 
 
 def test_trunk_features2_stagewise(R, lut):
