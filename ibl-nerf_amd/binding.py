@@ -21,6 +21,7 @@ EXPORTS = [
     "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query", "iblnerf_render_rays_sampled", "iblnerf_sample_pdf_u",
     "iblnerf_density_gradient", "iblnerf_trunk_backward", "iblnerf_trunk_features", "iblnerf_trunk_features_backward",
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
+    "iblnerf_composite_direct", "iblnerf_composite_direct_backward",
 ]
 
 
@@ -135,6 +136,10 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_trunk_features2_backward.restype = C.c_int
     lib.iblnerf_network_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, C.c_int, FP, FP, C.c_float, FP, FP]
     lib.iblnerf_network_backward.restype = C.c_int
+    lib.iblnerf_composite_direct.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP]
+    lib.iblnerf_composite_direct.restype = C.c_int
+    lib.iblnerf_composite_direct_backward.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
+    lib.iblnerf_composite_direct_backward.restype = C.c_int
     lib.iblnerf_sample_pdf.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP]
     lib.iblnerf_render_rays.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
                                         C.POINTER(Overrides), C.POINTER(Outputs)]

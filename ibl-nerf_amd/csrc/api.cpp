@@ -721,6 +721,29 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     return arm_range_snapshot(c, s);
 }
 
+int iblnerf_composite_direct(iblnerf_ctx* c, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays, int n_samples,
+                             float* d_maps, float* d_weights) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || n_samples > 256 || (n_rays > 0 && (!d_raw || !d_z || !d_rays_d || !d_maps)))
+        return c->fail(IBLNERF_ERR_INVALID, "composite_direct: bad arguments (1 <= n_samples <= 256)");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_composite_direct(d_raw, d_z, d_rays_d, (long)n_rays, n_samples, c->opt.use_radiance_linear, d_maps, d_weights, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_composite_direct_backward(iblnerf_ctx* c, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                                      int n_samples, const float* d_dmaps, const float* d_dweights, float* d_draw) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || n_samples > 256 || (n_rays > 0 && (!d_raw || !d_z || !d_rays_d || !d_dmaps || !d_draw)))
+        return c->fail(IBLNERF_ERR_INVALID, "composite_direct_backward: bad arguments (1 <= n_samples <= 256)");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_composite_direct_backward(d_raw, d_z, d_rays_d, (long)n_rays, n_samples, c->opt.use_radiance_linear, d_dmaps, d_dweights, d_draw,
+                                                (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
                        int n_bins, int n_out, float* d_samples) {
     return iblnerf_sample_pdf_u(c, stream, d_bins, d_weights, n_rays, n_bins, n_out, nullptr, d_samples);

@@ -115,6 +115,11 @@ struct OverrideArgs;
 hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, const float* noise,
                                  long R, int S, const OverrideArgs& ov, float* surf, hipStream_t s);
 
+// the 19 direct maps of one pass from its raw rows, and their backward (render_kernels.hip: k_composite_fwd / k_composite_bwd)
+hipError_t launch_composite_direct(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear, float* maps,
+                                   float* weights, hipStream_t s);
+hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,
+                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s);
 hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,
                                 float* weights, hipStream_t s);   // noise: [R,S] or null
 

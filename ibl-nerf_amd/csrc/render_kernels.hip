@@ -786,6 +786,137 @@ __global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc_bas
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The DIRECT maps of raw2outputs on their own, forward and backward (training: what torch autograd does between the raw rows and the
+// per-ray maps the losses read; ibl_nerf_renderer.py:203-206, 241-259, 281-318).  maps[r] = [depth, acc, albedo(3), roughness, irradiance,
+// radiance(3), radiance_1..3 (9)] = sum_s w_s * act_c(raw[s][c]) (depth: z_s; acc: 1).  Backward: with g_s = dL/dw_s (from all 19 maps and,
+// optionally, from a loss on the weights themselves),
+//   dL/d alpha_s = g_s T_s - (sum_{i>s} g_i w_i) / (1 - alpha_s + 1e-10),    dL/d raw_s0 = that * dist_s exp(-raw_s0 dist_s) [raw_s0 > 0],
+//   dL/d raw_sc  = w_s dL/dmap_c act_c'(raw_sc)                         — the depth-gradient scan of ray_depth_grad with g in place of z.
+constexpr int CM_CH = 19;
+__device__ __forceinline__ int cm_map_of_channel(int c) { return c < 3 ? 2 + c : c == 3 ? 5 : c == 4 ? 6 : 7 + (c - 5); }   // raw channel 1 + c -> map slot
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ zb, const float* __restrict__ rays_d,
+                                                       long R, int S, int radiance_linear, float* __restrict__ maps, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zb + (long)S * r;
+    float z[NPL], zn[NPL], sig[NPL], w[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        zn[i] = s + 1 < S ? zrow[s + 1] : 0.0f;
+        sig[i] = s < S ? raw[((long)r * S + s) * RAW_CH] : 0.0f;
+    }
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+    float m[CM_CH];
+#pragma unroll
+    for (int c = 0; c < CM_CH; ++c) m[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (s < S) {
+            if (weights) weights[(long)r * S + s] = w[i];
+            m[0] += w[i] * z[i];
+            m[1] += w[i];
+            const float* row = raw + ((long)r * S + s) * RAW_CH;
+#pragma unroll
+            for (int c = 0; c < 17; ++c) m[2 + c] += w[i] * (c < 4 ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], radiance_linear));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CM_CH; ++c) m[c] = wave_sum(m[c]);
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < CM_CH; ++c) maps[r * CM_CH + c] = m[c];
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ zb, const float* __restrict__ rays_d,
+                                                       long R, int S, int radiance_linear, const float* __restrict__ dmaps,
+                                                       const float* __restrict__ dweights, float* __restrict__ draw) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zb + (long)S * r;
+    float dm[CM_CH];
+#pragma unroll
+    for (int c = 0; c < CM_CH; ++c) dm[c] = dmaps[r * CM_CH + c];
+    // alpha, transmittance (double prefix product, as the forward), the activations and g_s = dL/dw_s
+    double alpha[NPL], om[NPL], da[NPL], T[NPL], g[NPL];
+    float act[NPL][17], dact[NPL][17];
+    double lane_prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        const bool in = s < S;
+        const float zz = in ? zrow[s] : 0.0f, zn = s + 1 < S ? zrow[s + 1] : 0.0f;
+        const float* row = raw + ((long)r * S + (in ? s : 0)) * RAW_CH;
+        const float sg = in ? row[0] : 0.0f;
+        const float dist = (s == S - 1 ? 1e10f : (zn - zz)) * norm;
+        const float af = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);                      // the forward's float alpha
+        alpha[i] = in ? (double)af : 0.0;
+        om[i] = in ? (double)((1.0f - af) + 1e-10f) : 1.0;
+        da[i] = (in && sg > 0.0f) ? (double)dist * (double)expf(-sg * dist) : 0.0;
+        lane_prod *= om[i];
+        double gs = in ? (double)dm[0] * zz + (double)dm[1] + (dweights ? (double)dweights[(long)r * S + s] : 0.0) : 0.0;
+#pragma unroll
+        for (int c = 0; c < 17; ++c) {
+            const float x = in ? row[1 + c] : 0.0f;
+            float a_, d_;
+            if (c < 4 || !radiance_linear) { a_ = sigmoidf_(x); d_ = a_ * (1.0f - a_); }
+            else { a_ = fmaxf(x, 0.0f); d_ = x > 0.0f ? 1.0f : 0.0f; }
+            act[i][c] = a_;
+            dact[i][c] = d_;
+            if (in) gs += (double)dm[2 + c] * a_;
+        }
+        g[i] = gs;
+    }
+    double incl = lane_prod;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const double o = __shfl_up(incl, dd);
+        if (lane >= dd) incl *= o;
+    }
+    double t = __shfl_up(incl, 1);
+    if (lane == 0) t = 1.0;
+    double lane_gw = 0.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        T[i] = t;
+        lane_gw += g[i] * alpha[i] * t;
+        t *= om[i];
+    }
+    double sfx = lane_gw;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const double o = __shfl_down(sfx, dd);
+        if (lane + dd < 64) sfx += o;
+    }
+    double after = __shfl_down(sfx, 1);
+    if (lane == 63) after = 0.0;
+#pragma unroll
+    for (int i = NPL - 1; i >= 0; --i) {
+        const int s = lane * NPL + i;
+        if (s < S) {
+            float* orow = draw + ((long)r * S + s) * RAW_CH;
+            orow[0] = (float)((g[i] * T[i] - after / om[i]) * da[i]);
+            const float wf = (float)(alpha[i] * T[i]);
+#pragma unroll
+            for (int c = 0; c < 17; ++c) orow[1 + c] = wf * dm[2 + c] * dact[i][c];
+        }
+        after += g[i] * alpha[i] * T[i];
+    }
+}
+
 template <class F>
 hipError_t by_npl(int S, F&& f) {
     const int npl = (S + 63) / 64;
@@ -827,6 +958,23 @@ hipError_t launch_pass_a(const PassAArgs& a, const PassOutputs& out, int gamma, 
     const dim3 grid((unsigned)((a.R + 3) / 4));
     return by_npl(a.S, [&](auto N) {
         hipLaunchKernelGGL(k_pass_a<decltype(N)::value>, grid, dim3(256), 0, s, a, out, gamma);
+    });
+}
+
+hipError_t launch_composite_direct(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear, float* maps,
+                                   float* weights, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((R + 3) / 4));
+    return by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL(k_composite_fwd<decltype(N)::value>, grid, dim3(256), 0, s, raw, z, rays_d, R, S, radiance_linear, maps, weights);
+    });
+}
+hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,
+                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((R + 3) / 4));
+    return by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL(k_composite_bwd<decltype(N)::value>, grid, dim3(256), 0, s, raw, z, rays_d, R, S, radiance_linear, dmaps, dweights, draw);
     });
 }
 

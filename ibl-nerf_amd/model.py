@@ -277,6 +277,43 @@ def fused_query(inputs, viewdirs, network_fn):
     return torch.cat(ret, -1)
 
 
+def fused_composite(raw, z_vals, rays_d, renderer=None):
+    """The compositing of raw2outputs (ibl_nerf_renderer.py:203-206, 241-259, 281-318) as a torch.autograd.Function on the per-ray kernels:
+    raw [n, S, 18] (gradient-carrying), z_vals [n, S], rays_d [n, 3] -> (maps dict {depth_map, acc_map, albedo_map, roughness_map, irradiance_map,
+    radiance_map, radiance_map_1..3}, weights [n, S]).  Gradients flow to `raw` (z_vals and rays_d are treated as constants, as the sample
+    positions are in the reference's training step: sample_pdf's output is detached, nerf_renderer_helper.py:704)."""
+    import torch
+    from . import renderer as R
+    r = renderer if renderer is not None else _composite_renderer(raw.device)
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, raw_, z_, d_):
+            ctx.save_for_backward(raw_, z_, d_)
+            maps, w = r.composite_direct(raw_, z_, d_)
+            return maps, w
+
+        @staticmethod
+        def backward(ctx, gmaps, gw):
+            raw_, z_, d_ = ctx.saved_tensors
+            gmaps = torch.zeros((raw_.shape[0], 19), device=raw_.device) if gmaps is None else gmaps.contiguous()
+            return r.composite_direct_backward(raw_, z_, d_, gmaps, None if gw is None else gw.contiguous()), None, None
+
+    maps, w = _Fn.apply(raw, z_vals, rays_d)
+    return {k: (maps[:, o] if n == 1 else maps[:, o:o + n]) for k, o, n in R.Renderer.MAP_SLOTS}, w
+
+
+_composite_ctx = {}
+
+
+def _composite_renderer(device):
+    from . import renderer as R
+    key = str(device)
+    if key not in _composite_ctx:
+        _composite_ctx[key] = R.Renderer(64, 0, max_rays_per_launch=1, device=device)
+    return _composite_ctx[key]
+
+
 def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):
     """`network_query_fn` for `render_kwargs_train` (train.py:286-297).  In the shipped training
     configuration the eps-normal queries (ibl_nerf_renderer.py:358-361) and the reflected-ray query

@@ -410,6 +410,33 @@ class Renderer:
             off += o * i + o
         return out[:, 1:].reshape(pts.shape), grads
 
+    MAP_SLOTS = (("depth_map", 0, 1), ("acc_map", 1, 1), ("albedo_map", 2, 3), ("roughness_map", 5, 1), ("irradiance_map", 6, 1), ("radiance_map", 7, 3),
+                 ("radiance_map_1", 10, 3), ("radiance_map_2", 13, 3), ("radiance_map_3", 16, 3))
+
+    def composite_direct(self, raw, z_vals, rays_d, want_weights=True):
+        """The direct maps of one raw2outputs pass from its raw rows (ibl_nerf_renderer.py:203-206, 241-259, 281-318): raw [n, S, 18], z_vals [n, S],
+        rays_d [n, 3] -> (maps [n, 19] in MAP_SLOTS order, weights [n, S] or None)."""
+        torch = _torch()
+        raw, z, rd = _dev_f32(raw, self.device), _dev_f32(z_vals, self.device), _dev_f32(rays_d, self.device)
+        n, S = raw.shape[0], raw.shape[1]
+        maps = torch.empty((n, 19), dtype=torch.float32, device=self.device)
+        w = torch.empty((n, S), dtype=torch.float32, device=self.device) if want_weights else None
+        B.check(self.ctx, self.lib.iblnerf_composite_direct(self.ctx, self._stream(), raw.data_ptr(), z.data_ptr(), rd.data_ptr(), n, S, maps.data_ptr(),
+                                                            None if w is None else w.data_ptr()))
+        return maps, w
+
+    def composite_direct_backward(self, raw, z_vals, rays_d, dmaps, dweights=None):
+        """dL/d maps [n, 19] (+ dL/d weights [n, S]) -> dL/d raw [n, S, 18]."""
+        torch = _torch()
+        raw, z, rd = _dev_f32(raw, self.device), _dev_f32(z_vals, self.device), _dev_f32(rays_d, self.device)
+        n, S = raw.shape[0], raw.shape[1]
+        dm = _dev_f32(dmaps, self.device).reshape(n, 19)
+        dw = None if dweights is None else _dev_f32(dweights, self.device).reshape(n, S)
+        draw = torch.empty((n, S, 18), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_composite_direct_backward(self.ctx, self._stream(), raw.data_ptr(), z.data_ptr(), rd.data_ptr(), n, S, dm.data_ptr(),
+                                                                     None if dw is None else dw.data_ptr(), draw.data_ptr()))
+        return draw
+
     def _run_backward(self, up, launch, out, grad, grad_scale, who):
         """Loss-scale policy around one fused backward.  `launch(up_rows, scale)` issues the kernels.  Eager contexts (and an explicit scale): start
         where the largest upstream gradient sits at 2^10, step down by 2^6 while the kernels report an overflow (one synchronisation per try).

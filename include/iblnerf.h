@@ -231,6 +231,16 @@ int iblnerf_trunk_features2_backward(iblnerf_ctx* ctx, void* stream, int which, 
 int iblnerf_network_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
                              const float* d_viewdirs, const float* d_draw, float grad_scale, float* d_out, float* d_grad);
 
+/* replaces: the compositing of raw2outputs WITH its autograd, for a training step (ibl_nerf_renderer.py:203-206, 241-259, 281-318): the 19
+ * direct maps of one pass from its raw rows —  d_maps [n_rays, 19] = [depth, acc, albedo(3), roughness, irradiance, radiance(3),
+ * radiance_1..3 (9)], d_weights [n_rays, S] (optional) — and the backward: dL/d maps [n_rays, 19] (+ optionally dL/d weights) -> dL/d raw
+ * [n_rays, S, 18], which is what iblnerf_network_backward takes.  One wavefront per ray, transmittance and the suffix sums of the backward as
+ * double-precision wave scans.  (The shading between these maps and color_map stays with the caller: ray-sized tensors.) */
+int iblnerf_composite_direct(iblnerf_ctx* ctx, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                             int n_samples, float* d_maps, float* d_weights);
+int iblnerf_composite_direct_backward(iblnerf_ctx* ctx, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d,
+                                      int64_t n_rays, int n_samples, const float* d_dmaps, const float* d_dweights, float* d_draw);
+
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
 int iblnerf_sample_pdf(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights,

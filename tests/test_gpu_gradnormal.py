@@ -435,3 +435,43 @@ def test_lazy_loss_scaling_never_synchronises_and_skips_an_overflowed_step(R, lu
     dp4, g4 = lazy.network_backward(g["pts"], g["dirs"], draw, 0)
     for k in g0:
         assert rel_linf(g4[k].cpu().numpy(), g0[k].cpu().numpy()) <= 1e-3, k
+
+
+def test_composite_direct_forward_against_the_reference_maps_and_backward_against_autograd(R, lut):
+    """iblnerf_composite_direct / _backward.  Forward: the reference's own recorded raw rows of a fixture's fine pass -> the reference's own
+    direct maps of those rays.  Backward: random dL/d maps and dL/d weights against torch autograd through a plain-torch restatement of the
+    compositing (tests/torch_ref.composite_direct, itself checked on the same fixture); then model.fused_composite inside autograd."""
+    from ibl_nerf_amd import model as M
+    from conftest import teacher_pass
+    from torch_ref import composite_direct
+    for name in ("plain_g10", "fitted_plain"):
+        g = load_golden(name)[0]
+        tp = teacher_pass(g, "f")
+        k, S = tp["k"], tp["z"].shape[1]
+        raw, z, rd = tp["raw"], tp["z"], g["rays_d"][:k]
+        r = R.Renderer(64, 128, max_rays_per_launch=64)
+        maps, w = r.composite_direct(raw, z, rd)
+        maps, w = maps.cpu().numpy(), w.cpu().numpy()
+        ref = np.concatenate([g["out__" + kk][:k].reshape(k, -1) for kk in ("depth_map", "acc_map", "albedo_map", "roughness_map", "irradiance_map", "radiance_map")], 1)
+        mine = maps[:, :10].copy()                # albedo, irradiance and radiance leave the reference gamma-corrected (ibl_nerf_renderer.py:480-487)
+        for c in (2, 3, 4, 6, 7, 8, 9):
+            mine[:, c] = (mine[:, c] + np.float32(1e-12)) ** np.float32(1 / 2.2)
+        assert rel_linf(mine, ref) <= 2e-5 and rel_linf(w, g["out__weights"][:k]) <= 2e-5, name
+        t_raw = torch.from_numpy(raw).cuda().requires_grad_(True)
+        tz, trd = torch.from_numpy(z).cuda(), torch.from_numpy(rd).cuda()
+        tm, tw = composite_direct(t_raw, tz, trd)
+        assert rel_linf(maps, tm.detach().cpu().numpy()) <= 2e-5
+        rng = np.random.RandomState(2)
+        dm = torch.from_numpy(rng.uniform(-1, 1, (k, 19)).astype(np.float32)).cuda()
+        dw = torch.from_numpy(rng.uniform(-1, 1, (k, S)).astype(np.float32)).cuda()
+        ((tm * dm).sum() + (tw * dw).sum()).backward()
+        draw = r.composite_direct_backward(raw, z, rd, dm, dw).cpu().numpy()
+        refd = t_raw.grad.cpu().numpy()
+        for ch in range(18):
+            assert rel_linf(draw[..., ch], refd[..., ch]) <= 2e-4, (name, ch, rel_linf(draw[..., ch], refd[..., ch]))
+        # inside autograd
+        t2 = torch.from_numpy(raw).cuda().requires_grad_(True)
+        md, w2 = M.fused_composite(t2, tz, trd, renderer=r)
+        loss = sum((md[kk].reshape(k, -1) * dm[:, o:o + n]).sum() for kk, o, n in R.Renderer.MAP_SLOTS) + (w2 * dw).sum()
+        loss.backward()
+        assert rel_linf(t2.grad.cpu().numpy(), refd) <= 2e-4

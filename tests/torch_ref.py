@@ -59,3 +59,15 @@ def torch_query(inputs, viewdirs, net):
         return net(e).reshape(*inputs.shape[:-1], 1)
     d = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
     return net(e, embed(d, 4)).reshape(*inputs.shape[:-1], 18)
+
+
+def composite_direct(raw, z_vals, rays_d):
+    """The compositing of raw2outputs (ibl_nerf_renderer.py:203-206, 241-259, 281-318) in plain torch, for the autograd comparison:
+    -> (maps [n, 19] = [depth, acc, albedo3, roughness, irradiance, radiance3, radiance_1..3], weights [n, S])."""
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1) * torch.norm(rays_d[..., None, :], dim=-1)
+    alpha = 1.0 - torch.exp(-F.relu(raw[..., 0]) * dists)
+    w = alpha * torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    cols = [torch.sum(w * z_vals, -1, keepdim=True), torch.sum(w, -1, keepdim=True)]
+    cols.append(torch.sum(w[..., None] * torch.sigmoid(raw[..., 1:18]), -2))        # sigmoid on every channel (use_radiance_linear=False)
+    return torch.cat(cols, -1), w
