@@ -308,10 +308,11 @@ _composite_ctx = {}
 
 def _composite_renderer(device):
     from . import renderer as R
-    key = str(device)
-    if key not in _composite_ctx:
-        _composite_ctx[key] = R.Renderer(64, 0, max_rays_per_launch=1, device=device)
-    return _composite_ctx[key]
+    import torch
+    index = device.index if isinstance(device, torch.device) and device.index is not None else torch.cuda.current_device()
+    if index not in _composite_ctx:
+        _composite_ctx[index] = R.Renderer(64, 0, max_rays_per_launch=1, device=index)
+    return _composite_ctx[index]
 
 
 def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):

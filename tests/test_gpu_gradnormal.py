@@ -475,3 +475,40 @@ def test_composite_direct_forward_against_the_reference_maps_and_backward_agains
         loss = sum((md[kk].reshape(k, -1) * dm[:, o:o + n]).sum() for kk, o, n in R.Renderer.MAP_SLOTS) + (w2 * dw).sum()
         loss.backward()
         assert rel_linf(t2.grad.cpu().numpy(), refd) <= 2e-4
+
+
+def test_a_training_step_composes_from_the_fused_pieces(R, lut):
+    """points -> network (fused, both directions) -> compositing (fused, both directions) -> losses on ray-sized maps -> Adam, against the same
+    step in plain torch (torch_query + torch_ref.composite_direct): per-step losses over eight steps, and the parameters at the end."""
+    from ibl_nerf_amd import model as M
+    from torch_ref import RefShaped, torch_query, composite_direct
+    g, sdc, _, _, _ = load_golden("plain_g10")
+    rng = np.random.RandomState(77)
+    n, S = 96, 64
+    o = torch.zeros((n, 3), device="cuda")
+    d = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32)).cuda()
+    z = torch.linspace(0.5, 4.0, S, device="cuda")[None].expand(n, S).contiguous()
+    pts = (o[:, None] + d[:, None] * z[..., None]).contiguous()
+    tgt_rgb = torch.from_numpy(rng.uniform(0, 1, (n, 3)).astype(np.float32)).cuda()
+    tgt_depth = torch.from_numpy(rng.uniform(1, 3, (n,)).astype(np.float32)).cuda()
+    nets = [RefShaped(sdc).cuda(), RefShaped(sdc).cuda()]
+    opts = [torch.optim.Adam(net.parameters(), lr=5e-4) for net in nets]
+    q = M.training_network_query_fn(torch_query, fused_trunk_backward=True)
+    losses = [[], []]
+    for step in range(8):
+        for j, (net, opt) in enumerate(zip(nets, opts)):
+            opt.zero_grad()
+            if j == 0:
+                maps, w = M.fused_composite(q(pts, d, net), z, d)
+                rad, alb, depth = maps["radiance_map"], maps["albedo_map"], maps["depth_map"]
+            else:
+                m, w = composite_direct(torch_query(pts, d, net), z, d)
+                rad, alb, depth = m[:, 7:10], m[:, 2:5], m[:, 0]
+            loss = (rad - tgt_rgb).square().mean() + 0.5 * (alb - tgt_rgb).square().mean() + 0.1 * (depth - tgt_depth).square().mean() + 0.01 * w.square().mean()
+            loss.backward()
+            opt.step()
+            losses[j].append(float(loss.detach()))
+    a, b = np.array(losses[0]), np.array(losses[1])
+    assert a[-1] < a[0] and np.abs(a - b).max() <= 1e-2 * b[0], (a, b)
+    for (k, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert float((pa - pb).detach().abs().max()) <= 5e-3 * max(float(pb.detach().abs().max()), 1e-3) + 2e-3, k     # eight Adam steps of 5e-4 move a weight by <= 4e-3
