@@ -103,6 +103,7 @@ def test_encoder_sincos_error_bound(lib):
 KS_BYTES, CH = 2048, 16
 CH_L0, CH_L1, CH_L5, CH_L6, CH_L7, CH_FEAT, CH_ALB, CH_IRR, CH_VIEW, CH_AR = 0, 2, 34, 44, 52, 60, 68, 72, 76, 85
 CH_G7, CH_G6, CH_G5, CH_G4, CH_G0 = 97, 105, 113, 123, 155      # backward stream of the trunk (layout.h)
+CH_GV, CH_GF, CH_GA, CH_GH = 157, 165, 173, 185                 # ... of feature_linear / views_linears.0, and the K-concatenated head tiles
 TAB_BIAS, TAB_SIG, TAB_ROUGH, TAB_ALB, TAB_IRR, TAB_RAD, TAB_AR, TAB_SCALAR = 0, 3200, 3456, 3712, 4096, 4224, 4992, 6144
 
 
@@ -189,6 +190,63 @@ class Emu:
     def back(self, chunk0, ntiles, dz):    # one backward layer: rows = the layer's input features, K = dZ of its 256 outputs, no bias
         a = self.frag_act(dz.astype(np.float32))
         return np.concatenate([self.ksteps((chunk0 + t) * CH, *a) for t in range(ntiles)], 1).astype(np.float32)
+
+    def back_cat(self, chunk0, operands):
+        """One K-concatenated backward layer (layout.h: CH_GA, CH_GH): 8 row tiles, per tile the k-steps of every operand in order;
+        operands = [dZ [P, 16 * nk] ...] (128-wide ones: nk = 8)."""
+        frs, nks = [], []
+        for dz in operands:
+            nk = dz.shape[1] // 16
+            full = np.zeros((dz.shape[0], 256), np.float32)
+            full[:, :dz.shape[1]] = dz
+            hi, lo = self.frag_act(full)
+            frs.append((hi[:, :nk], lo[:, :nk]))
+            nks.append(nk)
+        per = sum(nks)
+        out = []
+        for t in range(8):
+            ks, o = chunk0 * CH + t * per, 0.0
+            for (hi, lo), nk in zip(frs, nks):
+                o = o + self.ksteps(ks, hi, lo)
+                ks += nk
+            out.append(o)
+        return np.concatenate(out, 1).astype(np.float32)
+
+    def head_input_gradients(self, pts, dirs, draw):
+        """The head part of the VAR_NET_BWD program on the packed stream: FULL's forward, the 128-wide layers' dZ from the head tables, the two
+        K-concatenated tiles and the transposed views / feature layers -> (dL/dh2 before the views layer's pass bits, dL/dh7 before the trunk's)."""
+        emb = O.embed(pts, 10)
+        pe = self.frag_enc(emb, 15, 4)
+        h = self.layer(CH_L0, 8, None, pe, 0)
+        for l in range(1, 5):
+            h = self.layer(CH_L1 + 8 * (l - 1), 8, self.frag_act(h), None, 8 * l)
+        h = self.layer(CH_L5, 8, self.frag_act(h), pe, 40)
+        h = self.layer(CH_L6, 8, self.frag_act(h), None, 48)
+        h7 = self.layer(CH_L7, 8, self.frag_act(h), None, 56)
+        a7 = self.frag_act(h7)
+        feat = self.layer(CH_FEAT, 8, a7, None, 64, relu=False)
+        albf = self.layer(CH_ALB, 4, a7, None, 72)
+        irrf = self.layer(CH_IRR, 4, a7, None, 76)
+        de = self.frag_enc(O.embed(dirs, 4), 6, 2)
+        h2 = self.layer(CH_VIEW, 8, self.frag_act(feat), de, 80)
+        a2 = self.frag_act(h2)
+        d = draw.astype(np.float64)
+        dF = []
+        for k in range(3):
+            f = self.layer(CH_AR + 4 * k, 4, a2, None, 88 + 4 * k)
+            wk = np.stack([self.lane_vec(TAB_AR + (3 * k + c) * 128, 4) for c in range(3)], 0)          # [3, 128]
+            dF.append(((d[:, 9 + 3 * k:12 + 3 * k] @ wk) * (f > 0)).astype(np.float32))
+        rad = np.stack([self.lane_vec(TAB_RAD + c * 256, 8) for c in range(3)], 0)
+        dh2 = self.back_cat(CH_GA, [dF[2], np.concatenate([dF[0], dF[1]], 1)]) + d[:, 6:9] @ rad         # [ARF.2 | ARF.0 | ARF.1] + radiance_linear
+        dzv = (dh2 * (h2 > 0)).astype(np.float32)
+        dfeat = self.back(CH_GV, 8, dzv)
+        alb = np.stack([self.lane_vec(TAB_ALB + c * 128, 4) for c in range(3)], 0)
+        dfa = ((d[:, 1:4] @ alb) * (albf > 0)).astype(np.float32)
+        dfi = ((d[:, 5:6] @ self.lane_vec(TAB_IRR, 4)[None, :]) * (irrf > 0)).astype(np.float32)
+        dh7 = self.back_cat(CH_GH, [np.concatenate([dfa, dfi], 1), dfeat]) \
+            + d[:, 0:1] * self.lane_vec(TAB_SIG, 8)[None, :] + d[:, 4:5] * self.lane_vec(TAB_ROUGH, 8)[None, :]
+        assert np.abs(self.back(CH_GF, 8, dfeat) - self.back_cat(CH_GH, [np.zeros((dfeat.shape[0], 256), np.float32), dfeat])).max() <= 1e-6   # CH_GF = the feature_linear part of CH_GH
+        return dh2, dh7
 
     def density_gradient(self, pts):
         """The VAR_TRUNK_GRAD program on the packed stream: forward keeping the pass masks, dZ(l-1) = (W(l)^T dZ(l)) * mask(l-1) on the
@@ -285,6 +343,32 @@ def test_packed_stream_reproduces_oracle_mlp(lib, gain):
     err = np.abs(ge - gg).max(-1) / np.abs(gg).max()
     assert np.median(err) <= (2e-5 if gain == 1.0 else 2e-4) and err.max() <= 1e-2, (np.median(err), err.max())   # (a pass bit may flip at 2^-17 operands)
     assert np.abs(gg).max() > 0.5
+    # ... and the head layers' transposes (K-concatenated tiles of the whole-network backward): dL/dh2 and dL/dh7 for random dL/d raw against the
+    # plain matrices
+    if gain == 1.0:
+        draw = rng.uniform(-1, 1, (24, 18)).astype(np.float32)
+        dh2, dh7 = emu.head_input_gradients(pts, dirs, draw)
+        W = lambda n: sd[n + ".weight"].astype(np.float64)
+        h = O.embed(pts, 10); e0 = h
+        for i in range(8):
+            h = np.maximum(O._lin(sd, "positions_linears.%d" % i, h), 0)
+            if i == 4:
+                h = np.concatenate([e0, h], -1)
+        h7 = h
+        feat = O._lin(sd, "feature_linear", h7)
+        zv = O._lin(sd, "views_linears.0", np.concatenate([feat, O.embed(dirs, 4)], -1))
+        h2 = np.maximum(zv, 0)
+        d = draw.astype(np.float64)
+        r2 = d[:, 6:9] @ W("radiance_linear")
+        for k in range(3):
+            fk = O._lin(sd, "additional_radiance_feature_linear.%d" % k, h2)
+            r2 = r2 + ((d[:, 9 + 3 * k:12 + 3 * k] @ W("additional_radiance_linear.%d" % k)) * (fk > 0)) @ W("additional_radiance_feature_linear.%d" % k)
+        assert np.abs(dh2 - r2).max() <= 2e-5 * max(1.0, np.abs(r2).max()), np.abs(dh2 - r2).max()
+        r7 = ((r2 * (zv > 0)) @ W("views_linears.0"))[:, :256] @ W("feature_linear") + d[:, 0:1] @ W("sigma_linear") + d[:, 4:5] @ W("roughness_linear")
+        fa, fi = O._lin(sd, "albedo_feature_linear", h7), O._lin(sd, "irradiance_feature_linear", h7)
+        r7 = r7 + ((d[:, 1:4] @ W("albedo_linear")) * (fa > 0)) @ W("albedo_feature_linear") + ((d[:, 5:6] @ W("irradiance_linear")) * (fi > 0)) @ W("irradiance_feature_linear")
+        assert np.abs(dh7 - r7).max() <= 2e-5 * max(1.0, np.abs(r7).max()), np.abs(dh7 - r7).max()
+        assert np.abs(r7).max() > 0.05 and np.abs(r2).max() > 0.05
 
 
 # --------------------------------------------------------------------------------------------
