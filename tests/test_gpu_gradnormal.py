@@ -512,3 +512,27 @@ def test_a_training_step_composes_from_the_fused_pieces(R, lut):
     assert a[-1] < a[0] and np.abs(a - b).max() <= 1e-2 * b[0], (a, b)
     for (k, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
         assert float((pa - pb).detach().abs().max()) <= 5e-3 * max(float(pb.detach().abs().max()), 1e-3) + 2e-3, k     # eight Adam steps of 5e-4 move a weight by <= 4e-3
+
+
+def test_backward_launches_are_bit_identical(R, lut):
+    """Race detector for the backward programs (193 chunks through the same 3-slot LDS ring, hand-counted vmcnt with the stash stores in
+    between): 160 000 points through all 256 persistent workgroups four times — dL/dpts, the stash-fed weight gradients (no atomics on that
+    path) and the density-gradient query give the same bits every time."""
+    from ibl_nerf_amd import checkpoint as ck
+    sd = ck.blob_to_state_dict(np.load(GOLDEN + "/fitted_ckpt.npz")["fine"])
+    r = R.Renderer(64, 0, max_rays_per_launch=64)
+    r.load_weights(0, sd)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pts = (torch.rand((2500, 64, 3), device="cuda", generator=g) * 2.4 - 1.2).contiguous()
+    dirs = (torch.rand((2500, 3), device="cuda", generator=g) * 2 - 1).contiguous()
+    draw = (torch.rand((2500, 64, 18), device="cuda", generator=g) * 2 - 1).contiguous()
+    first = None
+    for _ in range(4):
+        dp, grads = r.network_backward(pts, dirs, draw, 0, grad_scale=4.0)
+        sg = r.density_gradient(pts.reshape(-1, 3), 0)[1]
+        cur = (dp.clone(), grads["positions_linears.3.weight"].clone(), grads["views_linears.0.weight"].clone(), grads["additional_radiance_feature_linear.1.weight"].clone(), sg.clone())
+        assert all(bool(torch.isfinite(t).all()) for t in cur)
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, cur))
