@@ -707,6 +707,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 };
                 using N1 = std::integral_constant<int, 1>;
                 using N3 = std::integral_constant<int, 3>;
+                // the feature layers' outputs are read back from the stash this lane wrote them to: all its stores must have completed first
+                // (once per 128 points; also drains the two prefetched weight chunks, which have long landed)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 {
                     Act DF01;      // dF.0 | dF.1
                     Half DF2;
