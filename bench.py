@@ -124,6 +124,22 @@ def _cpu_worker(job):
     return dt, np.concatenate(out) if out else np.zeros((0, 3), np.float32)
 
 
+def reference_cpu_record(kind):
+    """The reference's own PyTorch-CPU figure for this checkpoint, read from the file tests/golden/time_reference_cpu.py wrote in the build
+    container (the reference cannot travel to the GPU box; its measured timing can).  None if the file is missing."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_cpu_timing.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    ent = rec["checkpoints"].get(kind)
+    if not ent:
+        return None
+    threads = max(ent["threads"], key=int)
+    return {"value": ent["threads"][threads]["rays_per_s"], "unit": "rays/s", "cores": int(threads), "host": rec["host"], "n_rays": rec["n_rays"],
+            "weights_checksum": ent["weights_checksum"], "source": "tests/golden/reference_cpu_timing.json",
+            "note": rec["what"] + " (BASELINE.md section 2b); a recorded figure: the reference cannot travel to the GPU box"}
+
+
 def cpu_baseline(gpu_color_fn, kind, batch=256, batches_per_worker=3, threads=16):
     """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view, on as many of the host's
     cores as it scales to: independent processes of `threads` OpenBLAS threads each (the oracle's many small sgemms run
@@ -148,9 +164,7 @@ def cpu_baseline(gpu_color_fn, kind, batch=256, batches_per_worker=3, threads=16
     mse = float(np.mean((got - ref) ** 2))
     psnr = float(10 * np.log10(1.0 / max(mse, 1e-30)))
     return {"value": n / t, "unit": "rays/s", "cores": int(workers * threads), "kind": "port",
-            "reference_in_build_container": {"value": 131.8 if kind == "fitted" else 144.2, "unit": "rays/s", "cores": 8,
-                                             "note": "the reference's own PyTorch-CPU render_decomp on the same weights, 1 024 rays, 8 threads of an 8-vCPU Xeon 2.1 GHz "
-                                                     "(tests/golden/time_reference_cpu.py, BASELINE.md section 2b); a recorded figure: the reference cannot travel to the GPU box"},
+            "reference_in_build_container": reference_cpu_record(kind),
             "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm), %d processes x %d threads"
                       % (n, workers, threads)}, psnr
 
@@ -187,7 +201,10 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a process group whenever torch.distributed.run launched us — also with one rank, so that `--gpus 1` under the launcher takes the
+    # same pack + all-gather path (RCCL on device buffers) as the multi-GPU runs; a plain `python bench.py` has no group and no exchange
+    grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("IBLNERF_BENCH_GROUP") == "1"
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -213,15 +230,21 @@ def main():
     ro, rd = r.get_rays(H, W, K, c2w, row0, n_rows)     # rays resident in HBM before the timed region
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
 
-    def step():
+    def step(events=None):
         maps = r.render_rays(ro, rd, NEAR, FAR)
-        if world > 1:
+        if grouped:
+            if events:
+                events[0].record()
             buf, _ = D.pack_maps(maps, D.EXPORT_KEYS, n_rows, W)
+            if events:
+                events[1].record()
             D.all_gather_frame(buf, H, W)
+            if events:
+                events[2].record()
         return maps
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +256,7 @@ def main():
         maps = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -273,10 +296,15 @@ def main():
 
     # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
     r.set_profiling(True)
-    step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if grouped else None
+    step(ev)
     torch.cuda.synchronize()
     mlp_ms, n_launch, flop = r.last_mlp_time()
     r.set_profiling(False)
+    # the exchange step on its own (same untimed extra step; events on torch's current stream, where pack and all-gather are enqueued):
+    # packing the export maps into one buffer, and the all-gather (host-staged under the gloo test hook)
+    pack_ms = ev[0].elapsed_time(ev[1]) if grouped else None
+    gather_ms = ev[1].elapsed_time(ev[2]) if grouped else None
     achieved = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
 
     if rank == 0:
@@ -293,7 +321,7 @@ def main():
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
-                                      if world > 1 else "single GPU"},
+                                      if grouped else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "a committed figure, not a counter read in this run: HBM bytes per launch (reads x2-corrected + writes) of the rocprofv3 PMC pass %s; points in + raw outputs out, weights stay in L2" % traffic_src,
@@ -302,6 +330,10 @@ def main():
                          "range_fallbacks": r.range_fallbacks,
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues " + MODES[args.mlp_precision][2]},
         }
+        if grouped:
+            line["pack_ms"], line["gather_ms"] = pack_ms, gather_ms
+            line["exchange"] = {"backend": "RCCL" if backend == "nccl" else backend, "bytes_per_rank": int(n_rows * W * 4 * sum(3 if k in R.MAP_KEYS_3 else 1 for k in D.EXPORT_KEYS)),
+                                "note": "rank 0's pack (torch.cat of the export maps) and all-gather of one untimed extra frame; both are inside the timed step"}
         if value_min is not None:
             line["value_inference_min"] = value_min
         if by_precision:
@@ -314,7 +346,7 @@ def main():
 
             line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color, args.checkpoint)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("IBLNERF_LIB", os.path.join(_HERE, "libiblnerf_hip.so"))   # override: ablation builds only
+LIB_PATH = os.path.join(_HERE, "libiblnerf_hip.so")   # (an ablation build is loaded by passing its path to load_library first)
 
 EXPORTS = [
     "iblnerf_default_options", "iblnerf_create", "iblnerf_destroy", "iblnerf_last_error", "iblnerf_blob_floats",
@@ -21,7 +21,7 @@ EXPORTS = [
     "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query", "iblnerf_render_rays_sampled", "iblnerf_sample_pdf_u",
     "iblnerf_density_gradient", "iblnerf_trunk_backward", "iblnerf_trunk_features", "iblnerf_trunk_features_backward",
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
-    "iblnerf_composite_direct", "iblnerf_composite_direct_backward",
+    "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim",
 ]
 
 
@@ -35,12 +35,14 @@ class Options(C.Structure):
                 ("correct_depth_for_prefiltered_radiance", C.c_int32), ("coarse_outputs", C.c_int32),
                 ("max_rays_per_launch", C.c_int32), ("device", C.c_int32), ("lindisp", C.c_int32),
                 ("use_radiance_linear", C.c_int32), ("normal_mode", C.c_int32), ("color_independent_to_direction", C.c_int32), ("mlp_precision", C.c_int32),
-                ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32)]
+                ("epsilon_direction", C.c_float), ("infer_normal_at_surface", C.c_int32),
+                ("query_routing", C.c_int32), ("persistent_workgroups", C.c_int32)]
 
 
 MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_MAIN, MLP_F16X3_MXFP6X = 0, 1, 2, 3, 4, 5, 6
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
+ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE = 1, 2, 4   # iblnerf_options.query_routing bits
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -90,6 +92,14 @@ def load_library(path: str = LIB_PATH):
     if not os.path.exists(path):
         raise IblNerfError("%s not found: build it with `python ibl-nerf_amd/build.py` "
                            "(there is no CPU fallback for the render path)" % path)
+    try:
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so); this library is linked against /opt/rocm's.  Whichever is loaded FIRST
+        # serves both (same soname) — and it has to be torch's: with /opt/rocm's runtime loaded first, torch initialises a second runtime and
+        # this library's hipGetDeviceCount then reports "no ROCm-capable device" (seen when build() dlopen'ed the library before smoke()
+        # imported torch)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.iblnerf_default_options.argtypes = [C.POINTER(Options)]
     lib.iblnerf_default_options.restype = None
@@ -140,6 +150,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_composite_direct.restype = C.c_int
     lib.iblnerf_composite_direct_backward.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
     lib.iblnerf_composite_direct_backward.restype = C.c_int
+    lib.iblnerf_trim.argtypes = [C.c_void_p]
+    lib.iblnerf_trim.restype = C.c_int
     lib.iblnerf_sample_pdf.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP]
     lib.iblnerf_render_rays.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
                                         C.POINTER(Overrides), C.POINTER(Outputs)]

@@ -93,7 +93,7 @@ def build(verbose=True, force=False):
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, (entry[2] if len(entry) > 2 else src) + ".o")
         stamp = op + ".sha"
-        dg = _digest(_deps(sp), COMMON + flags)
+        dg = _digest(_deps(sp), [f for f in COMMON if not f.startswith("-I")] + flags)   # (not the -I path: the tree may live anywhere)
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or old != dg or not os.path.exists(op):
             jobs.append(([HIPCC] + COMMON + flags + ["-c", sp, "-o", op], stamp, dg))

@@ -29,6 +29,7 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 }  // namespace
 
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
+constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
 static bool wants_mx(int prec) {
     return prec == IBLNERF_MLP_F16_MXFP6 || prec == IBLNERF_MLP_F16_MIXED || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN ||
@@ -67,8 +68,7 @@ struct iblnerf_ctx {
     float* nrm_raw = nullptr;                 // [ws_rays, Smax, 3] normal_mlp samples (allocated with the first IBLNERF_AUX_NORMAL upload)
     float* d_lut = nullptr;
     bool have_lut = false;
-    // measurement / test aids, read from the environment at iblnerf_create: IBLNERF_X_COARSE routes the coarse grid's offset queries,
-    // IBLNERF_X_USER the trunk-only form of iblnerf_network_query, to the mixed TRUNK form (mode IBLNERF_MLP_F16X3_MXFP6X only)
+    // iblnerf_options.query_routing (IBLNERF_ROUTE_*), decoded at iblnerf_create
     bool x_coarse = false, x_user = false, fine_main_precise = false;
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
     size_t bwd_stash_bytes = 0;
@@ -176,6 +176,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
+    if (opts->query_routing < 0 || opts->query_routing > 7 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..7), persistent_workgroups >= 0";
+        return IBLNERF_ERR_INVALID;
+    }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
         g_create_error = "mlp_precision must be IBLNERF_MLP_BF16X3 (0), _F16_MXFP6 (1), _F16_MIXED (2), _F16X3 (3), _F16X3_MXFP6 (4), _F16X3_MAIN (5) or _F16X3_MXFP6X (6)";
         return IBLNERF_ERR_INVALID;
@@ -196,13 +200,10 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     c->opt = *opts;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, opts->device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-    if (const char* e = std::getenv("IBLNERF_GRID")) {   // measurement aid (scratch/): persistent workgroups to launch
-        const int g = std::atoi(e);
-        if (g > 0) c->n_cu = g;
-    }
-    c->x_coarse = std::getenv("IBLNERF_X_COARSE") != nullptr;
-    c->x_user = std::getenv("IBLNERF_X_USER") != nullptr;
-    c->fine_main_precise = std::getenv("IBLNERF_FINE_MAIN_PRECISE") != nullptr;   // measurement aid: the fine main query back on f16x3
+    if (opts->persistent_workgroups > 0) c->n_cu = opts->persistent_workgroups;
+    c->x_coarse = (opts->query_routing & IBLNERF_ROUTE_COARSE_OFFSETS_MIXED) != 0;
+    c->x_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_MIXED) != 0;
+    c->fine_main_precise = (opts->query_routing & IBLNERF_ROUTE_FINE_MAIN_PRECISE) != 0;
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -643,18 +644,23 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, hipMemsetAsync(d_grad, 0, blob_floats() * sizeof(float), s));
     if (n_pts == 0) return IBLNERF_OK;
-    const long groups = (n_pts + 127) / 128, wgs = groups * 4;
-    const size_t need = (size_t)stash_bytes(wgs);
-    WgradArgs w;
-    w.n_split = (int)std::min<long>(28, std::max<long>(1, wgs / 8));
+    // The operand stash costs 15.2 KiB per point, so a call is walked in pieces of at most BWD_CHUNK_POINTS points (whole rays: the kernels
+    // find a point's view direction by its index inside the piece); every piece adds its weight gradients into d_grad.
+    const long rays_per_piece = std::max<long>(1, BWD_CHUNK_POINTS / pts_per_ray);
+    const long piece = std::min<long>((long)n_pts, rays_per_piece * pts_per_ray);
+    const long groups = (piece + 127) / 128, wgs_max = groups * 4;
+    const size_t need = (size_t)stash_bytes(wgs_max);
+    const int n_split_max = (int)std::min<long>(28, std::max<long>(1, wgs_max / 8));
     if (need > c->bwd_stash_bytes) {
         HIP_TRY(c, hipStreamSynchronize(s));
         if (c->bwd_stash) (void)hipFree(c->bwd_stash);
         c->bwd_stash = nullptr; c->bwd_stash_bytes = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->bwd_stash, need));
+        if (hipMalloc((void**)&c->bwd_stash, need) != hipSuccess)
+            return c->fail(IBLNERF_ERR_NOMEM, "trunk_backward: hipMalloc of the %zu MiB operand stash failed (torch's caching allocator may hold the memory: "
+                                              "torch.cuda.empty_cache())", need >> 20);
         c->bwd_stash_bytes = need;
     }
-    const size_t pneed = (size_t)w.n_split * WGRAD_PARTIAL_FLOATS;
+    const size_t pneed = (size_t)n_split_max * WGRAD_PARTIAL_FLOATS;
     if (pneed > c->bwd_partial_floats) {
         HIP_TRY(c, hipStreamSynchronize(s));
         if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -662,63 +668,84 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
         HIP_TRY(c, hipMalloc((void**)&c->bwd_partial, pneed * sizeof(float)));
         c->bwd_partial_floats = pneed;
     }
-    MlpArgs a;
-    a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts; a.dirs = nullptr; a.out = d_out; a.out_stride = 4;
-    a.n_pts = n_pts; a.pts_per_ray = pts_per_ray; a.range_flag = c->d_range_flag; a.dsigma = d_dsigma; a.dh7 = d_dh7; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
-    a.dirs = d_dirs; a.dh2 = d_dh2; a.draw = d_draw;
     const bool net = d_draw != nullptr;
     const bool feat2 = d_dh2 != nullptr || net;
-    HIP_TRY(c, launch_mlp_f16x3(net ? VAR_NET_BWD : feat2 ? VAR_TRUNK_BWD_FEAT2 : d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
-    c->flop_alg += (double)n_pts * 3.0 * (net ? FLOP_FULL : FLOP_TRUNK + (feat2 ? FLOP_FEAT_VIEW : 0.0));
-    w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
-    w.n_gemm = net ? 17 : feat2 ? 12 : 9;
-    w.n_head = 0;
-    w.unscale = 1.0f / grad_scale;
     size_t wo[23], bo[23];
     for (int l = 0; l < 23; ++l) blob_offsets(l, &wo[l], &bo[l]);
-    long part = 0;
-    const long bias_part0 = 9 * 65536L + 2 * 16384L + 8192L + 5 * 32768L;
-    int n_bias = 0;
-    // (k, blob layer, dZ stash, input stash, row length, first column, keeps the layer's bias, output rows)
-    auto gemm_ = [&](int k, int layer, int dz_what, int x_what, int in_dim, int col_base, bool bias, int nrows = 256) {
-        const int ncols = x_what == STASH_ENC ? 64 : x_what == STASH_DENC ? 32 : 256;
-        w.gemm[k] = WgradGemm{dz_what, x_what, nrows, ncols, x_what == STASH_ENC ? PE_PAIRS_PER_HALF : x_what == STASH_DENC ? DE_PAIRS_PER_HALF : 0, in_dim, col_base,
-                              (long)wo[layer], part, bias ? bias_part0 + 512L * n_bias : -1L, (long)bo[layer]};
-        if (bias) ++n_bias;
-        part += (long)nrows * ncols;
-    };
-    auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
-        gemm_(k, layer, STASH_DZ + layer, x_what, in_dim, col_base, !(layer == 5 && x_what != STASH_ENC));   // positions_linears.5: its encoding block keeps the bias
-    };
-    gemm(0, 0, STASH_ENC, 63, 0);
-    for (int l = 1; l <= 4; ++l) gemm(l, l, STASH_X + l - 1, 256, 0);
-    gemm(5, 5, STASH_ENC, 319, 0);            // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
-    gemm(6, 5, STASH_X + 4, 319, 63);
-    gemm(7, 6, STASH_X + 5, 256, 0);
-    gemm(8, 7, STASH_X + 6, 256, 0);
-    if (feat2) {   // blob layers 8 = views_linears.0 ([feature256 | dir27], ibl_nerf.py:194), 9 = feature_linear
-        gemm_(9, 9, STASH_DZF, STASH_X + 7, 256, 0, true);
-        gemm_(10, 8, STASH_DZV, STASH_XF, 283, 0, true);
-        gemm_(11, 8, STASH_DZV, STASH_DENC, 283, 256, false);
-    }
-    if (net) {     // blob layers 11 / 14 = albedo / irradiance feature layers, 17..19 = additional_radiance_feature_linear.k; then the N = 1/3 heads
-        for (int k = 0; k < 3; ++k) gemm_(12 + k, 17 + k, STASH_DF0 + k, STASH_XH2, 256, 0, true, 128);
-        gemm_(15, 11, STASH_DFA, STASH_X + 7, 256, 0, true, 128);
-        gemm_(16, 14, STASH_DFI, STASH_X + 7, 256, 0, true, 128);
-        auto head = [&](int k, int layer, int x_what, int n_ksteps, int nc, int ch0) {
-            w.head[k] = WgradArgs::Head{x_what, n_ksteps, nc, ch0, (long)wo[layer], (long)bo[layer]};
+    for (long p0 = 0; p0 < n_pts; p0 += piece) {
+        const long np = std::min<long>(piece, (long)n_pts - p0);
+        const long wgs = ((np + 127) / 128) * 4;
+        WgradArgs w;
+        w.n_split = (int)std::min<long>(28, std::max<long>(1, wgs / 8));
+        MlpArgs a;
+        a.stream = c->d_stream_f16[which]; a.tables = c->d_tables[which]; a.pts = d_pts + 3 * p0; a.out = d_out + 4 * p0; a.out_stride = 4;
+        a.n_pts = np; a.pts_per_ray = pts_per_ray; a.range_flag = c->d_range_flag; a.stash = c->bwd_stash; a.grad_scale = grad_scale;
+        a.dsigma = d_dsigma ? d_dsigma + p0 : nullptr;
+        a.dh7 = d_dh7 ? d_dh7 + 256 * p0 : nullptr;
+        a.dh2 = d_dh2 ? d_dh2 + 256 * p0 : nullptr;
+        a.draw = d_draw ? d_draw + RAW_CH * p0 : nullptr;
+        a.dirs = d_dirs ? d_dirs + 3 * (p0 / pts_per_ray) : nullptr;
+        HIP_TRY(c, launch_mlp_f16x3(net ? VAR_NET_BWD : feat2 ? VAR_TRUNK_BWD_FEAT2 : d_dh7 ? VAR_TRUNK_BWD_FEAT : VAR_TRUNK_BWD, a, c->n_cu, s));
+        c->flop_alg += (double)np * 3.0 * (net ? FLOP_FULL : FLOP_TRUNK + (feat2 ? FLOP_FEAT_VIEW : 0.0));
+        w.stash = c->bwd_stash; w.partial = c->bwd_partial; w.grad = d_grad; w.wave_groups = wgs; w.partial_stride = WGRAD_PARTIAL_FLOATS;
+        w.n_gemm = net ? 17 : feat2 ? 12 : 9;
+        w.n_head = 0;
+        w.unscale = 1.0f / grad_scale;
+        long part = 0;
+        const long bias_part0 = 9 * 65536L + 2 * 16384L + 8192L + 5 * 32768L;
+        int n_bias = 0;
+        // (k, blob layer, dZ stash, input stash, row length, first column, keeps the layer's bias, output rows)
+        auto gemm_ = [&](int k, int layer, int dz_what, int x_what, int in_dim, int col_base, bool bias, int nrows = 256) {
+            const int ncols = x_what == STASH_ENC ? 64 : x_what == STASH_DENC ? 32 : 256;
+            w.gemm[k] = WgradGemm{dz_what, x_what, nrows, ncols, x_what == STASH_ENC ? PE_PAIRS_PER_HALF : x_what == STASH_DENC ? DE_PAIRS_PER_HALF : 0, in_dim, col_base,
+                                  (long)wo[layer], part, bias ? bias_part0 + 512L * n_bias : -1L, (long)bo[layer]};
+            if (bias) ++n_bias;
+            part += (long)nrows * ncols;
         };
-        head(0, 10, STASH_X + 7, 16, 1, 0);            // sigma_linear
-        head(1, 13, STASH_X + 7, 16, 1, 4);            // roughness_linear
-        head(2, 12, STASH_FA, 8, 3, 1);                // albedo_linear
-        head(3, 15, STASH_FI, 8, 1, 5);                // irradiance_linear
-        head(4, 16, STASH_XH2, 16, 3, 6);              // radiance_linear
-        for (int k = 0; k < 3; ++k) head(5 + k, 20 + k, STASH_F0 + k, 8, 3, 9 + 3 * k);   // additional_radiance_linear.k
-        w.n_head = 8;
+        auto gemm = [&](int k, int layer, int x_what, int in_dim, int col_base) {
+            gemm_(k, layer, STASH_DZ + layer, x_what, in_dim, col_base, !(layer == 5 && x_what != STASH_ENC));   // positions_linears.5: its encoding block keeps the bias
+        };
+        gemm(0, 0, STASH_ENC, 63, 0);
+        for (int l = 1; l <= 4; ++l) gemm(l, l, STASH_X + l - 1, 256, 0);
+        gemm(5, 5, STASH_ENC, 319, 0);            // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
+        gemm(6, 5, STASH_X + 4, 319, 63);
+        gemm(7, 6, STASH_X + 5, 256, 0);
+        gemm(8, 7, STASH_X + 6, 256, 0);
+        if (feat2) {   // blob layers 8 = views_linears.0 ([feature256 | dir27], ibl_nerf.py:194), 9 = feature_linear
+            gemm_(9, 9, STASH_DZF, STASH_X + 7, 256, 0, true);
+            gemm_(10, 8, STASH_DZV, STASH_XF, 283, 0, true);
+            gemm_(11, 8, STASH_DZV, STASH_DENC, 283, 256, false);
+        }
+        if (net) {     // blob layers 11 / 14 = albedo / irradiance feature layers, 17..19 = additional_radiance_feature_linear.k; then the N = 1/3 heads
+            for (int k = 0; k < 3; ++k) gemm_(12 + k, 17 + k, STASH_DF0 + k, STASH_XH2, 256, 0, true, 128);
+            gemm_(15, 11, STASH_DFA, STASH_X + 7, 256, 0, true, 128);
+            gemm_(16, 14, STASH_DFI, STASH_X + 7, 256, 0, true, 128);
+            auto head = [&](int k, int layer, int x_what, int n_ksteps, int nc, int ch0) {
+                w.head[k] = WgradArgs::Head{x_what, n_ksteps, nc, ch0, (long)wo[layer], (long)bo[layer]};
+            };
+            head(0, 10, STASH_X + 7, 16, 1, 0);            // sigma_linear
+            head(1, 13, STASH_X + 7, 16, 1, 4);            // roughness_linear
+            head(2, 12, STASH_FA, 8, 3, 1);                // albedo_linear
+            head(3, 15, STASH_FI, 8, 1, 5);                // irradiance_linear
+            head(4, 16, STASH_XH2, 16, 3, 6);              // radiance_linear
+            for (int k = 0; k < 3; ++k) head(5 + k, 20 + k, STASH_F0 + k, 8, 3, 9 + 3 * k);   // additional_radiance_linear.k
+            w.n_head = 8;
+        }
+        w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
+        HIP_TRY(c, launch_wgrad(w, net ? a.draw : a.dsigma, np, s));
     }
-    w.sigma_w_off = (long)wo[10]; w.sigma_b_off = (long)bo[10];
-    HIP_TRY(c, launch_wgrad(w, net ? d_draw : d_dsigma, (long)n_pts, s));
     return arm_range_snapshot(c, s);
+}
+
+int iblnerf_trim(iblnerf_ctx* c) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->bwd_stash) (void)hipFree(c->bwd_stash);
+    if (c->bwd_partial) (void)hipFree(c->bwd_partial);
+    c->bwd_stash = nullptr; c->bwd_stash_bytes = 0;
+    c->bwd_partial = nullptr; c->bwd_partial_floats = 0;
+    return IBLNERF_OK;
 }
 
 int iblnerf_composite_direct(iblnerf_ctx* c, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays, int n_samples,
@@ -1050,6 +1077,9 @@ int iblnerf_composite_pass(iblnerf_ctx* c, void* stream, const float* d_rays_o, 
     OverrideArgs ov;
     const float* gt_normal = nullptr;
     if (int rc = parse_overrides(c, ovr, ov, gt_normal)) return rc;
+    if (c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT || c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION)
+        return c->fail(IBLNERF_ERR_STATE, "composite_pass: not built for the two depth-gradient normal modes (their pass reads [n, S, 4] density-gradient "
+                                          "rows, not the [4, n, S] offset densities this entry takes)");
     const bool offsets = !gt_normal && c->opt.normal_mode != IBLNERF_NORMAL_INFERRED;
     if (offsets && !in->d_sigma_offsets) return c->fail(IBLNERF_ERR_INVALID, "composite_pass: this normal mode needs d_sigma_offsets");
     if (c->opt.normal_mode == IBLNERF_NORMAL_INFERRED && !in->d_normal_raw)

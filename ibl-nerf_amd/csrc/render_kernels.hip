@@ -669,6 +669,34 @@ __global__ __launch_bounds__(256) void k_surface_points(const float* __restrict_
         for (int c = 0; c < 3; ++c) surf[3 * r + c] = rays_o[3 * r + c] + d[c] * tdepth;   // :262
 }
 
+// torch.sum(weights + 1e-5, -1) of one row of n floats, BIT FOR BIT as ATen's CPU kernel forms it (cascade sum of cpu/SumKernel.cpp with
+// 8-float vectors: vectorized_inner_sum -> row_sum (4 interleaved partial rows; the cascade levels never fill below 512 elements) -> the
+// row's tail, then the 8 vector lanes, sequentially).  Why the order matters: sample_pdf replaces denominators below 1e-5 by 1
+// (nerf_renderer_helper.py:128-129), and an EMPTY bin's denominator is 1e-5 / sum = 9.994e-6 +- one fp32 ulp of the cdf (6e-8): 167 or 168
+// ulps, i.e. on either side of the threshold, depending on the last bit of `sum`.  A sample then lands at the bin's edge or in its interior
+// (0.04 apart on the coarse grid) — invisible unless the "empty" bin hides a thin structure (1 ray in 25 000 of the fitted checkpoint:
+// depth off by 3e-3).  The emulated order is pinned against torch.sum itself in tests/test_oracle_golden.py.
+// Returns the sum on every lane.  n < 512.
+__device__ __forceinline__ float aten_row_sum_eps(const float* __restrict__ wts, int n, int lane) {
+    const int vs = n >> 3, size_ilp = vs >> 2;
+    const int c = lane & 7, k = (lane >> 3) & 3;
+    float p = 0.0f;
+    if (lane < 32) {
+        for (int i = 0; i < size_ilp; ++i) p += wts[8 * (4 * i + k) + c] + 1e-5f;          // partial row k of vector lane c
+        if (k == 0)
+            for (int j = 4 * size_ilp; j < vs; ++j) p += wts[8 * j + c] + 1e-5f;           // the vectors beyond the last group of four
+    }
+    float P = p;                                                                            // ((p0 + p1) + p2) + p3, valid on lanes 0..7
+    P += __shfl(p, c + 8);
+    P += __shfl(p, c + 16);
+    P += __shfl(p, c + 24);
+    float fin = 0.0f;
+    for (int t = 8 * vs; t < n; ++t) fin += wts[t] + 1e-5f;                                 // the row's tail, then the vector lanes in order
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) fin += __shfl(P, cc);
+    return fin;
+}
+
 // sample_pdf(det=True), nerf_renderer_helper.py:91-134, for one ray held by one wavefront.
 // cdf/bins live in LDS (nb <= 257).  Writes n_out samples to `dst` (LDS or global).
 // u_row: this ray's n_out uniform draws (det=False, :103), or null for u = linspace(0, 1, n_out) (det=True, :100-101)
@@ -679,14 +707,12 @@ __device__ __forceinline__ void sample_pdf_wave(const float* __restrict__ wts, i
     // lane owns weights lane*NPL .. (contiguous) so the cumulative sum is lane-local + wave scan
     const int npl = (nw + 63) / 64;
     float wl[MAX_NPL + 1];
-    float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < MAX_NPL + 1; ++i) {
         const int k = lane * npl + i;
         wl[i] = (i < npl && k < nw) ? wts[k] + 1e-5f : 0.0f;
-        lsum += wl[i];
     }
-    const float tot = wave_sum(lsum);
+    const float tot = aten_row_sum_eps(wts, nw, lane);   // torch.sum's own summation order: the 1e-5 threshold below sits one ulp from an empty bin
     double run = 0.0, lane_tot = 0.0;
     float pdf[MAX_NPL + 1];
 #pragma unroll

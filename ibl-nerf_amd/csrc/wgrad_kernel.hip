@@ -189,14 +189,14 @@ __global__ void k_wgrad_reduce(WgradArgs a) {
     }
     float acc = 0.0f;
     for (int s = 0; s < a.n_split; ++s) acc += a.partial[(size_t)s * a.partial_stride + gm.part_off + idx];
-    a.grad[gm.blob_off + (size_t)m * gm.in_dim + gm.col_base + col] = acc * a.unscale;
+    a.grad[gm.blob_off + (size_t)m * gm.in_dim + gm.col_base + col] += acc * a.unscale;   // (+=: the caller zeroes the blob and may walk the points in pieces)
     if (gm.bias_part >= 0 && n == 0) {      // the layer's bias gradient: both lane halves of every split
         float b = 0.0f;
         for (int s = 0; s < a.n_split; ++s) {
             const float* bp = a.partial + (size_t)s * a.partial_stride + gm.bias_part;
             b += bp[m] + bp[256 + m];
         }
-        a.grad[gm.bias_off + m] = b * a.unscale;
+        a.grad[gm.bias_off + m] += b * a.unscale;
     }
 }
 

@@ -97,7 +97,8 @@ def render_frame_sharded(render_tile: Callable[[int, int], Dict[str, "object"]],
     """`render_tile(row0, n_rows)` renders this rank's rows and returns maps shaped [n_rows*W, ...] or
     [n_rows, W, ...].  Returns the full-frame maps ([H, W, ...]) on every rank."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    grouped = dist.is_available() and dist.is_initialized()
+    if grouped:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
@@ -105,7 +106,7 @@ def render_frame_sharded(render_tile: Callable[[int, int], Dict[str, "object"]],
     maps = render_tile(row0, n)
     keys = list(keys) + [k for k in ("inferred_normal_map",) if k in maps and k not in keys]   # present under infer_normal only
     buf, layout = pack_maps(maps, keys, n, W)
-    full = buf if world == 1 else all_gather_frame(buf, H, W, group)
+    full = all_gather_frame(buf, H, W, group) if grouped else buf     # (a one-rank group still goes through the collective)
     return unpack_maps(full, layout)
 
 

@@ -67,7 +67,7 @@ class Renderer:
                  correct_depth_for_prefiltered_radiance_infer=True, coarse_outputs=True,
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
-                 epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager"):
+                 epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager", query_routing=0, persistent_workgroups=0):
         """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6x" (default: three f16 products on hi/lo splits, ~2^-22
         per operand, for the coarse pass's main query, auxiliary networks and the coarse grid's offset queries; the fine pass's
         offset queries on the fast kernel's mixed trunk form — its first two layers as three f16 products, the others as one f16 +
@@ -82,7 +82,10 @@ class Renderer:
         for frame-sized calls whose results are read back anyway); "lazy" never synchronises: each call looks at the
         snapshot its predecessors left behind (iblnerf_range_peek), and on an out-of-range event warns that the flagged
         call's results were invalid and moves every later call to the bf16x3 context (the training hook's mode: many
-        small queries per step; `check_range()` forces the question, e.g. once per step)."""
+        small queries per step; `check_range()` forces the question, e.g. once per step).
+        query_routing: iblnerf_options.query_routing, a set of binding.ROUTE_* bits or their names ("coarse_offsets_mixed",
+        "user_trunk_mixed", "fine_main_precise"): measured deviations from the mode's query-class table (A/B aids and tests of one
+        kernel form on its own).  persistent_workgroups: MLP launches with that many workgroups instead of one per CU."""
         torch = _torch()
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
         if mlp_precision not in B.MLP_PRECISIONS:
@@ -114,6 +117,10 @@ class Renderer:
         o.mlp_precision = B.MLP_PRECISIONS[mlp_precision]
         o.normal_mode = NORMAL_MODES[normal_mode]
         o.color_independent_to_direction = int(bool(color_independent_to_direction))
+        if not isinstance(query_routing, int):
+            names = [query_routing] if isinstance(query_routing, str) else list(query_routing)
+            query_routing = sum(getattr(B, "ROUTE_" + n.upper()) for n in names)
+        o.query_routing, o.persistent_workgroups = int(query_routing), int(persistent_workgroups)
         self.normal_mode = normal_mode
         self.mlp_precision = mlp_precision
         self._ctor = dict(N_samples=N_samples, N_importance=N_importance, epsilon=epsilon, gamma_correct=gamma_correct,
@@ -122,7 +129,7 @@ class Renderer:
                           coarse_outputs=coarse_outputs, max_rays_per_launch=max_rays_per_launch, device=device,
                           lindisp=lindisp, use_radiance_linear=use_radiance_linear, normal_mode=normal_mode,
                           color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction,
-                          infer_normal_at_surface=infer_normal_at_surface, range_check=range_check)
+                          infer_normal_at_surface=infer_normal_at_surface, range_check=range_check, persistent_workgroups=persistent_workgroups)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
@@ -228,10 +235,11 @@ class Renderer:
                 self._wide.load_lut(lut)
 
     def out_of_range(self):
-        """f16_mxfp6 only: True if an MLP launch since the last check left the f16 range (synchronises)."""
+        """The f16 modes: True if a FORWARD launch since the last check left the f16 range (synchronises, clears the flags).  Bit 1 of the
+        flags (only the gradients of a fused backward overflowed) is not a forward failure: the backward entry points read range_bits()."""
         if self.mlp_precision == "bf16x3":
             return False
-        return bool(self.range_bits())
+        return bool(self.range_bits() & 1)
 
     def range_bits(self):
         """Synchronises, reads and clears the range flags: bit 0 = a forward activation / input / weight left the f16 range, bit 1 = only the
@@ -264,22 +272,48 @@ class Renderer:
             return
         flag, pending = C.c_int(), C.c_int()
         B.check(self.ctx, self.lib.iblnerf_range_peek(self.ctx, C.byref(flag), C.byref(pending)))
-        if flag.value & 1:
-            self._went_out_of_range()
-        elif flag.value & 2:                    # only a backward's gradients overflowed: the loss scale was too large for that batch
-            self.out_of_range()                 # clears the device flags (synchronises: once per event)
+        if flag.value & 3:
+            self._settle(self.range_bits())     # synchronises and clears the device flags: once per event.  The snapshot can be older
+                                                # than the flags (launches issued since), so the decision is taken on what was cleared.
+
+    def _settle(self, bits):
+        """Acts on range bits that have just been read AND cleared: bit 0 (a forward left the range) wins over bit 1 (a loss scale too large)."""
+        if bits & 1:
+            self._went_out_of_range(clear=False)
+        elif bits & 2:
             self._grad_overflowed()
+
+    # Loss scale of the lazy (sync-free) fused backward, torch.cuda.amp.GradScaler's policy: the upstream gradient is normalised to
+    # [0.5, 1] on the device, so the scale only has to keep the chain's growth inside f16.  An overflow skips the step and divides the
+    # scale by 64 (never below 1: beneath that the normalised upstream gradient itself starts to fall into the f16 denormals and small dZ
+    # would be truncated silently); GROWTH_INTERVAL clean backward calls in a row double it again, up to the starting value.
+    GRAD_SCALE_INIT, GRAD_SCALE_MIN, GRAD_SCALE_BACKOFF, GROWTH_INTERVAL = 2.0 ** 10, 1.0, 64.0, 200
 
     def _grad_overflowed(self):
         import warnings
-        self._grad_scale = getattr(self, "_grad_scale", 2.0 ** 10) / 64.0
-        warnings.warn("IBL-NeRF HIP renderer: the gradients of an earlier fused backward left the f16 range (range_check='lazy'): that "
-                      "call returned zero gradients (a skipped step); the loss scale is now 2^%d" % int(np.log2(self._grad_scale)),
-                      RuntimeWarning, stacklevel=3)
+        before = getattr(self, "_grad_scale", self.GRAD_SCALE_INIT)
+        self._grad_scale = max(before / self.GRAD_SCALE_BACKOFF, self.GRAD_SCALE_MIN)
+        self._clean_steps = 0
+        self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+        if before <= self.GRAD_SCALE_MIN:
+            warnings.warn("IBL-NeRF HIP renderer: a fused backward overflowed f16 at the minimum loss scale 2^0 (range_check='lazy'): "
+                          "that call returned zero gradients; this network's gradients do not fit the f16 stash", RuntimeWarning, stacklevel=3)
+        else:
+            warnings.warn("IBL-NeRF HIP renderer: the gradients of an earlier fused backward left the f16 range (range_check='lazy'): that "
+                          "call returned zero gradients (skipped step %d); the loss scale is now 2^%d" % (self.skipped_steps, int(np.log2(self._grad_scale))),
+                          RuntimeWarning, stacklevel=3)
 
-    def _went_out_of_range(self):
+    def _grad_step_clean(self):
+        """One more lazy backward issued with no overflow seen since the last one: grow the scale back after GROWTH_INTERVAL of them."""
+        self._clean_steps = getattr(self, "_clean_steps", 0) + 1
+        if self._clean_steps >= self.GROWTH_INTERVAL and getattr(self, "_grad_scale", self.GRAD_SCALE_INIT) < self.GRAD_SCALE_INIT:
+            self._grad_scale *= 2.0
+            self._clean_steps = 0
+
+    def _went_out_of_range(self, clear=True):
         import warnings
-        self.out_of_range()                     # clears the device flags (synchronises: once per event)
+        if clear:
+            self.range_bits()                   # clears the device flags (synchronises: once per event)
         self._force_wide = True
         self._wide_twin()
         warnings.warn("IBL-NeRF HIP renderer: an earlier f16 + MX-fp6 MLP launch left the f16 range (range_check='lazy'): that "
@@ -289,12 +323,12 @@ class Renderer:
         """range_check="lazy": synchronise and settle the question for everything issued so far.  True = an out-of-range
         event happened (now or earlier) and the context runs on bf16x3."""
         if not self._force_wide:
-            bits = self.range_bits()
-            if bits & 1:
-                self._went_out_of_range()
-            elif bits & 2:
-                self._grad_overflowed()
+            self._settle(self.range_bits())
         return self._force_wide
+
+    def trim(self):
+        """Frees the fused backward's workspace (iblnerf_trim)."""
+        B.check(self.ctx, self.lib.iblnerf_trim(self.ctx))
 
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
@@ -362,10 +396,27 @@ class Renderer:
         pts = _dev_f32(pts, self.device)
         flat = pts.reshape(-1, 3)
         out = torch.empty((flat.shape[0], 256), dtype=torch.float32, device=self.device)
+        self._before_feature_query("trunk_features")
         B.check(self.ctx, self.lib.iblnerf_trunk_features(self.ctx, self._stream(), int(which), flat.data_ptr(), flat.shape[0], out.data_ptr()))
-        if self.out_of_range():
-            raise FloatingPointError("trunk_features: an activation left the f16 range")
+        self._after_feature_query("trunk_features")
         return out.reshape(pts.shape[:-1] + (256,))
+
+    def _before_feature_query(self, who):
+        """The fused feature queries exist on the f16x3 stream only (no bf16x3 form to repeat on).  range_check="lazy": look at the snapshot of
+        earlier calls without synchronising — a forward range event there raises, a gradient overflow goes to the loss-scale policy."""
+        if self.range_check == "lazy":
+            self._lazy_poll()
+            if self._force_wide:
+                raise FloatingPointError(who + ": an activation left the f16 range on this context; this query has no bf16x3 form")
+
+    def _after_feature_query(self, who):
+        if self.range_check == "lazy":
+            return
+        bits = self.range_bits()              # eager: one synchronisation per call
+        if bits & 1:
+            raise FloatingPointError(who + ": an activation left the f16 range")
+        if bits & 2:                          # left behind by an earlier backward: not this call's failure
+            self._grad_overflowed()
 
     def trunk_features2(self, pts, viewdirs, which=0):
         """trunk_features one layer pair further (ibl_nerf.py:193-197): (h7, h2) with h2 = relu(views_linears.0([feature_linear(h7), dir27])),
@@ -375,9 +426,9 @@ class Renderer:
         N, S = pts.shape[0], pts.shape[1]
         h7 = torch.empty((N, S, 256), dtype=torch.float32, device=self.device)
         h2 = torch.empty((N, S, 256), dtype=torch.float32, device=self.device)
+        self._before_feature_query("trunk_features2")
         B.check(self.ctx, self.lib.iblnerf_trunk_features2(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), h7.data_ptr(), h2.data_ptr()))
-        if self.out_of_range():
-            raise FloatingPointError("trunk_features2: an activation left the f16 range")
+        self._after_feature_query("trunk_features2")
         return h7, h2
 
     def trunk_features2_backward(self, pts, viewdirs, dh7, dh2, which=0, grad_scale=None):
@@ -386,22 +437,12 @@ class Renderer:
         torch = _torch()
         pts, vd = _dev_f32(pts, self.device), _dev_f32(viewdirs, self.device)
         N, S = pts.shape[0], pts.shape[1]
-        g7, g2 = _dev_f32(dh7, self.device).reshape(N * S, 256), _dev_f32(dh2, self.device).reshape(N * S, 256)
+        up = torch.stack([_dev_f32(dh7, self.device).reshape(N * S, 256), _dev_f32(dh2, self.device).reshape(N * S, 256)])   # one tensor: one common scale
         out = torch.empty((N * S, 4), dtype=torch.float32, device=self.device)
         grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
-        if grad_scale is None:
-            top = max(float(g7.abs().max()), float(g2.abs().max())) if N * S else 1.0
-            scales = [2.0 ** (10 - int(np.ceil(np.log2(top))) - 6 * k) for k in range(4)] if top > 0 and np.isfinite(top) else [1.0]
-        else:
-            scales = [float(grad_scale)]
-        for sc in scales:
-            B.check(self.ctx, self.lib.iblnerf_trunk_features2_backward(self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(),
-                                                                        g7.data_ptr(), g2.data_ptr(), sc, out.data_ptr(), grad.data_ptr()))
-            if not self.out_of_range():
-                break
-        else:
-            raise FloatingPointError("trunk_features2_backward: an activation or gradient left the f16 range at every gradient scale tried (%s)" % scales)
-        self.last_grad_scale = sc
+        self._run_backward(up, lambda u, sc: B.check(self.ctx, self.lib.iblnerf_trunk_features2_backward(
+            self.ctx, self._stream(), int(which), pts.data_ptr(), N, S, vd.data_ptr(), u[0].data_ptr(), u[1].data_ptr(), sc, out.data_ptr(), grad.data_ptr())),
+            out, grad, grad_scale, "trunk_features2_backward")
         grads, off = {}, 0
         for name, o, i in ck.SCHEMA:
             if name.startswith(("positions_linears.", "feature_linear", "views_linears.0")):
@@ -449,7 +490,8 @@ class Renderer:
             if self._force_wide:
                 raise FloatingPointError(who + ": the forward left the f16 range on this context; the fused backward has no bf16x3 form")
             inv = torch.exp2(torch.ceil(torch.log2(up.abs().amax().clamp_min(1e-30))))          # device scalar, a power of two
-            self.last_grad_scale = getattr(self, "_grad_scale", 2.0 ** 10)
+            self._grad_step_clean()               # (an overflow of an earlier call was settled by _lazy_poll above and reset the count)
+            self.last_grad_scale = getattr(self, "_grad_scale", self.GRAD_SCALE_INIT)
             launch(up / inv, self.last_grad_scale)
             ok = torch.isfinite(grad).all() & torch.isfinite(out).all()
             zero = torch.zeros((), dtype=torch.float32, device=self.device)
@@ -463,10 +505,13 @@ class Renderer:
             scales = [float(grad_scale)]
         for sc in scales:
             launch(up, sc)
-            if not self.out_of_range():
+            bits = self.range_bits()              # synchronises; bit 0 = a forward activation, bit 1 = only the gradients
+            if bits & 1:                          # no loss scale repairs a forward overflow
+                raise FloatingPointError("%s: a forward activation left the f16 range; the fused backward has no bf16x3 form" % who)
+            if not bits and bool(torch.isfinite(grad).all()) and bool(torch.isfinite(out).all()):
                 break
         else:
-            raise FloatingPointError("%s: an activation or gradient left the f16 range at every gradient scale tried (%s)" % (who, scales))
+            raise FloatingPointError("%s: the gradients left the f16 range at every gradient scale tried (%s)" % (who, scales))
         self.last_grad_scale = sc
 
     def network_backward(self, pts, viewdirs, draw, which=0, grad_scale=None):

@@ -99,7 +99,19 @@ typedef struct {
                                           IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON */
     int32_t infer_normal_at_surface;   /* 0 | 1: the IBLNERF_AUX_NORMAL network is evaluated once per ray at the surface point
                                           o + d * target_depth instead of at every sample (ibl_nerf_renderer.py:268-271) */
+    int32_t query_routing;             /* 0 (default) | a set of IBLNERF_ROUTE_* bits: deviations from the per-query-class table of
+                                          mlp_precision above, for A/B measurements and for tests that need one kernel form on its
+                                          own.  They change results (another product scheme for a query class), which is why they
+                                          are options of the context and not environment variables.  Ignored by modes that do not
+                                          keep the stream a bit needs. */
+    int32_t persistent_workgroups;     /* 0 (default) = one persistent workgroup per compute unit; n > 0 = launch the MLP kernels
+                                          with n workgroups (scaling measurements below the chip's power limit) */
 } iblnerf_options;
+enum {
+    IBLNERF_ROUTE_COARSE_OFFSETS_MIXED = 1,   /* F16X3_MXFP6X: the coarse grid's offset queries on the mixed trunk form too */
+    IBLNERF_ROUTE_USER_TRUNK_MIXED = 2,       /* F16X3_MXFP6X: the trunk-only form of iblnerf_network_query on the mixed trunk form */
+    IBLNERF_ROUTE_FINE_MAIN_PRECISE = 4       /* F16X3_MXFP6X: the fine pass's main query back on F16X3 */
+};
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3, IBLNERF_NORMAL_DEPTH_GRADIENT = 4, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION = 5 };
@@ -193,7 +205,7 @@ int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const fl
  * d_pts [n_pts, 3], d_dsigma [n_pts]  ->  d_out [n_pts, 4] = (sigma, dL/dx, dL/dy, dL/dz);
  * d_grad: iblnerf_blob_floats() floats in the state-dict layout of iblnerf_upload_weights (zeroed here; entries of the other layers stay 0).
  * Two stages: the fused forward + backward chain of iblnerf_density_gradient, which also stashes every layer's input and dZ
- * fragments (8.1 KiB per point of workspace, grown on demand), then the weight-gradient GEMMs over the points (f16 operands,
+ * fragments (workspace grown on demand, 15.2 KiB per point — the stash is laid out for the whole-network backward, this entry fills 8.1 KiB of it —, see iblnerf_trim), then the weight-gradient GEMMs over the points (f16 operands,
  * fp32 accumulation; the operand transposition is done by the matrix core).  Needs an mlp_precision with the f16x3 stream.
  * grad_scale: a power of two applied to dL/dsigma inside the kernels and taken out of every result — the loss scaling of f16
  * training: gradients are stashed as f16, so small ones must be lifted out of the denormals (|dZ| < 6e-5) without the largest
@@ -227,9 +239,15 @@ int iblnerf_trunk_features2_backward(iblnerf_ctx* ctx, void* stream, int which, 
  * (sigma, dL/dpts) and d_grad = the gradients of all 23 layers in state-dict layout.  One fused launch (forward with the ReLU pass bits and
  * an operand stash, then the backward chain: the 128-wide feature layers' gradients are formed from their heads' weights, the transposed
  * layers that meet in dL/dh2 and dL/dh7 are packed K-concatenated, the N = 1 heads on those activations enter as rank-1 terms) + the
- * weight-gradient GEMMs and head reductions.  Not for colour-independent networks.  15 KiB of workspace per point. */
+ * weight-gradient GEMMs and head reductions.  Not for colour-independent networks.  15 KiB of workspace per point (see iblnerf_trim). */
 int iblnerf_network_backward(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
                              const float* d_viewdirs, const float* d_draw, float grad_scale, float* d_out, float* d_grad);
+
+/* Frees the workspace the fused backward entry points grow on demand (operand stash: 15.2 KiB per point of the largest piece, at most
+ * 262 144 points = 4 GiB — longer calls are walked in pieces —, and the weight-gradient partial sums).  Synchronises the device.  The
+ * memory is a raw hipMalloc outside torch's caching allocator: call this before a phase that needs it back (e.g. after training, before
+ * a full-frame render in the same process). */
+int iblnerf_trim(iblnerf_ctx* ctx);
 
 /* replaces: the compositing of raw2outputs WITH its autograd, for a training step (ibl_nerf_renderer.py:203-206, 241-259, 281-318): the 19
  * direct maps of one pass from its raw rows —  d_maps [n_rays, 19] = [depth, acc, albedo(3), roughness, irradiance, radiance(3),
@@ -342,8 +360,8 @@ typedef struct {
     const float* d_z;               /* [n_rays, S] z_vals of this pass */
     const float* d_raw;             /* [n_rays, S, 18] main query (network_query_fn output, :202) */
     const float* d_sigma_offsets;   /* [4, n_rays, S] density of the four offset / tilted queries (normal_from_depth.py:158-160);
-                                       in the two depth-gradient modes [n_rays, S, 4] rows of iblnerf_density_gradient;
-                                       NULL in the ground-truth and inferred normal modes */
+                                       NULL in the ground-truth and inferred normal modes (the two depth-gradient normal modes are not
+                                       served by this entry: IBLNERF_ERR_STATE) */
     const float* d_refl_raw;        /* [n_rays, N_samples, 13] reflected-ray query (:445): columns 0 and 6..17 of its raw rows */
     const float* d_normal_raw;      /* [n_rays, S, 3] normal_mlp samples ([n_rays, 3] with infer_normal_at_surface) or NULL */
     float* d_stage;                 /* optional out [n_rays, 8]: normal before the edit / insert overrides (3), LUT coordinates n.v and

@@ -330,11 +330,41 @@ def alpha_weights(sigma_raw, dists):
 # --------------------------------------------------------------------------------------------
 # A.6 fine sampling — nerf_models/nerf_renderer_helper.py:91-134 with det=True
 # --------------------------------------------------------------------------------------------
+def aten_sum_lastdim(x):
+    """torch.sum(x, -1, keepdim=True) of a contiguous float32 [N, n] array, bit for bit: ATen's CPU cascade sum (aten/src/ATen/native/cpu/
+    SumKernel.cpp) as it runs for 8-float vectors — vectorized_inner_sum: the row is read as n // 8 vectors; row_sum keeps 4 interleaved
+    partial vectors (vector j goes to partial j % 4 while j < 4 * (n // 32), later vectors to partial 0; the cascade levels of multi_row_sum
+    only fill from 16 groups = 512 elements on), folds them ((p0 + p1) + p2) + p3; the scalar tail x[8 * (n // 8):] is summed sequentially
+    from 0 and the 8 vector lanes are then added to it in order.  Pinned against torch.sum in tests/test_oracle_golden.py (n = 30 .. 255).
+    It matters because sample_pdf's `denom < 1e-5` test sits one fp32 ulp from the denominator of an empty bin (see sample_pdf)."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    N, n = x.shape
+    assert n < 512, "the cascade levels of ATen's sum start at 512 elements: not restated"
+    vs = n // 8
+    g = vs // 4
+    v = x[:, :8 * vs].reshape(N, vs, 8)
+    p = np.zeros((N, 4, 8), F32)
+    for i in range(g):
+        p = (p + v[:, 4 * i:4 * i + 4]).astype(F32)
+    for j in range(4 * g, vs):
+        p[:, 0] = (p[:, 0] + v[:, j]).astype(F32)
+    P = (((p[:, 0] + p[:, 1]).astype(F32) + p[:, 2]).astype(F32) + p[:, 3]).astype(F32)
+    fin = np.zeros((N,), F32)
+    for t in range(8 * vs, n):
+        fin = (fin + x[:, t]).astype(F32)
+    for c in range(8):
+        fin = (fin + P[:, c]).astype(F32)
+    return fin[:, None]
+
+
 def sample_pdf(bins, weights, n_samples, u=None):
-    """u: [N, n_samples] uniform draws of the det=False branch (:103), None = det=True (u = linspace)."""
+    """u: [N, n_samples] uniform draws of the det=False branch (:103), None = det=True (u = linspace).
+    The row sum follows torch.sum's own order (aten_sum_lastdim): an empty bin's cdf step is 1e-5 / sum = 9.994e-6 +- one ulp of the
+    cdf, i.e. 167 or 168 ulps where the `denom < 1e-5` test (:128-129) flips — the last bit of the sum decides whether such a bin's
+    samples collapse onto its edge."""
     bins = np.asarray(bins, dtype=F32)
     w = (np.asarray(weights, dtype=F32) + F32(1e-5)).astype(F32)
-    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32)
+    pdf = (w / aten_sum_lastdim(w.reshape(-1, w.shape[-1])).reshape(w.shape[:-1] + (1,))).astype(F32)
     cdf = np.cumsum(pdf.astype(np.float64), -1).astype(F32)           # double accumulate (ATen CPU)
     cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)
     u = np.broadcast_to(torch_linspace(0, 1, n_samples), cdf.shape[:-1] + (n_samples,)) if u is None else np.asarray(u, dtype=F32)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _pkg  # noqa: E402
 
 _pkg.load()
-from ibl_nerf_amd import run_test  # noqa: E402
+from ibl_nerf_amd import render_views  # noqa: E402
 
 if __name__ == "__main__":
-    run_test.main()
+    render_views.main()

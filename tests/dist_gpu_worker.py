@@ -71,6 +71,7 @@ def main():
         dist.broadcast(ref, 0)
         assert torch.equal(ref, mine)
     dist.barrier()
+    print("BACKEND %s" % dist.get_backend(), flush=True)
     print("DIST_OK %d" % rank, flush=True)
     dist.destroy_process_group()
 

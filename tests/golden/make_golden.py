@@ -490,6 +490,97 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         name, n_rays, mode, float(ret["color_map"].min()), float(ret["color_map"].max()), os.path.getsize(path) / 1e6))
 
 
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8):
+    """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
+    reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
+    every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
+    masked assignments run).  Kept: every map of both passes; `weights` / `weights0` for every `weights_every`-th ray;
+    `floor__<map>` = relative L-inf of the two runs; `floorray__<map>` [n_rays] = the same difference PER RAY (max over the map's
+    channels, over the map's global max) — the distribution the GPU tests bound the reflected-ray channels with.
+    mode: "plain" | "edit_cfg4" | "insert_cfg5" (tests/frame_overrides.py: the kwargs of the two shipped configs, analytic images)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import frame_overrides as FO
+    tmp = tempfile.mkdtemp()
+    try:
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 128))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    sd_c, sd_f = fitted_state_dicts()
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    kw.update(near=0.5, far=8.0)
+    kw["brdf_lut"] = lut
+    rng = np.random.RandomState(1000 + seed)
+    o, d, pix, focal = camera_rays(rng, n_rays)
+    edit = dict(EDIT_KEYS_OFF)
+    gt = {}
+    if mode == "edit_cfg4":
+        edit.update(FO.EDIT_CFG4)
+        gt = FO.edit_rows(pix)
+    elif mode == "insert_cfg5":
+        edit.update(FO.INSERT_CFG5)
+        gt = FO.insert_rows(pix)
+    K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
+
+    def render(dtype):
+        rays = torch.from_numpy(np.stack([o, d], 0)).to(dtype)
+        gt_t = {k: torch.from_numpy(v.copy()).to(dtype) for k, v in gt.items()}
+        with torch.no_grad():
+            if dtype == torch.float32:
+                ret = R.render_decomp(800, 800, K, chunk=chunk, rays=rays, gt_values=gt_t, approximate_radiance=True, **kw, **edit)
+            else:
+                # render_decomp casts the rays to float32 (:795-802); the float64 run enters one call below it, at the reference's own
+                # batchify_rays, with the ray rows [o, d, near, far, viewdirs] of :804-805 built in float64
+                ro, rd = rays[0], rays[1]
+                k2 = dict(kw)
+                near_, far_ = k2.pop("near"), k2.pop("far")
+                rows = torch.cat([ro, rd, near_ * torch.ones_like(rd[:, :1]), far_ * torch.ones_like(rd[:, :1]),
+                                  rd / torch.norm(rd, dim=-1, keepdim=True)], -1)
+                ret = R.batchify_rays(rows, chunk, gt_values=gt_t, approximate_radiance=True, **k2, **edit)
+        return {k: v.detach().numpy() for k, v in ret.items()}
+
+    import time
+    t0 = time.time()
+    ret = render(torch.float32)
+    t32 = time.time() - t0
+    nets = [kw["network_fn"], kw["network_fine"]]
+    torch.set_default_tensor_type(torch.DoubleTensor)     # (not set_default_dtype: torch.Tensor(list) must become float64 as well)
+    try:
+        for n_ in nets:
+            n_.double()
+        kw["brdf_lut"] = lut.double()
+        t0 = time.time()
+        ret64 = render(torch.float64)
+        t64 = time.time() - t0
+    finally:
+        torch.set_default_tensor_type(torch.FloatTensor)
+        for n_ in nets:
+            n_.float()
+        kw["brdf_lut"] = lut
+    assert all(v.dtype == np.float64 for v in ret64.values() if v.dtype.kind == "f")
+
+    out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(0.5), far=np.float32(8.0), gain=np.float64(1.0),
+               seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1), n_importance=np.int64(128), n_samples=np.int64(64),
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
+               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))), mode=np.array(mode), ckpt=np.array("fitted"),
+               weights_every=np.int64(weights_every), chunk=np.int64(chunk))
+    for k, v in gt.items():
+        out["gt__" + k] = v
+    for k, v in edit.items():
+        out["edit__" + k] = np.asarray(v, dtype=np.float32) if isinstance(v, list) else np.asarray(v)
+    for k, v in ret.items():
+        a, b = v.astype(np.float64), ret64[k]
+        scale = max(float(np.nanmax(np.abs(b))), 1e-30)
+        diff = np.abs(a - b).reshape(n_rays, -1)
+        out["floor__" + k] = np.float64(np.nanmax(diff) / scale)
+        out["floorray__" + k] = (np.nanmax(diff, -1) / scale).astype(np.float32)
+        out["out__" + k] = v.astype(np.float32)[::weights_every] if k.startswith("weights") else v.astype(np.float32)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %5d rays  %s  reference: %.0f s float32 (%.0f rays/s), %.0f s float64  %.2f MB" % (
+        name, n_rays, mode, t32, n_rays / t32, t64, os.path.getsize(path) / 1e6))
+
+
 def small_vectors(torch, R, Hh):
     """get_rays / sample_pdf / embedder known-answer vectors on tiny seeded inputs."""
     rng = np.random.RandomState(7)
@@ -522,6 +613,26 @@ def small_vectors(torch, R, Hh):
     assert d10 == 63 and d4 == 27
     np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **out)
     print("small_vectors.npz written")
+
+
+def sample_pdf_spiky(torch, Hh):
+    """sample_pdf(det=True) of the reference on rows from the regime a checkpoint with surfaces produces: one to four samples carry the
+    whole weight, the other bins are empty (exactly 0, or ~1e-8) — where the `denom < 1e-5` replacement (nerf_renderer_helper.py:128-129)
+    flips with the last bit of torch.sum.  The known answer of the summation order both the oracle and the HIP kernel follow."""
+    rng = np.random.RandomState(77)
+    N = 2048
+    z = (np.linspace(0., 1., 64, dtype=np.float64) * 7.5 + 0.5).astype(np.float32)
+    mids = np.broadcast_to((np.float32(0.5) * (z[1:] + z[:-1])).astype(np.float32), (N, 63)).copy()
+    w = np.zeros((N, 62), np.float32)
+    for r in range(N):
+        k = rng.randint(1, 5)
+        w[r, rng.choice(62, k, replace=False)] = (rng.dirichlet(np.ones(k)) * rng.uniform(0.7, 1.0)).astype(np.float32)
+        if r % 3 == 0:
+            w[r] += ((rng.rand(62) < 0.2) * rng.rand(62) * 1e-7).astype(np.float32)
+    s = Hh.sample_pdf(torch.from_numpy(mids), torch.from_numpy(w), 128, det=True).numpy()
+    tot = torch.sum(torch.from_numpy(w) + 1e-5, -1, keepdim=True).numpy()
+    np.savez_compressed(os.path.join(OUT, "sample_pdf_spiky.npz"), bins=mids[0], weights=w, samples=s, row_sum=tot)
+    print("sample_pdf_spiky.npz: %d rows  %.2f MB" % (N, os.path.getsize(os.path.join(OUT, "sample_pdf_spiky.npz")) / 1e6))
 
 
 def export_fixture(torch, R, M, lut):
@@ -577,6 +688,8 @@ def main(only=None):
     shutil.copyfile(os.path.join(REF, "data", "ibl_brdf_lut.png"), os.path.join(OUT, "ibl_brdf_lut.png"))
     if not only or "small_vectors" in only:
         small_vectors(torch, R, Hh)
+    if not only or "sample_pdf_spiky" in only:
+        sample_pdf_spiky(torch, Hh)
     if not only or "export_path" in only:
         export_fixture(torch, R, M, lut)
     if not only or "trunk_backward" in only:
@@ -638,6 +751,14 @@ def main(only=None):
     run_fixture("fitted_insert", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, mode="insert", fitted=True, n_keep=64)   # (the reference's masked assignments do not run in float64: the floor of fitted_plain stands for all three)
     # the same checkpoint on 1 024 rays (maps only): how the worst ray grows with the sample, and the reference's own fp64-vs-fp32 run on it
     run_fixture("fitted_wide", torch, R, M, lut, n_rays=1024, n_importance=128, gain=1.0, seed=23, fitted=True, n_keep=2, record_floor=True)
+    # launch scale (NOT part of the default run: minutes of reference CPU time each; name them on the command line): 16 384 pixels of
+    # the bench view, and BASELINE configs 4 / 5 (the shipped edit / insert kwargs on analytic mask / normal / depth images) at 4 096
+    for nm, kws in (("fitted_launch16k", dict(n_rays=16384, seed=30)),
+                    ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4)),
+                    ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4)),
+                    ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
+        if only and nm in only:
+            launch_scale_fixture(nm, torch, R, M, lut, **kws)
     # the autograd normal modes (normal_from_depth.py:16-52 direction, :102-137 position), run with gradients enabled as in training;
     # posed cameras; one on the fitted checkpoint
     run_fixture("gradnormal_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=24, posed=True, autograd=True, n_keep=4, record_floor=True,

@@ -1,4 +1,4 @@
-"""Mitsuba scene reader (ibl-nerf_amd/dataset.py) and the test.py-shaped driver (run_test.py) on a tiny
+"""Mitsuba scene reader (ibl-nerf_amd/dataset.py) and the test.py-shaped driver (render_views.py) on a tiny
 synthetic scene written in the reference's on-disk layout (dataset_mitsuba.py:8-137).  The
 reference's own reader needs cv2 / imageio / torchvision, none of which is in this image, so its
 behaviour is pinned here by the semantics stated in its source (cited per assertion), not by a run.
@@ -13,7 +13,7 @@ import iblnerf_oracle as O
 from ibl_nerf_amd import checkpoint as ck
 from ibl_nerf_amd import config as C
 from ibl_nerf_amd import dataset as DS
-from ibl_nerf_amd import run_test as RT
+from ibl_nerf_amd import render_views as RT
 
 H, W, FOV = 6, 8, 50.0
 N_TEST = 3

@@ -71,7 +71,7 @@ def _view_worker(rank, world, init_file, cfg_path, lut_path):
     import _pkg
     _pkg.load()
     from conftest import load_lut_rgb
-    from ibl_nerf_amd import checkpoint as ck, config as C, run_test as RT
+    from ibl_nerf_amd import checkpoint as ck, config as C, render_views as RT
     from test_dataset import oracle_render_fn
     res, out = RT.test(C.load_config(cfg_path, device="cpu"), brdf_lut_path=lut_path,
                        render_fn=oracle_render_fn(ck.synthetic_state_dict(0), ck.synthetic_state_dict(1), load_lut_rgb()))

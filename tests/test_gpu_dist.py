@@ -17,18 +17,18 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _launch(script_args, timeout=900):
+def _launch(script_args, timeout=900, nproc=2):
     n_gpu = torch.cuda.device_count()
     assert n_gpu >= 1, "GPU tests need a HIP device"
     env = dict(os.environ)
-    if n_gpu < 2:
+    if n_gpu < nproc:
         env["IBLNERF_BENCH_BACKEND"] = "gloo"
     else:
         env.pop("IBLNERF_BENCH_BACKEND", None)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env), env.get("IBLNERF_BENCH_BACKEND", "nccl")
 
@@ -53,3 +53,25 @@ def test_two_rank_frame_with_overrides_is_bit_identical():
     out, _ = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py")])
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "DIST_OK 0" in out.stdout and "DIST_OK 1" in out.stdout
+
+
+def test_rccl_one_rank_frame_on_device_buffers():
+    """The RCCL leg on one GPU: a world-size-1 `nccl` process group (librccl loaded, communicator up) and dist.render_frame's pack ->
+    all_gather_into_tensor on DEVICE buffers -> unpack, under the insert / edit gt_values — the branch of dist.all_gather_frame that
+    the two-rank tests cannot reach on a one-GPU box (they exchange over gloo)."""
+    out, backend = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py")], nproc=1)
+    assert backend == "nccl"
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "DIST_OK 0" in out.stdout and "BACKEND nccl" in out.stdout
+
+
+def test_rccl_one_rank_bench_line():
+    """bench.py --gpus 1 under torch.distributed.run: the group is initialised, the step packs and all-gathers over RCCL, and the JSON
+    line carries pack_ms / gather_ms so that the first multi-GPU run explains itself."""
+    out, backend = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"], nproc=1)
+    assert backend == "nccl"
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"]
+    assert d["pack_ms"] > 0 and d["gather_ms"] > 0 and d["exchange"]["backend"] == "RCCL"
+    assert d["pack_ms"] + d["gather_ms"] < 0.1 * d["ms_per_step"]          # the exchange is a few per cent of a frame at most

@@ -112,15 +112,15 @@ def test_fitted_render_error_class_of_the_coarser_modes(R, lut, prec):
     assert r.range_fallbacks == 0
 
 
-def test_mixed_trunk_form_of_the_fast_kernel(R, lut, monkeypatch):
+def test_mixed_trunk_form_of_the_fast_kernel(R, lut):
     """VAR_TRUNK_X (the fast kernel's trunk form with positions_linears.0 / .1 as three f16 products; the default mode's fine-grid
-    offset queries) on its own, through iblnerf_network_query (IBLNERF_X_USER routes the trunk-only form of that entry to it):
+    offset queries) on its own, through iblnerf_network_query (options.query_routing = IBLNERF_ROUTE_USER_TRUNK_MIXED routes the trunk-only
+    form of that entry to it):
     density of the fitted checkpoint's recorded offset points between the fast kernel's and the precise kernel's error (measured
     2.1e-3 against 7.4e-3 and 2.0e-4 abs), ragged point counts, bit-repeatability (the LDS-DMA of its chunks gathers network and
     residual blocks from two places per wave), device-side packing bit-identical to the host's."""
-    monkeypatch.setenv("IBLNERF_X_USER", "1")          # read by iblnerf_create
     g, sdc, sdf, _, _ = load_golden("fitted_plain")
-    rx = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x")
+    rx = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x", query_routing="user_trunk_mixed")
     fast = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16_mxfp6")
     prec = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=64, mlp_precision="f16x3")
     err = {}
@@ -134,8 +134,7 @@ def test_mixed_trunk_form_of_the_fast_kernel(R, lut, monkeypatch):
         assert torch.equal(rx.network_query(pts, None, 1), a)
     for n in (1, 31, 33, 127, 129):
         assert float((rx.network_query(pts[:n, :7], None, 1) - prec.network_query(pts[:n, :7], None, 1)).abs().max()) <= 5e-3
-    monkeypatch.setenv("IBLNERF_X_USER", "1")
-    dev = R.Renderer(64, 128, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x")
+    dev = R.Renderer(64, 128, max_rays_per_launch=64, mlp_precision="f16x3_mxfp6x", query_routing="user_trunk_mixed")
     dev.load_weights(1, {k: torch.from_numpy(v).cuda() for k, v in sdf.items()})
     assert torch.equal(dev.network_query(pts[:64], None, 1), rx.network_query(pts[:64], None, 1))
 

@@ -1,0 +1,163 @@
+"""Parity at launch scale, against the REFERENCE's own render.
+
+Fixtures (tests/golden/make_golden.py launch_scale_fixture, the reference's render_decomp on the fitted checkpoint, float32 and — as the
+yardstick — float64):
+    fitted_launch16k     16 384 seeded pixels of the 800x800 bench view (BASELINE configs[1])
+    fitted_edit_cfg4      4 096 pixels under the kwargs of configs/IBL-NeRF/kitchen/edit_intrinsic.txt:8-16      (configs[3])
+    fitted_insert_cfg5    4 096 pixels under the kwargs of configs/IBL-NeRF/living-room-2/object_insert.txt:8-14 (configs[4])
+The masks / normal / depth images of the two override configs are analytic functions of the pixel (tests/frame_overrides.py), so the
+whole 800x800 frames of configs 4 and 5 are rendered here too and compared at the fixtures' pixels.
+
+Rules.  The reference's own float64-vs-float32 difference is recorded PER RAY (fixture arrays floorray__*): a ray that grazes a
+surface amplifies round-off without bound in the reference itself (its two runs differ by 7e-2 on the normal of the worst of 16 384 rays, by
+5e-4 on depth), so an absolute L-inf bar over a launch is not attainable by any arithmetic; what is asserted instead:
+  (i)   direct channels: every map <= 1e-3 relative L-inf (the north-star bar; `weights`, per sample, <= WEIGHTS_CAP), AND every single ray
+        <= 2e-4 or 8x THAT RAY's own reference difference where larger;
+        the normal and n.v (a 50x amplified depth difference): every ray <= 1e-3 or 8x that ray's own reference difference; the number of
+        rays above 1e-3 stays below the number the reference's own two runs produce; the worst ray is reported in DESIGN.md, not bounded;
+  (ii)  the reflected-ray channels are ill-conditioned in the reference itself (its two runs differ by 1e-1 .. 6e-1 on the worst ray): their
+        per-ray error DISTRIBUTION is bounded: median / 99 % / 99.9 % of the HIP path's per-ray error against the reference's float32 run
+        stay within DIST_FACTOR x the same percentiles of the reference's own float64-vs-float32 per-ray difference, with an absolute floor of
+        fp32 round-off; the worst ray within 4x the reference's own worst ray;
+  (iii) whole frames of configs 4 / 5: the fixture pixels by rules (i) / (ii), and the override properties (masked pixels carry their
+        override rows exactly).
+"""
+import numpy as np
+import pytest
+
+import frame_overrides as FO
+from conftest import load_golden, rel_linf
+from test_gpu_parity import DERIVED, DIRECT, make_renderer, to_np
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+REFLECTED = ["specular_map", "color_map", "reflected_radiance_map", "prefiltered_reflected_map",
+             "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3"]
+WEIGHTS_CAP = 2e-3          # weights is [n, S], 192 chances per ray: its worst entry sits above the maps' (measured 8.5e-4; the reference's own two runs: 5e-4 .. 9e-4)
+DIST_FACTOR = 4.0           # per-ray percentiles of the reflected-ray channels: within this factor of the reference's own float64-vs-float32 percentiles
+DIST_FLOOR = {50: 2e-6, 99: 2e-5, 99.9: 1e-4}   # ... or this (fp32 round-off of a gamma-corrected sum of 64 samples), whichever is larger
+
+
+@pytest.fixture(scope="module")
+def R():
+    from ibl_nerf_amd import binding as B, renderer
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    B.load_library()
+    return renderer
+
+
+def per_ray(got, ref):
+    """max over a map's channels of |got - ref|, over the map's global max: [n]."""
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(float(np.nanmax(np.abs(ref))), 1e-30)
+    return np.nanmax(np.abs(np.asarray(got, dtype=np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1), -1) / scale
+
+
+NORMAL_LIKE = ["target_normal_map", "n_dot_v_map"]
+
+
+def check_against_fixture(res, g, report=None):
+    """Rules (i) and (ii) for the rays of fixture `g`; `res` holds the HIP maps of exactly those rays."""
+    we = int(g["weights_every"])
+    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    for sfx in ("", "0"):
+        for k in DIRECT + ["diffuse_map"] + NORMAL_LIKE:
+            key = k + sfx
+            got, f = res[key], g["floorray__" + key].astype(np.float64)
+            if k == "weights":
+                got, f = got[::we], f[::we]
+            e = per_ray(got, g["out__" + key])
+            base = 1e-3 if k in NORMAL_LIKE else 2e-4
+            bad = e > np.maximum(base, 8 * f)
+            if report is not None:
+                report[key] = (float(np.nanmax(e)), float(g["floor__" + key]), int((e > 1e-3).sum()), int((f > 1e-3 / 8).sum()))
+            assert not bad.any(), (key, "rays beyond max(%.0e, 8x their own reference difference):" % base, np.flatnonzero(bad)[:8], e[bad][:8], f[bad][:8])
+            if k in NORMAL_LIKE:
+                assert (e > 1e-3).sum() <= max(1, (f > 1e-3 / 8).sum()), (key, int((e > 1e-3).sum()), int((f > 1e-3 / 8).sum()))
+            else:
+                assert float(np.nanmax(e)) <= (WEIGHTS_CAP if k == "weights" else 1e-3), (key, float(np.nanmax(e)))
+        for k in REFLECTED:
+            key = k + sfx
+            e, f = per_ray(res[key], g["out__" + key]), g["floorray__" + key].astype(np.float64)
+            for q in (50, 99, 99.9):
+                bound = max(DIST_FACTOR * float(np.nanpercentile(f, q)), DIST_FLOOR[q])
+                if report is not None:
+                    report["%s p%s" % (key, q)] = (float(np.nanpercentile(e, q)), bound)
+                assert float(np.nanpercentile(e, q)) <= bound, (key, q, float(np.nanpercentile(e, q)), bound)
+            # the worst ray: inside 4x the reference's own worst ray (the rule of the 96 .. 1 024-ray fixtures), which is NOT a parity claim
+            assert float(np.nanmax(e)) <= max(1e-3, 4 * float(g["floor__" + key])), (key, float(np.nanmax(e)), float(g["floor__" + key]))
+    assert rel_linf(res["z_std"], g["out__z_std"]) <= max(1e-4, 4 * float(g["floor__z_std"]))
+    d = per_ray(res["depth_map"], g["out__depth_map"])
+    assert np.median(d) <= 2e-7 and np.percentile(d, 99) <= 2e-5 and np.percentile(d, 99.9) <= 1e-4, (np.median(d), np.percentile(d, 99), np.percentile(d, 99.9))
+
+
+@pytest.mark.parametrize("name", ["fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5"])
+def test_launch_scale_render_vs_reference(R, lut, name):
+    """The default mode on 16 384 / 4 096 / 4 096 rays of the reference's own render, in ONE launch."""
+    g, sdc, sdf, gt, edit = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384)
+    res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
+    assert r.range_fallbacks == 0
+    check_against_fixture(res, g)
+    psnr = 10 * np.log10(1.0 / max(np.mean((res["color_map"].astype(np.float64) - g["out__color_map"]) ** 2), 1e-30))
+    assert psnr > 55, psnr
+
+
+def _frame_rays(r):
+    H = W = 800
+    f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[f, 0, 400], [0, f, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    ro, rd = r.get_rays(H, W, K, c2w)
+    return ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+
+@pytest.mark.parametrize("name,rows_fn", [("fitted_edit_cfg4", FO.edit_rows), ("fitted_insert_cfg5", FO.insert_rows)])
+def test_full_frame_of_configs_4_and_5(R, lut, name, rows_fn):
+    """BASELINE configs[3] / [4] at full size on the HIP path: 640 000 rays of the fitted checkpoint under the shipped edit / insert kwargs
+    with image-shaped gt_values; the fixture's 4 096 pixels against the reference, and the override properties on every masked pixel."""
+    g, sdc, sdf, _, edit = load_golden(name)
+    r = make_renderer(R, g, sdc, sdf, lut)
+    ro, rd = _frame_rays(r)
+    pix = g["pix"]
+    # the fixture's rays are these pixels' rays (get_rays is bit-exact on origins, 2e-7 on directions)
+    assert np.abs(rd[torch.as_tensor(pix, device=rd.device)].cpu().numpy() - g["rays_d"]).max() <= 2e-7
+    gt = rows_fn(np.arange(800 * 800))
+    for k, v in gt.items():
+        assert np.array_equal(v[pix], g["gt__" + k]), k
+    m = r.render_rays(ro, rd, 0.5, 8.0, {k: torch.from_numpy(v).cuda() for k, v in gt.items()}, **edit)
+    torch.cuda.synchronize()
+    assert r.range_fallbacks == 0
+    assert all(bool(torch.isfinite(v).all()) for k, v in m.items() if not k.startswith("disp_map"))
+    idx = torch.as_tensor(pix, device=rd.device)
+    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g)
+    # override properties, all 640 000 pixels (ibl_nerf_renderer.py:253-256, :378-410): both passes
+    mask_key = "edit_intrinsic_mask" if name.endswith("cfg4") else "object_insert_mask"
+    level = gt[mask_key][:, 0]
+    any_obj = level > 0
+    assert 0.05 < any_obj.mean() < 0.5
+    nimg = 2.0 * gt["edit_normal" if name.endswith("cfg4") else "object_insert_normal"].astype(np.float64) - 1.0
+    nimg /= np.linalg.norm(nimg, axis=-1, keepdims=True)
+    for sfx in ("", "0"):
+        nrm = m["target_normal_map" + sfx].cpu().numpy()
+        assert np.abs(nrm[any_obj] - nimg[any_obj]).max() <= 2e-6
+        rough = m["roughness_map" + sfx].cpu().numpy()
+        if name.endswith("cfg4"):
+            assert np.all(rough[any_obj] == np.float32(FO.EDIT_CFG4["editing_target_roughness_list"][0]))
+            assert np.all(rough[~any_obj] > 0)
+        else:
+            alb, irr, tdep = (m[k + sfx].cpu().numpy() for k in ("albedo_map", "irradiance_map", "target_depth_map"))
+            assert np.array_equal(tdep[any_obj], gt["object_insert_depth"][any_obj, 0])
+            for k in range(4):
+                sel = np.abs(level - np.float32(10 * (k + 1)) / np.float32(255)) < 1e-6
+                assert sel.sum() > 1000
+                assert np.all(rough[sel] == np.float32(FO.INSERT_CFG5["inserting_target_roughness_list"][k]))
+                assert np.array_equal(alb[sel], np.broadcast_to(np.asarray(FO.INSERT_CFG5["inserting_target_albedo_list"][3 * k:3 * k + 3], np.float32), alb[sel].shape))
+                assert np.all(irr[sel] == np.float32(FO.INSERT_CFG5["inserting_target_irradiance_list"][k]))
+    # unmasked pixels are the plain render's: the overrides act per ray
+    plain = r.render_rays(ro[:8000], rd[:8000], 0.5, 8.0)
+    keep = torch.as_tensor(~any_obj[:8000], device=rd.device)
+    for k in ("color_map", "target_normal_map", "roughness_map", "depth_map"):
+        assert torch.equal(plain[k][keep], m[k][:8000][keep]), k

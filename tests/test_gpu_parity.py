@@ -97,6 +97,19 @@ def test_sample_pdf(R):
         r.sample_pdf(sv["sp_bins"], sv["sp_weights"][:, :-1].copy(), 8)
 
 
+def test_sample_pdf_spiky_rows_collapse_where_the_reference_collapses(R):
+    """The regime of a checkpoint with surfaces (fixture sample_pdf_spiky, the reference's own output): empty bins sit one ulp from the
+    `denom < 1e-5` replacement, so the kernel sums the row in torch.sum's own order (aten_row_sum_eps).  Every sample of every row within
+    fp32 round-off of the reference — before, 1 row in 3 had a sample a fraction of the bin width (0.12) away, and a ray whose "empty" bin
+    hides a thin structure came out 3e-3 off in depth (ray 1017 of fitted_edit_cfg4)."""
+    g = np.load(GOLDEN + "/sample_pdf_spiky.npz")
+    r = R.Renderer(64, 0, max_rays_per_launch=16)
+    bins = np.ascontiguousarray(np.broadcast_to(g["bins"], (len(g["weights"]), 63)))
+    s = r.sample_pdf(bins, g["weights"], 128).cpu().numpy()
+    assert np.abs(s - g["samples"]).max() <= 2e-6, np.abs(s - g["samples"]).max()
+    assert np.mean(s == g["samples"]) > 0.999
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", RENDER_FIXTURES)
 def test_network_query_stagewise(R, name, lut, prec):

@@ -42,6 +42,30 @@ def test_embedders(small):
     assert O.embed(small["pe_x"], 10).shape[1] == 63 and O.embed(small["pe_x"], 4).shape[1] == 27
 
 
+def test_row_sum_follows_torch_sum_bit_for_bit():
+    """oracle.aten_sum_lastdim restates the order in which ATen's CPU kernel sums a row; torch.sum itself is the known answer (torch is
+    in both images).  Lengths: N_samples - 2 for N_samples = 10 .. 257; rows of the spiky kind sample_pdf sees on a fitted checkpoint."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.RandomState(0)
+    for n in (8, 30, 62, 63, 126, 190, 254, 255):
+        x = ((rng.rand(1500, n) ** 8) * (rng.rand(1500, n) < 0.3)).astype(np.float32) + np.float32(1e-5)
+        assert np.array_equal(O.aten_sum_lastdim(x), torch.sum(torch.from_numpy(x), -1, keepdim=True).numpy()), n
+
+
+def test_sample_pdf_on_spiky_weights_is_bit_identical_to_the_reference():
+    """Fixture sample_pdf_spiky: 2 048 rows whose weight sits on 1 - 4 samples (all other bins empty), the reference's own samples.  An
+    empty bin's cdf step is 167 or 168 ulps, on either side of the `denom < 1e-5` replacement (nerf_renderer_helper.py:128-129): only with
+    torch.sum's own summation order do such bins collapse exactly where the reference's do (np.sum's order: 30 % of the rows differ in a
+    sample by up to the bin width)."""
+    g = np.load(os.path.join(GOLDEN, "sample_pdf_spiky.npz"))
+    bins = np.broadcast_to(g["bins"], (len(g["weights"]), 63))
+    assert np.array_equal(O.aten_sum_lastdim((g["weights"] + np.float32(1e-5)).astype(np.float32)), g["row_sum"])
+    assert np.array_equal(O.sample_pdf(bins, g["weights"], 128), g["samples"])
+    w = (g["weights"] + np.float32(1e-5)).astype(np.float32)
+    other = np.sum(w, -1, keepdims=True, dtype=np.float32)            # another, equally valid fp32 order
+    assert 0.05 < np.mean(other != g["row_sum"]) < 0.95                  # ... differs in the last bit on a good share of the rows
+
+
 def test_sample_pdf(small):
     s = O.sample_pdf(small["sp_bins"], small["sp_weights"], 128)
     assert np.abs(s - small["sp_samples"]).max() <= 1e-5      # bins span 7.5; cdf ulp * span / pdf
