@@ -21,7 +21,8 @@ EXPORTS = [
     "iblnerf_posdir_floats", "iblnerf_upload_posdir_mlp", "iblnerf_clear_posdir_mlp", "iblnerf_posdir_query", "iblnerf_render_rays_sampled", "iblnerf_sample_pdf_u",
     "iblnerf_density_gradient", "iblnerf_trunk_backward", "iblnerf_trunk_features", "iblnerf_trunk_features_backward",
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
-    "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim",
+    "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
+    "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
 ]
 
 
@@ -75,6 +76,10 @@ class StageInputs(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("d_t_rand", FP), ("d_u", FP), ("d_noise_coarse", FP), ("d_noise_fine", FP)]
+
+
+class Taps(C.Structure):
+    _fields_ = [("d_z_coarse", FP), ("d_z_fine", FP), ("d_raw_coarse", FP), ("d_raw_fine", FP)]
 
 
 class Outputs(C.Structure):
@@ -150,6 +155,16 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_composite_direct.restype = C.c_int
     lib.iblnerf_composite_direct_backward.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
     lib.iblnerf_composite_direct_backward.restype = C.c_int
+    lib.iblnerf_composite_direct_backward_full.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
+    lib.iblnerf_composite_direct_backward_full.restype = C.c_int
+    lib.iblnerf_coarse_z.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, FP, C.c_int64, FP]
+    lib.iblnerf_coarse_z.restype = C.c_int
+    lib.iblnerf_sample_points.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP]
+    lib.iblnerf_sample_points.restype = C.c_int
+    lib.iblnerf_fine_z.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, FP, FP, FP]
+    lib.iblnerf_fine_z.restype = C.c_int
+    lib.iblnerf_composite_sigma.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
+    lib.iblnerf_composite_sigma.restype = C.c_int
     lib.iblnerf_trim.argtypes = [C.c_void_p]
     lib.iblnerf_trim.restype = C.c_int
     lib.iblnerf_sample_pdf.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP]
@@ -169,6 +184,9 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_render_rays_sampled.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
                                                 C.POINTER(Overrides), C.POINTER(Sampling), C.POINTER(Outputs)]
     lib.iblnerf_render_rays_sampled.restype = C.c_int
+    lib.iblnerf_render_rays_tapped.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float,
+                                               C.POINTER(Overrides), C.POINTER(Sampling), C.POINTER(Outputs), C.POINTER(Taps)]
+    lib.iblnerf_render_rays_tapped.restype = C.c_int
     lib.iblnerf_sample_pdf_u.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_int, C.c_int, FP, FP]
     lib.iblnerf_sample_pdf_u.restype = C.c_int
     lib.iblnerf_set_profiling.argtypes = [C.c_void_p, C.c_int]

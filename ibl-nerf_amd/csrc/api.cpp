@@ -771,6 +771,67 @@ int iblnerf_composite_direct_backward(iblnerf_ctx* c, void* stream, const float*
     return IBLNERF_OK;
 }
 
+int iblnerf_composite_direct_backward_full(iblnerf_ctx* c, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                                           int n_samples, const float* d_dmaps, const float* d_dweights, float* d_draw) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || n_samples > 256 || (n_rays > 0 && (!d_raw || !d_z || !d_rays_d || !d_dmaps || !d_draw)))
+        return c->fail(IBLNERF_ERR_INVALID, "composite_direct_backward_full: bad arguments (1 <= n_samples <= 256)");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_composite_direct_backward(d_raw, d_z, d_rays_d, (long)n_rays, n_samples, c->opt.use_radiance_linear, d_dmaps, d_dweights, d_draw,
+                                                (hipStream_t)stream, 0));
+    return IBLNERF_OK;
+}
+
+int iblnerf_coarse_z(iblnerf_ctx* c, void* stream, float near_, float far_, const float* d_t_rand, int64_t n_rays, float* d_z) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || (n_rays > 0 && !d_z)) return c->fail(IBLNERF_ERR_INVALID, "coarse_z: bad arguments");
+    if (n_rays == 0) return IBLNERF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_coarse_z(near_, far_, c->Sc, c->opt.lindisp, c->zc, s));
+    if (d_t_rand) {
+        HIP_TRY(c, launch_jitter_z(c->zc, c->Sc, d_t_rand, (long)n_rays, d_z, s));
+    } else {   // the shared row, once per ray (z_vals.expand, :676)
+        HIP_TRY(c, launch_broadcast_rows(c->zc, c->Sc, (long)n_rays, d_z, s));
+    }
+    return IBLNERF_OK;
+}
+
+int iblnerf_sample_points(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t n_rays, int n_samples,
+                          float* d_pts) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_rays_o || !d_rays_d || !d_z || !d_pts)))
+        return c->fail(IBLNERF_ERR_INVALID, "sample_points: bad arguments");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_make_points(0, d_rays_o, d_rays_d, d_z, n_samples, 0.f, (long)n_rays, n_samples, d_pts, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_fine_z(iblnerf_ctx* c, void* stream, const float* d_z_coarse, const float* d_weights_coarse, int64_t n_rays, const float* d_u,
+                   float* d_z_fine, float* d_z_std) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || (n_rays > 0 && (!d_z_coarse || !d_weights_coarse || !d_z_fine)))
+        return c->fail(IBLNERF_ERR_INVALID, "fine_z: bad arguments");
+    if (c->opt.n_importance < 1) return c->fail(IBLNERF_ERR_STATE, "fine_z: the context has N_importance = 0");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_fine_z(d_z_coarse, c->Sc, c->Sc, d_weights_coarse, (long)n_rays, c->opt.n_importance, d_u, d_z_fine, d_z_std, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_composite_sigma(iblnerf_ctx* c, void* stream, const float* d_sigma, const float* d_z, const float* d_rays_d, int64_t n_rays, int n_samples,
+                            float* d_weights, float* d_depth, float* d_visibility) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || n_samples < 1 || n_samples > 256 || (n_rays > 0 && (!d_sigma || !d_z || !d_rays_d || !d_weights || !d_depth)))
+        return c->fail(IBLNERF_ERR_INVALID, "composite_sigma: bad arguments (1 <= n_samples <= 256)");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_sigma_weights(d_rays_d, d_z, n_samples, d_sigma, nullptr, (long)n_rays, n_samples, d_weights, (hipStream_t)stream, d_depth, d_visibility));
+    return IBLNERF_OK;
+}
+
 int iblnerf_sample_pdf(iblnerf_ctx* c, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
                        int n_bins, int n_out, float* d_samples) {
     return iblnerf_sample_pdf_u(c, stream, d_bins, d_weights, n_rays, n_bins, n_out, nullptr, d_samples);
@@ -991,7 +1052,15 @@ int iblnerf_render_rays(iblnerf_ctx* c, void* stream, const float* d_rays_o, con
 int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                                 float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_sampling* smp,
                                 const iblnerf_outputs* outs) {
+    return iblnerf_render_rays_tapped(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, ovr, smp, outs, nullptr);
+}
+
+int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                               float near_, float far_, const iblnerf_overrides* ovr, const iblnerf_sampling* smp,
+                               const iblnerf_outputs* outs, const iblnerf_taps* taps) {
     if (!c) return IBLNERF_ERR_INVALID;
+    if (taps && !c->opt.coarse_outputs && c->opt.n_importance > 0)
+        return c->fail(IBLNERF_ERR_STATE, "render_rays_tapped: the coarse pass's raw rows exist only with options.coarse_outputs");
     if (n_rays < 0 || !outs) return c->fail(IBLNERF_ERR_INVALID, "render_rays: negative ray count / null outputs");
     if (n_rays == 0) return IBLNERF_OK;   // empty batch: torch hands out null data pointers for zero-row tensors
     if (!d_rays_o || !d_rays_d) return c->fail(IBLNERF_ERR_INVALID, "render_rays: null rays");
@@ -1033,16 +1102,30 @@ int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_ray
             zcs = Sc;
         }
         int rc;
+        // taps (iblnerf_render_rays_tapped): this launch's z rows and main raw rows, out of the workspace before the next pass reuses it
+        auto tap_z = [&](float* dst, const float* z, int zstride, int S) -> int {
+            if (!dst) return IBLNERF_OK;
+            if (zstride == 0) HIP_TRY(c, launch_broadcast_rows(z, S, R, dst + r0 * S, s));
+            else HIP_TRY(c, hipMemcpyAsync(dst + r0 * S, z, (size_t)R * S * sizeof(float), hipMemcpyDeviceToDevice, s));   // (per-ray rows are contiguous: stride = S)
+            return IBLNERF_OK;
+        };
+        auto tap_raw = [&](float* dst, int S) -> int {
+            if (!dst) return IBLNERF_OK;
+            HIP_TRY(c, hipMemcpyAsync(dst + r0 * S * RAW_CH, c->raw, (size_t)R * S * RAW_CH * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return IBLNERF_OK;
+        };
         if (!fine) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
                            noise_c ? noise_c + r0 * Sc : nullptr);
             if (rc) return rc;
+            if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
                            noise_c ? noise_c + r0 * Sc : nullptr);
             if (rc) return rc;
+            if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
             rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE);
@@ -1054,6 +1137,7 @@ int iblnerf_render_rays_sampled(iblnerf_ctx* c, void* stream, const float* d_ray
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
                        noise_f ? noise_f + r0 * Sf : nullptr);
         if (rc) return rc;
+        if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
     }
     if (c->posdir_out_ch && outs->inferred_depth_map) {   // infer_depth (:722-726): depth_mlp(rays_o, viewdirs), relu of output 0
         if (c->posdir_out_ch != 1) return c->fail(IBLNERF_ERR_STATE, "render_rays: the depth_mlp must have one output (ibl_nerf.py:294-296)");

@@ -119,9 +119,9 @@ hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const
 hipError_t launch_composite_direct(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear, float* maps,
                                    float* weights, hipStream_t s);
 hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,
-                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s);
+                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s, int detach = 1);
 hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,
-                                float* weights, hipStream_t s);   // noise: [R,S] or null
+                                float* weights, hipStream_t s, float* depth = nullptr, float* visibility = nullptr);   // noise: [R,S] or null; depth / visibility: raw2outputs_depth's maps [R]
 
 struct PassBArgs {
     const float* state;        // [R, ST_FLOATS]
@@ -148,6 +148,7 @@ hipError_t launch_fine_z(const float* zc, int zc_stride, int Sc, const float* we
                          float* z_std, hipStream_t s);
 // ibl_nerf_renderer.py:678-692 (perturb > 0): z [S] shared base grid, t_rand [R,S] -> out [R,S]
 hipError_t launch_jitter_z(const float* z, int S, const float* t_rand, long R, float* out, hipStream_t s);
+hipError_t launch_broadcast_rows(const float* row, int S, long R, float* out, hipStream_t s);   // one shared row -> R rows
 
 // PositionDirectionMLP (src/networks/MLP.py:32-74), one evaluation per row of pts / dirs (posdir_kernel.hip).
 // weights: per layer [Wt (n_in x n_out, transposed) | bias], layers in registration order (positions_linears.0-7, feature_linear,

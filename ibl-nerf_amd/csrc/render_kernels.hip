@@ -52,7 +52,7 @@ __device__ __forceinline__ float linspace_at(float start, float end, int steps, 
 // Lane owns samples lane*NPL .. lane*NPL+NPL-1.
 template <int NPL>
 __device__ __forceinline__ void ray_weights(const float (&sigma)[NPL], const float (&z)[NPL], const float (&zn)[NPL],
-                                            float norm, int S, int lane, float (&w)[NPL]) {
+                                            float norm, int S, int lane, float (&w)[NPL], float* visibility = nullptr) {
     float alpha[NPL];
     double om[NPL];
     double lane_prod = 1.0;
@@ -80,6 +80,7 @@ __device__ __forceinline__ void ray_weights(const float (&sigma)[NPL], const flo
         w[i] = alpha[i] * (float)T;
         T *= om[i];
     }
+    if (visibility != nullptr) *visibility = (float)__shfl(incl, 63);   // cumprod(...)[:, -1]: the product over every sample (raw2outputs_depth, :140-141)
 }
 
 // d depth / d raw_s of depth = sum_s w_s z_s — what autograd returns through relu, exp, cumprod and the sum in
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 template <int NPL>
 __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__ rays_d, const float* __restrict__ zbase,
                                                       int z_stride, const float* __restrict__ sigma, const float* __restrict__ noise, long R, int S,
-                                                      float* __restrict__ weights) {
+                                                      float* __restrict__ weights, float* __restrict__ depth_out, float* __restrict__ vis_out) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -629,7 +630,16 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
         sig[i] = s < S ? sigma[r * S + s] : 0.0f;
         if (noise != nullptr && s < S) sig[i] = sig[i] + noise[r * S + s];
     }
-    ray_weights<NPL>(sig, z, zn, norm, S, lane, w);
+    float vis = 0.0f;
+    ray_weights<NPL>(sig, z, zn, norm, S, lane, w, &vis);
+    if (depth_out != nullptr) {       // raw2outputs_depth (ibl_nerf_renderer.py:118-152): depth_map and visibility beside the weights
+        float dp = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (lane * NPL + i < S) dp += w[i] * z[i];
+        dp = wave_sum(dp);
+        if (lane == 0) { depth_out[r] = dp; if (vis_out != nullptr) vis_out[r] = vis; }
+    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
@@ -816,8 +826,10 @@ __global__ __launch_bounds__(256) void k_fine_z(const float* __restrict__ zc_bas
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The DIRECT maps of raw2outputs on their own, forward and backward (training: what torch autograd does between the raw rows and the
 // per-ray maps the losses read; ibl_nerf_renderer.py:203-206, 241-259, 281-318).  maps[r] = [depth, acc, albedo(3), roughness, irradiance,
-// radiance(3), radiance_1..3 (9)] = sum_s w_s * act_c(raw[s][c]) (depth: z_s; acc: 1).  Backward: with g_s = dL/dw_s (from all 19 maps and,
-// optionally, from a loss on the weights themselves),
+// radiance(3), radiance_1..3 (9)] = sum_s w_s * act_c(raw[s][c]) (depth: z_s; acc: 1).  Backward: with g_s = dL/dw_s — collected from the maps
+// the reference composites with `weights` (depth, acc, radiance_map: :249, :259, :306) and, optionally, from a loss on the weights themselves;
+// albedo, roughness, irradiance and the three coarse radiances are composited with `weights_detached` (:246, :282-315) and send no gradient
+// to the density (detach = 1; detach = 0 differentiates every map through the weights) —,
 //   dL/d alpha_s = g_s T_s - (sum_{i>s} g_i w_i) / (1 - alpha_s + 1e-10),    dL/d raw_s0 = that * dist_s exp(-raw_s0 dist_s) [raw_s0 > 0],
 //   dL/d raw_sc  = w_s dL/dmap_c act_c'(raw_sc)                         — the depth-gradient scan of ray_depth_grad with g in place of z.
 constexpr int CM_CH = 19;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__
 template <int NPL>
 __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ zb, const float* __restrict__ rays_d,
                                                        long R, int S, int radiance_linear, const float* __restrict__ dmaps,
-                                                       const float* __restrict__ dweights, float* __restrict__ draw) {
+                                                       const float* __restrict__ dweights, float* __restrict__ draw, int detach) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             else { a_ = fmaxf(x, 0.0f); d_ = x > 0.0f ? 1.0f : 0.0f; }
             act[i][c] = a_;
             dact[i][c] = d_;
-            if (in) gs += (double)dm[2 + c] * a_;
+            if (in && (!detach || (c >= 5 && c < 8))) gs += (double)dm[2 + c] * a_;   // channels 5..7 = radiance_map: the one colour map on `weights`
         }
         g[i] = gs;
     }
@@ -958,6 +970,18 @@ hipError_t by_npl(int S, F&& f) {
 
 }  // namespace
 
+__global__ void k_broadcast_rows(const float* __restrict__ row, int S, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = row[i % S];
+}
+// z_vals.expand([N_rays, N_samples]) materialised (ibl_nerf_renderer.py:676): one shared row -> R rows
+hipError_t launch_broadcast_rows(const float* row, int S, long R, float* out, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const long n = R * S;
+    hipLaunchKernelGGL(k_broadcast_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, row, S, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s) {
     const long n = (long)n_rows * W;
     if (n <= 0) return hipSuccess;
@@ -996,20 +1020,20 @@ hipError_t launch_composite_direct(const float* raw, const float* z, const float
     });
 }
 hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,
-                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s) {
+                                            const float* dmaps, const float* dweights, float* draw, hipStream_t s, int detach) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
-        hipLaunchKernelGGL(k_composite_bwd<decltype(N)::value>, grid, dim3(256), 0, s, raw, z, rays_d, R, S, radiance_linear, dmaps, dweights, draw);
+        hipLaunchKernelGGL(k_composite_bwd<decltype(N)::value>, grid, dim3(256), 0, s, raw, z, rays_d, R, S, radiance_linear, dmaps, dweights, draw, detach);
     });
 }
 
 hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,
-                                float* weights, hipStream_t s) {
+                                float* weights, hipStream_t s, float* depth, float* visibility) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
-        hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, noise, R, S, weights);
+        hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, noise, R, S, weights, depth, visibility);
     });
 }
 

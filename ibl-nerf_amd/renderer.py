@@ -134,6 +134,7 @@ class Renderer:
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._blobs, self._lut = {}, None
+        self.has_fine = False            # a network_fine is loaded (run_fn = network_fn otherwise, ibl_nerf_renderer.py:705)
         self.range_fallbacks = 0
         self.opt = o
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
@@ -174,6 +175,8 @@ class Renderer:
                 blob = ck.state_dict_to_blob(blob)
             blob = np.ascontiguousarray(blob, dtype=np.float32)
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
+        if int(which) == 1:
+            self.has_fine = True
         if self.mlp_precision != "bf16x3":
             self._blobs[int(which)] = blob
             if self._wide is not None:
@@ -606,14 +609,16 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
         (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
         perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
         stochastic fine samples, from torch.rand on the device; pytest=True takes numpy's seed-0 stream instead, re-seeded for
         every `chunk` rays exactly as batchify_rays / render_rays / sample_pdf do, so the reference's test path reproduces.
         raw_noise_std > 0 (:208-216): noise on the main query's density before compositing, N(0, std) from the device generator, or
-        — pytest=True — std * numpy's seed-0 UNIFORM stream, which is what the reference's test hook draws."""
+        — pytest=True — std * numpy's seed-0 UNIFORM stream, which is what the reference's test hook draws.
+        draws = (t_rand [n, N_samples], u [n, N_importance]) device tensors (or (None, None)) replaces the perturb / pytest generation;
+        taps = a binding.Taps of caller-owned buffers (iblnerf_render_rays_tapped: both passes' z_vals and main raw rows, for a backward)."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = rays_o.shape[0]
@@ -633,7 +638,12 @@ class Renderer:
                 setattr(smp, field, nz.data_ptr())
                 keep.append(nz)
             self._keep_noise = keep
-        if perturb and float(perturb) > 0.:
+        if draws is not None:
+            if draws[0] is not None:
+                smp = smp or B.Sampling()
+                smp.d_t_rand, smp.d_u = draws[0].data_ptr(), draws[1].data_ptr()
+                self._keep_smp = draws
+        elif perturb and float(perturb) > 0.:
             Sc, Ni = self.N_samples, max(self.N_importance, 1)
             if pytest:
                 ch = int(chunk or n or 1)
@@ -650,7 +660,8 @@ class Renderer:
         if lazy:
             self._lazy_poll()
             if self._force_wide:
-                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, **edit)
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
+                                                                draws=draws, taps=taps, **edit)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -669,12 +680,14 @@ class Renderer:
         if self._depth_mlp is not None:
             inferred_depth = torch.empty((n,), dtype=torch.float32, device=self.device)
             outs.inferred_depth_map = inferred_depth.data_ptr()
-        B.check(self.ctx, self.lib.iblnerf_render_rays_sampled(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
-                                                               float(near), float(far), C.byref(ov) if ov is not None else None,
-                                                               C.byref(smp) if smp is not None else None, C.byref(outs)))
+        B.check(self.ctx, self.lib.iblnerf_render_rays_tapped(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
+                                                              float(near), float(far), C.byref(ov) if ov is not None else None,
+                                                              C.byref(smp) if smp is not None else None, C.byref(outs),
+                                                              C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, **edit)
+            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
+                                                 draws=draws, taps=taps, **edit)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:
@@ -829,10 +842,6 @@ def _check_supported(kw):
             # ibl_nerf_renderer.py:349-353 call functions whose import is commented out (:15): the reference raises NameError here
             raise NameError("name 'get_normal_from_sigma_gradient%s' is not defined" % ("_surface" if mode.endswith("surface") else ""))
         raise ValueError(mode)                                                       # ibl_nerf_renderer.py:374-375
-    if not kw.get("approximate_radiance", False):
-        raise NotImplementedError("approximate_radiance=False (training warm-up) is not built")
-    if kw.get("is_depth_only"):
-        raise NotImplementedError("is_depth_only is not built")
 
 
 _renderers = {}
@@ -923,6 +932,10 @@ def renderer_for(kw):
     return r
 
 
+def _ci_net(net):
+    return bool(getattr(net, "is_color_independent_to_direction", False))
+
+
 def _scalar(x, name):
     torch = _torch()
     if torch.is_tensor(x):
@@ -948,9 +961,29 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     sh = rays_d.shape
     edit = {k: kwargs[k] for k in kwargs
             if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
-    ret = r.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), _scalar(near, "near"), _scalar(far, "far"),
-                        kwargs.get("gt_values"), perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)),
-                        chunk=chunk, raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **edit)
+    from . import training as T
+    ro_f, rd_f = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    nf = (_scalar(near, "near"), _scalar(far, "far"))
+    smp = dict(perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)), chunk=chunk)
+    approx = bool(kwargs.get("approximate_radiance", False))
+    training = T.is_training_call(kwargs)
+    if is_depth_only or not approx or training:
+        # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
+        if any(v for k, v in edit.items() if isinstance(v, bool)) or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or r._aux or _ci_net(kwargs["network_fn"]):
+            raise NotImplementedError("edit / insert overrides, *_from_gt flags, raw_noise_std, auxiliary and colour-independent networks are not built "
+                                      "for is_depth_only, approximate_radiance=False and gradient-carrying renders")
+        if is_depth_only:                                                       # raw2outputs_depth (:197-198)
+            ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, **smp)
+            if kwargs.get("infer_depth") and r._depth_mlp is not None:        # :722-726 runs whatever the pass type
+                vd = rd_f / rd_f.norm(dim=-1, keepdim=True)
+                ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
+        elif training:
+            ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
+                                      approximate_radiance=approx, **smp)
+        else:
+            ret = T.render_rays_direct(r, ro_f, rd_f, *nf, **smp)
+        return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
+    ret = r.render_rays(ro_f, rd_f, *nf, kwargs.get("gt_values"), raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **smp, **edit)
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
 
 

@@ -1,0 +1,306 @@
+"""A training step's render on the fused kernels, forward AND backward: ONE torch.autograd.Function around render_rays.
+
+Replaces, for train.py:285-297 / :479-481, what torch autograd does through the reference's render_decomp -> batchify_rays -> render_rays ->
+raw2outputs (nerf_models/ibl_nerf_renderer.py:759-813, :629-732, :153-527) when `network_fn` / `network_fine` are trainable nn.Modules:
+
+    forward   approximate_radiance=True:  iblnerf_render_rays_tapped — the inference path itself, which also hands out both passes' z_vals
+              and main raw rows; approximate_radiance=False (the first N_iter_ignore_approximated_radiance iterations, train.py:295) and
+              is_depth_only (:366-374): the stages of render_rays strung together (iblnerf_coarse_z / _sample_points / _network_query /
+              _composite_direct / _fine_z / _composite_sigma).
+    backward  per pass: dL/d(output maps) -> dL/d(the 19 linear direct maps) by torch autograd over the RAY-sized part of raw2outputs
+              (`_ray_outputs`: output lambdas, disparity, and under approximate_radiance the split-sum shading :412-474 — LUT fetch by
+              F.grid_sample, Fresnel, mip interpolation, gamma — with everything the reference computes under no_grad / detached held
+              constant: the normal :358-361, x_surface :263, the reflected-ray maps :442-448, depth in the mip level :455) ->
+              iblnerf_composite_direct_backward (the reference's weights_detached stop-gradients, :246) -> dL/d raw [n, S, 18] ->
+              iblnerf_network_backward -> the 46 parameter gradients of that pass's network.
+Nothing of size [n_rays, n_samples] is computed by torch: such tensors exist only as buffers the kernels read and write.
+`forward_freezed` (ibl_nerf.py:88-152; train.py:275-283): with network.freeze_radiance only the albedo / irradiance feature layers and heads
+(and roughness_linear unless freeze_roughness) receive gradients — the upstream rows of the frozen outputs are zeroed and the gradients
+of the frozen layers dropped.
+
+Not built here (raise): edit / insert overrides and the *_from_gt flags in a training step, auxiliary and colour-independent networks,
+raw_noise_std > 0, a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+from . import checkpoint as ck
+
+ALL_PARAMS = tuple(n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias"))
+# parameters that still receive gradients under forward_freezed (ibl_nerf.py:113-131)
+UNFROZEN = ("albedo_feature_linear.", "albedo_linear.", "irradiance_feature_linear.", "irradiance_linear.", "roughness_linear.")
+MAP3 = ("albedo_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3")
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def is_training_call(kw):
+    """render_decomp was called the way train.py calls it: autograd on and a network with trainable parameters."""
+    torch = _torch()
+    if not torch.is_grad_enabled():
+        return False
+    for net in (kw.get("network_fn"), kw.get("network_fine")):
+        ps = getattr(net, "parameters", None)
+        if ps is not None and any(getattr(p, "requires_grad", False) for p in ps()):
+            return True
+    return False
+
+
+def _gamma(x, on):
+    return (x + 1e-12) ** (1.0 / 2.2) if on else x            # rgb_to_srgb, ibl_nerf_renderer.py:26-27
+
+
+def _ungamma(y, on):
+    return (y ** 2.2 - 1e-12).clamp_min(0.0) if on else y
+
+
+def _ray_outputs(x, consts, flags):
+    """The ray-sized part of raw2outputs as differentiable torch: x [n, 19] = the linear direct maps (Renderer.MAP_SLOTS order) -> the
+    pass's output maps.  consts (approximate_radiance): n_dot_v [n], env [n, 4, 3] linear reflected-ray maps, lut [3, 512, 512],
+    depth0 = (near + far) / 2."""
+    torch = _torch()
+    import torch.nn.functional as F
+    g, hdr = flags["gamma_correct"], flags["use_radiance_linear"]
+    out_f = (lambda v: _gamma(v / (v + 1) if hdr else v, g))                         # output_f (:480-490)
+    depth, acc = x[:, 0], x[:, 1]
+    albedo, rough, irr = x[:, 2:5], x[:, 5], x[:, 6]
+    res = {"radiance_map": out_f(x[:, 7:10])}
+    for k in range(3):
+        res["radiance_map_%d" % (k + 1)] = out_f(x[:, 10 + 3 * k:13 + 3 * k])
+    res["irradiance_map"] = out_f(irr[:, None])                                     # target_irradiance_map = irradiance_map[..., None] (:326)
+    res["albedo_map"] = _gamma(albedo, g)                                           # albedo_f (:491)
+    res["roughness_map"] = rough
+    q = depth / acc
+    res["disp_map"] = 1.0 / torch.maximum(torch.full_like(q, 1e-10), q)             # :258
+    res["acc_map"], res["depth_map"], res["target_depth_map"] = acc, depth, depth
+    if consts is None:
+        return res
+    ndv, env, lut = consts["n_dot_v"], consts["env"], consts["lut"]
+    uv = torch.stack([2 * ndv - 1, 2 * rough - 1], -1)                              # :418
+    e = F.grid_sample(lut[None], uv[None, :, None, :], align_corners=True)[0, :, :, 0].t()      # [n, 3]  (:419-421)
+    metallic = (1 - rough)[:, None]
+    F0 = 0.04 * (1 - metallic) + albedo * metallic                                  # :424-427
+    F1 = torch.maximum(1.0 - rough[:, None], F0) - F0                               # fresnel_schlick_roughness (microfacet.py:8-12)
+    fres = F0 + F1 * torch.clip(1.0 - ndv[:, None], 0.0, 1.0) ** 5.0
+    coef = (fres if flags["lut_coefficient"] == "F" else F0) * e[:, 0:1] + e[:, 1:2]             # :433-436
+    if flags["correct_depth"]:
+        level = torch.clip(rough * depth.detach() / consts["depth0"], 0, 1)         # :453-457
+    else:
+        level = rough
+    i1 = torch.clip((level * 3).long(), 0, 3)
+    i2 = torch.clip(i1 + 1, 0, 3)
+    rem = (level * 3 - i1)[:, None]
+    ar = torch.arange(env.shape[0], device=env.device)
+    pref = (1 - rem) * env[ar, i1] + rem * env[ar, i2]                              # :461-467
+    diffuse = (1 - fres) * (1 - metallic) * albedo * irr[:, None]                   # :469
+    spec = coef * pref
+    res.update(color_map=out_f(diffuse + spec), specular_map=out_f(spec), diffuse_map=out_f(diffuse), prefiltered_reflected_map=out_f(pref))
+    return res
+
+
+def _flags(r):
+    o = r.opt
+    return dict(gamma_correct=bool(o.gamma_correct), use_radiance_linear=bool(o.use_radiance_linear),
+                lut_coefficient="F0" if o.lut_coefficient_f0 else "F", correct_depth=bool(o.correct_depth_for_prefiltered_radiance))
+
+
+def _draws(r, n, perturb, pytest, chunk):
+    """(t_rand [n, N_samples], u [n, N_importance]) of perturb > 0, or (None, None): torch's generator on the device, or — pytest — numpy's
+    seed-0 stream re-seeded per chunk as batchify_rays / render_rays / sample_pdf do (ibl_nerf_renderer.py:686-690, nerf_renderer_helper.py:106-113)."""
+    torch = _torch()
+    from .renderer import _dev_f32, _pytest_uniform
+    if not perturb or float(perturb) <= 0.:
+        return None, None
+    Sc, Ni = r.N_samples, max(r.N_importance, 1)
+    if pytest:
+        ch = int(chunk or n or 1)
+        t = torch.cat([_pytest_uniform(min(ch, n - i), Sc) for i in range(0, n, ch)] or [torch.zeros((0, Sc))])
+        u = torch.cat([_pytest_uniform(min(ch, n - i), Ni) for i in range(0, n, ch)] or [torch.zeros((0, Ni))])
+        return _dev_f32(t, r.device), _dev_f32(u, r.device)
+    return torch.rand((n, Sc), device=r.device), torch.rand((n, Ni), device=r.device)
+
+
+class _Stages:
+    """Thin callers of the stage entry points (include/iblnerf.h: iblnerf_coarse_z ...), device tensors in and out."""
+
+    def __init__(self, r):
+        self.r, self.lib, self.ctx = r, r.lib, r.ctx
+
+    def _e(self, *sh):
+        torch = _torch()
+        return torch.empty(sh, dtype=torch.float32, device=self.r.device)
+
+    def coarse_z(self, near, far, t_rand, n):
+        z = self._e(n, self.r.N_samples)
+        B.check(self.ctx, self.lib.iblnerf_coarse_z(self.ctx, self.r._stream(), float(near), float(far), None if t_rand is None else t_rand.data_ptr(), n, z.data_ptr()))
+        return z
+
+    def points(self, ro, rd, z):
+        n, S = z.shape
+        pts = self._e(n, S, 3)
+        B.check(self.ctx, self.lib.iblnerf_sample_points(self.ctx, self.r._stream(), ro.data_ptr(), rd.data_ptr(), z.data_ptr(), n, S, pts.data_ptr()))
+        return pts
+
+    def fine_z(self, zc, wc, u):
+        n = zc.shape[0]
+        zf, zs = self._e(n, self.r.N_samples + self.r.N_importance), self._e(n)
+        B.check(self.ctx, self.lib.iblnerf_fine_z(self.ctx, self.r._stream(), zc.data_ptr(), wc.data_ptr(), n, None if u is None else u.data_ptr(), zf.data_ptr(), zs.data_ptr()))
+        return zf, zs
+
+    def composite_sigma(self, sigma, z, rd):
+        n, S = z.shape
+        w, d, v = self._e(n, S), self._e(n), self._e(n)
+        B.check(self.ctx, self.lib.iblnerf_composite_sigma(self.ctx, self.r._stream(), sigma.data_ptr(), z.data_ptr(), rd.data_ptr(), n, S, w.data_ptr(), d.data_ptr(), v.data_ptr()))
+        return w, d, v
+
+
+def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None):
+    """is_depth_only (raw2outputs_depth, ibl_nerf_renderer.py:118-152, through render_rays :693-718): trunk-only queries, the keys
+    depth_map / weights / visibility (+ '0') and z_std.  Forward only (train.py:374 detaches the one map it reads)."""
+    torch = _torch()
+    from .renderer import _dev_f32
+    ro, rd = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
+    n = ro.shape[0]
+    st = _Stages(r)
+    t_rand, u = _draws(r, n, perturb, pytest, chunk)
+    zc = st.coarse_z(near, far, t_rand, n)
+    sig = r.network_query(st.points(ro, rd, zc), None, 0)[..., 0].contiguous()
+    wc, dc, vc = st.composite_sigma(sig, zc, rd)
+    if r.N_importance <= 0:
+        return {"depth_map": dc, "weights": wc, "visibility": vc}
+    zf, zstd = st.fine_z(zc, wc, u)
+    sig = r.network_query(st.points(ro, rd, zf), None, 1 if r.has_fine else 0)[..., 0].contiguous()      # run_fn = network_fn if network_fine is None (:705)
+    wf, df, vf = st.composite_sigma(sig, zf, rd)
+    torch.cuda.current_stream(r.device).synchronize()      # the draws must outlive the launches
+    return {"depth_map": df, "weights": wf, "visibility": vf, "depth_map0": dc, "weights0": wc, "visibility0": vc, "z_std": zstd}
+
+
+BASE_KEYS = ["radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3", "irradiance_map", "albedo_map", "roughness_map", "disp_map",
+             "acc_map", "depth_map", "target_depth_map", "weights"]          # raw2outputs' non-None entries without approximate_radiance, in its order (:494-525)
+
+
+def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags):
+    """render_rays with approximate_radiance=False from its stages: (result dict, what a backward needs)."""
+    torch = _torch()
+    n = ro.shape[0]
+    zc = st.coarse_z(near, far, t_rand, n)
+    rawc = r.network_query(st.points(ro, rd, zc), rd, 0)
+    mc, wc = r.composite_direct(rawc, zc, rd)
+    zf, zstd = st.fine_z(zc, wc, u)
+    rawf = r.network_query(st.points(ro, rd, zf), rd, 1 if r.has_fine else 0)
+    mf, wf = r.composite_direct(rawf, zf, rd)
+    res = {}
+    for sfx, m, w in (("", mf, wf), ("0", mc, wc)):
+        o = _ray_outputs(m, None, flags)
+        o["weights"] = w
+        res.update({k + sfx: o[k] for k in BASE_KEYS})
+    res["z_std"] = zstd
+    torch.cuda.current_stream(r.device).synchronize()      # the draws must outlive the launches
+    return res, dict(zc=zc, zf=zf, rawc=rawc, rawf=rawf)
+
+
+def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None):
+    """approximate_radiance=False without autograd (e.g. a validation render during the warm-up iterations): the reference's result dict."""
+    from .renderer import _dev_f32
+    torch = _torch()
+    ro, rd = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
+    if r.N_importance <= 0:
+        raise NotImplementedError("approximate_radiance=False is built for N_importance > 0 (every shipped config)")
+    t_rand, u = _draws(r, ro.shape[0], perturb, pytest, chunk)
+    with torch.no_grad():
+        res, _ = _forward_direct(r, _Stages(r), ro, rd, near, far, t_rand, u, _flags(r))
+    return res
+
+
+def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None):
+    """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
+    `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for)."""
+    torch = _torch()
+    from .renderer import RESULT_ORDER, Renderer, _dev_f32
+    ro, rd = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
+    n = ro.shape[0]
+    if r.N_importance <= 0 or net_f is None:
+        raise NotImplementedError("a training step on the fused path needs N_importance > 0 and a network_fine (every shipped config)")
+    if not r.coarse_outputs:
+        raise NotImplementedError("a training step reads the coarse pass's maps: coarse_outputs=True")
+    flags = _flags(r)
+    named = [dict(net.named_parameters()) for net in (net_c, net_f)]
+    for nm in named:
+        if set(nm) != set(ALL_PARAMS):
+            raise NotImplementedError("the fused backward is built for the shipped IBLNeRF architecture (46 parameters per network)")
+    params = [nm[k] for nm in named for k in ALL_PARAMS]
+    frozen = [bool(getattr(net, "freeze_radiance", False)) for net in (net_c, net_f)]
+    frozen_rough = [bool(getattr(net, "freeze_roughness", False)) for net in (net_c, net_f)]
+    st = _Stages(r)
+    depth0 = 0.5 * (float(near) + float(far))
+    lut_t = _dev_f32(lut, r.device)
+
+    keys = [k + s for s in ("", "0") for k in (RESULT_ORDER if approximate_radiance else BASE_KEYS)] + ["z_std"]
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, ro_, rd_, *ps):
+            t_rand, u = _draws(r, n, perturb, pytest, chunk)
+            Sc, Sf = r.N_samples, r.N_samples + r.N_importance
+            if approximate_radiance:
+                taps = B.Taps()
+                sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18))
+                taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
+                res = r.render_rays(ro_, rd_, near, far, draws=(t_rand, u), taps=taps)
+            else:
+                res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags)
+            ctx.saved = dict(sv, ro=ro_, rd=rd_)
+            if approximate_radiance:
+                for sfx in ("", "0"):
+                    env = torch.stack([_ungamma(res[k + sfx], flags["gamma_correct"]) for k in
+                                       ("reflected_radiance_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")], 1)
+                    if flags["use_radiance_linear"]:
+                        env = env / (1 - env)                        # inverse of tonemap_reinherd
+                    ctx.saved["consts" + sfx] = dict(n_dot_v=res["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)
+            outs = tuple(res[k] for k in keys)
+            ctx.mark_non_differentiable(*[res[k] for k in keys if k.startswith(("target_normal_map", "n_dot_v_map", "reflected_", "z_std"))])
+            return outs
+
+        @staticmethod
+        def backward(ctx, *gouts):
+            sv = ctx.saved
+            gout = dict(zip(keys, gouts))
+            grads_all = []
+            for which, sfx, z, raw in ((0, "0", sv["zc"], sv["rawc"]), (1, "", sv["zf"], sv["rawf"])):
+                lin, _ = r.composite_direct(raw, z, sv["rd"], want_weights=False)
+                with torch.enable_grad():
+                    x = lin.detach().requires_grad_(True)
+                    outs = _ray_outputs(x, sv.get("consts" + sfx), flags)
+                    pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None]
+                    if pairs:
+                        (dx,) = torch.autograd.grad([o for o, _ in pairs], x, [g.reshape(o.shape).to(o.dtype) for o, g in pairs], allow_unused=True)
+                        dx = torch.zeros_like(lin) if dx is None else dx
+                    else:
+                        dx = torch.zeros_like(lin)
+                gw = gout.get("weights" + sfx)
+                draw = r.composite_direct_backward(raw, z, sv["rd"], dx.contiguous(), None if gw is None else gw.contiguous())
+                if frozen[which]:                                     # forward_freezed: sigma, radiance and the coarse radiances are computed under no_grad
+                    draw[..., 0] = 0
+                    draw[..., 6:] = 0
+                    if frozen_rough[which]:
+                        draw[..., 4] = 0
+                _, grads = r.network_backward(st.points(sv["ro"], sv["rd"], z), sv["rd"], draw, which)
+                for k in ALL_PARAMS:
+                    gk = grads[k]
+                    if frozen[which] and not (k.startswith(UNFROZEN) and not (frozen_rough[which] and k.startswith("roughness_linear."))):
+                        gk = None                                        # h is computed under no_grad: nothing reaches the trunk / view layers
+                    grads_all.append(gk)
+            out = []
+            for i, (p, gk) in enumerate(zip(params, grads_all)):
+                out.append(gk.reshape(p.shape).clone() if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
+            return (None, None) + tuple(out)
+
+    outs = _Fn.apply(ro, rd, *params)
+    return dict(zip(keys, outs))

@@ -258,6 +258,32 @@ int iblnerf_composite_direct(iblnerf_ctx* ctx, void* stream, const float* d_raw,
                              int n_samples, float* d_maps, float* d_weights);
 int iblnerf_composite_direct_backward(iblnerf_ctx* ctx, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d,
                                       int64_t n_rays, int n_samples, const float* d_dmaps, const float* d_dweights, float* d_draw);
+/* The backward follows the reference's stop-gradients: albedo, roughness, irradiance and the three coarse radiances are composited with
+ * `weights_detached` (ibl_nerf_renderer.py:246, :282-315) — their gradient reaches their own raw channels only —, while depth, acc and
+ * radiance_map (`weights`, :249, :259, :306) and a loss on the weights also reach the density.  iblnerf_composite_direct_backward_full is the
+ * same backward WITHOUT the stop-gradients (every map differentiated through the weights): not what the reference computes; kept for
+ * callers that build other losses. */
+int iblnerf_composite_direct_backward_full(iblnerf_ctx* ctx, void* stream, const float* d_raw, const float* d_z, const float* d_rays_d,
+                                           int64_t n_rays, int n_samples, const float* d_dmaps, const float* d_dweights, float* d_draw);
+
+/* The stages of render_rays between its network queries, on their own — what a training step needs around the fused network forward /
+ * backward so that nothing of size [n_rays, n_samples] is computed outside this library (train.py:285-297 -> ibl_nerf_renderer.py:629-732):
+ *   iblnerf_coarse_z       z_vals of the coarse pass (:670-692): the near..far grid (lindisp as the context's option), per ray; with
+ *                          d_t_rand [n_rays, N_samples] the stratified jitter of perturb > 0.  d_z [n_rays, N_samples].
+ *   iblnerf_sample_points  pts = rays_o + rays_d * z (:200), d_z [n_rays, n_samples] -> d_pts [n_rays, n_samples, 3], rounded as the
+ *                          reference's separate multiply and add.
+ *   iblnerf_fine_z         z_vals_mid -> sample_pdf(weights[1:-1]) (det = no d_u) -> sort(cat(z, z_samples)) and z_std (:700-707, :718):
+ *                          d_z_coarse [n_rays, N_samples], d_weights_coarse [n_rays, N_samples], d_u [n_rays, N_importance] or NULL ->
+ *                          d_z_fine [n_rays, N_samples + N_importance], d_z_std [n_rays] (may be NULL).
+ *   iblnerf_composite_sigma  raw2outputs_depth (:118-152, is_depth_only): d_sigma [n_rays, n_samples] (a trunk-only query's output) ->
+ *                          d_weights [n_rays, n_samples], d_depth [n_rays], d_visibility [n_rays] (the full transmittance product). */
+int iblnerf_coarse_z(iblnerf_ctx* ctx, void* stream, float near_, float far_, const float* d_t_rand, int64_t n_rays, float* d_z);
+int iblnerf_sample_points(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t n_rays,
+                          int n_samples, float* d_pts);
+int iblnerf_fine_z(iblnerf_ctx* ctx, void* stream, const float* d_z_coarse, const float* d_weights_coarse, int64_t n_rays, const float* d_u,
+                   float* d_z_fine, float* d_z_std);
+int iblnerf_composite_sigma(iblnerf_ctx* ctx, void* stream, const float* d_sigma, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                            int n_samples, float* d_weights, float* d_depth, float* d_visibility);
 
 /* replaces: sample_pdf(bins, weights, N_samples, det=True) (nerf_models/nerf_renderer_helper.py:91-134).
  * d_bins [n_rays, n_bins], d_weights [n_rays, n_bins-1] -> d_samples [n_rays, n_out]. */
@@ -346,6 +372,19 @@ typedef struct {
 int iblnerf_render_rays_sampled(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                                 float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_sampling* sampling,
                                 const iblnerf_outputs* outputs);
+/* iblnerf_render_rays_sampled that also hands out what a backward pass needs (a training step with approximate_radiance=True, train.py:295):
+ * the z_vals of both passes and the main query's raw rows of both passes (after auxiliary networks wrote their columns), copied out of the
+ * workspace launch by launch.  Any pointer may be NULL.  d_z_coarse [n_rays, N_samples], d_z_fine [n_rays, N_samples + N_importance],
+ * d_raw_coarse [n_rays, N_samples, 18], d_raw_fine [n_rays, N_samples + N_importance, 18].  Needs options.coarse_outputs. */
+typedef struct {
+    float* d_z_coarse;
+    float* d_z_fine;
+    float* d_raw_coarse;
+    float* d_raw_fine;
+} iblnerf_taps;
+int iblnerf_render_rays_tapped(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                               float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_sampling* sampling,
+                               const iblnerf_outputs* outputs, const iblnerf_taps* taps);
 /* sample_pdf(bins, weights, N_samples, det=False) with caller-supplied draws d_u [n_rays, n_out] (NULL = det=True). */
 int iblnerf_sample_pdf_u(iblnerf_ctx* ctx, void* stream, const float* d_bins, const float* d_weights, int64_t n_rays,
                          int n_bins, int n_out, const float* d_u, float* d_samples);

@@ -490,13 +490,83 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         name, n_rays, mode, float(ret["color_map"].min()), float(ret["color_map"].max()), os.path.getsize(path) / 1e6))
 
 
-def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8):
+def train_step_fixture(torch, R, M, lut, n_rays=64):
+    """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
+    fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
+    train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
+    (color_map, :330, from iteration N_iter_ignore_approximated_radiance on), albedo prior (:396, beta_prior_albedo), irradiance prior and
+    regulariser (:399, :404: MSE against targets) and the roughness initialisation (:411-412, before that iteration); the targets are seeded
+    arrays (a loss is a loss).  Records the loss and dL/d(every parameter of network_fn and network_fine), for four phases:
+        warmup    approximate_radiance=False  (the first N_iter_ignore_approximated_radiance iterations, :295)
+        full      approximate_radiance=True
+        frozen    approximate_radiance=True with freeze_radiance = freeze_roughness = True on both networks (:279-283: forward_freezed)
+        depth     is_depth_only=True, approximate_radiance=False (:366-374): forward only (its depth_map is detached in the loss)"""
+    tmp = tempfile.mkdtemp()
+    try:
+        kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128))      # [0] = render_kwargs_train
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert kw["perturb"] == 1.0
+    sd_c, sd_f = fitted_state_dicts()
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    kw.update(near=0.5, far=8.0, pytest=True)
+    kw["brdf_lut"] = lut
+    rng = np.random.RandomState(4100)
+    o, d, pix, focal = camera_rays(rng, n_rays)
+    K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
+    rays = torch.from_numpy(np.stack([o, d], 0))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import train_loss as TL
+    tg, beta = TL.targets(rng, n_rays), TL.BETA
+    out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(0.5), far=np.float32(8.0), chunk=np.int64(n_rays),
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))), ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
+               ckpt=np.array("fitted"))
+    for k, v in tg.items():
+        out["target__" + k] = v
+    for k, v in beta.items():
+        out["beta__" + k] = np.float64(v)
+    nets = (("c", kw["network_fn"]), ("f", kw["network_fine"]))
+
+    for phase in ("warmup", "full", "frozen", "depth"):
+        for _, net in nets:
+            net.zero_grad()
+            net.freeze_radiance = net.freeze_roughness = phase == "frozen"
+        approx = phase in ("full", "frozen")
+        with torch.enable_grad():
+            res = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values={}, approximate_radiance=approx,
+                                  is_depth_only=phase == "depth", **kw, **EDIT_KEYS_OFF)
+            for k, v in res.items():
+                out["%s__out__%s" % (phase, k)] = v.detach().numpy().copy()
+            if phase == "depth":
+                continue
+            loss = TL.total_loss(torch, res, tg, approx)
+            loss.backward()
+        out[phase + "__loss"] = np.float64(loss.item())
+        for tag, net in nets:
+            for name, prm in net.named_parameters():
+                out["%s__grad_%s__%s" % (phase, tag, name)] = (prm.grad.numpy().copy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32))
+    for _, net in nets:
+        net.freeze_radiance = net.freeze_roughness = False
+    path = os.path.join(OUT, "train_step.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %4d rays, 4 phases: losses %s  %.2f MB" % ("train_step", n_rays, {p_: round(float(out[p_ + "__loss"]), 5) for p_ in ("warmup", "full", "frozen")},
+                                                           os.path.getsize(path) / 1e6))
+
+
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3):
     """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
     reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
     every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
     masked assignments run).  Kept: every map of both passes; `weights` / `weights0` for every `weights_every`-th ray;
     `floor__<map>` = relative L-inf of the two runs; `floorray__<map>` [n_rays] = the same difference PER RAY (max over the map's
     channels, over the map's global max) — the distribution the GPU tests bound the reflected-ray channels with.
+    A second yardstick, `nudgeray__<map>` [n_rays]: the float64 run cannot see the reference's fp32 THRESHOLDS — sample_pdf replaces
+    denominators below 1e-5 by 1 (nerf_renderer_helper.py:128-129) and an empty bin's denominator is 1e-5 / sum = 167 or 168 ulps of the
+    cdf, so one ulp on a coarse weight decides whether that bin's fine samples collapse onto its edge.  So the float32 render is repeated
+    `n_nudge` times with the reference's own sample_pdf called on weights multiplied by (1 + s 2^-23), s in {-1, 0, 1} drawn per entry
+    (the wrapper passes them on; nothing else changes), and the largest per-ray change of each map against the un-nudged run is recorded:
+    what one ulp on the coarse pass's weights does to the reference's own output.
     mode: "plain" | "edit_cfg4" | "insert_cfg5" (tests/frame_overrides.py: the kwargs of the two shipped configs, analytic images)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import frame_overrides as FO
@@ -543,6 +613,21 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
     t0 = time.time()
     ret = render(torch.float32)
     t32 = time.time() - t0
+    nudged, t_nudge = [], 0.0
+    pdf0 = R.sample_pdf
+    for m in range(n_nudge):
+        nrng = np.random.RandomState(9000 + 10 * seed + m)
+
+        def pdf_nudged(bins, weights, N, det=False, pytest=False):
+            s_ = torch.from_numpy(nrng.randint(-1, 2, size=tuple(weights.shape)).astype(np.float32))
+            return pdf0(bins, weights * (1.0 + s_ * 2.0 ** -23), N, det=det, pytest=pytest)
+        R.sample_pdf = pdf_nudged
+        try:
+            t0 = time.time()
+            nudged.append(render(torch.float32))
+            t_nudge += time.time() - t0
+        finally:
+            R.sample_pdf = pdf0
     nets = [kw["network_fn"], kw["network_fine"]]
     torch.set_default_tensor_type(torch.DoubleTensor)     # (not set_default_dtype: torch.Tensor(list) must become float64 as well)
     try:
@@ -563,7 +648,7 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
                seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1), n_importance=np.int64(128), n_samples=np.int64(64),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
                ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))), mode=np.array(mode), ckpt=np.array("fitted"),
-               weights_every=np.int64(weights_every), chunk=np.int64(chunk))
+               weights_every=np.int64(weights_every), chunk=np.int64(chunk), n_nudge=np.int64(n_nudge))
     for k, v in gt.items():
         out["gt__" + k] = v
     for k, v in edit.items():
@@ -574,11 +659,14 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
         diff = np.abs(a - b).reshape(n_rays, -1)
         out["floor__" + k] = np.float64(np.nanmax(diff) / scale)
         out["floorray__" + k] = (np.nanmax(diff, -1) / scale).astype(np.float32)
+        if nudged and not k.endswith("0"):         # (the coarse pass comes before sample_pdf: its maps cannot move)
+            nd = np.maximum.reduce([np.nanmax(np.abs(r_[k].astype(np.float64) - a).reshape(n_rays, -1), -1) for r_ in nudged]) / scale
+            out["nudgeray__" + k] = nd.astype(np.float32)
         out["out__" + k] = v.astype(np.float32)[::weights_every] if k.startswith("weights") else v.astype(np.float32)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
-    print("%-28s %5d rays  %s  reference: %.0f s float32 (%.0f rays/s), %.0f s float64  %.2f MB" % (
-        name, n_rays, mode, t32, n_rays / t32, t64, os.path.getsize(path) / 1e6))
+    print("%-28s %5d rays  %s  reference: %.0f s float32 (%.0f rays/s), %.0f s float64, %.0f s for %d nudged runs  %.2f MB" % (
+        name, n_rays, mode, t32, n_rays / t32, t64, t_nudge, n_nudge, os.path.getsize(path) / 1e6))
 
 
 def small_vectors(torch, R, Hh):
@@ -688,6 +776,8 @@ def main(only=None):
     shutil.copyfile(os.path.join(REF, "data", "ibl_brdf_lut.png"), os.path.join(OUT, "ibl_brdf_lut.png"))
     if not only or "small_vectors" in only:
         small_vectors(torch, R, Hh)
+    if not only or "train_step" in only:
+        train_step_fixture(torch, R, M, lut)
     if not only or "sample_pdf_spiky" in only:
         sample_pdf_spiky(torch, Hh)
     if not only or "export_path" in only:
@@ -754,8 +844,8 @@ def main(only=None):
     # launch scale (NOT part of the default run: minutes of reference CPU time each; name them on the command line): 16 384 pixels of
     # the bench view, and BASELINE configs 4 / 5 (the shipped edit / insert kwargs on analytic mask / normal / depth images) at 4 096
     for nm, kws in (("fitted_launch16k", dict(n_rays=16384, seed=30)),
-                    ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4)),
-                    ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4)),
+                    ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4, n_nudge=4)),
+                    ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4, n_nudge=4)),
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:
             launch_scale_fixture(nm, torch, R, M, lut, **kws)

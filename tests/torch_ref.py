@@ -69,5 +69,7 @@ def composite_direct(raw, z_vals, rays_d):
     alpha = 1.0 - torch.exp(-F.relu(raw[..., 0]) * dists)
     w = alpha * torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
     cols = [torch.sum(w * z_vals, -1, keepdim=True), torch.sum(w, -1, keepdim=True)]
-    cols.append(torch.sum(w[..., None] * torch.sigmoid(raw[..., 1:18]), -2))        # sigmoid on every channel (use_radiance_linear=False)
+    act = torch.sigmoid(raw[..., 1:18])                                            # sigmoid on every channel (use_radiance_linear=False)
+    wd = w.detach()       # albedo, roughness, irradiance and the coarse radiances are composited with weights_detached (:246, :282-315)
+    cols += [torch.sum(wd[..., None] * act[..., 0:5], -2), torch.sum(w[..., None] * act[..., 5:8], -2), torch.sum(wd[..., None] * act[..., 8:17], -2)]
     return torch.cat(cols, -1), w
