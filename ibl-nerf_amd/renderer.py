@@ -979,7 +979,7 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
                 ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
-                                      approximate_radiance=approx, **smp)
+                                      approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), **smp)
         else:
             ret = T.render_rays_direct(r, ro_f, rd_f, *nf, **smp)
         return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}

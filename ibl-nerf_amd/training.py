@@ -219,9 +219,12 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
     return res
 
 
-def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None):
+def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
-    `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for)."""
+    `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
+    teacher_maps (parity tests; the backward's counterpart of iblnerf_composite_pass): {n_dot_v_map[0], reflected_radiance_map[0],
+    reflected_coarse_radiance_map_k[0]} taken as the shading backward's constants instead of this forward's own — the reflected-ray maps are
+    ill-conditioned in the reference itself, and d color / d roughness is proportional to them."""
     torch = _torch()
     from .renderer import RESULT_ORDER, Renderer, _dev_f32
     ro, rd = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
@@ -258,12 +261,13 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
             if approximate_radiance:
+                src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})
                 for sfx in ("", "0"):
-                    env = torch.stack([_ungamma(res[k + sfx], flags["gamma_correct"]) for k in
+                    env = torch.stack([_ungamma(src[k + sfx], flags["gamma_correct"]) for k in
                                        ("reflected_radiance_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")], 1)
                     if flags["use_radiance_linear"]:
                         env = env / (1 - env)                        # inverse of tonemap_reinherd
-                    ctx.saved["consts" + sfx] = dict(n_dot_v=res["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)
+                    ctx.saved["consts" + sfx] = dict(n_dot_v=src["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)
             outs = tuple(res[k] for k in keys)
             ctx.mark_non_differentiable(*[res[k] for k in keys if k.startswith(("target_normal_map", "n_dot_v_map", "reflected_", "z_std"))])
             return outs
