@@ -646,7 +646,10 @@ static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const fl
     if (n_pts == 0) return IBLNERF_OK;
     // The operand stash costs 15.2 KiB per point, so a call is walked in pieces of at most BWD_CHUNK_POINTS points (whole rays: the kernels
     // find a point's view direction by its index inside the piece); every piece adds its weight gradients into d_grad.
-    const long rays_per_piece = std::max<long>(1, BWD_CHUNK_POINTS / pts_per_ray);
+    // (equal-sized pieces: a short tail piece would leave most of the persistent grid idle)
+    const long n_rays_total = ((long)n_pts + pts_per_ray - 1) / pts_per_ray;
+    const long n_pieces = ((long)n_pts + BWD_CHUNK_POINTS - 1) / BWD_CHUNK_POINTS;
+    const long rays_per_piece = std::max<long>(1, (n_rays_total + n_pieces - 1) / n_pieces);
     const long piece = std::min<long>((long)n_pts, rays_per_piece * pts_per_ray);
     const long groups = (piece + 127) / 128, wgs_max = groups * 4;
     const size_t need = (size_t)stash_bytes(wgs_max);

@@ -303,7 +303,7 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     grads_all.append(gk)
             out = []
             for i, (p, gk) in enumerate(zip(params, grads_all)):
-                out.append(gk.reshape(p.shape).clone() if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
+                out.append(gk.reshape(p.shape).to(p.device, copy=True) if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
             return (None, None) + tuple(out)
 
     outs = _Fn.apply(ro, rd, *params)

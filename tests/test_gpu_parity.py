@@ -316,11 +316,12 @@ def test_torch_module_weights_are_tracked(R, lut):
               max_rays_per_launch=64)
     K = np.eye(3, dtype=np.float32)
     rays = torch.from_numpy(np.stack([g["rays_o"][:8], g["rays_d"][:8]], 0))
-    a = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    with torch.no_grad():                           # test.py:141-151 (with autograd on and trainable modules the call is a training step: test_gpu_training.py)
+        a = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
     assert rel_linf(a["albedo_map"].cpu().numpy(), g["out__albedo_map"][:8]) <= 2e-4
     with torch.no_grad():
         net_f.albedo_linear.bias.add_(0.5)          # in-place update, as an optimizer step does
-    b = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+        b = R.render_decomp(800, 800, K, rays=rays, gt_values={}, approximate_radiance=True, **kw)
     assert float((b["albedo_map"] - a["albedo_map"]).abs().min()) > 1e-2     # the new weights were uploaded
     assert torch.equal(b["albedo_map0"], a["albedo_map0"])                   # the coarse network did not change
 
