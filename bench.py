@@ -185,7 +185,9 @@ def main():
     ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6x",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
+    ap.add_argument("--query-routing", default="", help="comma-separated iblnerf_options.query_routing names (A/B measurements, e.g. point_batch)")
     args = ap.parse_args()
+    routing = [n for n in args.query_routing.split(",") if n]
 
     import torch
     import torch.distributed as dist
@@ -222,7 +224,7 @@ def main():
     lut = load_lut()
     K, c2w = camera()
     r = R.Renderer(N_SAMPLES, N_IMPORTANCE, coarse_outputs=not args.inference_min,
-                   max_rays_per_launch=args.rays_per_launch, mlp_precision=args.mlp_precision)
+                   max_rays_per_launch=args.rays_per_launch, mlp_precision=args.mlp_precision, query_routing=routing or 0)
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
@@ -320,6 +322,7 @@ def main():
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
+                       **({"query_routing": routing} if routing else {}),
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if grouped else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

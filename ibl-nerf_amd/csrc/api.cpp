@@ -70,6 +70,7 @@ struct iblnerf_ctx {
     bool have_lut = false;
     // iblnerf_options.query_routing (IBLNERF_ROUTE_*), decoded at iblnerf_create
     bool x_coarse = false, x_user = false, fine_main_precise = false;
+    bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
     size_t bwd_stash_bytes = 0;
     float* bwd_partial = nullptr;
@@ -176,8 +177,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 7 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..7), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 15 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..15), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -204,6 +205,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     c->x_coarse = (opts->query_routing & IBLNERF_ROUTE_COARSE_OFFSETS_MIXED) != 0;
     c->x_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_MIXED) != 0;
     c->fine_main_precise = (opts->query_routing & IBLNERF_ROUTE_FINE_MAIN_PRECISE) != 0;
+    c->fuse_points = (opts->query_routing & IBLNERF_ROUTE_POINT_BATCH) == 0;
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -464,7 +466,7 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
 }
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER) {
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
@@ -509,6 +511,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     a.out_stride = out_stride;
     a.n_pts = n_pts;
     a.pts_per_ray = pts_per_ray;
+    if (gen) a.gen = *gen;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (c->profiling) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -974,8 +977,14 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         rc = run_mlp(c, s, VAR_TRUNK_GRAD, which, c->pts, nullptr, S, R * S, c->sig4, 4, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
         if (rc) return rc;
     } else if (ov.gt_normal == nullptr && !inferred) {
-        HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
+        if (tilt || !c->fuse_points) {
+            HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
+            rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
+        } else {   // the four offset copies are generated in the MLP kernel's input stage: no [4][R][S][3] batch (9.2 KB per ray on the fine grid)
+            PointGen g;
+            g.rays_o = ro; g.rays_d = rd; g.z = z; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+            rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
+        }
         if (rc) return rc;
     }
     PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gen_points.h"
 #include "layout.h"
 
 namespace ibl {
@@ -26,6 +27,7 @@ struct MlpArgs {
     float* out2 = nullptr;           // VAR_TRUNK_FEAT2: [n_pts, 256] that output (out = the trunk features)
     const float* draw = nullptr;     // VAR_NET_BWD: [n_pts, 18] dL / d raw (the network's 18 output channels, ibl_nerf.py:200-208)
     char* stash = nullptr;
+    PointGen gen;                    // VAR_TRUNK / VAR_TRUNK_X only: gen.rays_o != null = the four epsilon-offset copies are generated in the input stage (pts is not read)
     float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
                                      // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels
 };

@@ -21,6 +21,8 @@
 //                 MlpArgs::range_flag (the caller repeats the call on the bf16 flavour).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include <cstdio>
 #include <type_traits>
 
@@ -544,7 +546,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const long p = g * 128 + wave * 32 + (lane & 31);
         const bool valid = p < a.n_pts;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) {
+        PointGenK gen = nullptr;
+#ifndef IBL_NO_POINT_GEN   // (-DIBL_NO_POINT_GEN: A/B build of scratch/trunk_ab.sh, the input stage without the generation branch)
+        if constexpr (VARIANT == VAR_TRUNK) gen = kernarg_point_gen((unsigned)offsetof(MlpArgs, gen));
+#endif
+        if (gen != nullptr && gen->rays_o != nullptr) {   // the offset copies of the epsilon-normal, generated here (gen_points.h) instead of read from a batch
+            if (valid) gen_offset_point(load_point_gen(gen), (unsigned)p, px, py, pz);
+        } else if (valid) {
             px = a.pts[3 * p + 0];
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];

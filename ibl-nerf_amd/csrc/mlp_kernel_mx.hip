@@ -10,6 +10,8 @@
 // residual terms) into one fp32 accumulator = 6 "slots" of ~32 cycles.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include <type_traits>
 
 #include "mlp_args.h"
@@ -625,13 +627,19 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
         const bool valid = p < a.n_pts;
+        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) {
+        PointGenK gen = nullptr;
+#ifndef IBL_NO_POINT_GEN   // (-DIBL_NO_POINT_GEN: A/B build of scratch/trunk_ab.sh, the input stage without the generation branch)
+        if constexpr (TRUNKV) gen = kernarg_point_gen((unsigned)offsetof(MlpArgs, gen));
+#endif
+        if (gen != nullptr && gen->rays_o != nullptr) {   // the offset copies of the epsilon-normal, generated here (gen_points.h) instead of read from a batch
+            if (valid) gen_offset_point(load_point_gen(gen), (unsigned)p, px, py, pz);
+        } else if (valid) {
             px = a.pts[3 * p + 0];
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
         }
-        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X;
         Blk pe, de;
         u32x16 pe_lo, loA[4];   // VAR_TRUNK_X: f16 residuals of the encoding and of layer 0's output
         encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak, VARIANT == VAR_TRUNK_X ? &pe_lo : nullptr);

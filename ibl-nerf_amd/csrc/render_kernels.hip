@@ -12,6 +12,7 @@
 
 #include <type_traits>
 
+#include "gen_points.h"
 #include "kernels.h"
 
 namespace ibl {
@@ -226,13 +227,15 @@ __global__ void k_make_points(int mode, const float* __restrict__ origin, const 
             for (int c = 0; c < 3; ++c) out[3 * (v * R * S + idx) + c] = o[c] + nd[v][c] * zz;
         return;
     }
+    // mode 1: the same device function the MLP kernels' input stage calls (gen_points.h), so a batch and a generated point are one arithmetic
+    PointGen g;
+    g.rays_o = origin; g.rays_d = dir; g.z = z; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float er = eps * right[c], eu = eps * up[c];
-        out[3 * (0 * R * S + idx) + c] = p[c] + er;
-        out[3 * (1 * R * S + idx) + c] = p[c] - er;
-        out[3 * (2 * R * S + idx) + c] = p[c] + eu;
-        out[3 * (3 * R * S + idx) + c] = p[c] - eu;
+    for (int v = 0; v < 4; ++v) {
+        float q[3];
+        gen_offset_point(g, (unsigned)(v * R * S + idx), q[0], q[1], q[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * (v * R * S + idx) + c] = q[c];
     }
 }
 
