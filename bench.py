@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6x",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the frame exchange: nccl (= RCCL, the default) | gloo (test hook: several ranks on one GPU, host-staged)")
     ap.add_argument("--query-routing", default="", help="comma-separated iblnerf_options.query_routing names (A/B measurements, e.g. point_batch)")
     args = ap.parse_args()
     routing = [n for n in args.query_routing.split(",") if n]
@@ -197,15 +199,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    # IBLNERF_BENCH_BACKEND=gloo is a test hook: it lets the N>1 code path run with several ranks sharing the
-    # one GPU of a test box (RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
-    backend = os.environ.get("IBLNERF_BENCH_BACKEND", "nccl")
+    # --backend gloo is a test hook: it lets the N>1 code path run with several ranks sharing the one GPU of a
+    # test box (RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
+    backend = args.backend
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     # a process group whenever torch.distributed.run launched us — also with one rank, so that `--gpus 1` under the launcher takes the
     # same pack + all-gather path (RCCL on device buffers) as the multi-GPU runs; a plain `python bench.py` has no group and no exchange
-    grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("IBLNERF_BENCH_GROUP") == "1"
+    grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

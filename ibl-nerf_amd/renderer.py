@@ -891,7 +891,7 @@ def renderer_for(kw):
            kw.get("mlp_precision") or DEFAULT_MLP_PRECISION,
            kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"),
            bool(getattr(net_c, "is_color_independent_to_direction", False)), float(kw.get("epsilon_direction", 0.005)),
-           bool(kw.get("infer_normal") and kw.get("infer_normal_at_surface")))
+           bool(kw.get("infer_normal") and kw.get("infer_normal_at_surface")), bool(kw.get("_lazy_range_check", False)))
     if net_f is not None and bool(getattr(net_f, "is_color_independent_to_direction", False)) != key[13]:
         raise ValueError("network_fn and network_fine disagree on is_color_independent_to_direction")
     ent = _renderers.get(key)
@@ -901,7 +901,8 @@ def renderer_for(kw):
         r = Renderer(key[0], key[1], epsilon=key[2], gamma_correct=key[3], lut_coefficient=key[4],
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
                      max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12],
-                     color_independent_to_direction=key[13], epsilon_direction=key[14], infer_normal_at_surface=key[15])
+                     color_independent_to_direction=key[13], epsilon_direction=key[14], infer_normal_at_surface=key[15],
+                     range_check="lazy" if key[16] else "eager")
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None, "aux": {}}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):
@@ -952,7 +953,11 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     _check_supported(dict(kwargs, is_depth_only=is_depth_only))
     if c2w_staticcam is not None:
         raise NotImplementedError("c2w_staticcam is a visualisation aid that is not built")
-    r = renderer_for(kwargs)
+    from . import training as T
+    training = T.is_training_call(kwargs)
+    # a training step issues a dozen calls per iteration: its context checks the f16 range without synchronising (range_check="lazy":
+    # the flag snapshot of earlier calls; a gradient overflow skips the step and lowers the loss scale, as torch.cuda.amp does)
+    r = renderer_for(dict(kwargs, _lazy_range_check=True) if training else kwargs)
     if c2w is not None:
         rays_o, rays_d = r.get_rays(H, W, K, c2w)
     else:
@@ -961,12 +966,10 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     sh = rays_d.shape
     edit = {k: kwargs[k] for k in kwargs
             if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
-    from . import training as T
     ro_f, rd_f = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
     nf = (_scalar(near, "near"), _scalar(far, "far"))
     smp = dict(perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)), chunk=chunk)
     approx = bool(kwargs.get("approximate_radiance", False))
-    training = T.is_training_call(kwargs)
     if is_depth_only or not approx or training:
         # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
         if any(v for k, v in edit.items() if isinstance(v, bool)) or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or r._aux or _ci_net(kwargs["network_fn"]):

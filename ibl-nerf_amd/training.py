@@ -178,7 +178,6 @@ def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=Fals
     zf, zstd = st.fine_z(zc, wc, u)
     sig = r.network_query(st.points(ro, rd, zf), None, 1 if r.has_fine else 0)[..., 0].contiguous()      # run_fn = network_fn if network_fine is None (:705)
     wf, df, vf = st.composite_sigma(sig, zf, rd)
-    torch.cuda.current_stream(r.device).synchronize()      # the draws must outlive the launches
     return {"depth_map": df, "weights": wf, "visibility": vf, "depth_map0": dc, "weights0": wc, "visibility0": vc, "z_std": zstd}
 
 
@@ -201,8 +200,7 @@ def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags):
         o = _ray_outputs(m, None, flags)
         o["weights"] = w
         res.update({k + sfx: o[k] for k in BASE_KEYS})
-    res["z_std"] = zstd
-    torch.cuda.current_stream(r.device).synchronize()      # the draws must outlive the launches
+    res["z_std"] = zstd       # (no synchronisation: every launch is on torch's current stream, whose allocator reuses freed blocks in stream order)
     return res, dict(zc=zc, zf=zf, rawc=rawc, rawf=rawf)
 
 

@@ -5,7 +5,7 @@ Every rank renders its row tile of a small frame with the HIP renderer under obj
 (BASELINE configs 3 and 5: partition + per-tile override rows + pack + all-gather + unpack, all on device tensors), then
 renders the WHOLE frame by itself and checks that the gathered frame is bit-identical to it.  Prints "DIST_OK <rank>".
 
-Backend: "nccl" (= RCCL; one GPU per rank) or, with IBLNERF_BENCH_BACKEND=gloo, gloo with all ranks sharing the one GPU of
+Backend: "nccl" (= RCCL; one GPU per rank) or, with `--backend gloo`, gloo with all ranks sharing the one GPU of
 a test box (RCCL refuses two ranks on one device).  Not a pytest file.
 """
 import os
@@ -22,7 +22,7 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    backend = os.environ.get("IBLNERF_BENCH_BACKEND", "nccl")
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "nccl"
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)

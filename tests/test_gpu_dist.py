@@ -1,5 +1,5 @@
 """The sharded path (BASELINE configs 3 and 5) on a GPU: two ranks under torch.distributed.run.  On a one-GPU box both ranks
-share the device and exchange over gloo (RCCL refuses two ranks on one device; IBLNERF_BENCH_BACKEND=gloo); with two or more
+share the device and exchange over gloo (RCCL refuses two ranks on one device; `--backend gloo`); with two or more
 GPUs visible the same tests run one rank per GPU over RCCL.  The launcher is a fresh child process (nothing is exec'd from this
 GPU-initialised process other than through subprocess)."""
 import json
@@ -20,17 +20,13 @@ torch = pytest.importorskip("torch")
 def _launch(script_args, timeout=900, nproc=2):
     n_gpu = torch.cuda.device_count()
     assert n_gpu >= 1, "GPU tests need a HIP device"
-    env = dict(os.environ)
-    if n_gpu < nproc:
-        env["IBLNERF_BENCH_BACKEND"] = "gloo"
-    else:
-        env.pop("IBLNERF_BENCH_BACKEND", None)
+    backend = "gloo" if n_gpu < nproc else "nccl"          # RCCL refuses two ranks on one device: those runs exchange over gloo, host-staged
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port)] + script_args
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env), env.get("IBLNERF_BENCH_BACKEND", "nccl")
+           "--master-port", str(port)] + script_args + ["--backend", backend]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT), backend
 
 
 def test_two_rank_bench_step():
@@ -45,6 +41,20 @@ def test_two_rank_bench_step():
     assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert ("RCCL" if backend == "nccl" else backend) in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
     assert d["roofline"]["range_fallbacks"] == 0 and d["roofline"]["launches_per_step"] > 0
+
+
+def test_eight_rank_bench_step():
+    """bench.py --gpus 8 as the driver launches it on an 8-GPU node (BASELINE configs 3 and 5): eight ranks, 100-row tiles, the padded flat
+    all-gather — here with the eight ranks sharing the one GPU of the test box over gloo (with eight GPUs visible: one each, RCCL)."""
+    out, backend = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"], nproc=8, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and "x8" in d["config"]["parallelism"]
+    assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["pack_ms"] > 0 and d["gather_ms"] > 0 and d["exchange"]["bytes_per_rank"] == 100 * 800 * 4 * 47
+    assert d["roofline"]["range_fallbacks"] == 0
 
 
 def test_two_rank_frame_with_overrides_is_bit_identical():
