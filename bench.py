@@ -318,7 +318,9 @@ def main():
             "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": MODES[args.mlp_precision][0],
+            "dtype": {"bf16x3": "bf16 (3 MFMA products on hi/lo splits), fp32 accumulate"}.get(
+                args.mlp_precision, "f16 (MFMA products per query class: 3x f16 on hi/lo splits, or f16 + 2x MX-fp6 residuals), fp32 accumulate"),
+            "dtype_detail": MODES[args.mlp_precision][0],
             "data": ("synthetic (checkpoint fitted to an analytic scene with the reference's own modules, reference state-dict schema; synthetic pinhole camera)"
                      if args.checkpoint == "fitted" else "synthetic (seeded random-init checkpoint in the reference state-dict schema, synthetic pinhole camera)"),
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
