@@ -125,6 +125,22 @@ def _frame_rays(r):
     return ro.reshape(-1, 3), rd.reshape(-1, 3)
 
 
+def test_full_frame_of_config_2_at_the_fixture_pixels(R, lut):
+    """BASELINE configs[1] at full size, the frame bench.py times (fitted checkpoint, default mode, 65 536-ray launches): the 16 384 pixels the
+    reference rendered, picked out of the 640 000, by the launch-scale rules — the frame path (get_rays on the device, ten equal launches)
+    against the reference, not only a 16 384-ray call."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    r = make_renderer(R, g, sdc, sdf, lut)
+    ro, rd = _frame_rays(r)
+    m = r.render_rays(ro, rd, 0.5, 8.0)
+    torch.cuda.synchronize()
+    assert r.range_fallbacks == 0
+    assert all(bool(torch.isfinite(v).all()) for v in m.values())
+    idx = torch.as_tensor(g["pix"], device=rd.device)
+    assert np.abs(rd[idx].cpu().numpy() - g["rays_d"]).max() <= 2e-7
+    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g)
+
+
 @pytest.mark.parametrize("name,rows_fn", [("fitted_edit_cfg4", FO.edit_rows), ("fitted_insert_cfg5", FO.insert_rows)])
 def test_full_frame_of_configs_4_and_5(R, lut, name, rows_fn):
     """BASELINE configs[3] / [4] at full size on the HIP path: 640 000 rays of the fitted checkpoint under the shipped edit / insert kwargs
