@@ -68,10 +68,14 @@ def network_query(sd, pts, viewdirs):
 O.network_query = network_query
 
 CLASS, n_rays = sys.argv[1], int(sys.argv[2])
-g, sdc, sdf, gt, edit = load_golden("fitted_launch16k")
+FIXTURE = os.environ.get("PROBE_FIXTURE", "fitted_launch16k")
+g, sdc, sdf, gt, edit = load_golden(FIXTURE)
 fl = np.maximum.reduce([g["floorray__" + k] for k in ("target_normal_map0", "target_normal_map", "depth_map", "depth_map0")])
 order = np.argsort(-fl)
 rsel = np.concatenate([order[:n_rays // 2], np.random.RandomState(0).permutation(order[n_rays // 2:])[:n_rays - n_rays // 2]])
+if os.environ.get("PROBE_RAYS"):      # explicit ray ids first (e.g. the rays a GPU run flagged)
+    extra = np.array([int(t) for t in os.environ["PROBE_RAYS"].split(",")])
+    rsel = np.concatenate([extra, np.setdiff1d(rsel, extra)[:n_rays - len(extra)]])
 lut = load_lut_rgb()
 keys = ("target_normal_map0", "target_normal_map", "depth_map0", "depth_map", "albedo_map", "roughness_map")
 print("class %s, %d rays (the %d worst-conditioned of 16 384 + random); reference's own f64-vs-f32 on them: %s" % (
@@ -87,3 +91,7 @@ for scheme in sys.argv[3:]:
         row.append("%s %.1e/%.1e" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)]))
     slots = sum({"p": 12, "f": 6, "a": 9, "w": 9}[c] for c in scheme[:8]) / 8
     print("%-10s %4.1f slots  (max / 98%%)  %s   [%.0f s]" % (scheme, slots, "  ".join(row), time.time() - t0), flush=True)
+    if os.environ.get("PROBE_RAYS"):
+        ref = g["out__target_normal_map"][rsel].astype(np.float64)
+        e = np.abs(res["target_normal_map"].astype(np.float64) - ref).max(-1)
+        print("           normal error on the listed rays:", " ".join("%.1e" % v for v in e[:len(extra)]), flush=True)

@@ -554,7 +554,7 @@ def train_step_fixture(torch, R, M, lut, n_rays=64):
                                                            os.path.getsize(path) / 1e6))
 
 
-def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3):
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False):
     """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
     reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
     every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
@@ -582,6 +582,13 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
     kw["brdf_lut"] = lut
     rng = np.random.RandomState(1000 + seed)
     o, d, pix, focal = camera_rays(rng, n_rays)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    if posed:   # a rotated + translated camera (BASELINE configs 3 / 5: "any fixed look-at"): rays_o != 0, rays_d = R dirs as get_rays builds them (:41-44)
+        q, _ = np.linalg.qr(np.eye(3) + 0.25 * rng.randn(3, 3))
+        q = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+        c2w = np.concatenate([q, np.array([[0.35], [-0.25], [0.5]], np.float32)], 1).astype(np.float32)
+        d = np.sum(d[:, None, :] * c2w[:3, :3], -1).astype(np.float32)
+        o = np.broadcast_to(c2w[:3, 3], d.shape).copy()
     edit = dict(EDIT_KEYS_OFF)
     gt = {}
     if mode == "edit_cfg4":
@@ -648,7 +655,7 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
                seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1), n_importance=np.int64(128), n_samples=np.int64(64),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
                ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))), mode=np.array(mode), ckpt=np.array("fitted"),
-               weights_every=np.int64(weights_every), chunk=np.int64(chunk), n_nudge=np.int64(n_nudge))
+               weights_every=np.int64(weights_every), chunk=np.int64(chunk), n_nudge=np.int64(n_nudge), c2w=c2w)
     for k, v in gt.items():
         out["gt__" + k] = v
     for k, v in edit.items():
@@ -846,6 +853,7 @@ def main(only=None):
     for nm, kws in (("fitted_launch16k", dict(n_rays=16384, seed=30)),
                     ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4, n_nudge=4)),
                     ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4, n_nudge=4)),
+                    ("fitted_posed4k", dict(n_rays=4096, seed=34, weights_every=4, n_nudge=4, posed=True)),
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:
             launch_scale_fixture(nm, torch, R, M, lut, **kws)
