@@ -554,7 +554,11 @@ def train_step_fixture(torch, R, M, lut, n_rays=64):
                                                            os.path.getsize(path) / 1e6))
 
 
-def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False):
+COMPACT_KEYS = ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "radiance_map", "target_normal_map", "n_dot_v_map", "prefiltered_reflected_map",
+                "specular_map", "diffuse_map", "color_map", "depth_map0", "target_normal_map0")
+
+
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False, compact=False):
     """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
     reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
     every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
@@ -567,7 +571,9 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
     `n_nudge` times with the reference's own sample_pdf called on weights multiplied by (1 + s 2^-23), s in {-1, 0, 1} drawn per entry
     (the wrapper passes them on; nothing else changes), and the largest per-ray change of each map against the un-nudged run is recorded:
     what one ulp on the coarse pass's weights does to the reference's own output.
-    mode: "plain" | "edit_cfg4" | "insert_cfg5" (tests/frame_overrides.py: the kwargs of the two shipped configs, analytic images)."""
+    mode: "plain" | "edit_cfg4" | "insert_cfg5" (tests/frame_overrides.py: the kwargs of the two shipped configs, analytic images).
+    compact (a whole 65 536-ray launch in < 30 MB): only COMPACT_KEYS are kept, the two per-ray yardsticks as float16, and the rays are not
+    stored (the test rebuilds them from `pix` with get_rays)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import frame_overrides as FO
     tmp = tempfile.mkdtemp()
@@ -660,15 +666,22 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
         out["gt__" + k] = v
     for k, v in edit.items():
         out["edit__" + k] = np.asarray(v, dtype=np.float32) if isinstance(v, list) else np.asarray(v)
+    if compact:
+        del out["rays_o"], out["rays_d"]
+        out["compact"] = np.asarray(True)
+        out["floor_scale"] = np.float64(16384.0)
     for k, v in ret.items():
+        if compact and k not in COMPACT_KEYS:
+            continue
         a, b = v.astype(np.float64), ret64[k]
         scale = max(float(np.nanmax(np.abs(b))), 1e-30)
         diff = np.abs(a - b).reshape(n_rays, -1)
         out["floor__" + k] = np.float64(np.nanmax(diff) / scale)
-        out["floorray__" + k] = (np.nanmax(diff, -1) / scale).astype(np.float32)
+        fdt, fs = (np.float16, 16384.0) if compact else (np.float32, 1.0)      # compact: float16 of 2^14 x the value (resolution down to 4e-9)
+        out["floorray__" + k] = np.minimum(np.nanmax(diff, -1) / scale * fs, 6e4).astype(fdt)
         if nudged and not k.endswith("0"):         # (the coarse pass comes before sample_pdf: its maps cannot move)
             nd = np.maximum.reduce([np.nanmax(np.abs(r_[k].astype(np.float64) - a).reshape(n_rays, -1), -1) for r_ in nudged]) / scale
-            out["nudgeray__" + k] = nd.astype(np.float32)
+            out["nudgeray__" + k] = np.minimum(nd * fs, 6e4).astype(fdt)
         out["out__" + k] = v.astype(np.float32)[::weights_every] if k.startswith("weights") else v.astype(np.float32)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
@@ -854,6 +867,7 @@ def main(only=None):
                     ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4, n_nudge=4)),
                     ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4, n_nudge=4)),
                     ("fitted_posed4k", dict(n_rays=4096, seed=34, weights_every=4, n_nudge=4, posed=True)),
+                    ("fitted_launch64k", dict(n_rays=65536, seed=35, n_nudge=2, compact=True)),        # one whole launch of bench.py's frame: ~40 minutes of reference CPU time
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:
             launch_scale_fixture(nm, torch, R, M, lut, **kws)
