@@ -624,10 +624,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     unsigned wsc = 0, peak = 0;
 
     const long n_groups = (a.n_pts + 127) / 128;
+#ifdef IBL_MX_ABLATE_PROLOGUE   // timing ablation only (results are garbage): the input stage (points + encoding) runs in the first iteration only
+    Blk pe, de;
+    u32x16 pe_lo, loA[4];
+#endif
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
         const bool valid = p < a.n_pts;
         constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X;
+#ifdef IBL_MX_ABLATE_PROLOGUE
+        if (g == blockIdx.x) {
+#endif
         float px = 0.f, py = 0.f, pz = 0.f;
         PointGenK gen = nullptr;
 #ifndef IBL_NO_POINT_GEN   // (-DIBL_NO_POINT_GEN: A/B build of scratch/trunk_ab.sh, the input stage without the generation branch)
@@ -640,8 +647,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
         }
+#ifndef IBL_MX_ABLATE_PROLOGUE
         Blk pe, de;
         u32x16 pe_lo, loA[4];   // VAR_TRUNK_X: f16 residuals of the encoding and of layer 0's output
+#endif
         encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak, VARIANT == VAR_TRUNK_X ? &pe_lo : nullptr);
         if constexpr (!TRUNKV && !variant_ci(VARIANT)) {
             float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -653,6 +662,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             }
             encode<DE_PAIRS_PER_HALF>(dx, dy, dz, h, de, peak);
         }
+#ifdef IBL_MX_ABLATE_PROLOGUE
+        }
+#endif
 
         Act A, B;
         f32x2 part[RAW_CH];

@@ -9,7 +9,8 @@ f = np.load(os.path.join(ROOT, "tests", "golden", "fitted_ckpt.npz"))
 sd = ck.blob_to_state_dict(f["fine"])
 N, S = 65536, 256
 pts = (torch.rand((N, S, 3), device="cuda") * 3 - 1.5).contiguous()
-for name, kw in (("mixed TRUNK (mxk<5>)", dict(mlp_precision="f16x3_mxfp6x", query_routing="user_trunk_mixed")), ("f16x3 TRUNK", dict(mlp_precision="f16x3"))):
+for name, kw in (("mixed TRUNK (mxk<5>)", dict(mlp_precision="f16x3_mxfp6x", query_routing="user_trunk_mixed")), ("f16x3 TRUNK", dict(mlp_precision="f16x3")),
+                 ("fast TRUNK (mxk<1>)", dict(mlp_precision="f16_mxfp6"))):
     r = R.Renderer(64, 128, max_rays_per_launch=64, **kw)
     r.load_weights(0, sd); r.load_weights(1, sd)
     r.network_query(pts, None, 1); torch.cuda.synchronize()
