@@ -558,7 +558,7 @@ COMPACT_KEYS = ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "r
                 "specular_map", "diffuse_map", "color_map", "depth_map0", "target_normal_map0")
 
 
-def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False, compact=False):
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False, compact=False, augment=False):
     """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
     reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
     every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
@@ -572,6 +572,13 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
     (the wrapper passes them on; nothing else changes), and the largest per-ray change of each map against the un-nudged run is recorded:
     what one ulp on the coarse pass's weights does to the reference's own output.
     mode: "plain" | "edit_cfg4" | "insert_cfg5" (tests/frame_overrides.py: the kwargs of the two shipped configs, analytic images).
+    A third, deterministic one, `branchray__<map>`: the nudges reach a threshold-critical ray only by luck (pixel 390 016 moved by 3.1e-3 under four
+    nudges in one fixture and not at all under two in another), so the float32 render is also repeated with the reference's sample_pdf output
+    post-processed: every fine sample whose denominator lies within 4e-7 of the 1e-5 threshold (an empty bin: 167 or 168 ulps of the cdf) is placed
+    once as the reference's `denom -> 1` branch places it (collapsed onto the bin's edge) and once as its other branch does (interpolated with
+    the computed denominator) — both are outcomes the reference reaches under last-bit changes of its own sums; the larger per-ray change of each
+    map against the reference's actual float32 output is recorded.
+    augment=True: the fixture exists; only the branch yardstick is (re)computed and added (the float32 outputs in the file are the base).
     compact (a whole 65 536-ray launch in < 30 MB): only COMPACT_KEYS are kept, the two per-ray yardsticks as float16, and the rays are not
     stored (the test rebuilds them from `pix` with get_rays)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -623,11 +630,66 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
         return {k: v.detach().numpy() for k, v in ret.items()}
 
     import time
+    pdf0 = R.sample_pdf
+
+    def pdf_branch(collapse):
+        """the reference's sample_pdf (det=True) with its threshold-critical samples re-placed by one of its two branches"""
+        def f(bins, weights, N, det=False, pytest=False):
+            out_ = pdf0(bins, weights, N, det=det, pytest=pytest)
+            assert det and not pytest
+            w_ = weights + 1e-5                                             # the reference's own operations (nerf_renderer_helper.py:93-96, :100-101, :116-129)
+            pdf_ = w_ / torch.sum(w_, -1, keepdim=True)
+            cdf_ = torch.cumsum(pdf_, -1)
+            cdf_ = torch.cat([torch.zeros_like(cdf_[..., :1]), cdf_], -1)
+            u_ = torch.linspace(0., 1., steps=N).expand(list(cdf_.shape[:-1]) + [N]).contiguous()
+            inds = torch.searchsorted(cdf_, u_, right=True)
+            below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+            above = torch.min((cdf_.shape[-1] - 1) * torch.ones_like(inds), inds)
+            c0, c1 = torch.gather(cdf_, 1, below), torch.gather(cdf_, 1, above)
+            b0, b1 = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+            den = c1 - c0
+            crit = (den - 1e-5).abs() <= 4e-7
+            t_ = (u_ - c0) / (torch.ones_like(den) if collapse else den)
+            return torch.where(crit, b0 + t_ * (b1 - b0), out_)
+        return f
+
+    def branch_runs():
+        outs, tt = [], time.time()
+        for collapse in (True, False):
+            R.sample_pdf = pdf_branch(collapse)
+            try:
+                outs.append(render(torch.float32))
+            finally:
+                R.sample_pdf = pdf0
+        return outs, time.time() - tt
+
+    path = os.path.join(OUT, name + ".npz")
+    if augment:
+        old_ = dict(np.load(path))
+        assert np.array_equal(old_["pix"], pix)
+        br, t_br = branch_runs()
+        fs = float(old_["floor_scale"]) if "floor_scale" in old_ else 1.0
+        we_ = int(old_["weights_every"])
+        for k in [k_[5:] for k_ in old_ if k_.startswith("out__")]:
+            if k.endswith("0") or k == "z_std":
+                continue
+            base = old_["out__" + k].astype(np.float64)
+            scale = max(float(np.nanmax(np.abs(base))), 1e-30)
+            sub = (lambda a: a[::we_]) if k.startswith("weights") else (lambda a: a)
+            nd = np.maximum.reduce([np.nanmax(np.abs(sub(r_[k]).astype(np.float64) - base).reshape(len(base), -1), -1) for r_ in br]) / scale
+            if k.startswith("weights"):      # per-ray arrays are full length; the weights themselves are kept for every `weights_every`-th ray
+                full = np.zeros(n_rays)
+                full[::we_] = nd
+                nd = full
+            old_["branchray__" + k] = np.minimum(nd * fs, 6e4).astype(old_["floorray__" + k].dtype)
+        np.savez_compressed(path, **old_)
+        print("%-28s %5d rays  + threshold-branch yardstick (%.0f s)  %.2f MB" % (name, n_rays, t_br, os.path.getsize(path) / 1e6))
+        return
     t0 = time.time()
     ret = render(torch.float32)
     t32 = time.time() - t0
     nudged, t_nudge = [], 0.0
-    pdf0 = R.sample_pdf
+    br, t_br = branch_runs()
     for m in range(n_nudge):
         nrng = np.random.RandomState(9000 + 10 * seed + m)
 
@@ -682,6 +744,9 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
         if nudged and not k.endswith("0"):         # (the coarse pass comes before sample_pdf: its maps cannot move)
             nd = np.maximum.reduce([np.nanmax(np.abs(r_[k].astype(np.float64) - a).reshape(n_rays, -1), -1) for r_ in nudged]) / scale
             out["nudgeray__" + k] = np.minimum(nd * fs, 6e4).astype(fdt)
+        if not k.endswith("0") and k != "z_std":
+            bd = np.maximum.reduce([np.nanmax(np.abs(r_[k].astype(np.float64) - a).reshape(n_rays, -1), -1) for r_ in br]) / scale
+            out["branchray__" + k] = np.minimum(bd * fs, 6e4).astype(fdt)
         out["out__" + k] = v.astype(np.float32)[::weights_every] if k.startswith("weights") else v.astype(np.float32)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
@@ -871,6 +936,8 @@ def main(only=None):
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:
             launch_scale_fixture(nm, torch, R, M, lut, **kws)
+        elif only and nm + "+branch" in only:       # add the threshold-branch yardstick to an existing fixture (two float32 renders)
+            launch_scale_fixture(nm, torch, R, M, lut, augment=True, **kws)
     # the autograd normal modes (normal_from_depth.py:16-52 direction, :102-137 position), run with gradients enabled as in training;
     # posed cameras; one on the fitted checkpoint
     run_fixture("gradnormal_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=24, posed=True, autograd=True, n_keep=4, record_floor=True,
