@@ -25,7 +25,7 @@ array for 8-bit PNGs; alpha is dropped by both).  `image_scale`: 1 and 0.5 (the 
 other scale goes through `resize_linear`, OpenCV's general bilinear path restated from its published algorithm (unpinned: no cv2 here);
 0.5 follows cv2.resize's documented INTER_LINEAR behaviour for an exact 2x reduction (a 2x2 box mean,
 rounded half up for 8-bit data) — cv2 is not in this image, so that one step is restated from OpenCV's source
-and NOT pinned by a run.  The prior images used only by the training losses are not
+and NOT pinned by a run.  (Round 3: the prior images and prefiltered targets of the training losses are read too.)  The prior images used only by the training losses were not
 built: they raise.  Nothing here touches the GPU until `to_tensor`."""
 from __future__ import annotations
 
@@ -160,9 +160,10 @@ class NerfDataset:
                   "load_priors", "load_edit_intrinsic_mask", "load_edit_albedo", "load_edit_normal", "load_edit_roughness",
                   "load_edit_irradiance", "load_edit_depth", "object_insert"):
             setattr(self, f, bool(g(f, False)))
-        if self.load_priors:
-            raise NotImplementedError("prior albedo/irradiance images feed the training losses only (SURVEY.md §8 f-3)")
         self.prior_type = g("prior_type", "bell")
+        self.prior_irradiance_mean = 0.7                                           # dataset_interface.py:44 (a Mitsuba scene reads it from avg_irradiance.json)
+        self.coarse_resize_scale = 4                                               # :63
+        self.prefiltered_images = []
         self.full_data_loaded = False
         self._lists = {}
         self.poses = []
@@ -192,6 +193,53 @@ class NerfDataset:
         if self.poses is not None and len(self.poses) > 0:
             self.poses = put(self.poses)
         self._lists = {k: put(v) for k, v in self._lists.items()}
+        self._device = device      # the prefiltered radiance targets rgb_1.. (:259-265) are built on first use: only a training step reads them,
+        self._prefiltered = None   # and test.py's flow (coarse_radiance_number = 3 on any image size) must not pay or fail for them
+
+    @property
+    def prefiltered_images(self):
+        if getattr(self, "_prefiltered", None) is None:
+            if "image" not in self._lists or len(self._lists["image"]) == 0:
+                return []
+            self._prefiltered = [self.get_coarse_images(i + 1).to(getattr(self, "_device", "cpu")) for i in range(self.coarse_radiance_number or 0)]
+        return self._prefiltered
+
+    @prefiltered_images.setter
+    def prefiltered_images(self, value):
+        self._prefiltered = value or None
+
+    def get_coarse_images(self, level):
+        """dataset_interface.py:162-176: every image reduced `level` times by coarse_resize_scale (integer division of the unscaled size) and
+        brought back to (height, width), both with torchvision's antialiased bilinear Resize — the targets of the coarse radiance heads."""
+        import torch
+        import torch.nn.functional as F
+        imgs = self._lists["image"]
+        sh, sw = int(self.height / self.scale), int(self.width / self.scale)
+        for _ in range(level):
+            sh, sw = sh // self.coarse_resize_scale, sw // self.coarse_resize_scale
+        out = []
+        for i in range(len(imgs)):
+            t = torch.as_tensor(imgs[i]).permute(2, 0, 1)[None]
+            t = F.interpolate(t, size=(sh, sw), mode="bilinear", antialias=True, align_corners=False)
+            t = F.interpolate(t, size=(self.height, self.width), mode="bilinear", antialias=True, align_corners=False)
+            out.append(t[0].permute(1, 2, 0))
+        return torch.stack(out, 0)
+
+    def get_info(self, image_index, u, v):
+        """dataset_interface.py:178-197: what a training step reads at pixel(s) (u, v) of one view — rgb, the prefiltered rgb_k, the loaded
+        intrinsics, and under load_priors the prior albedo and (one channel) prior irradiance."""
+        L = self._lists
+        info = {"rgb": L["image"][image_index][v, u, :]}
+        for i in range(self.coarse_radiance_number or 0):
+            info["rgb_%d" % (i + 1)] = self.prefiltered_images[i][image_index][v, u, :]
+        for key, flag, sl in (("albedo", "load_albedo", True), ("normal", "load_normal", True), ("roughness", "load_roughness", False),
+                              ("depth", "load_depth", False), ("irradiance", "load_irradiance", True)):
+            if getattr(self, flag):
+                info[key] = L[key][image_index][v, u, :] if sl else L[key][image_index][v, u]
+        if self.load_priors:
+            info["prior_albedo"] = L["prior_albedo"][image_index][v, u, :]
+            info["prior_irradiance"] = L["prior_irradiance"][image_index][v, u, 0]
+        return info
 
     @property
     def images(self):
@@ -220,6 +268,17 @@ class NerfDataset:
                                                     mode="bilinear", antialias=True, align_corners=False)
                 x = t[0].permute(1, 2, 0)
             out[key] = x
+        if self.load_priors and "prior_albedo" in self._lists:
+            # dataset_interface.py:121-125 permutes the resized [C, h, w] priors with (2, 0, 1) where every other map uses (1, 2, 0): they come
+            # out as [w, C, h].  Nothing on the render path reads them; mirrored so that the dict is the reference's.
+            import torch
+            import torch.nn.functional as F
+            for key in ("prior_albedo", "prior_irradiance"):
+                t = torch.as_tensor(self._lists[key][i]).permute(2, 0, 1)
+                if resize_factor not in (0, 1):
+                    t = F.interpolate(t[None], size=(self.height // resize_factor, self.width // resize_factor), mode="bilinear", antialias=True,
+                                      align_corners=False)[0]
+                out[key] = t.permute(2, 0, 1)
         return out
 
     def __str__(self):
@@ -237,6 +296,9 @@ class MitsubaDataset(NerfDataset):
             with open(os.path.join(basedir, "min_max_depth.json")) as fp:
                 f = json.load(fp)
             self.near, self.far = f["min_depth"] * 0.9, f["max_depth"] * 1.1
+        if self.load_priors:                                                       # :18-21
+            with open(os.path.join(basedir, "avg_irradiance.json")) as fp:
+                self.prior_irradiance_mean = json.load(fp)["mean_" + self.prior_type]
         with open(os.path.join(basedir, "transforms_{}.json".format(self.split))) as fp:
             self.meta = json.load(fp)
         self.skip = 1 if self.split == "train" else g("skip", 1)
@@ -267,6 +329,9 @@ class MitsubaDataset(NerfDataset):
                         sample[key] = load_numpy_from_path(p, self.scale)[..., None]
 
         read(_PER_VIEW)
+        if self.load_priors:                                                       # :66-67, :99-101: <n>_<prior_type>_r.png / _s.png
+            sample["prior_albedo"] = load_image_from_path(os.path.join(d, "%d_%s_r.png" % (n, self.prior_type)), self.scale)
+            sample["prior_irradiance"] = load_image_from_path(os.path.join(d, "%d_%s_s.png" % (n, self.prior_type)), self.scale)
         if self.load_edit_intrinsic_mask:                                          # dataset_mitsuba.py:105-117
             sample["edit_intrinsic_mask"] = load_image_from_path(os.path.join(d, "%d_edit_intrinsic_mask.png" % n), self.scale)
             read(_EDIT)
@@ -308,9 +373,12 @@ class ColmapDataset(NerfDataset):
             raise IndexError(index)
         frame = self.meta["frames"][::self.skip][self.index_list[index]]
         sample = {}
+        name = os.path.split(frame["file_path"])[-1]
         if self.load_image:
-            sample["image"] = load_image_from_path(os.path.join(self.basedir, "images", os.path.split(frame["file_path"])[-1]),
-                                                   self.scale)
+            sample["image"] = load_image_from_path(os.path.join(self.basedir, "images", name), self.scale)
+        if self.load_priors:                                                       # <name>_<prior_type>_r.png / _s.png beside the image (:49-60)
+            sample["prior_albedo"] = load_image_from_path(os.path.join(self.basedir, "images", name[:-4] + "_%s_r.png" % self.prior_type), self.scale)
+            sample["prior_irradiance"] = load_image_from_path(os.path.join(self.basedir, "images", name[:-4] + "_%s_s.png" % self.prior_type), self.scale)
         sample["pose"] = np.array(frame["transform_matrix"]).astype(np.float32)   # no axis flips (:62-63)
         return sample
 

@@ -168,11 +168,12 @@ def load_params(**over):
 
 MODES = {"plain": dict(skip=2), "all": dict(skip=1),
          "edit": dict(skip=1, load_edit_intrinsic_mask=True, load_edit_albedo=True, load_edit_normal=True, load_edit_depth=True, editing_idx=2),
-         "insert": dict(skip=1, object_insert=True, editing_idx=3)}
+         "insert": dict(skip=1, object_insert=True, editing_idx=3),
+         "train": dict(split="train", load_priors=True, coarse_radiance_number=1)}     # train.py:100-130's reader: priors + one prefiltered target level
 
 
 def read_with(load_dataset, root, mode, as_numpy):
-    ds = load_dataset("mitsuba", str(root), split="test", **load_params(**MODES[mode]))
+    ds = load_dataset("mitsuba", str(root), **dict(dict(split="test"), **load_params(**MODES[mode])))
     ds.load_all_data(num_of_workers=0)
     ds.to_tensor("cpu")
     out = {"hwf": np.array([ds.height, ds.width, ds.focal], np.float64), "near_far": np.array([ds.near, ds.far], np.float64),
@@ -180,6 +181,11 @@ def read_with(load_dataset, root, mode, as_numpy):
     for i in range(len(ds)):
         for k, v in ds.get_resized_normal_albedo(1, i).items():
             out["gt%d__%s" % (i, k)] = as_numpy(v)
+    if mode == "train":
+        out["prior_irradiance_mean"] = np.float64(ds.prior_irradiance_mean)
+        out["prefiltered_1"] = as_numpy(ds.prefiltered_images[0])
+        for k, v in ds.get_info(1, np.array([0, 3, 7]), np.array([5, 2, 0])).items():
+            out["info__" + k] = as_numpy(v)
     return out
 
 

@@ -58,6 +58,12 @@ def write_scene(root):
         truth[n]["insert_depth"] = d
         np.save(root / "test" / ("%d_insert_depth.npy" % n), d)                      # float64 on disk -> float32 in memory
         np.save(root / "test" / ("%d_edit_depth.npy" % n), d.astype(np.float32) + 1)
+    for n in range(1, N_TEST + 1):       # the train split: images (1.png exists), prior albedo / irradiance of prior_type "bell" (dataset_mitsuba.py:66-67)
+        if n > 1:
+            Image.fromarray(img()).save(root / "train" / ("%d.png" % n))
+        Image.fromarray(img()).save(root / "train" / ("%d_bell_r.png" % n))
+        Image.fromarray(img()).save(root / "train" / ("%d_bell_s.png" % n))
+    json.dump({"mean_bell": 0.4375, "mean_other": 0.9}, open(root / "avg_irradiance.json", "w"))
     frames = [{"fov_degree": FOV, "transform": look(i).tolist()} for i in range(N_TEST)]
     for split in ("train", "test"):
         json.dump({"frames": frames}, open(root / ("transforms_%s.json" % split), "w"))
@@ -132,8 +138,10 @@ def test_reader_colmap(tmp_path):
     assert test.get_resized_normal_albedo(1, 0) == {}
     half = DS.load_dataset("colmap", str(root), split="val", image_scale=0.5, load_image=False)
     assert (half.height, half.width) == (2, 3) and "image" not in half[0] and len(half) == 3
-    with pytest.raises(NotImplementedError):
-        DS.load_dataset("colmap", str(root), load_priors=True)
+    pri = DS.load_dataset("colmap", str(root), load_priors=True)                    # prior files sit beside the images (:49-60); none written here
+    assert pri.prior_irradiance_mean == 0.7 and pri.prior_type == "bell"           # dataset_interface.py:42-44
+    with pytest.raises(FileNotFoundError):
+        pri[0]
 
 
 def test_reader_mitsuba_eval(tmp_path):
@@ -264,10 +272,11 @@ def test_reader_matches_the_reference_reader(scene):
                 load_priors=False)
     modes = {"plain": dict(skip=2), "all": dict(skip=1),
              "edit": dict(skip=1, load_edit_intrinsic_mask=True, load_edit_albedo=True, load_edit_normal=True, load_edit_depth=True, editing_idx=2),
-             "insert": dict(skip=1, object_insert=True, editing_idx=3)}
+             "insert": dict(skip=1, object_insert=True, editing_idx=3),
+             "train": dict(split="train", load_priors=True, coarse_radiance_number=1)}     # train.py's reader: priors + one prefiltered target level
     seen = set()
     for mode, kw in modes.items():
-        ds = DS.load_dataset("mitsuba", str(root), split="test", **dict(base, **kw))
+        ds = DS.load_dataset("mitsuba", str(root), **dict(dict(base, split="test"), **kw))
         ds.load_all_data(num_of_workers=1)
         ds.to_tensor("cpu")
         got = {"hwf": np.array([ds.height, ds.width, ds.focal], np.float64), "near_far": np.array([ds.near, ds.far], np.float64),
@@ -275,6 +284,11 @@ def test_reader_matches_the_reference_reader(scene):
         for i in range(len(ds)):
             for k, v in ds.get_resized_normal_albedo(1, i).items():
                 got["gt%d__%s" % (i, k)] = v.numpy() if hasattr(v, "numpy") else np.asarray(v)
+        if mode == "train":
+            got["prior_irradiance_mean"] = np.float64(ds.prior_irradiance_mean)
+            got["prefiltered_1"] = ds.prefiltered_images[0].numpy()
+            for k, v in ds.get_info(1, np.array([0, 3, 7]), np.array([5, 2, 0])).items():
+                got["info__" + k] = np.asarray(v)
         for k, v in got.items():
             want = g["%s__%s" % (mode, k)]
             assert np.asarray(v).shape == want.shape and np.array_equal(np.asarray(v), want), (mode, k)
