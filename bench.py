@@ -11,7 +11,8 @@ One step = one full frame (640 000 rays): every rank renders its row tile of the
 ranks reassemble it with one RCCL all-gather (strong scaling: the frame is fixed, N divides it).
 Inputs (weights, LUT, camera) are resident in HBM before the timed region.  Rank 0 prints ONE
 JSON line.  The `roofline` object times the dominant kernel (the fused MLP) with HIP events on
-the launch stream; `cpu_baseline` times the numpy oracle on a bounded sample of the same rays.
+the launch stream; `cpu_baseline` times the C restatement of the path (oracle/csrc, OpenMP on the
+host's cores) on a bounded sample of the same rays.
 """
 import argparse
 import json
@@ -103,25 +104,29 @@ def load_checkpoint(kind):
 
 
 def _cpu_worker(job):
-    """One oracle process: renders its batches of seeded pixels with `threads` OpenBLAS threads."""
-    kind, sels, threads = job
+    """The C restatement (oracle/iblnerf_cpu.h: gcc + OpenMP, fp32) in a process of its own: a short calibration batch, then as many seeded
+    pixels as fill about `seconds` of wall time on all of the host's threads."""
+    kind, seconds = job
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import iblnerf_oracle as O
-    from threadpoolctl import threadpool_limits
+    import iblnerf_cpu as OC
+    threads = OC.usable_cpus()
     _pkg.load()
     sdc, sdf = load_checkpoint(kind)
     lut = load_lut()
     K, c2w = camera()
-    ro, rd = O.get_rays(H, W, K, c2w)
+    ro, rd = OC.get_rays(H, W, K, c2w)
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
-    out = []
-    with threadpool_limits(limits=threads):
-        O.render_rays(sdc, sdf, ro[:32], rd[:32], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)   # BLAS warm-up
-        t0 = time.perf_counter()
-        for sel in sels:
-            out.append(O.render_rays(sdc, sdf, ro[sel], rd[sel], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE)["color_map"])
-        dt = time.perf_counter() - t0
-    return dt, np.concatenate(out) if out else np.zeros((0, 3), np.float32)
+    pix = np.random.RandomState(0).permutation(H * W)
+    n0 = 12 * threads                                                     # one task (12 rays) per thread
+    t0 = time.perf_counter()
+    OC.render_rays(sdc, sdf, ro[pix[-n0:]], rd[pix[-n0:]], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE, n_threads=threads)
+    rate = n0 / (time.perf_counter() - t0)
+    n = int(min(H * W // 2, max(n0, rate * seconds)) // (12 * threads) * (12 * threads)) or n0
+    sel = pix[:n]
+    t0 = time.perf_counter()
+    color = OC.render_rays(sdc, sdf, ro[sel], rd[sel], NEAR, FAR, lut, N_SAMPLES, N_IMPORTANCE, n_threads=threads)["color_map"]
+    dt = time.perf_counter() - t0
+    return dt, sel, color, OC.isa(), threads
 
 
 def reference_cpu_record(kind):
@@ -140,33 +145,21 @@ def reference_cpu_record(kind):
             "note": rec["what"] + " (BASELINE.md section 2b); a recorded figure: the reference cannot travel to the GPU box"}
 
 
-def cpu_baseline(gpu_color_fn, kind, batch=256, batches_per_worker=3, threads=16):
-    """Oracle (numpy fp32 restatement, kind = "port") timed on seeded pixels of the same view, on as many of the host's
-    cores as it scales to: independent processes of `threads` OpenBLAS threads each (the oracle's many small sgemms run
-    2.6x SLOWER with one 64-thread pool than with 16 threads: 57 vs 150 rays/s), at most 8 processes.  Workers are
-    spawned (never forked: this process owns a GPU context).  value = all rays / slowest worker's render time."""
+def cpu_baseline(gpu_color_fn, kind, seconds=15.0):
+    """The C restatement of the path (kind = "port": oracle/csrc, pinned to the reference's fixtures by tests/test_oracle_c.py) timed on seeded
+    pixels of the same view on every hardware thread this process may use (oracle/iblnerf_cpu.py usable_cpus: affinity and cgroup quota; OpenMP, one 12-ray task at a time per thread), in
+    a spawned process (never forked: this process owns a GPU context).  value = rays / wall time of the one render call."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
-    threads = max(1, min(threads, ncpu))
-    workers = max(1, min(8, ncpu // threads))
-    pix = np.random.RandomState(0).permutation(H * W)
-    jobs = []
-    for w in range(workers):
-        sels = [pix[(w * batches_per_worker + b) * batch:(w * batches_per_worker + b + 1) * batch] for b in range(batches_per_worker)]
-        jobs.append((kind, sels, threads))
-    with mp.get_context("spawn").Pool(workers) as pool:
-        res = pool.map(_cpu_worker, jobs)
-    t = max(r[0] for r in res)
-    n = workers * batches_per_worker * batch
-    idx = np.concatenate([np.concatenate(j[1]) for j in jobs])
-    ref = np.concatenate([r[1] for r in res]).astype(np.float64)
+    with mp.get_context("spawn").Pool(1) as pool:
+        dt, idx, ref, isa, threads = pool.map(_cpu_worker, [(kind, seconds)])[0]
     got = gpu_color_fn(idx).astype(np.float64)
-    mse = float(np.mean((got - ref) ** 2))
+    mse = float(np.mean((got - ref.astype(np.float64)) ** 2))
     psnr = float(10 * np.log10(1.0 / max(mse, 1e-30)))
-    return {"value": n / t, "unit": "rays/s", "cores": int(workers * threads), "kind": "port",
+    return {"value": len(idx) / dt, "unit": "rays/s", "cores": int(threads), "kind": "port", "host_logical_cpus": os.cpu_count(),
+            "implementation": "C restatement of the reference path (oracle/csrc: gcc, OpenMP, fp32, %s dense layers)" % isa,
             "reference_in_build_container": reference_cpu_record(kind),
-            "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, numpy oracle (OpenBLAS sgemm), %d processes x %d threads"
-                      % (n, workers, threads)}, psnr
+            "sample": "%d seeded pixels of the same 800x800 view, 64+128 samples, full result dict, one call on %d OpenMP threads (%.1f s)"
+                      % (len(idx), threads, dt)}, psnr
 
 
 def main():

@@ -1,0 +1,174 @@
+"""Pins the C restatement (oracle/iblnerf_cpu.h, oracle/csrc/*.c: SURVEY.md section 8 b / d's `iblnerf_render_cpu`) to the reference's own
+outputs — the same fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from /root/reference) and the same tolerances as the
+numpy oracle's tests (tests/test_oracle_golden.py).  CPU only; the library is test infrastructure (nothing under ibl-nerf_amd/ loads it)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import iblnerf_cpu as OC
+import iblnerf_oracle as O
+from conftest import FITTED_FIXTURES, GOLDEN, color_independent, golden_flags, ill_conditioned, load_golden, n_samples, reference_floor, rel_linf
+from test_oracle_golden import DERIVED, DIRECT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFLECTED = ["reflected_radiance_map", "prefiltered_reflected_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2",
+             "reflected_coarse_radiance_map_3", "specular_map", "color_map"]
+# the fixtures whose flags the C path restates (shipped configs + lindisp / linear radiance / F0 / sample counts / epsilon / no gamma /
+# ground-truth normals / colour-independent networks); the other variants (aux networks, *_from_gt, the other normal modes) are the numpy oracle's
+C_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10", "edit2_g10", "variant_small_g10",
+              "gtnormal_g10", "colorindep_g10"]
+
+
+def test_library_exports_and_struct_mirror():
+    import ctypes as C
+    L = OC.lib()
+    for sym in ("iblnerf_render_cpu", "iblnerf_network_query_cpu", "iblnerf_sample_pdf_cpu", "iblnerf_get_rays_cpu", "iblnerf_cpu_last_error",
+                "iblnerf_cpu_isa"):
+        assert hasattr(L, sym), sym
+    assert OC.isa() in ("avx512", "avx2", "base")
+    # every prototype of the header is one of the above (the header is the contract)
+    import re
+    hdr = open(os.path.join(ROOT, "oracle", "iblnerf_cpu.h")).read()
+    assert sorted(set(re.findall(r"\b(iblnerf_\w+)\s*\(", hdr)) - {"iblnerf_upload_weights", "iblnerf_render_rays"}) == sorted(
+        ["iblnerf_render_cpu", "iblnerf_network_query_cpu", "iblnerf_sample_pdf_cpu", "iblnerf_get_rays_cpu", "iblnerf_cpu_last_error", "iblnerf_cpu_isa"])
+    # the product library does not carry a CPU path, and the package never mentions this one
+    for root, _, files in os.walk(os.path.join(ROOT, "ibl-nerf_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                assert "iblnerf_cpu" not in open(os.path.join(root, f), errors="ignore").read(), f
+
+
+def test_get_rays_linspace_and_sample_pdf_bitwise():
+    s = np.load(GOLDEN + "/small_vectors.npz")
+    H, W = s["gr_o"].shape[:2]
+    ro, rd = OC.get_rays(H, W, s["gr_K"], s["gr_c2w"])
+    assert np.array_equal(ro, s["gr_o"]) and np.allclose(rd, s["gr_d"], rtol=0, atol=2e-7)
+    ro2, rd2 = O.get_rays(H, W, s["gr_K"], s["gr_c2w"])
+    assert np.array_equal(rd, rd2)                                        # the two restatements agree bit for bit
+    # the threshold-critical fixture: an empty bin's cdf step sits one ulp from sample_pdf's 1e-5 test
+    g = np.load(GOLDEN + "/sample_pdf_spiky.npz")
+    bins = np.broadcast_to(g["bins"], (len(g["weights"]), 63))
+    assert np.array_equal(OC.sample_pdf(bins, g["weights"], 128), g["samples"])
+    assert np.abs(OC.sample_pdf(s["sp_bins"], s["sp_weights"], s["sp_samples"].shape[1]) - s["sp_samples"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["plain_g10", "plain_g16", "colorindep_g10"])
+def test_network_query_stagewise(name):
+    g, sdc, sdf, _, _ = load_golden(name)
+    ci = color_independent(g)
+    for p, sd in (("c", sdc), ("f", sdf)):
+        raw = OC.network_query(sd, g["q_%s_main_pts" % p], g["q_%s_main_dirs" % p], ci)
+        assert np.abs(raw - g["q_%s_main_raw" % p]).max() <= 2e-6
+        sig = OC.network_query(sd, g["q_%s_eps_pts" % p], None, ci)
+        assert np.abs(sig - g["q_%s_eps_sigma" % p]).max() <= 2e-6
+        refl = OC.network_query(sd, g["q_%s_refl_pts" % p], g["q_%s_refl_dirs" % p], ci)
+        assert np.abs(refl - g["q_%s_refl_raw" % p]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", C_FIXTURES)
+def test_render_rays_end_to_end(name, lut):
+    """tests/test_oracle_golden.py::test_render_rays_end_to_end, on the C restatement: the reference's own render of the fixture."""
+    g, sdc, sdf, gt, edit = load_golden(name)
+    res = OC.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, n_samples(g), int(g["n_importance"]), gt, edit,
+                         golden_flags(g), color_independent=color_independent(g))
+    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    assert all(np.isfinite(v).all() for v in res.values())               # every buffer was written (they start as NaN)
+    wide = ill_conditioned(g)
+    for sfx in ([""] + (["0"] if int(g["n_importance"]) > 0 else [])):
+        fine = sfx == "" and int(g["n_importance"]) > 0
+        tol = (2e-5 if wide else 5e-6) * (4 if fine else 1)
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= (5e-2 if wide else 6e-4), (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+    if int(g["n_importance"]) > 0:
+        assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
+
+
+@pytest.mark.parametrize("name", FITTED_FIXTURES)
+def test_fitted_checkpoint_end_to_end(name, lut):
+    """The checkpoint with surfaces, all rays of every fixture (fitted_wide: 1 024 — the numpy oracle's test stops at 256)."""
+    g, sdc, sdf, gt, edit = load_golden(name)
+    res = OC.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, 64, int(g["n_importance"]), gt, edit)
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            tol = max(1e-4, 2 * reference_floor(k + sfx, name))
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]), tol)
+        for k in DERIVED:
+            tol = 4 * reference_floor(k + sfx, name) if k in REFLECTED else max(6e-4, 2 * reference_floor(k + sfx, name))
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= tol, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]), tol)
+
+
+def test_against_the_numpy_oracle_and_invariances(lut):
+    """Two independent restatements of the same lines agree where the arithmetic is specified (sampling, compositing: to fp32 round-off
+    of different summation orders), and the C path does not depend on the thread count, the ray blocking or the vector width."""
+    g, sdc, sdf, gt, edit = load_golden("fitted_plain")
+    ro, rd = g["rays_o"][:40], g["rays_d"][:40]
+    a = OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, n_threads=1)
+    b = OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, n_threads=5)
+    c = OC.render_rays(sdc, sdf, ro[7:29], rd[7:29], 0.5, 8.0, lut, n_threads=2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k][7:29], c[k]), k
+    ref = O.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut)
+    for k in DIRECT:
+        assert rel_linf(a[k], ref[k]) <= max(1e-4, 2 * reference_floor(k)), k
+    # coarse_outputs = 0: the coarse pass only places the fine samples — same fine maps, bit for bit
+    d = OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, coarse_outputs=False)
+    assert not any(k.endswith("0") for k in d) and all(np.array_equal(d[k], a[k]) for k in d)
+    # the AVX2 build of the dense layer takes the same products in the same order as the AVX-512 one
+    if OC.isa() == "avx512":
+        code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]; import iblnerf_cpu as OC; from conftest import load_golden, load_lut_rgb;"
+                "g, sdc, sdf, _, _ = load_golden('fitted_plain'); assert OC.isa() == 'avx2';"
+                "r = OC.render_rays(sdc, sdf, g['rays_o'][:40], g['rays_d'][:40], 0.5, 8.0, load_lut_rgb(), n_threads=3);"
+                "np.savez(sys.argv[1], **r)") % (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            out = subprocess.run([sys.executable, "-c", code, td + "/r.npz"], env=dict(os.environ, IBLNERF_CPU_ISA="avx2"), capture_output=True, text=True)
+            assert out.returncode == 0, out.stderr[-2000:]
+            r = np.load(td + "/r.npz")
+            assert all(np.array_equal(r[k], a[k]) for k in a)
+
+
+def test_unsupported_requests_fail_loudly(lut):
+    g, sdc, sdf, gt, edit = load_golden("plain_g10")
+    ro, rd = g["rays_o"][:4], g["rays_d"][:4]
+    with pytest.raises(NotImplementedError):
+        OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, flags={"target_normal_map_for_radiance_calculation": "normal_map_from_depth_gradient"})
+    with pytest.raises(NotImplementedError):
+        OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, flags={"calculate_albedo_from_gt": True})
+    with pytest.raises(ValueError):
+        OC.render_rays(sdc, sdf, ro, rd, 0.5, 8.0, lut, flags={"lut_coefficient": "G"})                   # ibl_nerf_renderer.py:437-438
+    with pytest.raises(RuntimeError, match="798994"):
+        OC.network_query(np.zeros(10, np.float32), np.zeros((1, 2, 3), np.float32), None)
+    with pytest.raises(RuntimeError, match="fine network"):
+        OC.render_rays(sdc, None, ro, rd, 0.5, 8.0, lut)
+    import ctypes as C
+    B = OC._binding()
+    o = B.Options()
+    o.n_samples, o.n_importance, o.normal_mode = 64, 0, 4
+    outs = B.Outputs()
+    b = OC._blob(sdc)
+    rc = OC.lib().iblnerf_render_cpu(C.addressof(o), OC._fp(b), None, b.size, OC._fp(lut), OC._fp(OC._f32(ro)), OC._fp(OC._f32(rd)), 4, 0.5, 8.0, None,
+                                     C.addressof(outs), 1)
+    assert rc == -1 and b"normal_mode 4" in OC.lib().iblnerf_cpu_last_error()
+
+
+@pytest.mark.parametrize("name", ["fitted_posed4k", "fitted_edit_cfg4"])
+def test_launch_scale_rule_on_an_independent_fp32_implementation(name, lut):
+    """The per-ray rules the HIP path is held to at launch scale (tests/test_gpu_launch_scale.py: every ray against its OWN sensitivity in the
+    reference, the reflected channels by their distribution) applied to this fp32 CPU restatement on 4 096 rays of the reference's render: the
+    rules are satisfiable by an independent implementation, with room — and the C path sits closer to the reference's float32 run than the
+    reference's own float64 run does (depth: 1.4e-4 against 1.9e-3 on the worst ray from the rotated camera)."""
+    import test_gpu_launch_scale as LS
+    g, sdc, sdf, gt, edit = load_golden(name)
+    res = OC.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, 64, 128, gt, edit)
+    rep = {}
+    LS.check_against_fixture(res, g, rep)
+    for k in ("depth_map", "albedo_map", "roughness_map", "weights"):
+        worst, own = rep[k][0], rep[k][1]
+        assert worst <= 3e-4 and worst <= own, (k, worst, own)
+    assert rep["target_normal_map"][2] <= 2 and rep["target_normal_map0"][2] == 0          # rays above 1e-3 (the reference flags 95 / 113 and 33 / 314 of them)
