@@ -31,7 +31,7 @@ t0 = time.time()
 ref = OC.render_rays(sdc, sdf, ro.cpu().numpy(), rd.cpu().numpy(), 0.5, 8.0, lut)
 t_cpu = time.time() - t0
 n = ro.shape[0]
-print("rays %d   HIP %.2f s (%.0f rays/s)   C restatement %.1f s (%.0f rays/s, %d threads, %s)" % (n, t_gpu, n / t_gpu, t_cpu, n / t_cpu, os.cpu_count(), OC.isa()))
+print("rays %d   HIP %.2f s (%.0f rays/s)   C restatement %.1f s (%.0f rays/s, %d threads, %s)" % (n, t_gpu, n / t_gpu, t_cpu, n / t_cpu, OC.usable_cpus(), OC.isa()))
 out = {}
 for k in ref:
     a, b = got[k].astype(np.float64).reshape(n, -1), ref[k].astype(np.float64).reshape(n, -1)
@@ -42,4 +42,4 @@ for k in ref:
 mse = float(np.mean((got["color_map"].astype(np.float64) - ref["color_map"]) ** 2))
 print("color PSNR %.1f dB" % (10 * np.log10(1 / max(mse, 1e-30))))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(dict(rays=n, t_gpu=t_gpu, t_cpu=t_cpu, threads=os.cpu_count(), maps=out), open(os.path.join(ROOT, "gpurun_out", "full_frame_vs_c.json"), "w"), indent=1)
+json.dump(dict(rays=n, t_gpu=t_gpu, t_cpu=t_cpu, threads=OC.usable_cpus(), maps=out), open(os.path.join(ROOT, "gpurun_out", "full_frame_vs_c.json"), "w"), indent=1)
