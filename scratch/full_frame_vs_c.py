@@ -1,6 +1,7 @@
 """Whole 800x800 frame (BASELINE configs[1], fitted checkpoint, default precision mode) on the HIP path against the C restatement of the
 reference path (oracle/csrc, all host threads): per-ray error distribution of every map over all 640 000 rays.
-    python scratch/full_frame_vs_c.py [n_rows]      (default 800 = the whole frame)"""
+    python scratch/full_frame_vs_c.py [n_rows] [fitted|fitted2] [plain|edit|insert]      (defaults: 800 = the whole frame, fitted, plain)
+edit / insert: BASELINE configs 4 / 5 (the shipped kwargs on tests/frame_overrides.py's analytic images)."""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +11,11 @@ import torch
 import iblnerf_cpu as OC
 from conftest import load_lut_rgb
 
+import frame_overrides as FO
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 800
-f = np.load(os.path.join(ROOT, "tests", "golden", "fitted_ckpt.npz"))
+which = sys.argv[2] if len(sys.argv) > 2 else "fitted"
+config = sys.argv[3] if len(sys.argv) > 3 else "plain"
+f = np.load(os.path.join(ROOT, "tests", "golden", which + "_ckpt.npz"))
 ck = pkg.checkpoint
 sdc, sdf = ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
 lut = load_lut_rgb()
@@ -23,14 +27,22 @@ r.load_weights(0, sdc); r.load_weights(1, sdf); r.load_lut(lut)
 ro, rd = r.get_rays(800, 800, K, c2w)
 r0 = (800 - rows) // 2
 ro, rd = ro.reshape(800, 800, 3)[r0:r0 + rows].reshape(-1, 3), rd.reshape(800, 800, 3)[r0:r0 + rows].reshape(-1, 3)
+pix = np.arange(r0 * 800, (r0 + rows) * 800)
+gt, edit = {}, {}
+if config == "edit":
+    gt, edit = FO.edit_rows(pix), dict(FO.EDIT_CFG4)
+elif config == "insert":
+    gt, edit = FO.insert_rows(pix), dict(FO.INSERT_CFG5)
+gt_d = {k: torch.from_numpy(v).cuda() for k, v in gt.items()}
 torch.cuda.synchronize(); t0 = time.time()
-got = r.render_rays(ro, rd, 0.5, 8.0)
+got = r.render_rays(ro, rd, 0.5, 8.0, gt_d, **edit)
 torch.cuda.synchronize(); t_gpu = time.time() - t0
 got = {k: v.cpu().numpy() for k, v in got.items()}
 t0 = time.time()
-ref = OC.render_rays(sdc, sdf, ro.cpu().numpy(), rd.cpu().numpy(), 0.5, 8.0, lut)
+ref = OC.render_rays(sdc, sdf, ro.cpu().numpy(), rd.cpu().numpy(), 0.5, 8.0, lut, gt=gt, edit=edit)
 t_cpu = time.time() - t0
 n = ro.shape[0]
+print("checkpoint %s, config %s" % (which, config))
 print("rays %d   HIP %.2f s (%.0f rays/s)   C restatement %.1f s (%.0f rays/s, %d threads, %s)" % (n, t_gpu, n / t_gpu, t_cpu, n / t_cpu, OC.usable_cpus(), OC.isa()))
 out = {}
 for k in ref:
@@ -42,4 +54,4 @@ for k in ref:
 mse = float(np.mean((got["color_map"].astype(np.float64) - ref["color_map"]) ** 2))
 print("color PSNR %.1f dB" % (10 * np.log10(1 / max(mse, 1e-30))))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(dict(rays=n, t_gpu=t_gpu, t_cpu=t_cpu, threads=OC.usable_cpus(), maps=out), open(os.path.join(ROOT, "gpurun_out", "full_frame_vs_c.json"), "w"), indent=1)
+json.dump(dict(rays=n, t_gpu=t_gpu, t_cpu=t_cpu, threads=OC.usable_cpus(), maps=out), open(os.path.join(ROOT, "gpurun_out", "full_frame_vs_c_%s_%s.json" % (which, config)), "w"), indent=1)

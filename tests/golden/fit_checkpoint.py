@@ -45,23 +45,48 @@ SPH_C = np.array([[-0.7, -0.2, -3.2], [0.8, -0.45, -2.4]], np.float32)
 SPH_R = np.array([0.8, 0.5], np.float32)
 FLOOR_Y, WALL_Z = -1.0, -6.0
 SIGMA_IN, SIGMA_OUT, BAND = 60.0, -5.0, 0.02
+# the two half-spaces as (unit normal, offset): solid where n.x < c
+PLANE_N = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]], np.float32)
+PLANE_C = np.array([FLOOR_Y, WALL_Z], np.float32)
+SEED = 20261002
+
+
+def set_scene(which):
+    """Scene 1 (default): the checkpoint every `fitted_*` fixture uses.  Scene 2 (round 3, --scene 2 -> fitted2_ckpt.npz): an independent second
+    checkpoint — three spheres (one half hidden behind another: a grazing silhouette inside the frame), a floor TILTED towards the camera, a
+    side wall instead of a back wall far away (most rays end on a slanted surface), other materials and light, a denser interior over a thinner
+    band (sharper density steps) and another seed — so that the per-query precision policy and the launch-scale rules are also measured on a
+    network they were not developed on."""
+    global OBJ_ALBEDO, OBJ_ROUGH, SPH_C, SPH_R, PLANE_N, PLANE_C, SIGMA_IN, SIGMA_OUT, BAND, LIGHT, SEED
+    if which == 1:
+        return
+    assert which == 2
+    OBJ_ALBEDO = np.array([[0.15, 0.55, 0.35], [0.85, 0.75, 0.25], [0.55, 0.25, 0.65], [0.70, 0.68, 0.62], [0.30, 0.32, 0.45]], np.float32)
+    OBJ_ROUGH = np.array([0.10, 0.45, 0.90, 0.65, 0.30], np.float32)
+    SPH_C = np.array([[0.35, 0.10, -2.9], [1.05, 0.35, -3.9], [-1.1, -0.55, -2.2]], np.float32)
+    SPH_R = np.array([0.7, 0.6, 0.35], np.float32)
+    n_floor = np.array([0.0, 1.0, 0.22], np.float32) / np.float32(np.linalg.norm([0.0, 1.0, 0.22]))
+    n_wall = np.array([0.55, 0.0, 1.0], np.float32) / np.float32(np.linalg.norm([0.55, 0.0, 1.0]))
+    PLANE_N = np.stack([n_floor, n_wall]).astype(np.float32)
+    PLANE_C = np.array([-1.55, -4.4], np.float32)
+    SIGMA_IN, SIGMA_OUT, BAND = 80.0, -6.0, 0.015
+    LIGHT = (np.array([-0.5, 0.7, 0.5], np.float32) / np.linalg.norm([-0.5, 0.7, 0.5])).astype(np.float32)
+    SEED = 20261003
 
 
 def scene(torch, x):
-    """Signed distance, object id and outward normal of the analytic scene at points x [...,3] (torch)."""
-    c = torch.from_numpy(SPH_C)
-    r = torch.from_numpy(SPH_R)
-    d0 = (x - c[0]).norm(dim=-1) - r[0]
-    d1 = (x - c[1]).norm(dim=-1) - r[1]
-    d2 = x[..., 1] - FLOOR_Y          # solid below the floor
-    d3 = x[..., 2] - WALL_Z           # solid behind the wall
-    sd = torch.stack([d0, d1, d2, d3], -1)
-    sdf, obj = sd.min(-1)
-    n0 = torch.nn.functional.normalize(x - c[0], dim=-1)
-    n1 = torch.nn.functional.normalize(x - c[1], dim=-1)
-    n2 = torch.tensor([0.0, 1.0, 0.0]).expand_as(x)
-    n3 = torch.tensor([0.0, 0.0, 1.0]).expand_as(x)
-    nrm = torch.stack([n0, n1, n2, n3], -2)
+    """Signed distance, object id and outward normal of the analytic scene at points x [...,3] (torch): spheres, then half-spaces."""
+    sds, nrms = [], []
+    for c, r in zip(SPH_C, SPH_R):
+        c = torch.from_numpy(c)
+        sds.append((x - c).norm(dim=-1) - float(r))
+        nrms.append(torch.nn.functional.normalize(x - c, dim=-1))
+    for n, c in zip(PLANE_N, PLANE_C):
+        n = torch.from_numpy(n)
+        sds.append((x * n).sum(-1) - float(c))
+        nrms.append(n.expand_as(x))
+    sdf, obj = torch.stack(sds, -1).min(-1)
+    nrm = torch.stack(nrms, -2)
     n = torch.gather(nrm, -2, obj[..., None, None].expand(*obj.shape, 1, 3))[..., 0, :]
     return sdf, obj, n
 
@@ -98,10 +123,11 @@ def ray_hits(torch, o, d):
         disc = b * b - 4 * a * cc
         t = (-b - disc.clamp(min=0).sqrt()) / (2 * a)
         ts.append(torch.where((disc > 0) & (t > 0), t, torch.full_like(t, 1e9)))
-    tf = (FLOOR_Y - o[..., 1]) / d[..., 1]
-    ts.append(torch.where((d[..., 1] < 0) & (tf > 0), tf, torch.full_like(tf, 1e9)))
-    tw = (WALL_Z - o[..., 2]) / d[..., 2]
-    ts.append(torch.where((d[..., 2] < 0) & (tw > 0), tw, torch.full_like(tw, 1e9)))
+    for n, c in zip(PLANE_N, PLANE_C):
+        n = torch.from_numpy(n)
+        nd = (d * n).sum(-1)
+        tp = (float(c) - (o * n).sum(-1)) / nd
+        ts.append(torch.where((nd < 0) & (tp > 0), tp, torch.full_like(tp, 1e9)))
     t, obj = torch.stack(ts, -1).min(-1)
     return t, obj
 
@@ -146,12 +172,15 @@ def main():
     ap.add_argument("--batch1", type=int, default=8192)
     ap.add_argument("--steps2", type=int, default=60)
     ap.add_argument("--batch2", type=int, default=192)
-    ap.add_argument("--out", default=os.path.join(HERE, "fitted_ckpt.npz"))
+    ap.add_argument("--scene", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    set_scene(a.scene)
+    a.out = a.out or os.path.join(HERE, "fitted_ckpt.npz" if a.scene == 1 else "fitted2_ckpt.npz")
     torch, R, M, Hh = MG.import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    rng = np.random.RandomState(20261002)
+    rng = np.random.RandomState(SEED)
     tmp = tempfile.mkdtemp()
     try:
         kw_train, kw_test, *_ = M.create_IBLNeRF(MG.reference_args(tmp, 128))
@@ -215,7 +244,7 @@ def main():
     np.savez_compressed(a.out, coarse=blobs[0], fine=blobs[1],
                         ck_coarse=np.array(ck.blob_checksum(blobs[0])), ck_fine=np.array(ck.blob_checksum(blobs[1])),
                         near=np.float32(NEAR), far=np.float32(FAR), hist1=np.array(hist1), hist2=np.array(hist2),
-                        sph_c=SPH_C, sph_r=SPH_R, floor_y=np.float32(FLOOR_Y), wall_z=np.float32(WALL_Z))
+                        sph_c=SPH_C, sph_r=SPH_R, plane_n=PLANE_N, plane_c=PLANE_C, scene=np.int32(a.scene))
     print("wrote", a.out, "%.2f MB" % (os.path.getsize(a.out) / 1e6))
 
 

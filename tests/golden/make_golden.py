@@ -282,9 +282,10 @@ def network_backward_fixture(torch, M):
     print("%-28s every parameter gradient of the network by the reference's autograd  %.2f MB" % ("network_backward", os.path.getsize(path) / 1e6))
 
 
-def fitted_state_dicts():
-    """The checkpoint fit_checkpoint.py produced with the reference's modules (tests/golden/fitted_ckpt.npz)."""
-    f = np.load(os.path.join(OUT, "fitted_ckpt.npz"))
+def fitted_state_dicts(which="fitted"):
+    """The checkpoints fit_checkpoint.py produced with the reference's modules: "fitted" (tests/golden/fitted_ckpt.npz, scene 1: every fitted_*
+    fixture) | "fitted2" (fitted2_ckpt.npz, scene 2: an independent second checkpoint, fixtures fitted2_*)."""
+    f = np.load(os.path.join(OUT, which + "_ckpt.npz"))
     return ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
 
 
@@ -558,8 +559,8 @@ COMPACT_KEYS = ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "r
                 "specular_map", "diffuse_map", "color_map", "depth_map0", "target_normal_map0")
 
 
-def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False, compact=False, augment=False):
-    """The fitted checkpoint at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
+def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", chunk=2048, weights_every=8, n_nudge=3, posed=False, compact=False, augment=False, ckpt="fitted"):
+    """The fitted checkpoint (ckpt: "fitted" | "fitted2") at launch scale: `n_rays` seeded pixels of the 800x800 bench view through the
     reference's render_decomp in float32 and, as the yardstick, in float64 (torch's default tensor type switched for that run, so that
     every tensor the reference creates itself — torch.ones, torch.Tensor(list) of the edit / insert lists — is float64 too and its
     masked assignments run).  Kept: every map of both passes; `weights` / `weights0` for every `weights_every`-th ray;
@@ -588,7 +589,7 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
         _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 128))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    sd_c, sd_f = fitted_state_dicts()
+    sd_c, sd_f = fitted_state_dicts(ckpt)
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     kw.update(near=0.5, far=8.0)
@@ -722,7 +723,7 @@ def launch_scale_fixture(name, torch, R, M, lut, *, n_rays, seed, mode="plain", 
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(0.5), far=np.float32(8.0), gain=np.float64(1.0),
                seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1), n_importance=np.int64(128), n_samples=np.int64(64),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
-               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))), mode=np.array(mode), ckpt=np.array("fitted"),
+               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))), mode=np.array(mode), ckpt=np.array(ckpt),
                weights_every=np.int64(weights_every), chunk=np.int64(chunk), n_nudge=np.int64(n_nudge), c2w=c2w)
     for k, v in gt.items():
         out["gt__" + k] = v
@@ -932,6 +933,8 @@ def main(only=None):
                     ("fitted_edit_cfg4", dict(n_rays=4096, seed=31, mode="edit_cfg4", weights_every=4, n_nudge=4)),
                     ("fitted_insert_cfg5", dict(n_rays=4096, seed=32, mode="insert_cfg5", weights_every=4, n_nudge=4)),
                     ("fitted_posed4k", dict(n_rays=4096, seed=34, weights_every=4, n_nudge=4, posed=True)),
+                    ("fitted2_launch4k", dict(n_rays=4096, seed=36, weights_every=4, n_nudge=4, ckpt="fitted2")),   # the second, independent checkpoint (fit_checkpoint.py --scene 2)
+                    ("fitted2_posed4k", dict(n_rays=4096, seed=37, weights_every=4, n_nudge=4, posed=True, ckpt="fitted2")),
                     ("fitted_launch64k", dict(n_rays=65536, seed=35, n_nudge=2, compact=True)),        # one whole launch of bench.py's frame: ~40 minutes of reference CPU time
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:
