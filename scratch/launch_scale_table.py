@@ -12,7 +12,7 @@ KEYS = ["depth_map", "albedo_map", "roughness_map", "irradiance_map", "radiance_
         "prefiltered_reflected_map", "specular_map", "color_map", "color_map0"]
 q = lambda a: "%.1e %.1e %.1e %.1e" % (np.nanmedian(a), np.nanpercentile(a, 99), np.nanpercentile(a, 99.9), np.nanmax(a))
 print("per-ray error = max over a map's channels of |x - reference float32| / max|reference|;  columns: median  99%  99.9%  worst;  n>1e-3 = rays above 1e-3")
-for name in ("fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitted_posed4k"):
+for name in (sys.argv[1:] or ("fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitted_posed4k")):
     g, sdc, sdf, gt, edit = load_golden(name)
     we = int(g["weights_every"])
     print("\n== %s (%d rays)" % (name, len(g["rays_o"])))
@@ -29,9 +29,11 @@ for name in ("fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitt
     for k in KEYS:
         f = g["floorray__" + k].astype(np.float64)
         nd = g["nudgeray__" + k].astype(np.float64) if "nudgeray__" + k in g.files else None
+        if nd is not None and "branchray__" + k in g.files:
+            nd = np.maximum(nd, g["branchray__" + k].astype(np.float64))
         if k.startswith("weights"):
             f = f[::we]; nd = None if nd is None else nd[::we]
         print("%s" % k)
-        print("   reference f64-f32 %s  n>1e-3 %d" % (q(f), int((f > 1e-3).sum())) + ("" if nd is None else "   | one-ulp nudge %s" % q(nd)))
+        print("   reference f64-f32 %s  n>1e-3 %d" % (q(f), int((f > 1e-3).sum())) + ("" if nd is None else "   | one-ulp nudge / threshold branch %s" % q(nd)))
         for row in rows[k]:
             print("   " + row)
