@@ -133,6 +133,7 @@ class Renderer:
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
+        self._twin_ref = None        # (mode, Renderer) of precision_report
         self._blobs, self._lut = {}, None
         self.has_fine = False            # a network_fine is loaded (run_fn = network_fn otherwise, ibl_nerf_renderer.py:705)
         self.range_fallbacks = 0
@@ -328,6 +329,39 @@ class Renderer:
         if not self._force_wide:
             self._settle(self.range_bits())
         return self._force_wide
+
+    def precision_report(self, rays_o, rays_d, near, far, reference="f16x3", gt_values=None, **edit):
+        """A self-check of this context's product-scheme policy on the checkpoint it holds: the rays are rendered here and on a twin context in
+        `reference` mode (default: three f16 products, 2^-22 per operand, in EVERY query), and per map the per-ray deviation (max over the
+        map's channels over the map's largest value — the parity metric of the tests) is summarised as {p50, p99, p999, max, above_1e-3
+        (share of rays)}.  No reference counterpart: the reference computes in fp32 throughout.  Why it exists: the default policy was
+        measured on one fitted checkpoint; on a second one with sharper density steps the per-sample `weights` of the fine pass moved from
+        3.5e-4 to 1.6e-3 at the 99.9th percentile (DESIGN.md section 2 "Launch scale" 6).  If `weights` (or the bulk of a direct map)
+        matters to the caller and the report shows it, construct the renderer with query_routing=("fine_main_precise",) — or with
+        mlp_precision=`reference` itself."""
+        torch = _torch()
+        if self._twin_ref is None or self._twin_ref[0] != reference:
+            t = Renderer(mlp_precision=reference, **self._ctor)
+            for which, blob in self._blobs.items():
+                t.load_weights(which, blob)
+            for name, sd in self._aux.items():
+                if sd is not None:
+                    t.load_aux(name, sd)
+            if self._depth_mlp is not None:
+                t.load_depth_mlp(self._depth_mlp)
+            if self._lut is not None:
+                t.load_lut(self._lut)
+            self._twin_ref = (reference, t)
+        with torch.no_grad():
+            a = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+            b = self._twin_ref[1].render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+        rep = {}
+        for k in a:
+            x, y = a[k].double().reshape(a[k].shape[0], -1), b[k].double().reshape(a[k].shape[0], -1)
+            e = ((x - y).abs().nan_to_num(0.0).amax(-1) / y.abs().nan_to_num(0.0).amax().clamp_min(1e-30)).cpu()
+            q = torch.quantile(e, torch.tensor([0.5, 0.99, 0.999], dtype=e.dtype))
+            rep[k] = {"p50": float(q[0]), "p99": float(q[1]), "p999": float(q[2]), "max": float(e.max()), "above_1e-3": float((e > 1e-3).double().mean())}
+        return rep
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""

@@ -174,6 +174,22 @@ def test_second_checkpoint_with_the_fine_main_query_on_the_precise_kernel(R, lut
     assert np.percentile(e, 99.9) <= 4e-4 and e.max() <= 5e-4, (np.percentile(e, 99.9), e.max())
 
 
+def test_precision_report_shows_what_the_second_checkpoint_costs(R, lut):
+    """Renderer.precision_report: the context's own policy against an all-precise twin on the same rays — the self-check a caller runs on a new
+    checkpoint.  On the second checkpoint it shows the fine pass's per-sample weights (and nothing else) near 1e-3, and the routing bit removes it."""
+    from ibl_nerf_amd import binding as B
+    g, sdc, sdf, gt, edit = load_golden("fitted2_launch4k")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384)
+    rep = r.precision_report(g["rays_o"], g["rays_d"], 0.5, 8.0)
+    assert sorted(rep) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    assert 5e-4 < rep["weights"]["p999"] < 4e-3 and rep["weights0"]["max"] == 0.0, (rep["weights"], rep["weights0"])     # (the coarse pass IS all-precise)
+    for k in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "radiance_map"):
+        assert rep[k]["p999"] < 4e-4 and rep[k]["above_1e-3"] <= 1e-3, (k, rep[k])
+    r2 = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384, query_routing=("fine_main_precise",))
+    rep2 = r2.precision_report(g["rays_o"], g["rays_d"], 0.5, 8.0)
+    assert rep2["weights"]["p999"] < 0.25 * rep["weights"]["p999"] and rep2["albedo_map"]["p99"] < 0.25 * rep["albedo_map"]["p99"], (rep2["weights"], rep2["albedo_map"])
+
+
 def _frame_rays(r):
     H = W = 800
     f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
