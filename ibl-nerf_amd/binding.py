@@ -23,6 +23,7 @@ EXPORTS = [
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
+    "iblnerf_ray_outputs_backward",
 ]
 
 
@@ -157,6 +158,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_composite_direct_backward.restype = C.c_int
     lib.iblnerf_composite_direct_backward_full.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP, FP, FP]
     lib.iblnerf_composite_direct_backward_full.restype = C.c_int
+    lib.iblnerf_ray_outputs_backward.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_float, C.POINTER(Maps), C.c_int64, FP]
+    lib.iblnerf_ray_outputs_backward.restype = C.c_int
     lib.iblnerf_coarse_z.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, FP, C.c_int64, FP]
     lib.iblnerf_coarse_z.restype = C.c_int
     lib.iblnerf_sample_points.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_int64, C.c_int, FP]

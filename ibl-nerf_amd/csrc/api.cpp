@@ -789,6 +789,29 @@ int iblnerf_composite_direct_backward_full(iblnerf_ctx* c, void* stream, const f
     return IBLNERF_OK;
 }
 
+int iblnerf_ray_outputs_backward(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
+                                 const iblnerf_maps* up, int64_t n_rays, float* d_dmaps) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || !up || (n_rays > 0 && (!d_maps || !d_dmaps)) || ((d_n_dot_v == nullptr) != (d_env == nullptr)))
+        return c->fail(IBLNERF_ERR_INVALID, "ray_outputs_backward: bad arguments (n_dot_v and env: both or neither)");
+    if (d_n_dot_v && !c->have_lut) return c->fail(IBLNERF_ERR_STATE, "ray_outputs_backward: no LUT uploaded");
+    if (d_n_dot_v && !(depth0 > 0.f)) return c->fail(IBLNERF_ERR_INVALID, "ray_outputs_backward: depth0 = (near + far) / 2 must be positive");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    RayBwdArgs a{};
+    a.x = d_maps; a.ndv = d_n_dot_v; a.env = d_env; a.lut = c->d_lut; a.depth0 = depth0;
+    a.out_mode = (c->opt.gamma_correct ? 1 : 0) | (c->opt.use_radiance_linear ? 2 : 0);
+    a.lut_f0 = c->opt.lut_coefficient_f0; a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
+    a.g_color = up->color_map; a.g_radiance = up->radiance_map;
+    for (int k = 0; k < 3; ++k) a.g_radiance_k[k] = up->radiance_map_k[k];
+    a.g_irradiance = up->irradiance_map; a.g_albedo = up->albedo_map; a.g_roughness = up->roughness_map; a.g_specular = up->specular_map;
+    a.g_diffuse = up->diffuse_map; a.g_prefiltered = up->prefiltered_reflected_map; a.g_disp = up->disp_map; a.g_acc = up->acc_map;
+    a.g_depth = up->depth_map; a.g_target_depth = up->target_depth_map;
+    a.dx = d_dmaps;
+    HIP_TRY(c, launch_ray_outputs_backward(a, (long)n_rays, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
 int iblnerf_coarse_z(iblnerf_ctx* c, void* stream, float near_, float far_, const float* d_t_rand, int64_t n_rays, float* d_z) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (n_rays < 0 || (n_rays > 0 && !d_z)) return c->fail(IBLNERF_ERR_INVALID, "coarse_z: bad arguments");

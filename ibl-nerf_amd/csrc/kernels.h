@@ -118,6 +118,20 @@ hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const
 // the 19 direct maps of one pass from its raw rows, and their backward (render_kernels.hip: k_composite_fwd / k_composite_bwd)
 hipError_t launch_composite_direct(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear, float* maps,
                                    float* weights, hipStream_t s);
+// training: the ray-sized shading of a pass, differentiated (k_ray_outputs_bwd).  Upstream gradients per output map, null = none.
+struct RayBwdArgs {
+    const float* x;          // [n, 19] linear direct maps (the slots of launch_composite_direct)
+    const float* ndv;        // [n] n.v of the pass, or null = approximate_radiance=False (only the direct maps' output functions)
+    const float* env;        // [n, 4, 3] linear reflected-ray maps (radiance, coarse radiances 1..3)
+    const float* lut;        // [3, 512, 512]
+    float depth0;            // (near + far) / 2
+    int out_mode;            // bit 0 gamma_correct, bit 1 use_radiance_linear (out_map)
+    int lut_f0, correct_depth;
+    const float *g_color, *g_radiance, *g_radiance_k[3], *g_irradiance, *g_albedo, *g_roughness, *g_specular, *g_diffuse, *g_prefiltered,
+        *g_disp, *g_acc, *g_depth, *g_target_depth;
+    float* dx;               // [n, 19]
+};
+hipError_t launch_ray_outputs_backward(const RayBwdArgs& a, long n, hipStream_t s);
 hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,
                                             const float* dmaps, const float* dweights, float* draw, hipStream_t s, int detach = 1);
 hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_stride, const float* sigma, const float* noise, long R, int S,

@@ -1055,6 +1055,138 @@ hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s) {
     return by_npl(a.Sc, [&](auto N) { hipLaunchKernelGGL(k_pass_b<decltype(N)::value>, grid, dim3(256), 0, s, a); });
 }
 
+
+// ---- the ray-sized part of raw2outputs, differentiated (training: ibl_nerf_renderer.py:258, :412-474, :477-527) -----------------------------
+// One thread per ray: from the pass's linear direct maps x [19] (the slots of k_composite_fwd) and the pass's no-grad quantities (n.v, the four linear
+// reflected-ray maps, the LUT) it re-evaluates the shading and applies the chain rule by hand — what torch autograd does in ~160 ray-sized launches
+// (training.py _ray_outputs, which stays as the test's reference).  Ties of the two maximum() calls split the gradient in halves like ATen's.
+__device__ __forceinline__ float d_srgb(float y, int on) { return on ? (float)(1.0 / 2.2) * powf(y + 1e-12f, (float)(1.0 / 2.2) - 1.0f) : 1.0f; }
+// d out_f(v) / dv, out_f = gamma(tonemap(v)) (:30-31, :26-27, :487)
+__device__ __forceinline__ float d_out_map(float v, int on) {
+    if (on & 2) {
+        const float t = v + 1.0f;
+        return d_srgb(v / t, on & 1) / (t * t);
+    }
+    return d_srgb(v, on & 1);
+}
+
+__global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* x = a.x + 19 * r;
+    float dx[19];
+#pragma unroll
+    for (int i = 0; i < 19; ++i) dx[i] = 0.0f;
+    const int on = a.out_mode;
+    const float depth = x[0], acc = x[1], rough = x[5], irr = x[6];
+    auto up3 = [&](const float* g, int c) { return g ? g[3 * r + c] : 0.0f; };
+    auto up1 = [&](const float* g) { return g ? g[r] : 0.0f; };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dx[7 + c] += up3(a.g_radiance, c) * d_out_map(x[7 + c], on);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dx[10 + 3 * k + c] += up3(a.g_radiance_k[k], c) * d_out_map(x[10 + 3 * k + c], on);
+        dx[2 + c] += up3(a.g_albedo, c) * d_srgb(x[2 + c], on & 1);
+    }
+    dx[6] += up1(a.g_irradiance) * d_out_map(irr, on);
+    dx[5] += up1(a.g_roughness);
+    if (a.g_disp) {                                          // 1 / max(1e-10, depth / acc) (:258)
+        const float q = depth / acc;
+        const float share = q > 1e-10f ? 1.0f : (q == 1e-10f ? 0.5f : 0.0f);
+        const float dq = -a.g_disp[r] / (fmaxf(q, 1e-10f) * fmaxf(q, 1e-10f)) * share;
+        dx[0] += dq / acc;
+        dx[1] += -dq * depth / (acc * acc);
+    }
+    dx[1] += up1(a.g_acc);
+    dx[0] += up1(a.g_depth) + up1(a.g_target_depth);
+    if (a.ndv != nullptr) {
+        const float ndv = a.ndv[r];
+        // LUT fetch and its derivative along the roughness axis (F.grid_sample, bilinear, zeros padding, align_corners=True; :418-421)
+        constexpr int N = 512;
+        const float gx = 2.0f * ndv - 1.0f, gy = 2.0f * rough - 1.0f;
+        const float lx = ((gx + 1.0f) / 2.0f) * (float)(N - 1), ly = ((gy + 1.0f) / 2.0f) * (float)(N - 1);
+        const float x0 = floorf(lx), y0 = floorf(ly);
+        float e0 = 0.f, e1 = 0.f, de0 = 0.f, de1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ddx = k & 1, ddy = k >> 1;
+            const float xi = x0 + (float)ddx, yi = y0 + (float)ddy;
+            const float wx = ddx ? (lx - x0) : (x0 + 1.0f - lx), wy = ddy ? (ly - y0) : (y0 + 1.0f - ly);
+            if (xi >= 0.0f && xi <= (float)(N - 1) && yi >= 0.0f && yi <= (float)(N - 1)) {
+                const int o = (int)yi * N + (int)xi;
+                const float v0 = a.lut[o], v1 = a.lut[N * N + o];
+                e0 += v0 * (wx * wy);
+                e1 += v1 * (wx * wy);
+                de0 += v0 * wx * (ddy ? 1.0f : -1.0f);
+                de1 += v1 * wx * (ddy ? 1.0f : -1.0f);
+            }
+        }
+        de0 *= (float)(N - 1);                               // d ly / d rough = (N - 1) / 2 * 2
+        de1 *= (float)(N - 1);
+        const float m = 1.0f - rough;                        // metallic (:424)
+        const float one_m = 1.0f - m;
+        const float p5 = powf(fminf(fmaxf(1.0f - ndv, 0.0f), 1.0f), 5.0f);
+        // mip level (:453-467); the depth inside it carries no gradient (depth_map.detach())
+        float level = rough, dlevel = 1.0f;
+        if (a.correct_depth) {
+            const float v = rough * depth / a.depth0;
+            level = fminf(fmaxf(v, 0.0f), 1.0f);
+            dlevel = (v >= 0.0f && v <= 1.0f) ? depth / a.depth0 : 0.0f;
+        }
+        int i1 = (int)(level * 3.0f);
+        i1 = i1 < 0 ? 0 : (i1 > 3 ? 3 : i1);
+        const int i2 = i1 + 1 > 3 ? 3 : i1 + 1;
+        const float rem = level * 3.0f - (float)i1;
+        const float* env = a.env + 12 * r;
+        float g_rough = 0.f, g_e0 = 0.f, g_e1 = 0.f, g_rem = 0.f, g_irr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float alb = x[2 + c];
+            const float F0 = 0.04f * one_m + alb * m;                                             // :425-427
+            const float av = 1.0f - rough;
+            const float F1 = fmaxf(av, F0) - F0;                                                  // microfacet.py:8-12
+            const float fres = F0 + F1 * p5;
+            const float cb = a.lut_f0 ? F0 : fres;
+            const float coef = cb * e0 + e1;                                                      // :433-436
+            const float pref = (1.0f - rem) * env[3 * i1 + c] + rem * env[3 * i2 + c];            // :468-470
+            const float diffuse = (1.0f - fres) * one_m * alb * irr;                              // :472
+            const float spec = coef * pref;
+            const float G_col = up3(a.g_color, c) * d_out_map(diffuse + spec, on);
+            const float G_spec = up3(a.g_specular, c) * d_out_map(spec, on) + G_col;
+            const float G_diff = up3(a.g_diffuse, c) * d_out_map(diffuse, on) + G_col;
+            const float G_pref = up3(a.g_prefiltered, c) * d_out_map(pref, on) + G_spec * coef;
+            const float G_coef = G_spec * pref;
+            float G_fres = -G_diff * one_m * alb * irr;
+            g_rough += G_diff * (1.0f - fres) * alb * irr;                                        // through (1 - metallic) = 1 - (1 - rough)
+            dx[2 + c] += G_diff * (1.0f - fres) * one_m * irr;
+            g_irr += G_diff * (1.0f - fres) * one_m * alb;
+            g_e0 += G_coef * cb;
+            g_e1 += G_coef;
+            float G_F0 = 0.0f;
+            if (a.lut_f0) G_F0 = G_coef * e0; else G_fres += G_coef * e0;
+            G_F0 += G_fres;
+            const float G_F1 = G_fres * p5;
+            if (av > F0) { g_rough -= G_F1; G_F0 -= G_F1; }                                       // F1 = (1 - rough) - F0
+            else if (av == F0) { g_rough -= 0.5f * G_F1; G_F0 -= 0.5f * G_F1; }                   // (else F1 = F0 - F0: no gradient)
+            dx[2 + c] += G_F0 * m;
+            g_rough += G_F0 * (0.04f - alb);                                                      // d F0 / d rough through metallic = 1 - rough
+            g_rem += G_pref * (env[3 * i2 + c] - env[3 * i1 + c]);
+        }
+        g_rough += 3.0f * g_rem * dlevel + g_e0 * de0 + g_e1 * de1;
+        dx[5] += g_rough;
+        dx[6] += g_irr;
+    }
+    float* o = a.dx + 19 * r;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) o[i] = dx[i];
+}
+
+hipError_t launch_ray_outputs_backward(const RayBwdArgs& a, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ray_outputs_bwd, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, long R, int nb,
                              int n_out, const float* u, float* samples, hipStream_t s) {
     if (R <= 0) return hipSuccess;

@@ -515,6 +515,43 @@ class Renderer:
                                                                      None if dw is None else dw.data_ptr(), draw.data_ptr()))
         return draw
 
+    # output map -> (iblnerf_maps field, index in a [3] pointer array or None, channels): the maps whose upstream gradient iblnerf_ray_outputs_backward reads
+    _UPSTREAM = {"color_map": ("color_map", None, 3), "radiance_map": ("radiance_map", None, 3), "radiance_map_1": ("radiance_map_k", 0, 3),
+                 "radiance_map_2": ("radiance_map_k", 1, 3), "radiance_map_3": ("radiance_map_k", 2, 3), "irradiance_map": ("irradiance_map", None, 1),
+                 "albedo_map": ("albedo_map", None, 3), "roughness_map": ("roughness_map", None, 1), "specular_map": ("specular_map", None, 3),
+                 "diffuse_map": ("diffuse_map", None, 3), "prefiltered_reflected_map": ("prefiltered_reflected_map", None, 3), "disp_map": ("disp_map", None, 1),
+                 "acc_map": ("acc_map", None, 1), "depth_map": ("depth_map", None, 1), "target_depth_map": ("target_depth_map", None, 1)}
+
+    def ray_outputs_backward(self, maps, upstream, n_dot_v=None, env=None, depth0=1.0):
+        """dL/d(output maps) -> dL/d(linear direct maps [n, 19]) through the ray-sized part of raw2outputs (iblnerf_ray_outputs_backward): `maps` = the
+        pass's linear maps (composite_direct), `upstream` = {map name: gradient or None}; n_dot_v [n] / env [n, 4, 3] = the pass's no-grad
+        quantities (None, None for approximate_radiance=False)."""
+        torch = _torch()
+        x = _dev_f32(maps, self.device).reshape(-1, 19)
+        n = x.shape[0]
+        up, keep = B.Maps(), [x]
+        for name, g in upstream.items():
+            if g is None:
+                continue
+            if name not in self._UPSTREAM:
+                raise KeyError("ray_outputs_backward: %r carries no gradient in the reference (or is not an output of raw2outputs)" % name)
+            field, idx, ch = self._UPSTREAM[name]
+            t = _dev_f32(g, self.device).reshape(n, ch) if ch > 1 else _dev_f32(g, self.device).reshape(n)
+            keep.append(t)
+            if idx is None:
+                setattr(up, field, t.data_ptr())
+            else:
+                getattr(up, field)[idx] = t.data_ptr()
+        ndv = ev = None
+        if n_dot_v is not None:
+            ndv, ev = _dev_f32(n_dot_v, self.device).reshape(n), _dev_f32(env, self.device).reshape(n, 12)
+            keep += [ndv, ev]
+        dx = torch.empty((n, 19), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
+                                                                None if ev is None else ev.data_ptr(), float(depth0), C.byref(up), n, dx.data_ptr()))
+        self._keep_up = keep      # the inputs must outlive the asynchronous launch (same stream as torch's allocator, but some are temporaries of this call)
+        return dx
+
     def _run_backward(self, up, launch, out, grad, grad_scale, who):
         """Loss-scale policy around one fused backward.  `launch(up_rows, scale)` issues the kernels.  Eager contexts (and an explicit scale): start
         where the largest upstream gradient sits at 2^10, step down by 2^6 while the kernels report an overflow (one synchronisation per try).

@@ -34,6 +34,11 @@ ALL_PARAMS = tuple(n + s for n, _, _ in ck.SCHEMA for s in (".weight", ".bias"))
 # parameters that still receive gradients under forward_freezed (ibl_nerf.py:113-131)
 UNFROZEN = ("albedo_feature_linear.", "albedo_linear.", "irradiance_feature_linear.", "irradiance_linear.", "roughness_linear.")
 MAP3 = ("albedo_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3")
+# the ray-sized shading's backward: one fused launch (iblnerf_ray_outputs_backward) | torch autograd through _ray_outputs (False: the tests' reference)
+FUSED_SHADING_BACKWARD = True
+# output maps that carry a gradient into the linear direct maps (the others are computed under no_grad / detached in the reference)
+SHADED_KEYS = ("color_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3", "irradiance_map", "albedo_map", "roughness_map",
+               "specular_map", "diffuse_map", "prefiltered_reflected_map", "disp_map", "acc_map", "depth_map", "target_depth_map")
 
 
 def _torch():
@@ -277,15 +282,21 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             grads_all = []
             for which, sfx, z, raw in ((0, "0", sv["zc"], sv["rawc"]), (1, "", sv["zf"], sv["rawf"])):
                 lin, _ = r.composite_direct(raw, z, sv["rd"], want_weights=False)
-                with torch.enable_grad():
-                    x = lin.detach().requires_grad_(True)
-                    outs = _ray_outputs(x, sv.get("consts" + sfx), flags)
-                    pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None]
-                    if pairs:
-                        (dx,) = torch.autograd.grad([o for o, _ in pairs], x, [g.reshape(o.shape).to(o.dtype) for o, g in pairs], allow_unused=True)
-                        dx = torch.zeros_like(lin) if dx is None else dx
-                    else:
-                        dx = torch.zeros_like(lin)
+                consts = sv.get("consts" + sfx)
+                if FUSED_SHADING_BACKWARD:                           # one launch (iblnerf_ray_outputs_backward) instead of ~160 ray-sized ones
+                    ups = {k: gout.get(k + sfx) for k in SHADED_KEYS if (consts is not None or k in BASE_KEYS)}
+                    dx = r.ray_outputs_backward(lin, ups, None if consts is None else consts["n_dot_v"], None if consts is None else consts["env"],
+                                                depth0)
+                else:                                                # the same by torch autograd (the tests' reference for the kernel above)
+                    with torch.enable_grad():
+                        x = lin.detach().requires_grad_(True)
+                        outs = _ray_outputs(x, consts, flags)
+                        pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None]
+                        if pairs:
+                            (dx,) = torch.autograd.grad([o for o, _ in pairs], x, [g.reshape(o.shape).to(o.dtype) for o, g in pairs], allow_unused=True)
+                            dx = torch.zeros_like(lin) if dx is None else dx
+                        else:
+                            dx = torch.zeros_like(lin)
                 gw = gout.get("weights" + sfx)
                 draw = r.composite_direct_backward(raw, z, sv["rd"], dx.contiguous(), None if gw is None else gw.contiguous())
                 if frozen[which]:                                     # forward_freezed: sigma, radiance and the coarse radiances are computed under no_grad
@@ -301,7 +312,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     grads_all.append(gk)
             out = []
             for i, (p, gk) in enumerate(zip(params, grads_all)):
-                out.append(gk.reshape(p.shape).to(p.device, copy=True) if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
+                # (views of the call's own gradient blob, a fresh tensor per network_backward: no copy — 92 launches less per step)
+                out.append(gk.reshape(p.shape).to(p.device) if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
             return (None, None) + tuple(out)
 
     outs = _Fn.apply(ro, rd, *params)

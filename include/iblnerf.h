@@ -349,6 +349,21 @@ typedef struct {
     float* inferred_depth_map; /* [n]; written while a PositionDirectionMLP is uploaded (infer_depth, ibl_nerf_renderer.py:722-726); may be NULL */
 } iblnerf_outputs;
 
+/* The ray-sized part of raw2outputs, differentiated (a training step's backward between the loss and iblnerf_composite_direct_backward;
+ * replaces autograd through nerf_models/ibl_nerf_renderer.py:258 disparity, :412-474 LUT fetch / Fresnel / mip interpolation / diffuse +
+ * specular, :477-527 tone map + gamma of every output — about 160 ray-sized launches per pass in torch — by one launch).
+ * d_maps [n_rays, 19]: the pass's linear direct maps (iblnerf_composite_direct's slots).  d_n_dot_v [n_rays] and d_env [n_rays, 4, 3] (the
+ * LINEAR reflected-ray maps: radiance, coarse radiances 1..3): the pass's quantities the reference computes under no_grad (:442-448) or
+ * detaches (the normal: no_grad queries; depth inside the mip level: :457) — both NULL for approximate_radiance=False, where only the
+ * direct maps' output functions are differentiated.  depth0 = (near + far) / 2 (:456).  d_upstream: dL/d(output map) per map in the
+ * layout of iblnerf_maps, NULL = no gradient; read: color_map, radiance_map, radiance_map_k, irradiance_map ([n,1]), albedo_map,
+ * roughness_map, specular_map, diffuse_map, prefiltered_reflected_map, disp_map, acc_map, depth_map, target_depth_map (the others carry no
+ * gradient in the reference: target_normal_map, n_dot_v_map, the reflected maps).  d_dmaps [n_rays, 19] out.  Uses the context's LUT and
+ * its gamma_correct / use_radiance_linear / lut_coefficient_f0 / correct_depth_for_prefiltered_radiance options. */
+int iblnerf_ray_outputs_backward(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
+                                 const iblnerf_maps* d_upstream, int64_t n_rays, float* d_dmaps);
+
+
 /* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,
  * :629-732, :153-527) with approximate_radiance=True, perturb=0, raw_noise_std=0.
  * d_rays_o / d_rays_d [n_rays,3] (rays_d NOT normalised, as get_rays returns it).  Any n_rays: the

@@ -111,3 +111,69 @@ def test_warmup_render_without_autograd(G, lut):
     for k in ("radiance_map", "albedo_map", "depth_map", "weights", "radiance_map0"):
         assert rel_linf(res[k].cpu().numpy(), G["warmup__out__" + k]) <= 1e-3, k
         assert not res[k].requires_grad
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(gamma_correct=False), dict(use_radiance_linear=True), dict(lut_coefficient="F0"),
+                                   dict(correct_depth_for_prefiltered_radiance_infer=False), dict(use_radiance_linear=True, lut_coefficient="F0", gamma_correct=False)])
+def test_ray_outputs_backward_matches_autograd(lut, flags):
+    """iblnerf_ray_outputs_backward (one launch: LUT fetch, Fresnel, mip interpolation, diffuse + specular, tone map + gamma, disparity — differentiated
+    by hand) against torch autograd through the same ray-sized function (training._ray_outputs, itself pinned to the reference's maps by
+    tests/test_host_logic.py): random maps, random upstream gradients on all fifteen gradient-carrying outputs, every flag combination the
+    reference has; with and without the approximate_radiance part."""
+    from ibl_nerf_amd import binding as B, renderer as R, training as T
+    B.load_library()
+    r = R.Renderer(64, 128, max_rays_per_launch=1024, **flags)
+    r.load_lut(lut)
+    fl = T._flags(r)
+    rng = np.random.RandomState(7)
+    n = 4096
+    x = np.concatenate([rng.uniform(1.0, 6.0, (n, 1)), rng.uniform(0.5, 1.0, (n, 1)), rng.uniform(0.03, 0.97, (n, 17))], 1).astype(np.float32)
+    x[:64, 5] = rng.uniform(0.0, 1.0 / 511, 64)                      # the LUT's first row interval; and rays where 1 - rough < F0 (the other arm of the maximum)
+    x[64:128, 5], x[64:128, 2:5] = rng.uniform(0.9, 1.0, 64), rng.uniform(0.5, 0.97, (64, 3))
+    ndv = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    ndv[:16], ndv[16:32] = 0.0, 1.0                                    # clipped n.v (:412-413)
+    env = rng.uniform(0.02, 0.9, (n, 4, 3)).astype(np.float32)
+    xt, nd, ev = (torch.from_numpy(a).cuda() for a in (x, ndv, env))
+    lut_t = torch.from_numpy(lut).cuda()
+    for approx in (True, False):
+        consts = dict(n_dot_v=nd, env=ev, lut=lut_t, depth0=4.25) if approx else None
+        xg = xt.clone().requires_grad_(True)
+        outs = T._ray_outputs(xg, consts, fl)
+        keys = [k for k in T.SHADED_KEYS if k in outs]
+        assert len(keys) == (15 if approx else 11)
+        ups = {k: torch.from_numpy(rng.standard_normal(tuple(outs[k].shape)).astype(np.float32)).cuda() for k in keys}
+        (ref,) = torch.autograd.grad([outs[k] for k in keys], xg, [ups[k] for k in keys], retain_graph=True)
+        got = r.ray_outputs_backward(xt, ups, nd if approx else None, ev if approx else None, 4.25)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(ref).all())
+        err = (got - ref).abs().amax(0) / ref.abs().amax(0).clamp_min(1e-30)
+        assert float(err.max()) <= 2e-5, (approx, err.cpu().numpy())
+        # one map at a time: each output's own chain
+        for k in keys:
+            (rk,) = torch.autograd.grad(outs[k], xg, ups[k], retain_graph=True)
+            gk = r.ray_outputs_backward(xt, {k: ups[k]}, nd if approx else None, ev if approx else None, 4.25)
+            assert float((gk - rk).abs().max()) <= 2e-5 * max(float(rk.abs().max()), 1e-30), k
+    with pytest.raises(KeyError):
+        r.ray_outputs_backward(xt, {"target_normal_map": xt[:, :3]})
+    with pytest.raises(B.IblNerfError):
+        r.ray_outputs_backward(xt, {}, nd, ev, depth0=0.0)
+
+
+def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
+    """The fused shading backward against the autograd one inside a whole step: every parameter gradient of both networks."""
+    import train_loss as TL
+    from ibl_nerf_amd import renderer as R, training as T
+    grads = []
+    for fused in (True, False):
+        nets, kw, K, rays = _setup(G, lut, "full")
+        T.FUSED_SHADING_BACKWARD = fused
+        try:
+            res = R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values={}, approximate_radiance=True, **kw)
+            TL.total_loss(torch, res, {k[8:]: G[k] for k in G.files if k.startswith("target__")}, True).backward()
+        finally:
+            T.FUSED_SHADING_BACKWARD = True
+        grads.append({t + n: p.grad.clone() for t, net in (("c.", nets[0]), ("f.", nets[1])) for n, p in net.named_parameters()})
+    assert len(grads[0]) == 92
+    for k in grads[0]:
+        scale = max(float(grads[1][k].abs().max()), 1e-30)
+        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-4 * scale, (k, float((grads[0][k] - grads[1][k]).abs().max()) / scale)
