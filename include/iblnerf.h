@@ -85,6 +85,10 @@ typedef struct {
                                                                   on F16_MXFP6 (it places no samples and no difference is taken of it:
                                                                   its 2^-16 reaches the maps unamplified; the worst ray of every direct
                                                                   channel is set by the coarse pass's sample placement)
+                                                                  Re-measured on a second fitted checkpoint with sharper density steps: the composited maps
+                                                                  hold; the per-sample `weights` output of the fine pass, which sees that query's 2^-16
+                                                                  unaveraged, reaches 1.6e-3 at the 99.9th percentile there (3.5e-4 on the first checkpoint) —
+                                                                  IBLNERF_ROUTE_FINE_MAIN_PRECISE below is the option for callers who consume it
                                           IBLNERF_MLP_F16X3_MAIN  F16X3 for the queries whose results are direct channels (main query
                                                                   of both passes, auxiliary networks, iblnerf_network_query) and for
                                                                   the coarse grid's offset queries; F16_MXFP6 also for the fine
