@@ -54,9 +54,12 @@ def R():
 
 def per_ray(got, ref):
     """max over a map's channels of |got - ref|, over the map's global max: [n]."""
+    import warnings
     ref = np.asarray(ref, dtype=np.float64)
     scale = max(float(np.nanmax(np.abs(ref))), 1e-30)
-    return np.nanmax(np.abs(np.asarray(got, dtype=np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1), -1) / scale
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)      # a ray whose map is NaN in the reference and here (disp_map of an empty ray): NaN, compared as such by the caller
+        return np.nanmax(np.abs(np.asarray(got, dtype=np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1), -1) / scale
 
 
 NORMAL_LIKE = ["target_normal_map", "n_dot_v_map"]
