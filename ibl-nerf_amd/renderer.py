@@ -117,9 +117,7 @@ class Renderer:
         o.mlp_precision = B.MLP_PRECISIONS[mlp_precision]
         o.normal_mode = NORMAL_MODES[normal_mode]
         o.color_independent_to_direction = int(bool(color_independent_to_direction))
-        if not isinstance(query_routing, int):
-            names = [query_routing] if isinstance(query_routing, str) else list(query_routing)
-            query_routing = sum(getattr(B, "ROUTE_" + n.upper()) for n in names)
+        query_routing = _routing_bits(query_routing)
         o.query_routing, o.persistent_workgroups = int(query_routing), int(persistent_workgroups)
         self.normal_mode = normal_mode
         self.mlp_precision = mlp_precision
@@ -950,6 +948,14 @@ def _same_object(ref, obj):
     return ref is not None and ref() is obj
 
 
+def _routing_bits(q):
+    """iblnerf_options.query_routing from an int, a ROUTE_* name or a sequence of names (render kwarg `query_routing`)."""
+    if isinstance(q, int):
+        return q
+    names = [q] if isinstance(q, str) else list(q)
+    return sum(getattr(B, "ROUTE_" + n.upper()) for n in names)
+
+
 def renderer_for(kw):
     """Renderer for a reference-style render_kwargs dict; weights/LUT re-uploaded when they change."""
     torch = _torch()
@@ -962,7 +968,8 @@ def renderer_for(kw):
            kw.get("mlp_precision") or DEFAULT_MLP_PRECISION,
            kw.get("target_normal_map_for_radiance_calculation", "normal_map_from_depth_gradient_epsilon"),
            bool(getattr(net_c, "is_color_independent_to_direction", False)), float(kw.get("epsilon_direction", 0.005)),
-           bool(kw.get("infer_normal") and kw.get("infer_normal_at_surface")), bool(kw.get("_lazy_range_check", False)))
+           bool(kw.get("infer_normal") and kw.get("infer_normal_at_surface")), bool(kw.get("_lazy_range_check", False)),
+           _routing_bits(kw.get("query_routing", 0)))
     if net_f is not None and bool(getattr(net_f, "is_color_independent_to_direction", False)) != key[13]:
         raise ValueError("network_fn and network_fine disagree on is_color_independent_to_direction")
     ent = _renderers.get(key)
@@ -973,7 +980,7 @@ def renderer_for(kw):
                      correct_depth_for_prefiltered_radiance_infer=key[5], coarse_outputs=key[6],
                      max_rays_per_launch=key[7], lindisp=key[9], use_radiance_linear=key[10], mlp_precision=key[11], normal_mode=key[12],
                      color_independent_to_direction=key[13], epsilon_direction=key[14], infer_normal_at_surface=key[15],
-                     range_check="lazy" if key[16] else "eager")
+                     range_check="lazy" if key[16] else "eager", query_routing=key[17])
         ent = _renderers[key] = {"r": r, "w": [None, None], "lut": None, "aux": {}}
     r = ent["r"]
     for which, net in ((0, net_c), (1, net_f if N_imp > 0 else None)):

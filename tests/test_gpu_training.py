@@ -177,3 +177,15 @@ def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
     for k in grads[0]:
         scale = max(float(grads[1][k].abs().max()), 1e-30)
         assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-4 * scale, (k, float((grads[0][k] - grads[1][k]).abs().max()) / scale)
+
+
+def test_query_routing_render_kwarg_selects_its_own_context(G, lut):
+    """render kwarg `query_routing` (names or bits of iblnerf_options.query_routing) reaches the context; contexts are cached per routing."""
+    from ibl_nerf_amd import binding as B, renderer as R
+    nets, kw, K, rays = _setup(G, lut, "full")
+    a = R.renderer_for(kw)
+    b = R.renderer_for(dict(kw, query_routing=("fine_main_precise",)))
+    c = R.renderer_for(dict(kw, query_routing=B.ROUTE_FINE_MAIN_PRECISE))
+    assert a is not b and b is c and a.opt.query_routing == 0 and b.opt.query_routing == B.ROUTE_FINE_MAIN_PRECISE
+    with pytest.raises(AttributeError):
+        R.renderer_for(dict(kw, query_routing="no_such_route"))
