@@ -80,7 +80,7 @@ class Sampling(C.Structure):
 
 
 class Taps(C.Structure):
-    _fields_ = [("d_z_coarse", FP), ("d_z_fine", FP), ("d_raw_coarse", FP), ("d_raw_fine", FP)]
+    _fields_ = [("d_z_coarse", FP), ("d_z_fine", FP), ("d_raw_coarse", FP), ("d_raw_fine", FP), ("d_env_coarse", FP), ("d_env_fine", FP)]
 
 
 class Outputs(C.Structure):

@@ -966,7 +966,8 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 // coarse_grid: this pass's own samples are that grid.
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
-                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise) {
+                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise,
+                     float* env_tap = nullptr) {
     const int Sc = c->Sc;
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
@@ -1021,6 +1022,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     PassBArgs b;
     b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = zc; b.zc_stride = zc_stride; b.Sc = Sc;
     b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = R;
+    b.env_tap = env_tap;
     HIP_TRY(c, launch_pass_b(b, s));
     return IBLNERF_OK;
 }
@@ -1151,14 +1153,14 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         };
         if (!fine) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
@@ -1170,7 +1172,7 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
-                       noise_f ? noise_f + r0 * Sf : nullptr);
+                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr);
         if (rc) return rc;
         if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
     }

@@ -148,6 +148,7 @@ struct PassBArgs {
     int radiance_linear;
     PassOutputs out;
     long R;
+    float* env_tap = nullptr;  // [R,12] or null: the four LINEAR reflected-ray maps (radiance, coarse radiances 1..3) before tone map / gamma (training taps)
 };
 hipError_t launch_pass_b(const PassBArgs& a, hipStream_t s);
 

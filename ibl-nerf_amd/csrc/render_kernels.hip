@@ -581,6 +581,10 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 #pragma unroll
     for (int c = 0; c < 12; ++c) maps[c] = wave_sum(maps[c]);
     if (lane != 0) return;
+    if (a.env_tap != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) a.env_tap[12 * r + c] = maps[c];
+    }
 
     const float* st = a.state + r * ST_FLOATS;
     const float albedo[3] = {st[0], st[1], st[2]};

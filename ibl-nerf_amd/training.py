@@ -257,20 +257,24 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             Sc, Sf = r.N_samples, r.N_samples + r.N_importance
             if approximate_radiance:
                 taps = B.Taps()
-                sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18))
+                sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18), envc=st._e(n, 4, 3), envf=st._e(n, 4, 3))
                 taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
+                taps.d_env_coarse, taps.d_env_fine = sv["envc"].data_ptr(), sv["envf"].data_ptr()    # the linear reflected-ray maps, exact (no gamma round trip)
                 res = r.render_rays(ro_, rd_, near, far, draws=(t_rand, u), taps=taps)
             else:
                 res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
             if approximate_radiance:
                 src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})
-                for sfx in ("", "0"):
-                    env = torch.stack([_ungamma(src[k + sfx], flags["gamma_correct"]) for k in
-                                       ("reflected_radiance_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")], 1)
-                    if flags["use_radiance_linear"]:
-                        env = env / (1 - env)                        # inverse of tonemap_reinherd
-                    ctx.saved["consts" + sfx] = dict(n_dot_v=src["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)
+                for sfx, tap in (("", "envf"), ("0", "envc")):
+                    if teacher_maps:                                 # parity tests: the reference's own (gamma-corrected) maps, inverted
+                        env = torch.stack([_ungamma(src[k + sfx], flags["gamma_correct"]) for k in
+                                           ("reflected_radiance_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")], 1)
+                        if flags["use_radiance_linear"]:
+                            env = env / (1 - env)                    # inverse of tonemap_reinherd
+                    else:
+                        env = sv[tap]
+                    ctx.saved["consts" + sfx] = dict(n_dot_v=src["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)   # (a copy: the map itself goes to the caller)
             outs = tuple(res[k] for k in keys)
             ctx.mark_non_differentiable(*[res[k] for k in keys if k.startswith(("target_normal_map", "n_dot_v_map", "reflected_", "z_std"))])
             return outs

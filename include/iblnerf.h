@@ -396,12 +396,17 @@ int iblnerf_render_rays_sampled(iblnerf_ctx* ctx, void* stream, const float* d_r
 /* iblnerf_render_rays_sampled that also hands out what a backward pass needs (a training step with approximate_radiance=True, train.py:295):
  * the z_vals of both passes and the main query's raw rows of both passes (after auxiliary networks wrote their columns), copied out of the
  * workspace launch by launch.  Any pointer may be NULL.  d_z_coarse [n_rays, N_samples], d_z_fine [n_rays, N_samples + N_importance],
- * d_raw_coarse [n_rays, N_samples, 18], d_raw_fine [n_rays, N_samples + N_importance, 18].  Needs options.coarse_outputs. */
+ * d_raw_coarse [n_rays, N_samples, 18], d_raw_fine [n_rays, N_samples + N_importance, 18].  Needs options.coarse_outputs.
+ * d_env_coarse / d_env_fine [n_rays, 4, 3]: the pass's four reflected-ray maps (radiance, coarse radiances 1..3; raw2outputs_simple,
+ * ibl_nerf_renderer.py:38-68, :446-448) LINEAR, before tone map and gamma — the constants iblnerf_ray_outputs_backward takes (the output
+ * maps reflected_radiance_map / reflected_coarse_radiance_map_k are their gamma-corrected forms). */
 typedef struct {
     float* d_z_coarse;
     float* d_z_fine;
     float* d_raw_coarse;
     float* d_raw_fine;
+    float* d_env_coarse;
+    float* d_env_fine;
 } iblnerf_taps;
 int iblnerf_render_rays_tapped(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                                float near_, float far_, const iblnerf_overrides* overrides, const iblnerf_sampling* sampling,
