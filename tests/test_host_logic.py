@@ -57,6 +57,43 @@ def test_integration_stub_matches_options_struct():
     assert re.findall(r'\("(\w+)", C\.c_(?:int32|float)\)', stub) == [n for n, _ in B.Options._fields_]
 
 
+def test_ctypes_structs_mirror_the_header():
+    """Every struct of include/iblnerf.h against its ctypes mirror in binding.py (which oracle/iblnerf_cpu.py shares): field names in order,
+    array lengths, and the kind of each field (int32 / float / pointer) — a missing or reordered field would shift every later one."""
+    hdr = open(os.path.join(ROOT, "include", "iblnerf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    mirrors = {"iblnerf_options": B.Options, "iblnerf_overrides": B.Overrides, "iblnerf_maps": B.Maps, "iblnerf_outputs": B.Outputs,
+               "iblnerf_sampling": B.Sampling, "iblnerf_taps": B.Taps, "iblnerf_stage_inputs": B.StageInputs}
+    seen = 0
+    for body, name in re.findall(r"typedef struct \{(.*?)\}\s*(\w+);", hdr, flags=re.S):
+        if name not in mirrors:
+            continue
+        seen += 1
+        want = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(?:const )?(int32_t|float|iblnerf_maps)\s*(\*?)\s*(.*)$", decl)
+            assert m, (name, decl)
+            base, ptr, rest = m.groups()
+            for item in rest.split(","):
+                item = item.strip()
+                star = ptr == "*" or item.startswith("*")
+                am = re.match(r"\*?\s*(\w+)(?:\[(\d+)\])?$", item)
+                assert am, (name, item)
+                kind = "ptr" if star else base
+                want.append((am.group(1), kind, int(am.group(2) or 0)))
+        got = []
+        for fname, ftype in mirrors[name]._fields_:
+            n = getattr(ftype, "_length_", 0)
+            el = getattr(ftype, "_type_", ftype) if n else ftype
+            kind = {C.c_int32: "int32_t", C.c_float: "float", C.c_void_p: "ptr", B.Maps: "iblnerf_maps"}[el]
+            got.append((fname, kind, n))
+        assert got == want, (name, [a for a, b in zip(got, want) if a != b][:3], len(got), len(want))
+    assert seen == len(mirrors)
+
+
 def test_no_gpu_fails_loudly(lib):
     torch = pytest.importorskip("torch")
     if torch.cuda.is_available():
