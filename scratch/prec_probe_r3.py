@@ -43,6 +43,16 @@ def lin(sd, name, x):
     Wh, Xh = f16(W), f16(x)
     acc = x64(Xh) @ x64(Wh).T
     Wl, Xl = W - Wh, x - Xh
+    if s in "sSq":
+        # s: three f16 products whose residual operands are converted at a 2^12 larger exponent (no f16-denormal loss in the lo parts: what
+        #    scaling W and X per layer by powers of two would give); S: the same for the activation residual only; q: s plus the fourth product Wl Xl
+        sc = np.float32(4096.0)
+        Xl_ = x64(f16(Xl * sc)) / 4096.0 if s in "sSq" else x64(f16(Xl))
+        Wl_ = x64(f16(Wl * sc)) / 4096.0 if s in "sq" else x64(f16(Wl))
+        acc += Xl_ @ x64(Wh).T + x64(Xh) @ Wl_.T
+        if s == "q":
+            acc += Xl_ @ Wl_.T
+        return (acc + b).astype(np.float32)
     acc += (x64(f16(Xl)) @ x64(Wh).T) if s in "pa" else (q6(Xl) @ q6(Wh).T)
     acc += (x64(Xh) @ x64(f16(Wl)).T) if s in "pw" else (q6(Xh) @ q6(Wl).T)
     return (acc + b).astype(np.float32)
@@ -77,19 +87,22 @@ if os.environ.get("PROBE_RAYS"):      # explicit ray ids first (e.g. the rays a 
     extra = np.array([int(t) for t in os.environ["PROBE_RAYS"].split(",")])
     rsel = np.concatenate([extra, np.setdiff1d(rsel, extra)[:n_rays - len(extra)]])
 lut = load_lut_rgb()
-keys = ("target_normal_map0", "target_normal_map", "depth_map0", "depth_map", "albedo_map", "roughness_map")
+keys = ("weights0", "target_normal_map0", "target_normal_map", "depth_map0", "depth_map", "albedo_map", "roughness_map")
 print("class %s, %d rays (the %d worst-conditioned of 16 384 + random); reference's own f64-vs-f32 on them: %s" % (
     CLASS, n_rays, n_rays // 2, "  ".join("%s %.1e" % (k, g["floorray__" + k][rsel].max()) for k in keys)), flush=True)
+SCHEME = None; COUNT["off"] = COUNT["main"] = 0; CLASS_, CLASS = CLASS, "none"
+BASE = O.render_rays(sdc, sdf, g["rays_o"][rsel], g["rays_d"][rsel], 0.5, 8.0, lut)      # the fp32 oracle on the same rays (weights0: the fixtures keep every k-th row only)
+CLASS = CLASS_
 for scheme in sys.argv[3:]:
     SCHEME = scheme; COUNT["off"] = COUNT["main"] = 0
     t0 = time.time()
     res = O.render_rays(sdc, sdf, g["rays_o"][rsel], g["rays_d"][rsel], 0.5, 8.0, lut)
     row = []
     for k in keys:
-        ref = g["out__" + k][rsel].astype(np.float64)
+        ref = (BASE[k] if k.startswith("weights") else g["out__" + k][rsel]).astype(np.float64)
         e = np.abs(res[k].astype(np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1).max(-1) / np.abs(g["out__" + k]).max()
         row.append("%s %.1e/%.1e" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)]))
-    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9}[c] for c in scheme[:8]) / 8
+    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16}[c] for c in scheme[:8]) / 8
     print("%-10s %4.1f slots  (max / 98%%)  %s   [%.0f s]" % (scheme, slots, "  ".join(row), time.time() - t0), flush=True)
     if os.environ.get("PROBE_RAYS"):
         ref = g["out__target_normal_map"][rsel].astype(np.float64)

@@ -10,7 +10,9 @@ yardstick — float64):
 The masks / normal / depth images of the two override configs are analytic functions of the pixel (tests/frame_overrides.py), so the
 whole 800x800 frames of configs 4 and 5 are rendered here too and compared at the fixtures' pixels.
 
-Rules.  The reference's own float64-vs-float32 difference is recorded PER RAY (fixture arrays floorray__*): a ray that grazes a
+Rules.  A ray's own sensitivity in the reference = the largest of four per-ray yardsticks recorded with the fixture (ray_floor): its float64-vs-float32
+difference, one-ulp nudges of the coarse weights, both branches of sample_pdf's threshold, and its float32 render with the checkpoint rounded to 22-bit mantissas.
+The reference's own float64-vs-float32 difference is recorded PER RAY (fixture arrays floorray__*): a ray that grazes a
 surface amplifies round-off without bound in the reference itself (its two runs differ by 7e-2 on the normal of the worst of 16 384 rays, by
 5e-4 on depth), so an absolute L-inf bar over a launch is not attainable by any arithmetic; what is asserted instead:
   (i)   direct channels (and `weights`, per sample): every ray <= 5e-4, or <= 8x that ray's own reference difference where that is larger — for
@@ -70,7 +72,10 @@ def ray_floor(g, key):
     what one ulp on the coarse pass's weights does to its float32 output (`nudgeray__*`: the `denom < 1e-5` replacement of sample_pdf sits
     one ulp from an empty bin's denominator, which no float64 run can see; fine-pass maps only)."""
     f = g["floorray__" + key].astype(np.float64)
-    for y in ("nudgeray__", "branchray__"):     # branchray: the same threshold, deterministically — every critical sample placed by either branch
+    # branchray: the same threshold, deterministically — every critical sample placed by either branch.  paramray: the reference's float32 render with
+    # its checkpoint rounded to 22-bit mantissas (about one ulp per parameter — how the three-product kernels hold the weights): the sensitivity to the
+    # PARAMETERS, which the arithmetic yardsticks do not probe and which a fitted network's cancelling density sum amplifies ~300x (coarse and fine maps)
+    for y in ("nudgeray__", "branchray__", "paramray__"):
         if y + key in g.files:
             f = np.maximum(f, g[y + key].astype(np.float64))
     return f / (float(g["floor_scale"]) if "floor_scale" in g.files else 1.0)      # (the compact 65 536-ray fixture stores float16 of 2^14 x the value)
@@ -78,11 +83,14 @@ def ray_floor(g, key):
 
 # Rule parameters.  STRICT: calibrated on the first checkpoint (scene 1), where they are close to tight.  SECOND: what the default mode holds on
 # the second, independently fitted checkpoint (scene 2: density steps of 86 units over 3 cm, a slanted wall the network fits badly) — measured
-# with scratch/rule_report.py, profiles/r03_parity/rule_report_second_checkpoint.txt: the composited maps keep the strict numbers except
-# albedo's 99.9th percentile (2.8e-4 against 2.5e-4); one ray of 4 096 sits at 3.1e-3 on the normal with its own reference runs 5e-5 apart
-# in EVERY mode, all-precise included (the yardsticks are one-sample estimates); the per-sample `weights` of the fine pass — the one
-# output that sees the fine main query's 2^-16 density error unaveraged — reach 1.7e-3 (99.9 %: 1.6e-3; reference's own two runs: 9.2e-4),
-# and 2.5e-4 with that query on the precise kernel (query_routing = FINE_MAIN_PRECISE, -7 % rays/s; see the test below).
+# with scratch/rule_report.py, profiles/r03_parity/rule_report_second_checkpoint*.txt.  With all four yardsticks (the parameter one came out of
+# this checkpoint: one ray of 4 096 sat at 3.1e-3 on the normal in EVERY mode with the reference's arithmetic yardsticks 5e-5 apart — and the
+# reference with its checkpoint rounded to 22 bits moves it by 2.1e-3) the all-precise mode holds STRICT on both views, and so does the default on
+# the frontal view's composited maps and normal, except: albedo's 99.9th percentile (2.8e-4 against 2.5e-4) and the per-sample `weights` of the
+# fine pass — the one output that sees the fine main query's 2^-16 density error unaveraged: 1.7e-3 (99.9 %: 1.6e-3; reference's own two runs:
+# 9.2e-4), and 2.5e-4 with that query on the precise kernel (query_routing = FINE_MAIN_PRECISE, -7 % rays/s; see the test below).  From the
+# rotated camera, where most rays cross space the network was never fitted on, the fine offsets' mixed trunk form leaves 5 rays of 4 096
+# beyond 8x and 2 beyond 16x their own sensitivity on the normal (none all-precise).
 # (refl_worst: the worst ray of a reflected-ray channel within this multiple of the reference's own worst ray — a one-sample statistic, "NOT a
 # parity claim": on the second checkpoint one ray of color_map0 flips its reflected direction, 0.22 against the reference's own 0.034, so only the
 # distribution is asserted there; depth_p99: the bulk of the depth map — from the rotated camera most rays of scene 2 cross unfitted space.)
@@ -156,7 +164,10 @@ def test_launch_scale_render_vs_reference(R, lut, name):
     for k in res:                                      # rays that end in empty space (acc = 0, fitted2_posed4k): disp = 1 / max(1e-10, depth / acc) is NaN in both
         if not k.startswith("weights"):                 # (the fixtures keep every weights_every-th row of the two weights tensors)
             assert np.array_equal(np.isnan(res[k]), np.isnan(g["out__" + k])), k
-    check_against_fixture(res, g, rules=SECOND if name.startswith("fitted2") else STRICT)
+    # (frontal view of the second checkpoint: the per-ray rules at their strict values — with the parameter yardstick no ray of a composited map or of
+    #  the normal is left unexplained —, only the `weights` / albedo-99.9 % numbers of SECOND; the rotated view keeps SECOND's ray counts for the normal)
+    rules = STRICT if not name.startswith("fitted2") else (dict(SECOND, frac8=2000, n16=0) if name == "fitted2_launch4k" else SECOND)
+    check_against_fixture(res, g, rules=rules)
     psnr = 10 * np.log10(1.0 / max(np.mean((res["color_map"].astype(np.float64) - g["out__color_map"]) ** 2), 1e-30))
     # 55 dB, or what the reference's own two runs reach on these rays where that is less (its per-ray difference taken for all three channels:
     # 63.5 / 50.2 / 69.5 dB on the three fixtures; color_map carries the reflected-ray term)
@@ -172,7 +183,7 @@ def test_second_checkpoint_with_the_fine_main_query_on_the_precise_kernel(R, lut
     g, sdc, sdf, gt, edit = load_golden("fitted2_launch4k")
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384, query_routing=B.ROUTE_FINE_MAIN_PRECISE)
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
-    check_against_fixture(res, g, rules=dict(STRICT, n16=1, refl_worst=None))
+    check_against_fixture(res, g, rules=dict(STRICT, refl_worst=None))
     e = per_ray(res["weights"][::int(g["weights_every"])], g["out__weights"])
     assert np.percentile(e, 99.9) <= 4e-4 and e.max() <= 5e-4, (np.percentile(e, 99.9), e.max())
 
