@@ -43,6 +43,12 @@ def lin(sd, name, x):
     Wh, Xh = f16(W), f16(x)
     acc = x64(Xh) @ x64(Wh).T
     Wl, Xl = W - Wh, x - Xh
+    if s in "eE":
+        # e: EXACT weights (a three-way split of W: the third term costs one block-scaled slot per 64 k), activations as f16 pairs: W Xh + Wh Xl
+        # E: the same with the activation residual's product against the exact W too (W Xh + W Xl)
+        Xl_ = x64(f16(Xl))
+        acc = x64(Xh) @ x64(W).T + Xl_ @ (x64(W) if s == "E" else x64(Wh)).T
+        return (acc + b).astype(np.float32)
     if s in "sSq":
         # s: three f16 products whose residual operands are converted at a 2^12 larger exponent (no f16-denormal loss in the lo parts: what
         #    scaling W and X per layer by powers of two would give); S: the same for the activation residual only; q: s plus the fourth product Wl Xl
@@ -102,7 +108,7 @@ for scheme in sys.argv[3:]:
         ref = (BASE[k] if k.startswith("weights") else g["out__" + k][rsel]).astype(np.float64)
         e = np.abs(res[k].astype(np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1).max(-1) / np.abs(g["out__" + k]).max()
         row.append("%s %.1e/%.1e" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)]))
-    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16}[c] for c in scheme[:8]) / 8
+    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16, "e": 13, "E": 14}[c] for c in scheme[:8]) / 8
     print("%-10s %4.1f slots  (max / 98%%)  %s   [%.0f s]" % (scheme, slots, "  ".join(row), time.time() - t0), flush=True)
     if os.environ.get("PROBE_RAYS"):
         ref = g["out__target_normal_map"][rsel].astype(np.float64)
