@@ -51,6 +51,26 @@ for k in ref:
     out[k] = dict(p50=float(np.percentile(e, 50)), p99=float(np.percentile(e, 99)), p999=float(np.percentile(e, 99.9)), p9999=float(np.percentile(e, 99.99)), max=float(e.max()),
                   over_1e3=int((e > 1e-3).sum()), over_2e4=int((e > 2e-4).sum()))
     print("%-36s p50 %.1e  p99 %.1e  p99.9 %.1e  p99.99 %.1e  max %.1e   rays > 1e-3: %d   > 2e-4: %d" % (k, out[k]["p50"], out[k]["p99"], out[k]["p999"], out[k]["p9999"], out[k]["max"], out[k]["over_1e3"], out[k]["over_2e4"]))
+if len(sys.argv) > 4 and sys.argv[4] == "param":
+    # the same frame by the C restatement with both checkpoints rounded to 22-bit mantissas (f16(w) + f16(w - f16(w)): how the three-product kernels hold the weights)
+    def r22(sd):
+        o = {}
+        for k_, v in sd.items():
+            hi = v.astype(np.float16).astype(np.float32)
+            o[k_] = (hi + (v - hi).astype(np.float16).astype(np.float32)).astype(np.float32)
+        return o
+    t0 = time.time()
+    ref22 = OC.render_rays(r22(sdc), r22(sdf), ro.cpu().numpy(), rd.cpu().numpy(), 0.5, 8.0, lut, gt=gt, edit=edit)
+    print("\nC restatement with 22-bit parameters against the C restatement with the checkpoint as it is (%.0f s); HIP against the exact one in brackets:" % (time.time() - t0))
+    for k in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "radiance_map", "weights", "target_normal_map", "n_dot_v_map", "depth_map0", "target_normal_map0", "weights0"):
+        b = ref[k].astype(np.float64).reshape(n, -1)
+        sc = max(np.abs(b).max(), 1e-30)
+        ep = np.abs(ref22[k].astype(np.float64).reshape(n, -1) - b).max(-1) / sc
+        eh = np.abs(got[k].astype(np.float64).reshape(n, -1) - b).max(-1) / sc
+        both = int(((ep > 1e-3) & (eh > 1e-3)).sum())
+        print("%-22s p99 %.1e (%.1e)  p99.9 %.1e (%.1e)  p99.99 %.1e (%.1e)  rays > 1e-3: %d (%d; %d in both)   HIP rays beyond max(1e-3, 8x the parameter sensitivity): %d" % (
+            k, np.percentile(ep, 99), np.percentile(eh, 99), np.percentile(ep, 99.9), np.percentile(eh, 99.9), np.percentile(ep, 99.99), np.percentile(eh, 99.99),
+            int((ep > 1e-3).sum()), int((eh > 1e-3).sum()), both, int((eh > np.maximum(1e-3, 8 * ep)).sum())))
 mse = float(np.mean((got["color_map"].astype(np.float64) - ref["color_map"]) ** 2))
 print("color PSNR %.1f dB" % (10 * np.log10(1 / max(mse, 1e-30))))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
