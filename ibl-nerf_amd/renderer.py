@@ -1052,7 +1052,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
         # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
         if any(v for k, v in edit.items() if isinstance(v, bool)) or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or r._aux or _ci_net(kwargs["network_fn"]):
             raise NotImplementedError("edit / insert overrides, *_from_gt flags, raw_noise_std, auxiliary and colour-independent networks are not built "
-                                      "for is_depth_only, approximate_radiance=False and gradient-carrying renders")
+                                      "for is_depth_only, approximate_radiance=False and gradient-carrying renders (no shipped config has them; keep the "
+                                      "reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
         if is_depth_only:                                                       # raw2outputs_depth (:197-198)
             ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, **smp)
             if kwargs.get("infer_depth") and r._depth_mlp is not None:        # :722-726 runs whatever the pass type
