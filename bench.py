@@ -344,7 +344,11 @@ def main():
             def gpu_color(idx):
                 return color[torch.as_tensor(idx, device=color.device)].cpu().numpy()
 
-            line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color, args.checkpoint)
+            try:
+                line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color, args.checkpoint)
+            except Exception as e:      # the CPU leg must never cost the GPU line (e.g. no gcc on a host that did not receive oracle/_build/)
+                line["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": 0, "kind": "port", "sample": "not measured", "error": "%s: %s" % (type(e).__name__, e),
+                                        "reference_in_build_container": reference_cpu_record(args.checkpoint)}
         print(json.dumps(line), flush=True)
     if grouped:
         dist.barrier()
