@@ -182,6 +182,9 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
     left = {k: v for k, v in flags.items() if v}
     if left:
         raise NotImplementedError("flags not restated in C (the numpy oracle has them): %s" % sorted(left))
+    if edit.get("edit_roughness_by_img"):
+        raise NotImplementedError("edit_roughness_by_img (ibl_nerf_renderer.py:394-395) is not restated in C")
+    assert not (edit.get("edit_intrinsic") and edit.get("insert_object")), "edit_intrinsic and insert_object cannot be True at the same time"   # :218
     ro, rd = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
     n = ro.shape[0]
     keep = []
