@@ -43,6 +43,14 @@ def lin(sd, name, x):
     Wh, Xh = f16(W), f16(x)
     acc = x64(Xh) @ x64(Wh).T
     Wl, Xl = W - Wh, x - Xh
+    if s == "F":
+        # F: three f16 products + THREE block-scaled fp6 products for everything at the 2^-22 level: Wl Xl, W3 Xh, Wh X3 (W3, X3 = what two f16 halves
+        #    leave of the fp32 value) — 15 slots; every operand is then represented to ~2^-25
+        Xl16, Wl16 = f16(Xl), f16(Wl)
+        X3, W3 = (Xl - Xl16).astype(np.float32), (Wl - Wl16).astype(np.float32)
+        acc = x64(Xh) @ x64(Wh).T + x64(Xl16) @ x64(Wh).T + x64(Xh) @ x64(Wl16).T
+        acc += q6(Xl16) @ q6(Wl16).T + q6(Xh) @ q6(W3).T + q6(X3) @ q6(Wh).T
+        return (acc + b).astype(np.float32)
     if s in "eE":
         # e: EXACT weights (a three-way split of W: the third term costs one block-scaled slot per 64 k), activations as f16 pairs: W Xh + Wh Xl
         # E: the same with the activation residual's product against the exact W too (W Xh + W Xl)
@@ -108,7 +116,7 @@ for scheme in sys.argv[3:]:
         ref = (BASE[k] if k.startswith("weights") else g["out__" + k][rsel]).astype(np.float64)
         e = np.abs(res[k].astype(np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1).max(-1) / np.abs(g["out__" + k]).max()
         row.append("%s %.1e/%.1e" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)]))
-    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16, "e": 13, "E": 14}[c] for c in scheme[:8]) / 8
+    slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16, "e": 13, "E": 14, "F": 15}[c] for c in scheme[:8]) / 8
     print("%-10s %4.1f slots  (max / 98%%)  %s   [%.0f s]" % (scheme, slots, "  ".join(row), time.time() - t0), flush=True)
     if os.environ.get("PROBE_RAYS"):
         ref = g["out__target_normal_map"][rsel].astype(np.float64)
