@@ -177,3 +177,30 @@ def test_launch_scale_rule_on_an_independent_fp32_implementation(name, lut):
         worst, own = rep[k][0], rep[k][1]
         assert worst <= 3e-4 and worst <= own, (k, worst, own)
     assert rep["target_normal_map"][2] <= 2 and rep["target_normal_map0"][2] == 0          # rays above 1e-3 (the reference flags 95 / 113 and 33 / 314 of them)
+
+
+def test_parameter_sensitivity_matches_the_reference(lut):
+    """The fourth yardstick of the launch-scale fixtures (`paramray__*`: the reference's float32 render with its checkpoint rounded to 22-bit
+    mantissas, against its render with the checkpoint as it is) recomputed with the C restatement: the same distribution, ray by ray — the C
+    path reproduces not only the reference's outputs but their sensitivity to the parameters, which is what whole-frame sensitivity studies with
+    it rest on (scratch/full_frame_vs_c.py ... param; DESIGN.md section 2 "Launch scale" 7)."""
+    import test_gpu_launch_scale as LS
+
+    def r22(sd):
+        out = {}
+        for k, v in sd.items():
+            hi = v.astype(np.float16).astype(np.float32)
+            out[k] = (hi + (v - hi).astype(np.float16).astype(np.float32)).astype(np.float32)
+        return out
+    g, sdc, sdf, gt, edit = load_golden("fitted2_launch4k")
+    assert max(float(np.abs(sdc[k] - r22(sdc)[k]).max() / np.abs(sdc[k]).max()) for k in sdc) <= 2e-5          # about one ulp per parameter
+    a = OC.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut)
+    b = OC.render_rays(r22(sdc), r22(sdf), g["rays_o"], g["rays_d"], 0.5, 8.0, lut)
+    for key in ("depth_map", "target_normal_map", "albedo_map", "depth_map0", "target_normal_map0"):
+        pc, pr = LS.per_ray(b[key], a[key]), g["paramray__" + key].astype(np.float64)
+        for q in (99, 99.9):
+            assert 0.7 * np.percentile(pr, q) <= np.percentile(pc, q) <= 1.4 * np.percentile(pr, q), (key, q, np.percentile(pc, q), np.percentile(pr, q))
+        assert (np.abs(pc - pr) > 1e-4 + 0.1 * pr).sum() <= 12, (key, int((np.abs(pc - pr) > 1e-4 + 0.1 * pr).sum()))
+    # and it is two orders of magnitude above what a change of the ARITHMETIC does to the same implementation (fused multiply-adds or not: ~1e-6),
+    # which is why the arithmetic yardsticks could not see it
+    assert np.percentile(g["paramray__target_normal_map"], 99.9) > 1e-3 > 20 * np.percentile(g["paramray__target_normal_map0"].astype(np.float64), 50)
