@@ -22,7 +22,8 @@ lut = load_lut_rgb()
 fl = np.float32(0.5 * 800 / np.tan(0.5 * np.deg2rad(60.0)))
 K = np.array([[fl, 0, 400], [0, fl, 400], [0, 0, 1]], dtype=np.float32)
 c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
-r = pkg.Renderer(64, 128)
+routing = tuple(a[8:] for a in sys.argv if a.startswith("routing="))      # e.g. routing=fine_main_precise
+r = pkg.Renderer(64, 128, query_routing=routing or 0)
 r.load_weights(0, sdc); r.load_weights(1, sdf); r.load_lut(lut)
 ro, rd = r.get_rays(800, 800, K, c2w)
 r0 = (800 - rows) // 2
@@ -42,7 +43,7 @@ t0 = time.time()
 ref = OC.render_rays(sdc, sdf, ro.cpu().numpy(), rd.cpu().numpy(), 0.5, 8.0, lut, gt=gt, edit=edit)
 t_cpu = time.time() - t0
 n = ro.shape[0]
-print("checkpoint %s, config %s" % (which, config))
+print("checkpoint %s, config %s, query_routing %s" % (which, config, routing or "default"))
 print("rays %d   HIP %.2f s (%.0f rays/s)   C restatement %.1f s (%.0f rays/s, %d threads, %s)" % (n, t_gpu, n / t_gpu, t_cpu, n / t_cpu, OC.usable_cpus(), OC.isa()))
 out = {}
 for k in ref:
