@@ -115,7 +115,7 @@ for scheme in sys.argv[3:]:
     for k in keys:
         ref = (BASE[k] if k.startswith("weights") else g["out__" + k][rsel]).astype(np.float64)
         e = np.abs(res[k].astype(np.float64).reshape(ref.shape) - ref).reshape(len(ref), -1).max(-1) / np.abs(g["out__" + k]).max()
-        row.append("%s %.1e/%.1e" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)]))
+        row.append("%s %.1e/%.1e [%d>1e-3]" % (k.replace("target_", "").replace("_map", ""), e.max(), np.sort(e)[-max(2, len(e) // 50)], int((e > 1e-3).sum())))
     slots = sum({"p": 12, "f": 6, "a": 9, "w": 9, "s": 12, "S": 12, "q": 16, "e": 13, "E": 14, "F": 15}[c] for c in scheme[:8]) / 8
     print("%-10s %4.1f slots  (max / 98%%)  %s   [%.0f s]" % (scheme, slots, "  ".join(row), time.time() - t0), flush=True)
     if os.environ.get("PROBE_RAYS"):
