@@ -41,6 +41,17 @@ def test_library_exports_and_struct_mirror():
                 assert "iblnerf_cpu" not in open(os.path.join(root, f), errors="ignore").read(), f
 
 
+def test_usable_cpus_honours_affinity_and_quota():
+    n = OC.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            assert n <= int(np.ceil(int(quota) / int(period)))
+    except OSError:
+        pass
+
+
 def test_get_rays_linspace_and_sample_pdf_bitwise():
     s = np.load(GOLDEN + "/small_vectors.npz")
     H, W = s["gr_o"].shape[:2]
