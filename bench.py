@@ -174,6 +174,21 @@ def cpu_baseline(gpu_color_fn, kind, seconds=15.0):
                                                   "(DESIGN.md section 2: the tails are rays the reference itself is sensitive on; prefiltered radiance is ill-conditioned in the reference)")}, psnr
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <argv>` as a child
+    (one rank per GPU, rendezvous on 127.0.0.1 at a port that is free now) and return its exit code.  The child inherits stdout / stderr,
+    so rank 0's single JSON line is this command's single JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))   # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,14 +211,18 @@ def main():
     args = ap.parse_args()
     routing = [n for n in args.query_routing.split(",") if n]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (this process has not touched HIP and never
+        # will; nothing is exec'd).  Rank 0 of the child prints the one JSON line on the stdout it inherits from us.
+        return launch_ranks(args.gpus, sys.argv[1:])
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d rank(s): pass the same number to --nproc-per-node" % (args.gpus, world))
     # --backend gloo is a test hook: it lets the N>1 code path run with several ranks sharing the one GPU of a
     # test box (RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
     backend = args.backend
@@ -344,6 +363,11 @@ def main():
         }
         if grouped:
             line["pack_ms"], line["gather_ms"] = pack_ms, gather_ms
+            line["config"]["ranks_seen"] = dist.get_world_size()
+            try:
+                line["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:       # (a torch build without the query: the line must not depend on it)
+                line["rccl_version"] = None
             line["exchange"] = {"backend": "RCCL" if backend == "nccl" else backend, "bytes_per_rank": int(n_rows * W * 4 * sum(3 if k in R.MAP_KEYS_3 else 1 for k in D.EXPORT_KEYS)),
                                 "note": "rank 0's pack (torch.cat of the export maps) and all-gather of one untimed extra frame; both are inside the timed step"}
         if value_min is not None:
@@ -368,4 +392,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

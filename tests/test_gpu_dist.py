@@ -85,3 +85,27 @@ def test_rccl_one_rank_bench_line():
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"]
     assert d["pack_ms"] > 0 and d["gather_ms"] > 0 and d["exchange"]["backend"] == "RCCL"
     assert d["pack_ms"] + d["gather_ms"] < 0.1 * d["ms_per_step"]          # the exchange is a few per cent of a frame at most
+
+
+def _plain_bench(extra, timeout=900):
+    """`python bench.py ...` exactly as the driver types it: no launcher in front."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the form the driver uses): bench.py starts its two ranks itself as a child
+    `torch.distributed.run` and relays rank 0's one JSON line; `--gpus 1` stays a single process without a group."""
+    n_gpu = torch.cuda.device_count()
+    backend = "gloo" if n_gpu < 2 else "nccl"
+    d = _plain_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--backend", backend])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and "x2" in d["config"]["parallelism"]
+    assert d["pack_ms"] > 0 and d["gather_ms"] > 0 and "rccl_version" in d
+    assert (d["rccl_version"] is not None) == (backend == "nccl")
+    assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    d1 = _plain_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"])
+    assert d1["n_gpus"] == 1 and d1["config"]["parallelism"] == "single GPU" and "pack_ms" not in d1

@@ -746,3 +746,40 @@ def test_training_ray_section_reproduces_the_reference_maps(lut):
     (dx,) = torch.autograd.grad(out["color_map"].sum(), x)
     assert float(dx[:, 5].abs().max()) > 0 and float(dx[:, 2:5].abs().max()) > 0 and float(dx[:, 6].abs().max()) > 0
     assert float(dx[:, 0].abs().max()) == 0.0 and float(dx[:, 7:].abs().max()) == 0.0      # depth is detached in the mip level (:455); radiance does not feed color_map
+
+
+def test_bench_plain_multi_gpu_invocation_spawns_a_child_launcher(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) without a launcher in front — the form the driver types: bench.py starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` as a CHILD (subprocess.run, never exec: on the GPU pool an exec from
+    a process that touched HIP is fatal, and this parent must not touch HIP at all) and returns the child's exit code."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"])
+    had_cuda = "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized()
+    assert bench.main() == 7                                  # the child's return code, relayed
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "torch" in sys.modules:
+        assert sys.modules["torch"].cuda.is_initialized() == had_cuda      # the parent did not initialise the GPU
+    # under a launcher (WORLD_SIZE set) a mismatching --gpus is refused, not re-launched
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["cmd"] is cmd
