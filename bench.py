@@ -189,6 +189,34 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def parity_vs_reference_fixture(frame_maps_fn):
+    """The timed frame against the REFERENCE's own render at the 16 384 pixels it rendered of this very view and checkpoint (fixture
+    tests/golden/fitted_launch16k.npz, made by tests/golden/make_golden.py from /root/reference in the build container: the reference's
+    float32 maps and, per ray, its own sensitivity — float64-vs-float32 difference, one-ulp nudges of the coarse weights, both branches of
+    sample_pdf's threshold; NOT the fourth, 22-bit-parameter column, which describes this library, not the reference).  Per intrinsic channel:
+    per-ray relative error 99 % / 99.9 % / worst, rays above north_star's 1e-3, and `max_allowed_by_reference` = the number of these rays whose
+    own reference sensitivity exceeds 1e-3 / 8 (the rays the reference itself cannot place within 1e-3)."""
+    path = os.path.join(ROOT, "tests", "golden", "fitted_launch16k.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    pix = g["pix"]
+    out = {"n_rays": int(len(pix)), "fixture": "tests/golden/fitted_launch16k.npz",
+           "note": "HIP frame vs the reference's own float32 render (PyTorch, build container) at the pixels of the fixture; per-ray |diff| max over a map's channels "
+                   "over the map's largest value; max_allowed_by_reference counts rays whose own fp64-vs-fp32 / one-ulp-nudge / threshold-branch sensitivity in "
+                   "the reference exceeds 1e-3 / 8"}
+    for k in PARITY_KEYS:
+        ref = g["out__" + k].astype(np.float64).reshape(len(pix), -1)
+        e = np.abs(frame_maps_fn(pix, k).astype(np.float64).reshape(len(pix), -1) - ref).max(-1) / max(float(np.abs(ref).max()), 1e-30)
+        f = g["floorray__" + k].astype(np.float64)
+        for y in ("nudgeray__", "branchray__"):
+            if y + k in g.files:
+                f = np.maximum(f, g[y + k].astype(np.float64))
+        out[k] = {"p99": float(np.percentile(e, 99)), "p999": float(np.percentile(e, 99.9)), "max": float(e.max()), "rays_above_1e-3": int((e > 1e-3).sum()),
+                  "max_allowed_by_reference": int((f > 1e-3 / 8).sum())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +383,9 @@ def main():
                                       if grouped else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         # HBM bytes per camera ray (counter bytes of a frame's MLP launches / rays) over SURVEY 8(d)'s fused-ideal 236 B per ray:
+                         # points in, raw rows out and back in; ~0.2 % of HBM bandwidth at this frame rate, so a ratio to watch, not a time bound
+                         "traffic_ratio": (traffic * n_launch / (H * W // world) / 236.0) if traffic else None,
                          "traffic_note": "a committed figure, not a counter read in this run: HBM bytes per launch (reads x2-corrected + writes) of the rocprofv3 PMC pass %s; points in + raw outputs out, weights stay in L2" % traffic_src,
                          "kernel": MODES[args.mlp_precision][1] + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
@@ -380,6 +411,11 @@ def main():
             def gpu_color(idx, key="color_map"):
                 return maps[key][torch.as_tensor(idx, device=color.device)].cpu().numpy()
 
+            if args.checkpoint == "fitted" and not args.inference_min:
+                line["parity_vs_reference"] = parity_vs_reference_fixture(gpu_color)
+            line["psnr_note"] = ("psnr_vs_ref_db: colour PSNR of the HIP frame against the pinned fp32 C restatement of the reference path (oracle/csrc, "
+                                 "tests/test_oracle_c.py pins it to the reference's fixtures) on the CPU sample's rays - the reference itself cannot travel to this box; "
+                                 "parity_vs_reference holds the comparison with the reference's own render at the pixels it rendered in the build container")
             try:
                 line["cpu_baseline"], line["psnr_vs_ref_db"] = cpu_baseline(gpu_color, args.checkpoint)
             except Exception as e:      # the CPU leg must never cost the GPU line (e.g. no gcc on a host that did not receive oracle/_build/)

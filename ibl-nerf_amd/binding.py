@@ -23,7 +23,7 @@ EXPORTS = [
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
-    "iblnerf_ray_outputs_backward",
+    "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.iblnerf_range_peek.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.iblnerf_range_peek.restype = C.c_int
+    lib.iblnerf_range_flags_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.iblnerf_range_flags_async.restype = C.c_int
     lib.iblnerf_upload_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.iblnerf_upload_weights_device.restype = C.c_int

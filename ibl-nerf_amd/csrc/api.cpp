@@ -912,6 +912,14 @@ int iblnerf_range_peek(iblnerf_ctx* c, int* out_of_range, int* pending) {
     return IBLNERF_OK;
 }
 
+int iblnerf_range_flags_async(iblnerf_ctx* c, void* stream, uint32_t* d_out) {
+    if (!c || !d_out) return IBLNERF_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    if (!c->d_range_flag) HIP_TRY(c, hipMemsetAsync(d_out, 0, sizeof(uint32_t), (hipStream_t)stream));
+    else HIP_TRY(c, hipMemcpyAsync(d_out, c->d_range_flag, sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
 static PassOutputs slice_maps(const iblnerf_maps& m, long r0, int S, int irr_ch = 1) {
     auto off = [&](float* p, long w) { return p ? p + r0 * w : nullptr; };
     PassOutputs o;

@@ -565,7 +565,13 @@ class Renderer:
             self._grad_step_clean()               # (an overflow of an earlier call was settled by _lazy_poll above and reset the count)
             self.last_grad_scale = getattr(self, "_grad_scale", self.GRAD_SCALE_INIT)
             launch(up / inv, self.last_grad_scale)
-            ok = torch.isfinite(grad).all() & torch.isfinite(out).all()
+            # the step is kept only if the kernels' own range flag stayed clear (a saturated dZ behind a ReLU select leaves no inf in the results) and
+            # the results are finite; `last_backward_ok` lets a caller that issues several backward calls per step (training.py: one per network)
+            # gate them all on the conjunction — GradScaler's all-or-nothing step
+            flag = torch.empty((1,), dtype=torch.int32, device=self.device)
+            B.check(self.ctx, self.lib.iblnerf_range_flags_async(self.ctx, self._stream(), flag.data_ptr()))
+            ok = (flag[0] == 0) & torch.isfinite(grad).all() & torch.isfinite(out).all()
+            self.last_backward_ok = ok
             zero = torch.zeros((), dtype=torch.float32, device=self.device)
             grad.copy_(torch.where(ok, grad * inv, zero))
             out[:, 1:] = torch.where(ok, out[:, 1:] * inv, zero)          # (column 0 is sigma)
@@ -1011,6 +1017,19 @@ def renderer_for(kw):
     return r
 
 
+# the boolean switches among the edit / insert kwargs (test.py:115-139; the others are lists, counts and images)
+_SWITCHES = ("edit_intrinsic", "insert_object", "edit_depth", "edit_normal", "edit_albedo", "edit_albedo_by_img", "edit_roughness", "edit_roughness_by_img",
+             "load_edit_intrinsic_mask")
+
+
+def _truthy(v):
+    """A flag as the reference's `if flag:` reads it — bool, int, numpy scalar or one-element tensor."""
+    try:
+        return bool(v)
+    except (ValueError, RuntimeError):      # a multi-element array / tensor is not a switch
+        return True
+
+
 def _ci_net(net):
     return bool(getattr(net, "is_color_independent_to_direction", False))
 
@@ -1050,20 +1069,29 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     approx = bool(kwargs.get("approximate_radiance", False))
     if is_depth_only or not approx or training:
         # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
-        if any(v for k, v in edit.items() if isinstance(v, bool)) or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or r._aux or _ci_net(kwargs["network_fn"]):
+        flags_on = any(_truthy(v) for k, v in edit.items() if k in _SWITCHES or k in FROM_GT_FLAGS)
+        aux_on = any(v is not None for v in r._aux.values())           # (load_aux(name, None) leaves a {name: None} entry: a cleared network is no network)
+        if training and kwargs.get("infer_depth") and any(getattr(p, "requires_grad", False) for p in getattr(kwargs.get("depth_mlp"), "parameters", lambda: [])()):
+            # train.py:351-379 reads ret['inferred_depth_map'] and backpropagates loss_depth_random into depth_mlp; the posdir kernel has no backward
+            raise NotImplementedError("a depth_mlp with trainable parameters in a gradient-carrying render (infer_depth training, train.py:351-379) is not built: "
+                                      "its inferred_depth_map would carry no grad_fn and the network would silently never train; evaluate depth_mlp in torch, "
+                                      "or freeze it (requires_grad_(False)) to render with it")
+        if flags_on or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or aux_on or _ci_net(kwargs["network_fn"]):
             raise NotImplementedError("edit / insert overrides, *_from_gt flags, raw_noise_std, auxiliary and colour-independent networks are not built "
                                       "for is_depth_only, approximate_radiance=False and gradient-carrying renders (no shipped config has them; keep the "
                                       "reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
         if is_depth_only:                                                       # raw2outputs_depth (:197-198)
             ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, **smp)
-            if kwargs.get("infer_depth") and r._depth_mlp is not None:        # :722-726 runs whatever the pass type
-                vd = rd_f / rd_f.norm(dim=-1, keepdim=True)
-                ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
                                       approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), **smp)
         else:
             ret = T.render_rays_direct(r, ro_f, rd_f, *nf, **smp)
+        if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:
+            # :722-726 runs whatever the pass type; a constant here (a trainable depth_mlp was refused above), appended last as in the reference
+            with _torch().no_grad():
+                vd = rd_f / rd_f.norm(dim=-1, keepdim=True)
+                ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
         return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
     ret = r.render_rays(ro_f, rd_f, *nf, kwargs.get("gt_values"), raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **smp, **edit)
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}

@@ -283,7 +283,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
         def backward(ctx, *gouts):
             sv = ctx.saved
             gout = dict(zip(keys, gouts))
-            grads_all = []
+            grads_all, oks = [], []
+            r.last_backward_ok = None
             for which, sfx, z, raw in ((0, "0", sv["zc"], sv["rawc"]), (1, "", sv["zf"], sv["rawf"])):
                 lin, _ = r.composite_direct(raw, z, sv["rd"], want_weights=False)
                 consts = sv.get("consts" + sfx)
@@ -309,11 +310,19 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     if frozen_rough[which]:
                         draw[..., 4] = 0
                 _, grads = r.network_backward(st.points(sv["ro"], sv["rd"], z), sv["rd"], draw, which)
+                if getattr(r, "last_backward_ok", None) is not None:
+                    oks.append(r.last_backward_ok)
                 for k in ALL_PARAMS:
                     gk = grads[k]
                     if frozen[which] and not (k.startswith(UNFROZEN) and not (frozen_rough[which] and k.startswith("roughness_linear."))):
                         gk = None                                        # h is computed under no_grad: nothing reaches the trunk / view layers
                     grads_all.append(gk)
+            if r.range_check == "lazy" and len(oks) == 2:
+                # one decision for the step: an overflow in either network's backward skips BOTH networks' gradients (the range flag is sticky on
+                # the device until the next call settles it, so the second call's view already includes the first's overflow; this also zeroes the
+                # first network's gradients when only the second overflowed)
+                both = oks[0] & oks[1]
+                grads_all = [None if gk is None else torch.where(both, gk, torch.zeros((), dtype=gk.dtype, device=gk.device)) for gk in grads_all]
             out = []
             for i, (p, gk) in enumerate(zip(params, grads_all)):
                 # (views of the call's own gradient blob, a fresh tensor per network_backward: no copy — 92 launches less per step)

@@ -452,6 +452,13 @@ int iblnerf_range_status(iblnerf_ctx* ctx, int* out_of_range);
  * follow a positive answer with iblnerf_range_status. */
 int iblnerf_range_peek(iblnerf_ctx* ctx, int* out_of_range, int* pending);
 
+/* The same flags for a consumer ON THE DEVICE: enqueues, behind everything launched so far on `stream`, a copy of the flag word (bit 0: a forward
+ * activation / input / weight left the f16 range; bit 1: only the gradients of a fused backward did) into d_out (one uint32 in device memory).
+ * No synchronisation, nothing is cleared.  The sync-free training path gates a step's gradients on it (a skipped step, as torch.cuda.amp's
+ * GradScaler does on inf / NaN — but an f16 overflow need not leave an inf in the results: a ReLU select can mask a saturated dZ).
+ * Writes 0 for IBLNERF_MLP_BF16X3. */
+int iblnerf_range_flags_async(iblnerf_ctx* ctx, void* stream, uint32_t* d_out);
+
 /* Host-only: the f16 (hi, lo) form of iblnerf_pack_weights_host's stream (IBLNERF_MLP_F16X3), same sizes. */
 int iblnerf_pack_weights_host_f16x3(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
                                     float* h_tables, size_t table_floats);

@@ -536,3 +536,52 @@ def test_backward_launches_are_bit_identical(R, lut):
             first = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(first, cur))
+
+
+def test_backward_walks_a_long_call_in_pieces(R, lut):
+    """A fused backward longer than BWD_CHUNK_POINTS = 262 144 points (csrc/api.cpp: trunk_backward_impl walks it in equal pieces with per-piece
+    offsets into pts, dirs, the upstream rows and the outputs, one operand stash reused, every piece ADDING its weight gradients into the zeroed
+    blob) — a training step above ~1 365 rays x 192 samples.  2 048 rays x 192 samples = 393 216 points = two pieces of 1 024 rays: the point
+    gradients are those of the two halves called on their own (single-piece calls) bit for bit, the parameter gradients their sum, and the
+    trunk-only entry (no directions, dL/dsigma per point) takes the same walk.  Ragged: 1 500 rays = two pieces of 750 rays, the second
+    piece's first ray in the middle of a 128-point group's worth of rays."""
+    from ibl_nerf_amd import checkpoint as ck
+    sd = ck.blob_to_state_dict(np.load(GOLDEN + "/fitted_ckpt.npz")["fine"])
+    r = R.Renderer(64, 128, max_rays_per_launch=64)
+    r.load_weights(0, sd)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for n in (2048, 1500):
+        S, h = 192, (n // 2)
+        assert n * S > 262144 and h * S <= 262144
+        pts = (torch.rand((n, S, 3), device="cuda", generator=g) * 2.4 - 1.2).contiguous()
+        dirs = (torch.rand((n, 3), device="cuda", generator=g) * 2 - 1).contiguous()
+        draw = (torch.rand((n, S, 18), device="cuda", generator=g) * 2 - 1).contiguous()
+        dp, grads = r.network_backward(pts, dirs, draw, 0, grad_scale=4.0)
+        grads = {k: v.clone() for k, v in grads.items()}
+        dp = dp.clone()
+        dpa, ga = r.network_backward(pts[:h].contiguous(), dirs[:h].contiguous(), draw[:h].contiguous(), 0, grad_scale=4.0)
+        dpa, ga = dpa.clone(), {k: v.clone() for k, v in ga.items()}
+        dpb, gb = r.network_backward(pts[h:].contiguous(), dirs[h:].contiguous(), draw[h:].contiguous(), 0, grad_scale=4.0)
+        assert torch.equal(dp[:h], dpa) and torch.equal(dp[h:], dpb)            # per-point results: the same kernel on the same 128-point groups
+        for k in grads:
+            want = ga[k].double() + gb[k].double()
+            tol = 2e-6 * float(want.abs().max()) + 1e-30                           # two fp32 partial sums added in another order
+            assert float((grads[k].double() - want).abs().max()) <= tol, (n, k)
+        assert float(grads["views_linears.0.weight"].abs().max()) > 0 and float(grads["positions_linears.0.weight"].abs().max()) > 0
+        # the trunk-only entry on the same points (pts_per_ray = 1: pieces cut anywhere)
+        ds = (torch.rand((n * S,), device="cuda", generator=g) * 2 - 1).contiguous()
+        flat = pts.reshape(-1, 3)
+        cut = ((n * S + 1) // 2)
+        s_, dq, gt = r.trunk_backward(flat, ds, 0, grad_scale=4.0)
+        s_, dq, gt = s_.clone(), dq.clone(), {k: v.clone() for k, v in gt.items()}
+        s1, d1, g1 = r.trunk_backward(flat[:cut].contiguous(), ds[:cut].contiguous(), 0, grad_scale=4.0)
+        s1, d1, g1 = s1.clone(), d1.clone(), {k: v.clone() for k, v in g1.items()}
+        s2, d2, g2 = r.trunk_backward(flat[cut:].contiguous(), ds[cut:].contiguous(), 0, grad_scale=4.0)
+        if cut % 128 == 0:                                                        # (the halves then start on the whole call's group boundaries)
+            assert torch.equal(s_[:cut], s1) and torch.equal(dq[:cut], d1) and torch.equal(dq[cut:], d2)
+        else:
+            assert float((dq[:cut] - d1).abs().max()) <= 1e-6 * float(dq.abs().max())
+        for k in gt:
+            want = g1[k].double() + g2[k].double()
+            assert float((gt[k].double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-30, (n, k)
+    r.trim()
