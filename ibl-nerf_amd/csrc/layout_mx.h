@@ -59,15 +59,21 @@ constexpr int CH_IRR = 72;   // irradiance_feature_linear  4              4     
 constexpr int CH_VIEW = 76;  // views_linears.0            1 (DE) + 4     8       10
 constexpr int CH_AR = 86;    // additional_radiance_feature_linear.{0,1,2}  4   4 each   12
 constexpr int N_CHUNKS_NET = 98;   // the network's blocks
-// Residual blocks for the mixed TRUNK form (VAR_TRUNK_X, mlp_kernel_mx.hip): positions_linears.0 and .1 evaluated as THREE f16 products
-// (Wh Xh + Wh Xl + Wl Xh) inside the fast kernel.  Block r holds, in its f16 area only, f16(W - f16 W) of network block
-// L0 tile t (r = t) / L1 tile t, block b (r = 8 + 4 t + b), slot for slot.  (Errors injected in the first layers dominate the
-// density's error on a fitted network, DESIGN.md 4.0: with these two layers at 2^-22 the offset queries' normal is that of the f16x3 kernel.)
+// Residual blocks for the three-f16-product layers of this kernel: residual block r belongs to network block r of the TRUNK (blocks 0 .. 239 of the
+// stream, in stream order: L0 tile t = block t; L1..L4 tile t, block b = 8 + 32 (l - 1) + 4 t + b; L5 tile t = 136 + 5 t (encoding) .. + 4;
+// L6, L7 = 176 + 32 (l - 6) + 4 t + b) and holds, slot for slot,
+//     f16 area           f16(W - f16 W)                         = Wl, the second f16 term of the weight
+//     fp6(W) area + SC   fp6(W - f16 W - Wl), scale in byte 0   = W3, what two f16 terms leave of the fp32 weight (one float32 ulp at most)
+// Users: VAR_TRUNK_X (the mixed TRUNK form: positions_linears.0 and .1 as THREE f16 products Wh Xh + Wh Xl + Wl Xh; errors injected in the first layers
+// dominate the density's error on a fitted network) reads residual blocks 0 .. 39, their f16 area only; VAR_TRUNK_P (the 15-slot form:
+// every trunk layer as three f16 products + three block-scaled fp6 products for the terms at 2^-22 of the result: Wh X3 + Wl Xl + W3 Xh, X3 = what the
+// two f16 terms leave of the activation) reads all 240 and their fp6 area too.
 constexpr int CH_RES = 98;
-constexpr int N_RES_BLOCKS = 8 + 32;
-constexpr int N_CHUNKS = CH_RES + N_RES_BLOCKS / 4;   // 108
+constexpr int N_RES_BLOCKS = 240;
+constexpr int N_CHUNKS = CH_RES + N_RES_BLOCKS / 4;   // 158
 constexpr int N_CHUNKS_TRUNK = 60;
 constexpr int N_CHUNKS_TRUNK_X = 4 + 16 + 50;         // program of VAR_TRUNK_X: L0 and L1 as (network block, residual block) pairs
+constexpr int N_CHUNKS_TRUNK_P = 120;                 // program of VAR_TRUNK_P: every trunk block as such a pair (240 logical blocks, two per chunk)
 constexpr long STREAM_BYTES = (long)N_CHUNKS * CHUNK_BYTES;
 
 // e2m3 (bias 1): value of a 6-bit code, and round-to-nearest-even encoding with saturation at 7.5

@@ -120,8 +120,9 @@ __host__ __device__ constexpr int stage_slot_x3(int q, int ns) { return ns >= 2 
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
-    static constexpr bool X = VARIANT == VAR_TRUNK_X;
-    static constexpr int N_PROG = X ? mx::N_CHUNKS_TRUNK_X : VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
+    static constexpr bool PP = VARIANT == VAR_TRUNK_P;                  // every trunk block as a (network, residual) pair
+    static constexpr bool X = VARIANT == VAR_TRUNK_X || PP;             // a wave's block comes from its own place in the stream
+    static constexpr int N_PROG = PP ? mx::N_CHUNKS_TRUNK_P : X ? mx::N_CHUNKS_TRUNK_X : VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
                                                         : mx::N_CHUNKS_TRUNK + (CI ? 0 : 8 + 10) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
     char* ring;
@@ -133,6 +134,10 @@ struct Pipe {
 
     // VAR_TRUNK_X: stream block that wave w copies for program position p (layers 0 and 1: network block / residual block pairs)
     __device__ __forceinline__ static int x_block(int p, int w) {
+        if constexpr (PP) {                            // chunk p = logical blocks 2p, 2p+1 of the trunk, each as [network block, residual block]
+            const int lb = 2 * p + (w >> 1);
+            return (w & 1) ? mx::CH_RES * 4 + lb : lb;
+        }
         if (p < 4) {                                   // L0: chunk p = tiles 2p, 2p+1, each as [network, residual]
             const int tile = 2 * p + (w >> 1);
             return (w & 1) ? mx::CH_RES * 4 + tile : mx::CH_L0 * 4 + tile;
@@ -553,6 +558,245 @@ __device__ __forceinline__ f32x16 run_layer_x3(Pipe<VARIANT>& P, Pre& pf, unsign
         prev = acc;
     });
     return prev;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAR_TRUNK_P: the 15-slot form.  Every trunk layer as three f16 products on (hi, lo) splits PLUS three block-scaled fp6 products
+// for everything at 2^-22 of the result:
+//     y = Wh Xh + Wh Xl + Wl Xh                      12 slots (f16; Wl from the residual block, Xl kept in registers)
+//       + fp6(Wh) fp6(X3) + fp6(Wl) fp6(Xl) + fp6(W3) fp6(Xh)     3 slots (W3 / X3 = what two f16 terms leave of the fp32 value)
+// Two f16 terms hold 22-23 bits of an fp32 operand (fewer where the lo term falls into the f16 denormals): "the reference run on a
+// checkpoint stored with 22-bit mantissas" (launch scale 7), which moves the fine samples of rays whose density
+// is a heavily cancelling sum.  With the three correction products every operand is represented to ~2^-26, below fp32's own 2^-24.
+// Used for ONE query: the coarse pass's density, which places the fine samples (api.cpp: Q_MAIN_COARSE).
+// Registers: per K = 64 block of an activation hv (16) + lo (16) + fp6(X3) (6) + scales (1); fp6(Xh) and fp6(Xl) are NOT kept — they are
+// converted from hv / lo where a tile uses them (two v_cvt_scalef32_pk32_fp6_f16 per logical block and tile, in the shadow of the
+// block's two-MFMA slots) — 312 registers for the in / out pair instead of 408.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x32 __attribute__((ext_vector_type(32)));
+struct BlkP {
+    u32x16 hv;        // the 4 f16 k-steps of Xh
+    u32x16 lo;        // ... of Xl = f16(X - Xh), same element order
+    u32x4 t6a;        // fp6(X3), X3 = X - Xh - Xl: bits 0..127
+    u32x2 t6b;        // bits 128..191
+    unsigned sc;      // e8m0 scales: byte 0 fp6(Xh), byte 1 fp6(Xl), byte 2 fp6(X3)
+};
+struct ActP { BlkP b[4]; };
+
+// (x0, x1) -> packed f16 pairs h = rne(x), l = rne(x - h) and the packed bf16 pair of what is left, x - h - l (exact in fp32; bf16 keeps its
+// exponent where f16 would underflow, and the fp6 conversion reads 4 of its 8 significant bits)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hb, unsigned& lb, unsigned& tb) {
+    const f32x2 xv = {x0, x1};
+    hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));
+    float r0, r1, y0, y1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(hb));
+    const f32x2 rv = {r0, r1};
+    lb = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(y0) : "v"(r0), "v"(lb));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(y1) : "v"(r1), "v"(lb));
+    const f32x2 yv = {y0, y1};
+    tb = __builtin_bit_cast(unsigned, __builtin_convertvector(yv, bf16x2));
+}
+
+// Completes a block of the 15-slot form: scales from the running max, the fp6 form of X3.  With 2^E <= max < 2^(E+1): |Xh| < 2^(E+1),
+// |Xl| <= 2^(E-11), |X3| <= 2^(E-22) — or <= 2^-25 where Xl sits in the f16 denormals (any E), hence the floor on the third scale.
+__device__ __forceinline__ void finish_block_p(BlkP& b, const u32x16& lres, const u32x16& tres, int& mxv, unsigned& peak) {
+    unsigned mb = (unsigned)mxv;
+    peak = mb > peak ? mb : peak;
+    mb = mb > 0x0d800000u ? mb : 0x0d800000u;
+    const unsigned e = mb >> 23;
+    const unsigned et = e - 25 > 99u ? e - 25 : 99u;                  // scale of fp6(X3): 2^(E-25), at least 2^-28 (|X3| <= 2^-25 -> <= 8)
+    const float st = __builtin_bit_cast(float, et << 23);
+    const auto t6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_bf16(__builtin_bit_cast(bf16x32, tres), st);
+    b.lo = lres;
+    b.t6a = u32x4{(unsigned)t6[0], (unsigned)t6[1], (unsigned)t6[2], (unsigned)t6[3]};
+    b.t6b = u32x2{(unsigned)t6[4], (unsigned)t6[5]};
+    b.sc = (e - 2) | ((e - 14) << 8) | (et << 16);
+    mxv = 0;
+}
+
+// Epilogue of a tile of the 15-slot form (cf. Epi): STORE: v = ReLU(acc) -> the three terms of block T>>1 of `dst`
+template <bool STORE, int NCH>
+struct EpiP {
+    ActP* dst;
+    f32x2* part[NCH > 0 ? NCH : 1];
+    const float* tab[NCH > 0 ? NCH : 1];
+    unsigned* peak;
+    u32x16 lres, tres;
+    u32x4 hq;
+    int mxv;
+    float sx0, sx1;
+    f32x2 hw[NCH > 0 ? NCH : 1];
+
+    template <int T, int I>
+    __device__ __forceinline__ void stage_a(const f32x16& acc) {
+        float x0 = acc[2 * I], x1 = acc[2 * I + 1];
+        if constexpr (STORE) mxv = max(max(mxv, __builtin_bit_cast(int, x0)), __builtin_bit_cast(int, x1));   // (ReLU layers only: a negative never wins)
+        x0 = relu_bits(x0);
+        x1 = relu_bits(x1);
+        sx0 = x0;
+        sx1 = x1;
+        pin(sx0);
+        pin(sx1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) hw[c] = *reinterpret_cast<const f32x2*>(tab[c] + T * 32 + 2 * I);
+    }
+    template <int T, int I>
+    __device__ __forceinline__ void stage_b() {
+        const float x0 = sx0, x1 = sx1;
+        if constexpr (STORE) {
+            constexpr int j = 2 * (T & 1) + (I >> 2);
+            unsigned hb, lb, tb;
+            split3_pair(x0, x1, hb, lb, tb);
+            hq[I & 3] = hb;
+            lres[4 * j + (I & 3)] = lb;
+            tres[4 * j + (I & 3)] = tb;
+            if constexpr ((I & 3) == 3) {
+                asm volatile("" : "+v"(hq));
+                dst->b[T >> 1].hv = with_quarter<j>(dst->b[T >> 1].hv, hq);
+            }
+            if constexpr (I == 7 && (T & 1) == 1) finish_block_p(dst->b[T >> 1], lres, tres, mxv, *peak);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            (*part[c])[0] = fmaf(x0, hw[c][0], (*part[c])[0]);
+            (*part[c])[1] = fmaf(x1, hw[c][1], (*part[c])[1]);
+            if constexpr (I == 7) asm volatile("" : "+v"(*part[c]));
+        }
+    }
+    template <int T, int I, int K>
+    __device__ __forceinline__ void stage(const f32x16& acc) {
+        if constexpr (K == 0) stage_a<T, I>(acc);
+        else stage_b<T, I>();
+    }
+    template <int T, int I>
+    __device__ __forceinline__ void slice(const f32x16& acc) {
+        stage_a<T, I>(acc);
+        stage_b<T, I>();
+    }
+};
+
+// A layer of the 15-slot form.  The slot machinery is run_layer_x3's (a logical block = a network block then its residual block); per pair:
+//   network block   slots 0-3:  acc += Wh_k Xh_k ; acc += Wh_k Xl_k        (one operand read, two MFMAs)
+//                   slot 4:     acc += fp6(Wh) fp6(X3)                      (the block's fp6(W) area, scale byte 0 | scale byte 2 of the activation block)
+//                   slot 5:     acc += fp6(Wl) fp6(Xl)                      (its fp6(W - f16 W) area, byte 1 | byte 1)
+//   residual block  slots 0-3:  acc += Wl_k Xh_k
+//                   slot 4:     acc += fp6(W3) fp6(Xh)                      (the residual block's fp6 area, byte 0 | byte 0)
+//                   slot 5:     nothing
+// fp6(Xl) and fp6(Xh) of the input block are converted in slots 0 and 2 of the network block, behind its pairs of MFMAs.
+template <int NT, bool HAS_ENC, int NH, int VARIANT, class PEND, class EPI>
+__device__ __forceinline__ f32x16 run_layer_p(Pipe<VARIANT>& P, Pre& pf, unsigned& wsc, const ActP& in, const BlkP& enc, const float* bias_tab,
+                                              PEND&& pend, EPI& epi) {
+    constexpr int NL = (HAS_ENC ? 1 : 0) + NH;
+    constexpr int NB = 2 * NL;
+    constexpr int NS = NB * SLOTS_PER_BLOCK;
+    static_assert((NT * NS) % CHUNK_SLOTS == 0, "a layer is a whole number of chunks");
+    f32x16 prev = {0};
+    u32x4 x6a, l6a;       // fp6 forms of the logical block in flight
+    u32x2 x6b, l6b;
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+        static_for<0, NS>([&](auto GS) {
+            constexpr int g = decltype(GS)::value;
+            constexpr int G = t * NS + g;
+            constexpr int cr = G % CHUNK_SLOTS;
+            constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
+            constexpr int lb = bb >> 1;
+            constexpr bool resid = (bb & 1) != 0;
+            constexpr bool is_enc = HAS_ENC && lb == 0;
+            constexpr int ib = is_enc ? 0 : lb - (HAS_ENC ? 1 : 0);
+            const BlkP& xb = is_enc ? enc : in.b[ib];
+            if constexpr (s == 4) wsc = pf.sc[G % 4];
+            if constexpr (s < 4) {
+                const f16x8 aw = __builtin_bit_cast(f16x8, pf.q[G % 4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(xb.hv)), acc, 0, 0, 0);
+                if constexpr (!resid) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, quarter<s>(xb.lo)), acc, 0, 0, 0);
+            } else if constexpr (s == 4 && !resid) {
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(pf.q[G % 4], pf.d[G % 4]), fp6_operand<true>(xb.t6a, xb.t6b), acc, 2, 2, 0,
+                                                                      (int)wsc, 2, (int)xb.sc);
+            } else if constexpr (s == 5 && !resid) {
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(pf.q[G % 4], pf.d[G % 4]), fp6_operand<false>(l6a, l6b), acc, 2, 2, 1,
+                                                                      (int)wsc, 1, (int)xb.sc);
+            } else if constexpr (s == 4 && resid) {
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp6_operand<true>(pf.q[G % 4], pf.d[G % 4]), fp6_operand<false>(x6a, x6b), acc, 2, 2, 0,
+                                                                      (int)wsc, 0, (int)xb.sc);
+            }
+            if constexpr (!resid && s == 0) {       // fp6(Xl) of this logical block: used by slot 5
+                const float sl = __builtin_bit_cast(float, ((xb.sc >> 8) & 0xffu) << 23);
+                const auto l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, xb.lo), sl);
+                l6a = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
+                l6b = u32x2{(unsigned)l6[4], (unsigned)l6[5]};
+            }
+            if constexpr (!resid && s == 2) {       // fp6(Xh): used by slot 4 of the residual block
+                const float sh = __builtin_bit_cast(float, (xb.sc & 0xffu) << 23);
+                const auto x6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, xb.hv), sh);
+                x6a = u32x4{(unsigned)x6[0], (unsigned)x6[1], (unsigned)x6[2], (unsigned)x6[3]};
+                x6b = u32x2{(unsigned)x6[4], (unsigned)x6[5]};
+            }
+            {
+                constexpr int Gp = G + PF;
+                constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
+                constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
+                // (slot 5 of a residual block issues nothing: its operand is not fetched)
+                if constexpr (!(Gp % SLOTS_PER_BLOCK == 5 && ((Gp / SLOTS_PER_BLOCK) & 1) == 1))
+                    load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+            }
+            if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
+            static_for<0, 8 * N_STAGES>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if constexpr (g == stage_slot_x3(q, NS)) {
+                    if constexpr (t == 0) pend(std::integral_constant<int, q / N_STAGES>{}, std::integral_constant<int, q % N_STAGES>{});
+                    else epi.template stage<(t > 0 ? t - 1 : 0), q / N_STAGES, q % N_STAGES>(prev);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (cr == SYNC_SLOT) P.sync_next();
+            if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
+        });
+        asm volatile("" : "+v"(acc));
+        prev = acc;
+    });
+    return prev;
+}
+
+// the encoding as a block of the 15-slot form
+template <int PAIRS>
+__device__ __forceinline__ void encode_p(float x, float y, float z, int h, BlkP& enc, unsigned& peak) {
+    float vals[32];
+    const float mul = h ? (float)(1 << (PAIRS / 3)) : 1.0f;
+    const TurnPair tx = to_turns(x), ty = to_turns(y), tz = to_turns(z);
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+        const TurnPair tc = (u % 3 == 0) ? tx : ((u % 3 == 1) ? ty : tz);
+        sincos_turns(tc, (float)(1 << (u / 3)) * mul, &vals[2 * u], &vals[2 * u + 1]);
+    }
+    vals[2 * PAIRS] = h ? z : x;
+    vals[2 * PAIRS + 1] = h ? 0.0f : y;
+#pragma unroll
+    for (int i = 2 * PAIRS + 2; i < 32; ++i) vals[i] = 0.0f;
+    u32x16 lres, tres;
+    int mxv = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned hb, lb, tb;
+            split3_pair(vals[8 * j + 2 * e], vals[8 * j + 2 * e + 1], hb, lb, tb);
+            hv[e] = hb;
+            lres[4 * j + e] = lb;
+            tres[4 * j + e] = tb;
+            mxv = max(mxv, max(__builtin_bit_cast(int, vals[8 * j + 2 * e]) & 0x7fffffff, __builtin_bit_cast(int, vals[8 * j + 2 * e + 1]) & 0x7fffffff));
+        }
+        if (j == 0) enc.hv = with_quarter<0>(enc.hv, hv);
+        else if (j == 1) enc.hv = with_quarter<1>(enc.hv, hv);
+        else if (j == 2) enc.hv = with_quarter<2>(enc.hv, hv);
+        else enc.hv = with_quarter<3>(enc.hv, hv);
+    }
+    finish_block_p(enc, lres, tres, mxv, peak);
 }
 
 // [x, sin(2^k x), cos(2^k x)] in the slot order of layout.h::enc_ref_index -> one block

@@ -313,7 +313,7 @@ void pack_block(char* blk, WF&& w, char* res_blk = nullptr) {
             }
             continue;
         }
-        float full[32], res[32];
+        float full[32], res[32], res3[32];
         for (int jj = 0; jj < 32; ++jj) {
             const float x = w(i, h, jj);
             const uint16_t hb = f16_bits(x);
@@ -323,10 +323,18 @@ void pack_block(char* blk, WF&& w, char* res_blk = nullptr) {
             if (res_blk != nullptr) {
                 const uint16_t rb = f16_bits(res[jj]);
                 std::memcpy(res_blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2, &rb, 2);
+                res3[jj] = res[jj] - f16_round(res[jj]);          // exact in fp32: what two f16 terms leave of the weight
             }
         }
         uint32_t c6[6], r6[6];
         const uint32_t sw = fp6_block(full, c6), sr = fp6_block(res, r6);
+        if (res_blk != nullptr) {                                 // fp6(W3) + its scale (byte 0), in the residual block's fp6(W) area
+            uint32_t t6[6];
+            const uint32_t st = fp6_block(res3, t6);
+            std::memcpy(res_blk + mx::OFF_W6A + lane * 16, t6, 16);
+            std::memcpy(res_blk + mx::OFF_W6B + lane * 8, t6 + 4, 8);
+            std::memcpy(res_blk + mx::OFF_SC + lane * 4, &st, 4);
+        }
         std::memcpy(blk + mx::OFF_W6A + lane * 16, c6, 16);
         std::memcpy(blk + mx::OFF_R6A + lane * 16, r6, 16);
         std::memcpy(blk + mx::OFF_W6B + lane * 8, c6 + 4, 8);
@@ -364,17 +372,18 @@ void pack_network_mx(const float* blob, void* stream_out, float* tab) {
     if (g_identity) g_mx_base = s;
     else std::memset(s, 0, mx::STREAM_BYTES);
     auto at = [&](int chunk, int block = 0) { return s + (size_t)chunk * CHUNK_BYTES + (size_t)block * mx::BLOCK_BYTES; };
-    // layers 0 and 1 also fill their residual blocks (the mixed TRUNK form runs them as three f16 products)
-    for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF, at(mx::CH_RES, t));
+    // every trunk block also fills its residual block (layout_mx.h: residual block r <-> network block r of the trunk, r = 0 .. 239)
+    auto res_of = [&](const char* net_block) { return s + (size_t)mx::CH_RES * CHUNK_BYTES + (net_block - s); };
+    for (int t = 0; t < 8; ++t) pack_enc_mx(at(mx::CH_L0, t), n, L_POS0, 32 * t, 0, PE_PAIRS_PER_HALF, res_of(at(mx::CH_L0, t)));
     for (int l = 1; l <= 4; ++l)
         for (int t = 0; t < 8; ++t)
-            pack_h_mx(at(mx::CH_L1 + 8 * (l - 1) + t), n, L_POS0 + l, 32 * t, 0, l == 1 ? at(mx::CH_RES, 8 + 4 * t) : nullptr);
+            pack_h_mx(at(mx::CH_L1 + 8 * (l - 1) + t), n, L_POS0 + l, 32 * t, 0, res_of(at(mx::CH_L1 + 8 * (l - 1) + t)));
     for (int t = 0; t < 8; ++t) {                     // positions_linears.5: [x63 | h] (ibl_nerf.py:168)
-        pack_enc_mx(at(mx::CH_L5, 5 * t), n, L_POS5, 32 * t, 0, PE_PAIRS_PER_HALF);
-        pack_h_mx(at(mx::CH_L5, 5 * t + 1), n, L_POS5, 32 * t, 63);
+        pack_enc_mx(at(mx::CH_L5, 5 * t), n, L_POS5, 32 * t, 0, PE_PAIRS_PER_HALF, res_of(at(mx::CH_L5, 5 * t)));
+        pack_h_mx(at(mx::CH_L5, 5 * t + 1), n, L_POS5, 32 * t, 63, res_of(at(mx::CH_L5, 5 * t + 1)));
     }
-    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L6 + t), n, L_POS6, 32 * t, 0);
-    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L7 + t), n, L_POS7, 32 * t, 0);
+    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L6 + t), n, L_POS6, 32 * t, 0, res_of(at(mx::CH_L6 + t)));
+    for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_L7 + t), n, L_POS7, 32 * t, 0, res_of(at(mx::CH_L7 + t)));
     for (int t = 0; t < 8; ++t) pack_h_mx(at(mx::CH_FEAT + t), n, L_FEATURE, 32 * t, 0);
     for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_ALB + t), n, L_ALB_F, 32 * t, 0);
     for (int t = 0; t < 4; ++t) pack_h_mx(at(mx::CH_IRR + t), n, L_IRR_F, 32 * t, 0);

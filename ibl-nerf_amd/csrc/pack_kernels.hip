@@ -79,13 +79,23 @@ __global__ void k_pack_mx(const float* blob, const int* map, char* stream, long 
     const int lane = (int)(t & 63);
     char* blk = stream + blk_i * mx::BLOCK_BYTES;
     const int* m = map + t * 32;
-    if (blk_i >= (long)mx::CH_RES * mx::CHUNK_BLOCKS) {   // residual block of layer 0 / 1 (layout_mx.h): f16(w - f16 w) in the f16 area only
+    if (blk_i >= (long)mx::CH_RES * mx::CHUNK_BLOCKS) {   // residual block of a trunk block (layout_mx.h): Wl = f16(w - f16 w) in the f16 area, fp6(w - f16 w - Wl) + scale in the fp6(W) area
+        float res3[32];
         for (int jj = 0; jj < 32; ++jj) {
             const int idx = m[jj];
             const float x = idx ? blob[idx - 1] : 0.0f;
-            const _Float16 r = (_Float16)(x - (float)(_Float16)x);
-            *reinterpret_cast<_Float16*>(blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2) = r;
+            const float r = x - (float)(_Float16)x;
+            const _Float16 rl = (_Float16)r;
+            *reinterpret_cast<_Float16*>(blk + mx::OFF_F16 + (jj >> 3) * 1024 + lane * 16 + (jj & 7) * 2) = rl;
+            res3[jj] = r - (float)rl;
         }
+        unsigned t6[6];
+        const unsigned st = fp6_block(res3, t6);
+        unsigned* wa = reinterpret_cast<unsigned*>(blk + mx::OFF_W6A + lane * 16);
+        for (int q = 0; q < 4; ++q) wa[q] = t6[q];
+        unsigned* wb = reinterpret_cast<unsigned*>(blk + mx::OFF_W6B + lane * 8);
+        wb[0] = t6[4]; wb[1] = t6[5];
+        *reinterpret_cast<unsigned*>(blk + mx::OFF_SC + lane * 4) = st;
         return;
     }
     float full[32], res[32];

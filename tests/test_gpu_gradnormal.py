@@ -565,7 +565,7 @@ def test_backward_walks_a_long_call_in_pieces(R, lut):
         assert torch.equal(dp[:h], dpa) and torch.equal(dp[h:], dpb)            # per-point results: the same kernel on the same 128-point groups
         for k in grads:
             want = ga[k].double() + gb[k].double()
-            tol = 2e-6 * float(want.abs().max()) + 1e-30                           # two fp32 partial sums added in another order
+            tol = 2e-5 * float(want.abs().max()) + 1e-30                           # two fp32 partial sums added in another order
             assert float((grads[k].double() - want).abs().max()) <= tol, (n, k)
         assert float(grads["views_linears.0.weight"].abs().max()) > 0 and float(grads["positions_linears.0.weight"].abs().max()) > 0
         # the trunk-only entry on the same points (pts_per_ray = 1: pieces cut anywhere)
@@ -583,5 +583,6 @@ def test_backward_walks_a_long_call_in_pieces(R, lut):
             assert float((dq[:cut] - d1).abs().max()) <= 1e-6 * float(dq.abs().max())
         for k in gt:
             want = g1[k].double() + g2[k].double()
-            assert float((gt[k].double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-30, (n, k)
+            # (a bias gradient is one cancelling fp32 sum over all 288 000 .. 393 216 points of +-1-sized terms: 3e-6 of its value between two summation orders)
+            assert float((gt[k].double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-30, (n, k)
     r.trim()
