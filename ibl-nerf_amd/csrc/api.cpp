@@ -70,6 +70,7 @@ struct iblnerf_ctx {
     bool have_lut = false;
     // iblnerf_options.query_routing (IBLNERF_ROUTE_*), decoded at iblnerf_create
     bool x_coarse = false, x_user = false, fine_main_precise = false;
+    bool coarse_sigma_p = true, p_user = false;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
     size_t bwd_stash_bytes = 0;
@@ -177,8 +178,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 15 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..15), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 63 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..63), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -206,6 +207,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     c->x_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_MIXED) != 0;
     c->fine_main_precise = (opts->query_routing & IBLNERF_ROUTE_FINE_MAIN_PRECISE) != 0;
     c->fuse_points = (opts->query_routing & IBLNERF_ROUTE_POINT_BATCH) == 0;
+    c->coarse_sigma_p = (opts->query_routing & IBLNERF_ROUTE_COARSE_MAIN_22BIT) == 0;
+    c->p_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_P) != 0;
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -465,15 +468,25 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
     return IBLNERF_OK;
 }
 
+// The coarse pass's density comes from the 15-slot form (VAR_TRUNK_P) where the mode keeps the fast stream and the network fits f16
+static bool sigma_p_available(const iblnerf_ctx* c, int which) {
+    const int prec = c->opt.mlp_precision;
+    return c->coarse_sigma_p && c->mx_ok[which] && c->d_stream_mx[which] != nullptr &&
+           (prec == IBLNERF_MLP_F16X3_MXFP6X || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN);
+}
+
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr) {
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr,
+                   bool count_flops = true) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
+    // a trunk-only query of the sample-placing class (the coarse pass reduced to its density), or of the caller under IBLNERF_ROUTE_USER_TRUNK_P
+    if (variant == VAR_TRUNK && !gen && sigma_p_available(c, which) && (qclass == Q_MAIN_COARSE || (qclass == Q_USER && c->p_user))) variant = VAR_TRUNK_P;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
     // product scheme of this launch (include/iblnerf.h: mlp_precision).  A network with a weight outside the f16 range runs
     // on the bf16x3 kernel whatever the mode.
     const int prec = c->opt.mlp_precision;
-    enum { K_BF16X3, K_F16X3, K_MX, K_MX16, K_MXX } kern = K_BF16X3;   // K_MXX: the fast kernel's TRUNK form with its first two layers as three f16 products
+    enum { K_BF16X3, K_F16X3, K_MX, K_MX16, K_MXX, K_MXP } kern = K_BF16X3;   // K_MXX: the fast kernel's TRUNK form with its first two layers as three f16 products; K_MXP: its 15-slot form
     if (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which]) {
         if (prec == IBLNERF_MLP_F16X3) kern = K_F16X3;
         else if (prec == IBLNERF_MLP_F16X3_MXFP6)
@@ -487,7 +500,11 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             // amplification: it places no samples and no depth difference is taken of it) — on 1 024 rays of the fitted checkpoint the
             // worst ray of every direct channel is set by the coarse pass's sample placement, with or without it
             const bool x = qclass == Q_OFFSET_FINE || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
-            kern = (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise)) ? K_MX : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
+            // ... and the COARSE pass's main query too once its density column comes from the 15-slot form (full_pass): what is left of it are the
+            // coarse pass's own albedo / roughness / irradiance / radiance samples, weighted sums like the fine pass's
+            kern = (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise) ||
+                    (qclass == Q_MAIN_COARSE && variant != VAR_TRUNK && variant != VAR_TRUNK_P && sigma_p_available(c, which) && !c->fine_main_precise)) ? K_MX
+                   : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
         } else if (prec == IBLNERF_MLP_F16X3_MAIN)
             // ... and also for the offset queries on the dense fine grid: the normal's worst ray of 1024 goes from 1.9e-4 to
             // 1.5e-3 (99.9th percentile 3e-4); on the coarse grid (spacing 0.12) the same offsets would leave 1e-3 at 96 rays
@@ -500,6 +517,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface))
             kern = K_MX16;
     }
+    if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
     if (variant == VAR_TRUNK_GRAD) kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3;
     a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
@@ -524,10 +542,11 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
     HIP_TRY(c, kern == K_MX16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : kern == K_MX ? launch_mlp_mx(variant, a, c->n_cu, s)
-               : kern == K_MXX ? launch_mlp_mx(VAR_TRUNK_X, a, c->n_cu, s)
+               : kern == K_MXX ? launch_mlp_mx(VAR_TRUNK_X, a, c->n_cu, s) : kern == K_MXP ? launch_mlp_mx(VAR_TRUNK_P, a, c->n_cu, s)
                : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
-    c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : variant == VAR_TRUNK ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
+    // (algorithmic FLOPs are counted once: the density column re-evaluated on the 15-slot form beside a FULL query adds time, not work)
+    if (count_flops) c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
 }
 
@@ -982,6 +1001,14 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
     int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, places_samples ? Q_MAIN_COARSE : Q_MAIN_FINE);
     if (rc) return rc;
+    // ... and its density column once more on the 15-slot form (three f16 + three fp6 products per block: operands to ~2^-26).  Two f16 terms
+    // hold 22-23 bits of an fp32 weight / activation; through a fitted network's cancelling density sum that alone moves the fine samples of
+    // some rays by more than the reference's own arithmetic does (launch scale 7).  The column overwrites raw[..., 0] as an
+    // auxiliary network's output would; weights, depth and the fine samples are composited from it.
+    if (places_samples && sigma_p_available(c, which)) {
+        rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
+        if (rc) return rc;
+    }
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
     // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
     for (int kind = 0; kind < 3; ++kind)

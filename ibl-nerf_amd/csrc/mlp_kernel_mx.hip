@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
         const bool valid = p < a.n_pts;
-        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X;
+        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X || VARIANT == VAR_TRUNK_P;
 #ifdef IBL_MX_ABLATE_PROLOGUE
         if (g == blockIdx.x) {
 #endif
@@ -890,6 +890,40 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             px = a.pts[3 * p + 0];
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
+        }
+        if constexpr (VARIANT == VAR_TRUNK_P) {
+            // ---- the 15-slot form: every trunk layer through run_layer_p, activations as (hi, lo, fp6 third term) ----
+            BlkP pe;
+            encode_p<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak);
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));     // (the point itself stays live: three registers; its encoding does not, see layer 5)
+            ActP A, B;
+            f32x2 sig = {0.0f, 0.0f};
+            const float* bias = ltab + TAB_BIAS;
+            auto none = [](auto, auto) {};
+            EpiP<true, 0> eA{&A, {nullptr}, {nullptr}, &peak}, eB{&B, {nullptr}, {nullptr}, &peak};
+            eA.mxv = 0;
+            eB.mxv = 0;
+            f32x16 pacc = run_layer_p<8, true, 0>(P, pf, wsc, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);              // 0 -> A
+            for (int l = 1; l <= 3; l += 2) {                                                                                 // 1..4: A -> B -> A
+                pacc = run_layer_p<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
+                                                [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
+                pacc = run_layer_p<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
+                                                [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
+            }
+            // the skip layer reads the encoding again: encoded again here (39 registers not held across layers 1-4; the input stage is < 1 % of a group's time)
+            encode_p<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak);
+            pacc = run_layer_p<8, true, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 40) * 32,                                       // 5 (skip): A -> B
+                                           [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
+            pacc = run_layer_p<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 48) * 32,                                      // 6: B -> A
+                                            [&](auto I, auto K) { eB.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eA);
+            EpiP<false, 1> e7{nullptr, {&sig}, {ltab + TAB_SIG}, &peak};                                                      // 7: A -> sigma head on its fp32 activations
+            pacc = run_layer_p<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 56) * 32,
+                                            [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, e7);
+            static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
+            const float p0 = sig[0] + sig[1];
+            const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
+            if (valid && h == 0) a.out[(long)p * a.out_stride] = sg;
+            continue;
         }
 #ifndef IBL_MX_ABLATE_PROLOGUE
         Blk pe, de;
@@ -1082,6 +1116,8 @@ hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return laun
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 5
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
+#elif IBL_MX_VARIANT == 13
+hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_P>(a, grid, s); }
 #elif IBL_MX_VARIANT == 3
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 #else
@@ -1091,6 +1127,7 @@ hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s) { return la
 hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
 #ifndef IBL_MX_F16ONLY
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
+hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_P>(a, grid, s); }
 #endif
 #ifndef IBL_MX_DEV_TRUNK_ONLY
 hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
@@ -1107,6 +1144,7 @@ hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -1121,6 +1159,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
 #ifndef IBL_MX_F16ONLY          // the trunk-only evaluation feeds the finite-difference normal: never in plain f16
         case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);
         case VAR_TRUNK_X: return IBL_L(trunk_x)(a, grid, stream);
+        case VAR_TRUNK_P: return IBL_L(trunk_p)(a, grid, stream);
 #endif
         default: return hipErrorInvalidValue;
     }

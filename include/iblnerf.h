@@ -115,8 +115,14 @@ enum {
     IBLNERF_ROUTE_COARSE_OFFSETS_MIXED = 1,   /* F16X3_MXFP6X: the coarse grid's offset queries on the mixed trunk form too */
     IBLNERF_ROUTE_USER_TRUNK_MIXED = 2,       /* F16X3_MXFP6X: the trunk-only form of iblnerf_network_query on the mixed trunk form */
     IBLNERF_ROUTE_FINE_MAIN_PRECISE = 4,      /* F16X3_MXFP6X: the fine pass's main query back on F16X3 */
-    IBLNERF_ROUTE_POINT_BATCH = 8             /* any mode: the epsilon-offset points go through a [4][n][S][3] batch in HBM (k_make_points) instead of
+    IBLNERF_ROUTE_POINT_BATCH = 8,            /* any mode: the epsilon-offset points go through a [4][n][S][3] batch in HBM (k_make_points) instead of
                                                  being generated in the TRUNK kernels' input stage; same arithmetic, bit-identical results */
+    IBLNERF_ROUTE_COARSE_MAIN_22BIT = 16,     /* F16X3_MXFP6X / F16X3_MXFP6 / F16X3_MAIN: the coarse pass's density stays that of its main query's three f16 products (22-23
+                                                 bits per operand: round 3's arithmetic) instead of being evaluated on the 15-slot form — three f16 + three
+                                                 block-scaled fp6 products per block, operands to ~2^-26 (VAR_TRUNK_P; the default since round 4: the density of
+                                                 the coarse pass places the fine samples, and a fitted network's cancelling density sum amplifies a one-ulp
+                                                 perturbation of its parameters ~300x) */
+    IBLNERF_ROUTE_USER_TRUNK_P = 32           /* the same modes: the trunk-only form of iblnerf_network_query on the 15-slot form (tests of that kernel on its own) */
 };
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,

@@ -10,8 +10,9 @@ yardstick — float64):
 The masks / normal / depth images of the two override configs are analytic functions of the pixel (tests/frame_overrides.py), so the
 whole 800x800 frames of configs 4 and 5 are rendered here too and compared at the fixtures' pixels.
 
-Rules.  A ray's own sensitivity in the reference = the largest of four per-ray yardsticks recorded with the fixture (ray_floor): its float64-vs-float32
-difference, one-ulp nudges of the coarse weights, both branches of sample_pdf's threshold, and its float32 render with the checkpoint rounded to 22-bit mantissas.
+Rules.  A ray's own sensitivity in the reference = the largest of three per-ray yardsticks recorded with the fixture (ray_floor): its float64-vs-float32
+difference, one-ulp nudges of the coarse weights, both branches of sample_pdf's threshold.  (A fourth recorded column, the reference's float32 render with its checkpoint
+rounded to 22-bit mantissas, describes round 3's kernels and is reported, not used.)
 The reference's own float64-vs-float32 difference is recorded PER RAY (fixture arrays floorray__*): a ray that grazes a
 surface amplifies round-off without bound in the reference itself (its two runs differ by 7e-2 on the normal of the worst of 16 384 rays, by
 5e-4 on depth), so an absolute L-inf bar over a launch is not attainable by any arithmetic; what is asserted instead:
@@ -67,15 +68,17 @@ def per_ray(got, ref):
 NORMAL_LIKE = ["target_normal_map", "n_dot_v_map"]
 
 
-def ray_floor(g, key):
-    """The reference's own per-ray sensitivity on map `key`: the larger of its float64-vs-float32 difference (smooth conditioning) and of
-    what one ulp on the coarse pass's weights does to its float32 output (`nudgeray__*`: the `denom < 1e-5` replacement of sample_pdf sits
-    one ulp from an empty bin's denominator, which no float64 run can see; fine-pass maps only)."""
+def ray_floor(g, key, with_param=False):
+    """The reference's own per-ray sensitivity on map `key`: the largest of THREE yardsticks the reference recorded about itself — its
+    float64-vs-float32 difference (smooth conditioning), what one ulp on the coarse pass's weights does to its float32 output (`nudgeray__*`: the
+    `denom < 1e-5` replacement of sample_pdf sits one ulp from an empty bin's denominator, which no float64 run can see; fine-pass maps only), and
+    `branchray__*`: the same threshold deterministically, every critical sample placed by either branch.
+    with_param=True adds `paramray__*` — the reference's float32 render with its checkpoint rounded to 22-bit mantissas, which is how the
+    three-f16-product kernels hold the weights: that column describes THIS LIBRARY's round-3 arithmetic, not the reference, so it
+    is a report column (scratch/rule_report.py) and no part of any pass criterion.  Since round 4 the one query it mattered for — the coarse pass's
+    density, which places the fine samples — runs on the 15-slot form (operands to ~2^-26, csrc/mlp_kernel_mx.hip VAR_TRUNK_P)."""
     f = g["floorray__" + key].astype(np.float64)
-    # branchray: the same threshold, deterministically — every critical sample placed by either branch.  paramray: the reference's float32 render with
-    # its checkpoint rounded to 22-bit mantissas (about one ulp per parameter — how the three-product kernels hold the weights): the sensitivity to the
-    # PARAMETERS, which the arithmetic yardsticks do not probe and which a fitted network's cancelling density sum amplifies ~300x (coarse and fine maps)
-    for y in ("nudgeray__", "branchray__", "paramray__"):
+    for y in ("nudgeray__", "branchray__") + (("paramray__",) if with_param else ()):
         if y + key in g.files:
             f = np.maximum(f, g[y + key].astype(np.float64))
     return f / (float(g["floor_scale"]) if "floor_scale" in g.files else 1.0)      # (the compact 65 536-ray fixture stores float16 of 2^14 x the value)

@@ -489,6 +489,61 @@ class EmuMX(Emu):
         out = (np.concatenate(out, 1) + self.lane_vec(TAB_BIAS + bias_tile * 32, ntiles)).astype(np.float32)
         return np.maximum(out, 0) if relu else out
 
+    # ---- the 15-slot form (VAR_TRUNK_P, mlp_kernel_mx.hip): every trunk block as (network block, residual block 98 * 4 + r) ----
+    @staticmethod
+    def operands_p(v):
+        """v [P, nb, h, 32] fp32 -> (Xh, Xl, fp6 Xh, fp6 Xl, fp6 X3) as split3_pair / finish_block_p / run_layer_p build them."""
+        v = v.astype(np.float32)
+        xh = v.astype(np.float16).astype(np.float32)
+        r = v - xh                                                       # exact in fp32
+        xl = r.astype(np.float16).astype(np.float32)
+        x3 = (r - xl).astype(np.float64)                                 # exact; the kernel packs it as bf16 before the fp6 conversion
+        x3 = (x3.astype(np.float32).view(np.uint32) + 0x7fff + ((x3.astype(np.float32).view(np.uint32) >> 16) & 1) & 0xffff0000).view(np.float32).astype(np.float64)
+        mx = np.maximum(np.abs(v).max(-1, keepdims=True).astype(np.float64), 2.0 ** -100)
+        e = np.floor(np.log2(mx))
+        sh, sl, st = 2.0 ** (e - 2), 2.0 ** (e - 14), 2.0 ** np.maximum(e - 25, -28)
+        return (xh.astype(np.float64), xl.astype(np.float64), fp6_round(xh / sh) * sh, fp6_round(xl.astype(np.float64) / sl) * sl, fp6_round(x3 / st) * st)
+
+    def blocks_p(self, b0, ops):
+        xh, xl, x6, l6, t6 = ops
+        n = xh.shape[1]
+        sel = lambda a, o: a[o + b0:o + b0 + n]
+        R = 98 * 4
+        A16 = lambda o: sel(self.A16, o).transpose(0, 2, 3, 1, 4).reshape(n, 2, 32, 32)
+        Wh, Wl = A16(0), A16(R)
+        ein = lambda W, X: np.einsum("bhrj,pbhj->pr", W, X)
+        return (ein(Wh, xh) + ein(Wh, xl) + ein(Wl, xh)                  # three f16 products
+                + ein(sel(self.W6, 0), t6) + ein(sel(self.R6, 0), l6) + ein(sel(self.W6, R), x6))   # fp6(Wh) fp6(X3) + fp6(Wl) fp6(Xl) + fp6(W3) fp6(Xh)
+
+    def layer_p(self, chunk0, act, enc, bias_tile):
+        per = (1 if enc is not None else 0) + (4 if act is not None else 0)
+        out = []
+        for t in range(8):
+            b = chunk0 * 4 + t * per
+            o = 0.0
+            if enc is not None:
+                o = o + self.blocks_p(b, enc)
+                b += 1
+            if act is not None:
+                o = o + self.blocks_p(b, act)
+            out.append(o)
+        return np.maximum((np.concatenate(out, 1) + self.lane_vec(TAB_BIAS + bias_tile * 32, 8)).astype(np.float32), 0)
+
+    def forward_p(self, pts):
+        c = self.MX_CH
+        act = lambda f: self.operands_p(f[:, np.array([[[32 * (2 * b + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h) for jj in range(32)]
+                                                         for h in range(2)] for b in range(4)])])
+        idx = np.array([[[enc_ref_index(jj, h, 15) for jj in range(32)] for h in range(2)]])
+        emb = O.embed(pts, 10)
+        pe = self.operands_p(np.where(idx >= 0, emb[:, np.maximum(idx, 0)], 0.0))
+        h = self.layer_p(c["L0"], None, pe, 0)
+        for l in range(1, 5):
+            h = self.layer_p(c["L1"] + 8 * (l - 1), act(h), None, 8 * l)
+        h = self.layer_p(c["L5"], act(h), pe, 40)
+        h = self.layer_p(c["L6"], act(h), None, 48)
+        h7 = self.layer_p(c["L7"], act(h), None, 56)
+        return (h7 @ self.lane_vec(TAB_SIG, 8) + self.tab[TAB_SCALAR])[:, None].astype(np.float32)
+
     def forward(self, pts, dirs):
         c = self.MX_CH
         pe = self.frag_enc(O.embed(pts, 10), 15)
@@ -524,7 +579,7 @@ def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
     blob = ck.state_dict_to_blob(sd)
     stream = np.zeros(lib.iblnerf_stream_bytes_mx(), dtype=np.uint8)
     tab = np.zeros(lib.iblnerf_table_floats(), dtype=np.float32)
-    assert stream.size == (98 + 10) * 32768            # the network's 98 chunks + 40 residual blocks of layers 0 and 1 (layout_mx.h: CH_RES)
+    assert stream.size == (98 + 60) * 32768            # the network's 98 chunks + the 240 residual blocks of the trunk (layout_mx.h: CH_RES)
     assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size, tab.ctypes.data, tab.size) == 0
     assert lib.iblnerf_pack_weights_host_mx(blob.ctypes.data, blob.size, stream.ctypes.data, stream.size - 1, tab.ctypes.data, tab.size) == -1
     emu = EmuMX(stream.tobytes(), tab)
@@ -549,7 +604,22 @@ def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
             w0 = W0[160:192, ref_i] if ref_i >= 0 else np.zeros(32, np.float32)
             assert np.array_equal(emu.A16[rb0, jj >> 3, h, :, jj & 7], (w0 - w0.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float64))
     raw_blocks = np.frombuffer(stream.tobytes(), dtype=np.uint8).reshape(-1, 8192)
-    assert not raw_blocks[98 * 4:, 4096:].any()         # nothing but the f16 area is used in a residual block
+    # a residual block: the f16 area (Wl), the fp6(W) area with its scale byte (W3 = what two f16 terms leave of the weight), nothing else
+    assert not raw_blocks[98 * 4:, 5120:6144].any() and not raw_blocks[98 * 4:, 6656:7168].any()
+    assert not (raw_blocks[98 * 4:, 7168:7424].copy().view(np.uint32) >> 8).any()
+    # ... residual block r belongs to trunk block r: positions_linears.6, tile 2, block 3 (and the third term itself, to fp6 precision of its block)
+    W6_ = sd["positions_linears.6.weight"]
+    nb6 = 44 * 4 + 4 * 2 + 3
+    for h in range(2):
+        feat = np.array([32 * (6 + (jj >> 4)) + acc_feature(8 * ((jj >> 3) & 1) + (jj & 7), h) for jj in range(32)])
+        w = W6_[64:96][:, feat]                                            # [row][jj]
+        wh = w.astype(np.float16).astype(np.float32)
+        wl = (w - wh).astype(np.float16).astype(np.float32)
+        got_l = emu.A16[98 * 4 + nb6][:, h].transpose(1, 0, 2).reshape(32, 32)
+        assert np.array_equal(got_l, wl.astype(np.float64))
+        w3 = (w - wh - wl).astype(np.float64)
+        assert np.abs(w3).max() > 0
+        assert np.abs(emu.W6[98 * 4 + nb6, h] - w3).max() <= 0.07 * np.abs(w3).max(-1).max()
     rng = np.random.RandomState(3)
     pts = rng.uniform(-8, 8, (24, 3)).astype(np.float32)
     dirs = rng.uniform(-1.2, 1.2, (24, 3)).astype(np.float32)
@@ -558,6 +628,23 @@ def test_packed_mx_stream_reproduces_oracle_mlp(lib, gain):
     # f16 main term + fp6 residual terms: ~2^-16 per operand
     assert np.abs(got - ref).max() <= (4e-5 if gain == 1.0 else 4e-4), np.abs(got - ref).max()
     assert np.abs(emu.forward(pts, None) - O.mlp_forward(sd, O.embed(pts, 10))).max() <= (2e-5 if gain == 1.0 else 2e-4)
+    # the 15-slot form against the same network in FLOAT64 (same float32 embedding): below what float32 arithmetic itself leaves (the fp32 oracle),
+    # and several times below the three-f16-product form (the precise kernel's arithmetic, emulated here as the 15-slot form without its fp6 terms)
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+    x64 = O.embed(pts, 10).astype(np.float64)
+    h = x64
+    for l in range(8):
+        h = np.maximum((np.concatenate([x64, h], -1) if l == 5 else h) @ sd64["positions_linears.%d.weight" % l].T + sd64["positions_linears.%d.bias" % l], 0)
+    s64 = h @ sd64["sigma_linear.weight"].T + sd64["sigma_linear.bias"]
+    e_p = np.abs(emu.forward_p(pts) - s64).max()
+    e_32 = np.abs(O.mlp_forward(sd, O.embed(pts, 10)) - s64).max()
+    blocks_p = EmuMX.blocks_p
+    try:
+        EmuMX.blocks_p = lambda self, b0, ops: blocks_p(self, b0, ops[:2] + tuple(np.zeros_like(o) for o in ops[2:]))
+        e_3 = np.abs(emu.forward_p(pts) - s64).max()
+    finally:
+        EmuMX.blocks_p = blocks_p
+    assert e_p <= 1.5 * e_32 + 1e-7 and e_p <= 0.5 * e_3, (e_p, e_32, e_3)
 
 
 # --------------------------------------------------------------------------------------------
