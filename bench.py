@@ -34,6 +34,12 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # per mlp_precision: (dtype string, kernels, matrix-core products per algorithmic MAC)
 MODES = {
+    "auto": ("per checkpoint, measured at load (renderer.calibrate): the fast table f16x3_mxfp6x — f16 hi/lo splits x3 products (~2^-22 per operand) where errors are amplified "
+             "(coarse grid's offset queries, auxiliary networks), the coarse pass's density on three f16 + three MX-fp6 products (~2^-26), f16 + 2x MX-fp6 (~2^-16) for the "
+             "main queries' other channels, layers 2-7 of the fine offsets and the reflected-ray queries — or, where that leaves the checkpoint's per-sample weights / maps "
+             "beyond the calibration limits against it, f16x3_mxfp6 (x3 f16 products for every query but the reflected-ray ones); fp32 accumulate",
+             "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel<TRUNK_X|TRUNK_P>", "3 f16 MFMA products in the coarse pass's offsets (+3 block-scaled fp6 products for its density); "
+             "1 f16 + 2 block-scaled fp6 products elsewhere in the fast table, 3 f16 products in the safe one"),
     "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
                     "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in the reflected-ray queries"),
@@ -230,7 +236,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra frames (inference-minimum mode, other product schemes): profiling runs")
-    ap.add_argument("--mlp-precision", choices=["f16x3_mxfp6x", "f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="f16x3_mxfp6x",
+    ap.add_argument("--mlp-precision", choices=["auto", "f16x3_mxfp6x", "f16x3_mxfp6", "f16x3", "f16x3_main", "f16_mxfp6", "f16_mixed", "bf16x3"], default="auto",
                     help="matrix-core product scheme of the fused MLP kernel (include/iblnerf.h: mlp_precision); the default is "
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -282,6 +288,9 @@ def main():
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
+    # mlp_precision="auto": the checkpoint's query routing is decided here, once, on 4 096 seeded pixels of the whole frame (the same on every rank) —
+    # part of loading a checkpoint, like the weight upload, not of a frame
+    policy = D.calibrate_on_frame(r, H, W, K, c2w, NEAR, FAR) if args.mlp_precision == "auto" else r.policy
     row0, n_rows = D.tile_rows(H, rank, world)
     ro, rd = r.get_rays(H, W, K, c2w, row0, n_rows)     # rays resident in HBM before the timed region
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
@@ -336,8 +345,8 @@ def main():
 
     # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
     by_precision = {}
-    if world == 1 and args.mlp_precision == "f16x3_mxfp6x" and not args.inference_min and not args.no_extras:
-        for mode in ("f16x3_mxfp6", "f16_mxfp6"):
+    if world == 1 and args.mlp_precision == "auto" and not args.inference_min and not args.no_extras:
+        for mode in ("f16x3_mxfp6x", "f16x3_mxfp6", "f16_mxfp6"):
             r3 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=mode)
             r3.load_weights(0, sdc)
             r3.load_weights(1, sdf)
@@ -378,6 +387,7 @@ def main():
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
+                       "mlp_precision": args.mlp_precision, "policy": policy,
                        **({"query_routing": routing} if routing else {}),
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if grouped else "single GPU"},

@@ -70,6 +70,7 @@ struct iblnerf_ctx {
     bool have_lut = false;
     // iblnerf_options.query_routing (IBLNERF_ROUTE_*), decoded at iblnerf_create
     bool x_coarse = false, x_user = false, fine_main_precise = false;
+    bool x_fine_precise = false;                  // IBLNERF_ROUTE_FINE_OFFSETS_PRECISE
     bool coarse_sigma_p = true, p_user = false;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
@@ -107,7 +108,25 @@ struct iblnerf_ctx {
         if (e_ != hipSuccess) return (ctx)->fail(IBLNERF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+static void apply_routing(iblnerf_ctx* c, int bits) {
+    c->opt.query_routing = bits;
+    c->x_coarse = (bits & IBLNERF_ROUTE_COARSE_OFFSETS_MIXED) != 0;
+    c->x_user = (bits & IBLNERF_ROUTE_USER_TRUNK_MIXED) != 0;
+    c->fine_main_precise = (bits & IBLNERF_ROUTE_FINE_MAIN_PRECISE) != 0;
+    c->fuse_points = (bits & IBLNERF_ROUTE_POINT_BATCH) == 0;
+    c->coarse_sigma_p = (bits & IBLNERF_ROUTE_COARSE_MAIN_22BIT) == 0;
+    c->p_user = (bits & IBLNERF_ROUTE_USER_TRUNK_P) != 0;
+    c->x_fine_precise = (bits & IBLNERF_ROUTE_FINE_OFFSETS_PRECISE) != 0;
+}
+
 extern "C" {
+
+int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (bits < 0 || bits > 127) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..127)");
+    apply_routing(c, bits);
+    return IBLNERF_OK;
+}
 
 void iblnerf_default_options(iblnerf_options* o) {
     std::memset(o, 0, sizeof *o);
@@ -178,8 +197,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 63 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..63), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 127 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..127), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -203,12 +222,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, opts->device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     if (opts->persistent_workgroups > 0) c->n_cu = opts->persistent_workgroups;
-    c->x_coarse = (opts->query_routing & IBLNERF_ROUTE_COARSE_OFFSETS_MIXED) != 0;
-    c->x_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_MIXED) != 0;
-    c->fine_main_precise = (opts->query_routing & IBLNERF_ROUTE_FINE_MAIN_PRECISE) != 0;
-    c->fuse_points = (opts->query_routing & IBLNERF_ROUTE_POINT_BATCH) == 0;
-    c->coarse_sigma_p = (opts->query_routing & IBLNERF_ROUTE_COARSE_MAIN_22BIT) == 0;
-    c->p_user = (opts->query_routing & IBLNERF_ROUTE_USER_TRUNK_P) != 0;
+    apply_routing(c, opts->query_routing);
     c->Sc = opts->n_samples;
     c->Sf = opts->n_samples + opts->n_importance;
     c->Smax = c->Sf;
@@ -499,7 +513,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             // ... and the FINE pass's main query on the fast kernel: its raw rows enter the maps as weighted sums (2^-16 per operand, no
             // amplification: it places no samples and no depth difference is taken of it) — on 1 024 rays of the fitted checkpoint the
             // worst ray of every direct channel is set by the coarse pass's sample placement, with or without it
-            const bool x = qclass == Q_OFFSET_FINE || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
+            const bool x = (qclass == Q_OFFSET_FINE && !c->x_fine_precise) || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
             // ... and the COARSE pass's main query too once its density column comes from the 15-slot form (full_pass): what is left of it are the
             // coarse pass's own albedo / roughness / irradiance / radiance samples, weighted sums like the fine pass's
             kern = (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise) ||

@@ -110,9 +110,26 @@ def render_frame_sharded(render_tile: Callable[[int, int], Dict[str, "object"]],
     return unpack_maps(full, layout)
 
 
+def calibrate_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
+    """mlp_precision="auto": decide the checkpoint's query routing (Renderer.calibrate) on `n` seeded pixels of the WHOLE frame — the same pixels on
+    every rank, so that all tiles of a frame are rendered under one decision (the kernels are deterministic: same rays, same measurement)."""
+    import numpy as np
+    import torch
+    pix = np.sort(np.random.RandomState(seed).permutation(H * W)[:min(n, H * W)])
+    ro, rd = renderer.get_rays(H, W, K, c2w)                       # (15 MB for 800 x 800; once per checkpoint)
+    idx = torch.as_tensor(pix, device=ro.device)
+    if len(pix) < renderer.CAL_MIN_RAYS:       # a frame too small to measure on (the 9-row frames of the tests): rendered SAFE, question left open
+        renderer._set_routing(renderer.SAFE_ROUTING)
+        return None
+    return renderer.calibrate(ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous(), near, far)
+
+
 def render_frame(renderer, H, W, K, c2w, near, far, keys: Sequence[str] = EXPORT_KEYS, gt_values=None, group=None,
                  **edit):
     """Full frame with the HIP renderer, sharded over the ranks of `group` (or unsharded without one)."""
+    if getattr(renderer, "_auto", False) and renderer.policy is None:
+        calibrate_on_frame(renderer, H, W, K, c2w, near, far)
+
     def tile(row0, n_rows):
         ro, rd = renderer.get_rays(H, W, K, c2w, row0, n_rows)
         return renderer.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far,

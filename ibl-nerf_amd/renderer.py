@@ -68,7 +68,9 @@ class Renderer:
                  max_rays_per_launch=65536, device=None, lindisp=False, use_radiance_linear=False,
                  mlp_precision=None, normal_mode="normal_map_from_depth_gradient_epsilon", color_independent_to_direction=False,
                  epsilon_direction=0.005, infer_normal_at_surface=False, range_check="eager", query_routing=0, persistent_workgroups=0):
-        """mlp_precision (include/iblnerf.h has the table): "f16x3_mxfp6x" (default: three f16 products on hi/lo splits, ~2^-22
+        """mlp_precision: "auto" (the default) = an f16x3_mxfp6x context that decides per checkpoint, by measurement on the first frame-sized
+        call (see `calibrate`), whether the fine pass keeps that mode's fast forms or runs as f16x3_mxfp6; the pinned modes
+        (include/iblnerf.h has the table): "f16x3_mxfp6x" (three f16 products on hi/lo splits, ~2^-22
         per operand, for the coarse pass's main query, auxiliary networks and the coarse grid's offset queries; the fine pass's
         offset queries on the fast kernel's mixed trunk form — its first two layers as three f16 products, the others as one f16 +
         two block-scaled fp6 products; the fine pass's main query and the reflected-ray queries on the fast kernel),
@@ -88,8 +90,12 @@ class Renderer:
         kernel form on its own).  persistent_workgroups: MLP launches with that many workgroups instead of one per CU."""
         torch = _torch()
         mlp_precision = mlp_precision or DEFAULT_MLP_PRECISION
-        if mlp_precision not in B.MLP_PRECISIONS:
-            raise ValueError("mlp_precision must be one of %s" % sorted(B.MLP_PRECISIONS))
+        if mlp_precision not in B.MLP_PRECISIONS and mlp_precision != "auto":
+            raise ValueError("mlp_precision must be 'auto' or one of %s" % sorted(B.MLP_PRECISIONS))
+        # "auto" (the default): the context is an f16x3_mxfp6x one whose routing of the fine pass's queries is decided PER CHECKPOINT by a
+        # measurement on the first frame-sized call after the weights are loaded (see calibrate)
+        self._auto = mlp_precision == "auto"
+        self.policy = None if self._auto else {"decision": "pinned", "mode": mlp_precision}
         if range_check not in ("eager", "lazy"):
             raise ValueError("range_check must be 'eager' or 'lazy'")
         self.range_check, self._force_wide = range_check, False
@@ -114,10 +120,11 @@ class Renderer:
         o.device = self.device.index
         o.lindisp = int(bool(lindisp))
         o.use_radiance_linear = int(bool(use_radiance_linear))
-        o.mlp_precision = B.MLP_PRECISIONS[mlp_precision]
+        o.mlp_precision = B.MLP_PRECISIONS["f16x3_mxfp6x" if self._auto else mlp_precision]
         o.normal_mode = NORMAL_MODES[normal_mode]
         o.color_independent_to_direction = int(bool(color_independent_to_direction))
         query_routing = _routing_bits(query_routing)
+        self._routing = int(query_routing)         # the caller's bits; the calibration adds SAFE_ROUTING to them or not
         o.query_routing, o.persistent_workgroups = int(query_routing), int(persistent_workgroups)
         self.normal_mode = normal_mode
         self.mlp_precision = mlp_precision
@@ -176,6 +183,8 @@ class Renderer:
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
         if int(which) == 1:
             self.has_fine = True
+        if self._auto:
+            self.policy = None          # another checkpoint: measured again on the next frame-sized call
         if self.mlp_precision != "bf16x3":
             self._blobs[int(which)] = blob
             if self._wide is not None:
@@ -360,6 +369,75 @@ class Renderer:
             q = torch.quantile(e, torch.tensor([0.5, 0.99, 0.999], dtype=e.dtype))
             rep[k] = {"p50": float(q[0]), "p99": float(q[1]), "p999": float(q[2]), "max": float(e.max()), "above_1e-3": float((e > 1e-3).double().mean())}
         return rep
+
+    # ---- mlp_precision="auto": which routing of the fine pass's queries this checkpoint needs ---------------------------------------------
+    # FAST = the f16x3_mxfp6x table as it is (fine main query and the layers 2-7 of the fine offsets on the 6-slot scheme: 2^-16 per operand);
+    # SAFE = f16x3_mxfp6's table (every query but the reflected-ray ones on three f16 products).  Both keep the coarse pass's density on the
+    # 15-slot form.  FAST was fixed on one fitted checkpoint; a second one with sharper density steps showed the per-sample `weights` of the fine pass
+    # at 1.6e-3 (99.9 %) and, from a rotated camera, a handful of normals beyond 8x the reference's own sensitivity — SAFE holds
+    # the strict rules on both.  So the table is not assumed: the first frame-sized call after a checkpoint is loaded renders <= CAL_RAYS of its own
+    # rays under both routings (same context, iblnerf_set_query_routing; ~2 x 12 ms) and keeps FAST only if it stays within CAL_LIMITS of SAFE.
+    SAFE_ROUTING = B.ROUTE_FINE_MAIN_PRECISE | B.ROUTE_FINE_OFFSETS_PRECISE
+    CAL_RAYS, CAL_MIN_RAYS = 4096, 2048       # (a 99.9th percentile needs a few thousand rays: on 586 rays it is the worst ray)
+    # per-ray deviation FAST vs SAFE (max over a map's channels over the map's largest value): 99.9th percentile limits, and the share of rays above 1e-3.
+    # Measured (scratch/calibration_probe.py, gpurun_out/r4b/calibration.txt; subsets of 1 024 .. 4 096 rays): the checkpoint the FAST table was fixed on
+    # shows weights 1.2-1.9e-4, depth / albedo / roughness / irradiance <= 1.2e-4, normal 1e-4 .. 8e-4 (the rotated camera); the second, sharper one
+    # weights 1.1-1.8e-3, albedo 1.7-3.7e-4 from either camera.  `weights` — the one output that sees the fine main query's density error unaveraged —
+    # separates the two by a factor of six on every subset; the limits sit in the middle of that gap (log scale).
+    CAL_LIMITS = {"weights": 5e-4, "depth_map": 1.5e-4, "albedo_map": 1.5e-4, "roughness_map": 1.5e-4, "irradiance_map": 1.5e-4, "target_normal_map": 1.5e-3}
+    CAL_MAX_SHARE_ABOVE_1E3 = {"target_normal_map": 3e-3, "weights": 1e-3}
+
+    def _set_routing(self, extra):
+        B.check(self.ctx, self.lib.iblnerf_set_query_routing(self.ctx, int(self._routing | extra)))
+
+    def calibrate(self, rays_o, rays_d, near, far, gt_values=None, **edit):
+        """Decides FAST or SAFE for the checkpoint this context holds on the given rays (a few thousand of the view to be rendered: dist.render_frame
+        and bench.py pass the same seeded pixels on every rank, so that all tiles of a frame are rendered under one decision).  Returns and records
+        `self.policy` = {"decision": "fast" | "safe", "rays": n, "metrics": {map: {"p999", "above_1e-3"}}, "triggers": [...]}.  Only for
+        mlp_precision="auto"; a pinned mode keeps its table."""
+        torch = _torch()
+        if not self._auto:
+            return self.policy
+        keep = self.policy
+        self.policy = {"decision": "calibrating"}
+        try:
+            with torch.no_grad():
+                self._set_routing(0)
+                a = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+                self._set_routing(self.SAFE_ROUTING)
+                b = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+            metrics, triggers = {}, []
+            for k, lim in self.CAL_LIMITS.items():
+                if k not in a:
+                    continue
+                x, y = a[k].double().reshape(a[k].shape[0], -1), b[k].double().reshape(a[k].shape[0], -1)
+                e = (x - y).abs().nan_to_num(0.0).amax(-1) / y.abs().nan_to_num(0.0).amax().clamp_min(1e-30)
+                p999 = float(torch.quantile(e.cpu(), 0.999))
+                share = float((e > 1e-3).double().mean())
+                metrics[k] = {"p999": p999, "above_1e-3": share}
+                if p999 > lim:
+                    triggers.append("%s p99.9 %.1e > %.1e" % (k, p999, lim))
+                if share > self.CAL_MAX_SHARE_ABOVE_1E3.get(k, 1.0):
+                    triggers.append("%s: %.2f %% of the rays above 1e-3" % (k, 100 * share))
+            safe = bool(triggers)
+            self._set_routing(self.SAFE_ROUTING if safe else 0)
+            keep = {"decision": "safe" if safe else "fast", "rays": int(a["depth_map"].shape[0]), "metrics": metrics, "triggers": triggers,
+                    "routing": int(self._routing | (self.SAFE_ROUTING if safe else 0))}
+        finally:
+            self.policy = keep
+        return self.policy
+
+    def _auto_decide(self, rays_o, rays_d, near, far, gt_values, edit):
+        """First eager render after a checkpoint was loaded: calibrate on a strided subset of the call's own rays; a call too small to measure on is
+        rendered SAFE and leaves the question open."""
+        torch = _torch()
+        n = rays_o.shape[0]
+        if n < self.CAL_MIN_RAYS:
+            self._set_routing(self.SAFE_ROUTING)
+            return
+        idx = torch.linspace(0, n - 1, min(n, self.CAL_RAYS), device=rays_o.device).long()
+        gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
+        self.calibrate(rays_o[idx].contiguous(), rays_d[idx].contiguous(), near, far, gt, **edit)
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""
@@ -737,6 +815,9 @@ class Renderer:
             if self._force_wide:
                 return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
                                                                 draws=draws, taps=taps, **edit)
+        if self._auto and self.policy is None and not lazy and taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0.:
+            # (a training step's context — lazy, sampled, tapped — keeps the FAST table: its renders are stochastic and its weights change every step)
+            self._auto_decide(rays_o, rays_d, near, far, gt_values, edit)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -925,7 +1006,7 @@ NORMAL_MODES = {"normal_map_from_depth_gradient_epsilon": 0, "ground_truth": 1,
                 # the two autograd modes (normal_from_depth.py:102-137, :16-52): chain rule on the density-gradient query, no autograd —
                 # so they also run under no_grad, where the reference's depth_map.backward() raises
                 "normal_map_from_depth_gradient": 4, "normal_map_from_depth_gradient_direction": 5}   # target_normal_map_for_radiance_calculation values built
-DEFAULT_MLP_PRECISION = "f16x3_mxfp6x"
+DEFAULT_MLP_PRECISION = "auto"
 
 
 _tokens = itertools.count(1)

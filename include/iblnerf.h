@@ -122,8 +122,14 @@ enum {
                                                  block-scaled fp6 products per block, operands to ~2^-26 (VAR_TRUNK_P; the default since round 4: the density of
                                                  the coarse pass places the fine samples, and a fitted network's cancelling density sum amplifies a one-ulp
                                                  perturbation of its parameters ~300x) */
-    IBLNERF_ROUTE_USER_TRUNK_P = 32           /* the same modes: the trunk-only form of iblnerf_network_query on the 15-slot form (tests of that kernel on its own) */
+    IBLNERF_ROUTE_USER_TRUNK_P = 32,          /* the same modes: the trunk-only form of iblnerf_network_query on the 15-slot form (tests of that kernel on its own) */
+    IBLNERF_ROUTE_FINE_OFFSETS_PRECISE = 64   /* F16X3_MXFP6X: the fine grid's offset queries back on F16X3 (with IBLNERF_ROUTE_FINE_MAIN_PRECISE the mode then
+                                                 routes every query as F16X3_MXFP6 does: the "safe" policy of ibl-nerf_amd/renderer.py's load-time calibration) */
 };
+/* Changes options.query_routing of an existing context (no reallocation; takes effect with the next call; the caller orders it against work in
+ * flight by issuing it between calls on the context's stream).  Bits that need a stream the context's mlp_precision does not keep are ignored as at
+ * iblnerf_create.  Lets a caller measure two routings of one mode on the same rays and keep the cheaper one that holds its tolerance. */
+int iblnerf_set_query_routing(iblnerf_ctx* ctx, int query_routing);
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3, IBLNERF_NORMAL_DEPTH_GRADIENT = 4, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION = 5 };
