@@ -6,7 +6,8 @@ parameter of both networks) for the phases of train.py:275-295):
     full     approximate_radiance=True   (split-sum shading in the loss: LUT fetch, Fresnel, mip interpolation, gamma)
     frozen   ... with freeze_radiance / freeze_roughness on both networks (forward_freezed, ibl_nerf.py:88-152)
     depth    is_depth_only=True (raw2outputs_depth), forward only
-Bar: all 92 parameter gradients within 1e-3 of each tensor's largest entry; the loss within 1e-5 relative."""
+Bar: all 92 parameter gradients within 1e-3 of each tensor's largest entry (the fine network's under approximated radiance: 1.5e-3 — they
+also depend on which bin each stochastic fine sample falls into, see the test); the loss within 1e-5 relative."""
 import os
 
 import numpy as np
@@ -85,7 +86,11 @@ def test_training_step_gradients_against_the_reference(G, lut, phase, teacher):
     # roughness_linear under approximate_radiance: d color / d roughness is proportional to the prefiltered reflected-ray maps, which are
     # ill-conditioned in the reference itself (its float64 and float32 runs differ by 1e-2 .. 1e-1 there): end to end 5e-3, and 1e-3 with the
     # reference's own reflected-ray maps and n.v as the backward's constants (teacher forcing, below)
-    bad = {k: v for k, v in worst.items() if v > (5e-3 if (approx and "roughness_linear" in k and not teacher) else 1e-3)}
+    # the FINE network's gradients also depend on where the stochastic fine samples fall: on these 64 rays one sample lands in another bin than the
+    # reference's (z_std moves by 5.8e-3; 7.4e-3 with round 3's coarse density, another sample; the reference's own float64 run moves it by 5e-3 too),
+    # which is worth up to 1.1e-3 on one trunk tensor (scratch/train_grad_probe.py: positions_linears.1.weight 1.11e-3 | 4.9e-4 under the two routings)
+    lim = lambda k: 5e-3 if (approx and "roughness_linear" in k and not teacher) else (1.5e-3 if (approx and k.startswith("f.")) else 1e-3)
+    bad = {k: v for k, v in worst.items() if v > lim(k)}
     assert not bad, bad
 
 
