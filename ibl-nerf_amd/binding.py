@@ -58,7 +58,8 @@ class Overrides(C.Structure):
                 ("d_mask", FP), ("d_depth", FP), ("d_normal", FP), ("d_albedo", FP),
                 ("roughness_list", C.c_float * 8), ("albedo_list", C.c_float * 24),
                 ("irradiance_list", C.c_float * 8), ("d_gt_normal", FP),
-                ("d_gt_albedo", FP), ("d_gt_roughness", FP), ("d_gt_irradiance", FP), ("d_gt_depth", FP)]
+                ("d_gt_albedo", FP), ("d_gt_roughness", FP), ("d_gt_irradiance", FP), ("d_gt_depth", FP),
+                ("edit_roughness_by_img", C.c_int32), ("d_roughness", FP)]
 
 
 class Maps(C.Structure):
@@ -76,7 +77,7 @@ class StageInputs(C.Structure):
 
 
 class Sampling(C.Structure):
-    _fields_ = [("d_t_rand", FP), ("d_u", FP), ("d_noise_coarse", FP), ("d_noise_fine", FP)]
+    _fields_ = [("d_t_rand", FP), ("d_u", FP), ("d_noise_coarse", FP), ("d_noise_fine", FP), ("d_near", FP), ("d_far", FP)]
 
 
 class Taps(C.Structure):

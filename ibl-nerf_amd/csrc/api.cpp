@@ -1008,7 +1008,7 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
                      const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise,
-                     float* env_tap = nullptr) {
+                     float* env_tap = nullptr, const float* near_ray = nullptr, const float* far_ray = nullptr) {
     const int Sc = c->Sc;
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
@@ -1063,6 +1063,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
                               weights, near_, far_, ov);
     a.noise = noise;
+    a.near_ray = near_ray; a.far_ray = far_ray;
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, Sc, c->pts, s));
@@ -1092,6 +1093,8 @@ static int parse_overrides(iblnerf_ctx* c, const iblnerf_overrides* ovr, Overrid
         if (ovr->mode == 1 && ovr->edit_albedo && ovr->edit_albedo_by_img && !ovr->d_albedo)
             return c->fail(IBLNERF_ERR_INVALID, "edit_albedo_by_img needs edit_albedo rows");
         if (ovr->n_roughness_list < 0 || ovr->n_roughness_list > 8) return c->fail(IBLNERF_ERR_INVALID, "roughness list too long");
+        if (ovr->edit_roughness_by_img && (ovr->mode != 1 || !ovr->edit_roughness || !ovr->d_roughness))
+            return c->fail(IBLNERF_ERR_INVALID, "edit_roughness_by_img needs edit_intrinsic, edit_roughness and the per-ray d_roughness rows");
         ov.mode = ovr->mode; ov.num_objects = ovr->num_objects;
         ov.edit_depth = ovr->edit_depth; ov.edit_normal = ovr->edit_normal; ov.edit_albedo = ovr->edit_albedo;
         ov.edit_albedo_by_img = ovr->edit_albedo_by_img; ov.edit_roughness = ovr->edit_roughness;
@@ -1126,6 +1129,7 @@ static OverrideArgs rows_from(const OverrideArgs& ov, const iblnerf_overrides* o
         o.depth_img = ovr->d_depth ? ovr->d_depth + r0 : nullptr;
         o.normal_img = ovr->d_normal ? ovr->d_normal + 3 * r0 : nullptr;
         o.albedo_img = ovr->d_albedo ? ovr->d_albedo + 3 * r0 : nullptr;
+        o.rough_img = (ovr->edit_roughness_by_img && ovr->d_roughness) ? ovr->d_roughness + r0 : nullptr;
     }
     return o;
 }
@@ -1157,6 +1161,9 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     const float* noise_f = smp ? smp->d_noise_fine : nullptr;
     if ((t_rand == nullptr) != (u_rand == nullptr) && fine)   // perturb > 0 switches both (det = (perturb == 0), :703)
         return c->fail(IBLNERF_ERR_INVALID, "render_rays: d_t_rand and d_u go together (perturb > 0 jitters the grid and draws the fine samples)");
+    const float* near_ray = smp ? smp->d_near : nullptr;             // per-ray planes (:802-805 with [n, 1] tensors)
+    const float* far_ray = smp ? smp->d_far : nullptr;
+    if ((near_ray == nullptr) != (far_ray == nullptr)) return c->fail(IBLNERF_ERR_INVALID, "render_rays: d_near and d_far go together");
     if (!c->have_net[0]) return c->fail(IBLNERF_ERR_STATE, "render_rays: network_fn weights not uploaded");
     if (!c->have_lut) return c->fail(IBLNERF_ERR_STATE, "render_rays: brdf_lut not uploaded");
     const int fine_net = c->have_net[1] ? 1 : 0;   // run_fn = network_fn if network_fine is None (:705)
@@ -1170,7 +1177,7 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     c->flop_alg = 0.0;
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
-    if (t_rand && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
+    if ((t_rand || near_ray) && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
     // equal-sized launches (a short tail launch would leave most of the persistent grid idle)
     const long n_launch = (n_rays + c->ws_rays - 1) / c->ws_rays;
     const long per_launch = n_launch ? (n_rays + n_launch - 1) / n_launch : 0;
@@ -1182,11 +1189,17 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         // the coarse grid of this launch: one shared row, or per-ray rows after the stratified jitter (:678-692)
         const float* zc = c->zc;
         int zcs = 0;
-        if (t_rand) {
+        if (near_ray) {   // every ray its own grid (and its jitter)
+            HIP_TRY(c, launch_ray_grid(near_ray + r0, far_ray + r0, Sc, c->opt.lindisp, t_rand ? t_rand + r0 * Sc : nullptr, R, c->zc_ray, s));
+            zc = c->zc_ray;
+            zcs = Sc;
+        } else if (t_rand) {
             HIP_TRY(c, launch_jitter_z(c->zc, Sc, t_rand + r0 * Sc, R, c->zc_ray, s));
             zc = c->zc_ray;
             zcs = Sc;
         }
+        const float* nr = near_ray ? near_ray + r0 : nullptr;
+        const float* fr = far_ray ? far_ray + r0 : nullptr;
         int rc;
         // taps (iblnerf_render_rays_tapped): this launch's z rows and main raw rows, out of the workspace before the next pass reuses it
         auto tap_z = [&](float* dst, const float* z, int zstride, int S) -> int {
@@ -1202,14 +1215,14 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         };
         if (!fine) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
@@ -1221,7 +1234,7 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
-                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr);
+                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr);
         if (rc) return rc;
         if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
     }

@@ -25,6 +25,8 @@ hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float
 
 // ibl_nerf_renderer.py:670-672: z_k = near (1 - t_k) + far t_k, t = linspace(0,1,S)
 hipError_t launch_coarse_z(float near, float far, int S, int lindisp, float* z, hipStream_t s);
+// ... per ray, for rays with their own planes (near / far [R]); t_rand [R, S] or null: the stratified jitter on top
+hipError_t launch_ray_grid(const float* near, const float* far, int S, int lindisp, const float* t_rand, long R, float* out, hipStream_t s);
 
 // Point batches (rays x samples packed contiguously, [V][R][S][3]):
 //   mode 0: origin + dir * z                                  (ibl_nerf_renderer.py:200, :440)
@@ -51,6 +53,7 @@ struct OverrideArgs {          // edit_intrinsic / insert_object branches, ibl_n
     const float* gt_roughness;   // [R] (channel 0 of gt_values["roughness"])
     const float* gt_irradiance;  // [R,3]: the irradiance becomes a colour and the irradiance map has 3 channels
     const float* gt_depth;       // [R]   (channel 0 of gt_values["depth"]); target depth only: depth_map / disp stay the network's
+    const float* rough_img;      // [R] edit_roughness_by_img (:394-395): the roughness a masked ray takes (resolved per chunk by the caller), or null
     float rough_list[8];
     float albedo_list[24];
     float irr_list[8];
@@ -92,6 +95,8 @@ struct PassAArgs {
     float* weights;                             // [R,S] (always written: sample_pdf input / output map)
     const float* lut;                           // [3,512,512]
     float near, far, eps;
+    const float* near_ray = nullptr;            // per-ray planes [R] (iblnerf_sampling.d_near / d_far) or null: depth_0 of the mip level per ray
+    const float* far_ray = nullptr;
     int irradiance_sigmoid;                     // an irradiance_mlp's samples take sigmoid, whatever radiance_f is (:300-303)
     int tilted_rays;                            // 0: offset-sample depths (normal_from_depth.py:139-183), 1: tilted-ray depths (:55-100)
     int grad_normal = 0;                        // 1: normal from d depth / d ray origin (normal_from_depth.py:102-137), 2: d depth / d ray direction (:16-52)

@@ -184,6 +184,26 @@ __global__ void k_jitter_z(const float* __restrict__ z, int S, const float* __re
     out[idx] = lower + (upper - lower) * t_rand[idx];
 }
 
+// The coarse grid of rays with their own near / far planes (ibl_nerf_renderer.py:668-674 with near, far of shape [n, 1]) and, with t_rand, its
+// stratified jitter (:678-692) — k_coarse_z and k_jitter_z per ray.
+__global__ void k_ray_grid(const float* __restrict__ near, const float* __restrict__ far, int S, int lindisp, const float* __restrict__ t_rand, long R,
+                           float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * S) return;
+    const long r = idx / S;
+    const int k = (int)(idx - r * S);
+    const float nr = near[r], fr = far[r];
+    auto zk = [&](int i) {
+        const float t = linspace_at(0.0f, 1.0f, S, i);
+        return lindisp ? 1.0f / (1.0f / nr * (1.0f - t) + 1.0f / fr * t) : nr * (1.0f - t) + fr * t;
+    };
+    if (t_rand == nullptr) { out[idx] = zk(k); return; }
+    const float z0 = zk(k);
+    const float lower = k == 0 ? z0 : 0.5f * (z0 + zk(k - 1));
+    const float upper = k == S - 1 ? z0 : 0.5f * (zk(k + 1) + z0);
+    out[idx] = lower + (upper - lower) * t_rand[idx];
+}
+
 // normal_from_depth.py:64-67: F.normalize(rays_d +- eps * right), F.normalize(rays_d +- eps * up)
 __device__ __forceinline__ void tilted_dirs(const float* d, const float* right, const float* up, float eps, float nd[4][3]) {
 #pragma unroll
@@ -472,9 +492,14 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
                     if (in_obj(q)) for (int c = 0; c < 3; ++c) albedo[c] = ov.albedo_list[3 * q + c];
             }
         }
-        if (ov.edit_roughness)
-            for (int q = 0; q < ov.n_rough_list; ++q)
-                if (in_obj(q)) rough = ov.rough_list[q];
+        if (ov.edit_roughness) {
+            if (ov.rough_img != nullptr) {            // edit_roughness_by_img (:394-395)
+                if (mask_all) rough = ov.rough_img[r];
+            } else {
+                for (int q = 0; q < ov.n_rough_list; ++q)
+                    if (in_obj(q)) rough = ov.rough_list[q];
+            }
+        }
     } else if (ov.mode == 2) {   // :406-410
         for (int q = 0; q < ov.num_objects; ++q)
             if (in_obj(q)) {
@@ -503,7 +528,7 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
     const float rough_net = ov.gt_roughness != nullptr ? ch[3] : rough;
     float level = rough_net;
     if (a.correct_depth) {
-        const float depth_0 = (a.far + a.near) * 0.5f;                            // :456-460
+        const float depth_0 = a.near_ray != nullptr ? (a.far_ray[r] + a.near_ray[r]) * 0.5f : (a.far + a.near) * 0.5f;   // :456-460 (per-ray planes: depth_0[..., 0])
         level = fminf(fmaxf(rough_net * depth / depth_0, 0.0f), 1.0f);
     }
 
@@ -993,6 +1018,12 @@ hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float
     const long n = (long)n_rows * W;
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, row0, n_rows, cam, rays_o, rays_d);
+    return hipGetLastError();
+}
+
+hipError_t launch_ray_grid(const float* near, const float* far, int S, int lindisp, const float* t_rand, long R, float* out, hipStream_t s) {
+    const long n = R * S;
+    hipLaunchKernelGGL(k_ray_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, near, far, S, lindisp, t_rand, R, out);
     return hipGetLastError();
 }
 

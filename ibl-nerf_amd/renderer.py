@@ -136,6 +136,7 @@ class Renderer:
                           color_independent_to_direction=color_independent_to_direction, epsilon_direction=epsilon_direction,
                           infer_normal_at_surface=infer_normal_at_surface, range_check=range_check, persistent_workgroups=persistent_workgroups)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
+        self._chunk = None
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._twin_ref = None        # (mode, Renderer) of precision_report
@@ -437,6 +438,7 @@ class Renderer:
             return
         idx = torch.linspace(0, n - 1, min(n, self.CAL_RAYS), device=rays_o.device).long()
         gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
+        near, far = ((v[idx].contiguous() if torch.is_tensor(v) and v.numel() == n else v) for v in (near, far))       # per-ray planes follow their rays
         self.calibrate(rays_o[idx].contiguous(), rays_d[idx].contiguous(), near, far, gt, **edit)
 
     def trim(self):
@@ -776,6 +778,21 @@ class Renderer:
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = rays_o.shape[0]
         smp = None
+        # near / far: scalars, or one plane per ray ([n] / [n, 1], ibl_nerf_renderer.py:802-805) — a z grid and a mip-level depth_0 per ray
+        planes = None
+        if any(hasattr(v, "shape") and int(np.prod(tuple(v.shape))) > 1 for v in (near, far)):
+            planes = tuple((_dev_f32(v, self.device).reshape(-1) if hasattr(v, "shape") else torch.full((n,), float(v), dtype=torch.float32, device=self.device))
+                           for v in (near, far))
+            if any(p.numel() != n for p in planes):
+                raise RuntimeError("near / far planes must have one entry per ray (%d), got %s" % (n, [int(p.numel()) for p in planes]))
+            planes = tuple(p.contiguous() for p in planes)
+            smp = B.Sampling()
+            smp.d_near, smp.d_far = planes[0].data_ptr(), planes[1].data_ptr()
+            self._keep_planes = planes
+            near_arg, far_arg = near, far
+            near, far = (float(planes[0][0]), float(planes[1][0])) if n else (0.0, 1.0)      # (not read by the library when the planes are given)
+        elif hasattr(near, "shape") or hasattr(far, "shape"):
+            near, far = float(np.asarray(near.cpu() if hasattr(near, "cpu") else near).reshape(-1)[0]), float(np.asarray(far.cpu() if hasattr(far, "cpu") else far).reshape(-1)[0])
         std = float(raw_noise_std or 0.)
         if std > 0.:
             smp = B.Sampling()
@@ -813,11 +830,12 @@ class Renderer:
         if lazy:
             self._lazy_poll()
             if self._force_wide:
-                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
-                                                                draws=draws, taps=taps, **edit)
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb,
+                                                                pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
         if self._auto and self.policy is None and not lazy and taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0.:
             # (a training step's context — lazy, sampled, tapped — keeps the FAST table: its renders are stochastic and its weights change every step)
-            self._auto_decide(rays_o, rays_d, near, far, gt_values, edit)
+            self._auto_decide(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, edit)
+        self._chunk = chunk          # (one flag's result depends on the reference's chunking: edit_roughness_by_img, see _overrides)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -842,8 +860,8 @@ class Renderer:
                                                               C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
-                                                 draws=draws, taps=taps, **edit)
+            return self._wide_twin().render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb, pytest=pytest,
+                                                 chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:
@@ -925,6 +943,7 @@ class Renderer:
             assert nobj > 0, "num_edit_objects must be greater than 0"
             ov.mode, ov.num_objects = 1, nobj
             ov.d_mask = rows("edit_intrinsic_mask", 3)
+            mask_rows = keep[-1]
             ov.edit_depth = int(bool(edit.get("edit_depth", False)))
             ov.edit_normal = int(bool(edit.get("edit_normal", False)))
             ov.edit_albedo = int(bool(edit.get("edit_albedo", False)))
@@ -941,7 +960,26 @@ class Renderer:
             if ov.edit_albedo and ov.edit_albedo_by_img:
                 ov.d_albedo = rows("edit_albedo", 3)
             if ov.edit_roughness and edit.get("edit_roughness_by_img"):
-                raise NotImplementedError("edit_roughness_by_img (ibl_nerf_renderer.py:394-395) is not on the shipped-config path")
+                # :394-395: target_roughness_map[mask_all] = gt_values["edit_roughness"][mask_all][0] — inside raw2outputs, i.e. per `chunk` rays
+                # (batchify_rays, :735-756): every masked ray of a chunk takes the FIRST masked row of that chunk.  Ray-sized bookkeeping, resolved here.
+                torch = _torch()
+                if "edit_roughness" not in gt:
+                    raise KeyError("gt_values['edit_roughness'] is required by the requested edit")
+                img = _dev_f32(gt["edit_roughness"], self.device).reshape(n, -1)
+                if img.shape[1] != 1:   # the reference assigns row[0] of shape [C] to the masked entries of an [n] map: only one channel broadcasts
+                    raise RuntimeError("shape mismatch: gt_values['edit_roughness'] must have one channel for edit_roughness_by_img (the reference's "
+                                       "masked assignment of a [%d]-vector to a scalar map fails)" % img.shape[1])
+                masked = mask_rows[:, 0] > 0                                # mask_all (:229)
+                ch = int(self._chunk or n or 1)
+                per_ray = torch.zeros((n,), dtype=torch.float32, device=self.device)
+                pos = torch.arange(n, device=self.device)
+                for c0 in range(0, n, ch):
+                    m = masked[c0:c0 + ch]
+                    if bool(m.any()):
+                        first = int(pos[c0:c0 + ch][m][0])
+                        per_ray[c0:c0 + ch] = img[first, 0]
+                keep.append(per_ray)
+                ov.edit_roughness_by_img, ov.d_roughness = 1, per_ray.data_ptr()
             if ov.edit_albedo and not ov.edit_albedo_by_img and len(alb) < 3 * nobj:
                 raise IndexError("editing_target_albedo_list needs 3 values per edit object")
         else:                                                                           # :229-238
@@ -1115,12 +1153,18 @@ def _ci_net(net):
     return bool(getattr(net, "is_color_independent_to_direction", False))
 
 
-def _scalar(x, name):
+def _plane(x, n):
+    """render_decomp's near / far (:802): a scalar, or a plane per ray — a tensor that broadcasts against rays_d[..., :1] as `near * ones_like(...)` does
+    ([n, 1], [1], 0-d); a uniform tensor is a scalar."""
     torch = _torch()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
     if torch.is_tensor(x):
-        if x.numel() > 1 and not bool((x == x.reshape(-1)[0]).all()):
-            raise NotImplementedError("per-ray %s planes are not supported (all shipped datasets use one scalar)" % name)
-        return float(x.reshape(-1)[0])
+        if x.numel() == 1 or bool((x == x.reshape(-1)[0]).all()):
+            return float(x.reshape(-1)[0])
+        if x.numel() != n or x.dim() < 2 or x.shape[-1] != 1:      # (a 1-D [n] plane broadcasts to [n, n] in the reference and fails in its torch.cat)
+            raise RuntimeError("The size of tensor a (%s) must match the size of tensor b (%d, 1): near / far planes are [n_rays, 1]" % (tuple(x.shape), n))
+        return x.reshape(-1)
     return float(x)
 
 
@@ -1129,8 +1173,6 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     """Drop-in for nerf_models/ibl_nerf_renderer.py:759-813.  `chunk` is accepted and ignored: the
     library walks the rays in workspace-sized launches and chunking never changes results."""
     _check_supported(dict(kwargs, is_depth_only=is_depth_only))
-    if c2w_staticcam is not None:
-        raise NotImplementedError("c2w_staticcam is a visualisation aid that is not built")
     from . import training as T
     training = T.is_training_call(kwargs)
     # a training step issues a dozen calls per iteration: its context checks the f16 range without synchronising (range_check="lazy":
@@ -1141,13 +1183,24 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     else:
         rays_o, rays_d = rays
         rays_o, rays_d = _dev_f32(rays_o, r.device), _dev_f32(rays_d, r.device)
+    viewdirs_src = None
+    if c2w_staticcam is not None:
+        # :791-794 "special case to visualize effect of viewdirs": the rays come from the static camera, `viewdirs` from the pose above.  In this
+        # renderer `viewdirs` reaches exactly one thing — the depth_mlp query of infer_depth (:722-726); every network query takes rays_d (:201, :445)
+        viewdirs_src = rays_d.reshape(-1, 3)
+        rays_o, rays_d = r.get_rays(H, W, K, c2w_staticcam)
+        if viewdirs_src.shape[0] != rays_d.reshape(-1, 3).shape[0]:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: viewdirs of %d rays against %d rays of the static camera (torch.cat, :806)"
+                               % (viewdirs_src.shape[0], rays_d.reshape(-1, 3).shape[0]))
     sh = rays_d.shape
     edit = {k: kwargs[k] for k in kwargs
             if k.startswith(("edit", "insert", "num_edit", "num_insert", "load_edit")) or k in FROM_GT_FLAGS}
     ro_f, rd_f = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
-    nf = (_scalar(near, "near"), _scalar(far, "far"))
+    nf = (_plane(near, ro_f.shape[0]), _plane(far, ro_f.shape[0]))
     smp = dict(perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)), chunk=chunk)
     approx = bool(kwargs.get("approximate_radiance", False))
+    if (is_depth_only or not approx or training) and (viewdirs_src is not None or any(_torch().is_tensor(v) for v in nf)):
+        raise NotImplementedError("c2w_staticcam and per-ray near / far planes are built for the inference render (approximate_radiance=True, no gradients)")
     if is_depth_only or not approx or training:
         # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
         flags_on = any(_truthy(v) for k, v in edit.items() if k in _SWITCHES or k in FROM_GT_FLAGS)
@@ -1175,6 +1228,9 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
                 ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
         return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
     ret = r.render_rays(ro_f, rd_f, *nf, kwargs.get("gt_values"), raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **smp, **edit)
+    if viewdirs_src is not None and "inferred_depth_map" in ret:      # the one consumer of `viewdirs` (:722-726): the other pose's directions, normalised (:795)
+        vd = viewdirs_src / viewdirs_src.norm(dim=-1, keepdim=True)
+        ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
     return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
 
 

@@ -447,8 +447,10 @@ static void pass(const Job* j, const Net* net, Work* k, long r0, int nr, const f
                 if (ov->edit_albedo_by_img) { if (mask_all) for (int c = 0; c < 3; ++c) albedo[c] = ov->d_albedo[3 * ray + c]; }
                 else for (int q = 0; q < ov->num_objects; ++q) if (in_mask(m_val, q)) for (int c = 0; c < 3; ++c) albedo[c] = ov->albedo_list[3 * q + c];
             }
-            if (ov->edit_roughness)
-                for (int q = 0; q < ov->n_roughness_list; ++q) if (in_mask(m_val, q)) rough = ov->roughness_list[q];
+            if (ov->edit_roughness) {
+                if (ov->edit_roughness_by_img) { if (mask_all) rough = ov->d_roughness[ray]; }                          /* :394-395, resolved per chunk by the caller (iblnerf.h) */
+                else for (int q = 0; q < ov->n_roughness_list; ++q) if (in_mask(m_val, q)) rough = ov->roughness_list[q];
+            }
         } else if (mode == 2) {                                                                                     /* :400-410 */
             if (mask_all) {
                 float g[3];

@@ -52,8 +52,11 @@ def lib():
     """The loaded library; built on first use where gcc is present (the GPU box receives the prebuilt file)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        try:
+            build()          # (a stamp of sources + flags makes this a no-op when nothing changed; a stale library would silently check against old code)
+        except Exception:
+            if not os.path.exists(LIB_PATH):     # no gcc here and no prebuilt file: nothing to load
+                raise
         L = C.CDLL(LIB_PATH)
         L.iblnerf_cpu_last_error.restype = C.c_char_p
         L.iblnerf_cpu_isa.restype = C.c_char_p
@@ -182,8 +185,6 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
     left = {k: v for k, v in flags.items() if v}
     if left:
         raise NotImplementedError("flags not restated in C (the numpy oracle has them): %s" % sorted(left))
-    if edit.get("edit_roughness_by_img"):
-        raise NotImplementedError("edit_roughness_by_img (ibl_nerf_renderer.py:394-395) is not restated in C")
     assert not (edit.get("edit_intrinsic") and edit.get("insert_object")), "edit_intrinsic and insert_object cannot be True at the same time"   # :218
     ro, rd = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
     n = ro.shape[0]
@@ -213,6 +214,12 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near, far, lut, n_samples=64
             rgh = list(edit.get("editing_target_roughness_list") or [])
             alb = list(edit.get("editing_target_albedo_list") or [])
             ov.n_roughness_list = len(rgh)
+            if ov.edit_roughness and edit.get("edit_roughness_by_img"):     # :394-395: the first masked row (one chunk = this call), handed over per ray
+                m = np.asarray(gt["edit_intrinsic_mask"], dtype=F32).reshape(n, -1)[:, 0] > 0
+                img = np.asarray(gt["edit_roughness"], dtype=F32).reshape(n, -1)
+                per_ray = np.full((n,), img[m][0][0] if m.any() else 0.0, dtype=F32)
+                keep.append(per_ray)
+                ov.edit_roughness_by_img, ov.d_roughness = 1, per_ray.ctypes.data
         elif edit.get("insert_object"):
             ov.mode, ov.num_objects = 2, int(edit["num_insert_objects"])
             ov.d_mask, ov.d_depth, ov.d_normal = rows("object_insert_mask", 3), rows("object_insert_depth", 1), rows("object_insert_normal", 3)

@@ -608,8 +608,12 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
                 for q in range(edit["num_edit_objects"]):
                     albedo[masks[q]] = lst[3 * q:3 * q + 3]
         if edit.get("edit_roughness"):
-            for q, r in enumerate(edit["editing_target_roughness_list"]):
-                rough[masks[q]] = F32(r)
+            if edit.get("edit_roughness_by_img"):                                           # :394-395: the FIRST masked row of this call's rays, for all of them
+                if mask_all.any():
+                    rough[mask_all] = np.asarray(gt["edit_roughness"], dtype=F32).reshape(len(rough), -1)[mask_all][0][0]
+            else:
+                for q, r in enumerate(edit["editing_target_roughness_list"]):
+                    rough[masks[q]] = F32(r)
     elif edit.get("insert_object"):                                                         # :400-410
         normal[mask_all] = normalize(F32(2) * gt["object_insert_normal"] - F32(1))[mask_all]
         al = np.asarray(edit["inserting_target_albedo_list"], dtype=F32)
@@ -632,7 +636,9 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
     refl_pts = (x_surface[:, None, :] + refl_d[:, None, :] * z_const[:, :, None]).astype(F32)   # :440
     refl_raw = teacher["refl_raw"] if "refl_raw" in teacher else network_query(sd, refl_pts, refl_d)   # :445
     pref_maps = composite_reflected(refl_raw, z_const, refl_d, radiance_f)                  # :446-448
-    depth_0 = F32((F32(far) + F32(near)) * F32(0.5))                                        # :456
+    depth_0 = ((np.asarray(far, dtype=F32) + np.asarray(near, dtype=F32)) * F32(0.5)).astype(F32)   # :456
+    if depth_0.ndim:
+        depth_0 = depth_0.reshape(-1)                                                       # per-ray planes [N, 1]: depth_0[..., 0] (:458)
     if flags.get("correct_depth_for_prefiltered_radiance_infer", True):
         level = np.clip(rough_net * depth / depth_0, 0, 1).astype(F32)                      # :458-459 (roughness_map)
     else:
@@ -671,11 +677,13 @@ def raw2outputs(sd, rays_o, rays_d, z_vals, z_const, near, far, lut, gt=None, ed
 # render_rays / render_decomp — ibl_nerf_renderer.py:629-732, :759-813 (perturb=0, raw_noise_std=0)
 # --------------------------------------------------------------------------------------------
 def coarse_z(near, far, n_samples, n_rays, lindisp=False):
+    """near / far: scalars, or one plane per ray as [n_rays, 1] arrays (render_decomp :802-805 broadcasts them against rays_d[..., :1])."""
     t = torch_linspace(0, 1, n_samples)
+    near, far = np.asarray(near, dtype=F32), np.asarray(far, dtype=F32)
     if lindisp:                                                                            # :674
-        z = (F32(1) / (F32(1) / F32(near) * (F32(1) - t) + F32(1) / F32(far) * t)).astype(F32)
+        z = (F32(1) / (F32(1) / near * (F32(1) - t) + F32(1) / far * t)).astype(F32)
     else:
-        z = (F32(near) * (F32(1) - t) + F32(far) * t).astype(F32)                          # :672
+        z = (near * (F32(1) - t) + far * t).astype(F32)                                    # :672
     return np.broadcast_to(z, (n_rays, n_samples)).copy()
 
 

@@ -64,7 +64,7 @@ def rel_linf(x, ref):
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
-                   "infernormal_surface_g10", "inferdepth_g10"]
+                   "infernormal_surface_g10", "inferdepth_g10", "edit3_g10"]
 FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert", "fitted_wide"]   # rendered by the reference from the fitted checkpoint (fitted_wide: 1 024 rays, maps only)
 
 

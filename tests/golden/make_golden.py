@@ -351,6 +351,13 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
         gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
         gt["edit_depth"] = rng.uniform(1, 3, (n_rays, 1)).astype(np.float32)
         gt["edit_albedo"] = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+    elif mode == "edit3":  # edit_roughness_by_img (ibl_nerf_renderer.py:394-395): EVERY masked pixel takes the FIRST masked row of gt_values["edit_roughness"]
+        edit.update(edit_intrinsic=True, num_edit_objects=2, edit_roughness=True, edit_roughness_by_img=True,
+                    editing_target_roughness_list=[0.9, 0.9])   # must be non-empty (:392 assert) though the image wins
+        level = rng.choice([0, 10, 20], size=n_rays, p=[0.5, 0.3, 0.2]).astype(np.float32) / np.float32(255)
+        level[:3] = 0                                             # (the first masked row is not row 0)
+        gt["edit_intrinsic_mask"] = np.repeat(level[:, None], 3, 1).astype(np.float32)
+        gt["edit_roughness"] = rng.uniform(0.05, 0.95, (n_rays, 1)).astype(np.float32)
     elif mode == "gtnormal":  # target_normal_map_for_radiance_calculation = "ground_truth" (the parser's default), one edit on top
         edit.update(edit_intrinsic=True, num_edit_objects=1, edit_roughness=True, editing_target_roughness_list=[0.25])
         level = rng.choice([0, 10], size=n_rays, p=[0.6, 0.4]).astype(np.float32) / np.float32(255)
@@ -489,6 +496,64 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     np.savez_compressed(path, **out)
     print("%-28s %4d rays  %s  color range [%.3f, %.3f]  %.2f MB" % (
         name, n_rays, mode, float(ret["color_map"].min()), float(ret["color_map"].max()), os.path.getsize(path) / 1e6))
+
+
+def seam_fixture(name, torch, R, M, lut, kind, seed):
+    """Two arguments of render_decomp itself (ibl_nerf_renderer.py:759-813) on random-init networks, 64 + 128 samples:
+    "staticcam"  c2w + c2w_staticcam (:791-794): the rays come from the static camera, `viewdirs` from the other pose — they reach nothing but the
+                 depth_mlp query of infer_depth (:722-726; every network query takes rays_d), so the fixture runs with infer_depth;
+    "nearfar"    per-ray near / far planes as [n, 1] tensors (:802-805): a z grid per ray (:668-674) and a per-ray depth_0 in the mip level (:456)."""
+    tmp = tempfile.mkdtemp()
+    try:
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, 128, 64, infer_depth=(kind == "staticcam")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    sd_c, sd_f = ck.synthetic_state_dict(seed=2 * seed, gain=1.0), ck.synthetic_state_dict(seed=2 * seed + 1, gain=1.0)
+    kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
+    kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    kw["brdf_lut"] = lut
+    rng = np.random.RandomState(2000 + seed)
+    out = dict(gain=np.float64(1.0), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1), n_importance=np.int64(128), n_samples=np.int64(64),
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))), ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
+               mode=np.array(kind))
+
+    def pose(shift):
+        q, _ = np.linalg.qr(np.eye(3) + 0.3 * rng.randn(3, 3))
+        q = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+        return np.concatenate([q, np.asarray(shift, np.float32).reshape(3, 1)], 1).astype(np.float32)
+
+    if kind == "staticcam":
+        aux_seed = 100 * seed + 1
+        kw["depth_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in ck.synthetic_position_direction_mlp(aux_seed, 1, 1.0).items()})
+        H, W = 10, 12
+        f = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
+        K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=np.float32)
+        c2w, c2w_static = pose([0.3, -0.2, 0.4]), pose([-0.1, 0.25, 0.2])
+        kw.update(near=0.5, far=8.0)
+        with torch.no_grad():
+            ret = R.render_decomp(H, W, K, chunk=H * W, c2w=torch.from_numpy(c2w), c2w_staticcam=torch.from_numpy(c2w_static), gt_values={},
+                                  approximate_radiance=True, **kw, **EDIT_KEYS_OFF)
+            plain = R.render_decomp(H, W, K, chunk=H * W, c2w=torch.from_numpy(c2w_static), gt_values={}, approximate_radiance=True, **kw, **EDIT_KEYS_OFF)
+        # (what the argument changes, recorded as a fact: only inferred_depth_map differs from a plain render from the static pose)
+        assert all(torch.equal(ret[k], plain[k]) for k in ret if k != "inferred_depth_map") and not torch.equal(ret["inferred_depth_map"], plain["inferred_depth_map"])
+        out.update(H=np.int64(H), W=np.int64(W), K=K, c2w=c2w, c2w_staticcam=c2w_static, near=np.float32(0.5), far=np.float32(8.0))
+        out["aux__depth_mlp"] = np.int64(aux_seed)
+        out["flag__infer_depth"] = np.asarray(True)
+    else:
+        n = 96
+        o, d, pix, focal = camera_rays(rng, n)
+        near = (0.4 + 0.6 * rng.uniform(0, 1, (n, 1))).astype(np.float32)
+        far = (6.0 + 3.0 * rng.uniform(0, 1, (n, 1))).astype(np.float32)
+        K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
+        with torch.no_grad():
+            ret = R.render_decomp(800, 800, K, chunk=n, rays=torch.from_numpy(np.stack([o, d], 0)), near=torch.from_numpy(near), far=torch.from_numpy(far),
+                                  gt_values={}, approximate_radiance=True, **kw, **EDIT_KEYS_OFF)
+        out.update(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=near, far=far)
+    for k, v in ret.items():
+        out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %s  %d maps  %.2f MB" % (name, kind, len(ret), os.path.getsize(path) / 1e6))
 
 
 def train_step_fixture(torch, R, M, lut, n_rays=64):
@@ -928,6 +993,11 @@ def main(only=None):
                 flags=dict(use_radiance_linear=True, lindisp=True, lut_coefficient="F0"))
     # image-driven edits (edit_depth, edit_albedo_by_img) — flags of config_parser.py:246-256 the shipped edit config leaves off
     run_fixture("edit2_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=5, mode="edit2")
+    # edit_roughness_by_img (:394-395; first-masked-row semantics), and two arguments of render_decomp itself: c2w_staticcam, per-ray near / far
+    run_fixture("edit3_g10", torch, R, M, lut, n_rays=96, n_importance=128, gain=1.0, seed=40, mode="edit3")
+    for nm, kind, sd_ in (("staticcam_g10", "staticcam", 41), ("nearfar_g10", "nearfar", 42)):
+        if not only or nm in only:
+            seam_fixture(nm, torch, R, M, lut, kind, sd_)
     # other sample counts / epsilon / planes / no gamma / roughness-only mip level, posed camera
     run_fixture("variant_small_g10", torch, R, M, lut, n_rays=96, n_importance=48, gain=1.0, seed=6, n_samples=32,
                 near=1.0, far=5.0, posed=True,

@@ -19,7 +19,7 @@ REFLECTED = ["reflected_radiance_map", "prefiltered_reflected_map", "reflected_c
 # the fixtures whose flags the C path restates (shipped configs + lindisp / linear radiance / F0 / sample counts / epsilon / no gamma /
 # ground-truth normals / colour-independent networks); the other variants (aux networks, *_from_gt, the other normal modes) are the numpy oracle's
 C_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10", "edit2_g10", "variant_small_g10",
-              "gtnormal_g10", "colorindep_g10"]
+              "gtnormal_g10", "colorindep_g10", "edit3_g10"]
 
 
 def test_library_exports_and_struct_mirror():

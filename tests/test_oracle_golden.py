@@ -353,3 +353,33 @@ def test_network_backward_against_reference_autograd():
     assert rel_linf(dp, g["dpts"]) <= 5e-6 and len(grads) == 46
     for k, v in grads.items():
         assert v.shape == g["grad__" + k].shape and rel_linf(v, g["grad__" + k]) <= 5e-6, k
+
+
+def test_per_ray_planes_and_static_camera_fixtures(lut):
+    """Two arguments of render_decomp itself as the reference runs them (fixtures nearfar_g10, staticcam_g10; make_golden.py seam_fixture):
+    per-ray near / far planes ([n, 1]: a z grid per ray, a mip-level depth_0 per ray, ibl_nerf_renderer.py:802-805, :668-674, :456) and c2w_staticcam
+    (:791-794: rays from the static pose; the other pose's directions reach only the depth_mlp query of infer_depth)."""
+    g, sdc, sdf, _, _ = load_golden("nearfar_g10")
+    assert g["near"].shape == (96, 1) and np.ptp(g["near"]) > 0.3 and np.ptp(g["far"]) > 1.0
+    res = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], g["near"], g["far"], lut)
+    assert sorted(res) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= (2e-5 if sfx == "" else 5e-6), k + sfx
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 6e-4, k + sfx
+    # the planes matter: the same rays between the scalar planes of the other fixtures give other depths
+    other = O.render_rays(sdc, sdf, g["rays_o"], g["rays_d"], 0.5, 8.0, lut)
+    assert rel_linf(other["depth_map"], g["out__depth_map"]) > 1e-2
+    g, sdc, sdf, _, _ = load_golden("staticcam_g10")
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = O.get_rays(H, W, g["K"], g["c2w_staticcam"])
+    _, vd = O.get_rays(H, W, g["K"], g["c2w"])
+    res = O.render_rays(sdc, sdf, ro.reshape(-1, 3), rd.reshape(-1, 3), float(g["near"]), float(g["far"]), lut)
+    for k in ("depth_map", "albedo_map", "weights0", "radiance_map"):
+        assert rel_linf(res[k], g["out__" + k].reshape(res[k].shape)) <= 2e-5, k
+    vdn = (vd / np.linalg.norm(vd, axis=-1, keepdims=True)).reshape(-1, 3).astype(np.float32)
+    from ibl_nerf_amd import checkpoint as ck
+    dm = ck.synthetic_position_direction_mlp(int(g["aux__depth_mlp"]), 1, 1.0)
+    inferred = np.maximum(O.position_direction_mlp_query(dm, ro.reshape(-1, 1, 3), vdn)[:, 0, 0], 0)
+    assert rel_linf(inferred, g["out__inferred_depth_map"].reshape(-1)) <= 1e-5 and np.ptp(inferred) > 0
