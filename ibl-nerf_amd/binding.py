@@ -23,7 +23,7 @@ EXPORTS = [
     "iblnerf_trunk_features2", "iblnerf_trunk_features2_backward", "iblnerf_network_backward",
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
-    "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing",
+    "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges",
 ]
 
 
@@ -123,6 +123,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.iblnerf_range_peek.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.iblnerf_range_peek.restype = C.c_int
+    lib.iblnerf_layer_ranges.argtypes = [C.c_void_p, C.c_void_p, FP, C.c_size_t, FP, FP, C.c_int64, FP]
+    lib.iblnerf_layer_ranges.restype = C.c_int
     lib.iblnerf_set_query_routing.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_set_query_routing.restype = C.c_int
     lib.iblnerf_range_flags_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -57,6 +57,7 @@ SOURCES = [
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("posdir_kernel.hip", []),
+    ("range_kernel.hip", []),
     ("wgrad_kernel.hip", []),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),

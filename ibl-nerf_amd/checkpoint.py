@@ -57,6 +57,55 @@ def synthetic_state_dict(seed: int, gain: float = 1.0, sigma_bias: float = 0.3) 
     return sd
 
 
+# the 15 wide activations of IBLNeRF.forward in the order iblnerf_layer_ranges reports them (include/iblnerf.h)
+ACTIVATIONS = tuple("positions_linears.%d" % i for i in range(8)) + ("feature_linear", "albedo_feature_linear", "irradiance_feature_linear", "views_linears.0") \
+    + tuple("additional_radiance_feature_linear.%d" % i for i in range(3))
+
+
+def scale_activations(sd, t, color_independent=False):
+    """The same network with activation `name` held as t[name] * (its value): an EXACT reparametrisation when every t is a power of two
+    (relu(t x) = t relu(x) for t > 0; a power-of-two factor changes no mantissa) — each producing layer's weight and bias take t_out / t_in
+    per input column block and t_out, each consumer's columns 1 / t_in, the N = 1 / 3 heads included, so the raw outputs are unchanged.
+    `t`: {activation name (ACTIVATIONS): factor}, missing = 1.  Used by the renderer's f16 range policy: a checkpoint whose activations leave
+    the f16 range (65504) is rescaled until they fit instead of being given to the 2^-17 bf16x3 kernels.  Works on numpy arrays and torch tensors."""
+    g = lambda k: float(t.get(k, 1.0))
+    out = OrderedDict((k, v.copy() if isinstance(v, np.ndarray) else v.clone()) for k, v in sd.items())
+
+    def produce(name, t_out, col_blocks):
+        """weight columns [c0, c1) scaled by t_out / t_in for each (c0, c1, t_in); bias by t_out"""
+        w = out[name + ".weight"]
+        for c0, c1, t_in in col_blocks:
+            w[:, c0:c1] *= np.float32(t_out / t_in)
+        out[name + ".bias"] *= np.float32(t_out)
+
+    def consume(name, t_in):
+        out[name + ".weight"] *= np.float32(1.0 / t_in)
+
+    P = "positions_linears.%d"
+    produce(P % 0, g(P % 0), [(0, 63, 1.0)])
+    for l in (1, 2, 3, 4, 6, 7):
+        produce(P % l, g(P % l), [(0, 256, g(P % (l - 1)))])
+    produce(P % 5, g(P % 5), [(0, 63, 1.0), (63, 319, g(P % 4))])                      # cat([x63, h]) (ibl_nerf.py:168)
+    t7 = g(P % 7)
+    consume("sigma_linear", t7)
+    consume("roughness_linear", t7)
+    produce("albedo_feature_linear", g("albedo_feature_linear"), [(0, 256, t7)])
+    consume("albedo_linear", g("albedo_feature_linear"))
+    produce("irradiance_feature_linear", g("irradiance_feature_linear"), [(0, 256, t7)])
+    consume("irradiance_linear", g("irradiance_feature_linear"))
+    t2 = t7                                                                              # what the radiance heads read
+    if not color_independent:
+        produce("feature_linear", g("feature_linear"), [(0, 256, t7)])
+        produce("views_linears.0", g("views_linears.0"), [(0, 256, g("feature_linear")), (256, 283, 1.0)])   # cat([feature, dir27]) (:194)
+        t2 = g("views_linears.0")
+    consume("radiance_linear", t2)
+    for k in range(3):
+        n = "additional_radiance_feature_linear.%d" % k
+        produce(n, g(n), [(0, 256, t2)])
+        consume("additional_radiance_linear.%d" % k, g(n))
+    return out
+
+
 # Auxiliary PositionMLPs (src/networks/MLP.py:6-30, ibl_nerf.py:312-326): the main network's trunk shape + out_linears
 AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1, "normal_mlp": 3}
 TRUNK_SCHEMA = tuple(e for e in SCHEMA if e[0].startswith("positions_linears."))

@@ -945,6 +945,23 @@ int iblnerf_range_peek(iblnerf_ctx* c, int* out_of_range, int* pending) {
     return IBLNERF_OK;
 }
 
+int iblnerf_layer_ranges(iblnerf_ctx* c, void* stream, const float* d_blob, size_t n_floats, const float* d_pts, const float* d_dirs, int64_t n_pts, float* d_max) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!d_blob || !d_max || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_dirs))) return c->fail(IBLNERF_ERR_INVALID, "layer_ranges: bad arguments");
+    if (n_floats != blob_floats()) return c->fail(IBLNERF_ERR_INVALID, "layer_ranges: blob has %zu floats, the IBLNeRF state dict has %zu", n_floats, blob_floats());
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipMemsetAsync(d_max, 0, 15 * sizeof(float), (hipStream_t)stream));
+    LayerRangeArgs a{};
+    a.blob = d_blob; a.pts = d_pts; a.dirs = d_dirs; a.n = (long)n_pts; a.color_independent = c->opt.color_independent_to_direction; a.d_max = d_max;
+    for (int l = 0; l < 23; ++l) {
+        size_t w, b;
+        blob_offsets(l, &w, &b);
+        a.w_off[l] = (long)w; a.b_off[l] = (long)b;
+    }
+    HIP_TRY(c, launch_layer_ranges(a, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
 int iblnerf_range_flags_async(iblnerf_ctx* c, void* stream, uint32_t* d_out) {
     if (!c || !d_out) return IBLNERF_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->opt.device));

@@ -185,6 +185,18 @@ struct PosDirArgs {
 };
 constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (319L * 256 + 256) + 2 * (256L * 256 + 256) + (256L * 256 + 256) +
                                     (283L * 128 + 128) + 3 * (128L * 128 + 128) + (128L * 1 + 1);
+// iblnerf_layer_ranges (range_kernel.hip): largest |value| of each of a network's 15 wide activations on n points; blob = the fp32 state dict in device memory
+struct LayerRangeArgs {
+    const float* blob;
+    long w_off[23], b_off[23];   // float offsets of every layer's weight / bias in the blob (pack.cpp: blob_offsets)
+    const float* pts;            // [n, 3]
+    const float* dirs;           // [n, 3] view direction per point (as the network takes it: rays_d, not normalised)
+    long n;
+    int color_independent;
+    float* d_max;                // [15] (zeroed by the caller): trunk 0-7, feature_linear, albedo feature, irradiance feature, views_linears.0, additional radiance features 0-2
+};
+hipError_t launch_layer_ranges(const LayerRangeArgs& a, hipStream_t s);
+
 hipError_t launch_posdir_mlp(const PosDirArgs& a, hipStream_t s);
 
 // Weight gradient of the trunk from the backward kernel's operand stash (wgrad_kernel.hip; layout.h: STASH_*).

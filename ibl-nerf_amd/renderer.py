@@ -137,6 +137,8 @@ class Renderer:
                           infer_normal_at_surface=infer_normal_at_surface, range_check=range_check, persistent_workgroups=persistent_workgroups)
         self._aux = {}               # auxiliary networks in effect (replayed on the bf16x3 twin)
         self._chunk = None
+        self._act_scale = {}         # network slot -> {activation: power-of-two factor} of the f16 range policy (see _rescale_into_range)
+        self.range_rescales = 0
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._twin_ref = None        # (mode, Renderer) of precision_report
@@ -167,6 +169,10 @@ class Renderer:
         or numpy arrays) or an already-flattened blob.  Parameters that live on this GPU are flattened and packed
         on the device (one torch.cat + one pack kernel on the current stream: no host copy, no synchronisation);
         anything else goes through the host packer."""
+        self._act_scale.pop(int(which), None)        # the caller's own weights: any range rescaling of the previous ones is gone
+        self._upload(which, state_dict_or_blob, remember=True)
+
+    def _upload(self, which, state_dict_or_blob, remember):
         torch = _torch()
         blob = state_dict_or_blob
         if isinstance(blob, dict) and blob and all(torch.is_tensor(v) and v.is_cuda for v in blob.values()):
@@ -184,6 +190,8 @@ class Renderer:
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
         if int(which) == 1:
             self.has_fine = True
+        if not remember:
+            return
         if self._auto:
             self.policy = None          # another checkpoint: measured again on the next frame-sized call
         if self.mlp_precision != "bf16x3":
@@ -261,6 +269,47 @@ class Renderer:
         flag = C.c_int()
         B.check(self.ctx, self.lib.iblnerf_range_status(self.ctx, C.byref(flag)))
         return int(flag.value)
+
+    RANGE_TARGET = 2048.0      # largest activation after rescaling (on the sampled points): a factor 32 below the f16 limit for the points not sampled
+
+    def _rescale_into_range(self, pts, dirs):
+        """An f16 range event, answered at full precision: measure every wide activation of the loaded networks on (a sample of) the call's points
+        (iblnerf_layer_ranges: plain fp32), and re-upload each network as the SAME function with its activations scaled by powers of two
+        (checkpoint.scale_activations: exact) so that the largest sits at RANGE_TARGET.  Returns False when nothing could be gained (the overflow
+        is not an activation's: an input beyond the range, an auxiliary network, weights beyond the range) — the caller then falls back to
+        the bf16x3 kernels as before."""
+        torch = _torch()
+        if not self._blobs or any(v is not None for v in self._aux.values()):
+            return False
+        pts = _dev_f32(pts, self.device).reshape(-1, 3)
+        dirs = _dev_f32(dirs, self.device).reshape(-1, 3)
+        if pts.shape[0] == 0 or not bool(torch.isfinite(pts).all()) or float(pts.abs().max()) >= 65504.0:      # (the encoding carries x itself: an input out of range)
+            return False
+        step = max(1, pts.shape[0] // 65536)
+        pts, dirs = pts[::step].contiguous(), dirs[::step].contiguous()
+        changed = False
+        ci = bool(self.opt.color_independent_to_direction)
+        for which, blob in list(self._blobs.items()):
+            if torch.is_tensor(blob):
+                blob = blob.detach().cpu().numpy()
+            sd = ck.blob_to_state_dict(np.ascontiguousarray(blob, dtype=np.float32)) if isinstance(blob, np.ndarray) else blob
+            if not bool(np.all(np.abs(ck.state_dict_to_blob(sd)) < 65504.0)):
+                return False                     # a weight beyond the range: that network runs on bf16x3 whatever the activations do
+            dblob = torch.from_numpy(ck.state_dict_to_blob(sd)).to(self.device)
+            dmax = torch.empty((15,), dtype=torch.float32, device=self.device)
+            B.check(self.ctx, self.lib.iblnerf_layer_ranges(self.ctx, self._stream(), dblob.data_ptr(), dblob.numel(), pts.data_ptr(), dirs.data_ptr(), pts.shape[0],
+                                                            dmax.data_ptr()))
+            mx = dmax.cpu().numpy().astype(np.float64)
+            if not np.all(np.isfinite(mx)):
+                return False
+            t = {name: 2.0 ** -max(0, int(np.ceil(np.log2(m / self.RANGE_TARGET)))) for name, m in zip(ck.ACTIVATIONS, mx) if m > self.RANGE_TARGET}
+            if t != self._act_scale.get(which, {}) and t:
+                self._upload(which, ck.scale_activations(sd, t, ci), remember=False)
+                self._act_scale[which] = t
+                changed = True
+        if changed:
+            self.range_rescales += 1
+        return changed
 
     def _wide_twin(self, count=True):
         """The bf16x3 context a call is repeated on after an out-of-range event."""
@@ -471,7 +520,7 @@ class Renderer:
                                                     c2w_h.ctypes.data, int(row0), int(n_rows), ro.data_ptr(), rd.data_ptr()))
         return ro, rd
 
-    def network_query(self, inputs, viewdirs, which=0):
+    def network_query(self, inputs, viewdirs, which=0, _retry=False):
         torch = _torch()
         inputs = _dev_f32(inputs, self.device)
         N, S = inputs.shape[0], inputs.shape[1]
@@ -485,6 +534,8 @@ class Renderer:
         B.check(self.ctx, self.lib.iblnerf_network_query(self.ctx, self._stream(), int(which), inputs.data_ptr(), N, S,
                                                          None if vd is None else vd.data_ptr(), out.data_ptr()))
         if not lazy and self.out_of_range():
+            if not _retry and self._rescale_into_range(inputs, (vd if vd is not None else torch.zeros((N, 3), device=self.device))[:, None, :].expand(N, S, 3)):
+                return self.network_query(inputs, vd, which, _retry=True)
             return self._wide_twin().network_query(inputs, vd, which)
         return out
 
@@ -637,6 +688,9 @@ class Renderer:
         ON THE DEVICE, the kernels run at the context's persistent scale, a call whose gradients overflowed returns all-zero gradients (a skipped
         step, as under torch.cuda.amp) and the scale steps down when a later call sees the flag."""
         torch = _torch()
+        if self._act_scale:
+            raise FloatingPointError(who + ": this context holds a network rescaled into the f16 range (an earlier forward left it); its gradients "
+                                           "would be those of the rescaled parameters — the fused backward is not built for that")
         if self.range_check == "lazy" and grad_scale is None and up.numel():
             self._lazy_poll()
             if self._force_wide:
@@ -764,7 +818,7 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, _retry=False, **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
         (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
         perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
@@ -860,8 +914,18 @@ class Renderer:
                                                               C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            return self._wide_twin().render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb, pytest=pytest,
-                                                 chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
+            again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
+            if not _retry and n:
+                # the coarse grid's points of (up to) 1 024 of the call's rays: where both networks are evaluated, within the margin RANGE_TARGET leaves
+                idx = torch.linspace(0, n - 1, min(n, 1024), device=self.device).long()
+                nr = planes[0][idx, None] if planes else torch.full((len(idx), 1), float(near), device=self.device)
+                fr = planes[1][idx, None] if planes else torch.full((len(idx), 1), float(far), device=self.device)
+                tt = torch.linspace(0.0, 1.0, self.N_samples, device=self.device)[None, :]
+                z = nr * (1.0 - tt) + fr * tt
+                pts = rays_o[idx, None, :] + rays_d[idx, None, :] * z[..., None]
+                if self._rescale_into_range(pts, rays_d[idx, None, :].expand_as(pts)):
+                    return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, _retry=True, **again)
+            return self._wide_twin().render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, **again)
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:

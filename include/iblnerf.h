@@ -482,6 +482,16 @@ int iblnerf_range_peek(iblnerf_ctx* ctx, int* out_of_range, int* pending);
  * Writes 0 for IBLNERF_MLP_BF16X3. */
 int iblnerf_range_flags_async(iblnerf_ctx* ctx, void* stream, uint32_t* d_out);
 
+/* Largest magnitude of each of a network's 15 wide activations (IBLNeRF.forward, ibl_nerf.py:154-210) on a sample of points — a measurement
+ * for the caller's range policy (no reference counterpart: fp32 has the range).  d_blob = the state dict as iblnerf_upload_weights_device takes it,
+ * d_pts / d_dirs [n_pts, 3] (one view direction per point, as the network receives it), d_max [15] floats, written (not accumulated):
+ * positions_linears.0-7, feature_linear, albedo_feature_linear, irradiance_feature_linear, views_linears.0, additional_radiance_feature_linear.0-2
+ * (entries 8 and 11 stay 0 for colour-independent networks).  Plain fp32 arithmetic.  ibl-nerf_amd/renderer.py answers an f16 range event with it:
+ * the network is rescaled by powers of two (exact: relu(t x) = t relu(x)) until every activation fits, and only then — or if that fails — falls
+ * back to IBLNERF_MLP_BF16X3. */
+int iblnerf_layer_ranges(iblnerf_ctx* ctx, void* stream, const float* d_blob, size_t n_floats, const float* d_pts, const float* d_dirs, int64_t n_pts,
+                         float* d_max);
+
 /* Host-only: the f16 (hi, lo) form of iblnerf_pack_weights_host's stream (IBLNERF_MLP_F16X3), same sizes. */
 int iblnerf_pack_weights_host_f16x3(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
                                     float* h_tables, size_t table_floats);

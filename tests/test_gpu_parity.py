@@ -448,9 +448,11 @@ def test_training_query_fn_dispatch(R, lut):
 
 @pytest.mark.parametrize("prec", F16_MODES)
 def test_f16_range_fallback(R, lut, prec):
-    """An f16 mode on a checkpoint whose activations leave the f16 range: the kernel flags it (f16 + MX-fp6: running maximum
-    of the converted values; f16x3: the overflow turns into NaN outputs, which the kernel's tail checks) and the call is
-    repeated on the bf16x3 twin, so the caller gets exactly the bf16x3 result."""
+    """An f16 mode on a checkpoint whose activations leave the f16 range (a gain of 16 per trunk layer: 16^8 through the trunk).  The kernel flags it
+    (f16 + MX-fp6: running maximum of the converted values; f16x3: the overflow turns into NaN outputs, which the kernel's tail checks); the renderer
+    measures every activation's magnitude on the call's points (iblnerf_layer_ranges), re-uploads the network as the SAME function with its
+    activations scaled by powers of two (checkpoint.scale_activations: exact) and repeats the call on the f16 kernels — at their own precision, not
+    bf16x3's 2^-17.  Where rescaling cannot help (an input beyond the range) the call still goes to the bf16x3 twin."""
     from ibl_nerf_amd import checkpoint as ck
     g, _, _, _, _ = load_golden("plain_g10")
     sd = {k: (v * np.float32(16.0) if k.endswith("weight") and k.startswith("positions_linears") else v)
@@ -462,11 +464,57 @@ def test_f16_range_fallback(R, lut, prec):
         r.load_lut(lut)
     pts, dirs = g["q_c_main_pts"], g["q_c_main_dirs"]
     a, b = fast.network_query(pts, dirs, 0), wide.network_query(pts, dirs, 0)
-    assert fast.range_fallbacks == 1 and torch.equal(a, b) and bool(torch.isfinite(b).all())
+    assert fast.range_rescales == 1 and fast.range_fallbacks == 0 and bool(torch.isfinite(a).all())
+    ref = O.network_query(sd, pts, dirs)
+    scale = np.abs(ref).max((0, 1))
+    ea, eb = (np.abs(x.cpu().numpy() - ref).max((0, 1)) / scale for x in (a, b))
+    tol = 2e-4 if prec in ("f16_mxfp6",) else 2e-5                 # (2^-16 operands in every query of that mode)
+    assert ea.max() <= tol, (prec, ea)
+    assert prec == "f16_mxfp6" or ea.max() <= 0.5 * eb.max(), (ea.max(), eb.max())      # ... which the bf16x3 twin does not reach
+    t = fast._act_scale[0]
+    assert all(v < 1.0 and np.log2(v) == int(np.log2(v)) for v in t.values()) and t["positions_linears.7"] <= 2.0 ** -10
+    a2 = fast.network_query(pts, dirs, 0)                         # the rescaled network stays: no second event
+    assert fast.range_rescales == 1 and torch.equal(a, a2)
     ra = fast.render_rays(g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0)
-    rb = wide.render_rays(g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0)
-    assert fast.range_fallbacks == 2 and all(torch.equal(ra[k], rb[k]) for k in rb)
+    assert fast.range_fallbacks == 0 and all(bool(torch.isfinite(v).all()) for k, v in ra.items() if not k.startswith("disp"))
+    rb = O.render_rays(sd, None, g["rays_o"][:16], g["rays_d"][:16], 0.5, 8.0, lut, 64, 0)
+    for k in ("depth_map", "albedo_map", "roughness_map", "radiance_map", "weights"):
+        assert rel_linf(ra[k].cpu().numpy(), rb[k]) <= 2e-4, k
+    if prec.startswith("f16x3"):                                  # (the modes that keep the backward's stream)
+        with pytest.raises(FloatingPointError):                   # gradients of a rescaled network are those of other parameters: refused
+            fast.trunk_backward(pts.reshape(-1, 3), np.ones(pts.shape[0] * pts.shape[1], np.float32), 0)
+    fast.load_weights(0, sd)                                      # the caller's own upload forgets the rescaling
+    assert fast._act_scale == {}
+    # an input beyond the range: nothing to rescale, the bf16x3 twin answers
+    far_pts = pts.copy()
+    far_pts[0, 0, 0] = np.float32(7.0e4)
+    fast2 = R.Renderer(64, 0, max_rays_per_launch=64, mlp_precision=prec)
+    fast2.load_weights(0, ck.synthetic_state_dict(0))
+    wide.load_weights(0, ck.synthetic_state_dict(0))
+    c, d = fast2.network_query(far_pts, dirs, 0), wide.network_query(far_pts, dirs, 0)
+    assert fast2.range_fallbacks == 1 and fast2.range_rescales == 0 and torch.equal(c, d)
     assert not wide.out_of_range()
+
+
+def test_a_checkpoint_beyond_the_f16_range_renders_at_full_precision(R, lut):
+    """the range fallback must be parity-grade.  The fitted checkpoint reparametrised so that its later trunk activations reach 1e6
+    (checkpoint.scale_activations with factors 2^14: the SAME function bit for bit in fp32, as the oracle confirms) on 4 096 rays of the reference's own
+    launch-scale render: a default-constructed renderer hits the range event on its first launch, rescales by measurement and holds the launch-scale
+    rules (direct maps <= 5e-4 or 8x the ray's own reference sensitivity, ...) that the plain checkpoint holds — no bf16x3 launch anywhere."""
+    import test_gpu_launch_scale as LS
+    from ibl_nerf_amd import checkpoint as ck
+    g, sdc, sdf, gt, edit = load_golden("fitted_posed4k")
+    up = {k: 2.0 ** 14 for k in ck.ACTIVATIONS[3:8]}
+    up.update({"feature_linear": 2.0 ** 13, "views_linears.0": 2.0 ** 15, "albedo_feature_linear": 2.0 ** 12})
+    big_c, big_f = ck.scale_activations(sdc, up), ck.scale_activations(sdf, up)
+    p = g["rays_o"][:8, None, :] + g["rays_d"][:8, None, :] * np.linspace(0.5, 8, 64, dtype=np.float32)[None, :, None]
+    assert np.array_equal(O.network_query(big_f, p, g["rays_d"][:8]), O.network_query(sdf, p, g["rays_d"][:8]))        # the same function
+    r = make_renderer(R, g, big_c, big_f, lut, max_rays_per_launch=16384)
+    res = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0, gt, **edit))
+    assert r.range_rescales >= 1 and r.range_fallbacks == 0 and r._wide is None
+    assert r.policy["decision"] == "fast"
+    LS.check_against_fixture(res, g, rules=LS.rules_for("fitted_posed4k"))
+    assert max(r._act_scale[1].values()) <= 2.0 ** -5 and set(r._act_scale[1]) >= set(ck.ACTIVATIONS[3:8])
 
 
 @pytest.mark.parametrize("prec", F16_MODES)
