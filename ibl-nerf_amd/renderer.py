@@ -794,6 +794,22 @@ class Renderer:
             torch.cuda.current_stream(self.device).synchronize()       # `u` must outlive the launch
         return out
 
+    def noise_rows(self, n, std, pytest=False, chunk=None):
+        """The density noise of raw_noise_std > 0 for both passes, already multiplied by the std (ibl_nerf_renderer.py:208-216): N(0, std) from the
+        device generator, or — pytest=True — std x numpy's seed-0 UNIFORM stream re-seeded per chunk, which is what the reference's test hook draws.
+        -> ([n, N_samples], [n, N_samples + N_importance])"""
+        torch = _torch()
+        Sc, Sf = self.N_samples, self.N_samples + self.N_importance
+        ch = int(chunk or n or 1)
+        out = []
+        for S in (Sc, Sf):
+            if pytest:
+                nz = torch.cat([_pytest_uniform(min(ch, n - i), S) for i in range(0, n, ch)] or [torch.zeros((0, S))])
+                out.append(_dev_f32(nz * np.float32(std), self.device))
+            else:
+                out.append(torch.randn((n, S), device=self.device) * std)
+        return out
+
     def _alloc_maps(self, n, S, want=True, irr_ch=1, inferred_normal=False):
         torch = _torch()
         m, t = B.Maps(), {}
@@ -818,7 +834,7 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, _retry=False, **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, _retry=False, noise=None, **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
         (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
         perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
@@ -849,18 +865,9 @@ class Renderer:
             near, far = float(np.asarray(near.cpu() if hasattr(near, "cpu") else near).reshape(-1)[0]), float(np.asarray(far.cpu() if hasattr(far, "cpu") else far).reshape(-1)[0])
         std = float(raw_noise_std or 0.)
         if std > 0.:
-            smp = B.Sampling()
-            Sc, Sf = self.N_samples, self.N_samples + self.N_importance
-            ch = int(chunk or n or 1)
-            keep = []
-            for S, field in ((Sc, "d_noise_coarse"), (Sf, "d_noise_fine")):
-                if pytest:
-                    nz = torch.cat([_pytest_uniform(min(ch, n - i), S) for i in range(0, n, ch)] or [torch.zeros((0, S))])
-                    nz = _dev_f32(nz * np.float32(std), self.device)
-                else:
-                    nz = torch.randn((n, S), device=self.device) * std
-                setattr(smp, field, nz.data_ptr())
-                keep.append(nz)
+            smp = smp or B.Sampling()
+            keep = list(noise) if noise is not None else self.noise_rows(n, std, pytest, chunk)
+            smp.d_noise_coarse, smp.d_noise_fine = keep[0].data_ptr(), keep[1].data_ptr()
             self._keep_noise = keep
         if draws is not None:
             if draws[0] is not None:
@@ -914,7 +921,7 @@ class Renderer:
                                                               C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         if not lazy and self.out_of_range():
-            again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
+            again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, **edit)
             if not _retry and n:
                 # the coarse grid's points of (up to) 1 024 of the call's rays: where both networks are evaluated, within the margin RANGE_TARGET leaves
                 idx = torch.linspace(0, n - 1, min(n, 1024), device=self.device).long()
@@ -1274,17 +1281,18 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
             raise NotImplementedError("a depth_mlp with trainable parameters in a gradient-carrying render (infer_depth training, train.py:351-379) is not built: "
                                       "its inferred_depth_map would carry no grad_fn and the network would silently never train; evaluate depth_mlp in torch, "
                                       "or freeze it (requires_grad_(False)) to render with it")
-        if flags_on or float(kwargs.get("raw_noise_std", 0.) or 0.) > 0. or aux_on or _ci_net(kwargs["network_fn"]):
-            raise NotImplementedError("edit / insert overrides, *_from_gt flags, raw_noise_std, auxiliary and colour-independent networks are not built "
+        if flags_on or aux_on or _ci_net(kwargs["network_fn"]):
+            raise NotImplementedError("edit / insert overrides, *_from_gt flags, auxiliary and colour-independent networks are not built "
                                       "for is_depth_only, approximate_radiance=False and gradient-carrying renders (no shipped config has them; keep the "
                                       "reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
+        std = float(kwargs.get("raw_noise_std", 0.) or 0.)
         if is_depth_only:                                                       # raw2outputs_depth (:197-198)
-            ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, **smp)
+            ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
-                                      approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), **smp)
+                                      approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std, **smp)
         else:
-            ret = T.render_rays_direct(r, ro_f, rd_f, *nf, **smp)
+            ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
         if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:
             # :722-726 runs whatever the pass type; a constant here (a trainable depth_mlp was refused above), appended last as in the reference
             with _torch().no_grad():

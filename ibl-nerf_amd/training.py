@@ -19,7 +19,8 @@ Nothing of size [n_rays, n_samples] is computed by torch: such tensors exist onl
 of the frozen layers dropped.
 
 Not built here (raise): edit / insert overrides and the *_from_gt flags in a training step, auxiliary and colour-independent networks,
-raw_noise_std > 0, a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.
+a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.  (raw_noise_std > 0 is: the step's noise rows are drawn once, added to the
+density the compositing reads in both directions, and are constants of the backward.)
 """
 from __future__ import annotations
 
@@ -166,7 +167,7 @@ class _Stages:
         return w, d, v
 
 
-def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None):
+def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None, raw_noise_std=0.):
     """is_depth_only (raw2outputs_depth, ibl_nerf_renderer.py:118-152, through render_rays :693-718): trunk-only queries, the keys
     depth_map / weights / visibility (+ '0') and z_std.  Forward only (train.py:374 detaches the one map it reads)."""
     torch = _torch()
@@ -175,14 +176,15 @@ def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=Fals
     n = ro.shape[0]
     st = _Stages(r)
     t_rand, u = _draws(r, n, perturb, pytest, chunk)
+    noise = r.noise_rows(n, raw_noise_std, False, chunk) if raw_noise_std > 0. else (None, None)       # raw2outputs_depth (:131-133): torch.randn, no pytest hook there
     zc = st.coarse_z(near, far, t_rand, n)
     sig = r.network_query(st.points(ro, rd, zc), None, 0)[..., 0].contiguous()
-    wc, dc, vc = st.composite_sigma(sig, zc, rd)
+    wc, dc, vc = st.composite_sigma(sig if noise[0] is None else (sig + noise[0]).contiguous(), zc, rd)
     if r.N_importance <= 0:
         return {"depth_map": dc, "weights": wc, "visibility": vc}
     zf, zstd = st.fine_z(zc, wc, u)
     sig = r.network_query(st.points(ro, rd, zf), None, 1 if r.has_fine else 0)[..., 0].contiguous()      # run_fn = network_fn if network_fine is None (:705)
-    wf, df, vf = st.composite_sigma(sig, zf, rd)
+    wf, df, vf = st.composite_sigma(sig if noise[1] is None else (sig + noise[1]).contiguous(), zf, rd)
     return {"depth_map": df, "weights": wf, "visibility": vf, "depth_map0": dc, "weights0": wc, "visibility0": vc, "z_std": zstd}
 
 
@@ -190,15 +192,25 @@ BASE_KEYS = ["radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3
              "acc_map", "depth_map", "target_depth_map", "weights"]          # raw2outputs' non-None entries without approximate_radiance, in its order (:494-525)
 
 
-def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags):
+def _with_noise(raw, noise):
+    """raw rows whose density column carries the pass's noise (raw[..., 0] + noise, ibl_nerf_renderer.py:242): what the compositing reads; the noise is a
+    constant of the step, so dL/d raw is unchanged by it"""
+    if noise is None:
+        return raw
+    out = raw.clone()
+    out[..., 0] += noise
+    return out
+
+
+def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags, noise=(None, None)):
     """render_rays with approximate_radiance=False from its stages: (result dict, what a backward needs)."""
     torch = _torch()
     n = ro.shape[0]
     zc = st.coarse_z(near, far, t_rand, n)
-    rawc = r.network_query(st.points(ro, rd, zc), rd, 0)
+    rawc = _with_noise(r.network_query(st.points(ro, rd, zc), rd, 0), noise[0])
     mc, wc = r.composite_direct(rawc, zc, rd)
     zf, zstd = st.fine_z(zc, wc, u)
-    rawf = r.network_query(st.points(ro, rd, zf), rd, 1 if r.has_fine else 0)
+    rawf = _with_noise(r.network_query(st.points(ro, rd, zf), rd, 1 if r.has_fine else 0), noise[1])
     mf, wf = r.composite_direct(rawf, zf, rd)
     res = {}
     for sfx, m, w in (("", mf, wf), ("0", mc, wc)):
@@ -209,7 +221,7 @@ def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags):
     return res, dict(zc=zc, zf=zf, rawc=rawc, rawf=rawf)
 
 
-def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None):
+def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None, raw_noise_std=0.):
     """approximate_radiance=False without autograd (e.g. a validation render during the warm-up iterations): the reference's result dict."""
     from .renderer import _dev_f32
     torch = _torch()
@@ -217,12 +229,14 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
     if r.N_importance <= 0:
         raise NotImplementedError("approximate_radiance=False is built for N_importance > 0 (every shipped config)")
     t_rand, u = _draws(r, ro.shape[0], perturb, pytest, chunk)
+    noise = r.noise_rows(ro.shape[0], raw_noise_std, pytest, chunk) if raw_noise_std > 0. else (None, None)
     with torch.no_grad():
-        res, _ = _forward_direct(r, _Stages(r), ro, rd, near, far, t_rand, u, _flags(r))
+        res, _ = _forward_direct(r, _Stages(r), ro, rd, near, far, t_rand, u, _flags(r), noise)
     return res
 
 
-def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None):
+def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None,
+                      raw_noise_std=0.):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
     `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
     teacher_maps (parity tests; the backward's counterpart of iblnerf_composite_pass): {n_dot_v_map[0], reflected_radiance_map[0],
@@ -254,15 +268,18 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
         @staticmethod
         def forward(ctx, ro_, rd_, *ps):
             t_rand, u = _draws(r, n, perturb, pytest, chunk)
+            # raw_noise_std > 0 (train.py's option; :208-216, :242): the step's density noise, drawn once and shared by forward and backward
+            noise = r.noise_rows(n, raw_noise_std, pytest, chunk) if raw_noise_std > 0. else (None, None)
             Sc, Sf = r.N_samples, r.N_samples + r.N_importance
             if approximate_radiance:
                 taps = B.Taps()
                 sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18), envc=st._e(n, 4, 3), envf=st._e(n, 4, 3))
                 taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
                 taps.d_env_coarse, taps.d_env_fine = sv["envc"].data_ptr(), sv["envf"].data_ptr()    # the linear reflected-ray maps, exact (no gamma round trip)
-                res = r.render_rays(ro_, rd_, near, far, draws=(t_rand, u), taps=taps)
+                res = r.render_rays(ro_, rd_, near, far, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std, noise=None if noise[0] is None else noise)
+                sv["rawc"], sv["rawf"] = _with_noise(sv["rawc"], noise[0]), _with_noise(sv["rawf"], noise[1])     # (the taps are the network's rows: the noise is added in pass A)
             else:
-                res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags)
+                res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
             if approximate_radiance:
                 src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})

@@ -556,7 +556,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
     print("%-28s %s  %d maps  %.2f MB" % (name, kind, len(ret), os.path.getsize(path) / 1e6))
 
 
-def train_step_fixture(torch, R, M, lut, n_rays=64):
+def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -577,6 +577,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64):
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     kw.update(near=0.5, far=8.0, pytest=True)
+    if raw_noise_std > 0:       # train.py's raw_noise_std (:208-216, :242): density noise on the main query of each pass; the pytest hook draws it uniform
+        kw["raw_noise_std"] = raw_noise_std
     kw["brdf_lut"] = lut
     rng = np.random.RandomState(4100)
     o, d, pix, focal = camera_rays(rng, n_rays)
@@ -594,7 +596,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64):
         out["beta__" + k] = np.float64(v)
     nets = (("c", kw["network_fn"]), ("f", kw["network_fine"]))
 
-    for phase in ("warmup", "full", "frozen", "depth"):
+    out["raw_noise_std"] = np.float32(raw_noise_std)
+    for phase in phases:
         for _, net in nets:
             net.zero_grad()
             net.freeze_radiance = net.freeze_roughness = phase == "frozen"
@@ -614,9 +617,9 @@ def train_step_fixture(torch, R, M, lut, n_rays=64):
                 out["%s__grad_%s__%s" % (phase, tag, name)] = (prm.grad.numpy().copy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32))
     for _, net in nets:
         net.freeze_radiance = net.freeze_roughness = False
-    path = os.path.join(OUT, "train_step.npz")
+    path = os.path.join(OUT, fixture + ".npz")
     np.savez_compressed(path, **out)
-    print("%-28s %4d rays, 4 phases: losses %s  %.2f MB" % ("train_step", n_rays, {p_: round(float(out[p_ + "__loss"]), 5) for p_ in ("warmup", "full", "frozen")},
+    print("%-28s %4d rays, %d phases: losses %s  %.2f MB" % (fixture, n_rays, len(phases), {p_: round(float(out[p_ + "__loss"]), 5) for p_ in phases if p_ != "depth"},
                                                            os.path.getsize(path) / 1e6))
 
 
@@ -967,6 +970,8 @@ def main(only=None):
         small_vectors(torch, R, Hh)
     if not only or "train_step" in only:
         train_step_fixture(torch, R, M, lut)
+    if not only or "train_step_noise" in only:      # the same step with raw_noise_std = 1 (f-3: density noise inside a gradient-carrying render)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_noise", phases=("warmup", "full"), raw_noise_std=1.0)
     if not only or "sample_pdf_spiky" in only:
         sample_pdf_spiky(torch, Hh)
     if not only or "export_path" in only:

@@ -46,11 +46,22 @@ def _setup(G, lut, phase):
     return nets, kw, K, rays
 
 
-@pytest.mark.parametrize("phase,teacher", [("warmup", False), ("full", False), ("full", True), ("frozen", False)])
-def test_training_step_gradients_against_the_reference(G, lut, phase, teacher):
+@pytest.fixture(scope="module")
+def GN():
+    """the same step with raw_noise_std = 1 (density noise on both passes' main query, drawn by the reference's pytest hook): train_step_noise.npz"""
+    return np.load(os.path.join(GOLDEN, "train_step_noise.npz"))
+
+
+@pytest.mark.parametrize("phase,teacher,noise", [("warmup", False, False), ("full", False, False), ("full", True, False), ("frozen", False, False),
+                                                 ("warmup", False, True), ("full", False, True)])
+def test_training_step_gradients_against_the_reference(G, GN, lut, phase, teacher, noise):
     import train_loss as TL
     from ibl_nerf_amd import renderer as R
+    if noise:      # f-3 leftover closed in round 4: raw_noise_std > 0 inside a gradient-carrying render (it used to raise)
+        G = GN
+        assert float(G["raw_noise_std"]) == 1.0
     nets, kw, K, rays = _setup(G, lut, phase)
+    kw["raw_noise_std"] = float(G["raw_noise_std"]) if "raw_noise_std" in G.files else 0.0
     approx = phase != "warmup"
     if teacher:      # the reference's own no-grad maps (n.v, reflected-ray maps of both passes) as the constants of the shading backward
         kw["teacher_maps"] = {k[len(phase) + 7:]: torch.from_numpy(G[k]).cuda() for k in G.files
