@@ -29,6 +29,10 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 }  // namespace
 
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
+// k_select_points: a density estimate below -MARGIN is empty space whatever its error (the fast kernel's is < 1e-2 on a fitted checkpoint); a sample
+// behind a transmittance of TMIN carries, with everything behind it, a weight below TMIN
+constexpr float COARSE_SELECT_MARGIN = 1.0f, COARSE_SELECT_TMIN = 1e-8f;
+constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
 static bool wants_mx(int prec) {
@@ -39,7 +43,8 @@ static bool wants_f16x3(int prec) {
     return prec == IBLNERF_MLP_F16X3 || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN || prec == IBLNERF_MLP_F16X3_MXFP6X;
 }
 // query classes of render_rays, for the per-class choice of the product scheme
-enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER };
+enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER,
+                  Q_ESTIMATE };   // a density estimate on the fast kernel, to be refined on the relevant points (k_select_points)
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
 constexpr int AUX_SLOT0[N_AUX] = {2, 5, 6, 7}, AUX_CHANNELS[N_AUX] = {3, 1, 1, 3}, AUX_RAW_COLUMN[3] = {1, 4, 5};
 
@@ -71,7 +76,16 @@ struct iblnerf_ctx {
     // iblnerf_options.query_routing (IBLNERF_ROUTE_*), decoded at iblnerf_create
     bool x_coarse = false, x_user = false, fine_main_precise = false;
     bool x_fine_precise = false;                  // IBLNERF_ROUTE_FINE_OFFSETS_PRECISE
-    bool coarse_sigma_p = true, p_user = false;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
+    bool coarse_sigma_p = true, p_user = false;
+    bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
+    float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
+    int* sel_index = nullptr;                     // [4 * ws_rays * Sc] their flat indices
+    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call
+    long sel_candidates = 0;                      // ... and how many samples were candidates
+    // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
+    // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
+    // host upload of network 0, on the first launch's own count (one stream synchronisation per checkpoint), and frozen: results must not depend on call history.
+    bool sel_decided = false, sel_on = true;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
     size_t bwd_stash_bytes = 0;
@@ -117,13 +131,14 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->coarse_sigma_p = (bits & IBLNERF_ROUTE_COARSE_MAIN_22BIT) == 0;
     c->p_user = (bits & IBLNERF_ROUTE_USER_TRUNK_P) != 0;
     c->x_fine_precise = (bits & IBLNERF_ROUTE_FINE_OFFSETS_PRECISE) != 0;
+    c->p_all_points = (bits & IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS) != 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 127) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..127)");
+    if (bits < 0 || bits > 255) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..255)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -197,8 +212,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 127 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..127), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 255 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..255), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -238,6 +253,12 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             iblnerf_destroy(c);
             return IBLNERF_ERR_NOMEM;
         }
+    if (hipMalloc((void**)&c->sel_pts, 4 * R * Sc * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sc * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->sel_count, 4 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 4 * sizeof(int)) != hipSuccess) {
+        g_create_error = "hipMalloc of the render workspace failed";
+        iblnerf_destroy(c);
+        return IBLNERF_ERR_NOMEM;
+    }
     for (int w = 0; w < 2; ++w)
         if (hipMalloc((void**)&c->d_stream[w], STREAM_BYTES) != hipSuccess ||
             hipMalloc((void**)&c->d_tables[w], TAB_BYTES) != hipSuccess) {
@@ -287,6 +308,9 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
         if (c->d_stream_f16[w]) (void)hipFree(c->d_stream_f16[w]);
     }
+    if (c->sel_pts) (void)hipFree(c->sel_pts);
+    if (c->sel_index) (void)hipFree(c->sel_index);
+    if (c->sel_count) (void)hipFree(c->sel_count);
     if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->bwd_stash) (void)hipFree(c->bwd_stash);
     if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -330,6 +354,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[slot], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
     }
     c->have_net[slot] = true;
+    if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
     return IBLNERF_OK;
 }
 
@@ -491,7 +516,7 @@ static bool sigma_p_available(const iblnerf_ctx* c, int which) {
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
                    int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr,
-                   bool count_flops = true) {
+                   bool count_flops = true, const int* n_pts_dev = nullptr, const int* out_index = nullptr) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     // a trunk-only query of the sample-placing class (the coarse pass reduced to its density), or of the caller under IBLNERF_ROUTE_USER_TRUNK_P
@@ -532,6 +557,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             kern = K_MX16;
     }
     if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
+    if (qclass == Q_ESTIMATE) kern = K_MX;      // (likewise)
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
     if (variant == VAR_TRUNK_GRAD) kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3;
     a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
@@ -544,6 +570,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     a.n_pts = n_pts;
     a.pts_per_ray = pts_per_ray;
     if (gen) a.gen = *gen;
+    a.n_pts_dev = n_pts_dev;
+    a.out_index = out_index;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (c->profiling) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -1036,8 +1064,27 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // hold 22-23 bits of an fp32 weight / activation; through a fitted network's cancelling density sum that alone moves the fine samples of
     // some rays by more than the reference's own arithmetic does (launch scale 7).  The column overwrites raw[..., 0] as an
     // auxiliary network's output would; weights, depth and the fine samples are composited from it.
+    // Only the RELEVANT samples need it: a sample whose density estimate (the main query's own, error < 1e-2) is below -1 has alpha = 0 exactly whatever
+    // the estimate's last bits are, and a sample behind a transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest (on a
+    // scene with surfaces: the few samples around each ray's first surface, ~5 %) is compacted, evaluated and scattered over the estimates (k_select_points).
     if (places_samples && sigma_p_available(c, which)) {
-        rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
+        if (c->p_all_points || !c->sel_on) {
+            rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
+        } else {
+            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+            c->sel_candidates += R * S;
+            HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->raw, RAW_CH, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+                                            c->sel_count, s));
+            if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
+                int n_sel = 0;
+                HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                c->sel_decided = true;
+                c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * S);
+            }
+            if (c->sel_on) rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            else rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
+        }
         if (rc) return rc;
     }
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
@@ -1073,7 +1120,21 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         } else {   // the four offset copies are generated in the MLP kernel's input stage: no [4][R][S][3] batch (9.2 KB per ray on the fine grid)
             PointGen g;
             g.rays_o = ro; g.rays_d = rd; g.z = z; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
-            rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
+            if (coarse_grid && S == c->Sc && sigma_p_available(c, which) && !c->p_all_points && !c->x_coarse && c->sel_decided && c->sel_on) {
+                // The coarse grid's offsets need all eight layers at 2^-22 (DESIGN 4.0 ladder) — on the samples that can reach a weight.  So: an ESTIMATE of
+                // all 4 R S densities on the fast kernel (6 slots), then the relevant ones (neither clearly empty nor behind saturation, per offset copy:
+                // ~6 % on a scene with surfaces) again on the 15-slot form, scattered over the estimates.  The others composite to the same weights
+                // bit for bit (alpha = 0) or to within 1e-8 of a weight (the saturated tail).
+                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
+                if (rc) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+                c->sel_candidates += 4 * R * S;
+                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+                                                c->sel_count, s, true, eps));
+                rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            } else {
+                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
+            }
         }
         if (rc) return rc;
     }
@@ -1192,6 +1253,8 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     HIP_TRY(c, hipSetDevice(c->opt.device));
     c->ev_used = 0;
     c->flop_alg = 0.0;
+    c->sel_candidates = 0;
+    HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 2 * sizeof(int), s));
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
     if ((t_rand || near_ray) && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
@@ -1300,6 +1363,17 @@ int iblnerf_composite_pass(iblnerf_ctx* c, void* stream, const float* d_rays_o, 
     b.state = c->state; b.refl_raw = in->d_refl_raw; b.refl_d = c->refl_d; b.zc = c->zc; b.Sc = c->Sc;
     b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = n_rays;
     HIP_TRY(c, launch_pass_b(b, s));
+    return IBLNERF_OK;
+}
+
+int iblnerf_last_selection(iblnerf_ctx* c, int64_t* n_selected, int64_t* n_candidates) {
+    if (!c || !n_selected || !n_candidates) return IBLNERF_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long tot = 0;
+    HIP_TRY(c, hipMemcpy(&tot, c->sel_count + 2, sizeof tot, hipMemcpyDeviceToHost));
+    *n_selected = (int64_t)tot;
+    *n_candidates = (int64_t)c->sel_candidates;
     return IBLNERF_OK;
 }
 

@@ -185,6 +185,13 @@ struct PosDirArgs {
 };
 constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (319L * 256 + 256) + 2 * (256L * 256 + 256) + (256L * 256 + 256) +
                                     (283L * 128 + 128) + 3 * (128L * 128 + 128) + (128L * 1 + 1);
+// The samples whose density can reach a ray's weights through more than a negative sign or a saturated tail (render_kernels.hip: k_select_points): their points
+// [n_sel, 3] and flat indices r * S + s, n_sel counted into *counter (zeroed by the caller); sigma = the density estimate, element (r, s) at (r S + s) * sigma_stride
+// offsets: the rays are the 4 R epsilon-offset copies (sigma = sig4 [4][R][S], stride 1; points from gen_offset_point with `eps`)
+hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
+                                long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets = false,
+                                float eps = 0.0f);
+
 // iblnerf_layer_ranges (range_kernel.hip): largest |value| of each of a network's 15 wide activations on n points; blob = the fp32 state dict in device memory
 struct LayerRangeArgs {
     const float* blob;

@@ -28,6 +28,10 @@ struct MlpArgs {
     const float* draw = nullptr;     // VAR_NET_BWD: [n_pts, 18] dL / d raw (the network's 18 output channels, ibl_nerf.py:200-208)
     char* stash = nullptr;
     PointGen gen;                    // VAR_TRUNK / VAR_TRUNK_X only: gen.rays_o != null = the four epsilon-offset copies are generated in the input stage (pts is not read)
+    // VAR_TRUNK_P only: a compact point list whose length lives in device memory (k_select_points) and whose results are scattered: point i of the list ->
+    // out[out_index[i] * out_stride]; n_pts is then only the upper bound that sizes the launch
+    const int* n_pts_dev = nullptr;
+    const int* out_index = nullptr;
     float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
                                      // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels
 };

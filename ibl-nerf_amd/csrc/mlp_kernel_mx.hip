@@ -867,14 +867,18 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     load_frag<3, 3>(pf, P.block(false, 0), lane);
     unsigned wsc = 0, peak = 0;
 
-    const long n_groups = (a.n_pts + 127) / 128;
+    long n_total = a.n_pts;
+    if constexpr (VARIANT == VAR_TRUNK_P) {
+        if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
+    }
+    const long n_groups = (n_total + 127) / 128;
 #ifdef IBL_MX_ABLATE_PROLOGUE   // timing ablation only (results are garbage): the input stage (points + encoding) runs in the first iteration only
     Blk pe, de;
     u32x16 pe_lo, loA[4];
 #endif
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
-        const bool valid = p < a.n_pts;
+        const bool valid = p < n_total;
         constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X || VARIANT == VAR_TRUNK_P;
 #ifdef IBL_MX_ABLATE_PROLOGUE
         if (g == blockIdx.x) {
@@ -922,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float p0 = sig[0] + sig[1];
             const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
-            if (valid && h == 0) a.out[(long)p * a.out_stride] = sg;
+            if (valid && h == 0) a.out[(a.out_index != nullptr ? (long)a.out_index[p] : (long)p) * a.out_stride] = sg;
             continue;
         }
 #ifndef IBL_MX_ABLATE_PROLOGUE

@@ -679,6 +679,91 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
     }
 }
 
+// "Precision where it matters", per POINT (round 4).  A density estimate's last bits can reach a ray's weights only through samples that are neither
+//   (a) clearly empty:   sigma_s + noise_s <= -margin  ->  relu(.) = 0 and alpha_s = 0 EXACTLY, whatever the estimate's error below the margin, nor
+//   (b) behind saturation: T_s <= t_min  ->  w_s = alpha_s T_s <= t_min, and so is the sum of every weight from s on.
+// Everything else is relevant: its point and its flat index r * S + s go to a compact list (order across rays: whatever the atomics give — a point's
+// result does not depend on its place in a batch), which the precise query then evaluates and scatters over the estimate.  One wavefront per ray.
+// OFFSETS: the "rays" are the 4 R epsilon-offset copies of the samples (normal_from_depth.py:143-160: virtual ray v R + r composites sig4[v][r][:] on ray r's own z
+// and dists, no noise); their points come from gen_offset_point, the generator the TRUNK kernels' input stage uses.
+template <int NPL, bool OFFSETS>
+__global__ __launch_bounds__(256) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
+                                                      const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
+                                                      float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63;
+    const long vr = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (virtual) ray
+    if (vr >= (OFFSETS ? 4 * R : R)) return;
+    const long r = OFFSETS ? vr % R : vr;
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zbase + (long)z_stride * r;
+    float z[NPL], sg[NPL];
+    double om[NPL];
+    double lane_prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        const float zn = s + 1 < S ? zrow[s + 1] : 0.0f;
+        sg[i] = s < S ? sigma[(vr * S + s) * (long)sigma_stride] : -1e30f;
+        if (noise != nullptr && s < S) sg[i] = sg[i] + noise[r * S + s];
+        const float dist = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
+        const float a = s < S ? 1.0f - expf(-fmaxf(sg[i], 0.0f) * dist) : 0.0f;
+        om[i] = s < S ? (double)((1.0f - a) + 1e-10f) : 1.0;
+        lane_prod *= om[i];
+    }
+    double incl = lane_prod;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const double other = __shfl_up(incl, dd);
+        if (lane >= dd) incl *= other;
+    }
+    double T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.0;
+    bool sel[NPL];
+    int total = 0;
+    unsigned long long masks[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        // (a sample is judged by the transmittance the ESTIMATE gives in front of it, with a margin on the estimate itself: sigma > -margin counts as
+        // possibly opaque for nobody else's T, because T only ever gets smaller by counting it)
+        sel[i] = s < S && sg[i] > -margin && T > (double)t_min;
+        T *= om[i];
+        masks[i] = __ballot(sel[i]);
+        total += __popcll(masks[i]);
+    }
+    int base = 0;
+    if (lane == 0 && total > 0) {
+        base = atomicAdd(counter, total);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), (unsigned long long)total);     // running total of the call (iblnerf_last_selection)
+    }
+    base = __shfl(base, 0);
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        if (sel[i]) {
+            const int pos = base + before + __popcll(masks[i] & ((1ull << lane) - 1ull));
+            float p[3];
+            const unsigned flat = (unsigned)(vr * S + lane * NPL + i);
+            if constexpr (OFFSETS) {
+                PointGen g;
+                g.rays_o = rays_o; g.rays_d = rays_d; g.z = zbase; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+                gen_offset_point(g, flat, p[0], p[1], p[2]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = o[c] + d[c] * z[i];      // the arithmetic of k_make_points mode 0 (this file is compiled without contraction)
+            }
+            pts_out[3 * (long)pos] = p[0];
+            pts_out[3 * (long)pos + 1] = p[1];
+            pts_out[3 * (long)pos + 2] = p[2];
+            index_out[pos] = (int)flat;
+        }
+        before += __popcll(masks[i]);
+    }
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256) void k_surface_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const float* __restrict__ zbase, int z_stride, const float* __restrict__ raw,
@@ -1072,6 +1157,20 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
     const dim3 grid((unsigned)((R + 3) / 4));
     return by_npl(S, [&](auto N) {
         hipLaunchKernelGGL(k_sigma_weights<decltype(N)::value>, grid, dim3(256), 0, s, rays_d, z, z_stride, sigma, noise, R, S, weights, depth, visibility);
+    });
+}
+
+hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
+                                long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(((offsets ? 4 * R : R) + 3) / 4));
+    return by_npl(S, [&](auto N) {
+        if (offsets)
+            hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
+                               t_min, eps, pts_out, index_out, counter);
+        else
+            hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
+                               t_min, eps, pts_out, index_out, counter);
     });
 }
 

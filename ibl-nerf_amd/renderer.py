@@ -494,6 +494,12 @@ class Renderer:
         """Frees the fused backward's workspace (iblnerf_trim)."""
         B.check(self.ctx, self.lib.iblnerf_trim(self.ctx))
 
+    def last_selection(self):
+        """(selected, candidates) of the last render_rays call: how many coarse samples were evaluated on the 15-slot density form (synchronises)."""
+        a, b = C.c_int64(), C.c_int64()
+        B.check(self.ctx, self.lib.iblnerf_last_selection(self.ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
 

@@ -123,6 +123,9 @@ enum {
                                                  the coarse pass places the fine samples, and a fitted network's cancelling density sum amplifies a one-ulp
                                                  perturbation of its parameters ~300x) */
     IBLNERF_ROUTE_USER_TRUNK_P = 32,          /* the same modes: the trunk-only form of iblnerf_network_query on the 15-slot form (tests of that kernel on its own) */
+    IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS = 128, /* the 15-slot density on EVERY coarse sample instead of the relevant ones only (those that are neither clearly
+                                                 empty — density estimate below -1: alpha = 0 exactly — nor behind a transmittance of 1e-8); an A/B aid: results
+                                                 agree to ~1e-9 on a weight */
     IBLNERF_ROUTE_FINE_OFFSETS_PRECISE = 64   /* F16X3_MXFP6X: the fine grid's offset queries back on F16X3 (with IBLNERF_ROUTE_FINE_MAIN_PRECISE the mode then
                                                  routes every query as F16X3_MXFP6 does: the "safe" policy of ibl-nerf_amd/renderer.py's load-time calibration) */
 };
@@ -499,6 +502,10 @@ int iblnerf_pack_weights_host_f16x3(const float* h_blob, size_t n_floats, void* 
 int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_stream, size_t stream_bytes,
                                  float* h_tables, size_t table_floats);
 size_t iblnerf_stream_bytes_mx(void);
+
+/* Measurement aid: of the coarse samples of the last iblnerf_render_rays* call, how many were evaluated on the 15-slot density form (the "relevant" ones: neither
+ * clearly empty nor behind saturation; IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: not counted, both 0).  Synchronises. */
+int iblnerf_last_selection(iblnerf_ctx* ctx, int64_t* n_selected, int64_t* n_candidates);
 
 /* Timing aid for bench.py: HIP-event time (ms) of the MLP kernels launched by the last
  * iblnerf_render_rays call on this ctx, and their count.  Enabled by iblnerf_set_profiling(ctx, 1),

@@ -243,7 +243,8 @@ def test_calibration_measures_and_decides(R, lut):
     assert r.policy["decision"] == "safe" and r.policy["routing"] & r.SAFE_ROUTING == r.SAFE_ROUTING
     assert fast.policy["decision"] == "pinned" and fast.calibrate(g["rays_o"][:2048], g["rays_d"][:2048], 0.5, 8.0)["decision"] == "pinned"
     rep = fast.precision_report(g2["rays_o"], g2["rays_d"], 0.5, 8.0, reference="f16x3_mxfp6")      # (on checkpoint 1's weights: the twin copies them)
-    assert rep["weights"]["p999"] < 3e-4 and rep["weights0"]["p999"] == 0.0, (rep["weights"], rep["weights0"])   # (the coarse pass is the same in both tables)
+    # (the coarse pass's weights are the same in both tables up to the estimates behind saturation — weights below 1e-8, from the fast or the precise FULL kernel)
+    assert rep["weights"]["p999"] < 3e-4 and rep["weights0"]["max"] < 1e-9, (rep["weights"], rep["weights0"])
 
 
 def _frame_rays(r):
