@@ -516,7 +516,7 @@ static bool sigma_p_available(const iblnerf_ctx* c, int which) {
 
 static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
                    int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr,
-                   bool count_flops = true, const int* n_pts_dev = nullptr, const int* out_index = nullptr) {
+                   bool count_flops = true, const int* n_pts_dev = nullptr, const int* out_index = nullptr, double flop_per_point = -1.0) {
     if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
     MlpArgs a;
     // a trunk-only query of the sample-placing class (the coarse pass reduced to its density), or of the caller under IBLNERF_ROUTE_USER_TRUNK_P
@@ -588,7 +588,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     // (algorithmic FLOPs are counted once: the density column re-evaluated on the 15-slot form beside a FULL query adds time, not work)
-    if (count_flops) c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
+    if (count_flops && flop_per_point >= 0.0) c->flop_alg += (double)n_pts * flop_per_point;      // (an estimate launch standing for the query it belongs to)
+    else if (count_flops) c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
 }
 
@@ -1053,12 +1054,44 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
                      const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise,
-                     float* env_tap = nullptr, const float* near_ray = nullptr, const float* far_ray = nullptr) {
+                     float* env_tap = nullptr, const float* near_ray = nullptr, const float* far_ray = nullptr, bool keep_all_rows = false) {
     const int Sc = c->Sc;
+    // "precision where it matters" also decides WHERE a query is evaluated at all: a sample that is clearly empty (alpha = 0 exactly) or behind saturation carries
+    // no weight, so its 17 other channels (coarse main query) / its 12 radiance channels (reflected query) are never read with a non-zero factor.  Such a query runs as a
+    // density ESTIMATE on the fast TRUNK form over all samples, and the whole network only on the relevant ones (VAR_FULL_LIST / VAR_REFL_LIST); the other rows are zero.
+    const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (!c->sel_decided || c->sel_on);
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
-    int rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, places_samples ? Q_MAIN_COARSE : Q_MAIN_FINE);
+    int rc = IBLNERF_OK;
+    bool main_done = false, est_counted = false;
+    if (places_samples && list_ok && !keep_all_rows && !c->fine_main_precise && c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
+        // (the FAST table's coarse main query: its other channels are on the fast kernel anyway)
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
+        if (rc) return rc;
+        est_counted = true;     // (the query's algorithmic FLOPs are counted once, on its estimate)
+        HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)R * S * RAW_CH * sizeof(float), s));
+        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        c->sel_candidates += R * S;
+        HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+                                        false, 0.f, c->raw, RAW_CH));
+        if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
+            int n_sel = 0;
+            HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            c->sel_decided = true;
+            c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * S);
+        }
+        if (c->sel_on) {
+            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
+            if (rc) return rc;
+            rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            if (rc) return rc;
+            main_done = true;
+        }
+    }
+    if (!main_done) {
+    rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, places_samples ? Q_MAIN_COARSE : Q_MAIN_FINE, nullptr, !est_counted);
     if (rc) return rc;
     // ... and its density column once more on the 15-slot form (three f16 + three fp6 products per block: operands to ~2^-26).  Two f16 terms
     // hold 22-23 bits of an fp32 weight / activation; through a fitted network's cancelling density sum that alone moves the fine samples of
@@ -1087,6 +1120,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         }
         if (rc) return rc;
     }
+    }   // !main_done
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
     // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
     for (int kind = 0; kind < 3; ++kind)
@@ -1145,7 +1179,20 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
     HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, Sc, c->pts, s));
-    rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
+    if (list_ok && c->sel_decided && c->sel_on) {
+        // the reflected ray leaves its surface into empty space and ends on the next one: a density estimate everywhere (fast TRUNK form; the same trunk
+        // arithmetic the REFL form runs), the view layers and the twelve radiance channels on the relevant samples only, zero rows elsewhere (weight 0, or < 1e-8)
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_REFL);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->refl_raw, 0, (size_t)R * Sc * REFL_CH * sizeof(float), s));
+        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        c->sel_candidates += R * Sc;
+        HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+                                        c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH));
+        rc = run_mlp(c, s, VAR_REFL_LIST, which, c->sel_pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
+    } else {
+        rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
+    }
     if (rc) return rc;
     PassBArgs b;
     b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = zc; b.zc_stride = zc_stride; b.Sc = Sc;
@@ -1295,14 +1342,14 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         };
         if (!fine) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
             rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
@@ -1314,7 +1361,7 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
         rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
-                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr);
+                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr, taps != nullptr);
         if (rc) return rc;
         if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
     }

@@ -158,9 +158,11 @@ enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_R
                VAR_TRUNK_FEAT2 = 10,      // ... one layer pair further: outputs h7 AND h2 = relu(views_linears.0([feature_linear(h7), dir27])) rows
                VAR_TRUNK_BWD_FEAT2 = 11,  // its backward: dL/dh7 and dL/dh2 rows in; also stashes for feature_linear's and views_linears.0's weight gradients
                VAR_NET_BWD = 12,          // the whole network's backward: dL/d raw rows [n, 18] in, every layer differentiated
-               VAR_TRUNK_P = 13 };        // fast kernel only: TRUNK with every layer as three f16 products + three block-scaled fp6 products for the 2^-22 terms
+               VAR_TRUNK_P = 13,          // fast kernel only: TRUNK with every layer as three f16 products + three block-scaled fp6 products for the 2^-22 terms
                                           // (15 matrix slots per 64 MACs; operands to ~2^-26): the coarse pass's density, which places the fine samples
+               VAR_REFL_LIST = 15,        // fast kernel only: REFL / FULL on a compact list of points (length in device memory, a flat index r * S + s per point: the
+               VAR_FULL_LIST = 16 };      // ray's direction and the output row are found through it) — the relevant samples of a query (k_select_points)
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
-__host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI; }   // albedo / roughness / irradiance heads
+__host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI || v == VAR_FULL_LIST; }   // albedo / roughness / irradiance heads
 
 }  // namespace ibl

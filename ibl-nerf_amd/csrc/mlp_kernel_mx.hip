@@ -867,8 +867,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     load_frag<3, 3>(pf, P.block(false, 0), lane);
     unsigned wsc = 0, peak = 0;
 
+    constexpr bool LIST = VARIANT == VAR_REFL_LIST || VARIANT == VAR_FULL_LIST;      // a compact list of points with a flat index each (MlpArgs::out_index)
     long n_total = a.n_pts;
-    if constexpr (VARIANT == VAR_TRUNK_P) {
+    if constexpr (VARIANT == VAR_TRUNK_P || LIST) {
         if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
     }
     const long n_groups = (n_total + 127) / 128;
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         if constexpr (!TRUNKV && !variant_ci(VARIANT)) {
             float dx = 0.f, dy = 0.f, dz = 0.f;
             if (valid) {
-                const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;
+                const unsigned r = (LIST ? (unsigned)a.out_index[p] : (unsigned)p) / (unsigned)a.pts_per_ray;
                 dx = a.dirs[3 * (size_t)r + 0];
                 dy = a.dirs[3 * (size_t)r + 1];
                 dz = a.dirs[3 * (size_t)r + 2];
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const float* rad[3] = {ltab + TAB_RAD, ltab + TAB_RAD + 256, ltab + TAB_RAD + 512};
         // with is_color_independent_to_direction the radiance_linear rows are dotted with h7 itself (ibl_nerf.py:192, :199)
         auto e7 = [&] {
-            if constexpr (VARIANT == VAR_FULL)
+            if constexpr (VARIANT == VAR_FULL || VARIANT == VAR_FULL_LIST)
                 return Epi<true, true, 2>{&B, {&part[0], &part[4]}, {ltab + TAB_SIG, ltab + TAB_ROUGH}, &peak};
             else if constexpr (VARIANT == VAR_FULL_CI)
                 return Epi<true, true, 5>{&B, {&part[0], &part[4], &part[6], &part[7], &part[8]},
@@ -1058,8 +1059,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 tot[c] = pc + __shfl_xor(pc, 32) + sc[c];
             }
             if (valid) {
+                const long row = LIST ? (long)a.out_index[p] : p;        // (a list: the sample's own row of the query's output)
                 if constexpr (variant_albirr(VARIANT)) {
-                    float* o = a.out + p * RAW_CH;
+                    float* o = a.out + row * RAW_CH;
                     if (h == 0) {
 #pragma unroll
                         for (int c = 0; c < 9; ++c) o[c] = tot[c];
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                         for (int c = 9; c < 18; ++c) o[c] = tot[c];
                     }
                 } else {
-                    float* o = a.out + p * REFL_CH;
+                    float* o = a.out + row * REFL_CH;
                     if (h == 0) {
                         o[0] = tot[0];
 #pragma unroll
@@ -1122,6 +1124,10 @@ hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launc
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
 #elif IBL_MX_VARIANT == 13
 hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_P>(a, grid, s); }
+#elif IBL_MX_VARIANT == 15
+hipError_t IBL_L(refl_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_LIST>(a, grid, s); }
+#elif IBL_MX_VARIANT == 16
+hipError_t IBL_L(full_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_LIST>(a, grid, s); }
 #elif IBL_MX_VARIANT == 3
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 #else
@@ -1136,6 +1142,10 @@ hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return la
 #ifndef IBL_MX_DEV_TRUNK_ONLY
 hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
+#ifndef IBL_MX_F16ONLY
+hipError_t IBL_L(refl_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_LIST>(a, grid, s); }
+hipError_t IBL_L(full_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_LIST>(a, grid, s); }
+#endif
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_CI>(a, grid, s); }
 #endif
@@ -1149,6 +1159,8 @@ hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(refl_ci)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(refl_list)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(full_list)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -1164,6 +1176,10 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);
         case VAR_TRUNK_X: return IBL_L(trunk_x)(a, grid, stream);
         case VAR_TRUNK_P: return IBL_L(trunk_p)(a, grid, stream);
+#ifndef IBL_MX_DEV_TRUNK_ONLY
+        case VAR_REFL_LIST: return IBL_L(refl_list)(a, grid, stream);
+        case VAR_FULL_LIST: return IBL_L(full_list)(a, grid, stream);
+#endif
 #endif
         default: return hipErrorInvalidValue;
     }

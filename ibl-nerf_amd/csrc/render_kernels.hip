@@ -689,7 +689,8 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
 template <int NPL, bool OFFSETS>
 __global__ __launch_bounds__(256) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
                                                       const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
-                                                      float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter) {
+                                                      float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
+                                                      float* __restrict__ est_out, int est_stride) {
     const int lane = threadIdx.x & 63;
     const long vr = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (virtual) ray
     if (vr >= (OFFSETS ? 4 * R : R)) return;
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(256) void k_select_points(const float* __restrict__
         z[i] = s < S ? zrow[s] : 0.0f;
         const float zn = s + 1 < S ? zrow[s + 1] : 0.0f;
         sg[i] = s < S ? sigma[(vr * S + s) * (long)sigma_stride] : -1e30f;
+        if (est_out != nullptr && s < S) est_out[(vr * S + s) * (long)est_stride] = sg[i];     // the estimate itself, as the density of the samples nobody refines
         if (noise != nullptr && s < S) sg[i] = sg[i] + noise[r * S + s];
         const float dist = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
         const float a = s < S ? 1.0f - expf(-fmaxf(sg[i], 0.0f) * dist) : 0.0f;
@@ -1161,16 +1163,17 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
 }
 
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
-                                long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps) {
+                                long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps,
+                                float* est_out, int est_stride) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)(((offsets ? 4 * R : R) + 3) / 4));
     return by_npl(S, [&](auto N) {
         if (offsets)
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride);
         else
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride);
     });
 }
 

@@ -197,6 +197,58 @@ def test_fifteen_slot_trunk_form(R, lut, ckpt):
     assert rp.range_fallbacks == 0
 
 
+def test_refinement_on_the_relevant_samples_only(R, lut):
+    """Round 4, "precision where it matters" per POINT (csrc/render_kernels.hip k_select_points; api.cpp full_pass): the coarse pass's 15-slot density, the
+    coarse grid's precise offset queries, the coarse main query's other 17 channels and the reflected query's radiance channels are evaluated only on samples
+    that are neither clearly empty (estimate below -1: alpha = 0 exactly) nor behind a transmittance of 1e-8 — about 6 % of those samples on a scene with
+    surfaces — and scattered over fast-kernel density estimates (zero rows for channels that no weight multiplies).  Against the same render with
+    every sample refined (query_routing = coarse_density_all_points): every FINE-pass map bit for bit (the coarse weights agree to 1e-9, so the fine samples are
+    the same), the coarse pass's direct maps to fp32 round-off, its normal within what two precise evaluations differ by.  A fog checkpoint (random init: every
+    sample relevant) switches the refinement off by itself — decided once per checkpoint upload on the first launch's count, then frozen."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    n = 8192
+    out = {}
+    for label, routing in (("selected", ()), ("all", ("coarse_density_all_points",))):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
+        sel, cand = r.last_selection()
+        if label == "selected":
+            assert cand == n * 64 * 7 and 0.02 * cand < sel < 0.15 * cand, (sel, cand)       # 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass)
+            again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                  # the compaction's order is whatever the atomics give: results are not
+            assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)
+        else:
+            assert (sel, cand) == (0, 0)
+    a, b = out["selected"], out["all"]
+    refl_dep = ("color_map", "specular_map", "prefiltered_reflected_map", "reflected_radiance_map", "reflected_coarse_radiance_map_1",
+                "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")
+    for k in a:
+        if k.endswith("0") or k == "z_std":
+            continue
+        if k in refl_dep:   # the reflected query's rows behind saturation are zero instead of (radiance x a weight below 1e-8)
+            assert rel_linf(a[k].cpu().numpy(), b[k].cpu().numpy()) <= 1e-6, k
+        else:
+            assert torch.equal(a[k], b[k]), k                                                 # the fine pass's samples, weights, direct maps and normal: bit for bit
+    assert torch.equal(a["z_std"], b["z_std"]) and float((a["weights0"] - b["weights0"]).abs().max()) <= 1e-9
+    for k in ("depth_map0", "albedo_map0", "roughness_map0", "irradiance_map0", "radiance_map0", "acc_map0"):
+        assert rel_linf(a[k].cpu().numpy(), b[k].cpu().numpy()) <= 1e-6, k
+    e = (a["target_normal_map0"] - b["target_normal_map0"]).abs().amax(-1).cpu().numpy()
+    assert np.percentile(e, 99) <= 2e-4 and e.max() <= 5e-3, (np.percentile(e, 99), e.max())   # 15-slot against three-product offsets on the relevant samples
+    # both are inside the rules against the reference's own coarse normal (the launch-scale tests hold the default to all of them)
+    ref = g["out__target_normal_map0"][:n]
+    for lab, m in (("selected", a), ("all", b)):
+        er = np.abs(m["target_normal_map0"].cpu().numpy() - ref).max(-1)
+        assert np.percentile(er, 99.9) <= 1e-3, (lab, np.percentile(er, 99.9))
+    # fog: everything is relevant -> the refinement switches itself off (results = the all-points path, bit for bit)
+    from ibl_nerf_amd import checkpoint as ck
+    fc, ff = ck.synthetic_state_dict(0), ck.synthetic_state_dict(1)
+    fog = {}
+    for label, routing in (("selected", ()), ("all", ("coarse_density_all_points",))):
+        r = R.Renderer(64, 128, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        r.load_weights(0, fc); r.load_weights(1, ff); r.load_lut(lut)
+        fog[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
+    assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
+
+
 def test_fitted_wide_error_class_of_f16x3_main(R, lut):
     """f16x3_main on 1 024 rays of the fitted checkpoint: direct channels exactly those of f16x3_mxfp6 (the same kernels produce them),
     the normal's worst ray an order above (1.5e-3 against 1.9e-4; 99.9th percentile 3e-4) — why its f16 + fp6 offset queries
