@@ -365,6 +365,7 @@ def main():
     step(ev)
     torch.cuda.synchronize()
     mlp_ms, n_launch, flop = r.last_mlp_time()
+    flop_executed, selection = r.last_executed_flops(), r.last_selection()
     r.set_profiling(False)
     # the exchange step on its own (same untimed extra step; events on torch's current stream, where pack and all-gather are enqueued):
     # packing the export maps into one buffer, and the all-gather (host-staged under the gloo test hook)
@@ -400,6 +401,13 @@ def main():
                          "kernel": MODES[args.mlp_precision][1] + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
                          "range_fallbacks": r.range_fallbacks,
+                         # what the launches really evaluated: `achieved` prices every sample of every query as the reference evaluates it (SURVEY 8 d); the kernels
+                         # run the coarse main / coarse-offset / reflected queries as a trunk-only density estimate everywhere and the rest on the relevant samples
+                         "executed": {"tflops": flop_executed / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
+                                      "frac": (flop_executed / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if mlp_ms > 0 else 0.0,
+                                      "share_of_algorithmic": flop_executed / flop if flop else None,
+                                      "samples_refined": selection[0], "of_candidates": selection[1],
+                                      "note": "2 x nn.Linear MACs of the launches as run (estimates: trunk only; head layers, 15-slot densities and refinements: selected samples only)"},
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues " + MODES[args.mlp_precision][2]},
         }
         if grouped:

@@ -24,6 +24,7 @@ EXPORTS = [
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
+    "iblnerf_last_executed_flops",
 ]
 
 
@@ -127,6 +128,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_layer_ranges.restype = C.c_int
     lib.iblnerf_last_selection.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.iblnerf_last_selection.restype = C.c_int
+    lib.iblnerf_last_executed_flops.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.iblnerf_last_executed_flops.restype = C.c_int
     lib.iblnerf_set_query_routing.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_set_query_routing.restype = C.c_int
     lib.iblnerf_range_flags_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -80,7 +80,7 @@ struct iblnerf_ctx {
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
     int* sel_index = nullptr;                     // [4 * ws_rays * Sc] their flat indices
-    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call
+    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs
     long sel_candidates = 0;                      // ... and how many samples were candidates
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
@@ -104,6 +104,7 @@ struct iblnerf_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double flop_alg = 0.0;
+    double flop_exec = 0.0;                       // 2 x MACs the forward launches of the last render call evaluated on whole batches (list launches: sel_count[4..5])
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -254,7 +255,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             return IBLNERF_ERR_NOMEM;
         }
     if (hipMalloc((void**)&c->sel_pts, 4 * R * Sc * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sc * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&c->sel_count, 4 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 4 * sizeof(int)) != hipSuccess) {
+        hipMalloc((void**)&c->sel_count, 8 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 8 * sizeof(int)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
         return IBLNERF_ERR_NOMEM;
@@ -588,6 +589,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
                : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     // (algorithmic FLOPs are counted once: the density column re-evaluated on the 15-slot form beside a FULL query adds time, not work)
+    if (n_pts_dev == nullptr)
+        c->flop_exec += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     if (count_flops && flop_per_point >= 0.0) c->flop_alg += (double)n_pts * flop_per_point;      // (an estimate launch standing for the query it belongs to)
     else if (count_flops) c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
     return IBLNERF_OK;
@@ -1074,7 +1077,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += R * S;
         HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
-                                        false, 0.f, c->raw, RAW_CH));
+                                        false, 0.f, c->raw, RAW_CH, FLOP_FULL + FLOP_TRUNK));
         if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
             int n_sel = 0;
             HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1107,7 +1110,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
             c->sel_candidates += R * S;
             HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->raw, RAW_CH, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                            c->sel_count, s));
+                                            c->sel_count, s, false, 0.f, nullptr, 0, FLOP_TRUNK));
             if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
                 int n_sel = 0;
                 HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1164,7 +1167,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
                 c->sel_candidates += 4 * R * S;
                 HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                                c->sel_count, s, true, eps));
+                                                c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
                 rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
             } else {
                 rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
@@ -1188,7 +1191,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += R * Sc;
         HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                        c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH));
+                                        c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL));
         rc = run_mlp(c, s, VAR_REFL_LIST, which, c->sel_pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
     } else {
         rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
@@ -1301,7 +1304,8 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     c->ev_used = 0;
     c->flop_alg = 0.0;
     c->sel_candidates = 0;
-    HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 2 * sizeof(int), s));
+    c->flop_exec = 0.0;
+    HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 4 * sizeof(int), s));
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
     if ((t_rand || near_ray) && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
@@ -1421,6 +1425,16 @@ int iblnerf_last_selection(iblnerf_ctx* c, int64_t* n_selected, int64_t* n_candi
     HIP_TRY(c, hipMemcpy(&tot, c->sel_count + 2, sizeof tot, hipMemcpyDeviceToHost));
     *n_selected = (int64_t)tot;
     *n_candidates = (int64_t)c->sel_candidates;
+    return IBLNERF_OK;
+}
+
+int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
+    if (!c || !flop_executed) return IBLNERF_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    double on_lists = 0.0;
+    HIP_TRY(c, hipMemcpy(&on_lists, c->sel_count + 4, sizeof on_lists, hipMemcpyDeviceToHost));
+    *flop_executed = c->flop_exec + on_lists;
     return IBLNERF_OK;
 }
 

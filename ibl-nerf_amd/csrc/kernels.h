@@ -190,7 +190,8 @@ constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (
 // offsets: the rays are the 4 R epsilon-offset copies (sigma = sig4 [4][R][S], stride 1; points from gen_offset_point with `eps`)
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets = false,
-                                float eps = 0.0f, float* est_out = nullptr, int est_stride = 0);    // est_out: the estimate copied to element (r S + s) * est_stride
+                                float eps = 0.0f, float* est_out = nullptr, int est_stride = 0,     // est_out: the estimate copied to element (r S + s) * est_stride
+                                double list_flop_per_point = 0.0);   // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
 
 // iblnerf_layer_ranges (range_kernel.hip): largest |value| of each of a network's 15 wide activations on n points; blob = the fp32 state dict in device memory
 struct LayerRangeArgs {

@@ -686,14 +686,25 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
 // result does not depend on its place in a batch), which the precise query then evaluates and scatters over the estimate.  One wavefront per ray.
 // OFFSETS: the "rays" are the 4 R epsilon-offset copies of the samples (normal_from_depth.py:143-160: virtual ray v R + r composites sig4[v][r][:] on ray r's own z
 // and dists, no noise); their points come from gen_offset_point, the generator the TRUNK kernels' input stage uses.
+constexpr int SELECT_WAVES = 8;      // rays per block of k_select_points
+
+// the call's running totals behind a list launch (iblnerf_last_selection / iblnerf_last_executed_flops): [2..3] one uint64 of list entries, [4..5] one double of the
+// MACs x 2 the list launches evaluate on them
+__global__ void k_count_selection(int* counter, double flop_per_point) {
+    const int n = counter[0];
+    *reinterpret_cast<unsigned long long*>(counter + 2) += (unsigned long long)n;
+    *reinterpret_cast<double*>(counter + 4) += (double)n * flop_per_point;
+}
+
 template <int NPL, bool OFFSETS>
-__global__ __launch_bounds__(256) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
+__global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
                                                       const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
                                                       float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
                                                       float* __restrict__ est_out, int est_stride) {
-    const int lane = threadIdx.x & 63;
-    const long vr = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (virtual) ray
-    if (vr >= (OFFSETS ? 4 * R : R)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;      // (virtual) ray
+    const bool live = vr_raw < (OFFSETS ? 4 * R : R);                // (a dead wave of the last block still takes part in the block's count)
+    const long vr = live ? vr_raw : 0;
     const long r = OFFSETS ? vr % R : vr;
     const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
     const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
@@ -708,7 +719,7 @@ __global__ __launch_bounds__(256) void k_select_points(const float* __restrict__
         z[i] = s < S ? zrow[s] : 0.0f;
         const float zn = s + 1 < S ? zrow[s + 1] : 0.0f;
         sg[i] = s < S ? sigma[(vr * S + s) * (long)sigma_stride] : -1e30f;
-        if (est_out != nullptr && s < S) est_out[(vr * S + s) * (long)est_stride] = sg[i];     // the estimate itself, as the density of the samples nobody refines
+        if (est_out != nullptr && s < S && live) est_out[(vr * S + s) * (long)est_stride] = sg[i];     // the estimate itself, as the density of the samples nobody refines
         if (noise != nullptr && s < S) sg[i] = sg[i] + noise[r * S + s];
         const float dist = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
         const float a = s < S ? 1.0f - expf(-fmaxf(sg[i], 0.0f) * dist) : 0.0f;
@@ -731,17 +742,25 @@ __global__ __launch_bounds__(256) void k_select_points(const float* __restrict__
         const int s = lane * NPL + i;
         // (a sample is judged by the transmittance the ESTIMATE gives in front of it, with a margin on the estimate itself: sigma > -margin counts as
         // possibly opaque for nobody else's T, because T only ever gets smaller by counting it)
-        sel[i] = s < S && sg[i] > -margin && T > (double)t_min;
+        sel[i] = live && s < S && sg[i] > -margin && T > (double)t_min;
         T *= om[i];
         masks[i] = __ballot(sel[i]);
         total += __popcll(masks[i]);
     }
-    int base = 0;
-    if (lane == 0 && total > 0) {
-        base = atomicAdd(counter, total);
-        atomicAdd(reinterpret_cast<unsigned long long*>(counter + 2), (unsigned long long)total);     // running total of the call (iblnerf_last_selection)
+    // one atomic per BLOCK: every wave of a launch adding to the one counter by itself serialises in L2 (256 000 waves of the coarse grid's offset copies: 5.6 ms)
+    __shared__ int wave_total[SELECT_WAVES];
+    __shared__ int block_base;
+    if (lane == 0) wave_total[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < SELECT_WAVES; ++w) sum += wave_total[w];
+        block_base = sum > 0 ? atomicAdd(counter, sum) : 0;
     }
-    base = __shfl(base, 0);
+    __syncthreads();
+    int base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_total[w];
     int before = 0;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -1164,17 +1183,20 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
 
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps,
-                                float* est_out, int est_stride) {
+                                float* est_out, int est_stride, double list_flop_per_point) {
     if (R <= 0) return hipSuccess;
-    const dim3 grid((unsigned)(((offsets ? 4 * R : R) + 3) / 4));
-    return by_npl(S, [&](auto N) {
+    const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
+    const hipError_t e = by_npl(S, [&](auto N) {
         if (offsets)
-            hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
+            hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
                                t_min, eps, pts_out, index_out, counter, est_out, est_stride);
         else
-            hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, dim3(256), 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
+            hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
                                t_min, eps, pts_out, index_out, counter, est_out, est_stride);
     });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point);
+    return hipGetLastError();
 }
 
 hipError_t launch_surface_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* raw, const float* noise,

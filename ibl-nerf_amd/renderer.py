@@ -495,10 +495,18 @@ class Renderer:
         B.check(self.ctx, self.lib.iblnerf_trim(self.ctx))
 
     def last_selection(self):
-        """(selected, candidates) of the last render_rays call: how many coarse samples were evaluated on the 15-slot density form (synchronises)."""
+        """(selected, candidates) of the last render_rays call: of the samples that were candidates for a refinement on a list (coarse main query, the coarse
+        grid's offset copies, the reflected rays), how many were evaluated there (synchronises)."""
         a, b = C.c_int64(), C.c_int64()
         B.check(self.ctx, self.lib.iblnerf_last_selection(self.ctx, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def last_executed_flops(self):
+        """2 x the nn.Linear MACs the forward MLP launches of the last render_rays call really evaluated (iblnerf_last_executed_flops; synchronises) — beside
+        last_mlp_time()'s algorithmic count, which prices every sample of every query as the reference evaluates it."""
+        v = C.c_double()
+        B.check(self.ctx, self.lib.iblnerf_last_executed_flops(self.ctx, C.byref(v)))
+        return float(v.value)
 
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))

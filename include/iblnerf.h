@@ -503,9 +503,14 @@ int iblnerf_pack_weights_host_mx(const float* h_blob, size_t n_floats, void* h_s
                                  float* h_tables, size_t table_floats);
 size_t iblnerf_stream_bytes_mx(void);
 
-/* Measurement aid: of the coarse samples of the last iblnerf_render_rays* call, how many were evaluated on the 15-slot density form (the "relevant" ones: neither
- * clearly empty nor behind saturation; IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: not counted, both 0).  Synchronises. */
+/* Measurement aid: of the samples of the last iblnerf_render_rays* call that were candidates for a refinement on a list (coarse main query, the coarse grid's four
+ * offset copies, the reflected ray of each pass), how many were evaluated there (the "relevant" ones: neither clearly empty nor behind saturation;
+ * IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: not counted, both 0).  Synchronises. */
 int iblnerf_last_selection(iblnerf_ctx* ctx, int64_t* n_selected, int64_t* n_candidates);
+/* Measurement aid beside iblnerf_last_mlp_time's ALGORITHMIC count (the reference's nn.Linear MACs x 2 for every sample of every query, ibl_nerf_renderer.py:201-446):
+ * the MACs x 2 the forward MLP launches of the last iblnerf_render_rays* call really evaluated — estimates on the trunk only, head layers and refinements on the selected
+ * samples only, the 15-slot density counted beside the query it refines; each product scheme counts as one MAC.  Synchronises. */
+int iblnerf_last_executed_flops(iblnerf_ctx* ctx, double* flop_executed);
 
 /* Timing aid for bench.py: HIP-event time (ms) of the MLP kernels launched by the last
  * iblnerf_render_rays call on this ctx, and their count.  Enabled by iblnerf_set_profiling(ctx, 1),

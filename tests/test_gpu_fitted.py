@@ -212,12 +212,19 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
         sel, cand = r.last_selection()
+        executed, algorithmic = r.last_executed_flops(), r.last_mlp_time()[2]
+        # (algorithmic: every sample of every query priced as the reference evaluates it; executed: what the launches ran — FLOP_* of csrc/api.cpp)
+        full, trunk, refl = 1591552.0, 982528.0, 1458944.0
+        assert algorithmic == n * ((64 + 192) * full + (256 + 768) * trunk + 128 * refl)
         if label == "selected":
+            want = n * (192 * full + (64 + 256 + 768 + 128) * trunk) + 0.0     # the fine pass as it is; estimates on the trunk ...
+            assert want < executed <= want + sel * (full + trunk), (executed, want)      # ... and at most (whole network + 15-slot density) on each selected sample
+            assert executed < 0.97 * algorithmic           # (the fine pass — 192 whole-network and 768 trunk evaluations per ray — is evaluated everywhere)
             assert cand == n * 64 * 7 and 0.02 * cand < sel < 0.15 * cand, (sel, cand)       # 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass)
             again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                  # the compaction's order is whatever the atomics give: results are not
             assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)
         else:
-            assert (sel, cand) == (0, 0)
+            assert (sel, cand) == (0, 0) and executed == algorithmic + n * 64 * trunk        # (the 15-slot density beside the coarse main query)
     a, b = out["selected"], out["all"]
     refl_dep = ("color_map", "specular_map", "prefiltered_reflected_map", "reflected_radiance_map", "reflected_coarse_radiance_map_1",
                 "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")
