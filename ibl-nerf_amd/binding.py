@@ -24,7 +24,7 @@ EXPORTS = [
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
-    "iblnerf_last_executed_flops",
+    "iblnerf_last_executed_flops", "iblnerf_estimate_policy",
 ]
 
 
@@ -46,6 +46,7 @@ MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE, ROUTE_POINT_BATCH, ROUTE_COARSE_MAIN_22BIT, ROUTE_USER_TRUNK_P, ROUTE_FINE_OFFSETS_PRECISE, ROUTE_COARSE_DENSITY_ALL_POINTS = 1, 2, 4, 8, 16, 32, 64, 128   # iblnerf_options.query_routing bits
+ROUTE_ESTIMATES_6SLOT = 256
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -130,6 +131,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_last_selection.restype = C.c_int
     lib.iblnerf_last_executed_flops.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.iblnerf_last_executed_flops.restype = C.c_int
+    lib.iblnerf_estimate_policy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.iblnerf_estimate_policy.restype = C.c_int
     lib.iblnerf_set_query_routing.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_set_query_routing.restype = C.c_int
     lib.iblnerf_range_flags_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

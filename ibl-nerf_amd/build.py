@@ -53,6 +53,7 @@ SOURCES = [
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=0"], "mlp_kernel_mx16_full"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=1"], "mlp_kernel_mx16_trunk"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=2"], "mlp_kernel_mx16_refl"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=3"], "mlp_kernel_mx16_full_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=4"], "mlp_kernel_mx16_refl_ci"),

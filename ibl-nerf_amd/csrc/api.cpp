@@ -29,9 +29,11 @@ constexpr double FLOP_FEAT_VIEW = 2.0 * (256.0 * 256.0 + 256.0 * 283.0);   // wh
 }  // namespace
 
 constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
-// k_select_points: a density estimate below -MARGIN is empty space whatever its error (the fast kernel's is < 1e-2 on a fitted checkpoint); a sample
-// behind a transmittance of TMIN carries, with everything behind it, a weight below TMIN
-constexpr float COARSE_SELECT_MARGIN = 1.0f, COARSE_SELECT_TMIN = 1e-8f;
+// k_select_points: a density estimate below -MARGIN is empty space whatever its error, and a sample behind a transmittance of TMIN carries, with everything behind
+// it, a weight below TMIN (the transmittance taken conservatively: render_kernels.hip).  Estimate errors measured on the two fitted checkpoints (3 M coarse-grid points
+// and offset copies each, scratch/estimate_error.py): plain f16 0.20 / 1.45 at worst (99.99 %: 0.12 / 0.84; 11 % of a density above 10), f16 + 2 fp6 below 1e-2.
+// Widening the margin is nearly free: densities between -2 and -1 are 0.2 % of the samples.
+constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
@@ -77,10 +79,13 @@ struct iblnerf_ctx {
     bool x_coarse = false, x_user = false, fine_main_precise = false;
     bool x_fine_precise = false;                  // IBLNERF_ROUTE_FINE_OFFSETS_PRECISE
     bool coarse_sigma_p = true, p_user = false;
+    bool est_f16 = true;                          // density estimates behind a list refinement in plain f16 (IBLNERF_ROUTE_ESTIMATES_6SLOT: on the f16 + 2 fp6 form) ...
+    bool est_checked[2] = {false, false}, est_ok[2] = {false, false};   // ... once the network's first launch has shown that they are good enough (check_estimates)
+    bool est_probe = false;                       // (that check's own plain-f16 launch)
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
     int* sel_index = nullptr;                     // [4 * ws_rays * Sc] their flat indices
-    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs
+    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs; [6] check_estimates' count
     long sel_candidates = 0;                      // ... and how many samples were candidates
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
@@ -133,13 +138,14 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->p_user = (bits & IBLNERF_ROUTE_USER_TRUNK_P) != 0;
     c->x_fine_precise = (bits & IBLNERF_ROUTE_FINE_OFFSETS_PRECISE) != 0;
     c->p_all_points = (bits & IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS) != 0;
+    c->est_f16 = (bits & IBLNERF_ROUTE_ESTIMATES_6SLOT) == 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 255) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..255)");
+    if (bits < 0 || bits > 511) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..511)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -213,8 +219,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 255 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..255), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 511 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..511), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -356,6 +362,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     }
     c->have_net[slot] = true;
     if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
+    if (slot < 2) c->est_checked[slot] = c->est_ok[slot] = false;
     return IBLNERF_OK;
 }
 
@@ -558,7 +565,8 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             kern = K_MX16;
     }
     if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
-    if (qclass == Q_ESTIMATE) kern = K_MX;      // (likewise)
+    // (likewise; the trunk-only estimates in plain f16: all an estimate has to get right is which side of -1 a raw density lies on)
+    if (qclass == Q_ESTIMATE) kern = (variant == VAR_TRUNK && which < 2 && ((c->est_f16 && c->est_checked[which] && c->est_ok[which]) || c->est_probe)) ? K_MX16 : K_MX;
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
     if (variant == VAR_TRUNK_GRAD) kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3;
     a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
@@ -1051,6 +1059,26 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
     return a;
 }
 
+// Once per uploaded network: may its density estimates run in plain f16?  Both estimates of the launch's main-query samples (c->pts), compared by
+// k_compare_estimates; one stream synchronisation.  A network whose plain-f16 trunk is ever half-way to a wrong selection keeps the f16 + 2 fp6 estimates.
+static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts, int S) {
+    c->est_checked[which] = true;
+    c->est_ok[which] = false;
+    int rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, n_pts, c->sig4, 1, Q_ESTIMATE, nullptr, false);
+    if (rc) return rc;
+    c->est_probe = true;
+    rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, n_pts, c->sig4 + n_pts, 1, Q_ESTIMATE, nullptr, false);
+    c->est_probe = false;
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->sel_count + 6, 0, sizeof(int), s));
+    HIP_TRY(c, launch_compare_estimates(c->sig4 + n_pts, c->sig4, n_pts, COARSE_SELECT_MARGIN, c->sel_count + 6, s));
+    int bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->sel_count + 6, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->est_ok[which] = bad == 0;
+    return IBLNERF_OK;
+}
+
 // One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
 // zc / zc_stride: z_vals_constant, the coarse grid the reflected ray is sampled on (one shared row, or per-ray rows under perturb);
 // coarse_grid: this pass's own samples are that grid.
@@ -1065,6 +1093,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (!c->sel_decided || c->sel_on);
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
+    if (list_ok && c->est_f16 && which < 2 && !c->est_checked[which])
+        if (int rc0 = check_estimates(c, s, which, R * S, S)) return rc0;
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
     int rc = IBLNERF_OK;
     bool main_done = false, est_counted = false;
@@ -1425,6 +1455,13 @@ int iblnerf_last_selection(iblnerf_ctx* c, int64_t* n_selected, int64_t* n_candi
     HIP_TRY(c, hipMemcpy(&tot, c->sel_count + 2, sizeof tot, hipMemcpyDeviceToHost));
     *n_selected = (int64_t)tot;
     *n_candidates = (int64_t)c->sel_candidates;
+    return IBLNERF_OK;
+}
+
+int iblnerf_estimate_policy(iblnerf_ctx* c, int which, int* checked, int* plain_f16) {
+    if (!c || which < 0 || which > 1 || !checked || !plain_f16) return IBLNERF_ERR_INVALID;
+    *checked = c->est_checked[which] ? 1 : 0;
+    *plain_f16 = (c->est_f16 && c->est_checked[which] && c->est_ok[which]) ? 1 : 0;
     return IBLNERF_OK;
 }
 

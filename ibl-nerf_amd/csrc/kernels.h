@@ -193,6 +193,9 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                 float eps = 0.0f, float* est_out = nullptr, int est_stride = 0,     // est_out: the estimate copied to element (r S + s) * est_stride
                                 double list_flop_per_point = 0.0);   // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
 
+// counts into *bad the samples on which estimate `a` (plain f16) is half-way to a wrong k_select_points decision against estimate `b` (f16 + 2 fp6)
+hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, int* bad, hipStream_t s);
+
 // iblnerf_layer_ranges (range_kernel.hip): largest |value| of each of a network's 15 wide activations on n points; blob = the fp32 state dict in device memory
 struct LayerRangeArgs {
     const float* blob;

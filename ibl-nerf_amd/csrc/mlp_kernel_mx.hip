@@ -1172,8 +1172,8 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_FULL_CI: return IBL_L(full_ci)(a, grid, stream);
         case VAR_REFL_CI: return IBL_L(refl_ci)(a, grid, stream);
 #endif
-#ifndef IBL_MX_F16ONLY          // the trunk-only evaluation feeds the finite-difference normal: never in plain f16
-        case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);
+        case VAR_TRUNK: return IBL_L(trunk)(a, grid, stream);   // (in plain f16: a density ESTIMATE only, api.cpp Q_ESTIMATE — never what feeds the finite-difference normal)
+#ifndef IBL_MX_F16ONLY
         case VAR_TRUNK_X: return IBL_L(trunk_x)(a, grid, stream);
         case VAR_TRUNK_P: return IBL_L(trunk_p)(a, grid, stream);
 #ifndef IBL_MX_DEV_TRUNK_ONLY

@@ -501,6 +501,13 @@ class Renderer:
         B.check(self.ctx, self.lib.iblnerf_last_selection(self.ctx, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def estimate_policy(self, which=0):
+        """(checked, plain_f16) of network `which`: whether its first render launch has compared the plain-f16 density estimates with the f16 + 2 fp6 ones, and whether
+        they passed (iblnerf_estimate_policy)."""
+        a, b = C.c_int(), C.c_int()
+        B.check(self.ctx, self.lib.iblnerf_estimate_policy(self.ctx, int(which), C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def last_executed_flops(self):
         """2 x the nn.Linear MACs the forward MLP launches of the last render_rays call really evaluated (iblnerf_last_executed_flops; synchronises) — beside
         last_mlp_time()'s algorithmic count, which prices every sample of every query as the reference evaluates it."""

@@ -126,8 +126,11 @@ enum {
     IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS = 128, /* the 15-slot density on EVERY coarse sample instead of the relevant ones only (those that are neither clearly
                                                  empty — density estimate below -1: alpha = 0 exactly — nor behind a transmittance of 1e-8); an A/B aid: results
                                                  agree to ~1e-9 on a weight */
-    IBLNERF_ROUTE_FINE_OFFSETS_PRECISE = 64   /* F16X3_MXFP6X: the fine grid's offset queries back on F16X3 (with IBLNERF_ROUTE_FINE_MAIN_PRECISE the mode then
+    IBLNERF_ROUTE_FINE_OFFSETS_PRECISE = 64,  /* F16X3_MXFP6X: the fine grid's offset queries back on F16X3 (with IBLNERF_ROUTE_FINE_MAIN_PRECISE the mode then
                                                  routes every query as F16X3_MXFP6 does: the "safe" policy of ibl-nerf_amd/renderer.py's load-time calibration) */
+    IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
+                                                 f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
+                                                 only has to be right to within the selection margin of 1.0 in raw density */
 };
 /* Changes options.query_routing of an existing context (no reallocation; takes effect with the next call; the caller orders it against work in
  * flight by issuing it between calls on the context's stream).  Bits that need a stream the context's mlp_precision does not keep are ignored as at
@@ -507,6 +510,10 @@ size_t iblnerf_stream_bytes_mx(void);
  * offset copies, the reflected ray of each pass), how many were evaluated there (the "relevant" ones: neither clearly empty nor behind saturation;
  * IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: not counted, both 0).  Synchronises. */
 int iblnerf_last_selection(iblnerf_ctx* ctx, int64_t* n_selected, int64_t* n_candidates);
+/* Which form the density estimates of network `which` (0 network_fn, 1 network_fine) run on: *checked = 1 once the network's first render launch has compared the
+ * plain-f16 trunk against the f16 + 2 fp6 one on that launch's samples (once per upload), *plain_f16 = 1 if it was never half-way to a wrong selection (a positive
+ * density estimated below -1, or overshot beyond what the conservative transmittance allows for) and IBLNERF_ROUTE_ESTIMATES_6SLOT is not set. */
+int iblnerf_estimate_policy(iblnerf_ctx* ctx, int which, int* checked, int* plain_f16);
 /* Measurement aid beside iblnerf_last_mlp_time's ALGORITHMIC count (the reference's nn.Linear MACs x 2 for every sample of every query, ibl_nerf_renderer.py:201-446):
  * the MACs x 2 the forward MLP launches of the last iblnerf_render_rays* call really evaluated — estimates on the trunk only, head layers and refinements on the selected
  * samples only, the 15-slot density counted beside the query it refines; each product scheme counts as one MAC.  Synchronises. */

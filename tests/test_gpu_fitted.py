@@ -208,23 +208,30 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
     out = {}
-    for label, routing in (("selected", ()), ("all", ("coarse_density_all_points",))):
+    for label, routing in (("selected", ()), ("est6", ("estimates_6slot",)), ("all", ("coarse_density_all_points",))):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        assert r.estimate_policy(0) == (False, False)
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
         sel, cand = r.last_selection()
+        # the density estimates run in plain f16 once the network's first launch has compared them with the f16 + 2 fp6 ones (api.cpp check_estimates)
+        assert r.estimate_policy(0) == r.estimate_policy(1) == {"selected": (True, True), "est6": (False, False), "all": (False, False)}[label]
+        again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                      # the compaction's order is whatever the atomics give: results are not
+        assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)
         executed, algorithmic = r.last_executed_flops(), r.last_mlp_time()[2]
         # (algorithmic: every sample of every query priced as the reference evaluates it; executed: what the launches ran — FLOP_* of csrc/api.cpp)
         full, trunk, refl = 1591552.0, 982528.0, 1458944.0
         assert algorithmic == n * ((64 + 192) * full + (256 + 768) * trunk + 128 * refl)
-        if label == "selected":
+        if label != "all":
             want = n * (192 * full + (64 + 256 + 768 + 128) * trunk) + 0.0     # the fine pass as it is; estimates on the trunk ...
             assert want < executed <= want + sel * (full + trunk), (executed, want)      # ... and at most (whole network + 15-slot density) on each selected sample
             assert executed < 0.97 * algorithmic           # (the fine pass — 192 whole-network and 768 trunk evaluations per ray — is evaluated everywhere)
             assert cand == n * 64 * 7 and 0.02 * cand < sel < 0.15 * cand, (sel, cand)       # 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass)
-            again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                  # the compaction's order is whatever the atomics give: results are not
-            assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)
         else:
             assert (sel, cand) == (0, 0) and executed == algorithmic + n * 64 * trunk        # (the 15-slot density beside the coarse main query)
+    # plain-f16 estimates select (nearly) the same samples as the f16 + 2 fp6 ones, and nothing that is not selected matters: the two renders agree to fp32 round-off
+    for k in out["selected"]:
+        x, y = out["selected"][k].cpu().numpy(), out["est6"][k].cpu().numpy()
+        assert rel_linf(x, y) <= (1e-5 if "normal" in k or "n_dot_v" in k or "reflected" in k or k.startswith(("specular", "color")) else 1e-6), k
     a, b = out["selected"], out["all"]
     refl_dep = ("color_map", "specular_map", "prefiltered_reflected_map", "reflected_radiance_map", "reflected_coarse_radiance_map_1",
                 "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3")
@@ -254,6 +261,45 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
         r.load_weights(0, fc); r.load_weights(1, ff); r.load_lut(lut)
         fog[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
     assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
+
+
+def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
+    """api.cpp check_estimates, the refusing side.  A network whose last trunk layer cancels large terms — four copies of one active layer-6 feature h weighted
+    +3K, -K, -K, -K in every row of positions_linears.7 on top of the fitted weights, K = 12004.4: fp32 and every scheme with a second term per operand see the
+    weights' low bits, one f16 term rounds 3K and K to 36000 and 12008 and shifts every pre-activation of the layer by -24 h — fails the comparison on its first
+    launch and keeps the f16 + 2 fp6 estimates (the coarse pass then equals the estimates_6slot routing bit for bit); the untouched fine network passes.
+    (The density head itself runs on the VALU from fp32 weights in every kernel: the cancellation has to sit in a matrix layer.)"""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    n = 8192
+    sd = {k: np.array(v, dtype=np.float32) for k, v in sdc.items()}
+    pts = (g["rays_o"][:64, None, :] + g["rays_d"][:64, None, :] * np.linspace(0.5, 8.0, 64, dtype=np.float32)[None, :, None]).reshape(-1, 3)
+    e = O.embed(pts, 10)
+    h = e
+    for i in range(7):
+        h = np.maximum(h @ sd["positions_linears.%d.weight" % i].T + sd["positions_linears.%d.bias" % i], 0)
+        if i == 4:
+            h = np.concatenate([e, h], -1)
+    order = np.argsort(h.mean(0))
+    a, others = int(order[-1]), [int(i) for i in order[:3]]          # the most active layer-6 feature, copied over the three least active ones
+    assert h[:, a].mean() > 0.05
+    K = np.float32(12004.4)
+    for b in others:
+        sd["positions_linears.6.weight"][b] = sd["positions_linears.6.weight"][a]
+        sd["positions_linears.6.bias"][b] = sd["positions_linears.6.bias"][a]
+        sd["positions_linears.7.weight"][:, b] -= K
+    sd["positions_linears.7.weight"][:, a] += 3 * K
+    out = {}
+    for label, routing in (("default", ()), ("est6", ("estimates_6slot",))):
+        r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
+        sel, cand = r.last_selection()
+        assert cand == n * 64 * 7 and 0 < sel < 0.3 * cand, (sel, cand)             # (still a scene with surfaces: the refinement itself stays on)
+        if label == "default":
+            assert r.estimate_policy(0) == (True, False) and r.estimate_policy(1) == (True, True)
+        assert r.range_fallbacks == 0
+    for k in out["default"]:
+        if k.endswith("0"):
+            assert torch.equal(out["default"][k], out["est6"][k]), k
 
 
 def test_fitted_wide_error_class_of_f16x3_main(R, lut):
