@@ -34,6 +34,7 @@ constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // and offset copies each, scratch/estimate_error.py): plain f16 0.20 / 1.45 at worst (99.99 %: 0.12 / 0.84; 11 % of a density above 10), f16 + 2 fp6 below 1e-2.
 // Widening the margin is nearly free: densities between -2 and -1 are 0.2 % of the samples.
 constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
+constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample) + share x whole network
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
@@ -90,6 +91,7 @@ struct iblnerf_ctx {
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
     // host upload of network 0, on the first launch's own count (one stream synchronisation per checkpoint), and frozen: results must not depend on call history.
+    bool fsel_decided = false, fsel_on = true;   // the FINE main query on the relevant samples only (decided like sel_on, on the fine pass's first launch)
     bool sel_decided = false, sel_on = true;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
@@ -362,6 +364,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     }
     c->have_net[slot] = true;
     if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
+    if (slot < 2) { c->fsel_decided = false; c->fsel_on = true; }
     if (slot < 2) c->est_checked[slot] = c->est_ok[slot] = false;
     return IBLNERF_OK;
 }
@@ -1119,6 +1122,32 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
             if (rc) return rc;
             rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            if (rc) return rc;
+            main_done = true;
+        }
+    }
+    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (!c->fsel_decided || c->fsel_on) && !keep_all_rows && !c->fine_main_precise &&
+        c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
+        // the FAST table's FINE main query likewise: the importance samples crowd around the surface, so about half of them are relevant (against 6-7 % on the coarse
+        // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
+        // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
+        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
+        if (rc) return rc;
+        est_counted = true;
+        HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)R * S * RAW_CH * sizeof(float), s));
+        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        c->sel_candidates += R * S;
+        HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+                                        false, 0.f, c->raw, RAW_CH, FLOP_FULL));
+        if (!c->fsel_decided) {
+            int n_sel = 0;
+            HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            c->fsel_decided = true;
+            c->fsel_on = (double)n_sel <= FINE_SELECT_MAX_FRACTION * (double)(R * S);
+        }
+        if (c->fsel_on) {
+            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
             if (rc) return rc;
             main_done = true;
         }
