@@ -50,6 +50,7 @@ SOURCES = [
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=13"], "mlp_kernel_mx_trunk_p"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=15"], "mlp_kernel_mx_refl_list"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=16"], "mlp_kernel_mx_full_list"),
+    ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=17"], "mlp_kernel_mx_trunk_x_list"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=3"], "mlp_kernel_mx_full_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=4"], "mlp_kernel_mx_refl_ci"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_F16ONLY", "-DIBL_MX_VARIANT=0"], "mlp_kernel_mx16_full"),

@@ -34,6 +34,10 @@ constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // and offset copies each, scratch/estimate_error.py): plain f16 0.20 / 1.45 at worst (99.99 %: 0.12 / 0.84; 11 % of a density above 10), f16 + 2 fp6 below 1e-2.
 // Widening the margin is nearly free: densities between -2 and -1 are 0.2 % of the samples.
 constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
+// ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
+// normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
+constexpr float OFFSET_SELECT_TMIN = 1e-10f;
+constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42;   // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation) + share x TRUNK_X
 constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample) + share x whole network
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
@@ -91,6 +95,7 @@ struct iblnerf_ctx {
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
     // host upload of network 0, on the first launch's own count (one stream synchronisation per checkpoint), and frozen: results must not depend on call history.
+    bool xsel_decided = false, xsel_on = true;   // ... and the fine grid's offset copies
     bool fsel_decided = false, fsel_on = true;   // the FINE main query on the relevant samples only (decided like sel_on, on the fine pass's first launch)
     bool sel_decided = false, sel_on = true;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
@@ -262,7 +267,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             iblnerf_destroy(c);
             return IBLNERF_ERR_NOMEM;
         }
-    if (hipMalloc((void**)&c->sel_pts, 4 * R * Sc * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sc * sizeof(int)) != hipSuccess ||
+    if (hipMalloc((void**)&c->sel_pts, 4 * R * Sm * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sm * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->sel_count, 8 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 8 * sizeof(int)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
@@ -364,7 +369,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     }
     c->have_net[slot] = true;
     if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
-    if (slot < 2) { c->fsel_decided = false; c->fsel_on = true; }
+    if (slot < 2) { c->fsel_decided = c->xsel_decided = false; c->fsel_on = c->xsel_on = true; }
     if (slot < 2) c->est_checked[slot] = c->est_ok[slot] = false;
     return IBLNERF_OK;
 }
@@ -568,6 +573,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             kern = K_MX16;
     }
     if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
+    if (variant == VAR_TRUNK_X_LIST) kern = K_MX;
     // (likewise; the trunk-only estimates in plain f16: all an estimate has to get right is which side of -1 a raw density lies on)
     if (qclass == Q_ESTIMATE) kern = (variant == VAR_TRUNK && which < 2 && ((c->est_f16 && c->est_checked[which] && c->est_ok[which]) || c->est_probe)) ? K_MX16 : K_MX;
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
@@ -1225,9 +1231,29 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 if (rc) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
                 c->sel_candidates += 4 * R * S;
-                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
                                                 c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
                 rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (!c->xsel_decided || c->xsel_on) && !c->x_fine_precise &&
+                       c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
+                // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
+                // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
+                // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
+                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
+                if (rc) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+                c->sel_candidates += 4 * R * S;
+                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
+                                                c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
+                if (!c->xsel_decided) {
+                    int n_sel = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    c->xsel_decided = true;
+                    c->xsel_on = (double)n_sel <= FINE_OFFSET_SELECT_MAX_FRACTION * (double)(4 * R * S);
+                }
+                if (c->xsel_on) rc = run_mlp(c, s, VAR_TRUNK_X_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, nullptr, false, c->sel_count, c->sel_index);
+                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, &g, false);
             } else {
                 rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
             }

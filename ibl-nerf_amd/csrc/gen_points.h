@@ -2,9 +2,12 @@
 // (ibl_nerf_renderer.py:200) and the four epsilon-offset copies x +- eps right, x +- eps up of get_normal_from_depth_gradient_epsilon
 // (normal_from_depth.py:143-156), as ONE device function shared by k_make_points (render_kernels.hip, which still fills the [V][R][S][3] batch
 // for the queries that read one) and by the TRUNK forms of the MLP kernels, which call it in their input stage instead of reading a batch.
-// Every operation is an explicitly rounded intrinsic (__fmul_rn / __fadd_rn / __fsub_rn are never contracted into an fma): the MLP kernels
-// are compiled with contraction on, and positions feed a 2^9 frequency multiplier, so they must round like the reference's separate torch
-// multiply and add — bit-identical points are what the stage tests feed and what the chunk- and tile-invariance tests rely on.
+// No operation here may be contracted into an fma: the MLP kernels are compiled with contraction on, and positions feed a 2^9 frequency multiplier,
+// so they must round like the reference's separate torch multiply and add — bit-identical points are what the stage tests feed and what the chunk- and
+// tile-invariance tests rely on.  `#pragma clang fp contract(off)` at the head of each body does that (hipcc's default is fast-honor-pragmas).  NOT the
+// __fmul_rn / __fadd_rn intrinsics: this toolchain defines them as plain `x * y` / `x + y` (__clang_hip_math.h) and fuses them like any other — round 3's
+// version of this file did, and the up axis of rays with d_x != 0 (d_x^2 + 1 as one fma) and the base point of posed cameras (o + d z) were one ulp off the
+// batch k_make_points writes (found in round 4 when a list of points from render_kernels.hip met the same kernel: 27 rays of 262 144 moved by 1e-6 .. 4.5e-5).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,12 +25,13 @@ struct PointGen {
 
 // right = d x (0,1,0), up = right x d with torch.cross's products and differences rounded one by one (normal_from_depth.py:143-147)
 __device__ __forceinline__ void gen_right_up(const float (&d)[3], float (&right)[3], float (&up)[3]) {
-    right[0] = __fsub_rn(__fmul_rn(d[1], 0.0f), __fmul_rn(d[2], 1.0f));
-    right[1] = __fsub_rn(__fmul_rn(d[2], 0.0f), __fmul_rn(d[0], 0.0f));
-    right[2] = __fsub_rn(__fmul_rn(d[0], 1.0f), __fmul_rn(d[1], 0.0f));
-    up[0] = __fsub_rn(__fmul_rn(right[1], d[2]), __fmul_rn(right[2], d[1]));
-    up[1] = __fsub_rn(__fmul_rn(right[2], d[0]), __fmul_rn(right[0], d[2]));
-    up[2] = __fsub_rn(__fmul_rn(right[0], d[1]), __fmul_rn(right[1], d[0]));
+#pragma clang fp contract(off)
+    right[0] = d[1] * 0.0f - d[2] * 1.0f;
+    right[1] = d[2] * 0.0f - d[0] * 0.0f;
+    right[2] = d[0] * 1.0f - d[1] * 0.0f;
+    up[0] = right[1] * d[2] - right[2] * d[1];
+    up[1] = right[2] * d[0] - right[0] * d[2];
+    up[2] = right[0] * d[1] - right[1] * d[0];
 }
 
 // The generator's parameters as the MLP kernels read them: NOT from the by-value kernel argument (seven more scalars live across an
@@ -58,11 +62,15 @@ __device__ __forceinline__ void gen_offset_point(const PointGen& g, unsigned p, 
     gen_right_up(d, right, up);
     const float* axis = v < 2 ? right : up;
     float q[3];
+    {
+#pragma clang fp contract(off)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float base = __fadd_rn(o[c], __fmul_rn(d[c], zz));
-        const float e = __fmul_rn(g.eps, axis[c]);
-        q[c] = (v & 1u) ? __fsub_rn(base, e) : __fadd_rn(base, e);
+        for (int c = 0; c < 3; ++c) {
+            const float t = d[c] * zz;
+            const float base = o[c] + t;
+            const float e = g.eps * axis[c];
+            q[c] = (v & 1u) ? base - e : base + e;
+        }
     }
     px = q[0]; py = q[1]; pz = q[2];
 }

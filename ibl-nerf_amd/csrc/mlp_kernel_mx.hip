@@ -121,7 +121,7 @@ template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
     static constexpr bool PP = VARIANT == VAR_TRUNK_P;                  // every trunk block as a (network, residual) pair
-    static constexpr bool X = VARIANT == VAR_TRUNK_X || PP;             // a wave's block comes from its own place in the stream
+    static constexpr bool X = variant_trunk_x(VARIANT) || PP;             // a wave's block comes from its own place in the stream
     static constexpr int N_PROG = PP ? mx::N_CHUNKS_TRUNK_P : X ? mx::N_CHUNKS_TRUNK_X : VARIANT == VAR_TRUNK ? mx::N_CHUNKS_TRUNK
                                                         : mx::N_CHUNKS_TRUNK + (CI ? 0 : 8 + 10) + (ALBIRR ? 8 : 0) + 12;
     const char* stream;
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     load_frag<3, 3>(pf, P.block(false, 0), lane);
     unsigned wsc = 0, peak = 0;
 
-    constexpr bool LIST = VARIANT == VAR_REFL_LIST || VARIANT == VAR_FULL_LIST;      // a compact list of points with a flat index each (MlpArgs::out_index)
+    constexpr bool LIST = VARIANT == VAR_REFL_LIST || VARIANT == VAR_FULL_LIST || VARIANT == VAR_TRUNK_X_LIST;      // a compact list of points with a flat index each (MlpArgs::out_index)
     long n_total = a.n_pts;
     if constexpr (VARIANT == VAR_TRUNK_P || LIST) {
         if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
         const bool valid = p < n_total;
-        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_X || VARIANT == VAR_TRUNK_P;
+        constexpr bool TRUNKV = VARIANT == VAR_TRUNK || variant_trunk_x(VARIANT) || VARIANT == VAR_TRUNK_P;
 #ifdef IBL_MX_ABLATE_PROLOGUE
         if (g == blockIdx.x) {
 #endif
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         Blk pe, de;
         u32x16 pe_lo, loA[4];   // VAR_TRUNK_X: f16 residuals of the encoding and of layer 0's output
 #endif
-        encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak, VARIANT == VAR_TRUNK_X ? &pe_lo : nullptr);
+        encode<PE_PAIRS_PER_HALF>(px, py, pz, h, pe, peak, variant_trunk_x(VARIANT) ? &pe_lo : nullptr);
         if constexpr (!TRUNKV && !variant_ci(VARIANT)) {
             float dx = 0.f, dy = 0.f, dz = 0.f;
             if (valid) {
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         Epi<true, true, 0> eA{&A, {nullptr}, {nullptr}, &peak}, eB{&B, {nullptr}, {nullptr}, &peak};
 
         f32x16 pacc;
-        if constexpr (VARIANT == VAR_TRUNK_X) {
+        if constexpr (variant_trunk_x(VARIANT)) {
             // positions_linears.0 and .1 as three f16 products (-> A with its f16 residuals in loA, -> B), then .2 (B -> A)
             Epi<true, true, 0, true> eA0{&A, {nullptr}, {nullptr}, &peak, loA};
             pacc = run_layer_x3<8, true, 0>(P, pf, wsc, A /*unused*/, loA /*unused*/, pe, pe_lo, bias + BT_L0 * 32, none, eA0);
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             pacc = run_layer<8, true, 0>(P, pf, wsc, A /*unused*/, pe, bias + BT_L0 * 32, none, eA);
         }
         // positions_linears.1..4, two layers per trip (A -> B -> A)   (VAR_TRUNK_X: .3 and .4 only)
-        for (int l = (VARIANT == VAR_TRUNK_X ? 3 : 1); l <= 3; l += 2) {
+        for (int l = (variant_trunk_x(VARIANT) ? 3 : 1); l <= 3; l += 2) {
             pacc = run_layer<8, false, 4>(P, pf, wsc, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32,
                                           [&](auto I, auto K) { eA.template stage<7, decltype(I)::value, decltype(K)::value>(pacc); }, eB);
             pacc = run_layer<8, false, 4>(P, pf, wsc, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32,
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         if constexpr (TRUNKV) {
             const float p0 = part[0][0] + part[0][1];
             const float s = p0 + __shfl_xor(p0, 32) + sc[0];
-            if (valid && h == 0) a.out[(long)p * a.out_stride] = s;
+            if (valid && h == 0) a.out[(LIST ? (long)a.out_index[p] : (long)p) * a.out_stride] = s;
         } else {
             float tot[RAW_CH];
 #pragma unroll
@@ -1128,6 +1128,8 @@ hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return la
 hipError_t IBL_L(refl_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL_LIST>(a, grid, s); }
 #elif IBL_MX_VARIANT == 16
 hipError_t IBL_L(full_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_LIST>(a, grid, s); }
+#elif IBL_MX_VARIANT == 17
+hipError_t IBL_L(trunk_x_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X_LIST>(a, grid, s); }
 #elif IBL_MX_VARIANT == 3
 hipError_t IBL_L(full_ci)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL_CI>(a, grid, s); }
 #else
@@ -1138,6 +1140,7 @@ hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return laun
 #ifndef IBL_MX_F16ONLY
 hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X>(a, grid, s); }
 hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_P>(a, grid, s); }
+hipError_t IBL_L(trunk_x_list)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK_X_LIST>(a, grid, s); }
 #endif
 #ifndef IBL_MX_DEV_TRUNK_ONLY
 hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
@@ -1161,6 +1164,7 @@ hipError_t IBL_L(trunk_x)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(trunk_p)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(refl_list)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_L(full_list)(const MlpArgs& a, int grid, hipStream_t s);
+hipError_t IBL_L(trunk_x_list)(const MlpArgs& a, int grid, hipStream_t s);
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
     const long n_groups = (a.n_pts + 127) / 128;
@@ -1176,6 +1180,7 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
 #ifndef IBL_MX_F16ONLY
         case VAR_TRUNK_X: return IBL_L(trunk_x)(a, grid, stream);
         case VAR_TRUNK_P: return IBL_L(trunk_p)(a, grid, stream);
+        case VAR_TRUNK_X_LIST: return IBL_L(trunk_x_list)(a, grid, stream);
 #ifndef IBL_MX_DEV_TRUNK_ONLY
         case VAR_REFL_LIST: return IBL_L(refl_list)(a, grid, stream);
         case VAR_FULL_LIST: return IBL_L(full_list)(a, grid, stream);

@@ -225,9 +225,11 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
         if label != "all":
             want = n * (64 + 256 + 768 + 128 + 192) * trunk + 0.0              # the fine grid's offset queries as they are; estimates on the trunk ...
             assert want < executed <= want + sel * (full + trunk), (executed, want)      # ... and at most (whole network + 15-slot density) on each selected sample
-            assert executed < 0.98 * algorithmic           # (MAC counts barely differ: the gain is in the estimates' plain-f16 MACs costing 4 matrix slots instead of 6-15)
-            # 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass) + the fine main query's 192 (about half of which are relevant)
-            assert cand == n * (64 * 7 + 192) and 0.05 * cand < sel < 0.3 * cand, (sel, cand)
+            # candidates: 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass) + the fine main query's 192 (about 40 % of which are
+            # relevant) + the fine grid's 4 x 192 offset copies where the first launch found few enough of them relevant (FINE_OFFSET_SELECT_MAX_FRACTION)
+            assert cand in (n * (64 * 7 + 192), n * (64 * 7 + 192 + 768)) and 0.05 * cand < sel < 0.45 * cand, (sel, cand)
+            if cand == n * (64 * 7 + 192):
+                assert executed < 0.98 * algorithmic       # (MAC counts barely differ: the gain is in the estimates' plain-f16 MACs costing 4 matrix slots instead of 6-15)
         else:
             assert (sel, cand) == (0, 0) and executed == algorithmic + n * 64 * trunk        # (the 15-slot density beside the coarse main query)
     # plain-f16 estimates select (nearly) the same samples as the f16 + 2 fp6 ones, and nothing that is not selected matters: the two renders agree to fp32 round-off
@@ -267,6 +269,28 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
 
 
+@pytest.mark.parametrize("prec,routing", [("f16x3", ()), ("bf16x3", ()), ("f16x3_mxfp6x", ("coarse_density_all_points",)), ("f16x3_mxfp6x", ())])
+def test_generated_points_are_the_batch_bit_for_bit(R, lut, prec, routing):
+    """csrc/gen_points.h: the epsilon-offset copies generated in the MLP kernels' input stage (contraction on) are the points k_make_points writes into a batch
+    (IBLNERF_ROUTE_POINT_BATCH; render_kernels.hip, contraction off) — on a rotated camera away from the origin, where o + d z and d_x^2 + 1 round differently as
+    one fma (round 3's generator did: __fmul_rn / __fadd_rn are plain operators on this toolchain and were fused; 27 rays of 262 144 moved by up to 4.5e-5).
+    With the list refinement on (last case) a third producer of the same points joins: k_select_points."""
+    g, sdc, sdf, _, _ = load_golden("fitted_posed4k")
+    assert np.abs(g["rays_o"]).max() > 0.1 and (np.abs(g["rays_d"][:, 0]) > 0.1).any()
+    out = {}
+    for label, extra in (("generated", ()), ("batch", ("point_batch",))):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec, query_routing=tuple(routing) + extra)
+        out[label] = r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]))
+    if routing == () and prec == "f16x3_mxfp6x":
+        # (the batch routing evaluates the offset copies whole, the default refines lists of them: the same arithmetic on the relevant samples, estimates on the rest)
+        # fine grid: TRUNK_X either way; coarse grid: the 15-slot form on the list against three f16 products on the batch
+        assert float((out["generated"]["target_normal_map"] - out["batch"]["target_normal_map"]).abs().max()) <= 2e-6
+        assert float((out["generated"]["target_normal_map0"] - out["batch"]["target_normal_map0"]).abs().max()) <= 5e-3
+    else:
+        for k in out["batch"]:
+            assert torch.equal(out["generated"][k], out["batch"][k]), k
+
+
 def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
     """api.cpp check_estimates, the refusing side.  A network whose last trunk layer cancels large terms — four copies of one active layer-6 feature h weighted
     +3K, -K, -K, -K in every row of positions_linears.7 on top of the fitted weights, K = 12004.4: fp32 and every scheme with a second term per operand see the
@@ -297,7 +321,7 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
         r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
         sel, cand = r.last_selection()
-        assert cand == n * (64 * 7 + 192) and 0 < sel < 0.5 * cand, (sel, cand)     # (still a scene with surfaces: the refinement itself stays on)
+        assert cand in (n * (64 * 7 + 192), n * (64 * 7 + 192 + 768)) and 0 < sel < 0.5 * cand, (sel, cand)     # (still a scene with surfaces: the refinement itself stays on)
         if label == "default":
             assert r.estimate_policy(0) == (True, False) and r.estimate_policy(1) == (True, True)
         assert r.range_fallbacks == 0
