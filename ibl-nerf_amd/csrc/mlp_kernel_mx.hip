@@ -66,12 +66,19 @@ struct Blk {
 };
 struct Act { Blk b[4]; };   // 256 features
 
+#ifdef IBL_MX_F16ONLY
+constexpr int PF = 8;    // (plain f16: no fp6 operand forms to hold, so eight entries = two whole blocks ahead are affordable; LDS latency under four waves' reads is not
+                         // covered by four MFMAs)
+#else
+constexpr int PF = 4;                                          // A operands are read from LDS this many slots ahead (PF rotating entries:
+                                                               // the read for slot G+PF is issued right after slot G's MFMA has consumed its entry)
+#endif
 // A operands read ahead from the LDS ring, 4 rotating entries: q for the four f16 slots of a block; q+d (+sc at
 // slot 4) for its two fp6 slots
 struct Pre {
-    u32x4 q[4];
-    u32x2 d[4];
-    unsigned sc[4];
+    u32x4 q[PF];
+    u32x2 d[PF];
+    unsigned sc[PF];
 };
 
 template <int I, int N, class F>
@@ -82,10 +89,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifdef IBL_MX_F16ONLY
+constexpr int SLOTS_PER_BLOCK = 4;    // plain f16: no residual slots (with two empty ones the operand read-ahead of PF slots shrank to one or two MFMAs at every block end)
+#else
 constexpr int SLOTS_PER_BLOCK = 6;
-constexpr int CHUNK_SLOTS = CHUNK_BLOCKS * SLOTS_PER_BLOCK;   // 24
-constexpr int PF = 4;                                          // A operands are read from LDS this many slots ahead (4 rotating entries:
-                                                               // the read for slot G+4 is issued right after slot G's MFMA has consumed its entry)
+#endif
+constexpr int CHUNK_SLOTS = CHUNK_BLOCKS * SLOTS_PER_BLOCK;   // 24 (16)
 constexpr int SYNC_SLOT = CHUNK_SLOTS - PF - 1;                // after this slot the next chunk must be readable
 // One DMA piece of the chunk two ahead is issued in each of 8 chunk-relative slots.  A piece costs its wave
 // 60+ cycles of issue, more when it meets LDS reads, so the slots chosen are those whose operand prefetch is a
@@ -93,7 +102,11 @@ constexpr int SYNC_SLOT = CHUNK_SLOTS - PF - 1;                // after this slo
 // half of the chunk so the data has a full chunk and a half to land before sync_next needs it.
 __host__ __device__ constexpr int dma_piece(int cr) {
     const int b = cr / SLOTS_PER_BLOCK, s = cr % SLOTS_PER_BLOCK;
+#ifdef IBL_MX_F16ONLY
+    return (b < 2 && s >= 2) ? 2 * b + (s - 2) : -1;     // (the four pieces of the f16 half)
+#else
     return (b < 2 && s >= 2) ? 4 * b + (s - 2) : -1;
+#endif
 }
 // Tile-local slot after whose MFMA slice i of the previous tile's epilogue runs.  When the previous tile is
 // the last one of the PREVIOUS layer, its slices still write block 3 of this layer's input (f16 k-step 2 at
@@ -449,22 +462,22 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
             constexpr int G = t * NS + g;            // slot inside the layer
             constexpr int cr = G % CHUNK_SLOTS;      // slot inside the chunk
             constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
-            if constexpr (s == 4 && !F16O) wsc = pf.sc[G % 4];
-            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
-            else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
+            if constexpr (s == 4 && !F16O) wsc = pf.sc[G % PF];
+            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % PF], pf.d[G % PF], wsc, enc, acc);
+            else acc = slot_mfma<s>(pf.q[G % PF], pf.d[G % PF], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
 #ifdef IBL_MX_DOUBLE_MFMA   // measurement only (results are garbage): every matrix instruction twice
-            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, enc, acc);
-            else acc = slot_mfma<s>(pf.q[G % 4], pf.d[G % 4], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
+            if constexpr (HAS_ENC && bb == 0) acc = slot_mfma<s>(pf.q[G % PF], pf.d[G % PF], wsc, enc, acc);
+            else acc = slot_mfma<s>(pf.q[G % PF], pf.d[G % PF], wsc, in.b[bb - (HAS_ENC ? 1 : 0)], acc);
 #endif
             // A operand of slot G + PF, into the entry this slot's MFMA has just consumed
             {
                 constexpr int Gp = G + PF;
                 constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
                 constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
-                load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % PF>(pf, P.block(next, blk), P.lane);
 #ifdef IBL_MX_DOUBLE_LDS    // measurement only: every operand read twice
-                asm volatile("" : "+v"(pf.q[Gp % 4]));
-                load_frag<Gp % SLOTS_PER_BLOCK, Gp % 4>(pf, P.block(next, blk), P.lane);
+                asm volatile("" : "+v"(pf.q[Gp % PF]));
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % PF>(pf, P.block(next, blk), P.lane);
 #endif
             }
             if constexpr (g == NS / 2 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x16*>(bias_tab + (t + 1) * 32);
@@ -861,10 +874,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     P.voff = lane * 16 + wave * 8192;
     P.start();
     Pre pf;
-    load_frag<0, 0>(pf, P.block(false, 0), lane);
-    load_frag<1, 1>(pf, P.block(false, 0), lane);
-    load_frag<2, 2>(pf, P.block(false, 0), lane);
-    load_frag<3, 3>(pf, P.block(false, 0), lane);
+    static_for<0, PF>([&](auto I) {     // the operands of the first PF slots
+        constexpr int i = decltype(I)::value;
+        load_frag<i % SLOTS_PER_BLOCK, i>(pf, P.block(false, i / SLOTS_PER_BLOCK), lane);
+    });
     unsigned wsc = 0, peak = 0;
 
     constexpr bool LIST = VARIANT == VAR_REFL_LIST || VARIANT == VAR_FULL_LIST || VARIANT == VAR_TRUNK_X_LIST;      // a compact list of points with a flat index each (MlpArgs::out_index)
