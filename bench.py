@@ -37,9 +37,12 @@ MODES = {
     "auto": ("per checkpoint, measured at load (renderer.calibrate): the fast table f16x3_mxfp6x — f16 hi/lo splits x3 products (~2^-22 per operand) where errors are amplified "
              "(coarse grid's offset queries, auxiliary networks), the coarse pass's density on three f16 + three MX-fp6 products (~2^-26), f16 + 2x MX-fp6 (~2^-16) for the "
              "main queries' other channels, layers 2-7 of the fine offsets and the reflected-ray queries — or, where that leaves the checkpoint's per-sample weights / maps "
-             "beyond the calibration limits against it, f16x3_mxfp6 (x3 f16 products for every query but the reflected-ray ones); fp32 accumulate",
-             "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel<TRUNK_X|TRUNK_P>", "3 f16 MFMA products in the coarse pass's offsets (+3 block-scaled fp6 products for its density); "
-             "1 f16 + 2 block-scaled fp6 products elsewhere in the fast table, 3 f16 products in the safe one"),
+             "beyond the calibration limits against it, f16x3_mxfp6 (x3 f16 products for every query but the reflected-ray ones); fp32 accumulate.  Since round 4 "
+             "each query of the fast table (and the coarse / reflected ones of the safe table) runs as a plain-f16 density ESTIMATE on every sample and in the precision "
+             "named here only on the samples that can carry a weight (k_select_points; roofline.executed)",
+             "ibl::mxk16::mlp_kernel<TRUNK> (estimates) + ibl::mxk::mlp_kernel<TRUNK_X_LIST|FULL_LIST|REFL_LIST|TRUNK_P> (relevant samples)",
+             "1 f16 product on every sample (density estimate); on the relevant samples 3 f16 + 3 block-scaled fp6 products in the coarse pass (density and offsets), "
+             "1 f16 + 2 block-scaled fp6 products elsewhere in the fast table (layers 0-1 of the fine offsets: 3 f16), 3 f16 products in the safe one"),
     "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
                     "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
                     "ibl::f16x3k::mlp_kernel + ibl::mxk::mlp_kernel", "3 f16 MFMA products; 1 f16 + 2 block-scaled fp6 products in the reflected-ray queries"),
@@ -104,8 +107,8 @@ def load_checkpoint(kind):
     ships with the reference), "synthetic" = round 1's seeded random-init networks (fog).  The work per ray is the same either way
     (fixed sample counts, no early termination); the operand statistics the matrix cores see are not."""
     from ibl_nerf_amd import checkpoint as ck
-    if kind == "fitted":
-        f = np.load(os.path.join(ROOT, "tests", "golden", "fitted_ckpt.npz"))
+    if kind in ("fitted", "fitted2"):    # (fitted2: the second, sharper scene of tests/golden/fit_checkpoint.py — the checkpoint on which mlp_precision="auto" decides "safe")
+        f = np.load(os.path.join(ROOT, "tests", "golden", kind + "_ckpt.npz"))
         return ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
     return ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
 
@@ -231,7 +234,7 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=65536)
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
-    ap.add_argument("--checkpoint", choices=["fitted", "synthetic"], default="fitted",
+    ap.add_argument("--checkpoint", choices=["fitted", "fitted2", "synthetic"], default="fitted",
                     help="fitted: the checkpoint with surfaces (tests/golden/fitted_ckpt.npz); synthetic: round 1's random-init networks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -384,7 +387,7 @@ def main():
                 args.mlp_precision, "f16 (MFMA products per query class: 3x f16 on hi/lo splits, or f16 + 2x MX-fp6 residuals), fp32 accumulate"),
             "dtype_detail": MODES[args.mlp_precision][0],
             "data": ("synthetic (checkpoint fitted to an analytic scene with the reference's own modules, reference state-dict schema; synthetic pinhole camera)"
-                     if args.checkpoint == "fitted" else "synthetic (seeded random-init checkpoint in the reference state-dict schema, synthetic pinhole camera)"),
+                     if args.checkpoint.startswith("fitted") else "synthetic (seeded random-init checkpoint in the reference state-dict schema, synthetic pinhole camera)"),
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
@@ -398,7 +401,7 @@ def main():
                          # points in, raw rows out and back in; ~0.2 % of HBM bandwidth at this frame rate, so a ratio to watch, not a time bound
                          "traffic_ratio": (traffic * n_launch / (H * W // world) / 236.0) if traffic else None,
                          "traffic_note": "a committed figure, not a counter read in this run: HBM bytes per launch (reads x2-corrected + writes) of the rocprofv3 PMC pass %s; points in + raw outputs out, weights stay in L2" % traffic_src,
-                         "kernel": MODES[args.mlp_precision][1] + "<FULL|TRUNK|REFL>", "launches_per_step": n_launch,
+                         "kernel": MODES[args.mlp_precision][1] + ("" if args.mlp_precision == "auto" else "<FULL|TRUNK|REFL>"), "launches_per_step": n_launch,
                          "avg_launch_ms": mlp_ms / max(n_launch, 1), "mlp_share_of_step": mlp_ms / (1e3 * dt / args.steps),
                          "range_fallbacks": r.range_fallbacks,
                          # what the launches really evaluated: `achieved` prices every sample of every query as the reference evaluates it (SURVEY 8 d); the kernels

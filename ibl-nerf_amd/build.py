@@ -43,6 +43,8 @@ SOURCES = [
     ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=10"], "mlp_kernel_f16x3_trunk_feat2"),
     ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=11"], "mlp_kernel_f16x3_trunk_bwd_feat2"),
     ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=12"], "mlp_kernel_f16x3_net_bwd"),
+    ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=16"], "mlp_kernel_f16x3_full_list"),
+    ("mlp_kernel.hip", ["-DIBL_F16X3", "-DIBL_VARIANT=18"], "mlp_kernel_f16x3_trunk_list"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=0"], "mlp_kernel_mx_full"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=1"], "mlp_kernel_mx_trunk"),
     ("mlp_kernel_mx.hip", MX_FLAGS + ["-DIBL_MX_VARIANT=2"], "mlp_kernel_mx_refl"),

@@ -37,8 +37,9 @@ constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
-constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42;   // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation) + share x TRUNK_X
-constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample) + share x whole network
+// the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
+constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
+constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample; 0.18 on three products) + share x whole network
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
@@ -51,7 +52,8 @@ static bool wants_f16x3(int prec) {
 }
 // query classes of render_rays, for the per-class choice of the product scheme
 enum QueryClass { Q_MAIN_COARSE, Q_MAIN_FINE, Q_OFFSET_COARSE, Q_OFFSET_FINE, Q_REFL, Q_AUX, Q_USER,
-                  Q_ESTIMATE };   // a density estimate on the fast kernel, to be refined on the relevant points (k_select_points)
+                  Q_ESTIMATE,     // a density estimate on the fast kernel, to be refined on the relevant points (k_select_points); also the fast kernel's list forms
+                  Q_LIST3 };      // a list form on the three-product f16 kernel (VAR_FULL_LIST / VAR_TRUNK_LIST of mlp_kernel.hip)
 // albedo, roughness, irradiance (each channel overwrites a column of the raw rows), normal (own buffer)
 constexpr int AUX_SLOT0[N_AUX] = {2, 5, 6, 7}, AUX_CHANNELS[N_AUX] = {3, 1, 1, 3}, AUX_RAW_COLUMN[3] = {1, 4, 5};
 
@@ -95,8 +97,9 @@ struct iblnerf_ctx {
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
     // host upload of network 0, on the first launch's own count (one stream synchronisation per checkpoint), and frozen: results must not depend on call history.
-    bool xsel_decided = false, xsel_on = true;   // ... and the fine grid's offset copies
-    bool fsel_decided = false, fsel_on = true;   // the FINE main query on the relevant samples only (decided like sel_on, on the fine pass's first launch)
+    // the FINE main query / the fine grid's offset copies on the relevant samples only: the share of relevant samples, measured on the fine pass's first launch
+    // (-1: not yet); whether it pays depends on the table (the estimate costs 0.33 / 0.53 of a fast evaluation, 0.18 / 0.40 of a three-product one)
+    double fsel_fraction = -1.0, xsel_fraction = -1.0;
     bool sel_decided = false, sel_on = true;   // the coarse pass's density on the 15-slot form (VAR_TRUNK_P) | ... and the trunk-only form of iblnerf_network_query
     bool fuse_points = true;                  // the epsilon-offset points are generated inside the TRUNK kernels (IBLNERF_ROUTE_POINT_BATCH: the [4][R][S][3] batch instead)
     char* bwd_stash = nullptr;                // trunk backward: operand stash and the weight-gradient kernel's partial sums (grown on demand)
@@ -369,7 +372,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     }
     c->have_net[slot] = true;
     if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
-    if (slot < 2) { c->fsel_decided = c->xsel_decided = false; c->fsel_on = c->xsel_on = true; }
+    if (slot < 2) c->fsel_fraction = c->xsel_fraction = -1.0;
     if (slot < 2) c->est_checked[slot] = c->est_ok[slot] = false;
     return IBLNERF_OK;
 }
@@ -574,6 +577,7 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
     }
     if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
     if (variant == VAR_TRUNK_X_LIST) kern = K_MX;
+    if (qclass == Q_LIST3) kern = K_F16X3;      // (its callers checked the f16 pair stream: d_stream_f16)
     // (likewise; the trunk-only estimates in plain f16: all an estimate has to get right is which side of -1 a raw density lies on)
     if (qclass == Q_ESTIMATE) kern = (variant == VAR_TRUNK && which < 2 && ((c->est_f16 && c->est_checked[which] && c->est_ok[which]) || c->est_probe)) ? K_MX16 : K_MX;
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
@@ -1132,8 +1136,12 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             main_done = true;
         }
     }
-    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (!c->fsel_decided || c->fsel_on) && !keep_all_rows && !c->fine_main_precise &&
-        c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
+    const int prec_mode = c->opt.mlp_precision;
+    // (the fast table's fine main query on the fast kernel's list form; the safe table's — IBLNERF_ROUTE_FINE_MAIN_PRECISE, or the F16X3_MXFP6 mode — on the three-product one)
+    const bool fine_main_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->fine_main_precise;
+    const bool fine_main_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_main_fast && c->d_stream_f16[which] != nullptr;
+    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 || c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
+        (fine_main_fast || fine_main_3)) {
         // the FAST table's FINE main query likewise: the importance samples crowd around the surface, so about half of them are relevant (against 6-7 % on the coarse
         // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
         // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
@@ -1145,15 +1153,14 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         c->sel_candidates += R * S;
         HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
                                         false, 0.f, c->raw, RAW_CH, FLOP_FULL));
-        if (!c->fsel_decided) {
+        if (c->fsel_fraction < 0.0) {
             int n_sel = 0;
             HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            c->fsel_decided = true;
-            c->fsel_on = (double)n_sel <= FINE_SELECT_MAX_FRACTION * (double)(R * S);
+            c->fsel_fraction = (double)n_sel / (double)(R * S);
         }
-        if (c->fsel_on) {
-            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
+        if (c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) {
+            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, fine_main_fast ? Q_ESTIMATE : Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
             if (rc) return rc;
             main_done = true;
         }
@@ -1222,6 +1229,9 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         } else {   // the four offset copies are generated in the MLP kernel's input stage: no [4][R][S][3] batch (9.2 KB per ray on the fine grid)
             PointGen g;
             g.rays_o = ro; g.rays_d = rd; g.z = z; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+            // (the fine grid's offset copies: the fast table's on the mixed trunk form's list, the safe table's on the three-product trunk form's)
+            const bool fine_x_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->x_fine_precise;
+            const bool fine_x_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_x_fast && c->d_stream_f16[which] != nullptr;
             if (coarse_grid && S == c->Sc && sigma_p_available(c, which) && !c->p_all_points && !c->x_coarse && c->sel_decided && c->sel_on) {
                 // The coarse grid's offsets need all eight layers at 2^-22 (DESIGN 4.0 ladder) — on the samples that can reach a weight.  So: an ESTIMATE of
                 // all 4 R S densities on the fast kernel (6 slots), then the relevant ones (neither clearly empty nor behind saturation, per offset copy:
@@ -1233,9 +1243,14 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 c->sel_candidates += 4 * R * S;
                 HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
                                                 c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
-                rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
-            } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (!c->xsel_decided || c->xsel_on) && !c->x_fine_precise &&
-                       c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
+                // (on the three-product f16 kernel where the mode keeps its stream — what the whole-batch launch runs; 2 MB of weights against the 15-slot form's
+                // 3.9 MB, which sits at the edge of an XCD's 4 MB L2: its list launches took 2.1 - 5.7 ms from box to box)
+                if (c->d_stream_f16[which] != nullptr && c->mx_ok[which])
+                    rc = run_mlp(c, s, VAR_TRUNK_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
+                else
+                    rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
+            } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (fine_x_fast || fine_x_3) &&
+                       (c->xsel_fraction < 0.0 || c->xsel_fraction <= (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))) {
                 // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
                 // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
                 // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
@@ -1245,15 +1260,18 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 c->sel_candidates += 4 * R * S;
                 HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
                                                 c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
-                if (!c->xsel_decided) {
+                if (c->xsel_fraction < 0.0) {
                     int n_sel = 0;
                     HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
-                    c->xsel_decided = true;
-                    c->xsel_on = (double)n_sel <= FINE_OFFSET_SELECT_MAX_FRACTION * (double)(4 * R * S);
+                    c->xsel_fraction = (double)n_sel / (double)(4 * R * S);
                 }
-                if (c->xsel_on) rc = run_mlp(c, s, VAR_TRUNK_X_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, nullptr, false, c->sel_count, c->sel_index);
-                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, &g, false);
+                if (c->xsel_fraction > (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))
+                    rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, &g, false);
+                else if (fine_x_fast)
+                    rc = run_mlp(c, s, VAR_TRUNK_X_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, nullptr, false, c->sel_count, c->sel_index);
+                else
+                    rc = run_mlp(c, s, VAR_TRUNK_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
             } else {
                 rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
             }

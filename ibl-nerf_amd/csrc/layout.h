@@ -162,8 +162,13 @@ enum Variant { VAR_FULL = 0, VAR_TRUNK = 1, VAR_REFL = 2, VAR_FULL_CI = 3, VAR_R
                                           // (15 matrix slots per 64 MACs; operands to ~2^-26): the coarse pass's density, which places the fine samples
                VAR_REFL_LIST = 15,        // fast kernel only: REFL / FULL on a compact list of points (length in device memory, a flat index r * S + s per point: the
                VAR_FULL_LIST = 16,        // ray's direction and the output row are found through it) — the relevant samples of a query (k_select_points)
-               VAR_TRUNK_X_LIST = 17 };   // ... and TRUNK_X on such a list (the fine grid's offset copies)
+               VAR_TRUNK_X_LIST = 17,     // ... and TRUNK_X on such a list (the fine grid's offset copies)
+               VAR_TRUNK_LIST = 18 };     // three-product f16 kernel only (which also serves VAR_FULL_LIST): TRUNK on such a list — the safe table's fine pass
 __host__ __device__ constexpr bool variant_trunk_x(int v) { return v == VAR_TRUNK_X || v == VAR_TRUNK_X_LIST; }
+__host__ __device__ constexpr bool variant_list(int v) { return v == VAR_REFL_LIST || v == VAR_FULL_LIST || v == VAR_TRUNK_X_LIST || v == VAR_TRUNK_LIST; }
+__host__ __device__ constexpr int variant_base(int v) {     // the form a list variant evaluates
+    return v == VAR_REFL_LIST ? VAR_REFL : v == VAR_FULL_LIST ? VAR_FULL : v == VAR_TRUNK_X_LIST ? VAR_TRUNK_X : v == VAR_TRUNK_LIST ? VAR_TRUNK : v;
+}
 __host__ __device__ constexpr bool variant_ci(int v) { return v == VAR_FULL_CI || v == VAR_REFL_CI; }
 __host__ __device__ constexpr bool variant_albirr(int v) { return v == VAR_FULL || v == VAR_FULL_CI || v == VAR_FULL_LIST; }   // albedo / roughness / irradiance heads
 

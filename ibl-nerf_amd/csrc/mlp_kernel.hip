@@ -513,8 +513,12 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Enc& en
     }
 }
 
-template <int VARIANT>
+template <int VARIANT_IN>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
+    // a list variant (VAR_FULL_LIST / VAR_TRUNK_LIST: a compact list of points with a flat index each, its length in device memory — the relevant samples of a
+    // query, k_select_points) evaluates its base form; only where points come from, whose direction they take and where the rows go differs
+    constexpr int VARIANT = variant_base(VARIANT_IN);
+    constexpr bool LIST = variant_list(VARIANT_IN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -541,14 +545,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     P.voff = lane * 16 + wave * 8192;
     P.start();
 
-    const long n_groups = (a.n_pts + 127) / 128;
+    long n_total = a.n_pts;
+    if constexpr (LIST) n_total = *a.n_pts_dev;
+    const long n_groups = (n_total + 127) / 128;
     for (long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long p = g * 128 + wave * 32 + (lane & 31);
-        const bool valid = p < a.n_pts;
+        const bool valid = p < n_total;
         float px = 0.f, py = 0.f, pz = 0.f;
         PointGenK gen = nullptr;
 #ifndef IBL_NO_POINT_GEN   // (-DIBL_NO_POINT_GEN: A/B build of scratch/trunk_ab.sh, the input stage without the generation branch)
-        if constexpr (VARIANT == VAR_TRUNK) gen = kernarg_point_gen((unsigned)offsetof(MlpArgs, gen));
+        if constexpr (VARIANT == VAR_TRUNK && !LIST) gen = kernarg_point_gen((unsigned)offsetof(MlpArgs, gen));
 #endif
         if (gen != nullptr && gen->rays_o != nullptr) {   // the offset copies of the epsilon-normal, generated here (gen_points.h) instead of read from a batch
             if (valid) gen_offset_point(load_point_gen(gen), (unsigned)p, px, py, pz);
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             // ibl_nerf.py:244-247)
             float dx = 0.f, dy = 0.f, dz = 0.f;
             if (valid) {
-                const unsigned r = (unsigned)p / (unsigned)a.pts_per_ray;   // n_pts < 2^31 per launch
+                const unsigned r = (LIST ? (unsigned)a.out_index[p] : (unsigned)p) / (unsigned)a.pts_per_ray;   // n_pts < 2^31 per launch
                 dx = a.dirs[3 * (size_t)r + 0];
                 dy = a.dirs[3 * (size_t)r + 1];
                 dz = a.dirs[3 * (size_t)r + 2];
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const float* sc = tabs + TAB_SCALAR;
         if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT || VARIANT == VAR_TRUNK_FEAT2) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
-            if (VARIANT == VAR_TRUNK && valid && h == 0) a.out[(long)p * a.out_stride] = s;
+            if (VARIANT == VAR_TRUNK && valid && h == 0) a.out[(LIST ? (long)a.out_index[p] : (long)p) * a.out_stride] = s;
 #ifdef IBL_F16X3
             if (valid && !(fabsf(s) < __builtin_inff()) && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);   // range guard (see split_pair)
 #endif
@@ -959,8 +965,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             }
 #endif
             if (valid) {
+                const long row = LIST ? (long)a.out_index[p] : p;        // (a list: the sample's own row of the query's output)
                 if constexpr (variant_albirr(VARIANT)) {
-                    float* o = a.out + p * RAW_CH;
+                    float* o = a.out + row * RAW_CH;
                     if (h == 0) {
 #pragma unroll
                         for (int c = 0; c < 9; ++c) o[c] = tot[c];
@@ -969,7 +976,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                         for (int c = 9; c < 18; ++c) o[c] = tot[c];
                     }
                 } else {
-                    float* o = a.out + p * REFL_CH;
+                    float* o = a.out + row * REFL_CH;
                     if (h == 0) {
                         o[0] = tot[0];
 #pragma unroll
@@ -1040,6 +1047,10 @@ IBL_DEFINE_LAUNCH(10)
 IBL_DEFINE_LAUNCH(11)
 #elif IBL_VARIANT == 12
 IBL_DEFINE_LAUNCH(12)
+#elif IBL_VARIANT == 16
+IBL_DEFINE_LAUNCH(16)
+#elif IBL_VARIANT == 18
+IBL_DEFINE_LAUNCH(18)
 #else
 IBL_DEFINE_LAUNCH(4)
 #endif
@@ -1062,6 +1073,8 @@ hipError_t IBL_LAUNCH_NAME(9)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(10)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(11)(const MlpArgs&, int, hipStream_t);
 hipError_t IBL_LAUNCH_NAME(12)(const MlpArgs&, int, hipStream_t);
+hipError_t IBL_LAUNCH_NAME(16)(const MlpArgs&, int, hipStream_t);   // (the list variants: built for this flavour only)
+hipError_t IBL_LAUNCH_NAME(18)(const MlpArgs&, int, hipStream_t);
 #endif
 hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t stream) {
     if (a.n_pts <= 0) return hipSuccess;
@@ -1082,6 +1095,8 @@ hipError_t IBL_DISPATCH(int variant, const MlpArgs& a, int n_cu, hipStream_t str
         case VAR_TRUNK_FEAT2: rc = IBL_LAUNCH_NAME(10)(a, grid, stream); break;
         case VAR_TRUNK_BWD_FEAT2: rc = IBL_LAUNCH_NAME(11)(a, grid, stream); break;
         case VAR_NET_BWD: rc = IBL_LAUNCH_NAME(12)(a, grid, stream); break;
+        case VAR_FULL_LIST: rc = IBL_LAUNCH_NAME(16)(a, grid, stream); break;
+        case VAR_TRUNK_LIST: rc = IBL_LAUNCH_NAME(18)(a, grid, stream); break;
 #endif
         default: return hipErrorInvalidValue;
     }

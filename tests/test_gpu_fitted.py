@@ -331,7 +331,7 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
 
 
 def test_fitted_wide_error_class_of_f16x3_main(R, lut):
-    """f16x3_main on 1 024 rays of the fitted checkpoint: direct channels exactly those of f16x3_mxfp6 (the same kernels produce them),
+    """f16x3_main on 1 024 rays of the fitted checkpoint: direct channels those of f16x3_mxfp6 (the same kernels produce them on every sample that carries a weight),
     the normal's worst ray an order above (1.5e-3 against 1.9e-4; 99.9th percentile 3e-4) — why its f16 + fp6 offset queries
     on the fine grid are an opt-in and not the default.  Bounds: the measured class x2."""
     g, sdc, sdf, gt, edit = load_golden("fitted_wide")
@@ -339,8 +339,10 @@ def test_fitted_wide_error_class_of_f16x3_main(R, lut):
     for prec in ("f16x3_main", "f16x3_mxfp6"):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec)
         out[prec] = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0))
-    for k in ("depth_map", "albedo_map", "weights", "depth_map0", "target_normal_map0"):
+    for k in ("depth_map0", "target_normal_map0"):
         assert np.array_equal(out["f16x3_main"][k], out["f16x3_mxfp6"][k]), k
+    for k in ("depth_map", "albedo_map", "weights"):     # (f16x3_mxfp6 evaluates its fine main query on the relevant samples only: rows behind saturation are zero)
+        assert rel_linf(out["f16x3_main"][k], out["f16x3_mxfp6"][k]) <= 1e-6, k
     e = lambda p: np.abs(out[p]["target_normal_map"] - g["out__target_normal_map"]).max(-1)
     assert e("f16x3_mxfp6").max() <= 4e-4 and e("f16x3_main").max() <= 3e-3 and np.percentile(e("f16x3_main"), 99.9) <= 6e-4
     assert e("f16x3_main").max() > 2 * e("f16x3_mxfp6").max()
