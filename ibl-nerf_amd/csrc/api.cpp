@@ -1111,8 +1111,12 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
     int rc = IBLNERF_OK;
     bool main_done = false, est_counted = false;
-    if (places_samples && list_ok && !keep_all_rows && !c->fine_main_precise && c->opt.mlp_precision == IBLNERF_MLP_F16X3_MXFP6X) {
-        // (the FAST table's coarse main query: its other channels are on the fast kernel anyway)
+    const int prec_mode = c->opt.mlp_precision;
+    // (the fast table's main queries on the fast kernel's list form; the safe table's — IBLNERF_ROUTE_FINE_MAIN_PRECISE, or the F16X3_MXFP6 mode — on the three-product one)
+    const bool fine_main_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->fine_main_precise;
+    const bool fine_main_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_main_fast && c->d_stream_f16[which] != nullptr;
+    if (places_samples && list_ok && !keep_all_rows && (fine_main_fast || fine_main_3)) {
+        // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
         if (rc) return rc;
         est_counted = true;     // (the query's algorithmic FLOPs are counted once, on its estimate)
@@ -1129,17 +1133,13 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * S);
         }
         if (c->sel_on) {
-            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
+            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, fine_main_fast ? Q_ESTIMATE : Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
             if (rc) return rc;
             rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
             if (rc) return rc;
             main_done = true;
         }
     }
-    const int prec_mode = c->opt.mlp_precision;
-    // (the fast table's fine main query on the fast kernel's list form; the safe table's — IBLNERF_ROUTE_FINE_MAIN_PRECISE, or the F16X3_MXFP6 mode — on the three-product one)
-    const bool fine_main_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->fine_main_precise;
-    const bool fine_main_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_main_fast && c->d_stream_f16[which] != nullptr;
     if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 || c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
         (fine_main_fast || fine_main_3)) {
         // the FAST table's FINE main query likewise: the importance samples crowd around the surface, so about half of them are relevant (against 6-7 % on the coarse
