@@ -1461,9 +1461,35 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
-            rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE);
+            const float* nz = noise_c ? noise_c + r0 * Sc : nullptr;
+            bool listed = false, est_ran = false;
+            if (sigma_p_available(c, 0) && !c->p_all_points && (!c->sel_decided || c->sel_on)) {
+                // (as in full_pass: a plain-f16 estimate everywhere, the 15-slot density on the samples that can carry a weight; this is also where a checkpoint's
+                // refinement decision is taken when no full coarse pass ever runs)
+                if (c->est_f16 && !c->est_checked[0] && (rc = check_estimates(c, s, 0, R * Sc, Sc))) return rc;
+                rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE);
+                if (rc) return rc;
+                est_ran = true;
+                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+                c->sel_candidates += R * Sc;
+                HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, nz, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+                                                false, 0.f, nullptr, 0, FLOP_TRUNK));
+                if (!c->sel_decided) {
+                    int n_sel = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    c->sel_decided = true;
+                    c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * Sc);
+                }
+                if (c->sel_on) {
+                    rc = run_mlp(c, s, VAR_TRUNK_P, 0, c->sel_pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
+                    if (rc) return rc;
+                    listed = true;
+                }
+            }
+            if (!listed) rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE, nullptr, !est_ran);   // (algorithmic FLOPs: once per query)
             if (rc) return rc;
-            HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, noise_c ? noise_c + r0 * Sc : nullptr, R, Sc, c->w_c, s));
+            HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, nz, R, Sc, c->w_c, s));
         }
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));

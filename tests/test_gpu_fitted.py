@@ -269,6 +269,23 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
 
 
+def test_density_only_coarse_pass_refines_the_same_samples(R, lut):
+    """coarse_outputs=False (the inference-minimum coarse pass: density only) takes the same route as the full coarse pass — plain-f16 estimate, k_select_points,
+    15-slot density on the list, the checkpoint's refinement decision — so the fine pass is the full render's bit for bit, and its own lists are on."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    n = 8192
+    out = {}
+    for label, kw in (("full", {}), ("lean", {"coarse_outputs": False})):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", **kw)
+        out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
+        sel, cand = r.last_selection()
+        assert cand in ((n * (64 * (7 if label == "full" else 2) + 192 + x)) for x in (0, 768)) and sel > 0, (label, sel, cand)
+        assert r.estimate_policy(0) == r.estimate_policy(1) == (True, True)
+    assert not any(k.endswith("0") for k in out["lean"])
+    for k in out["lean"]:
+        assert torch.equal(out["lean"][k], out["full"][k]), k
+
+
 @pytest.mark.parametrize("prec,routing", [("f16x3", ()), ("bf16x3", ()), ("f16x3_mxfp6x", ("coarse_density_all_points",)), ("f16x3_mxfp6x", ())])
 def test_generated_points_are_the_batch_bit_for_bit(R, lut, prec, routing):
     """csrc/gen_points.h: the epsilon-offset copies generated in the MLP kernels' input stage (contraction on) are the points k_make_points writes into a batch
