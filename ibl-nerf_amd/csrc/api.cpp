@@ -40,6 +40,7 @@ constexpr float OFFSET_SELECT_TMIN = 1e-10f;
 // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
 constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
 constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample; 0.18 on three products) + share x whole network
+constexpr long SELECT_MIN_RAYS = 1024;        // a launch of fewer rays takes no per-network decision (and, while none is taken, evaluates every sample)
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
@@ -1103,10 +1104,13 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // "precision where it matters" also decides WHERE a query is evaluated at all: a sample that is clearly empty (alpha = 0 exactly) or behind saturation carries
     // no weight, so its 17 other channels (coarse main query) / its 12 radiance channels (reflected query) are never read with a non-zero factor.  Such a query runs as a
     // density ESTIMATE on the fast TRUNK form over all samples, and the whole network only on the relevant ones (VAR_FULL_LIST / VAR_REFL_LIST); the other rows are zero.
-    const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (!c->sel_decided || c->sel_on);
+    // (the per-network decisions — is this a scene with empty space, are plain-f16 estimates good enough, how many fine samples are relevant — are taken on a launch of at
+    // least SELECT_MIN_RAYS rays; until one has come by, smaller launches evaluate every sample: a handful of rays must not fix a checkpoint's route)
+    const bool can_decide = R >= SELECT_MIN_RAYS;
+    const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (c->sel_decided ? c->sel_on : can_decide);
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
-    if (list_ok && c->est_f16 && which < 2 && !c->est_checked[which])
+    if (list_ok && can_decide && c->est_f16 && which < 2 && !c->est_checked[which])
         if (int rc0 = check_estimates(c, s, which, R * S, S)) return rc0;
     // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
     int rc = IBLNERF_OK;
@@ -1140,7 +1144,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
             main_done = true;
         }
     }
-    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 || c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
+    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 ? can_decide : c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
         (fine_main_fast || fine_main_3)) {
         // the FAST table's FINE main query likewise: the importance samples crowd around the surface, so about half of them are relevant (against 6-7 % on the coarse
         // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
@@ -1176,7 +1180,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // the estimate's last bits are, and a sample behind a transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest (on a
     // scene with surfaces: the few samples around each ray's first surface, ~5 %) is compacted, evaluated and scattered over the estimates (k_select_points).
     if (places_samples && sigma_p_available(c, which)) {
-        if (c->p_all_points || !c->sel_on) {
+        if (c->p_all_points || !c->sel_on || (!c->sel_decided && !can_decide)) {
             rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
         } else {
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
@@ -1250,7 +1254,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 else
                     rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
             } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (fine_x_fast || fine_x_3) &&
-                       (c->xsel_fraction < 0.0 || c->xsel_fraction <= (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))) {
+                       (c->xsel_fraction < 0.0 ? can_decide : c->xsel_fraction <= (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))) {
                 // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
                 // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
                 // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
@@ -1463,10 +1467,10 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
             HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
             const float* nz = noise_c ? noise_c + r0 * Sc : nullptr;
             bool listed = false, est_ran = false;
-            if (sigma_p_available(c, 0) && !c->p_all_points && (!c->sel_decided || c->sel_on)) {
+            if (sigma_p_available(c, 0) && !c->p_all_points && (c->sel_decided ? c->sel_on : R >= SELECT_MIN_RAYS)) {
                 // (as in full_pass: a plain-f16 estimate everywhere, the 15-slot density on the samples that can carry a weight; this is also where a checkpoint's
                 // refinement decision is taken when no full coarse pass ever runs)
-                if (c->est_f16 && !c->est_checked[0] && (rc = check_estimates(c, s, 0, R * Sc, Sc))) return rc;
+                if (c->est_f16 && !c->est_checked[0] && R >= SELECT_MIN_RAYS && (rc = check_estimates(c, s, 0, R * Sc, Sc))) return rc;
                 rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE);
                 if (rc) return rc;
                 est_ran = true;

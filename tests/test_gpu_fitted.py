@@ -269,6 +269,24 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
 
 
+def test_a_handful_of_rays_decides_nothing(R, lut):
+    """The per-network decisions behind the list refinement (empty space or fog, plain-f16 estimates or not, the fine grid's relevant share) wait for a launch of at
+    least 1 024 rays (api.cpp SELECT_MIN_RAYS): a first call of 64 rays evaluates every sample and leaves them open; the next call of 4 096 takes them."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    small = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
+    assert r.last_selection() == (0, 0) and r.estimate_policy(0) == r.estimate_policy(1) == (False, False)
+    big = r.render_rays(g["rays_o"][:4096], g["rays_d"][:4096], 0.5, 8.0)
+    sel, cand = r.last_selection()
+    assert sel > 0 and cand >= 4096 * (64 * 7 + 192) and r.estimate_policy(0) == r.estimate_policy(1) == (True, True)
+    again = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)          # (decided: the small call now takes the lists too)
+    assert r.last_selection()[1] >= 64 * (64 * 7 + 192)
+    for k in ("target_normal_map", "target_normal_map0", "depth_map", "depth_map0"):
+        assert torch.equal(small[k], again[k]) and torch.equal(small[k], big[k][:64]), k
+    for k in small:
+        assert rel_linf(small[k].cpu().numpy(), again[k].cpu().numpy()) <= 1e-6, k
+
+
 def test_density_only_coarse_pass_refines_the_same_samples(R, lut):
     """coarse_outputs=False (the inference-minimum coarse pass: density only) takes the same route as the full coarse pass — plain-f16 estimate, k_select_points,
     15-slot density on the list, the checkpoint's refinement decision — so the fine pass is the full render's bit for bit, and its own lists are on."""

@@ -579,10 +579,9 @@ def test_render_decomp_ground_truth_normal_mode(R, lut):
                           approximate_radiance=True, **kw, **edit)
     n_launch = r.last_mlp_time()[1]
     r.set_profiling(False)
-    # 2 launches x ((coarse, fine) x (main + reflected) + the coarse pass's density on the 15-slot form): no offset queries; + the two density estimates the
-    # first launch of an uploaded network_fn compares (api.cpp check_estimates), and that launch's own density estimate of the coarse main query (on this
-    # random-init fog it finds every sample relevant and switches the list refinement off for the checkpoint)
-    assert n_launch == 2 * (2 * 2 + 1) + 2 + 1
+    # 2 launches x ((coarse, fine) x (main + reflected) + the coarse pass's density on the 15-slot form): no offset queries (and, in launches of 64 rays, none of the
+    # per-network decisions behind the list refinement: they wait for a launch of >= 1 024 rays, api.cpp SELECT_MIN_RAYS — every sample is evaluated)
+    assert n_launch == 2 * (2 * 2 + 1)
     assert rel_linf(ret["target_normal_map"].cpu().numpy(), g["out__target_normal_map"]) <= 1e-6
     assert rel_linf(ret["color_map"].cpu().numpy(), g["out__color_map"]) <= 2e-4
     with pytest.raises(KeyError):
@@ -746,8 +745,8 @@ def test_infer_normal_drop_in(R, lut, tmp_path):
     ret = to_np(R.render_decomp(800, 800, np.eye(3, dtype=np.float32), rays=rays, gt_values={}, approximate_radiance=True, **kw))
     n_launch = r.last_mlp_time()[1]
     r.set_profiling(False)
-    # 2 launches x ((coarse, fine) x (main + 3 normal channels + reflected) + the coarse pass's density on the 15-slot form) + check_estimates' two
-    assert n_launch == 2 * (2 * (1 + 3 + 1) + 1) + 2 + 1         # (+ the first launch's estimate of the coarse main query, as above)
+    # 2 launches x ((coarse, fine) x (main + 3 normal channels + reflected) + the coarse pass's density on the 15-slot form)
+    assert n_launch == 2 * (2 * (1 + 3 + 1) + 1)
     assert list(ret).index("inferred_normal_map") == list(ret).index("target_normal_map") - 1      # reference's key order
     assert np.array_equal(ret["inferred_normal_map"], ret["target_normal_map"])
     for k in ("inferred_normal_map", "inferred_normal_map0", "n_dot_v_map", "color_map"):
