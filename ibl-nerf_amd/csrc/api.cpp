@@ -1103,7 +1103,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const int Sc = c->Sc;
     // "precision where it matters" also decides WHERE a query is evaluated at all: a sample that is clearly empty (alpha = 0 exactly) or behind saturation carries
     // no weight, so its 17 other channels (coarse main query) / its 12 radiance channels (reflected query) are never read with a non-zero factor.  Such a query runs as a
-    // density ESTIMATE on the fast TRUNK form over all samples, and the whole network only on the relevant ones (VAR_FULL_LIST / VAR_REFL_LIST); the other rows are zero.
+    // density ESTIMATE on the plain-f16 TRUNK form over all samples, and in its own precision only on the relevant ones (the list variants); the other
+    // rows are zero.  The offset copies likewise: estimates everywhere, the query's kernel on each copy's relevant samples.
     // (the per-network decisions — is this a scene with empty space, are plain-f16 estimates good enough, how many fine samples are relevant — are taken on a launch of at
     // least SELECT_MIN_RAYS rays; until one has come by, smaller launches evaluate every sample: a handful of rays must not fix a checkpoint's route)
     const bool can_decide = R >= SELECT_MIN_RAYS;
@@ -1146,7 +1147,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     }
     if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 ? can_decide : c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
         (fine_main_fast || fine_main_3)) {
-        // the FAST table's FINE main query likewise: the importance samples crowd around the surface, so about half of them are relevant (against 6-7 % on the coarse
+        // the FINE main query likewise: the importance samples crowd around the surface, so about 40 % of them are relevant (against 6-8 % on the coarse
         // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
         // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
