@@ -878,7 +878,14 @@ int iblnerf_composite_direct_backward_full(iblnerf_ctx* c, void* stream, const f
 
 int iblnerf_ray_outputs_backward(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
                                  const iblnerf_maps* up, int64_t n_rays, float* d_dmaps) {
+    return iblnerf_ray_outputs_backward_gt(c, stream, d_maps, d_n_dot_v, d_env, depth0, up, nullptr, n_rays, d_dmaps);
+}
+
+int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
+                                    const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
     if (!c) return IBLNERF_ERR_INVALID;
+    if (ovr && ovr->mode != 0)
+        return c->fail(IBLNERF_ERR_STATE, "ray_outputs_backward: edit / insert overrides in a gradient-carrying render are not built (only the *_from_gt constants)");
     if (n_rays < 0 || !up || (n_rays > 0 && (!d_maps || !d_dmaps)) || ((d_n_dot_v == nullptr) != (d_env == nullptr)))
         return c->fail(IBLNERF_ERR_INVALID, "ray_outputs_backward: bad arguments (n_dot_v and env: both or neither)");
     if (d_n_dot_v && !c->have_lut) return c->fail(IBLNERF_ERR_STATE, "ray_outputs_backward: no LUT uploaded");
@@ -894,6 +901,7 @@ int iblnerf_ray_outputs_backward(iblnerf_ctx* c, void* stream, const float* d_ma
     a.g_irradiance = up->irradiance_map; a.g_albedo = up->albedo_map; a.g_roughness = up->roughness_map; a.g_specular = up->specular_map;
     a.g_diffuse = up->diffuse_map; a.g_prefiltered = up->prefiltered_reflected_map; a.g_disp = up->disp_map; a.g_acc = up->acc_map;
     a.g_depth = up->depth_map; a.g_target_depth = up->target_depth_map;
+    if (ovr) { a.gt_albedo = ovr->d_gt_albedo; a.gt_roughness = ovr->d_gt_roughness; a.gt_irradiance = ovr->d_gt_irradiance; a.gt_depth = ovr->d_gt_depth; }
     a.dx = d_dmaps;
     HIP_TRY(c, launch_ray_outputs_backward(a, (long)n_rays, (hipStream_t)stream));
     return IBLNERF_OK;

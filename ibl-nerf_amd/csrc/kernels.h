@@ -135,6 +135,12 @@ struct RayBwdArgs {
     const float *g_color, *g_radiance, *g_radiance_k[3], *g_irradiance, *g_albedo, *g_roughness, *g_specular, *g_diffuse, *g_prefiltered,
         *g_disp, *g_acc, *g_depth, *g_target_depth;
     float* dx;               // [n, 19]
+    // calculate_*_from_gt / depth_map_from_ground_truth (:251-252, :320-330): the target maps the shading reads and the output maps of the same name are the ground
+    // truth — constants of the backward ([n, 3], [n], [n, 3], [n]; null = the network's own map)
+    const float* gt_albedo = nullptr;
+    const float* gt_roughness = nullptr;
+    const float* gt_irradiance = nullptr;
+    const float* gt_depth = nullptr;
 };
 hipError_t launch_ray_outputs_backward(const RayBwdArgs& a, long n, hipStream_t s);
 hipError_t launch_composite_direct_backward(const float* raw, const float* z, const float* rays_d, long R, int S, int radiance_linear,

@@ -1255,7 +1255,10 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
 #pragma unroll
     for (int i = 0; i < 19; ++i) dx[i] = 0.0f;
     const int on = a.out_mode;
-    const float depth = x[0], acc = x[1], rough = x[5], irr = x[6];
+    // target maps (:320-330): the network's, or the ground truth as a constant; roughness_map itself (the network's) still sets the mip level (:457-460)
+    const bool alb_gt = a.gt_albedo != nullptr, rough_gt = a.gt_roughness != nullptr, irr_gt = a.gt_irradiance != nullptr;
+    const float depth = x[0], acc = x[1], rough_net = x[5];
+    const float rough = rough_gt ? a.gt_roughness[r] : rough_net;
     auto up3 = [&](const float* g, int c) { return g ? g[3 * r + c] : 0.0f; };
     auto up1 = [&](const float* g) { return g ? g[r] : 0.0f; };
 #pragma unroll
@@ -1263,10 +1266,10 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         dx[7 + c] += up3(a.g_radiance, c) * d_out_map(x[7 + c], on);
 #pragma unroll
         for (int k = 0; k < 3; ++k) dx[10 + 3 * k + c] += up3(a.g_radiance_k[k], c) * d_out_map(x[10 + 3 * k + c], on);
-        dx[2 + c] += up3(a.g_albedo, c) * d_srgb(x[2 + c], on & 1);
+        if (!alb_gt) dx[2 + c] += up3(a.g_albedo, c) * d_srgb(x[2 + c], on & 1);     // (results["albedo_map"] = albedo_f(target_albedo_map): a constant under the flag)
     }
-    dx[6] += up1(a.g_irradiance) * d_out_map(irr, on);
-    dx[5] += up1(a.g_roughness);
+    if (!irr_gt) dx[6] += up1(a.g_irradiance) * d_out_map(x[6], on);
+    if (!rough_gt) dx[5] += up1(a.g_roughness);
     if (a.g_disp) {                                          // 1 / max(1e-10, depth / acc) (:258)
         const float q = depth / acc;
         const float share = q > 1e-10f ? 1.0f : (q == 1e-10f ? 0.5f : 0.0f);
@@ -1275,7 +1278,7 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         dx[1] += -dq * depth / (acc * acc);
     }
     dx[1] += up1(a.g_acc);
-    dx[0] += up1(a.g_depth) + up1(a.g_target_depth);
+    dx[0] += up1(a.g_depth) + (a.gt_depth != nullptr ? 0.0f : up1(a.g_target_depth));
     if (a.ndv != nullptr) {
         const float ndv = a.ndv[r];
         // LUT fetch and its derivative along the roughness axis (F.grid_sample, bilinear, zeros padding, align_corners=True; :418-421)
@@ -1304,9 +1307,9 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         const float one_m = 1.0f - m;
         const float p5 = powf(fminf(fmaxf(1.0f - ndv, 0.0f), 1.0f), 5.0f);
         // mip level (:453-467); the depth inside it carries no gradient (depth_map.detach())
-        float level = rough, dlevel = 1.0f;
+        float level = rough_net, dlevel = 1.0f;
         if (a.correct_depth) {
-            const float v = rough * depth / a.depth0;
+            const float v = rough_net * depth / a.depth0;
             level = fminf(fmaxf(v, 0.0f), 1.0f);
             dlevel = (v >= 0.0f && v <= 1.0f) ? depth / a.depth0 : 0.0f;
         }
@@ -1318,7 +1321,8 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         float g_rough = 0.f, g_e0 = 0.f, g_e1 = 0.f, g_rem = 0.f, g_irr = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float alb = x[2 + c];
+            const float alb = alb_gt ? a.gt_albedo[3 * r + c] : x[2 + c];
+            const float irr = irr_gt ? a.gt_irradiance[3 * r + c] : x[6];
             const float F0 = 0.04f * one_m + alb * m;                                             // :425-427
             const float av = 1.0f - rough;
             const float F1 = fmaxf(av, F0) - F0;                                                  // microfacet.py:8-12
@@ -1335,7 +1339,7 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
             const float G_coef = G_spec * pref;
             float G_fres = -G_diff * one_m * alb * irr;
             g_rough += G_diff * (1.0f - fres) * alb * irr;                                        // through (1 - metallic) = 1 - (1 - rough)
-            dx[2 + c] += G_diff * (1.0f - fres) * one_m * irr;
+            float g_alb = G_diff * (1.0f - fres) * one_m * irr;
             g_irr += G_diff * (1.0f - fres) * one_m * alb;
             g_e0 += G_coef * cb;
             g_e1 += G_coef;
@@ -1345,13 +1349,14 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
             const float G_F1 = G_fres * p5;
             if (av > F0) { g_rough -= G_F1; G_F0 -= G_F1; }                                       // F1 = (1 - rough) - F0
             else if (av == F0) { g_rough -= 0.5f * G_F1; G_F0 -= 0.5f * G_F1; }                   // (else F1 = F0 - F0: no gradient)
-            dx[2 + c] += G_F0 * m;
+            g_alb += G_F0 * m;
+            if (!alb_gt) dx[2 + c] += g_alb;
             g_rough += G_F0 * (0.04f - alb);                                                      // d F0 / d rough through metallic = 1 - rough
             g_rem += G_pref * (env[3 * i2 + c] - env[3 * i1 + c]);
         }
-        g_rough += 3.0f * g_rem * dlevel + g_e0 * de0 + g_e1 * de1;
-        dx[5] += g_rough;
-        dx[6] += g_irr;
+        g_rough += g_e0 * de0 + g_e1 * de1;
+        dx[5] += 3.0f * g_rem * dlevel + (rough_gt ? 0.0f : g_rough);     // (the mip level reads the network's roughness_map whatever the target is)
+        if (!irr_gt) dx[6] += g_irr;
     }
     float* o = a.dx + 19 * r;
 #pragma unroll

@@ -672,10 +672,11 @@ class Renderer:
                  "diffuse_map": ("diffuse_map", None, 3), "prefiltered_reflected_map": ("prefiltered_reflected_map", None, 3), "disp_map": ("disp_map", None, 1),
                  "acc_map": ("acc_map", None, 1), "depth_map": ("depth_map", None, 1), "target_depth_map": ("target_depth_map", None, 1)}
 
-    def ray_outputs_backward(self, maps, upstream, n_dot_v=None, env=None, depth0=1.0):
+    def ray_outputs_backward(self, maps, upstream, n_dot_v=None, env=None, depth0=1.0, gt=None):
         """dL/d(output maps) -> dL/d(linear direct maps [n, 19]) through the ray-sized part of raw2outputs (iblnerf_ray_outputs_backward): `maps` = the
         pass's linear maps (composite_direct), `upstream` = {map name: gradient or None}; n_dot_v [n] / env [n, 4, 3] = the pass's no-grad
-        quantities (None, None for approximate_radiance=False)."""
+        quantities (None, None for approximate_radiance=False).  gt: {"albedo" [n,3], "roughness" [n], "irradiance" [n,3], "depth" [n]} — the target maps
+        of the calculate_*_from_gt / depth_map_from_ground_truth flags that are on, constants of the backward (iblnerf_ray_outputs_backward_gt)."""
         torch = _torch()
         x = _dev_f32(maps, self.device).reshape(-1, 19)
         n = x.shape[0]
@@ -697,8 +698,17 @@ class Renderer:
             ndv, ev = _dev_f32(n_dot_v, self.device).reshape(n), _dev_f32(env, self.device).reshape(n, 12)
             keep += [ndv, ev]
         dx = torch.empty((n, 19), dtype=torch.float32, device=self.device)
-        B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
-                                                                None if ev is None else ev.data_ptr(), float(depth0), C.byref(up), n, dx.data_ptr()))
+        ov = None
+        if gt:
+            ov = B.Overrides()
+            for name, field, ch in (("albedo", "d_gt_albedo", 3), ("roughness", "d_gt_roughness", 1), ("irradiance", "d_gt_irradiance", 3), ("depth", "d_gt_depth", 1)):
+                if gt.get(name) is not None:
+                    t = _dev_f32(gt[name], self.device).reshape(n, ch).contiguous()
+                    keep.append(t)
+                    setattr(ov, field, t.data_ptr())
+        B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward_gt(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
+                                                                   None if ev is None else ev.data_ptr(), float(depth0), C.byref(up),
+                                                                   None if ov is None else C.byref(ov), n, dx.data_ptr()))
         self._keep_up = keep      # the inputs must outlive the asynchronous launch (same stream as torch's allocator, but some are temporaries of this call)
         return dx
 
@@ -1295,7 +1305,11 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
         raise NotImplementedError("c2w_staticcam and per-ray near / far planes are built for the inference render (approximate_radiance=True, no gradients)")
     if is_depth_only or not approx or training:
         # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
-        flags_on = any(_truthy(v) for k, v in edit.items() if k in _SWITCHES or k in FROM_GT_FLAGS)
+        # the four ground-truth substitutions are built for the gradient-carrying approximate_radiance render (constants of its backward: training.render_rays_train)
+        gt_flags = {k: True for k in ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth")
+                    if _truthy(edit.get(k))}
+        gt_ok = training and approx and not is_depth_only
+        flags_on = any(_truthy(v) for k, v in edit.items() if (k in _SWITCHES or k in FROM_GT_FLAGS) and not (gt_ok and k in gt_flags))
         aux_on = any(v is not None for v in r._aux.values())           # (load_aux(name, None) leaves a {name: None} entry: a cleared network is no network)
         if training and kwargs.get("infer_depth") and any(getattr(p, "requires_grad", False) for p in getattr(kwargs.get("depth_mlp"), "parameters", lambda: [])()):
             # train.py:351-379 reads ret['inferred_depth_map'] and backpropagates loss_depth_random into depth_mlp; the posdir kernel has no backward
@@ -1311,7 +1325,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
             ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
-                                      approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std, **smp)
+                                      approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std,
+                                      gt_values=kwargs.get("gt_values"), from_gt=gt_flags if gt_ok else None, **smp)
         else:
             ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
         if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:

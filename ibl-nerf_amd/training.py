@@ -67,25 +67,30 @@ def _ungamma(y, on):
     return (y ** 2.2 - 1e-12).clamp_min(0.0) if on else y
 
 
-def _ray_outputs(x, consts, flags):
+def _ray_outputs(x, consts, flags, gt=None):
     """The ray-sized part of raw2outputs as differentiable torch: x [n, 19] = the linear direct maps (Renderer.MAP_SLOTS order) -> the
     pass's output maps.  consts (approximate_radiance): n_dot_v [n], env [n, 4, 3] linear reflected-ray maps, lut [3, 512, 512],
-    depth0 = (near + far) / 2."""
+    depth0 = (near + far) / 2.  gt: the target maps of the *_from_gt flags that are on (:251-252, :320-330), constants."""
     torch = _torch()
     import torch.nn.functional as F
+    gt = gt or {}
     g, hdr = flags["gamma_correct"], flags["use_radiance_linear"]
     out_f = (lambda v: _gamma(v / (v + 1) if hdr else v, g))                         # output_f (:480-490)
     depth, acc = x[:, 0], x[:, 1]
-    albedo, rough, irr = x[:, 2:5], x[:, 5], x[:, 6]
+    rough_net = x[:, 5]                                                             # roughness_map: the mip level reads it whatever the target is (:457-460)
+    albedo = gt["albedo"] if gt.get("albedo") is not None else x[:, 2:5]
+    rough = gt["roughness"] if gt.get("roughness") is not None else rough_net
+    irr = gt["irradiance"] if gt.get("irradiance") is not None else x[:, 6:7]       # [n, 3] | [n, 1]
     res = {"radiance_map": out_f(x[:, 7:10])}
     for k in range(3):
         res["radiance_map_%d" % (k + 1)] = out_f(x[:, 10 + 3 * k:13 + 3 * k])
-    res["irradiance_map"] = out_f(irr[:, None])                                     # target_irradiance_map = irradiance_map[..., None] (:326)
+    res["irradiance_map"] = out_f(irr)                                              # target_irradiance_map = irradiance_map[..., None] (:326)
     res["albedo_map"] = _gamma(albedo, g)                                           # albedo_f (:491)
     res["roughness_map"] = rough
     q = depth / acc
     res["disp_map"] = 1.0 / torch.maximum(torch.full_like(q, 1e-10), q)             # :258
-    res["acc_map"], res["depth_map"], res["target_depth_map"] = acc, depth, depth
+    res["acc_map"], res["depth_map"] = acc, depth
+    res["target_depth_map"] = gt["depth"] if gt.get("depth") is not None else depth
     if consts is None:
         return res
     ndv, env, lut = consts["n_dot_v"], consts["env"], consts["lut"]
@@ -97,15 +102,15 @@ def _ray_outputs(x, consts, flags):
     fres = F0 + F1 * torch.clip(1.0 - ndv[:, None], 0.0, 1.0) ** 5.0
     coef = (fres if flags["lut_coefficient"] == "F" else F0) * e[:, 0:1] + e[:, 1:2]             # :433-436
     if flags["correct_depth"]:
-        level = torch.clip(rough * depth.detach() / consts["depth0"], 0, 1)         # :453-457
+        level = torch.clip(rough_net * depth.detach() / consts["depth0"], 0, 1)     # :453-457
     else:
-        level = rough
+        level = rough_net
     i1 = torch.clip((level * 3).long(), 0, 3)
     i2 = torch.clip(i1 + 1, 0, 3)
     rem = (level * 3 - i1)[:, None]
     ar = torch.arange(env.shape[0], device=env.device)
     pref = (1 - rem) * env[ar, i1] + rem * env[ar, i2]                              # :461-467
-    diffuse = (1 - fres) * (1 - metallic) * albedo * irr[:, None]                   # :469
+    diffuse = (1 - fres) * (1 - metallic) * albedo * irr                            # :469
     spec = coef * pref
     res.update(color_map=out_f(diffuse + spec), specular_map=out_f(spec), diffuse_map=out_f(diffuse), prefiltered_reflected_map=out_f(pref))
     return res
@@ -236,7 +241,7 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
 
 
 def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None,
-                      raw_noise_std=0.):
+                      raw_noise_std=0., gt_values=None, from_gt=None):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
     `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
     teacher_maps (parity tests; the backward's counterpart of iblnerf_composite_pass): {n_dot_v_map[0], reflected_radiance_map[0],
@@ -261,6 +266,19 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
     st = _Stages(r)
     depth0 = 0.5 * (float(near) + float(far))
     lut_t = _dev_f32(lut, r.device)
+    # calculate_*_from_gt / depth_map_from_ground_truth (render kwargs of a step; :251-252, :320-330): the forward substitutes the target maps (pass A), the backward
+    # takes them as constants — no gradient reaches the network's own map through the shading or through the output of the same name
+    from_gt = {k: True for k, v in (from_gt or {}).items() if v}
+    gt_const = {}
+    if from_gt:
+        if not approximate_radiance:
+            raise NotImplementedError("*_from_gt flags in a gradient-carrying render are built for approximate_radiance=True")
+        gv = gt_values or {}
+        for flag, key, name, ch in (("calculate_albedo_from_gt", "albedo", "albedo", 3), ("calculate_roughness_from_gt", "roughness", "roughness", 1),
+                                    ("calculate_irradiance_from_gt", "irradiance", "irradiance", 3), ("depth_map_from_ground_truth", "depth", "depth", 1)):
+            if from_gt.get(flag):
+                t = _dev_f32(gv[key], r.device).reshape(n, -1)
+                gt_const[name] = (t[:, :3] if ch == 3 else t[:, 0]).contiguous()      # gt_values["roughness"][..., 0] (:326), gt_values["depth"][..., 0] (:252)
 
     keys = [k + s for s in ("", "0") for k in (RESULT_ORDER if approximate_radiance else BASE_KEYS)] + ["z_std"]
 
@@ -276,7 +294,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18), envc=st._e(n, 4, 3), envf=st._e(n, 4, 3))
                 taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
                 taps.d_env_coarse, taps.d_env_fine = sv["envc"].data_ptr(), sv["envf"].data_ptr()    # the linear reflected-ray maps, exact (no gamma round trip)
-                res = r.render_rays(ro_, rd_, near, far, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std, noise=None if noise[0] is None else noise)
+                res = r.render_rays(ro_, rd_, near, far, gt_values if from_gt else None, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std,
+                                    noise=None if noise[0] is None else noise, **from_gt)
                 sv["rawc"], sv["rawf"] = _with_noise(sv["rawc"], noise[0]), _with_noise(sv["rawf"], noise[1])     # (the taps are the network's rows: the noise is added in pass A)
             else:
                 res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise)
@@ -293,7 +312,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                         env = sv[tap]
                     ctx.saved["consts" + sfx] = dict(n_dot_v=src["n_dot_v_map" + sfx].clone(), env=env, lut=lut_t, depth0=depth0)   # (a copy: the map itself goes to the caller)
             outs = tuple(res[k] for k in keys)
-            ctx.mark_non_differentiable(*[res[k] for k in keys if k.startswith(("target_normal_map", "n_dot_v_map", "reflected_", "z_std"))])
+            const_maps = tuple({"albedo": "albedo_map", "roughness": "roughness_map", "irradiance": "irradiance_map", "depth": "target_depth_map"}[k] for k in gt_const)
+            ctx.mark_non_differentiable(*[res[k] for k in keys if k.startswith(("target_normal_map", "n_dot_v_map", "reflected_", "z_std") + const_maps)])
             return outs
 
         @staticmethod
@@ -307,13 +327,16 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 consts = sv.get("consts" + sfx)
                 if FUSED_SHADING_BACKWARD:                           # one launch (iblnerf_ray_outputs_backward) instead of ~160 ray-sized ones
                     ups = {k: gout.get(k + sfx) for k in SHADED_KEYS if (consts is not None or k in BASE_KEYS)}
+                    for name in ("albedo", "roughness", "irradiance"):          # (an output map that IS the ground truth carries no gradient; the irradiance one is [n, 3] then)
+                        if name in gt_const:
+                            ups.pop(name + "_map", None)
                     dx = r.ray_outputs_backward(lin, ups, None if consts is None else consts["n_dot_v"], None if consts is None else consts["env"],
-                                                depth0)
+                                                depth0, gt=gt_const or None)
                 else:                                                # the same by torch autograd (the tests' reference for the kernel above)
                     with torch.enable_grad():
                         x = lin.detach().requires_grad_(True)
-                        outs = _ray_outputs(x, consts, flags)
-                        pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None]
+                        outs = _ray_outputs(x, consts, flags, gt_const)
+                        pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None and outs[k].requires_grad]     # (a *_from_gt output is a constant)
                         if pairs:
                             (dx,) = torch.autograd.grad([o for o, _ in pairs], x, [g.reshape(o.shape).to(o.dtype) for o, g in pairs], allow_unused=True)
                             dx = torch.zeros_like(lin) if dx is None else dx

@@ -390,6 +390,12 @@ typedef struct {
  * its gamma_correct / use_radiance_linear / lut_coefficient_f0 / correct_depth_for_prefiltered_radiance options. */
 int iblnerf_ray_outputs_backward(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
                                  const iblnerf_maps* d_upstream, int64_t n_rays, float* d_dmaps);
+/* ... under calculate_albedo_from_gt / calculate_roughness_from_gt / calculate_irradiance_from_gt / depth_map_from_ground_truth (:251-252, :320-330): the
+ * d_gt_albedo [n,3] / d_gt_roughness [n] / d_gt_irradiance [n,3] / d_gt_depth [n] rows of `overrides` (NULL each = flag off) are the target maps the shading
+ * reads and the output maps of the same name — constants of the backward: no gradient reaches the network's own map through them (roughness_map itself still
+ * sets the mip level, :457-460).  overrides->mode must be 0 (edit / insert in a gradient-carrying render: IBLNERF_ERR_STATE); overrides = NULL is the entry above. */
+int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
+                                    const iblnerf_maps* d_upstream, const iblnerf_overrides* overrides, int64_t n_rays, float* d_dmaps);
 
 
 /* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,

@@ -556,7 +556,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
     print("%-28s %s  %d maps  %.2f MB" % (name, kind, len(ret), os.path.getsize(path) / 1e6))
 
 
-def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0):
+def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=()):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -579,6 +579,15 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     kw.update(near=0.5, far=8.0, pytest=True)
     if raw_noise_std > 0:       # train.py's raw_noise_std (:208-216, :242): density noise on the main query of each pass; the pytest hook draws it uniform
         kw["raw_noise_std"] = raw_noise_std
+    # from_gt: names of the ground-truth substitutions switched on (render kwargs, ibl_nerf.py:411-416; raw2outputs :251-252, :320-330) with seeded gt_values
+    # (train.py:294 passes target_info): the target maps become constants, so no gradient reaches the network's own map through the shading
+    gt_rng = np.random.RandomState(4200)
+    gt_values = {}
+    for flag, key, ch, lo, hi in (("calculate_albedo_from_gt", "albedo", 3, 0.15, 0.85), ("calculate_roughness_from_gt", "roughness", 1, 0.1, 0.9),
+                                  ("calculate_irradiance_from_gt", "irradiance", 3, 0.2, 1.2), ("depth_map_from_ground_truth", "depth", 1, 1.5, 5.0)):
+        if flag in from_gt:
+            kw[flag] = True
+            gt_values[key] = gt_rng.uniform(lo, hi, (n_rays, ch)).astype(np.float32)
     kw["brdf_lut"] = lut
     rng = np.random.RandomState(4100)
     o, d, pix, focal = camera_rays(rng, n_rays)
@@ -597,14 +606,17 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     nets = (("c", kw["network_fn"]), ("f", kw["network_fine"]))
 
     out["raw_noise_std"] = np.float32(raw_noise_std)
+    for k, v in gt_values.items():
+        out["gt__" + k] = v
+    out["from_gt"] = np.array(sorted(from_gt))
     for phase in phases:
         for _, net in nets:
             net.zero_grad()
             net.freeze_radiance = net.freeze_roughness = phase == "frozen"
         approx = phase in ("full", "frozen")
         with torch.enable_grad():
-            res = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values={}, approximate_radiance=approx,
-                                  is_depth_only=phase == "depth", **kw, **EDIT_KEYS_OFF)
+            res = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values={k: torch.from_numpy(v) for k, v in gt_values.items()},
+                                  approximate_radiance=approx, is_depth_only=phase == "depth", **kw, **EDIT_KEYS_OFF)
             for k, v in res.items():
                 out["%s__out__%s" % (phase, k)] = v.detach().numpy().copy()
             if phase == "depth":
@@ -972,6 +984,12 @@ def main(only=None):
         train_step_fixture(torch, R, M, lut)
     if not only or "train_step_noise" in only:      # the same step with raw_noise_std = 1 (f-3: density noise inside a gradient-carrying render)
         train_step_fixture(torch, R, M, lut, fixture="train_step_noise", phases=("warmup", "full"), raw_noise_std=1.0)
+    if not only or "train_step_from_gt" in only:    # ... with the four ground-truth substitutions on (f-3: constants of the backward)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt", phases=("full",),
+                           from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
+    if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt2", phases=("full",),
+                           from_gt=("calculate_roughness_from_gt", "depth_map_from_ground_truth"))
     if not only or "sample_pdf_spiky" in only:
         sample_pdf_spiky(torch, Hh)
     if not only or "export_path" in only:

@@ -175,6 +175,68 @@ def test_ray_outputs_backward_matches_autograd(lut, flags):
         r.ray_outputs_backward(xt, {}, nd, ev, depth0=0.0)
 
 
+@pytest.mark.parametrize("name,fused,teacher", [("train_step_from_gt", True, False), ("train_step_from_gt", False, False), ("train_step_from_gt2", True, False),
+                                                ("train_step_from_gt", True, True), ("train_step_from_gt2", True, True)])
+def test_training_step_with_ground_truth_targets(lut, name, fused, teacher):
+    """f-3 leftover closed in round 4: calculate_albedo_from_gt / calculate_roughness_from_gt / calculate_irradiance_from_gt / depth_map_from_ground_truth inside a
+    gradient-carrying render (they used to raise).  The forward substitutes the target maps (pass A of the inference path), the backward takes them as constants
+    (iblnerf_ray_outputs_backward_gt): no gradient reaches the network's own map through the shading or through the output map of the same name — roughness_map
+    still sets the mip level (ibl_nerf_renderer.py:457-460).  Fixtures = the reference's own loss.backward() with the flags and seeded gt_values (all four on; roughness and
+    depth only): loss and all 92 parameter gradients at the bars of the plain step; a head whose map is replaced gets exactly zero."""
+    import train_loss as TL
+    from ibl_nerf_amd import renderer as R, training as T
+    G = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nets, kw, K, rays = _setup(G, lut, "full")
+    flags = [str(f) for f in G["from_gt"]]
+    assert flags and all(f in ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth") for f in flags)
+    kw.update({f: True for f in flags})
+    gt = {k[4:]: torch.from_numpy(G[k]).cuda() for k in G.files if k.startswith("gt__")}
+    if teacher:      # the reference's own no-grad maps (n.v, reflected-ray maps of both passes) as the constants of the shading backward
+        kw["teacher_maps"] = {k[11:]: torch.from_numpy(G[k]).cuda() for k in G.files
+                              if k.startswith("full__out__") and k[11:].startswith(("n_dot_v_map", "reflected_"))}
+    T.FUSED_SHADING_BACKWARD = fused
+    try:
+        res = R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values=gt, approximate_radiance=True, **kw)
+        assert sorted(res.keys()) == sorted(k[11:] for k in G.files if k.startswith("full__out__"))
+        for k in ("radiance_map", "albedo_map", "irradiance_map", "roughness_map", "depth_map", "target_depth_map", "diffuse_map", "weights"):
+            for sfx in ("", "0"):
+                e = rel_linf(res[k + sfx].detach().cpu().numpy(), G["full__out__" + k + sfx])
+                assert e <= 1e-3, (k + sfx, e)
+        if "calculate_irradiance_from_gt" in flags:
+            assert res["irradiance_map"].shape[-1] == 3 and not res["irradiance_map"].requires_grad
+        loss = TL.total_loss(torch, res, {k[8:]: G[k] for k in G.files if k.startswith("target__")}, True)
+        assert abs(float(loss.detach()) - float(G["full__loss"])) <= 3e-4 * float(G["full__loss"])
+        loss.backward()
+    finally:
+        T.FUSED_SHADING_BACKWARD = True
+    worst, zero = {}, []
+    for tag, net in (("c", nets[0]), ("f", nets[1])):
+        for pname, prm in net.named_parameters():
+            ref = G["full__grad_%s__%s" % (tag, pname)]
+            got = np.zeros_like(ref) if prm.grad is None else prm.grad.cpu().numpy()
+            scale = float(np.abs(ref).max())
+            if scale == 0.0:
+                assert float(np.abs(got).max()) == 0.0, (tag, pname)
+                zero.append(tag + "." + pname)
+                continue
+            if pname.endswith(".bias") and ref.size <= 3:
+                scale = max(scale, float(np.abs(G["full__grad_%s__%s" % (tag, pname[:-4] + "weight")]).max()))
+            worst[tag + "." + pname] = float(np.abs(got - ref).max()) / scale
+    if "calculate_albedo_from_gt" in flags:      # albedo_map IS the ground truth and the shading reads the ground truth: the albedo branch gets nothing
+        assert any(k.endswith("albedo_linear.weight") for k in zero), zero
+    assert len(worst) + len(zero) == 92
+    # roughness_linear: under calculate_roughness_from_gt its ONLY gradient is the mip interpolation between the reflected-ray maps (the LUT and Fresnel read the
+    # ground truth), i.e. proportional to differences of maps that are ill-conditioned in the reference itself: 8.6e-3 end to end (5e-3 in the plain step, where the
+    # LUT term dominates); with the reference's own reflected-ray maps as the backward's constants 2.4e-3 / 8e-4 on the two fixtures (what is left is the mip
+    # level's integer part: one ray of 64 at a boundary of floor(3 level) interpolates another pair of maps when its depth moves in the last digits)
+    lim = lambda k: (3e-3 if teacher else 2e-2) if "roughness_linear" in k else (1.5e-3 if k.startswith("f.") else 1e-3)
+    bad = {k: v for k, v in worst.items() if v > lim(k)}
+    assert not bad, bad
+    # the refused combinations still raise
+    with pytest.raises(NotImplementedError):
+        R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values=gt, approximate_radiance=False, **kw)
+
+
 def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
     """The fused shading backward against the autograd one inside a whole step: every parameter gradient of both networks."""
     import train_loss as TL

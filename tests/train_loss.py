@@ -22,7 +22,12 @@ def total_loss(torch, res, tg, approximate_radiance, beta=BETA):
         if isinstance(target, float):
             return sum(torch.mean((res[k] - target) ** 2) for k in (key, key + "0") if k in res)
         t = torch.as_tensor(target, device=dev)
-        return sum(mse(res[k], t.reshape(res[k].shape)) for k in (key, key + "0") if k in res)
+        t = t.reshape(t.shape[0], -1)
+
+        def one(x):      # (irradiance_map is [n, 3] under calculate_irradiance_from_gt: its [n, 1] target broadcasts)
+            x = x.reshape(t.shape[0], -1)
+            return mse(x, t if t.shape == x.shape else t.expand_as(x))
+        return sum(one(res[k]) for k in (key, key + "0") if k in res)
 
     loss = beta["radiance"] * both("radiance_map", tg["rgb"])
     for k in range(3):
