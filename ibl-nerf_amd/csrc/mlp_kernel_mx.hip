@@ -32,6 +32,17 @@ namespace ibl {
 // those layers is a PAIR of stream blocks: the network's block (its f16 area = Wh) and a residual block (its f16 area = f16(W - Wh),
 // layout_mx.h CH_RES); a chunk of four blocks is assembled by the four waves' LDS-DMA from the two places.  Per pair: slots 0-3 of
 // the first block issue Wh Xh and Wh Xl (one operand read, two MFMAs), slots 0-3 of the second Wl Xh; their fp6 slots are idle.
+// -DIBL_MX_F16ONLY -DIBL_MX_VARIANT=1 (the plain-f16 TRUNK form = the density-ESTIMATE kernel of api.cpp's Q_ESTIMATE, most of a frame's matrix time since round 4)
+// is built as its own flavour, IBL_MX_EST: two workgroups per CU (<= 256 registers, an LDS ring of the blocks' f16 halves only: 3 x 16 KB + tables = 72 KB), a plain
+// loop per layer (operands read two slots ahead, each tile's epilogue right behind its MFMAs) instead of the hand-scheduled slot program — the second wave of a SIMD
+// hides what the program's software pipeline hides in the one-wave kernels, and the body no longer needs 500 registers.
+#if defined(IBL_MX_F16ONLY) && defined(IBL_MX_VARIANT) && IBL_MX_VARIANT == 1 && !defined(IBL_MX_NO_EST)
+#define IBL_MX_EST
+#ifndef IBL_MX_EST_TILES
+#define IBL_MX_EST_TILES 1      // 32-point tiles per wave: 1 = two workgroups per CU (11.8 ms per estimate launch of the bench frame); 2 = one workgroup per CU whose
+                                // weight fragments each feed two MFMAs (A/B build: 14.3 ms — 143 spilled registers, 447 accumulator-file moves per evaluation)
+#endif
+#endif
 #ifdef IBL_MX_F16ONLY
 #define IBL_MXK mxk16
 constexpr bool F16O = true;
@@ -66,7 +77,9 @@ struct Blk {
 };
 struct Act { Blk b[4]; };   // 256 features
 
-#ifdef IBL_MX_F16ONLY
+#ifdef IBL_MX_EST
+constexpr int PF = 2;
+#elif defined(IBL_MX_F16ONLY)
 constexpr int PF = 8;    // (plain f16: no fp6 operand forms to hold, so eight entries = two whole blocks ahead are affordable; LDS latency under four waves' reads is not
                          // covered by four MFMAs)
 #else
@@ -130,6 +143,14 @@ __host__ __device__ constexpr int stage_slot_x3(int q, int ns) { return ns >= 2 
 // read PF slots ahead, the "next chunk has landed" wait + barrier sits PF+1 slots BEFORE the chunk
 // boundary (sync_next), and the ring indices rotate at the boundary itself (advance).
 // ---------------------------------------------------------------------------------------------
+#ifdef IBL_MX_EST
+constexpr int R_CHUNK = CHUNK_BYTES / 2, R_BLOCK = BLOCK_BYTES / 2;     // the ring holds the f16 half of each block only
+#else
+constexpr int R_CHUNK = CHUNK_BYTES, R_BLOCK = BLOCK_BYTES;
+#endif
+constexpr int R_RING_BYTES = RING_SLOTS * R_CHUNK;
+constexpr int R_LDS_BYTES = R_RING_BYTES + TAB_BYTES;
+
 template <int VARIANT>
 struct Pipe {
     static constexpr bool CI = variant_ci(VARIANT), ALBIRR = variant_albirr(VARIANT);
@@ -184,7 +205,7 @@ struct Pipe {
         if constexpr (F16O && I >= 4) return;   // pieces 4..7 of a wave are the fp6 half of its block
         // (VAR_TRUNK_X: the wave's block comes from its own place in the stream, so the wave term moves from the offset register to the base)
         const char* src = X ? stream + (size_t)x_block(prog, wave) * BLOCK_BYTES : stream + (size_t)stream_chunk(prog) * CHUNK_BYTES;
-        const unsigned dst = lds_ring + (unsigned)slt * CHUNK_BYTES + wave * 8192 + (I / 4) * 4096;
+        const unsigned dst = lds_ring + (unsigned)slt * R_CHUNK + wave * R_BLOCK + (I / 4) * 4096;
         const unsigned v = (X ? voff - wave * 8192 : voff) + (I / 4) * 4096;
         if constexpr (I % 4 != 0) {
             asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(v), "s"(src), "n"((I % 4) * 1024) : "memory");
@@ -224,7 +245,7 @@ struct Pipe {
     }
     // byte address of block `blk` of the current / next chunk, this lane's 16-byte column
     __device__ __forceinline__ const char* block(bool next, int blk) const {
-        return ring + (next ? slot1 : slot) * CHUNK_BYTES + blk * BLOCK_BYTES;
+        return ring + (next ? slot1 : slot) * R_CHUNK + blk * R_BLOCK;
     }
     template <int I>
     __device__ __forceinline__ void prefetch_piece() const { issue_piece<I>(prog2, slot2); }
@@ -510,6 +531,84 @@ __device__ __forceinline__ f32x16 run_layer(Pipe<VARIANT>& P, Pre& pf, unsigned&
     return prev;
 }
 
+
+#ifdef IBL_MX_EST
+// The estimate kernel keeps an activation as sixteen 4-register k-steps (the MFMA's B operand), not as four 16-register blocks: nothing here reads a whole block
+// (no fp6 conversion), and 16-wide register tuples do not pack into a 256-register budget (the same body on `Act`: 200-280 spilled registers).
+struct ActE { u32x4 k[16]; };    // k[4 b + s]: f16 k-step s of block b
+
+// Epilogue of one finished 32-feature tile T: ReLU, f16 pairs into k-steps 2(T&1), 2(T&1)+1 of block T>>1 of `dst` (the element order of Epi::stage_b), the
+// running maximum for the f16 range guard — or, for the last trunk layer, the density head's dot product on the fp32 activations.
+template <int T>
+__device__ __forceinline__ void est_store(const f32x16& acc, ActE& dst, f16x2& peak16) {
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+        u32x4 hq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 xv = {acc[8 * J + 2 * e], acc[8 * J + 2 * e + 1]};
+            const f16x2 hv = __builtin_elementwise_max(__builtin_convertvector(xv, f16x2), f16x2{(_Float16)0.0f, (_Float16)0.0f});     // ReLU on the packed pair
+            peak16 = __builtin_elementwise_max(peak16, hv);       // (an overflowed conversion is +inf here: the range guard reads it at the end of the kernel)
+            hq[e] = __builtin_bit_cast(unsigned, hv);
+        }
+        dst.k[4 * (T >> 1) + 2 * (T & 1) + J] = hq;
+    }
+}
+template <int T>
+__device__ __forceinline__ void est_head(const f32x16& acc, const float* tab, f32x2& sig) {
+#pragma unroll
+    for (int I = 0; I < 8; ++I) {
+        const f32x2 w = *reinterpret_cast<const f32x2*>(tab + T * 32 + 2 * I);
+        sig[0] = fmaf(relu_bits(acc[2 * I]), w[0], sig[0]);
+        sig[1] = fmaf(relu_bits(acc[2 * I + 1]), w[1], sig[1]);
+    }
+}
+
+// One layer of the estimate kernel: per output tile the MFMAs of its blocks (operand of slot G + PF read at slot G), then the tile's epilogue at once.
+// NP point tiles per wave share every weight fragment.  enc: the encoding's four k-steps (HAS_ENC: the tile's first block).  HEAD: the output is not stored but
+// dotted with the density head's row.
+template <int NT, bool HAS_ENC, int NH, bool HEAD, int NP, int VARIANT>
+__device__ __forceinline__ void run_layer_simple(Pipe<VARIANT>& P, Pre& pf, const ActE (&in)[NP], const u32x4 (&enc)[NP][4], const float* bias_tab, ActE (&dst)[NP],
+                                                 const float* head_tab, f32x2 (&sig)[NP], f16x2& peak16) {
+    constexpr int NB = (HAS_ENC ? 1 : 0) + NH;
+    constexpr int NS = NB * SLOTS_PER_BLOCK;
+    static_assert((NT * NS) % CHUNK_SLOTS == 0, "a layer is a whole number of chunks");
+    static_for<0, NT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        f32x16 acc[NP];
+        acc[0] = *reinterpret_cast<const f32x16*>(bias_tab + t * 32);
+#pragma unroll
+        for (int q = 1; q < NP; ++q) acc[q] = acc[0];
+        static_for<0, NS>([&](auto GS) {
+            constexpr int g = decltype(GS)::value;
+            constexpr int G = t * NS + g;
+            constexpr int cr = G % CHUNK_SLOTS;
+            constexpr int bb = g / SLOTS_PER_BLOCK, s = g % SLOTS_PER_BLOCK;
+            const f16x8 aw = __builtin_bit_cast(f16x8, pf.q[G % PF]);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if constexpr (HAS_ENC && bb == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, enc[q][s]), acc[q], 0, 0, 0);
+                else acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, in[q].k[4 * (bb - (HAS_ENC ? 1 : 0)) + s]), acc[q], 0, 0, 0);
+            }
+            {
+                constexpr int Gp = G + PF;
+                constexpr bool next = (Gp / CHUNK_SLOTS) != (G / CHUNK_SLOTS);
+                constexpr int blk = (Gp / SLOTS_PER_BLOCK) % CHUNK_BLOCKS;
+                load_frag<Gp % SLOTS_PER_BLOCK, Gp % PF>(pf, P.block(next, blk), P.lane);
+            }
+            if constexpr (dma_piece(cr) >= 0) P.template prefetch_piece<(dma_piece(cr) >= 0 ? dma_piece(cr) : 0)>();
+            if constexpr (cr == SYNC_SLOT) P.sync_next();
+            if constexpr (cr == CHUNK_SLOTS - 1) P.advance();
+        });
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if constexpr (HEAD) est_head<t>(acc[q], head_tab, sig[q]);
+            else est_store<t>(acc[q], dst[q], peak16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+#endif
 
 // A layer as THREE f16 products (VAR_TRUNK_X, layers 0 and 1): every logical block is a pair of stream blocks, the network's (its
 // f16 area = Wh) then a residual block (f16 area = f16(W - Wh)).  The slot machinery (operand prefetch PF slots ahead, DMA pieces,
@@ -849,13 +948,18 @@ __device__ __forceinline__ void encode(float x, float y, float z, int h, Blk& en
     finish_block(enc, lres, mxv, peak);
 }
 
+#if defined(IBL_MX_EST) && IBL_MX_EST_TILES == 1
+#define IBL_MX_WGS_PER_CU 2
+#else
+#define IBL_MX_WGS_PER_CU 1
+#endif
 template <int VARIANT>
-__global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
+__global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
-    float* tabs = reinterpret_cast<float*>(smem + LDS_RING_BYTES);
+    float* tabs = reinterpret_cast<float*>(smem + R_RING_BYTES);
     for (int i = threadIdx.x; i < TAB_FLOATS / 4; i += 256)
         reinterpret_cast<f32x4*>(tabs)[i] = reinterpret_cast<const f32x4*>(a.tables)[i];
     __syncthreads();
@@ -885,7 +989,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
     if constexpr (VARIANT == VAR_TRUNK_P || LIST) {
         if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
     }
+#if defined(IBL_MX_EST) && IBL_MX_EST_TILES > 1
+    const long n_groups = (n_total + 128 * IBL_MX_EST_TILES - 1) / (128 * IBL_MX_EST_TILES);
+#else
     const long n_groups = (n_total + 127) / 128;
+#endif
 #ifdef IBL_MX_ABLATE_PROLOGUE   // timing ablation only (results are garbage): the input stage (points + encoding) runs in the first iteration only
     Blk pe, de;
     u32x16 pe_lo, loA[4];
@@ -909,6 +1017,57 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
             py = a.pts[3 * p + 1];
             pz = a.pts[3 * p + 2];
         }
+#ifdef IBL_MX_EST
+        {
+            constexpr int NP = IBL_MX_EST_TILES;
+            u32x4 pe[NP][4];
+            long pq[NP];
+            bool okq[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                pq[q] = NP == 1 ? p : g * (128L * NP) + wave * (32L * NP) + 32 * q + (lane & 31);
+                okq[q] = pq[q] < n_total;
+                float x = px, y = py, z = pz;
+                if (NP > 1) {
+                    x = y = z = 0.f;
+                    if (gen != nullptr && gen->rays_o != nullptr) {
+                        if (okq[q]) gen_offset_point(load_point_gen(gen), (unsigned)pq[q], x, y, z);
+                    } else if (okq[q]) {
+                        x = a.pts[3 * pq[q] + 0]; y = a.pts[3 * pq[q] + 1]; z = a.pts[3 * pq[q] + 2];
+                    }
+                }
+                Blk enc_blk;
+                encode<PE_PAIRS_PER_HALF>(x, y, z, h, enc_blk, peak, nullptr);
+                pe[q][0] = quarter<0>(enc_blk.hv); pe[q][1] = quarter<1>(enc_blk.hv); pe[q][2] = quarter<2>(enc_blk.hv); pe[q][3] = quarter<3>(enc_blk.hv);
+            }
+            ActE A[NP], B[NP];
+            f32x2 sig[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) sig[q] = f32x2{0.0f, 0.0f};
+            f16x2 peak16 = {(_Float16)0.0f, (_Float16)0.0f};
+            const float* bias = ltab + TAB_BIAS;
+            run_layer_simple<8, true, 0, false>(P, pf, A /*unused*/, pe, bias + BT_L0 * 32, A, nullptr, sig, peak16);                       // 0 -> A
+            for (int l = 1; l <= 3; l += 2) {                                                                                                 // 1..4: A -> B -> A
+                run_layer_simple<8, false, 4, false>(P, pf, A, pe, bias + (BT_L0 + 8 * (l & 3)) * 32, B, nullptr, sig, peak16);
+                run_layer_simple<8, false, 4, false>(P, pf, B, pe, bias + (BT_L0 + 8 * (l & 3) + 8) * 32, A, nullptr, sig, peak16);
+            }
+            run_layer_simple<8, true, 4, false>(P, pf, A, pe, bias + (BT_L0 + 40) * 32, B, nullptr, sig, peak16);                            // 5 (skip): A -> B
+            run_layer_simple<8, false, 4, false>(P, pf, B, pe, bias + (BT_L0 + 48) * 32, A, nullptr, sig, peak16);                           // 6: B -> A
+            run_layer_simple<8, false, 4, true>(P, pf, A, pe, bias + (BT_L0 + 56) * 32, B /*unused*/, ltab + TAB_SIG, sig, peak16);          // 7: A -> sigma head on its fp32 activations
+            {   // the largest activation of the group, as the bits of a non-negative float (what the range guard at the end of the kernel compares)
+                const float pk = fmaxf((float)peak16[0], (float)peak16[1]);
+                const unsigned pb = __builtin_bit_cast(unsigned, pk);
+                peak = pb > peak ? pb : peak;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const float p0 = sig[q][0] + sig[q][1];
+                const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
+                if (okq[q] && h == 0) a.out[pq[q] * a.out_stride] = sg;
+            }
+            continue;
+        }
+#endif
         if constexpr (VARIANT == VAR_TRUNK_P) {
             // ---- the 15-slot form: every trunk layer through run_layer_p, activations as (hi, lo, fp6 third term) ----
             BlkP pe;
@@ -1112,10 +1271,10 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)IBL_MXK::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)IBL_MXK::mlp_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, IBL_MXK::R_LDS_BYTES);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(IBL_MXK::mlp_kernel<VARIANT>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(IBL_MXK::mlp_kernel<VARIANT>, dim3(grid), dim3(256), IBL_MXK::R_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
@@ -1130,7 +1289,15 @@ static hipError_t launch_variant(const MlpArgs& a, int grid, hipStream_t stream)
 #if IBL_MX_VARIANT == 0
 hipError_t IBL_L(full)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_FULL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 1
+#ifdef IBL_MX_EST
+hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) {      // (two workgroups per CU: the dispatcher's grid is one per CU)
+    const long n_groups = (a.n_pts + 128 * IBL_MX_EST_TILES - 1) / (128 * IBL_MX_EST_TILES);
+    const long wgs = (IBL_MX_EST_TILES == 1 ? 2L : 1L) * grid;
+    return launch_variant<VAR_TRUNK>(a, (int)(n_groups < wgs ? n_groups : wgs), s);
+}
+#else
 hipError_t IBL_L(trunk)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_TRUNK>(a, grid, s); }
+#endif
 #elif IBL_MX_VARIANT == 2
 hipError_t IBL_L(refl)(const MlpArgs& a, int grid, hipStream_t s) { return launch_variant<VAR_REFL>(a, grid, s); }
 #elif IBL_MX_VARIANT == 5
