@@ -1115,7 +1115,9 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     // rows are zero.  The offset copies likewise: estimates everywhere, the query's kernel on each copy's relevant samples.
     // (the per-network decisions — is this a scene with empty space, are plain-f16 estimates good enough, how many fine samples are relevant — are taken on a launch of at
     // least SELECT_MIN_RAYS rays; until one has come by, smaller launches evaluate every sample: a handful of rays must not fix a checkpoint's route)
-    const bool can_decide = R >= SELECT_MIN_RAYS;
+    // ... and never inside a tapped call (a training step's forward: its weights are uploaded anew every step, so every step would decide again — with a stream
+    // synchronisation each — for a route it then may not even take)
+    const bool can_decide = R >= SELECT_MIN_RAYS && !keep_all_rows;
     const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (c->sel_decided ? c->sel_on : can_decide);
     // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
     HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));

@@ -237,6 +237,25 @@ def test_training_step_with_ground_truth_targets(lut, name, fused, teacher):
         R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values=gt, approximate_radiance=False, **kw)
 
 
+def test_a_training_step_takes_no_routing_decisions(G, lut):
+    """A gradient-carrying render of 2 048 rays (a tapped call: its weights change every step) neither decides the list refinement nor checks the estimates — each
+    would synchronise the stream, every step — and evaluates every sample; the inference render of the same context does decide."""
+    import train_loss as TL
+    from conftest import load_golden
+    from ibl_nerf_amd import renderer as R
+    nets, kw, K, _ = _setup(G, lut, "full")
+    g = load_golden("fitted_launch16k")[0]
+    rays = torch.from_numpy(np.stack([g["rays_o"][:2048], g["rays_d"][:2048]], 0)).cuda()
+    res = R.render_decomp(800, 800, K, chunk=2048, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    r = R.renderer_for(kw)
+    assert r.estimate_policy(0) == r.estimate_policy(1) == (False, False) and r.last_selection() == (0, 0)
+    res["color_map"].square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for net in nets for p in net.parameters())
+    with torch.no_grad():
+        R.render_decomp(800, 800, K, chunk=2048, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, perturb=0.0))
+    assert r.last_selection()[0] > 0
+
+
 def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
     """The fused shading backward against the autograd one inside a whole step: every parameter gradient of both networks."""
     import train_loss as TL
