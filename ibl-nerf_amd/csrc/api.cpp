@@ -37,6 +37,9 @@ constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
+// estimate_chunked: a ray counts as saturated behind its first chunk below this transmittance — two decades under the selection's own thresholds, so that what a
+// skipped sample could have carried (its weight set to exactly zero instead of < 1e-12) is far below half an ulp of any map: renders stay bit-identical
+constexpr float CHUNK_TMIN = 1e-12f;
 // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
 constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
 constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample; 0.18 on three products) + share x whole network
@@ -1081,6 +1084,29 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
     return a;
 }
 
+// Are network `which`'s estimates on the plain-f16 estimate kernel (the one that also takes lists)?
+static bool est_plain(const iblnerf_ctx* c, int which) { return which < 2 && c->est_f16 && c->est_checked[which] && c->est_ok[which] && !c->est_probe; }
+
+// A density estimate of the S samples of nv = (offsets ? 4 R : R) (virtual) rays in TWO z-chunks: samples [0, split) of every ray, then [split, S) only of the rays
+// whose transmittance behind their first `split` samples — composited conservatively from those estimates — is not yet below t_min (CHUNK_TMIN); the other rays'
+// later samples get -1e30 (k_select_points would not select them either: its transmittance only falls, and its thresholds are higher).  On the coarse grid half of the rays saturate in
+// the first half of the grid, on the fine grid a quarter to a half of them before its last quarter (scratch/saturation_depth.py).  Rows land in c->sig4 [nv, S].
+static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, const float* z, int z_stride, int S, long R, bool offsets,
+                            float eps, const float* noise, int split, float t_min, double flop_alg_per_point) {
+    const long nv = offsets ? 4 * R : R;
+    HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, 0, split, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
+                                   true, 0.0));
+    int rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * split, c->sig4, 1, Q_ESTIMATE, nullptr, false, nullptr, c->sel_index);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+    HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, split, S, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
+                                   false, FLOP_TRUNK));
+    rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * (S - split), c->sig4, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
+    if (rc) return rc;
+    c->flop_alg += (double)nv * S * flop_alg_per_point;      // (the query's algorithmic FLOPs: every sample, once)
+    return IBLNERF_OK;
+}
+
 // Once per uploaded network: may its density estimates run in plain f16?  Both estimates of the launch's main-query samples (c->pts), compared by
 // k_compare_estimates; one stream synchronisation.  A network whose plain-f16 trunk is ever half-way to a wrong selection keeps the f16 + 2 fp6 estimates.
 static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts, int S) {
@@ -1132,6 +1158,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     const bool fine_main_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_main_fast && c->d_stream_f16[which] != nullptr;
     if (places_samples && list_ok && !keep_all_rows && (fine_main_fast || fine_main_3)) {
         // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
+        // (not in z-chunks: this query's weights place the fine samples, and sample_pdf's thresholds see the last bit of their sum — a weight of 1e-12 behind saturation
+        // set to exactly zero moved z_std of one ray of a frame by 5e-5)
         rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
         if (rc) return rc;
         est_counted = true;     // (the query's algorithmic FLOPs are counted once, on its estimate)
@@ -1160,7 +1188,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         // the FINE main query likewise: the importance samples crowd around the surface, so about 40 % of them are relevant (against 6-8 % on the coarse
         // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
         // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
+        if (est_plain(c, which) && c->fsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, false, 0.f, noise, (3 * S) / 4, CHUNK_TMIN, FLOP_FULL);
+        else rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
         if (rc) return rc;
         est_counted = true;
         HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)R * S * RAW_CH * sizeof(float), s));
@@ -1252,7 +1281,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 // all 4 R S densities on the fast kernel (6 slots), then the relevant ones (neither clearly empty nor behind saturation, per offset copy:
                 // ~6 % on a scene with surfaces) again on the 15-slot form, scattered over the estimates.  The others composite to the same weights
                 // bit for bit (alpha = 0) or to within 1e-8 of a weight (the saturated tail).
-                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
+                if (est_plain(c, which)) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, S / 2, CHUNK_TMIN, FLOP_TRUNK);
+                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
                 if (rc) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
                 c->sel_candidates += 4 * R * S;
@@ -1269,7 +1299,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
                 // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
                 // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
-                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
+                if (est_plain(c, which) && c->xsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, (3 * S) / 4, CHUNK_TMIN, FLOP_TRUNK);
+                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
                 if (rc) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
                 c->sel_candidates += 4 * R * S;

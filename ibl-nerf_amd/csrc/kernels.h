@@ -199,6 +199,12 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                 float eps = 0.0f, float* est_out = nullptr, int est_stride = 0,     // est_out: the estimate copied to element (r S + s) * est_stride
                                 double list_flop_per_point = 0.0);   // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
 
+// estimates in two z-chunks: points + flat indices of samples [s0, s1) of every (virtual) ray (first: of all rays, in ray order; else: of the rays not yet saturated
+// behind their first s0 samples — list length at counter[0], executed MACs added to counter[4..5]; the others' samples get the density -1e30)
+hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const float* noise, long R, int S, int s0, int s1,
+                               float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps, bool first,
+                               double flop_per_point);
+
 // counts into *bad the samples on which estimate `a` (plain f16) is half-way to a wrong k_select_points decision against estimate `b` (f16 + 2 fp6)
 hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, int* bad, hipStream_t s);
 

@@ -986,7 +986,12 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
 
     constexpr bool LIST = VARIANT == VAR_REFL_LIST || VARIANT == VAR_FULL_LIST || VARIANT == VAR_TRUNK_X_LIST;      // a compact list of points with a flat index each (MlpArgs::out_index)
     long n_total = a.n_pts;
-    if constexpr (VARIANT == VAR_TRUNK_P || LIST) {
+#ifdef IBL_MX_EST
+    constexpr bool EST_FLAVOUR = true;      // (the estimate kernel also takes a list: estimates in z-chunks, api.cpp estimate_chunked)
+#else
+    constexpr bool EST_FLAVOUR = false;
+#endif
+    if constexpr (VARIANT == VAR_TRUNK_P || LIST || EST_FLAVOUR) {
         if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
     }
 #if defined(IBL_MX_EST) && IBL_MX_EST_TILES > 1
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
             for (int q = 0; q < NP; ++q) {
                 const float p0 = sig[q][0] + sig[q][1];
                 const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
-                if (okq[q] && h == 0) a.out[pq[q] * a.out_stride] = sg;
+                if (okq[q] && h == 0) a.out[(a.out_index != nullptr ? (long)a.out_index[pq[q]] : pq[q]) * a.out_stride] = sg;
             }
             continue;
         }

@@ -690,10 +690,90 @@ constexpr int SELECT_WAVES = 8;      // rays per block of k_select_points
 
 // the call's running totals behind a list launch (iblnerf_last_selection / iblnerf_last_executed_flops): [2..3] one uint64 of list entries, [4..5] one double of the
 // MACs x 2 the list launches evaluate on them
-__global__ void k_count_selection(int* counter, double flop_per_point) {
+__global__ void k_count_selection(int* counter, double flop_per_point, int count_entries) {
     const int n = counter[0];
-    *reinterpret_cast<unsigned long long*>(counter + 2) += (unsigned long long)n;
+    if (count_entries) *reinterpret_cast<unsigned long long*>(counter + 2) += (unsigned long long)n;
     *reinterpret_cast<double*>(counter + 4) += (double)n * flop_per_point;
+}
+
+// Estimates in two z-chunks (api.cpp estimate_chunked): the points and flat indices r S + s of samples [s0, s1) of every (virtual) ray — FIRST: of all rays, at
+// position vr (s1 - s0) + (s - s0), no counter — or, second chunk, of the rays whose transmittance behind their first s0 samples (composited conservatively from the
+// estimates already there, as in k_select_points) is still above t_min; the other rays' samples [s0, s1) get the density -1e30: behind saturation, never relevant.
+template <int NPL, bool OFFSETS, bool FIRST>
+__global__ __launch_bounds__(64 * SELECT_WAVES) void k_chunk_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
+                                                                    float* __restrict__ sigma, const float* __restrict__ noise, long R, int S, int s0, int s1, float margin,
+                                                                    float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;
+    const bool live = vr_raw < (OFFSETS ? 4 * R : R);
+    const long vr = live ? vr_raw : 0;
+    const long r = OFFSETS ? vr % R : vr;
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float* zrow = zbase + (long)z_stride * r;
+    bool alive = live;
+    if constexpr (!FIRST) {
+        const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        double lane_prod = 1.0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int s = lane * NPL + i;
+            if (s < s0) {
+                float sg = sigma[vr * S + s];
+                if (noise != nullptr) sg = sg + noise[r * S + s];
+                const float dist = (zrow[s + 1] - zrow[s]) * norm;                       // (s + 1 <= s0 < S)
+                const float a = 1.0f - expf(-fmaxf(sg * 0.75f - margin, 0.0f) * dist);    // the conservative transmittance of k_select_points
+                lane_prod *= (double)((1.0f - a) + 1e-10f);
+            }
+        }
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) lane_prod *= __shfl_xor(lane_prod, dd);
+        alive = live && lane_prod > (double)t_min;
+    }
+    int base = 0;
+    const int per_ray = s1 - s0;
+    if constexpr (FIRST) {
+        base = (int)(vr * per_ray);
+    } else {
+        __shared__ int wave_total[SELECT_WAVES];
+        __shared__ int block_base;
+        if (lane == 0) wave_total[wave] = alive ? per_ray : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sum = 0;
+#pragma unroll
+            for (int w = 0; w < SELECT_WAVES; ++w) sum += wave_total[w];
+            block_base = sum > 0 ? atomicAdd(counter, sum) : 0;
+        }
+        __syncthreads();
+        base = block_base;
+        for (int w = 0; w < wave; ++w) base += wave_total[w];
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (!live || s < s0 || s >= s1) continue;
+        const unsigned flat = (unsigned)(vr * S + s);
+        if (!alive) {
+            sigma[flat] = -1e30f;
+            continue;
+        }
+        float p[3];
+        if constexpr (OFFSETS) {
+            PointGen g;
+            g.rays_o = rays_o; g.rays_d = rays_d; g.z = zbase; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+            gen_offset_point(g, flat, p[0], p[1], p[2]);
+        } else {
+            const float zz = zrow[s];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = o[c] + d[c] * zz;      // (k_make_points mode 0; this file is compiled without contraction)
+        }
+        const long pos = (long)base + (s - s0);
+        pts_out[3 * pos] = p[0];
+        pts_out[3 * pos + 1] = p[1];
+        pts_out[3 * pos + 2] = p[2];
+        index_out[pos] = (int)flat;
+    }
 }
 
 // Is a plain-f16 density estimate good enough for k_select_points on this network?  Two estimates of the same n samples (b: the f16 + 2 fp6 form, error < 1e-2);
@@ -1207,7 +1287,25 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                t_min, eps, pts_out, index_out, counter, est_out, est_stride);
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point);
+    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const float* noise, long R, int S, int s0, int s1,
+                               float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps, bool first,
+                               double flop_per_point) {
+    if (R <= 0 || s1 <= s0) return hipSuccess;
+    const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
+    const hipError_t e = by_npl(S, [&](auto N) {
+        constexpr int NPL = decltype(N)::value;
+#define IBL_CHUNK(OFF, FST) hipLaunchKernelGGL((k_chunk_points<NPL, OFF, FST>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, noise, R, S, s0, s1, margin, t_min, \
+                                               eps, pts_out, index_out, counter)
+        if (offsets) { if (first) IBL_CHUNK(true, true); else IBL_CHUNK(true, false); }
+        else { if (first) IBL_CHUNK(false, true); else IBL_CHUNK(false, false); }
+#undef IBL_CHUNK
+    });
+    if (e != hipSuccess) return e;
+    if (!first) hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, 0);     // (the chunk's estimates: executed MACs, not refined samples)
     return hipGetLastError();
 }
 

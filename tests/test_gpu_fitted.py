@@ -217,7 +217,10 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
         # the density estimates run in plain f16 once the network's first launch has compared them with the f16 + 2 fp6 ones (api.cpp check_estimates)
         assert r.estimate_policy(0) == r.estimate_policy(1) == {"selected": (True, True), "est6": (False, False), "all": (False, False)}[label]
         again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                      # the compaction's order is whatever the atomics give: results are not
-        assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)
+        # (the first launch of a checkpoint estimates whole batches, later ones in z-chunks: a sample behind a transmittance of 1e-12 then weighs exactly zero
+        # instead of 1e-17 — every map the same bit for bit, the per-sample weights to 1e-15)
+        assert all(torch.equal(again[k], out[label][k]) for k in again if k != "weights") and r.last_selection() == (sel, cand)
+        assert float((again["weights"] - out[label]["weights"]).abs().max()) <= 1e-15
         executed, algorithmic = r.last_executed_flops(), r.last_mlp_time()[2]
         # (algorithmic: every sample of every query priced as the reference evaluates it; executed: what the launches ran — FLOP_* of csrc/api.cpp)
         full, trunk, refl = 1591552.0, 982528.0, 1458944.0

@@ -204,7 +204,16 @@ def test_the_fast_table_on_the_second_checkpoint_is_what_the_calibration_says(R,
     ra = make_renderer(R, g2, sdc2, sdf2, lut, max_rays_per_launch=16384)
     rb = make_renderer(R, g2, sdc2, sdf2, lut, max_rays_per_launch=16384, mlp_precision="f16x3_mxfp6")
     a, b = ra.render_rays(g2["rays_o"], g2["rays_d"], 0.5, 8.0), rb.render_rays(g2["rays_o"], g2["rays_d"], 0.5, 8.0)
-    assert ra.policy["decision"] == "safe" and all(torch.equal(a[k].nan_to_num(7.0), b[k].nan_to_num(7.0)) for k in a)
+    # (per-sample weights to 1e-15: a context's first launch estimates whole batches, later ones in z-chunks — a sample behind a transmittance of 1e-12 then weighs
+    # exactly zero instead of ~1e-17; every map is the same bit for bit)
+    assert ra.policy["decision"] == "safe" and all(_same(a[k], b[k]) for k in a)
+
+
+def _same(x, y):
+    """torch.equal, NaNs matching; the per-sample weights to 1e-15 (see above)."""
+    if x.dim() == 2 and x.shape[1] > 18:
+        return float((x.nan_to_num(7.0) - y.nan_to_num(7.0)).abs().max()) <= 1e-15
+    return torch.equal(x.nan_to_num(7.0), y.nan_to_num(7.0))
 
 
 def test_calibration_measures_and_decides(R, lut):
@@ -233,9 +242,9 @@ def test_calibration_measures_and_decides(R, lut):
     few = r.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)
     assert r.policy is None and torch.equal(few["weights"], safe.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)["weights"])
     many = r.render_rays(g["rays_o"][:4000], g["rays_d"][:4000], 0.5, 8.0)
-    assert r.policy["decision"] == "fast" and torch.equal(many["weights"], fast.render_rays(g["rays_o"][:4000], g["rays_d"][:4000], 0.5, 8.0)["weights"])
+    assert r.policy["decision"] == "fast" and _same(many["weights"], fast.render_rays(g["rays_o"][:4000], g["rays_d"][:4000], 0.5, 8.0)["weights"])
     few2 = r.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)                 # decided: small calls follow the decision
-    assert torch.equal(few2["weights"], many["weights"][:300])
+    assert _same(few2["weights"], many["weights"][:300])
     r.load_weights(0, sdc2)
     r.load_weights(1, sdf2)
     assert r.policy is None
