@@ -46,7 +46,7 @@ MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE, ROUTE_POINT_BATCH, ROUTE_COARSE_MAIN_22BIT, ROUTE_USER_TRUNK_P, ROUTE_FINE_OFFSETS_PRECISE, ROUTE_COARSE_DENSITY_ALL_POINTS = 1, 2, 4, 8, 16, 32, 64, 128   # iblnerf_options.query_routing bits
-ROUTE_ESTIMATES_6SLOT = 256
+ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE = 256, 512
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 

@@ -90,6 +90,7 @@ struct iblnerf_ctx {
     bool x_coarse = false, x_user = false, fine_main_precise = false;
     bool x_fine_precise = false;                  // IBLNERF_ROUTE_FINE_OFFSETS_PRECISE
     bool coarse_sigma_p = true, p_user = false;
+    bool est_whole = false;                       // IBLNERF_ROUTE_ESTIMATES_WHOLE: no z-chunks (estimate_chunked)
     bool est_f16 = true;                          // density estimates behind a list refinement in plain f16 (IBLNERF_ROUTE_ESTIMATES_6SLOT: on the f16 + 2 fp6 form) ...
     bool est_checked[2] = {false, false}, est_ok[2] = {false, false};   // ... once the network's first launch has shown that they are good enough (check_estimates)
     bool est_probe = false;                       // (that check's own plain-f16 launch)
@@ -153,13 +154,14 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->x_fine_precise = (bits & IBLNERF_ROUTE_FINE_OFFSETS_PRECISE) != 0;
     c->p_all_points = (bits & IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS) != 0;
     c->est_f16 = (bits & IBLNERF_ROUTE_ESTIMATES_6SLOT) == 0;
+    c->est_whole = (bits & IBLNERF_ROUTE_ESTIMATES_WHOLE) != 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 511) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..511)");
+    if (bits < 0 || bits > 1023) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..1023)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -233,8 +235,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 511 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..511), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 1023 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..1023), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -1086,23 +1088,26 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
 
 // Are network `which`'s estimates on the plain-f16 estimate kernel (the one that also takes lists)?
 static bool est_plain(const iblnerf_ctx* c, int which) { return which < 2 && c->est_f16 && c->est_checked[which] && c->est_ok[which] && !c->est_probe; }
+static bool est_chunks(const iblnerf_ctx* c, int which) { return est_plain(c, which) && !c->est_whole; }     // ... and in z-chunks (IBLNERF_ROUTE_ESTIMATES_WHOLE: never)
 
-// A density estimate of the S samples of nv = (offsets ? 4 R : R) (virtual) rays in TWO z-chunks: samples [0, split) of every ray, then [split, S) only of the rays
-// whose transmittance behind their first `split` samples — composited conservatively from those estimates — is not yet below t_min (CHUNK_TMIN); the other rays'
+// A density estimate of the S samples of nv = (offsets ? 4 R : R) (virtual) rays in up to THREE z-chunks: samples [0, cut0) of every ray, then [cut0, cut1) and
+// [cut1, S) only of the rays whose transmittance behind the samples in front of the chunk — composited conservatively from those estimates — is not yet below t_min (CHUNK_TMIN); the other rays'
 // later samples get -1e30 (k_select_points would not select them either: its transmittance only falls, and its thresholds are higher).  On the coarse grid half of the rays saturate in
 // the first half of the grid, on the fine grid a quarter to a half of them before its last quarter (scratch/saturation_depth.py).  Rows land in c->sig4 [nv, S].
 static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, const float* z, int z_stride, int S, long R, bool offsets,
-                            float eps, const float* noise, int split, float t_min, double flop_alg_per_point) {
+                            float eps, const float* noise, int cut0, int cut1, float t_min, double flop_alg_per_point) {
     const long nv = offsets ? 4 * R : R;
-    HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, 0, split, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
-                                   true, 0.0));
-    int rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * split, c->sig4, 1, Q_ESTIMATE, nullptr, false, nullptr, c->sel_index);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-    HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, split, S, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
-                                   false, FLOP_TRUNK));
-    rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * (S - split), c->sig4, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
-    if (rc) return rc;
+    const int cuts[4] = {0, cut0, cut1, S};          // chunks [0, cut0) of every ray, then [cut0, cut1) and [cut1, S) of the rays still alive at their start
+    for (int k = 0; k < 3; ++k) {
+        const int s0 = cuts[k], s1 = cuts[k + 1];
+        if (s1 <= s0) continue;
+        const bool first = k == 0;
+        if (!first) HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, s0, s1, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
+                                       first, FLOP_TRUNK));
+        const int rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * (s1 - s0), c->sig4, 1, Q_ESTIMATE, nullptr, false, first ? nullptr : c->sel_count, c->sel_index);
+        if (rc) return rc;
+    }
     c->flop_alg += (double)nv * S * flop_alg_per_point;      // (the query's algorithmic FLOPs: every sample, once)
     return IBLNERF_OK;
 }
@@ -1188,7 +1193,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
         // the FINE main query likewise: the importance samples crowd around the surface, so about 40 % of them are relevant (against 6-8 % on the coarse
         // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
         // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
-        if (est_plain(c, which) && c->fsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, false, 0.f, noise, (3 * S) / 4, CHUNK_TMIN, FLOP_FULL);
+        if (est_chunks(c, which) && c->fsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, false, 0.f, noise, (3 * S) / 4, (7 * S) / 8, CHUNK_TMIN, FLOP_FULL);
         else rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
         if (rc) return rc;
         est_counted = true;
@@ -1281,7 +1286,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 // all 4 R S densities on the fast kernel (6 slots), then the relevant ones (neither clearly empty nor behind saturation, per offset copy:
                 // ~6 % on a scene with surfaces) again on the 15-slot form, scattered over the estimates.  The others composite to the same weights
                 // bit for bit (alpha = 0) or to within 1e-8 of a weight (the saturated tail).
-                if (est_plain(c, which)) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, S / 2, CHUNK_TMIN, FLOP_TRUNK);
+                if (est_chunks(c, which)) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, S / 2, (3 * S) / 4, CHUNK_TMIN, FLOP_TRUNK);
                 else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
                 if (rc) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
@@ -1299,7 +1304,7 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
                 // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
                 // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
                 // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
-                if (est_plain(c, which) && c->xsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, (3 * S) / 4, CHUNK_TMIN, FLOP_TRUNK);
+                if (est_chunks(c, which) && c->xsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, (3 * S) / 4, (7 * S) / 8, CHUNK_TMIN, FLOP_TRUNK);
                 else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
                 if (rc) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));

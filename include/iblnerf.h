@@ -129,6 +129,8 @@ enum {
                                                  agree to ~1e-9 on a weight */
     IBLNERF_ROUTE_FINE_OFFSETS_PRECISE = 64,  /* F16X3_MXFP6X: the fine grid's offset queries back on F16X3 (with IBLNERF_ROUTE_FINE_MAIN_PRECISE the mode then
                                                  routes every query as F16X3_MXFP6 does: the "safe" policy of ibl-nerf_amd/renderer.py's load-time calibration) */
+    IBLNERF_ROUTE_ESTIMATES_WHOLE = 512,      /* the density estimates of the offset copies and of the fine main query on every sample at once instead of in z-chunks
+                                                 (the later chunks only for rays not yet saturated; results are the same bit for bit, per-sample weights to 1e-15) */
     IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
                                                  f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
                                                  only has to be right to within the selection margin of 1.0 in raw density */

@@ -17,7 +17,7 @@ for which in ("fitted", "fitted2", "synthetic"):
         f = np.load(os.path.join(ROOT, "tests", "golden", which + "_ckpt.npz"))
         sdc, sdf = ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
     out = {}
-    for label, routing in (("selected", ()), ("est 6-slot", ("estimates_6slot",)), ("all points", ("coarse_density_all_points",))):
+    for label, routing in (("selected", ()), ("est whole", ("estimates_whole",)), ("all points", ("coarse_density_all_points",))):
         r = R.Renderer(64, 128, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         r.load_weights(0, sdc); r.load_weights(1, sdf); r.load_lut(lut)
         ro, rd = r.get_rays(800, 800, K, c2w)
@@ -28,7 +28,7 @@ for which in ("fitted", "fitted2", "synthetic"):
         torch.cuda.synchronize(); dt = time.time() - t0
         out[label] = m
         print("%-10s %-10s %.3f s/frame  selection %s" % (which, label, dt, r.last_selection()), flush=True)
-    for a, b in ((out["selected"], out["all points"]), (out["selected"], out["est 6-slot"])):
+    for a, b in ((out["selected"], out["all points"]), (out["selected"], out["est whole"])):
         worst = {k: float(((a[k] - b[k]).abs().nan_to_num(0).amax() / b[k].abs().nan_to_num(0).amax().clamp_min(1e-30))) for k in a}
         top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
         same = sum(bool(torch.equal(a[k].nan_to_num(7), b[k].nan_to_num(7))) for k in a)

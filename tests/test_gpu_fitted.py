@@ -272,6 +272,26 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     assert all(torch.equal(fog["selected"][k], fog["all"][k]) for k in fog["all"])
 
 
+def test_estimates_in_z_chunks_change_nothing(R, lut):
+    """api.cpp estimate_chunked: the density estimates of the offset copies and of the fine main query run on the first samples of every (virtual) ray and on the later
+    ones only for rays whose conservative transmittance is still above 1e-12 (the skipped samples get -1e30).  Against IBLNERF_ROUTE_ESTIMATES_WHOLE: the same samples
+    refined, every map bit for bit, the per-sample weights to 1e-15 (exactly zero instead of ~1e-17 behind saturation) — and fewer MACs executed."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    n = 8192
+    out, sel, flops = {}, {}, {}
+    for label, routing in (("chunks", ()), ("whole", ("estimates_whole",))):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                 # (the first launch takes the decisions)
+        out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
+        sel[label], flops[label] = r.last_selection(), r.last_executed_flops()
+    assert sel["chunks"] == sel["whole"] and flops["chunks"] < 0.97 * flops["whole"], (sel, flops)
+    for k in out["whole"]:
+        if k == "weights":
+            assert float((out["chunks"][k] - out["whole"][k]).abs().max()) <= 1e-15
+        else:
+            assert torch.equal(out["chunks"][k], out["whole"][k]), k
+
+
 def test_a_handful_of_rays_decides_nothing(R, lut):
     """The per-network decisions behind the list refinement (empty space or fog, plain-f16 estimates or not, the fine grid's relevant share) wait for a launch of at
     least 1 024 rays (api.cpp SELECT_MIN_RAYS): a first call of 64 rays evaluates every sample and leaves them open; the next call of 4 096 takes them."""
