@@ -482,7 +482,7 @@ static void pass(const Job* j, const Net* net, Work* k, long r0, int nr, const f
     }
 
     /* the reflected rays: :442-448, raw2outputs_simple :38-68 — the network is queried with the reflected direction as view direction */
-    float* refl_dirs = (float*)malloc(sizeof(float) * 3 * nr);
+    float* refl_dirs = (float*)calloc((size_t)3 * (nr > 0 ? nr : 1), sizeof(float));
     for (int i = 0; i < nr; ++i) for (int c = 0; c < 3; ++c) refl_dirs[3 * i + c] = keep[i][12 + c];
     mlp_eval(net, &k->sc, k->rpts, (long)nr * Sc, refl_dirs, Sc, k->rraw);
     free(refl_dirs);
