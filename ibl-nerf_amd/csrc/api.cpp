@@ -1339,7 +1339,8 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     if (list_ok && c->sel_decided && c->sel_on) {
         // the reflected ray leaves its surface into empty space and ends on the next one: a density estimate everywhere (fast TRUNK form; the same trunk
         // arithmetic the REFL form runs), the view layers and the twelve radiance channels on the relevant samples only, zero rows elsewhere (weight 0, or < 1e-8)
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_REFL);
+        if (est_chunks(c, which)) rc = estimate_chunked(c, s, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, Sc / 2, (3 * Sc) / 4, CHUNK_TMIN, FLOP_REFL);
+        else rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_REFL);
         if (rc) return rc;
         HIP_TRY(c, hipMemsetAsync(c->refl_raw, 0, (size_t)R * Sc * REFL_CH * sizeof(float), s));
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
