@@ -107,7 +107,7 @@ def load_checkpoint(kind):
     ships with the reference), "synthetic" = round 1's seeded random-init networks (fog).  The work per ray is the same either way
     (fixed sample counts, no early termination); the operand statistics the matrix cores see are not."""
     from ibl_nerf_amd import checkpoint as ck
-    if kind in ("fitted", "fitted2"):    # (fitted2: the second, sharper scene of tests/golden/fit_checkpoint.py — the checkpoint on which mlp_precision="auto" decides "safe")
+    if kind in ("fitted", "fitted2", "fitted3"):    # (fitted3: round 5's hold-out scene; fitted2: the second, sharper scene of tests/golden/fit_checkpoint.py — the checkpoint on which mlp_precision="auto" decides "safe")
         f = np.load(os.path.join(ROOT, "tests", "golden", kind + "_ckpt.npz"))
         return ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
     return ck.synthetic_state_dict(0, 1.0), ck.synthetic_state_dict(1, 1.0)
@@ -203,8 +203,10 @@ def parity_vs_reference_fixture(frame_maps_fn):
     tests/golden/fitted_launch16k.npz, made by tests/golden/make_golden.py from /root/reference in the build container: the reference's
     float32 maps and, per ray, its own sensitivity — float64-vs-float32 difference, one-ulp nudges of the coarse weights, both branches of
     sample_pdf's threshold; NOT the fourth, 22-bit-parameter column, which describes this library, not the reference).  Per intrinsic channel:
-    per-ray relative error 99 % / 99.9 % / worst, rays above north_star's 1e-3, and `max_allowed_by_reference` = the number of these rays whose
-    own reference sensitivity exceeds 1e-3 / 8 (the rays the reference itself cannot place within 1e-3)."""
+    per-ray relative error 99 % / 99.9 % / worst, rays above north_star's 1e-3; `rays_sensitive_in_reference` = the number of these rays whose
+    own reference sensitivity exceeds 1e-3 / 8 (a statement about the reference's conditioning, not an allowance); and — the yardstick — `c_restatement` = the same
+    statistics of the fp32 C restatement (oracle/csrc) on the same rays against the same reference render (tests/golden/c_restatement_column.json, written by
+    tests/golden/make_c_column.py): what an actual fp32 implementation attains."""
     path = os.path.join(ROOT, "tests", "golden", "fitted_launch16k.npz")
     if not os.path.exists(path):
         return None
@@ -212,8 +214,10 @@ def parity_vs_reference_fixture(frame_maps_fn):
     pix = g["pix"]
     out = {"n_rays": int(len(pix)), "fixture": "tests/golden/fitted_launch16k.npz",
            "note": "HIP frame vs the reference's own float32 render (PyTorch, build container) at the pixels of the fixture; per-ray |diff| max over a map's channels "
-                   "over the map's largest value; max_allowed_by_reference counts rays whose own fp64-vs-fp32 / one-ulp-nudge / threshold-branch sensitivity in "
-                   "the reference exceeds 1e-3 / 8"}
+                   "over the map's largest value; c_restatement = the fp32 C restatement against the same render on the same rays (the yardstick: what fp32 attains); "
+                   "rays_sensitive_in_reference counts rays whose own fp64-vs-fp32 / one-ulp-nudge / threshold-branch sensitivity in the reference exceeds 1e-3 / 8"}
+    col_path = os.path.join(ROOT, "tests", "golden", "c_restatement_column.json")
+    col = json.load(open(col_path)).get("fitted_launch16k", {}) if os.path.exists(col_path) else {}
     for k in PARITY_KEYS:
         ref = g["out__" + k].astype(np.float64).reshape(len(pix), -1)
         e = np.abs(frame_maps_fn(pix, k).astype(np.float64).reshape(len(pix), -1) - ref).max(-1) / max(float(np.abs(ref).max()), 1e-30)
@@ -222,7 +226,8 @@ def parity_vs_reference_fixture(frame_maps_fn):
             if y + k in g.files:
                 f = np.maximum(f, g[y + k].astype(np.float64))
         out[k] = {"p99": float(np.percentile(e, 99)), "p999": float(np.percentile(e, 99.9)), "max": float(e.max()), "rays_above_1e-3": int((e > 1e-3).sum()),
-                  "max_allowed_by_reference": int((f > 1e-3 / 8).sum())}
+                  "c_restatement": ({"rays_above_1e-3": col[k]["above_1e-3"], "p999": col[k]["p999"], "max": col[k]["max"]} if k in col else None),
+                  "rays_sensitive_in_reference": int((f > 1e-3 / 8).sum())}
     return out
 
 
@@ -234,7 +239,7 @@ def main():
     ap.add_argument("--rays-per-launch", type=int, default=65536)
     ap.add_argument("--inference-min", action="store_true",
                     help="coarse pass evaluates density only (no coarse '0' maps): SURVEY.md §8 d mode (ii)")
-    ap.add_argument("--checkpoint", choices=["fitted", "fitted2", "synthetic"], default="fitted",
+    ap.add_argument("--checkpoint", choices=["fitted", "fitted2", "fitted3", "synthetic"], default="fitted",
                     help="fitted: the checkpoint with surfaces (tests/golden/fitted_ckpt.npz); synthetic: round 1's random-init networks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -244,6 +249,9 @@ def main():
                          "the renderer's default, the mode that holds parity on a checkpoint with surfaces")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the frame exchange: nccl (= RCCL, the default) | gloo (test hook: several ranks on one GPU, host-staged)")
+    ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved", help="how the frame's rows are dealt to the ranks (dist.tile_row_indices)")
+    ap.add_argument("--tile-times", action="store_true", help="also time each of the 8 contiguous and 8 interleaved row tiles of the frame by itself on this one GPU "
+                                                              "(the balance of an 8-rank frame, measured without an 8-GPU node) and report them as `tile_ms`")
     ap.add_argument("--query-routing", default="", help="comma-separated iblnerf_options.query_routing names (A/B measurements, e.g. point_batch)")
     args = ap.parse_args()
     routing = [n for n in args.query_routing.split(",") if n]
@@ -291,12 +299,19 @@ def main():
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
-    # mlp_precision="auto": the checkpoint's query routing is decided here, once, on 4 096 seeded pixels of the whole frame (the same on every rank) —
-    # part of loading a checkpoint, like the weight upload, not of a frame
-    policy = D.calibrate_on_frame(r, H, W, K, c2w, NEAR, FAR) if args.mlp_precision == "auto" else r.policy
-    row0, n_rows = D.tile_rows(H, rank, world)
-    ro, rd = r.get_rays(H, W, K, c2w, row0, n_rows)     # rays resident in HBM before the timed region
-    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    # The checkpoint's ROUTE (which queries run as estimate + list, on which estimates: Renderer.decide_route) and, for mlp_precision="auto", its precision table
+    # (Renderer.calibrate) are measured here, once, on 4 096 seeded pixels of the whole frame (the same on every rank) — part of loading a checkpoint, like the
+    # weight upload, not of a frame; `calibration_ms` reports what it costs
+    torch.cuda.synchronize()
+    t_cal = time.perf_counter()
+    policy = D.calibrate_on_frame(r, H, W, K, c2w, NEAR, FAR)
+    torch.cuda.synchronize()
+    calibration_ms = 1e3 * (time.perf_counter() - t_cal)
+    rows = D.tile_row_indices(H, rank, world, args.partition)      # interleaved: rank, rank + world, ... (a ray's cost depends on what it sees: every rank gets the same mix)
+    n_rows = len(rows)
+    ro, rd = r.get_rays(H, W, K, c2w)                   # rays resident in HBM before the timed region
+    sl = slice(rows.start, rows.stop, rows.step)
+    ro, rd = ro[sl].reshape(-1, 3).contiguous(), rd[sl].reshape(-1, 3).contiguous()
 
     def step(events=None):
         maps = r.render_rays(ro, rd, NEAR, FAR)
@@ -306,7 +321,7 @@ def main():
             buf, _ = D.pack_maps(maps, D.EXPORT_KEYS, n_rows, W)
             if events:
                 events[1].record()
-            D.all_gather_frame(buf, H, W)
+            D.all_gather_frame(buf, H, W, partition=args.partition)
             if events:
                 events[2].record()
         return maps
@@ -362,13 +377,56 @@ def main():
             by_precision[mode] = H * W / (time.perf_counter() - t1)
             del r3
 
+    # the same frame of the OTHER checkpoints (the headline is scene-dependent since round 4: what a ray costs depends on what it sees) — extras, never `value`
+    by_checkpoint = {}
+    if world == 1 and not args.inference_min and not args.no_extras:
+        for kind in ("fitted", "fitted2", "fitted3", "synthetic"):
+            if kind == args.checkpoint or (kind.startswith("fitted") and not os.path.exists(os.path.join(ROOT, "tests", "golden", kind + "_ckpt.npz"))):
+                continue
+            r4 = R.Renderer(N_SAMPLES, N_IMPORTANCE, max_rays_per_launch=args.rays_per_launch, mlp_precision=args.mlp_precision)
+            c4, f4 = load_checkpoint(kind)
+            r4.load_weights(0, c4)
+            r4.load_weights(1, f4)
+            r4.load_lut(lut)
+            pol4 = D.calibrate_on_frame(r4, H, W, K, c2w, NEAR, FAR)
+            r4.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r4.render_rays(ro, rd, NEAR, FAR)
+            torch.cuda.synchronize()
+            by_checkpoint[kind] = {"value": H * W / (time.perf_counter() - t1), "decision": (pol4 or {}).get("decision"), "route": r4.get_route(), "trips": r4.trips,
+                                   "slot_units_per_ray": r4.last_slot_units() / (H * W)}
+            del r4
+
+    # the balance of an 8-rank frame on ONE GPU: each of the 8 contiguous bands and each of the 8 interleaved row sets of the frame rendered by itself
+    tile_ms = None
+    if world == 1 and args.tile_times:
+        fo, fd = r.get_rays(H, W, K, c2w)
+        tile_ms = {}
+        for part in ("contiguous", "interleaved"):
+            ms = []
+            for tr in range(8):
+                rr = D.tile_row_indices(H, tr, 8, part)
+                ts = slice(rr.start, rr.stop, rr.step)
+                to, td = fo[ts].reshape(-1, 3).contiguous(), fd[ts].reshape(-1, 3).contiguous()
+                r.render_rays(to, td, NEAR, FAR)
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    r.render_rays(to, td, NEAR, FAR)
+                    torch.cuda.synchronize()
+                    best = min(best, 1e3 * (time.perf_counter() - t1))
+                ms.append(best)
+            tile_ms[part] = {"ms": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms))}
+
     # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
     r.set_profiling(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if grouped else None
     step(ev)
     torch.cuda.synchronize()
     mlp_ms, n_launch, flop = r.last_mlp_time()
-    flop_executed, selection = r.last_executed_flops(), r.last_selection()
+    flop_executed, selection, slot_units = r.last_executed_flops(), r.last_selection(), r.last_slot_units()
     r.set_profiling(False)
     # the exchange step on its own (same untimed extra step; events on torch's current stream, where pack and all-gather are enqueued):
     # packing the export maps into one buffer, and the all-gather (host-staged under the gloo test hook)
@@ -391,7 +449,8 @@ def main():
             "config": {"workload": "Kitchen 800x800 full test view, 64+128 samples, eps-normal + reflected pass"
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
-                       "mlp_precision": args.mlp_precision, "policy": policy,
+                       "mlp_precision": args.mlp_precision, "policy": policy, "route": r.get_route(), "route_table": r.describe_route().splitlines(),
+                       "calibration_ms": calibration_ms, "partition": args.partition, "tripwire_events": r.trips,
                        **({"query_routing": routing} if routing else {}),
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if grouped else "single GPU"},
@@ -410,6 +469,9 @@ def main():
                                       "frac": (flop_executed / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if mlp_ms > 0 else 0.0,
                                       "share_of_algorithmic": flop_executed / flop if flop else None,
                                       "samples_refined": selection[0], "of_candidates": selection[1],
+                                      # what governs speed on a power-bound chip (STATE.md section 2): per launch points x 64-MAC groups x the matrix slots its
+                                      # product scheme spends per group (plain f16 4, f16 + 2 fp6 6, mixed trunk 7.5, three f16 products 12, 15-slot 15), per ray
+                                      "slot_units_per_ray": slot_units / max(n_rows * W, 1),
                                       "note": "2 x nn.Linear MACs of the launches as run (estimates: trunk only; head layers, 15-slot densities and refinements: selected samples only)"},
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues " + MODES[args.mlp_precision][2]},
         }
@@ -426,6 +488,11 @@ def main():
             line["value_inference_min"] = value_min
         if by_precision:
             line["value_by_mlp_precision"] = dict(by_precision, **{args.mlp_precision: line["value"]})
+        if by_checkpoint:
+            line["value_by_checkpoint"] = dict({k: v["value"] for k, v in by_checkpoint.items()}, **{args.checkpoint: line["value"]})
+            line["by_checkpoint"] = by_checkpoint
+        if tile_ms:
+            line["tile_ms"] = tile_ms
         if world == 1 and not args.no_cpu_baseline:
             color = maps["color_map"]
 

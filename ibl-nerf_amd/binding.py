@@ -25,6 +25,7 @@ EXPORTS = [
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
     "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt",
+    "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units",
 ]
 
 
@@ -46,7 +47,7 @@ MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE, ROUTE_POINT_BATCH, ROUTE_COARSE_MAIN_22BIT, ROUTE_USER_TRUNK_P, ROUTE_FINE_OFFSETS_PRECISE, ROUTE_COARSE_DENSITY_ALL_POINTS = 1, 2, 4, 8, 16, 32, 64, 128   # iblnerf_options.query_routing bits
-ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE = 256, 512
+ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE, ROUTE_OFFSETS_ESTIMATE_ALL, ROUTE_NO_RESCUE = 256, 512, 1024, 2048
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -84,6 +85,17 @@ class Sampling(C.Structure):
 
 class Taps(C.Structure):
     _fields_ = [("d_z_coarse", FP), ("d_z_fine", FP), ("d_raw_coarse", FP), ("d_raw_fine", FP), ("d_env_coarse", FP), ("d_env_fine", FP)]
+
+
+class Route(C.Structure):
+    """iblnerf_route: the checkpoint's measured route (which queries run as estimate + list, on which estimates)."""
+    _fields_ = [("decided", C.c_int32), ("estimates_plain_f16", C.c_int32 * 2), ("tripped", C.c_int32),
+                ("coarse_share", C.c_double), ("fine_main_share", C.c_double), ("fine_offsets_share", C.c_double)]
+
+    def as_dict(self):
+        return {"decided": bool(self.decided), "estimates_plain_f16": [bool(self.estimates_plain_f16[0]), bool(self.estimates_plain_f16[1])],
+                "tripped": int(self.tripped), "coarse_share": float(self.coarse_share), "fine_main_share": float(self.fine_main_share),
+                "fine_offsets_share": float(self.fine_offsets_share)}
 
 
 class Outputs(C.Structure):
@@ -133,6 +145,16 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_last_executed_flops.restype = C.c_int
     lib.iblnerf_estimate_policy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.iblnerf_estimate_policy.restype = C.c_int
+    lib.iblnerf_decide_route.argtypes = [C.c_void_p, C.c_void_p, FP, FP, C.c_int64, C.c_float, C.c_float, C.POINTER(Route)]
+    lib.iblnerf_decide_route.restype = C.c_int
+    lib.iblnerf_set_route.argtypes = [C.c_void_p, C.POINTER(Route)]
+    lib.iblnerf_set_route.restype = C.c_int
+    lib.iblnerf_get_route.argtypes = [C.c_void_p, C.POINTER(Route)]
+    lib.iblnerf_get_route.restype = C.c_int
+    lib.iblnerf_describe_route.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.iblnerf_describe_route.restype = C.c_int
+    lib.iblnerf_last_slot_units.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.iblnerf_last_slot_units.restype = C.c_int
     lib.iblnerf_set_query_routing.argtypes = [C.c_void_p, C.c_int]
     lib.iblnerf_set_query_routing.restype = C.c_int
     lib.iblnerf_range_flags_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

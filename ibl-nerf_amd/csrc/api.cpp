@@ -42,8 +42,11 @@ constexpr float OFFSET_SELECT_TMIN = 1e-10f;
 constexpr float CHUNK_TMIN = 1e-12f;
 // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
 constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
+// ... with the main ray's prediction a sample costs an estimate OR an evaluation (offsets_on_lists): in MAC terms the lists then always pay; what remains against them are the
+// lists' extra launches and scattered rows.  Fog (everything relevant: share 1.0) stays a whole-batch launch.
+constexpr double OFFSET_PREDICTED_MAX_FRACTION = 0.85;
 constexpr double FINE_SELECT_MAX_FRACTION = 0.6;   // the fine main query: estimate (0.33 of the whole network's time per sample; 0.18 on three products) + share x whole network
-constexpr long SELECT_MIN_RAYS = 1024;        // a launch of fewer rays takes no per-network decision (and, while none is taken, evaluates every sample)
+constexpr long SELECT_MIN_RAYS = 1024;        // iblnerf_decide_route's probe needs at least this many rays: a handful of rays must not fix a checkpoint's route
 constexpr double SELECT_MAX_FRACTION = 0.3;   // above this share of relevant samples (measured on the first launch of a checkpoint) the refinement is not worth its estimate
 constexpr long BWD_CHUNK_POINTS = 262144;   // points per piece of a fused backward: 4 GiB of operand stash (15.2 KiB per point) at most
 // which fast weight streams a precision mode keeps beside the always-present bf16 (hi, lo) stream
@@ -94,10 +97,18 @@ struct iblnerf_ctx {
     bool est_f16 = true;                          // density estimates behind a list refinement in plain f16 (IBLNERF_ROUTE_ESTIMATES_6SLOT: on the f16 + 2 fp6 form) ...
     bool est_checked[2] = {false, false}, est_ok[2] = {false, false};   // ... once the network's first launch has shown that they are good enough (check_estimates)
     bool est_probe = false;                       // (that check's own plain-f16 launch)
+    bool deciding = false;                        // inside iblnerf_decide_route's probe render: the only place a decision of the route is taken
+    bool route_decided = false;                   // iblnerf_route.decided
+    int tripped = 0;                              // the estimate tripwire has fired since the decision (fold_flags): 1 = the estimates moved to f16 + 2 fp6, 2 = the lists went off
+    double coarse_share = -1.0;                   // the probe's relevant share of the coarse grid (sel_on = it is <= SELECT_MAX_FRACTION)
+    bool offsets_estimate_all = false;            // IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL: round 4's offsets (an estimate on every sample of every copy)
+    bool no_rescue = false;                       // IBLNERF_ROUTE_NO_RESCUE
+    int* main_range = nullptr;                    // [ws_rays][2] first / last relevant sample of each ray's main query in the current pass (k_select_points range_out)
+    double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
     int* sel_index = nullptr;                     // [4 * ws_rays * Sc] their flat indices
-    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs; [6] check_estimates' count
+    int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs; [6] check_estimates' count; [8..9] (one double) the list launches' matrix-slot units
     long sel_candidates = 0;                      // ... and how many samples were candidates
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
     // them in fog (a random-init or barely trained network), where estimate + refinement of everything costs more than the precise kernel alone.  Decided ONCE per
@@ -155,13 +166,15 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->p_all_points = (bits & IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS) != 0;
     c->est_f16 = (bits & IBLNERF_ROUTE_ESTIMATES_6SLOT) == 0;
     c->est_whole = (bits & IBLNERF_ROUTE_ESTIMATES_WHOLE) != 0;
+    c->offsets_estimate_all = (bits & IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL) != 0;
+    c->no_rescue = (bits & IBLNERF_ROUTE_NO_RESCUE) != 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 1023) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..1023)");
+    if (bits < 0 || bits > 4095) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..4095)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -235,8 +248,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 1023 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..1023), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 4095 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..4095), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -277,7 +290,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
             return IBLNERF_ERR_NOMEM;
         }
     if (hipMalloc((void**)&c->sel_pts, 4 * R * Sm * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sm * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&c->sel_count, 8 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 8 * sizeof(int)) != hipSuccess) {
+        hipMalloc((void**)&c->sel_count, 12 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 12 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
         return IBLNERF_ERR_NOMEM;
@@ -334,6 +348,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     if (c->sel_pts) (void)hipFree(c->sel_pts);
     if (c->sel_index) (void)hipFree(c->sel_index);
     if (c->sel_count) (void)hipFree(c->sel_count);
+    if (c->main_range) (void)hipFree(c->main_range);
     if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->bwd_stash) (void)hipFree(c->bwd_stash);
     if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -345,6 +360,17 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     if (c->d_map_tab) (void)hipFree(c->d_map_tab);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
+}
+
+// Another network in slot 0 / 1: whatever was measured on the previous one is gone (both upload paths: a training context that uploads every step thus never holds
+// a route, and a checkpoint loaded onto a used context is measured anew — ADVICE r4)
+static void reset_route(iblnerf_ctx* c, int slot) {
+    if (slot >= 2) return;
+    c->route_decided = false;
+    c->tripped = 0;
+    c->sel_decided = false; c->sel_on = true; c->coarse_share = -1.0;
+    c->fsel_fraction = c->xsel_fraction = -1.0;
+    c->est_checked[0] = c->est_checked[1] = c->est_ok[0] = c->est_ok[1] = false;
 }
 
 static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_floats, const char* who) {
@@ -377,9 +403,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[slot], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
     }
     c->have_net[slot] = true;
-    if (slot == 0) { c->sel_decided = false; c->sel_on = true; }
-    if (slot < 2) c->fsel_fraction = c->xsel_fraction = -1.0;
-    if (slot < 2) c->est_checked[slot] = c->est_ok[slot] = false;
+    reset_route(c, slot);
     return IBLNERF_OK;
 }
 
@@ -446,6 +470,7 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
                                    (hipStream_t)stream));
     c->mx_ok[which] = true;
     c->have_net[which] = true;
+    reset_route(c, which);
     return arm_range_snapshot(c, (hipStream_t)stream);
 }
 
@@ -539,18 +564,57 @@ static bool sigma_p_available(const iblnerf_ctx* c, int which) {
            (prec == IBLNERF_MLP_F16X3_MXFP6X || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN);
 }
 
-static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
-                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr,
-                   bool count_flops = true, const int* n_pts_dev = nullptr, const int* out_index = nullptr, double flop_per_point = -1.0) {
-    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
-    MlpArgs a;
+// One MLP launch = a kernel FAMILY (which product scheme, which weight stream) and a VARIANT of it (which layers, whole batch or list).  Every launch of a render
+// call is named by such a pair in the route table (plan_main / plan_offsets / plan_reflected below); run_launch executes one.
+enum KernelFamily { K_NONE = -1, K_BF16X3 = 0, K_F16X3, K_MX, K_MX16 };
+struct Launch {
+    int kern = K_NONE;
+    int variant = 0;
+    bool none() const { return kern == K_NONE; }
+};
+static const char* launch_name(const Launch& l) {
+    static const char* fam[] = {"bf16x3", "f16x3", "mx (f16 + 2 fp6)", "mx16 (plain f16)"};
+    static const char* var[] = {"FULL", "TRUNK", "REFL", "FULL_CI", "REFL_CI", "TRUNK_X (layers 0-1 3 x f16)", "TRUNK_GRAD", "TRUNK_BWD", "TRUNK_FEAT", "TRUNK_BWD_FEAT", "TRUNK_FEAT2",
+                                "TRUNK_BWD_FEAT2", "NET_BWD", "TRUNK_P (15-slot)", "?", "REFL_LIST", "FULL_LIST", "TRUNK_X_LIST", "TRUNK_LIST"};
+    static thread_local char buf[96];
+    if (l.none()) return "-";
+    std::snprintf(buf, sizeof buf, "%s %s", fam[l.kern], (l.variant >= 0 && l.variant <= 18) ? var[l.variant] : "?");
+    return buf;
+}
+// 2 x the nn.Linear MACs per point of a variant (FLOP_* above)
+static double variant_flops(int variant) {
+    if (variant == VAR_TRUNK_GRAD) return 2.0 * FLOP_TRUNK;
+    if (variant == VAR_TRUNK || variant == VAR_TRUNK_P || variant == VAR_TRUNK_X || variant == VAR_TRUNK_X_LIST || variant == VAR_TRUNK_LIST) return FLOP_TRUNK;
+    return (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0);
+}
+// matrix-core slots per 64 MACs of a launch (one slot = one 32x32x16 f16 MFMA's time; an MX-fp6 K = 64 product counts 1): what a point really costs — STATE.md section 2,
+// the quantity that governs speed on a power-bound chip.  TRUNK_X: layers 0-1 on three f16 products, 2-7 on f16 + 2 fp6 (7.5 on average)
+static double launch_slots(const Launch& l) {
+    switch (l.kern) {
+        case K_BF16X3: case K_F16X3: return 12.0;
+        case K_MX16: return 4.0;
+        case K_MX: return l.variant == VAR_TRUNK_P ? 15.0 : variant_trunk_x(l.variant) ? 7.5 : 6.0;
+        default: return 0.0;
+    }
+}
+
+// Are network `which`'s estimates on the plain-f16 estimate kernel (the one that also takes lists)?
+static bool est_plain(const iblnerf_ctx* c, int which) { return which < 2 && c->est_f16 && c->est_checked[which] && c->est_ok[which] && !c->est_probe; }
+// ... in z-chunks / on the offset copies' front and behind ranges (lists): both estimate kernels take them — the plain-f16 one and, for a network whose plain-f16 estimates
+// were refused (probe or tripwire), the f16 + 2 fp6 TRUNK form, so that such a network pays 6 instead of 4 slots per estimate and nothing else (IBLNERF_ROUTE_ESTIMATES_WHOLE: never)
+static bool est_chunks(const iblnerf_ctx* c, int which) { return which < 2 && c->est_checked[which] && !c->est_probe && !c->est_whole; }
+
+// The kernel a query CLASS runs on under the context's mlp_precision and routing bits (include/iblnerf.h: the mode table).  `variant` is the form the caller asks for;
+// the class decides the product scheme (and, for the sample-placing density, the 15-slot form).
+static Launch pick_kernel(const iblnerf_ctx* c, int which, int variant, int qclass, bool generated_points) {
     // a trunk-only query of the sample-placing class (the coarse pass reduced to its density), or of the caller under IBLNERF_ROUTE_USER_TRUNK_P
-    if (variant == VAR_TRUNK && !gen && sigma_p_available(c, which) && (qclass == Q_MAIN_COARSE || (qclass == Q_USER && c->p_user))) variant = VAR_TRUNK_P;
+    if (variant == VAR_TRUNK && !generated_points && sigma_p_available(c, which) && (qclass == Q_MAIN_COARSE || (qclass == Q_USER && c->p_user))) variant = VAR_TRUNK_P;
     if (c->opt.color_independent_to_direction) variant = variant == VAR_FULL ? VAR_FULL_CI : (variant == VAR_REFL ? VAR_REFL_CI : variant);
     // product scheme of this launch (include/iblnerf.h: mlp_precision).  A network with a weight outside the f16 range runs
     // on the bf16x3 kernel whatever the mode.
     const int prec = c->opt.mlp_precision;
-    enum { K_BF16X3, K_F16X3, K_MX, K_MX16, K_MXX, K_MXP } kern = K_BF16X3;   // K_MXX: the fast kernel's TRUNK form with its first two layers as three f16 products; K_MXP: its 15-slot form
+    int kern = K_BF16X3;
+    bool mixed_trunk = false;        // the fast kernel's TRUNK form with its first two layers as three f16 products (VAR_TRUNK_X)
     if (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which]) {
         if (prec == IBLNERF_MLP_F16X3) kern = K_F16X3;
         else if (prec == IBLNERF_MLP_F16X3_MXFP6)
@@ -566,9 +630,10 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             const bool x = (qclass == Q_OFFSET_FINE && !c->x_fine_precise) || (c->x_coarse && qclass == Q_OFFSET_COARSE) || (c->x_user && qclass == Q_USER);
             // ... and the COARSE pass's main query too once its density column comes from the 15-slot form (full_pass): what is left of it are the
             // coarse pass's own albedo / roughness / irradiance / radiance samples, weighted sums like the fine pass's
-            kern = (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise) ||
-                    (qclass == Q_MAIN_COARSE && variant != VAR_TRUNK && variant != VAR_TRUNK_P && sigma_p_available(c, which) && !c->fine_main_precise)) ? K_MX
-                   : (x && variant == VAR_TRUNK) ? K_MXX : K_F16X3;
+            if (qclass == Q_REFL || (qclass == Q_MAIN_FINE && !c->fine_main_precise) ||
+                (qclass == Q_MAIN_COARSE && variant != VAR_TRUNK && variant != VAR_TRUNK_P && sigma_p_available(c, which) && !c->fine_main_precise)) kern = K_MX;
+            else if (x && variant == VAR_TRUNK) { kern = K_MX; mixed_trunk = true; }
+            else kern = K_F16X3;
         } else if (prec == IBLNERF_MLP_F16X3_MAIN)
             // ... and also for the offset queries on the dense fine grid: the normal's worst ray of 1024 goes from 1.9e-4 to
             // 1.5e-3 (99.9th percentile 3e-4); on the coarse grid (spacing 0.12) the same offsets would leave 1e-3 at 96 rays
@@ -581,25 +646,51 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
             !c->opt.use_radiance_linear && !(c->aux_on[IBLNERF_AUX_NORMAL] && c->opt.infer_normal_at_surface))
             kern = K_MX16;
     }
-    if (variant == VAR_TRUNK_P) kern = K_MXP;   // (its callers checked sigma_p_available)
-    if (variant == VAR_TRUNK_X_LIST) kern = K_MX;
-    if (qclass == Q_LIST3) kern = K_F16X3;      // (its callers checked the f16 pair stream: d_stream_f16)
+    if (variant == VAR_TRUNK_P) { kern = K_MX; mixed_trunk = false; }   // (its callers checked sigma_p_available)
+    if (variant == VAR_TRUNK_X_LIST) { kern = K_MX; mixed_trunk = false; }
+    if (qclass == Q_LIST3) { kern = K_F16X3; mixed_trunk = false; }     // (its callers checked the f16 pair stream: d_stream_f16)
     // (likewise; the trunk-only estimates in plain f16: all an estimate has to get right is which side of -1 a raw density lies on)
-    if (qclass == Q_ESTIMATE) kern = (variant == VAR_TRUNK && which < 2 && ((c->est_f16 && c->est_checked[which] && c->est_ok[which]) || c->est_probe)) ? K_MX16 : K_MX;
+    if (qclass == Q_ESTIMATE) { kern = (variant == VAR_TRUNK && which < 2 && ((c->est_f16 && c->est_checked[which] && c->est_ok[which]) || c->est_probe)) ? K_MX16 : K_MX; mixed_trunk = false; }
     // the density-gradient query exists in the three-product kernels only: f16 pairs when the mode keeps that stream, else bf16 pairs
-    if (variant == VAR_TRUNK_GRAD) kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3;
-    a.stream = kern == K_BF16X3 ? c->d_stream[which] : kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
+    if (variant == VAR_TRUNK_GRAD) { kern = (prec != IBLNERF_MLP_BF16X3 && c->mx_ok[which] && c->d_stream_f16[which]) ? K_F16X3 : K_BF16X3; mixed_trunk = false; }
+    Launch l;
+    l.kern = kern;
+    l.variant = mixed_trunk ? VAR_TRUNK_X : variant;
+    return l;
+}
+
+struct MlpCall {
+    const float* pts = nullptr;
+    const float* dirs = nullptr;
+    int pts_per_ray = 1;
+    long n_pts = 0;
+    float* out = nullptr;
+    int out_stride = 1;
+    const PointGen* gen = nullptr;
+    bool count_flops = true;            // this launch's points enter the call's ALGORITHMIC count (every sample of every query, once) ...
+    double flop_per_point = -1.0;       // ... priced as this (an estimate launch standing for the query it belongs to), or as the variant itself (< 0)
+    const int* n_pts_dev = nullptr;     // a list: its length in device memory, n_pts = the bound that sizes the launch
+    const int* out_index = nullptr;
+    float trip_margin = 0.0f;           // a list launched over the estimates that selected it: MlpArgs::trip_margin
+};
+
+static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which, const MlpCall& m) {
+    if (l.none()) return c->fail(IBLNERF_ERR_STATE, "internal: a route table row without a kernel was executed");
+    if (m.n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
+    MlpArgs a;
+    a.stream = l.kern == K_BF16X3 ? c->d_stream[which] : l.kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
     a.range_flag = c->d_range_flag;
     a.tables = c->d_tables[which];
-    a.pts = pts;
-    a.dirs = dirs;
-    a.out = out;
-    a.out_stride = out_stride;
-    a.n_pts = n_pts;
-    a.pts_per_ray = pts_per_ray;
-    if (gen) a.gen = *gen;
-    a.n_pts_dev = n_pts_dev;
-    a.out_index = out_index;
+    a.pts = m.pts;
+    a.dirs = m.dirs;
+    a.out = m.out;
+    a.out_stride = m.out_stride;
+    a.n_pts = m.n_pts;
+    a.pts_per_ray = m.pts_per_ray;
+    if (m.gen) a.gen = *m.gen;
+    a.n_pts_dev = m.n_pts_dev;
+    a.out_index = m.out_index;
+    a.trip_margin = m.trip_margin;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (c->profiling) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -611,16 +702,27 @@ static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const 
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->first, s));
     }
-    HIP_TRY(c, kern == K_MX16 ? launch_mlp_mx16(variant, a, c->n_cu, s) : kern == K_MX ? launch_mlp_mx(variant, a, c->n_cu, s)
-               : kern == K_MXX ? launch_mlp_mx(VAR_TRUNK_X, a, c->n_cu, s) : kern == K_MXP ? launch_mlp_mx(VAR_TRUNK_P, a, c->n_cu, s)
-               : kern == K_F16X3 ? launch_mlp_f16x3(variant, a, c->n_cu, s) : launch_mlp(variant, a, c->n_cu, s));
+    HIP_TRY(c, l.kern == K_MX16 ? launch_mlp_mx16(l.variant, a, c->n_cu, s) : l.kern == K_MX ? launch_mlp_mx(l.variant, a, c->n_cu, s)
+               : l.kern == K_F16X3 ? launch_mlp_f16x3(l.variant, a, c->n_cu, s) : launch_mlp(l.variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
+    // what the launch costs (whole batches here; list launches: k_count_selection adds theirs on the device, sel_count[4..7])
+    const int flop_variant = l.variant == VAR_TRUNK_X ? VAR_TRUNK : l.variant;
+    if (m.n_pts_dev == nullptr) {
+        c->flop_exec += (double)m.n_pts * variant_flops(flop_variant);
+        c->slot_units += (double)m.n_pts * variant_flops(flop_variant) / 128.0 * launch_slots(l);      // (64 MACs = 128 FLOP per slot group)
+    }
     // (algorithmic FLOPs are counted once: the density column re-evaluated on the 15-slot form beside a FULL query adds time, not work)
-    if (n_pts_dev == nullptr)
-        c->flop_exec += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
-    if (count_flops && flop_per_point >= 0.0) c->flop_alg += (double)n_pts * flop_per_point;      // (an estimate launch standing for the query it belongs to)
-    else if (count_flops) c->flop_alg += (double)n_pts * (variant == VAR_TRUNK_GRAD ? 2.0 * FLOP_TRUNK : (variant == VAR_TRUNK || variant == VAR_TRUNK_P) ? FLOP_TRUNK : (variant_albirr(variant) ? FLOP_FULL : FLOP_REFL) - (variant_ci(variant) ? FLOP_FEAT_VIEW : 0.0));
+    if (m.count_flops) c->flop_alg += (double)m.n_pts * (m.flop_per_point >= 0.0 ? m.flop_per_point : variant_flops(flop_variant));
     return IBLNERF_OK;
+}
+
+// (the entry points outside render_rays: the kernel of the query's class, whole batch)
+static int run_mlp(iblnerf_ctx* c, hipStream_t s, int variant, int which, const float* pts, const float* dirs,
+                   int pts_per_ray, long n_pts, float* out, int out_stride = 1, int qclass = Q_USER, const PointGen* gen = nullptr,
+                   bool count_flops = true) {
+    MlpCall m;
+    m.pts = pts; m.dirs = dirs; m.pts_per_ray = pts_per_ray; m.n_pts = n_pts; m.out = out; m.out_stride = out_stride; m.gen = gen; m.count_flops = count_flops;
+    return run_launch(c, s, pick_kernel(c, which, variant, qclass, gen != nullptr), which, m);
 }
 
 int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
@@ -980,7 +1082,18 @@ int iblnerf_sample_pdf_u(iblnerf_ctx* c, void* stream, const float* d_bins, cons
 
 // Folds a snapshot of the flag words into the context: a flagged slot runs on the bf16x3 kernel from now on.
 static int fold_flags(iblnerf_ctx* c, const unsigned* v) {
-    int any = (int)(v[0] & 3u);      // bit 0: an activation / input left the f16 range; bit 1: only a backward's gradients did (mlp_kernel.hip)
+    int any = (int)(v[0] & 15u);      // bit 0: an activation / input left the f16 range; bit 1: only a backward's gradients did (mlp_kernel.hip);
+                                     // bits 2, 3: the estimate tripwire — a list launch refined a positive density whose plain-f16 estimate was half-way to being
+                                     // dropped (2), or overshot beyond what the conservative transmittance allows for (3)
+    if (v[0] & 12u) {
+        // ... plain-f16 estimates: they run on the f16 + 2 fp6 form from now on; f16 + 2 fp6 estimates already (a network whose density cancels beyond THAT form's 2^-16:
+        // tests/test_gpu_fitted.py builds one): no estimate of this network can be trusted — the lists go off, every query evaluates all of its samples.  Either way the
+        // call that raised the flag is to be repeated.
+        const bool were_plain = c->est_f16 && ((c->est_checked[0] && c->est_ok[0]) || (c->est_checked[1] && c->est_ok[1]));
+        c->est_ok[0] = c->est_ok[1] = false;
+        if (!were_plain) { c->sel_decided = true; c->sel_on = false; }
+        c->tripped = were_plain ? 1 : 2;
+    }
     for (int slot = 0; slot < N_SLOTS; ++slot)
         if (v[1 + slot]) { c->mx_ok[slot] = false; any |= 1; }
     return any;
@@ -1086,15 +1199,152 @@ static PassAArgs pass_a_args(iblnerf_ctx* c, const float* ro, const float* rd, l
     return a;
 }
 
-// Are network `which`'s estimates on the plain-f16 estimate kernel (the one that also takes lists)?
-static bool est_plain(const iblnerf_ctx* c, int which) { return which < 2 && c->est_f16 && c->est_checked[which] && c->est_ok[which] && !c->est_probe; }
-static bool est_chunks(const iblnerf_ctx* c, int which) { return est_plain(c, which) && !c->est_whole; }     // ... and in z-chunks (IBLNERF_ROUTE_ESTIMATES_WHOLE: never)
+// ---- the route table ------------------------------------------------------------------------------------------------------------------------------
+// A render pass (one raw2outputs, ibl_nerf_renderer.py:153-527) asks the network three things: the MAIN query at the ray's samples (:201), the four epsilon-OFFSET
+// copies of them for the finite-difference normal (normal_from_depth.py:139-158) and the REFLECTED ray on the coarse grid (:439-446).  "Precision where it matters"
+// also decides WHERE a query is evaluated at all: a sample that is clearly empty (alpha = 0 exactly) or behind saturation carries no weight, so such a query runs
+// as a density ESTIMATE (plain-f16 TRUNK form) on every sample and in its own precision only on the relevant ones (a list form of the query's kernel; the other rows
+// are zero / keep their estimate).  How each of the three is evaluated is ONE row of this table — a pure function of the context's mode, routing bits and
+// the checkpoint's route (iblnerf_route: decided once, by measurement, outside any render call) — which plan_* computes, iblnerf_describe_route prints and full_pass executes.
+enum PassKind { PASS_COARSE = 0 /* its weights place the fine samples */, PASS_FINE = 1, PASS_SINGLE = 2 /* N_importance = 0: the coarse grid is the only pass */ };
+
+struct QueryPlan {
+    bool run = true;                 // false: the query does not exist under these options (e.g. ground-truth normals: no offset copies)
+    bool list = false;               // estimate everywhere + the query's kernel on the list of relevant samples; false: `whole` on every sample
+    bool open = false;               // iblnerf_decide_route's probe only: this query's list decision is still open — measured on this launch, kept iff share <= share_max
+    double share_max = 1.0;
+    Launch est;                      // the density estimate
+    int cut0 = 0, cut1 = 0;          // ... in z-chunks [0, cut0) | [cut0, cut1) | [cut1, S), the later ones only for rays not yet saturated (0, 0: every sample at once)
+    bool predicted = false;          // offset copies: the main ray's relevant range goes to the list without an estimate, estimates on the rest only (offsets_on_lists)
+    float t_min = COARSE_SELECT_TMIN;
+    Launch on_list;                  // the relevant samples
+    Launch density_list;             // coarse main query: its density once more on the 15-slot form, same list
+    Launch whole;                    // every sample (list == false, or the probe decided against the list)
+    Launch density;                  // coarse main query, whole batch: the 15-slot density column ...
+    bool density_on_list = false;    // ... on the samples its own density selects
+    bool point_batch = false;        // offset copies: points through the [4][R][S][3] batch (tilted rays, IBLNERF_ROUTE_POINT_BATCH), else generated in the kernel
+    bool gradient = false;           // the two autograd normal modes: density + position gradient at the main points instead of offset copies
+};
+
+static bool lists_possible(const iblnerf_ctx* c, int which, bool keep_all_rows) {
+    const bool can_decide = c->deciding && !keep_all_rows;
+    return sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (c->sel_decided ? c->sel_on : can_decide);
+}
+
+static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, bool keep_all_rows) {
+    QueryPlan q;
+    const bool can_decide = c->deciding && !keep_all_rows;
+    const bool list_ok = lists_possible(c, which, keep_all_rows);
+    const int prec = c->opt.mlp_precision;
+    // (the fast table's main queries on the fast kernel's list form; the safe table's — IBLNERF_ROUTE_FINE_MAIN_PRECISE, or the F16X3_MXFP6 mode — on the three-product one)
+    const bool fast = prec == IBLNERF_MLP_F16X3_MXFP6X && !c->fine_main_precise;
+    const bool three = (prec == IBLNERF_MLP_F16X3_MXFP6X || prec == IBLNERF_MLP_F16X3_MXFP6) && !fast && c->d_stream_f16[which] != nullptr;
+    q.whole = pick_kernel(c, which, VAR_FULL, kind == PASS_COARSE ? Q_MAIN_COARSE : Q_MAIN_FINE, false);
+    q.est = pick_kernel(c, which, VAR_TRUNK, Q_ESTIMATE, false);
+    if (kind == PASS_COARSE && sigma_p_available(c, which)) {
+        // the density column once more on the 15-slot form (three f16 + three fp6 products per block: operands to ~2^-26).  Two f16 terms
+        // hold 22-23 bits of an fp32 weight / activation; through a fitted network's cancelling density sum that alone moves the fine samples of
+        // some rays by more than the reference's own arithmetic does (launch scale 7).  The column overwrites raw[..., 0] as an
+        // auxiliary network's output would; weights, depth and the fine samples are composited from it.  Only the RELEVANT samples need it.
+        q.density.kern = K_MX; q.density.variant = VAR_TRUNK_P;
+        q.density_on_list = !(c->p_all_points || (c->sel_decided ? !c->sel_on : !can_decide));
+    }
+    if (kind == PASS_COARSE && list_ok && !keep_all_rows && (fast || three)) {
+        // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
+        // (not in z-chunks: this query's weights place the fine samples, and sample_pdf's thresholds see the last bit of their sum — a weight of 1e-12 behind saturation
+        // set to exactly zero moved z_std of one ray of a frame by 5e-5)
+        q.list = true; q.open = !c->sel_decided; q.share_max = SELECT_MAX_FRACTION;
+        q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
+        q.density_list.kern = K_MX; q.density_list.variant = VAR_TRUNK_P;
+    }
+    if (kind == PASS_FINE && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 ? can_decide : c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
+        (fast || three)) {
+        // the FINE main query likewise: the importance samples crowd around the surface, so about 40 % of them are relevant (against 6-8 % on the coarse
+        // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION.
+        // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
+        q.list = true; q.open = c->fsel_fraction < 0.0; q.share_max = FINE_SELECT_MAX_FRACTION;
+        q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
+        if (est_chunks(c, which)) { q.cut0 = (3 * S) / 4; q.cut1 = (7 * S) / 8; }
+    }
+    return q;
+}
+
+static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, bool keep_all_rows, bool main_listed, bool gt_normal) {
+    QueryPlan q;
+    const bool coarse_grid = kind != PASS_FINE;
+    const int qclass = coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE;
+    const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
+    q.t_min = OFFSET_SELECT_TMIN;
+    if (c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT || c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION) {
+        q.gradient = true;
+        q.whole = pick_kernel(c, which, VAR_TRUNK_GRAD, qclass, false);
+        return q;
+    }
+    if (gt_normal || c->opt.normal_mode == IBLNERF_NORMAL_INFERRED) { q.run = false; return q; }
+    if (tilt || !c->fuse_points) {
+        q.point_batch = true;
+        q.whole = pick_kernel(c, which, VAR_TRUNK, qclass, false);
+        return q;
+    }
+    const bool can_decide = c->deciding && !keep_all_rows;
+    const bool list_ok = lists_possible(c, which, keep_all_rows);
+    const int prec = c->opt.mlp_precision;
+    q.whole = pick_kernel(c, which, VAR_TRUNK, qclass, true);
+    q.est = pick_kernel(c, which, VAR_TRUNK, Q_ESTIMATE, true);
+    // (the fine grid's offset copies: the fast table's on the mixed trunk form's list, the safe table's on the three-product trunk form's)
+    const bool fine_x_fast = prec == IBLNERF_MLP_F16X3_MXFP6X && !c->x_fine_precise;
+    const bool fine_x_3 = (prec == IBLNERF_MLP_F16X3_MXFP6X || prec == IBLNERF_MLP_F16X3_MXFP6) && !fine_x_fast && c->d_stream_f16[which] != nullptr;
+    const bool could_predict = main_listed && est_chunks(c, which) && !c->offsets_estimate_all;
+    if (coarse_grid && S == c->Sc && sigma_p_available(c, which) && !c->p_all_points && !c->x_coarse && c->sel_decided && c->sel_on) {
+        // The coarse grid's offsets need all eight layers at 2^-22 (DESIGN 4.0 ladder) — on the samples that can reach a weight: the relevant ones (neither clearly
+        // empty nor behind saturation, per offset copy: ~6 % on a scene with surfaces) on the three-product f16 kernel where the mode keeps its stream — what the
+        // whole-batch launch runs; 2 MB of weights against the 15-slot form's 3.9 MB, which sits at the edge of an XCD's 4 MB L2 — scattered over the estimates.
+        // The others composite to the same weights bit for bit (alpha = 0) or to within 1e-10 of a weight (the saturated tail).
+        q.list = true;
+        if (c->d_stream_f16[which] != nullptr && c->mx_ok[which]) q.on_list = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
+        else { q.on_list.kern = K_MX; q.on_list.variant = VAR_TRUNK_P; }
+        if (est_chunks(c, which)) { q.cut0 = S / 2; q.cut1 = (3 * S) / 4; }
+        q.predicted = could_predict;
+    } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (fine_x_fast || fine_x_3)) {
+        // The offsets on the fine grid (768 densities per ray, more than half of a frame): the mixed trunk form (TRUNK_X; safe table: three f16 products) on the
+        // relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  With an estimate on every sample (0.53 of a TRUNK_X
+        // evaluation) this pays below a relevant share of FINE_OFFSET_SELECT_MAX_FRACTION; with the main ray's prediction (estimates only where the main ray
+        // found nothing: each sample costs an estimate OR an evaluation, a few per cent both) up to OFFSET_PREDICTED_MAX_FRACTION — above that the lists' launches
+        // and scattered rows cost more than they save.
+        const double share_max = could_predict ? OFFSET_PREDICTED_MAX_FRACTION : (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3);
+        if (c->xsel_fraction < 0.0 ? can_decide : c->xsel_fraction <= share_max) {
+            q.list = true; q.open = c->xsel_fraction < 0.0; q.share_max = share_max;
+            if (fine_x_fast) { q.on_list.kern = K_MX; q.on_list.variant = VAR_TRUNK_X_LIST; }
+            else q.on_list = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
+            if (est_chunks(c, which)) { q.cut0 = (3 * S) / 4; q.cut1 = (7 * S) / 8; }
+            q.predicted = could_predict;
+        }
+    }
+    return q;
+}
+
+static QueryPlan plan_reflected(const iblnerf_ctx* c, int which, bool keep_all_rows) {
+    QueryPlan q;
+    const int Sc = c->Sc;
+    q.whole = pick_kernel(c, which, VAR_REFL, Q_REFL, false);
+    q.est = pick_kernel(c, which, VAR_TRUNK, Q_ESTIMATE, false);
+    if (lists_possible(c, which, keep_all_rows) && c->sel_decided && c->sel_on) {
+        // the reflected ray leaves its surface into empty space and ends on the next one: a density estimate everywhere (fast TRUNK form; the same trunk
+        // arithmetic the REFL form runs), the view layers and the twelve radiance channels on the relevant samples only, zero rows elsewhere (weight 0, or < 1e-8)
+        q.list = true;
+        q.on_list = pick_kernel(c, which, VAR_REFL_LIST, Q_ESTIMATE, false);
+        if (est_chunks(c, which)) { q.cut0 = Sc / 2; q.cut1 = (3 * Sc) / 4; }
+    }
+    return q;
+}
+
+static double list_slots(const Launch& l) { return l.none() ? 0.0 : variant_flops(l.variant) / 128.0 * launch_slots(l); }
 
 // A density estimate of the S samples of nv = (offsets ? 4 R : R) (virtual) rays in up to THREE z-chunks: samples [0, cut0) of every ray, then [cut0, cut1) and
 // [cut1, S) only of the rays whose transmittance behind the samples in front of the chunk — composited conservatively from those estimates — is not yet below t_min (CHUNK_TMIN); the other rays'
 // later samples get -1e30 (k_select_points would not select them either: its transmittance only falls, and its thresholds are higher).  On the coarse grid half of the rays saturate in
 // the first half of the grid, on the fine grid a quarter to a half of them before its last quarter (scratch/saturation_depth.py).  Rows land in c->sig4 [nv, S].
-static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, const float* z, int z_stride, int S, long R, bool offsets,
+static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, const Launch& est, int which, const float* ro, const float* rd, const float* z, int z_stride, int S, long R, bool offsets,
                             float eps, const float* noise, int cut0, int cut1, float t_min, double flop_alg_per_point) {
     const long nv = offsets ? 4 * R : R;
     const int cuts[4] = {0, cut0, cut1, S};          // chunks [0, cut0) of every ray, then [cut0, cut1) and [cut1, S) of the rays still alive at their start
@@ -1104,16 +1354,18 @@ static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, int which, const floa
         const bool first = k == 0;
         if (!first) HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, s0, s1, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
-                                       first, FLOP_TRUNK));
-        const int rc = run_mlp(c, s, VAR_TRUNK, which, c->sel_pts, nullptr, S, nv * (s1 - s0), c->sig4, 1, Q_ESTIMATE, nullptr, false, first ? nullptr : c->sel_count, c->sel_index);
-        if (rc) return rc;
+                                       first, FLOP_TRUNK, list_slots(est)));
+        MlpCall m;
+        m.pts = c->sel_pts; m.pts_per_ray = S; m.n_pts = nv * (s1 - s0); m.out = c->sig4; m.count_flops = false; m.n_pts_dev = first ? nullptr : c->sel_count; m.out_index = c->sel_index;
+        if (int rc = run_launch(c, s, est, which, m)) return rc;
     }
     c->flop_alg += (double)nv * S * flop_alg_per_point;      // (the query's algorithmic FLOPs: every sample, once)
     return IBLNERF_OK;
 }
 
-// Once per uploaded network: may its density estimates run in plain f16?  Both estimates of the launch's main-query samples (c->pts), compared by
+// Once per route decision: may this network's density estimates run in plain f16?  Both estimates of the probe's main-query samples (c->pts), compared by
 // k_compare_estimates; one stream synchronisation.  A network whose plain-f16 trunk is ever half-way to a wrong selection keeps the f16 + 2 fp6 estimates.
+// (Every later list launch repeats the comparison on the samples it refines — the tripwire, MlpArgs::trip_margin.)
 static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts, int S) {
     c->est_checked[which] = true;
     c->est_ok[which] = false;
@@ -1132,127 +1384,240 @@ static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts,
     return IBLNERF_OK;
 }
 
-// One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
-// zc / zc_stride: z_vals_constant, the coarse grid the reflected ray is sampled on (one shared row, or per-ray rows under perturb);
-// coarse_grid: this pass's own samples are that grid.
-static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, const float* rd, long R, const float* z,
-                     int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
-                     const PassOutputs& out, bool places_samples, const float* zc, int zc_stride, bool coarse_grid, const float* noise,
-                     float* env_tap = nullptr, const float* near_ray = nullptr, const float* far_ray = nullptr, bool keep_all_rows = false) {
-    const int Sc = c->Sc;
-    // "precision where it matters" also decides WHERE a query is evaluated at all: a sample that is clearly empty (alpha = 0 exactly) or behind saturation carries
-    // no weight, so its 17 other channels (coarse main query) / its 12 radiance channels (reflected query) are never read with a non-zero factor.  Such a query runs as a
-    // density ESTIMATE on the plain-f16 TRUNK form over all samples, and in its own precision only on the relevant ones (the list variants); the other
-    // rows are zero.  The offset copies likewise: estimates everywhere, the query's kernel on each copy's relevant samples.
-    // (the per-network decisions — is this a scene with empty space, are plain-f16 estimates good enough, how many fine samples are relevant — are taken on a launch of at
-    // least SELECT_MIN_RAYS rays; until one has come by, smaller launches evaluate every sample: a handful of rays must not fix a checkpoint's route)
-    // ... and never inside a tapped call (a training step's forward: its weights are uploaded anew every step, so every step would decide again — with a stream
-    // synchronisation each — for a route it then may not even take)
-    const bool can_decide = R >= SELECT_MIN_RAYS && !keep_all_rows;
-    const bool list_ok = sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (c->sel_decided ? c->sel_on : can_decide);
-    // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
-    HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
-    if (list_ok && can_decide && c->est_f16 && which < 2 && !c->est_checked[which])
-        if (int rc0 = check_estimates(c, s, which, R * S, S)) return rc0;
-    // the coarse pass's main query places the fine samples (and through them the normal): it keeps the full product scheme
-    int rc = IBLNERF_OK;
-    bool main_done = false, est_counted = false;
-    const int prec_mode = c->opt.mlp_precision;
-    // (the fast table's main queries on the fast kernel's list form; the safe table's — IBLNERF_ROUTE_FINE_MAIN_PRECISE, or the F16X3_MXFP6 mode — on the three-product one)
-    const bool fine_main_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->fine_main_precise;
-    const bool fine_main_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_main_fast && c->d_stream_f16[which] != nullptr;
-    if (places_samples && list_ok && !keep_all_rows && (fine_main_fast || fine_main_3)) {
-        // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
-        // (not in z-chunks: this query's weights place the fine samples, and sample_pdf's thresholds see the last bit of their sum — a weight of 1e-12 behind saturation
-        // set to exactly zero moved z_std of one ray of a frame by 5e-5)
-        rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
+// (iblnerf_decide_route's probe: the length of the list k_select_points has just written)
+static int read_list_length(iblnerf_ctx* c, hipStream_t s, long* n) {
+    int v = 0;
+    HIP_TRY(c, hipMemcpyAsync(&v, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *n = v;
+    return IBLNERF_OK;
+}
+
+struct PassRays {                 // the rays of one pass of one launch
+    const float* ro; const float* rd; long R;
+    const float* z; int z_stride; int S;
+    const float* noise;
+};
+
+// The MAIN query of a pass into c->raw [R, S, 18].  *main_listed: c->main_range holds every ray's first / last relevant sample (a selection ran and the lists are on).
+static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, const PassRays& p, bool keep_all_rows, bool* main_listed) {
+    const long R = p.R, n = p.R * p.S;
+    const int S = p.S;
+    *main_listed = false;
+    QueryPlan q = plan_main(c, which, kind, S, keep_all_rows);
+    bool est_counted = false;
+    int rc;
+    if (q.list) {
+        if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, false, 0.f, p.noise, q.cut0, q.cut1, CHUNK_TMIN, FLOP_FULL);
+        else {
+            MlpCall m;
+            m.pts = c->pts; m.pts_per_ray = S; m.n_pts = n; m.out = c->sig4; m.flop_per_point = FLOP_FULL;
+            rc = run_launch(c, s, q.est, which, m);
+        }
         if (rc) return rc;
         est_counted = true;     // (the query's algorithmic FLOPs are counted once, on its estimate)
-        HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)R * S * RAW_CH * sizeof(float), s));
+        HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)n * RAW_CH * sizeof(float), s));
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        c->sel_candidates += R * S;
-        HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
-                                        false, 0.f, c->raw, RAW_CH, FLOP_FULL + FLOP_TRUNK));
-        if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
-            int n_sel = 0;
-            HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            c->sel_decided = true;
-            c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * S);
+        c->sel_candidates += n;
+        HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
+                                        false, 0.f, c->raw, RAW_CH, variant_flops(q.on_list.variant) + (q.density_list.none() ? 0.0 : FLOP_TRUNK), c->main_range, nullptr,
+                                        list_slots(q.on_list) + list_slots(q.density_list)));
+        if (q.open) {     // the probe: does this network have empty space and surfaces, or is it fog?  / how many of the fine samples are relevant?
+            long n_sel = 0;
+            if ((rc = read_list_length(c, s, &n_sel))) return rc;
+            const double share = (double)n_sel / (double)n;
+            if (kind == PASS_COARSE) { c->sel_decided = true; c->sel_on = share <= q.share_max; c->coarse_share = share; }
+            else c->fsel_fraction = share;
+            q.list = share <= q.share_max;
         }
-        if (c->sel_on) {
-            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, fine_main_fast ? Q_ESTIMATE : Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
-            if (rc) return rc;
-            rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
-            if (rc) return rc;
-            main_done = true;
-        }
-    }
-    if (!places_samples && !coarse_grid && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 ? can_decide : c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
-        (fine_main_fast || fine_main_3)) {
-        // the FINE main query likewise: the importance samples crowd around the surface, so about 40 % of them are relevant (against 6-8 % on the coarse
-        // grid) — still less than the whole network everywhere, as long as the share stays below FINE_SELECT_MAX_FRACTION (decided on the first launch, like sel_on).
-        // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
-        if (est_chunks(c, which) && c->fsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, false, 0.f, noise, (3 * S) / 4, (7 * S) / 8, CHUNK_TMIN, FLOP_FULL);
-        else rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, R * S, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_FULL);
-        if (rc) return rc;
-        est_counted = true;
-        HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)R * S * RAW_CH * sizeof(float), s));
-        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        c->sel_candidates += R * S;
-        HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
-                                        false, 0.f, c->raw, RAW_CH, FLOP_FULL));
-        if (c->fsel_fraction < 0.0) {
-            int n_sel = 0;
-            HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-            c->fsel_fraction = (double)n_sel / (double)(R * S);
-        }
-        if (c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) {
-            rc = run_mlp(c, s, VAR_FULL_LIST, which, c->sel_pts, rd, S, R * S, c->raw, 1, fine_main_fast ? Q_ESTIMATE : Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
-            if (rc) return rc;
-            main_done = true;
-        }
-    }
-    if (!main_done) {
-    rc = run_mlp(c, s, VAR_FULL, which, c->pts, rd, S, R * S, c->raw, 1, places_samples ? Q_MAIN_COARSE : Q_MAIN_FINE, nullptr, !est_counted);
-    if (rc) return rc;
-    // ... and its density column once more on the 15-slot form (three f16 + three fp6 products per block: operands to ~2^-26).  Two f16 terms
-    // hold 22-23 bits of an fp32 weight / activation; through a fitted network's cancelling density sum that alone moves the fine samples of
-    // some rays by more than the reference's own arithmetic does (launch scale 7).  The column overwrites raw[..., 0] as an
-    // auxiliary network's output would; weights, depth and the fine samples are composited from it.
-    // Only the RELEVANT samples need it: a sample whose density estimate (the main query's own, error < 1e-2) is below -1 has alpha = 0 exactly whatever
-    // the estimate's last bits are, and a sample behind a transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest (on a
-    // scene with surfaces: the few samples around each ray's first surface, ~5 %) is compacted, evaluated and scattered over the estimates (k_select_points).
-    if (places_samples && sigma_p_available(c, which)) {
-        if (c->p_all_points || !c->sel_on || (!c->sel_decided && !can_decide)) {
-            rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
-        } else {
-            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            c->sel_candidates += R * S;
-            HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->raw, RAW_CH, noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                            c->sel_count, s, false, 0.f, nullptr, 0, FLOP_TRUNK));
-            if (!c->sel_decided) {     // once per checkpoint: does this network have empty space and surfaces, or is it fog?
-                int n_sel = 0;
-                HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                c->sel_decided = true;
-                c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * S);
+        if (q.list) {
+            MlpCall m;
+            m.pts = c->sel_pts; m.dirs = p.rd; m.pts_per_ray = S; m.n_pts = n; m.out = c->raw; m.count_flops = false; m.n_pts_dev = c->sel_count; m.out_index = c->sel_index;
+            m.trip_margin = COARSE_SELECT_MARGIN;
+            if ((rc = run_launch(c, s, q.on_list, which, m))) return rc;
+            if (!q.density_list.none()) {
+                m.dirs = nullptr; m.out_stride = RAW_CH; m.trip_margin = 0.0f;
+                if ((rc = run_launch(c, s, q.density_list, which, m))) return rc;
             }
-            if (c->sel_on) rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
-            else rc = run_mlp(c, s, VAR_TRUNK_P, which, c->pts, nullptr, S, R * S, c->raw, RAW_CH, Q_MAIN_COARSE, nullptr, false);
+            *main_listed = true;
+            return IBLNERF_OK;
         }
-        if (rc) return rc;
+        q = plan_main(c, which, kind, S, keep_all_rows);      // (the probe decided against the list: the whole-batch row, under the decision just taken)
     }
-    }   // !main_done
+    {
+        MlpCall m;
+        m.pts = c->pts; m.dirs = p.rd; m.pts_per_ray = S; m.n_pts = n; m.out = c->raw; m.count_flops = !est_counted;
+        if ((rc = run_launch(c, s, q.whole, which, m))) return rc;
+    }
+    if (!q.density.none()) {
+        MlpCall m;
+        m.pts_per_ray = S; m.n_pts = n; m.out = c->raw; m.out_stride = RAW_CH; m.count_flops = false;
+        bool on_list = q.density_on_list;
+        if (on_list) {
+            // a sample whose density (the main query's own, error < 1e-2) is below -margin has alpha = 0 exactly whatever its last bits are, and a sample behind a
+            // transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest is compacted, evaluated and scattered over raw[..., 0].
+            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+            c->sel_candidates += n;
+            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->raw, RAW_CH, p.noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+                                            c->sel_count, s, false, 0.f, nullptr, 0, FLOP_TRUNK, c->main_range, nullptr, list_slots(q.density)));
+            if (!c->sel_decided) {     // (the probe, in a mode whose main query takes no list)
+                long n_sel = 0;
+                if ((rc = read_list_length(c, s, &n_sel))) return rc;
+                c->sel_decided = true;
+                c->coarse_share = (double)n_sel / (double)n;
+                c->sel_on = c->coarse_share <= SELECT_MAX_FRACTION;
+                on_list = c->sel_on;
+            }
+        }
+        if (on_list) { m.pts = c->sel_pts; m.n_pts_dev = c->sel_count; m.out_index = c->sel_index; *main_listed = true; }
+        else m.pts = c->pts;
+        if ((rc = run_launch(c, s, q.density, which, m))) return rc;
+    }
+    return IBLNERF_OK;
+}
+
+// The four epsilon-offset copies of a pass's samples on lists (into c->sig4 [4, R, S]): estimate + own selection + the query's kernel on the relevant ones.
+// q.predicted (round 5): a copy lies 0.01 beside its ray, so the samples the MAIN ray found relevant (first to last selected, one more on either side: c->main_range)
+// are almost exactly the copy's relevant ones (measured: 0.377 / 0.378 of the fine grid's samples, scratch/offset_candidates.py) — they go to the query's kernel
+// WITHOUT an estimate (k_range_points mode 1); estimates run on the rest only: in front of the range for every copy (mode 2), behind it for the copies that have not
+// saturated by then (mode 3; the others' get -1e30 as in estimate_chunked: 0.1-1 % of the copies, a silhouette between a ray and its copy), and the copy's OWN
+// selection among those (k_select_points with skip_range) sends what the prediction missed to the kernel too.  So every sample is still either evaluated by the
+// query's kernel or judged irrelevant on an estimate of ITS OWN: the main ray predicts cost, never a result (a rule that let the main ray's estimates stand in for the
+// copies' was measured and rejected: it misses relevant samples with weights up to 0.9, STATE.md).  Estimates per ray: 1 024 -> ~400.
+static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const QueryPlan& q, const PassRays& p, float eps, const PointGen& g, double* share) {
+    const long R = p.R, n4 = 4 * p.R * p.S;
+    const int S = p.S;
+    int rc;
+    MlpCall refine;
+    refine.pts = c->sel_pts; refine.pts_per_ray = S; refine.n_pts = n4; refine.out = c->sig4; refine.count_flops = false; refine.n_pts_dev = c->sel_count; refine.out_index = c->sel_index;
+    c->sel_candidates += n4;
+    unsigned long long entries_before = 0;
+    if (share) {      // (the probe: the call's running total of list entries so far, sel_count[2..3])
+        HIP_TRY(c, hipMemcpyAsync(&entries_before, c->sel_count + 2, sizeof entries_before, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (q.predicted) {
+        MlpCall est = refine;
+        // 1: the predicted range, straight to the query's kernel (no estimate underneath: no tripwire)
+        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, COARSE_SELECT_MARGIN, CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
+                                       FLOP_TRUNK, list_slots(q.on_list), true));
+        if ((rc = run_launch(c, s, q.on_list, which, refine))) return rc;
+        // 2, 3: estimates in front of it, and behind it where a copy is still alive
+        for (int mode = 2; mode <= 3; ++mode) {
+            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, COARSE_SELECT_MARGIN, CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count,
+                                           s, FLOP_TRUNK, list_slots(q.est), false));
+            if ((rc = run_launch(c, s, q.est, which, est))) return rc;
+        }
+        c->flop_alg += (double)n4 * FLOP_TRUNK;
+    } else if (q.cut1 > 0) {
+        if ((rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, true, eps, nullptr, q.cut0, q.cut1, CHUNK_TMIN, FLOP_TRUNK))) return rc;
+    } else {
+        MlpCall m;
+        m.pts_per_ray = S; m.n_pts = n4; m.out = c->sig4; m.gen = &g;
+        if ((rc = run_launch(c, s, q.est, which, m))) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+    HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index, c->sel_count, s, true, eps,
+                                    nullptr, 0, FLOP_TRUNK, nullptr, q.predicted ? c->main_range : nullptr, list_slots(q.on_list)));
+    if (share) {      // the probe: (predicted +) selected share of the 4 R S samples
+        unsigned long long now = 0;
+        HIP_TRY(c, hipMemcpyAsync(&now, c->sel_count + 2, sizeof now, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        *share = (double)(now - entries_before) / (double)n4;
+        if (*share > q.share_max) return IBLNERF_OK;      // (the caller runs the whole batch instead)
+    }
+    refine.trip_margin = COARSE_SELECT_MARGIN;
+    return run_launch(c, s, q.on_list, which, refine);
+}
+
+// The offset copies of a pass (or the density-gradient rows of the autograd normal modes) into c->sig4.
+static int run_offset_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, const PassRays& p, bool keep_all_rows, bool main_listed, bool gt_normal) {
+    const long R = p.R;
+    const int S = p.S;
+    const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
+    const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
+    QueryPlan q = plan_offsets(c, which, kind, S, keep_all_rows, main_listed, gt_normal);
+    if (!q.run) return IBLNERF_OK;
+    MlpCall m;
+    m.pts_per_ray = S;
+    if (q.gradient) {
+        // the autograd normal modes (normal_from_depth.py:16-52, :102-137): density and its position gradient at the main query's own
+        // points (c->pts still holds them), rows [sigma, d sigma / d x, y, z]; pass A applies the chain rule through the compositing
+        m.pts = c->pts; m.n_pts = R * S; m.out = c->sig4; m.out_stride = 4;
+        return run_launch(c, s, q.whole, which, m);
+    }
+    m.n_pts = 4 * R * S; m.out = c->sig4;
+    if (q.point_batch) {
+        HIP_TRY(c, launch_make_points(tilt ? 2 : 1, p.ro, p.rd, p.z, p.z_stride, eps, R, S, c->pts, s));
+        m.pts = c->pts;
+        return run_launch(c, s, q.whole, which, m);
+    }
+    // the four offset copies are generated in the MLP kernel's input stage: no [4][R][S][3] batch (9.2 KB per ray on the fine grid)
+    PointGen g;
+    g.rays_o = p.ro; g.rays_d = p.rd; g.z = p.z; g.z_stride = p.z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+    m.gen = &g;
+    if (q.list) {
+        double share = 0.0;
+        if (int rc = offsets_on_lists(c, s, which, q, p, eps, g, q.open ? &share : nullptr)) return rc;
+        if (!q.open) return IBLNERF_OK;
+        c->xsel_fraction = share;
+        if (share <= q.share_max) return IBLNERF_OK;
+        m.count_flops = false;                               // (counted with the estimates)
+    }
+    return run_launch(c, s, q.whole, which, m);
+}
+
+// The reflected ray of a pass on the coarse grid (:439-446) into c->refl_raw [R, Sc, 13]; c->pts holds its points.
+static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R, const float* zc, int zc_stride, bool keep_all_rows) {
+    const int Sc = c->Sc;
+    const QueryPlan q = plan_reflected(c, which, keep_all_rows);
+    MlpCall m;
+    m.pts_per_ray = Sc; m.n_pts = R * Sc;
+    if (!q.list) {
+        m.pts = c->pts; m.dirs = c->refl_d; m.out = c->refl_raw;
+        return run_launch(c, s, q.whole, which, m);
+    }
+    int rc;
+    if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, q.cut0, q.cut1, CHUNK_TMIN, FLOP_REFL);
+    else {
+        m.pts = c->pts; m.out = c->sig4; m.flop_per_point = FLOP_REFL;
+        rc = run_launch(c, s, q.est, which, m);
+    }
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->refl_raw, 0, (size_t)R * Sc * REFL_CH * sizeof(float), s));
+    HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+    c->sel_candidates += R * Sc;
+    HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index,
+                                    c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL, nullptr, nullptr, list_slots(q.on_list)));
+    MlpCall l;
+    l.pts = c->sel_pts; l.dirs = c->refl_d; l.pts_per_ray = Sc; l.n_pts = R * Sc; l.out = c->refl_raw; l.count_flops = false; l.n_pts_dev = c->sel_count; l.out_index = c->sel_index;
+    l.trip_margin = COARSE_SELECT_MARGIN;
+    return run_launch(c, s, q.on_list, which, l);
+}
+
+// One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
+// zc / zc_stride: z_vals_constant, the coarse grid the reflected ray is sampled on (one shared row, or per-ray rows under perturb).
+// keep_all_rows: a tapped call (a training step's forward: the backward reads every raw row) — its main queries evaluate every sample.
+static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, int kind, const float* ro, const float* rd, long R, const float* z,
+                     int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
+                     const PassOutputs& out, const float* zc, int zc_stride, const float* noise,
+                     float* env_tap = nullptr, const float* near_ray = nullptr, const float* far_ray = nullptr, bool keep_all_rows = false) {
+    const PassRays p{ro, rd, R, z, z_stride, S, noise};
+    int rc;
+    // main query: pts = o + d z, view direction = rays_d (not the normalised viewdirs, :201)
+    HIP_TRY(c, launch_make_points(0, ro, rd, z, z_stride, 0.f, R, S, c->pts, s));
+    // (the probe of iblnerf_decide_route: first of all, are this network's plain-f16 estimates good enough?)
+    if (c->deciding && !keep_all_rows && lists_possible(c, which, keep_all_rows) && c->est_f16 && which < 2 && !c->est_checked[which])
+        if ((rc = check_estimates(c, s, which, R * S, S))) return rc;
+    bool main_listed = false;
+    if ((rc = run_main_query(c, s, which, kind, p, keep_all_rows, &main_listed))) return rc;
     // auxiliary PositionMLPs (:291-303): same points, trunk-shaped network, out_linears row as the head; each output
     // channel overwrites its column of the raw rows, so compositing and everything after it are unchanged
-    for (int kind = 0; kind < 3; ++kind)
-        for (int ch = 0; c->aux_on[kind] && ch < AUX_CHANNELS[kind]; ++ch) {
-            rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[kind] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[kind] + ch, RAW_CH, Q_AUX);
-            if (rc) return rc;
-        }
-    const bool inferred = c->opt.normal_mode == IBLNERF_NORMAL_INFERRED;
+    for (int k = 0; k < 3; ++k)
+        for (int ch = 0; c->aux_on[k] && ch < AUX_CHANNELS[k]; ++ch)
+            if ((rc = run_mlp(c, s, VAR_TRUNK, AUX_SLOT0[k] + ch, c->pts, nullptr, S, R * S, c->raw + AUX_RAW_COLUMN[k] + ch, RAW_CH, Q_AUX))) return rc;
     const bool at_surface = c->opt.infer_normal_at_surface != 0;
     if (c->aux_on[IBLNERF_AUX_NORMAL] && at_surface)      // one point per ray: x_surface (:262, :268-271); refl_o is free until pass A
         HIP_TRY(c, launch_surface_points(ro, rd, z, z_stride, c->raw, noise, R, S, ov, c->refl_o, s));
@@ -1263,101 +1628,58 @@ static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, const float* ro, 
     }
     // finite-difference normal: 4 offset copies of the samples (normal_from_depth.py:139-158) or 4 rays with tilted directions
     // (:55-75), trunk only; none in the ground-truth normal mode
-    const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
-    const float eps = tilt ? c->opt.epsilon_direction : c->opt.epsilon;
-    const bool by_gradient = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT || c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION;
-    if (by_gradient) {
-        // the autograd normal modes (normal_from_depth.py:16-52, :102-137): density and its position gradient at the main query's own
-        // points (c->pts still holds them), rows [sigma, d sigma / d x, y, z]; pass A applies the chain rule through the compositing
-        rc = run_mlp(c, s, VAR_TRUNK_GRAD, which, c->pts, nullptr, S, R * S, c->sig4, 4, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
-        if (rc) return rc;
-    } else if (ov.gt_normal == nullptr && !inferred) {
-        if (tilt || !c->fuse_points) {
-            HIP_TRY(c, launch_make_points(tilt ? 2 : 1, ro, rd, z, z_stride, eps, R, S, c->pts, s));
-            rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE);
-        } else {   // the four offset copies are generated in the MLP kernel's input stage: no [4][R][S][3] batch (9.2 KB per ray on the fine grid)
-            PointGen g;
-            g.rays_o = ro; g.rays_d = rd; g.z = z; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
-            // (the fine grid's offset copies: the fast table's on the mixed trunk form's list, the safe table's on the three-product trunk form's)
-            const bool fine_x_fast = prec_mode == IBLNERF_MLP_F16X3_MXFP6X && !c->x_fine_precise;
-            const bool fine_x_3 = (prec_mode == IBLNERF_MLP_F16X3_MXFP6X || prec_mode == IBLNERF_MLP_F16X3_MXFP6) && !fine_x_fast && c->d_stream_f16[which] != nullptr;
-            if (coarse_grid && S == c->Sc && sigma_p_available(c, which) && !c->p_all_points && !c->x_coarse && c->sel_decided && c->sel_on) {
-                // The coarse grid's offsets need all eight layers at 2^-22 (DESIGN 4.0 ladder) — on the samples that can reach a weight.  So: an ESTIMATE of
-                // all 4 R S densities on the fast kernel (6 slots), then the relevant ones (neither clearly empty nor behind saturation, per offset copy:
-                // ~6 % on a scene with surfaces) again on the 15-slot form, scattered over the estimates.  The others composite to the same weights
-                // bit for bit (alpha = 0) or to within 1e-8 of a weight (the saturated tail).
-                if (est_chunks(c, which)) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, S / 2, (3 * S) / 4, CHUNK_TMIN, FLOP_TRUNK);
-                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
-                if (rc) return rc;
-                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-                c->sel_candidates += 4 * R * S;
-                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                                c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
-                // (on the three-product f16 kernel where the mode keeps its stream — what the whole-batch launch runs; 2 MB of weights against the 15-slot form's
-                // 3.9 MB, which sits at the edge of an XCD's 4 MB L2: its list launches took 2.1 - 5.7 ms from box to box)
-                if (c->d_stream_f16[which] != nullptr && c->mx_ok[which])
-                    rc = run_mlp(c, s, VAR_TRUNK_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
-                else
-                    rc = run_mlp(c, s, VAR_TRUNK_P, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_COARSE, nullptr, false, c->sel_count, c->sel_index);
-            } else if (!coarse_grid && list_ok && c->sel_decided && c->sel_on && (fine_x_fast || fine_x_3) &&
-                       (c->xsel_fraction < 0.0 ? can_decide : c->xsel_fraction <= (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))) {
-                // The FAST table's offsets on the fine grid (768 densities per ray, more than half of a frame): plain-f16 estimates of all of them, the mixed trunk
-                // form (TRUNK_X) on the relevant ones of each offset copy — bit for bit what the whole-batch launch computes for them.  About 40 % are relevant; the
-                // estimate costs 0.53 of a TRUNK_X evaluation, so this pays below FINE_OFFSET_SELECT_MAX_FRACTION (decided on the first launch).
-                if (est_chunks(c, which) && c->xsel_fraction >= 0.0) rc = estimate_chunked(c, s, which, ro, rd, z, z_stride, S, R, true, eps, nullptr, (3 * S) / 4, (7 * S) / 8, CHUNK_TMIN, FLOP_TRUNK);
-                else rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_ESTIMATE, &g);
-                if (rc) return rc;
-                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-                c->sel_candidates += 4 * R * S;
-                HIP_TRY(c, launch_select_points(ro, rd, z, z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, OFFSET_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                                c->sel_count, s, true, eps, nullptr, 0, FLOP_TRUNK));
-                if (c->xsel_fraction < 0.0) {
-                    int n_sel = 0;
-                    HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    c->xsel_fraction = (double)n_sel / (double)(4 * R * S);
-                }
-                if (c->xsel_fraction > (fine_x_fast ? FINE_OFFSET_SELECT_MAX_FRACTION : FINE_OFFSET_SELECT_MAX_FRACTION_3))
-                    rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, &g, false);
-                else if (fine_x_fast)
-                    rc = run_mlp(c, s, VAR_TRUNK_X_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_OFFSET_FINE, nullptr, false, c->sel_count, c->sel_index);
-                else
-                    rc = run_mlp(c, s, VAR_TRUNK_LIST, which, c->sel_pts, nullptr, S, 4 * R * S, c->sig4, 1, Q_LIST3, nullptr, false, c->sel_count, c->sel_index);
-            } else {
-                rc = run_mlp(c, s, VAR_TRUNK, which, nullptr, nullptr, S, 4 * R * S, c->sig4, 1, coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE, &g);
-            }
-        }
-        if (rc) return rc;
-    }
+    if ((rc = run_offset_query(c, s, which, kind, p, keep_all_rows, main_listed, ov.gt_normal != nullptr))) return rc;
     PassAArgs a = pass_a_args(c, ro, rd, R, z, z_stride, S, c->raw, c->sig4, c->aux_on[IBLNERF_AUX_NORMAL] ? c->nrm_raw : nullptr,
                               weights, near_, far_, ov);
     a.noise = noise;
     a.near_ray = near_ray; a.far_ray = far_ray;
     HIP_TRY(c, launch_pass_a(a, out, c->opt.gamma_correct, s));
     // reflected ray through the same network, always on the coarse z grid (:439-446)
-    HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, Sc, c->pts, s));
-    if (list_ok && c->sel_decided && c->sel_on) {
-        // the reflected ray leaves its surface into empty space and ends on the next one: a density estimate everywhere (fast TRUNK form; the same trunk
-        // arithmetic the REFL form runs), the view layers and the twelve radiance channels on the relevant samples only, zero rows elsewhere (weight 0, or < 1e-8)
-        if (est_chunks(c, which)) rc = estimate_chunked(c, s, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, Sc / 2, (3 * Sc) / 4, CHUNK_TMIN, FLOP_REFL);
-        else rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE, nullptr, true, nullptr, nullptr, FLOP_REFL);
-        if (rc) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->refl_raw, 0, (size_t)R * Sc * REFL_CH * sizeof(float), s));
-        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        c->sel_candidates += R * Sc;
-        HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
-                                        c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL));
-        rc = run_mlp(c, s, VAR_REFL_LIST, which, c->sel_pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_ESTIMATE, nullptr, false, c->sel_count, c->sel_index);
-    } else {
-        rc = run_mlp(c, s, VAR_REFL, which, c->pts, c->refl_d, Sc, R * Sc, c->refl_raw, 1, Q_REFL);
-    }
-    if (rc) return rc;
+    HIP_TRY(c, launch_make_points(0, c->refl_o, c->refl_d, zc, zc_stride, 0.f, R, c->Sc, c->pts, s));
+    if ((rc = run_reflected_query(c, s, which, R, zc, zc_stride, keep_all_rows))) return rc;
     PassBArgs b;
-    b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = zc; b.zc_stride = zc_stride; b.Sc = Sc;
+    b.state = c->state; b.refl_raw = c->refl_raw; b.refl_d = c->refl_d; b.zc = zc; b.zc_stride = zc_stride; b.Sc = c->Sc;
     b.gamma_correct = c->opt.gamma_correct; b.radiance_linear = c->opt.use_radiance_linear; b.out = out; b.R = R;
     b.env_tap = env_tap;
     HIP_TRY(c, launch_pass_b(b, s));
     return IBLNERF_OK;
+}
+
+// The coarse pass reduced to its density (options.coarse_outputs = 0: all the fine sampling needs from the coarse network) into c->sig4 [R, Sc]; c->pts holds the points.
+// The same route as the full coarse pass's density: a plain-f16 estimate everywhere, the 15-slot form on the samples that can carry a weight.
+static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const float* rd, long R, const float* zc, int zcs, const float* noise) {
+    const int Sc = c->Sc;
+    const long n = R * Sc;
+    int rc;
+    bool est_ran = false;
+    if (sigma_p_available(c, 0) && !c->p_all_points && (c->sel_decided ? c->sel_on : c->deciding)) {
+        if (c->deciding && c->est_f16 && !c->est_checked[0] && (rc = check_estimates(c, s, 0, n, Sc))) return rc;
+        const Launch est = pick_kernel(c, 0, VAR_TRUNK, Q_ESTIMATE, false);
+        Launch p15;
+        p15.kern = K_MX; p15.variant = VAR_TRUNK_P;
+        MlpCall m;
+        m.pts = c->pts; m.pts_per_ray = Sc; m.n_pts = n; m.out = c->sig4;
+        if ((rc = run_launch(c, s, est, 0, m))) return rc;
+        est_ran = true;
+        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        c->sel_candidates += n;
+        HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+                                        false, 0.f, nullptr, 0, FLOP_TRUNK, nullptr, nullptr, list_slots(p15)));
+        if (!c->sel_decided) {      // (the probe: this is also where a checkpoint's refinement decision is taken when no full coarse pass ever runs)
+            long n_sel = 0;
+            if ((rc = read_list_length(c, s, &n_sel))) return rc;
+            c->sel_decided = true;
+            c->coarse_share = (double)n_sel / (double)n;
+            c->sel_on = c->coarse_share <= SELECT_MAX_FRACTION;
+        }
+        if (c->sel_on) {
+            MlpCall l;
+            l.pts = c->sel_pts; l.pts_per_ray = Sc; l.n_pts = n; l.out = c->sig4; l.count_flops = false; l.n_pts_dev = c->sel_count; l.out_index = c->sel_index;
+            l.trip_margin = COARSE_SELECT_MARGIN;
+            return run_launch(c, s, p15, 0, l);
+        }
+    }
+    return run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, n, c->sig4, 1, Q_MAIN_COARSE, nullptr, !est_ran);   // (algorithmic FLOPs: once per query)
 }
 
 // Validates the caller's overrides (the reference's asserts at ibl_nerf_renderer.py:222, :232) and copies the scalar part.
@@ -1460,7 +1782,8 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     c->flop_alg = 0.0;
     c->sel_candidates = 0;
     c->flop_exec = 0.0;
-    HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 4 * sizeof(int), s));
+    c->slot_units = 0.0;
+    HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 8 * sizeof(int), s));
     const int Sc = c->Sc, Sf = c->Sf;
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
     if ((t_rand || near_ray) && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
@@ -1500,52 +1823,26 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
             return IBLNERF_OK;
         };
         if (!fine) {
-            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), false, zc, zcs, true,
+            rc = full_pass(c, s, 0, PASS_SINGLE, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), zc, zcs,
                            noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
-            rc = full_pass(c, s, 0, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), true, zc, zcs, true,
+            rc = full_pass(c, s, 0, PASS_COARSE, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), zc, zcs,
                            noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
             HIP_TRY(c, launch_make_points(0, ro, rd, zc, zcs, 0.f, R, Sc, c->pts, s));
             const float* nz = noise_c ? noise_c + r0 * Sc : nullptr;
-            bool listed = false, est_ran = false;
-            if (sigma_p_available(c, 0) && !c->p_all_points && (c->sel_decided ? c->sel_on : R >= SELECT_MIN_RAYS)) {
-                // (as in full_pass: a plain-f16 estimate everywhere, the 15-slot density on the samples that can carry a weight; this is also where a checkpoint's
-                // refinement decision is taken when no full coarse pass ever runs)
-                if (c->est_f16 && !c->est_checked[0] && R >= SELECT_MIN_RAYS && (rc = check_estimates(c, s, 0, R * Sc, Sc))) return rc;
-                rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_ESTIMATE);
-                if (rc) return rc;
-                est_ran = true;
-                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-                c->sel_candidates += R * Sc;
-                HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, nz, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
-                                                false, 0.f, nullptr, 0, FLOP_TRUNK));
-                if (!c->sel_decided) {
-                    int n_sel = 0;
-                    HIP_TRY(c, hipMemcpyAsync(&n_sel, c->sel_count, sizeof(int), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    c->sel_decided = true;
-                    c->sel_on = (double)n_sel <= SELECT_MAX_FRACTION * (double)(R * Sc);
-                }
-                if (c->sel_on) {
-                    rc = run_mlp(c, s, VAR_TRUNK_P, 0, c->sel_pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE, nullptr, false, c->sel_count, c->sel_index);
-                    if (rc) return rc;
-                    listed = true;
-                }
-            }
-            if (!listed) rc = run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, R * Sc, c->sig4, 1, Q_MAIN_COARSE, nullptr, !est_ran);   // (algorithmic FLOPs: once per query)
-            if (rc) return rc;
+            if ((rc = density_pass(c, s, ro, rd, R, zc, zcs, nz))) return rc;
             HIP_TRY(c, launch_sigma_weights(rd, zc, zcs, c->sig4, nz, R, Sc, c->w_c, s));
         }
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
-        rc = full_pass(c, s, fine_net, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), false, zc, zcs, false,
+        rc = full_pass(c, s, fine_net, PASS_FINE, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), zc, zcs,
                        noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr, taps != nullptr);
         if (rc) return rc;
         if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
@@ -1624,6 +1921,115 @@ int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
     HIP_TRY(c, hipMemcpy(&on_lists, c->sel_count + 4, sizeof on_lists, hipMemcpyDeviceToHost));
     *flop_executed = c->flop_exec + on_lists;
     return IBLNERF_OK;
+}
+
+int iblnerf_last_slot_units(iblnerf_ctx* c, double* slot_units) {
+    if (!c || !slot_units) return IBLNERF_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    double on_lists = 0.0;
+    HIP_TRY(c, hipMemcpy(&on_lists, c->sel_count + 8, sizeof on_lists, hipMemcpyDeviceToHost));
+    *slot_units = c->slot_units + on_lists;
+    return IBLNERF_OK;
+}
+
+static void fill_route(const iblnerf_ctx* c, iblnerf_route* r) {
+    std::memset(r, 0, sizeof *r);
+    r->decided = c->route_decided ? 1 : 0;
+    for (int w = 0; w < 2; ++w) r->estimates_plain_f16[w] = (c->est_f16 && c->est_checked[w] && c->est_ok[w]) ? 1 : 0;
+    r->tripped = c->tripped;
+    r->coarse_share = c->coarse_share;
+    r->fine_main_share = c->fsel_fraction;
+    r->fine_offsets_share = c->xsel_fraction;
+}
+
+int iblnerf_get_route(iblnerf_ctx* c, iblnerf_route* out) {
+    if (!c || !out) return IBLNERF_ERR_INVALID;
+    fill_route(c, out);
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_route(iblnerf_ctx* c, const iblnerf_route* r) {
+    if (!c || !r) return IBLNERF_ERR_INVALID;
+    reset_route(c, 0);
+    if (!r->decided) return IBLNERF_OK;
+    c->route_decided = true;
+    c->tripped = r->tripped;
+    for (int w = 0; w < 2; ++w) { c->est_checked[w] = true; c->est_ok[w] = r->estimates_plain_f16[w] != 0 && !c->tripped; }
+    c->sel_decided = true;
+    c->coarse_share = r->coarse_share;
+    c->sel_on = r->coarse_share >= 0.0 && r->coarse_share <= SELECT_MAX_FRACTION && c->tripped < 2;
+    // (a share that was not measured switches its list off: 2.0 is above every threshold)
+    c->fsel_fraction = r->fine_main_share >= 0.0 ? r->fine_main_share : 2.0;
+    c->xsel_fraction = r->fine_offsets_share >= 0.0 ? r->fine_offsets_share : 2.0;
+    return IBLNERF_OK;
+}
+
+int iblnerf_decide_route(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_, iblnerf_route* out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!d_rays_o || !d_rays_d || n_rays < SELECT_MIN_RAYS || n_rays > c->ws_rays)
+        return c->fail(IBLNERF_ERR_INVALID, "decide_route: needs %ld <= n_rays <= max_rays_per_launch (%ld) probe rays", SELECT_MIN_RAYS, c->ws_rays);
+    reset_route(c, 0);
+    iblnerf_outputs outs;                          // every map null: the probe's results are discarded
+    std::memset(&outs, 0, sizeof outs);
+    c->deciding = true;
+    const int rc = iblnerf_render_rays_tapped(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, nullptr, nullptr, &outs, nullptr);
+    c->deciding = false;
+    if (rc) { reset_route(c, 0); return rc; }
+    // whatever the probe did not reach stays off: from here on nothing is decided inside a render call
+    c->route_decided = true;
+    if (!c->sel_decided) { c->sel_decided = true; c->sel_on = false; }
+    for (int w = 0; w < 2; ++w)
+        if (!c->est_checked[w]) { c->est_checked[w] = true; c->est_ok[w] = false; }
+    if (c->fsel_fraction < 0.0) c->fsel_fraction = 2.0;
+    if (c->xsel_fraction < 0.0) c->xsel_fraction = 2.0;
+    if (out) fill_route(c, out);
+    return IBLNERF_OK;
+}
+
+int iblnerf_describe_route(iblnerf_ctx* c, char* buf, size_t n) {
+    if (!c || (!buf && n)) return -1;
+    std::string t;
+    char line[512];
+    auto add = [&](const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(line, sizeof line, fmt, ap);
+        va_end(ap);
+        t += line;
+    };
+    add("route: %s; estimates plain f16: coarse net %d, fine net %d%s; relevant shares on the probe: coarse grid %.3f, fine main %.3f, fine offsets %.3f\n",
+        c->route_decided ? "decided" : "NOT decided (every query evaluates all of its samples)", (int)est_plain(c, 0), (int)est_plain(c, 1), c->tripped == 2 ? " (tripwire fired twice: lists off)" : c->tripped ? " (tripwire fired)" : "",
+        c->coarse_share, c->fsel_fraction, c->xsel_fraction);
+    const bool fine = c->opt.n_importance > 0;
+    const int fine_net = c->have_net[1] ? 1 : 0;
+    auto row = [&](const char* pass, const char* query, const QueryPlan& q, int S) {
+        if (!q.run) { add("%-7s %-10s none\n", pass, query); return; }
+        if (!q.list) {
+            add("%-7s %-10s whole batch: %s", pass, query, launch_name(q.whole));
+            if (!q.density.none()) add(" + density on %s (%s)", launch_name(q.density), q.density_on_list ? "the samples it selects" : "every sample");
+            add("%s\n", q.gradient ? " [density gradient]" : q.point_batch ? " [point batch]" : "");
+            return;
+        }
+        add("%-7s %-10s estimate: %s", pass, query, launch_name(q.est));
+        if (q.predicted) add(" on the samples outside the main ray's relevant range only (predicted range -> list directly)");
+        else if (q.cut1 > 0) add(" in z-chunks [0,%d) [%d,%d) [%d,%d)", q.cut0, q.cut0, q.cut1, q.cut1, S);
+        else add(" on every sample");
+        add("; select T > %.0e; list: %s", (double)q.t_min, launch_name(q.on_list));
+        if (!q.density_list.none()) add(" + %s", launch_name(q.density_list));
+        add("\n");
+    };
+    struct { const char* name; int which, kind, S; bool on; } passes[] = {
+        {"coarse", 0, fine ? PASS_COARSE : PASS_SINGLE, c->Sc, !fine || c->opt.coarse_outputs != 0}, {"fine", fine_net, PASS_FINE, c->Sf, fine}};
+    for (auto& p : passes) {
+        if (!p.on) { if (fine) add("coarse  density    %s\n", (sigma_p_available(c, 0) && !c->p_all_points && c->sel_decided && c->sel_on) ? "estimate + 15-slot list" : "whole batch"); continue; }
+        const QueryPlan m = plan_main(c, p.which, p.kind, p.S, false);
+        row(p.name, "main", m, p.S);
+        row(p.name, "offsets", plan_offsets(c, p.which, p.kind, p.S, false, m.list || m.density_on_list, c->opt.normal_mode == IBLNERF_NORMAL_GROUND_TRUTH), p.S);
+        row(p.name, "reflected", plan_reflected(c, p.which, false), c->Sc);
+    }
+    if (buf && n) { std::strncpy(buf, t.c_str(), n - 1); buf[n - 1] = 0; }
+    return (int)t.size();
 }
 
 int iblnerf_set_profiling(iblnerf_ctx* c, int enabled) {

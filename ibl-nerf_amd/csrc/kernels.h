@@ -197,13 +197,21 @@ constexpr long POSDIR_FLOATS_OUT1 = 63L * 256 + 256 + 4 * (256L * 256 + 256) + (
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets = false,
                                 float eps = 0.0f, float* est_out = nullptr, int est_stride = 0,     // est_out: the estimate copied to element (r S + s) * est_stride
-                                double list_flop_per_point = 0.0);   // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
+                                double list_flop_per_point = 0.0,    // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
+                                int* range_out = nullptr,            // [R][2] (not with offsets): each ray's first and last selected sample ({S, -1}: none)
+                                const int* skip_range = nullptr,     // offsets: such a record of the MAIN rays — the samples predicted relevant by it ([first - 1, last + 1]) are not selected (again)
+                                double list_slots_per_point = 0.0);  // ... and their matrix-slot units per entry (counter[8..9])
+
+// the offset copies' samples by the main ray's relevant range (k_range_points: mode 1 the predicted range, 2 in front of it, 3 behind it for the copies still alive);
+// list length at counter[0] (zeroed by the caller), executed MACs x 2 (flop_per_point per entry) added to counter[4..5], entries to counter[2..3] if count_entries
+hipError_t launch_range_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const int* main_range, long R, int S, int mode,
+                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries);
 
 // estimates in two z-chunks: points + flat indices of samples [s0, s1) of every (virtual) ray (first: of all rays, in ray order; else: of the rays not yet saturated
 // behind their first s0 samples — list length at counter[0], executed MACs added to counter[4..5]; the others' samples get the density -1e30)
 hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const float* noise, long R, int S, int s0, int s1,
                                float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps, bool first,
-                               double flop_per_point);
+                               double flop_per_point, double slots_per_point);
 
 // counts into *bad the samples on which estimate `a` (plain f16) is half-way to a wrong k_select_points decision against estimate `b` (f16 + 2 fp6)
 hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, int* bad, hipStream_t s);

@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
 #else
     constexpr bool EST_FLAVOUR = false;
 #endif
-    if constexpr (VARIANT == VAR_TRUNK_P || LIST || EST_FLAVOUR) {
+    if constexpr (VARIANT == VAR_TRUNK_P || VARIANT == VAR_TRUNK || LIST || EST_FLAVOUR) {
         if (a.n_pts_dev != nullptr) n_total = *a.n_pts_dev;      // a compact list: its length is known on the device only (k_select_points)
     }
 #if defined(IBL_MX_EST) && IBL_MX_EST_TILES > 1
@@ -1104,7 +1104,11 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float p0 = sig[0] + sig[1];
             const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
-            if (valid && h == 0) a.out[(a.out_index != nullptr ? (long)a.out_index[p] : (long)p) * a.out_stride] = sg;
+            if (valid && h == 0) {
+                float* slot = a.out + (a.out_index != nullptr ? (long)a.out_index[p] : (long)p) * a.out_stride;
+                if (a.out_index != nullptr) estimate_tripwire(a, slot, sg);
+                *slot = sg;
+            }
             continue;
         }
 #ifndef IBL_MX_ABLATE_PROLOGUE
@@ -1227,7 +1231,14 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
         if constexpr (TRUNKV) {
             const float p0 = part[0][0] + part[0][1];
             const float s = p0 + __shfl_xor(p0, 32) + sc[0];
-            if (valid && h == 0) a.out[(LIST ? (long)a.out_index[p] : (long)p) * a.out_stride] = s;
+            if (valid && h == 0) {
+                // (the plain TRUNK form also takes a list when it serves as the density ESTIMATE of a network whose plain-f16 estimates were refused: z-chunks and the
+                // offset copies' front / behind ranges, api.cpp estimate_chunked / offsets_on_lists — a run-time question there, like VAR_TRUNK_P's)
+                const bool scattered = LIST || (VARIANT == VAR_TRUNK && a.out_index != nullptr);
+                float* slot = a.out + (scattered ? (long)a.out_index[p] : (long)p) * a.out_stride;
+                if constexpr (LIST) estimate_tripwire(a, slot, s);
+                *slot = s;
+            }
         } else {
             float tot[RAW_CH];
 #pragma unroll
@@ -1240,6 +1251,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
                 if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + row * RAW_CH;
                     if (h == 0) {
+                        if constexpr (LIST) estimate_tripwire(a, o, tot[0]);
 #pragma unroll
                         for (int c = 0; c < 9; ++c) o[c] = tot[c];
                     } else {
@@ -1249,6 +1261,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
                 } else {
                     float* o = a.out + row * REFL_CH;
                     if (h == 0) {
+                        if constexpr (LIST) estimate_tripwire(a, o, tot[0]);
                         o[0] = tot[0];
 #pragma unroll
                         for (int c = 1; c < 7; ++c) o[c] = tot[5 + c];

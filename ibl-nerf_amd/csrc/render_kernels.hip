@@ -687,13 +687,15 @@ __global__ __launch_bounds__(256) void k_sigma_weights(const float* __restrict__
 // OFFSETS: the "rays" are the 4 R epsilon-offset copies of the samples (normal_from_depth.py:143-160: virtual ray v R + r composites sig4[v][r][:] on ray r's own z
 // and dists, no noise); their points come from gen_offset_point, the generator the TRUNK kernels' input stage uses.
 constexpr int SELECT_WAVES = 8;      // rays per block of k_select_points
+constexpr int AUDIT_LOG2 = 6;        // one in 64 of the samples k_select_points drops as clearly empty is refined all the same (the tripwire's audit)
 
 // the call's running totals behind a list launch (iblnerf_last_selection / iblnerf_last_executed_flops): [2..3] one uint64 of list entries, [4..5] one double of the
 // MACs x 2 the list launches evaluate on them
-__global__ void k_count_selection(int* counter, double flop_per_point, int count_entries) {
+__global__ void k_count_selection(int* counter, double flop_per_point, double slots_per_point, int count_entries) {
     const int n = counter[0];
     if (count_entries) *reinterpret_cast<unsigned long long*>(counter + 2) += (unsigned long long)n;
     *reinterpret_cast<double*>(counter + 4) += (double)n * flop_per_point;
+    *reinterpret_cast<double*>(counter + 8) += (double)n * slots_per_point;      // [8..9]: matrix-slot units (api.cpp launch_slots)
 }
 
 // Estimates in two z-chunks (api.cpp estimate_chunked): the points and flat indices r S + s of samples [s0, s1) of every (virtual) ray — FIRST: of all rays, at
@@ -776,6 +778,88 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_chunk_points(const float*
     }
 }
 
+// The samples of a ray that its own selection found relevant, one more on either side: [lo, hi] — what the ray's four epsilon-offset copies (0.01 beside it) are
+// PREDICTED relevant by.  main_range: k_select_points' range_out, {first, last} selected sample per ray ({S, -1}: none -> lo = S, hi = S - 1: an empty range behind the ray).
+__device__ __forceinline__ void predicted_range(const int* __restrict__ main_range, long r, int S, int& lo, int& hi) {
+    const int a = main_range[2 * r], b = main_range[2 * r + 1];
+    if (b < a) { lo = S; hi = S - 1; }
+    else { lo = max(a - 1, 0); hi = min(b + 1, S - 1); }
+}
+
+// Round 5: the offset copies without an estimate of every sample (api.cpp offsets_on_lists).  Emits, per virtual ray v R + r, the points + flat indices of
+//   mode 1  its predicted range [lo, hi]           -> straight to the query's own kernel, no estimate;
+//   mode 2  the samples in front of it, [0, lo)    -> density estimates;
+//   mode 3  the samples behind it, (hi, S)         -> density estimates, for the copies whose transmittance behind [0, hi] — composited conservatively, as k_select_points
+//                                                     does, from the front estimates and the refined densities already in `sigma` — is still above t_min; the other
+//                                                     copies' samples behind get the density -1e30 (behind saturation, never relevant), exactly as k_chunk_points does.
+// Every sample of every copy lands in exactly one of the three; the prediction decides what a sample costs, never what it yields.
+template <int NPL>
+__global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
+                                                                    float* __restrict__ sigma, const int* __restrict__ main_range, long R, int S, int mode, float margin,
+                                                                    float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;
+    const bool live = vr_raw < 4 * R;
+    const long vr = live ? vr_raw : 0;
+    const long r = vr % R;
+    int lo, hi;
+    predicted_range(main_range, r, S, lo, hi);
+    const int s0 = mode == 1 ? lo : mode == 2 ? 0 : hi + 1;
+    const int s1 = mode == 1 ? hi + 1 : mode == 2 ? lo : S;
+    bool alive = live && s1 > s0;
+    if (mode == 3 && alive) {        // (wave-uniform)
+        const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const float* zrow = zbase + (long)z_stride * r;
+        double lane_prod = 1.0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int s = lane * NPL + i;
+            if (s < s0) {
+                const float sg = sigma[vr * S + s];
+                const float dist = (zrow[s + 1] - zrow[s]) * norm;                       // (s + 1 <= s0 < S)
+                const float a = 1.0f - expf(-fmaxf(sg * 0.75f - margin, 0.0f) * dist);    // the conservative transmittance of k_select_points
+                lane_prod *= (double)((1.0f - a) + 1e-10f);
+            }
+        }
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) lane_prod *= __shfl_xor(lane_prod, dd);
+        alive = lane_prod > (double)t_min;
+    }
+    __shared__ int wave_total[SELECT_WAVES];
+    __shared__ int block_base;
+    if (lane == 0) wave_total[wave] = alive ? s1 - s0 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < SELECT_WAVES; ++w) sum += wave_total[w];
+        block_base = sum > 0 ? atomicAdd(counter, sum) : 0;
+    }
+    __syncthreads();
+    int base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_total[w];
+    PointGen g;
+    g.rays_o = rays_o; g.rays_d = rays_d; g.z = zbase; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        if (!live || s < s0 || s >= s1) continue;
+        const unsigned flat = (unsigned)(vr * S + s);
+        if (!alive) {
+            sigma[flat] = -1e30f;
+            continue;
+        }
+        float p[3];
+        gen_offset_point(g, flat, p[0], p[1], p[2]);
+        const long pos = (long)base + (s - s0);
+        pts_out[3 * pos] = p[0];
+        pts_out[3 * pos + 1] = p[1];
+        pts_out[3 * pos + 2] = p[2];
+        index_out[pos] = (int)flat;
+    }
+}
+
 // Is a plain-f16 density estimate good enough for k_select_points on this network?  Two estimates of the same n samples (b: the f16 + 2 fp6 form, error < 1e-2);
 // counts the samples on which `a` is half-way to a wrong decision: a positive density estimated below -margin / 2, or a density overshot by more than the
 // conservative transmittance allows for (0.75 a - margin > b).
@@ -790,7 +874,7 @@ template <int NPL, bool OFFSETS>
 __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
                                                       const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
                                                       float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
-                                                      float* __restrict__ est_out, int est_stride) {
+                                                      float* __restrict__ est_out, int est_stride, int* __restrict__ range_out, const int* __restrict__ skip_range) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;      // (virtual) ray
     const bool live = vr_raw < (OFFSETS ? 4 * R : R);                // (a dead wave of the last block still takes part in the block's count)
@@ -829,15 +913,38 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
     bool sel[NPL];
     int total = 0;
     unsigned long long masks[NPL];
+    // skip_range (offset copies, api.cpp offsets_on_lists): the samples [lo, hi] of the ray were predicted relevant and hold their refined density already — they
+    // count for the transmittance of what lies behind them, and are not selected again
+    int skip_lo = S, skip_hi = -1;
+    if (skip_range != nullptr) predicted_range(skip_range, r, S, skip_lo, skip_hi);
+    int first_sel = S, last_sel = -1;
+    bool first_sel_candidate[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
         // (a sample is judged by the transmittance the ESTIMATE gives in front of it, with a margin on the estimate itself: sigma > -margin counts as
         // possibly opaque for nobody else's T, because T only ever gets smaller by counting it)
-        sel[i] = live && s < S && sg[i] > -margin && T > (double)t_min;
+        const bool reachable = live && s < S && T > (double)t_min && !(s >= skip_lo && s <= skip_hi);
+        sel[i] = reachable && sg[i] > -margin;
+        // the AUDIT (round 5): one in AUDIT_ONE_IN of the samples dropped as clearly empty goes to the list all the same.  Its refined density replaces the estimate
+        // (both <= 0: alpha = 0 either way, no map changes) — and the list kernel's tripwire (MlpArgs::trip_margin) sees an estimate that was GROSSLY wrong, which no
+        // selected sample would show: a positive density estimated below -margin is never selected, so never refined, so never compared.  Chosen by a hash of the
+        // sample's flat index: the same samples on every route and rank.
+        const bool audit = reachable && !sel[i] && ((unsigned)(vr * S + s) * 2654435761u) >> (32 - AUDIT_LOG2) == 0u;
+        first_sel_candidate[i] = sel[i];
+        sel[i] = sel[i] || audit;
         T *= om[i];
         masks[i] = __ballot(sel[i]);
         total += __popcll(masks[i]);
+        if (first_sel_candidate[i]) { first_sel = min(first_sel, s); last_sel = max(last_sel, s); }      // (an audited sample does not stretch the range its copies are predicted by)
+    }
+    if (range_out != nullptr) {       // the ray's first and last selected sample ({S, -1}: none): what its offset copies are predicted relevant by
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            first_sel = min(first_sel, __shfl_xor(first_sel, dd));
+            last_sel = max(last_sel, __shfl_xor(last_sel, dd));
+        }
+        if (live && lane == 0) { range_out[2 * vr] = first_sel; range_out[2 * vr + 1] = last_sel; }
     }
     // one atomic per BLOCK: every wave of a launch adding to the one counter by itself serialises in L2 (256 000 waves of the coarse grid's offset copies: 5.6 ms)
     __shared__ int wave_total[SELECT_WAVES];
@@ -1275,25 +1382,25 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
 
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps,
-                                float* est_out, int est_stride, double list_flop_per_point) {
+                                float* est_out, int est_stride, double list_flop_per_point, int* range_out, const int* skip_range, double list_slots_per_point) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
     const hipError_t e = by_npl(S, [&](auto N) {
         if (offsets)
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range);
         else
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range);
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point, 1);
+    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point, list_slots_per_point, 1);
     return hipGetLastError();
 }
 
 hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const float* noise, long R, int S, int s0, int s1,
                                float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps, bool first,
-                               double flop_per_point) {
+                               double flop_per_point, double slots_per_point) {
     if (R <= 0 || s1 <= s0) return hipSuccess;
     const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
     const hipError_t e = by_npl(S, [&](auto N) {
@@ -1305,7 +1412,20 @@ hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const f
 #undef IBL_CHUNK
     });
     if (e != hipSuccess) return e;
-    if (!first) hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, 0);     // (the chunk's estimates: executed MACs, not refined samples)
+    if (!first) hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, slots_per_point, 0);     // (the chunk's estimates: executed MACs, not refined samples)
+    return hipGetLastError();
+}
+
+hipError_t launch_range_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const int* main_range, long R, int S, int mode,
+                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries) {
+    if (R <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((4 * R + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
+    const hipError_t e = by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL((k_range_points<decltype(N)::value>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, main_range, R, S, mode, margin, t_min, eps, pts_out,
+                           index_out, counter);
+    });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, slots_per_point, count_entries ? 1 : 0);
     return hipGetLastError();
 }
 

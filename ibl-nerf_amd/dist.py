@@ -1,12 +1,17 @@
 """Ray-tile sharding of one frame across the GPUs of a node + reassembly by ONE all-gather.
 
 The reference is single-process; rays are independent (no cross-ray op in
-render_rays / raw2outputs), cost per ray is constant, so a static partition into contiguous
-row tiles is perfectly balanced.  One process per GPU (`torch.distributed`, backend "nccl" =
-RCCL over xGMI; "gloo" in the CPU tests).  Per frame and rank: generate the tile's rays from
-(K, c2w, rows), render them, pack the wanted maps into one [rows, W, C] buffer, all-gather it
-(the only exchange step on the path), unpack.  Weights/LUT are replicated by each rank's own
-upload — no broadcast is needed because every rank reads the same checkpoint.
+render_rays / raw2outputs).  Since round 4 a ray's cost depends on what it sees (estimates in
+z-chunks, list lengths), so the partition is INTERLEAVED: rank r renders image rows r, r + N,
+r + 2N, ... — every rank sees the same mix of sky, floor and silhouettes (measured:
+profiles/r05_tiles) — instead of one contiguous band.  One process per GPU (`torch.distributed`,
+backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Per frame and rank: the tile's rays
+from (K, c2w, rows), render them, pack the wanted maps into one [rows, W, C] buffer, ONE flat
+all-gather (the only exchange step on the path), undo the interleave with a transposed view, unpack.
+Weights/LUT are replicated by each rank's own upload — no broadcast is needed because every rank
+reads the same checkpoint, and every rank measures the checkpoint's route (Renderer.decide_route)
+on the same seeded pixels of the frame: all tiles take one route, and the N-rank frame is the
+1-rank frame bit for bit.
 """
 from __future__ import annotations
 
@@ -20,13 +25,26 @@ EXPORT_KEYS = ["color_map", "radiance_map", "radiance_map_1", "radiance_map_2", 
 
 
 def tile_rows(H: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous row tile of `rank`: (row0, n_rows); the first H % world ranks get one extra row."""
+    """Contiguous row tile of `rank`: (row0, n_rows); the first H % world ranks get one extra row.  (Round 4's partition; kept for the balance measurement
+    and as `partition="contiguous"`.)"""
     if not 0 <= rank < world:
         raise ValueError("rank %d outside world of %d" % (rank, world))
     base, extra = divmod(H, world)
     n = base + (1 if rank < extra else 0)
     row0 = rank * base + min(rank, extra)
     return row0, n
+
+
+def tile_row_indices(H: int, rank: int, world: int, partition: str = "interleaved") -> range:
+    """The image rows of `rank`: rows rank, rank + world, ... ("interleaved", the default) or tile_rows' contiguous band."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    if partition == "interleaved":
+        return range(rank, H, world)
+    if partition != "contiguous":
+        raise ValueError("partition must be 'interleaved' or 'contiguous'")
+    row0, n = tile_rows(H, rank, world)
+    return range(row0, row0 + n)
 
 
 def view_indices(n_views: int, rank: int, world: int) -> range:
@@ -37,11 +55,19 @@ def view_indices(n_views: int, rank: int, world: int) -> range:
     return range(rank, n_views, world)
 
 
-def slice_gt_rows(gt_values: Optional[dict], W: int, row0: int, n_rows: int) -> dict:
-    """gt_values arrive flattened to [H*W, C] (ibl_nerf_renderer.py:864-866); take this tile's rows."""
+def slice_gt_rows(gt_values: Optional[dict], W: int, row0, n_rows: Optional[int] = None) -> dict:
+    """gt_values arrive flattened to [H*W, C] (ibl_nerf_renderer.py:864-866); take this tile's image rows: (row0, n_rows) contiguous, or a range of rows."""
     if not gt_values:
         return {}
-    return {k: v[row0 * W:(row0 + n_rows) * W] for k, v in gt_values.items()}
+    if n_rows is not None:
+        return {k: v[row0 * W:(row0 + n_rows) * W] for k, v in gt_values.items()}
+    rows = row0
+    H = None
+    out = {}
+    for k, v in gt_values.items():
+        H = v.shape[0] // W
+        out[k] = v.reshape((H, W) + tuple(v.shape[1:]))[rows.start:rows.stop:rows.step].reshape((len(rows) * W,) + tuple(v.shape[1:]))
+    return out
 
 
 def pack_maps(maps: Dict[str, "object"], keys: Sequence[str], n_rows: int, W: int):
@@ -64,15 +90,15 @@ def unpack_maps(buf, layout: List[Tuple[str, int]]) -> Dict[str, "object"]:
     return out
 
 
-def all_gather_frame(local, H: int, W: int, group=None):
+def all_gather_frame(local, H: int, W: int, group=None, partition: str = "interleaved"):
     """local: [n_rows(rank), W, C] on every rank -> [H, W, C] on every rank (one collective)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     C = local.shape[-1]
-    max_rows = tile_rows(H, 0, world)[1]
-    row0, n = tile_rows(H, rank, world)
+    max_rows = len(tile_row_indices(H, 0, world, partition))
+    n = len(tile_row_indices(H, rank, world, partition))
     assert local.shape[0] == n and local.shape[1] == W
     padded = local
     if n < max_rows:   # equal-size contributions let RCCL run one flat all-gather
@@ -86,52 +112,91 @@ def all_gather_frame(local, H: int, W: int, group=None):
     else:
         gathered = torch.empty((world * max_rows, W, C), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
+    if partition == "interleaved":
+        # block r of the gathered buffer holds rows r, r + world, ...: row j * world + r sits at [r, j] — a transposed view puts the frame back in order; the padding
+        # rows of the shorter tiles (j = max_rows - 1, r >= H % world) are exactly the indices >= H
+        if world == 1:
+            return gathered
+        return gathered.reshape(world, max_rows, W, C).transpose(0, 1).reshape(world * max_rows, W, C)[:H].contiguous()
     if H % world == 0:
         return gathered
     parts = [gathered[r * max_rows: r * max_rows + tile_rows(H, r, world)[1]] for r in range(world)]
     return torch.cat(parts, 0)
 
 
-def render_frame_sharded(render_tile: Callable[[int, int], Dict[str, "object"]], H: int, W: int,
-                         keys: Sequence[str] = EXPORT_KEYS, group=None) -> Dict[str, "object"]:
-    """`render_tile(row0, n_rows)` renders this rank's rows and returns maps shaped [n_rows*W, ...] or
-    [n_rows, W, ...].  Returns the full-frame maps ([H, W, ...]) on every rank."""
+def render_frame_sharded(render_tile: Callable[..., Dict[str, "object"]], H: int, W: int,
+                         keys: Sequence[str] = EXPORT_KEYS, group=None, partition: str = "interleaved") -> Dict[str, "object"]:
+    """`render_tile(rows)` renders this rank's image rows (a range: rank, rank + world, ... — or the contiguous band of partition="contiguous") and returns maps
+    shaped [n_rows*W, ...] or [n_rows, W, ...].  Returns the full-frame maps ([H, W, ...]) on every rank."""
     import torch.distributed as dist
     grouped = dist.is_available() and dist.is_initialized()
     if grouped:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    row0, n = tile_rows(H, rank, world)
-    maps = render_tile(row0, n)
+    rows = tile_row_indices(H, rank, world, partition)
+    n = len(rows)
+    maps = render_tile(rows)
     keys = list(keys) + [k for k in ("inferred_normal_map",) if k in maps and k not in keys]   # present under infer_normal only
     buf, layout = pack_maps(maps, keys, n, W)
-    full = all_gather_frame(buf, H, W, group) if grouped else buf     # (a one-rank group still goes through the collective)
+    full = all_gather_frame(buf, H, W, group, partition) if grouped else buf     # (a one-rank group still goes through the collective)
     return unpack_maps(full, layout)
 
 
-def calibrate_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
-    """mlp_precision="auto": decide the checkpoint's query routing (Renderer.calibrate) on `n` seeded pixels of the WHOLE frame — the same pixels on
-    every rank, so that all tiles of a frame are rendered under one decision (the kernels are deterministic: same rays, same measurement)."""
+def frame_probe(renderer, H, W, K, c2w, n=4096, seed=0):
+    """`n` seeded pixels of the WHOLE frame — the same on every rank — as rays: what a checkpoint's route and precision table are measured on."""
     import numpy as np
     import torch
     pix = np.sort(np.random.RandomState(seed).permutation(H * W)[:min(n, H * W)])
     ro, rd = renderer.get_rays(H, W, K, c2w)                       # (15 MB for 800 x 800; once per checkpoint)
     idx = torch.as_tensor(pix, device=ro.device)
-    if len(pix) < renderer.CAL_MIN_RAYS:       # a frame too small to measure on (the 9-row frames of the tests): rendered SAFE, question left open
+    return ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous()
+
+
+def decide_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
+    """The checkpoint's route (Renderer.decide_route: which queries run as estimate + list, on which estimates) measured on the frame's seeded probe pixels: every
+    rank measures the same rays with the same deterministic kernels, so all tiles of a frame take one route — whatever the mlp_precision mode, pinned or "auto".
+    A frame too small to measure on (the 9-row frames of the tests) leaves the route undecided: every query then evaluates all of its samples."""
+    if renderer.route is not None or H * W < renderer.ROUTE_MIN_RAYS or renderer.mlp_precision == "bf16x3" or int(renderer.opt.max_rays_per_launch) < renderer.ROUTE_MIN_RAYS:
+        return renderer.route
+    ro, rd = frame_probe(renderer, H, W, K, c2w, n, seed)
+    return renderer.decide_route(ro, rd, near, far)
+
+
+def calibrate_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
+    """mlp_precision="auto": decide the checkpoint's query routing (Renderer.calibrate) on `n` seeded pixels of the WHOLE frame — the same pixels on
+    every rank, so that all tiles of a frame are rendered under one decision (the kernels are deterministic: same rays, same measurement).  The route
+    (decide_on_frame) is measured first, on the same pixels."""
+    decide_on_frame(renderer, H, W, K, c2w, near, far, n, seed)
+    if not getattr(renderer, "_auto", False):
+        return renderer.policy
+    if min(n, H * W) < renderer.CAL_MIN_RAYS:       # a frame too small to measure on (the 9-row frames of the tests): rendered SAFE, question left open
         renderer._set_routing(renderer.SAFE_ROUTING)
         return None
-    return renderer.calibrate(ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous(), near, far)
+    ro, rd = frame_probe(renderer, H, W, K, c2w, n, seed)
+    return renderer.calibrate(ro, rd, near, far)
 
 
-def render_frame(renderer, H, W, K, c2w, near, far, keys: Sequence[str] = EXPORT_KEYS, gt_values=None, group=None,
+def render_frame(renderer, H, W, K, c2w, near, far, keys: Sequence[str] = EXPORT_KEYS, gt_values=None, group=None, partition: str = "interleaved",
                  **edit):
     """Full frame with the HIP renderer, sharded over the ranks of `group` (or unsharded without one)."""
-    if getattr(renderer, "_auto", False) and renderer.policy is None:
+    import torch
+    if renderer.route is None or (getattr(renderer, "_auto", False) and renderer.policy is None):
         calibrate_on_frame(renderer, H, W, K, c2w, near, far)
+    gt_values = dict(gt_values or {})
+    if edit.get("edit_intrinsic") and edit.get("edit_roughness") and edit.get("edit_roughness_by_img") and "edit_roughness" in gt_values:
+        # the one override whose value depends on the reference's chunking of the FLAT frame (ibl_nerf_renderer.py:394-395 inside batchify_rays' chunks of
+        # `chunk` = 32 768 rays, :735-756): resolved once on the whole frame, then sliced like any other row image
+        from .renderer import resolve_edit_roughness, _dev_f32
+        m = _dev_f32(gt_values["edit_intrinsic_mask"], renderer.device).reshape(H * W, -1)[:, 0]
+        img = _dev_f32(gt_values["edit_roughness"], renderer.device).reshape(H * W, -1)[:, 0]
+        gt_values["_edit_roughness_resolved"] = resolve_edit_roughness(m, img, edit.get("chunk", 1024 * 32))
+    full = {}
 
-    def tile(row0, n_rows):
-        ro, rd = renderer.get_rays(H, W, K, c2w, row0, n_rows)
-        return renderer.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far,
-                                    slice_gt_rows(gt_values, W, row0, n_rows), **edit)
-    return render_frame_sharded(tile, H, W, keys, group)
+    def tile(rows):
+        if not full:
+            full["o"], full["d"] = renderer.get_rays(H, W, K, c2w)          # (every pixel's ray is computed by itself: a tile's rays are the frame's, bit for bit)
+        sl = slice(rows.start, rows.stop, rows.step)
+        ro, rd = full["o"][sl].reshape(-1, 3).contiguous(), full["d"][sl].reshape(-1, 3).contiguous()
+        return renderer.render_rays(ro, rd, near, far, slice_gt_rows(gt_values, W, rows), **{k: v for k, v in edit.items() if k != "chunk"})
+    return render_frame_sharded(tile, H, W, keys, group, partition)

@@ -143,6 +143,8 @@ class Renderer:
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._twin_ref = None        # (mode, Renderer) of precision_report
         self._blobs, self._lut = {}, None
+        self.route = None            # iblnerf_route of the loaded checkpoint as a dict (decide_route), None = not decided yet
+        self.trips = 0               # render calls repeated because the estimate tripwire fired
         self.has_fine = False            # a network_fine is loaded (run_fn = network_fn otherwise, ibl_nerf_renderer.py:705)
         self.range_fallbacks = 0
         self.opt = o
@@ -190,6 +192,7 @@ class Renderer:
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
         if int(which) == 1:
             self.has_fine = True
+        self.route = None                # (the library withdrew it with the upload: another network, another measurement)
         if not remember:
             return
         if self._auto:
@@ -439,6 +442,62 @@ class Renderer:
 
     def _set_routing(self, extra):
         B.check(self.ctx, self.lib.iblnerf_set_query_routing(self.ctx, int(self._routing | extra)))
+        self._routing_extra = int(extra)        # what is applied on top of the caller's bits right now (policy["routing"] is the decision's)
+
+    # ---- the checkpoint's route (include/iblnerf.h: iblnerf_route) ---------------------------------------------------------------------------
+    ROUTE_MIN_RAYS, ROUTE_RAYS = 1024, 4096
+
+    def decide_route(self, rays_o, rays_d, near, far):
+        """Measures on these probe rays which queries of the loaded checkpoint run as "estimate everywhere + the query's kernel on the relevant samples" and
+        whether plain-f16 estimates are good enough (iblnerf_decide_route: one discarded render of the probe), and freezes the answer until the next
+        load_weights: no render call decides anything, so results and speed do not depend on call history, launch size or rank.  render_rays calls this by
+        itself on <= ROUTE_RAYS strided rays of the first eager call of at least ROUTE_MIN_RAYS rays; dist.decide_on_frame / bench.py pass the same seeded
+        pixels of the frame on every rank.  Returns and records `self.route`."""
+        torch = _torch()
+        rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
+        n = int(rays_o.shape[0])
+        cap = min(self.ROUTE_RAYS, int(self.opt.max_rays_per_launch))
+        if n > cap:
+            idx = torch.linspace(0, n - 1, cap, device=self.device).long()
+            rays_o, rays_d, n = rays_o[idx].contiguous(), rays_d[idx].contiguous(), cap
+        route = B.Route()
+        B.check(self.ctx, self.lib.iblnerf_decide_route(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near), float(far), C.byref(route)))
+        torch.cuda.current_stream(self.device).synchronize()         # (the probe's rays may be temporaries)
+        self.route = route.as_dict()
+        self.route["probe_rays"] = n
+        return self.route
+
+    def get_route(self):
+        route = B.Route()
+        B.check(self.ctx, self.lib.iblnerf_get_route(self.ctx, C.byref(route)))
+        return route.as_dict()
+
+    def set_route(self, route):
+        """Imposes a route measured elsewhere (a dict as decide_route returns it, or None to withdraw the current one)."""
+        r = B.Route()
+        if route is not None:
+            r.decided = int(bool(route.get("decided", True)))
+            r.estimates_plain_f16[0], r.estimates_plain_f16[1] = (int(bool(v)) for v in route["estimates_plain_f16"])
+            r.tripped = int(route.get("tripped", 0))
+            r.coarse_share, r.fine_main_share, r.fine_offsets_share = float(route["coarse_share"]), float(route["fine_main_share"]), float(route["fine_offsets_share"])
+        B.check(self.ctx, self.lib.iblnerf_set_route(self.ctx, C.byref(r)))
+        self.route = self.get_route() if route is not None else None
+
+    def describe_route(self):
+        """The route table as text (iblnerf_describe_route): per pass and query class, which kernel estimates and which evaluates."""
+        n = self.lib.iblnerf_describe_route(self.ctx, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.iblnerf_describe_route(self.ctx, buf, n + 1)
+        return buf.value.decode()
+
+    def last_slot_units(self):
+        """Matrix-slot units of the last render_rays call's MLP launches (iblnerf_last_slot_units; synchronises)."""
+        v = C.c_double()
+        B.check(self.ctx, self.lib.iblnerf_last_slot_units(self.ctx, C.byref(v)))
+        return float(v.value)
+
+    def _route_wanted(self, n):
+        return (self.route is None and self.mlp_precision != "bf16x3" and n >= self.ROUTE_MIN_RAYS and int(self.opt.max_rays_per_launch) >= self.ROUTE_MIN_RAYS)
 
     def calibrate(self, rays_o, rays_d, near, far, gt_values=None, **edit):
         """Decides FAST or SAFE for the checkpoint this context holds on the given rays (a few thousand of the view to be rendered: dist.render_frame
@@ -450,8 +509,12 @@ class Renderer:
             return self.policy
         keep = self.policy
         self.policy = {"decision": "calibrating"}
+        applied = getattr(self, "_routing_extra", 0)
         try:
             with torch.no_grad():
+                if self._route_wanted(rays_o.shape[0]):      # the route first (a property of the networks, measured on the same rays; both routings then run under it)
+                    self.decide_route(rays_o, rays_d, float(near) if not hasattr(near, "shape") else float(_torch().as_tensor(near).min()),
+                                      float(far) if not hasattr(far, "shape") else float(_torch().as_tensor(far).max()))
                 self._set_routing(0)
                 a = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
                 self._set_routing(self.SAFE_ROUTING)
@@ -470,10 +533,11 @@ class Renderer:
                 if share > self.CAL_MAX_SHARE_ABOVE_1E3.get(k, 1.0):
                     triggers.append("%s: %.2f %% of the rays above 1e-3" % (k, 100 * share))
             safe = bool(triggers)
-            self._set_routing(self.SAFE_ROUTING if safe else 0)
+            applied = self.SAFE_ROUTING if safe else 0
             keep = {"decision": "safe" if safe else "fast", "rays": int(a["depth_map"].shape[0]), "metrics": metrics, "triggers": triggers,
                     "routing": int(self._routing | (self.SAFE_ROUTING if safe else 0))}
         finally:
+            self._set_routing(applied)          # (also after an exception inside a probe render: the context goes back to the routing it had — ADVICE r4)
             self.policy = keep
         return self.policy
 
@@ -489,6 +553,10 @@ class Renderer:
         gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
         near, far = ((v[idx].contiguous() if torch.is_tensor(v) and v.numel() == n else v) for v in (near, far))       # per-ray planes follow their rays
         self.calibrate(rays_o[idx].contiguous(), rays_d[idx].contiguous(), near, far, gt, **edit)
+
+    @staticmethod
+    def trips_in_a_row(retry):
+        return 3 if retry == "trip2" else 2 if retry == "trip" else 1
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""
@@ -927,6 +995,11 @@ class Renderer:
         if self._auto and self.policy is None and not lazy and taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0.:
             # (a training step's context — lazy, sampled, tapped — keeps the FAST table: its renders are stochastic and its weights change every step)
             self._auto_decide(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, edit)
+        if (taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0. and self._route_wanted(n)
+                and not (self.policy or {}).get("decision") == "calibrating"):
+            # the first eager frame-sized call after a checkpoint was loaded: its route, measured on <= ROUTE_RAYS strided rays of the call
+            # (a training step's context — lazy, sampled, tapped — holds no route: its weights change every step, its main queries evaluate every sample)
+            self.decide_route(rays_o, rays_d, float(planes[0].min()) if planes else near, float(planes[1].max()) if planes else far)
         self._chunk = chunk          # (one flag's result depends on the reference's chunking: edit_roughness_by_img, see _overrides)
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
@@ -951,9 +1024,21 @@ class Renderer:
                                                               C.byref(smp) if smp is not None else None, C.byref(outs),
                                                               C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
-        if not lazy and self.out_of_range():
+        bits = 0 if lazy else self.range_bits()
+        if bits & 12 and not bits & 1:
+            # the estimate tripwire: a list launch of this call refined a positive density whose plain-f16 estimate was half-way to dropping it.  The library
+            # has moved the estimates to the f16 + 2 fp6 form (error < 1e-2 on a network that fits that form) — or, if they were there already, switched the
+            # lists off; the call is repeated.
+            self.trips += 1
+            self.trip_bits = getattr(self, "trip_bits", 0) | (bits & 12)
+            self.route = self.get_route() if self.route is not None else None
+            if self.trips_in_a_row(_retry) > 2:
+                raise B.IblNerfError("the estimate tripwire fired with the lists off: an internal error")
+            return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk,
+                                    raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, _retry="trip2" if _retry == "trip" else "trip", **edit)
+        if bits & 1:
             again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, **edit)
-            if not _retry and n:
+            if _retry is not True and n:
                 # the coarse grid's points of (up to) 1 024 of the call's rays: where both networks are evaluated, within the margin RANGE_TARGET leaves
                 idx = torch.linspace(0, n - 1, min(n, 1024), device=self.device).long()
                 nr = planes[0][idx, None] if planes else torch.full((len(idx), 1), float(near), device=self.device)
@@ -1071,15 +1156,10 @@ class Renderer:
                 if img.shape[1] != 1:   # the reference assigns row[0] of shape [C] to the masked entries of an [n] map: only one channel broadcasts
                     raise RuntimeError("shape mismatch: gt_values['edit_roughness'] must have one channel for edit_roughness_by_img (the reference's "
                                        "masked assignment of a [%d]-vector to a scalar map fails)" % img.shape[1])
-                masked = mask_rows[:, 0] > 0                                # mask_all (:229)
-                ch = int(self._chunk or n or 1)
-                per_ray = torch.zeros((n,), dtype=torch.float32, device=self.device)
-                pos = torch.arange(n, device=self.device)
-                for c0 in range(0, n, ch):
-                    m = masked[c0:c0 + ch]
-                    if bool(m.any()):
-                        first = int(pos[c0:c0 + ch][m][0])
-                        per_ray[c0:c0 + ch] = img[first, 0]
+                if "_edit_roughness_resolved" in gt:     # (a tile of a frame: resolved on the whole flat frame by dist.render_frame, in the reference's chunks)
+                    per_ray = _dev_f32(gt["_edit_roughness_resolved"], self.device).reshape(n).contiguous()
+                else:
+                    per_ray = resolve_edit_roughness(mask_rows[:, 0], img[:, 0], self._chunk)
                 keep.append(per_ray)
                 ov.edit_roughness_by_img, ov.d_roughness = 1, per_ray.data_ptr()
             if ov.edit_albedo and not ov.edit_albedo_by_img and len(alb) < 3 * nobj:
@@ -1108,6 +1188,23 @@ class Renderer:
         for i, v in enumerate(alb[:24]):
             ov.albedo_list[i] = float(v)
         return ov, keep
+
+
+def resolve_edit_roughness(mask0, img0, chunk):
+    """edit_roughness_by_img (ibl_nerf_renderer.py:394-395): `target_roughness_map[mask_all] = gt_values["edit_roughness"][mask_all][0]` runs inside raw2outputs,
+    i.e. once per `chunk` rays of the FLAT ray list batchify_rays walks (:735-756): every masked ray of a chunk takes the first masked row of that chunk.
+    mask0 [n] (channel 0 of the mask rows), img0 [n] -> the roughness each ray would take [n] (rays of a chunk without a masked ray: 0, never read).
+    One scatter-amin, no host synchronisation."""
+    torch = _torch()
+    n = int(mask0.shape[0])
+    ch = int(chunk or n or 1)
+    pos = torch.arange(n, device=mask0.device)
+    cid = pos // ch
+    masked = mask0 > 0                                                # mask_all (:229)
+    first = torch.full(((n + ch - 1) // ch,), n, dtype=torch.long, device=mask0.device)
+    first.scatter_reduce_(0, cid[masked], pos[masked], "amin")
+    val = torch.where(first < n, img0[first.clamp(max=max(n - 1, 0))], torch.zeros((), dtype=img0.dtype, device=img0.device))
+    return val[cid].to(torch.float32).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -131,6 +131,14 @@ enum {
                                                  routes every query as F16X3_MXFP6 does: the "safe" policy of ibl-nerf_amd/renderer.py's load-time calibration) */
     IBLNERF_ROUTE_ESTIMATES_WHOLE = 512,      /* the density estimates of the offset copies and of the fine main query on every sample at once instead of in z-chunks
                                                  (the later chunks only for rays not yet saturated; results are the same bit for bit, per-sample weights to 1e-15) */
+    IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL = 1024, /* round 4's route for the epsilon-offset copies: a density estimate on every sample of every copy, then the copy's own
+                                                 selection.  Default since round 5 (iblnerf_route below, api.cpp offsets_on_lists): the samples the MAIN ray of the same
+                                                 pass found relevant (its first to its last selected sample, one more on either side) are PREDICTED relevant for the four
+                                                 copies and go to the query's own kernel without an estimate; estimates run on the rest only (in front of that range for
+                                                 every copy, behind it for the copies that have not saturated by then), followed by the copy's own selection among them.
+                                                 Every sample is still either evaluated by the query's kernel or judged on an estimate of its own: the prediction decides
+                                                 cost, never a result (against this bit: the same samples and more refined; maps agree to ~1e-7) */
+    IBLNERF_ROUTE_NO_RESCUE = 2048,           /* no second, 15-slot evaluation of the fine pass's densities on the rays k_pass_a flags as threshold-critical (api.cpp rescue) */
     IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
                                                  f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
                                                  only has to be right to within the selection margin of 1.0 in raw density */
@@ -139,6 +147,36 @@ enum {
  * flight by issuing it between calls on the context's stream).  Bits that need a stream the context's mlp_precision does not keep are ignored as at
  * iblnerf_create.  Lets a caller measure two routings of one mode on the same rays and keep the cheaper one that holds its tolerance. */
 int iblnerf_set_query_routing(iblnerf_ctx* ctx, int query_routing);
+
+/* The ROUTE of a checkpoint: which queries run as "estimate everywhere + the query's own kernel on a list of the relevant samples" (csrc/api.cpp full_pass).
+ * Whether that pays, and whether plain-f16 estimates are good enough, are properties of the networks — so they are MEASURED, once per checkpoint, on probe rays the
+ * caller chooses (iblnerf_decide_route), and from then on every render call of the context takes the same route whatever its size, order or rank: nothing is decided
+ * inside a render call.  Until a route is decided (after iblnerf_create and after every upload of network 0 / 1) every query evaluates all of its samples on its
+ * own kernel (round 3's path: correct, ~1.5x slower on a scene with surfaces).  ibl-nerf_amd/renderer.py decides on <= 4 096 strided rays of the first call of at
+ * least 1 024 rays; dist.py / bench.py on the same seeded pixels of the frame on every rank, so that all tiles of a frame take one route and an N-rank frame is
+ * the 1-rank frame bit for bit.  No reference counterpart: the reference evaluates every sample in fp32 (ibl_nerf_renderer.py:201, :446, normal_from_depth.py:158). */
+typedef struct iblnerf_route {
+    int32_t decided;                   /* 0: no route yet (see above); the other fields are then meaningless */
+    int32_t estimates_plain_f16[2];    /* per network: its density estimates run in plain f16 (4 matrix slots per 64 MACs); 0: on the f16 + 2 fp6 form (6), because the
+                                          probe found a plain-f16 estimate half-way to a wrong selection, because the tripwire fired since, or IBLNERF_ROUTE_ESTIMATES_6SLOT */
+    int32_t tripped;                   /* the estimate tripwire (every list launch checks the estimates it overwrites — those of the samples it refines and of one in 64
+                                          of the samples dropped as clearly empty, the audit — bits 2 / 3 of the range flag) has fired since the decision: 1 = the plain-f16
+                                          estimates were withdrawn, 2 = it fired on f16 + 2 fp6 estimates too and the lists went off (iblnerf_range_status folds the
+                                          flag in; the call that raised it must be repeated: ibl-nerf_amd/renderer.py does) */
+    double coarse_share;               /* share of the probe's coarse-grid samples that were relevant (neither clearly empty nor behind saturation); lists are on for
+                                          the coarse main query, the coarse grid's offset copies and the reflected rays iff it is <= 0.30.  -1: not measured (lists off) */
+    double fine_main_share;            /* likewise the fine main query (on a list iff <= 0.60) */
+    double fine_offsets_share;         /* likewise the fine grid's offset copies (on lists iff <= 0.42, or 0.55 where the mode refines them on three f16 products) */
+} iblnerf_route;
+/* Measures and freezes the route on n_rays probe rays (device pointers; 1 024 <= n_rays <= options.max_rays_per_launch; scalar planes): one render of them whose
+ * outputs are discarded, with three stream synchronisations.  Needs the networks and the LUT uploaded.  *out (nullable) receives the result. */
+int iblnerf_decide_route(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_, iblnerf_route* out);
+/* Imposes a route (e.g. the one another rank or an earlier run decided); decided = 0 withdraws it. */
+int iblnerf_set_route(iblnerf_ctx* ctx, const iblnerf_route* route);
+int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
+/* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
+ * Writes at most n bytes including the terminating 0; returns the length the full text needs (snprintf's convention), < 0 on error. */
+int iblnerf_describe_route(iblnerf_ctx* ctx, char* buf, size_t n);
 enum { IBLNERF_MLP_BF16X3 = 0, IBLNERF_MLP_F16_MXFP6 = 1, IBLNERF_MLP_F16_MIXED = 2, IBLNERF_MLP_F16X3 = 3, IBLNERF_MLP_F16X3_MXFP6 = 4, IBLNERF_MLP_F16X3_MAIN = 5, IBLNERF_MLP_F16X3_MXFP6X = 6 };
 enum { IBLNERF_NORMAL_DEPTH_GRADIENT_EPSILON = 0, IBLNERF_NORMAL_GROUND_TRUTH = 1, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON = 2,
        IBLNERF_NORMAL_INFERRED = 3, IBLNERF_NORMAL_DEPTH_GRADIENT = 4, IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION = 5 };
@@ -519,14 +557,19 @@ size_t iblnerf_stream_bytes_mx(void);
  * offset copies, the reflected ray of each pass), how many were evaluated there (the "relevant" ones: neither clearly empty nor behind saturation;
  * IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: not counted, both 0).  Synchronises. */
 int iblnerf_last_selection(iblnerf_ctx* ctx, int64_t* n_selected, int64_t* n_candidates);
-/* Which form the density estimates of network `which` (0 network_fn, 1 network_fine) run on: *checked = 1 once the network's first render launch has compared the
- * plain-f16 trunk against the f16 + 2 fp6 one on that launch's samples (once per upload), *plain_f16 = 1 if it was never half-way to a wrong selection (a positive
- * density estimated below -1, or overshot beyond what the conservative transmittance allows for) and IBLNERF_ROUTE_ESTIMATES_6SLOT is not set. */
+/* Which form the density estimates of network `which` (0 network_fn, 1 network_fine) run on: *checked = 1 once iblnerf_decide_route has compared the
+ * plain-f16 trunk against the f16 + 2 fp6 one on its probe's samples (once per upload), *plain_f16 = 1 if it was never half-way to a wrong selection (a positive
+ * density estimated below -1, or overshot beyond what the conservative transmittance allows for), the tripwire has not fired since, and IBLNERF_ROUTE_ESTIMATES_6SLOT is not set. */
 int iblnerf_estimate_policy(iblnerf_ctx* ctx, int which, int* checked, int* plain_f16);
 /* Measurement aid beside iblnerf_last_mlp_time's ALGORITHMIC count (the reference's nn.Linear MACs x 2 for every sample of every query, ibl_nerf_renderer.py:201-446):
  * the MACs x 2 the forward MLP launches of the last iblnerf_render_rays* call really evaluated — estimates on the trunk only, head layers and refinements on the selected
  * samples only, the 15-slot density counted beside the query it refines; each product scheme counts as one MAC.  Synchronises. */
 int iblnerf_last_executed_flops(iblnerf_ctx* ctx, double* flop_executed);
+
+/* ... and the same launches in matrix-slot units: per launch n_points x (2 x MACs of its form / 128) x the slots its product scheme spends per 64 MACs (plain f16 4,
+ * f16 + 2 fp6 6, mixed trunk 7.5, three f16 products 12, 15-slot 15; one slot = one 32x32x16 f16 MFMA's time).  On a power-bound chip this — not the MAC count — is what
+ * a frame costs (STATE.md section 2).  Synchronises. */
+int iblnerf_last_slot_units(iblnerf_ctx* ctx, double* slot_units);
 
 /* Timing aid for bench.py: HIP-event time (ms) of the MLP kernels launched by the last
  * iblnerf_render_rays call on this ctx, and their count.  Enabled by iblnerf_set_profiling(ctx, 1),

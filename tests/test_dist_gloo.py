@@ -36,8 +36,9 @@ def _worker(rank, world, init_file, out_dir):
     from ibl_nerf_amd import dist as D
     ro_all, rd_all = O.get_rays(H, W, K, c2w)
 
-    def tile(row0, n):
-        rays = np.stack([ro_all[row0:row0 + n].reshape(-1, 3), rd_all[row0:row0 + n].reshape(-1, 3)], 0)
+    def tile(rows):           # (interleaved: rank, rank + world, ...)
+        sl = slice(rows.start, rows.stop, rows.step)
+        rays = np.stack([ro_all[sl].reshape(-1, 3), rd_all[sl].reshape(-1, 3)], 0)
         m = O.render_decomp(H, W, K, sdc, sdf, lut, 0.5, 8.0, rays=rays, n_importance=16)
         return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in m.items()}
 

@@ -205,34 +205,34 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     samples are relevant: the importance samples crowd around the surface).  Against the same render with
     every sample refined (query_routing = coarse_density_all_points): every FINE-pass map bit for bit (the coarse weights agree to 1e-9, so the fine samples are
     the same), the coarse pass's direct maps to fp32 round-off, its normal within what two precise evaluations differ by.  A fog checkpoint (random init: every
-    sample relevant) switches the refinement off by itself — decided once per checkpoint upload on the first launch's count, then frozen."""
+    sample relevant) switches the refinement off by itself — decided once per checkpoint, by the route's probe (iblnerf_decide_route: here <= 4 096 strided rays of the
+    first call), then frozen: the second call of a context is the first one bit for bit."""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
     out = {}
     for label, routing in (("selected", ()), ("est6", ("estimates_6slot",)), ("all", ("coarse_density_all_points",))):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
-        assert r.estimate_policy(0) == (False, False)
+        assert r.estimate_policy(0) == (False, False) and r.route is None
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
         sel, cand = r.last_selection()
-        # the density estimates run in plain f16 once the network's first launch has compared them with the f16 + 2 fp6 ones (api.cpp check_estimates)
-        assert r.estimate_policy(0) == r.estimate_policy(1) == {"selected": (True, True), "est6": (False, False), "all": (False, False)}[label]
+        # the density estimates run in plain f16 once the route's probe has compared them with the f16 + 2 fp6 ones (api.cpp check_estimates)
+        assert r.route["decided"] and r.route["probe_rays"] == 4096
+        assert r.estimate_policy(0) == r.estimate_policy(1) == {"selected": (True, True), "est6": (True, False), "all": (True, False)}[label]
+        assert r.route["estimates_plain_f16"] == [label == "selected"] * 2 and not r.route["tripped"] and r.trips == 0
+        assert ("coarse  offsets    estimate" in r.describe_route()) == (label != "all") and ("predicted range" in r.describe_route()) == (label != "all")
         again = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                      # the compaction's order is whatever the atomics give: results are not
-        # (the first launch of a checkpoint estimates whole batches, later ones in z-chunks: a sample behind a transmittance of 1e-12 then weighs exactly zero
-        # instead of 1e-17 — every map the same bit for bit, the per-sample weights to 1e-15)
-        assert all(torch.equal(again[k], out[label][k]) for k in again if k != "weights") and r.last_selection() == (sel, cand)
-        assert float((again["weights"] - out[label]["weights"]).abs().max()) <= 1e-15
+        assert all(torch.equal(again[k], out[label][k]) for k in again) and r.last_selection() == (sel, cand)      # (nothing is decided inside a render call: no first-call effect)
         executed, algorithmic = r.last_executed_flops(), r.last_mlp_time()[2]
         # (algorithmic: every sample of every query priced as the reference evaluates it; executed: what the launches ran — FLOP_* of csrc/api.cpp)
         full, trunk, refl = 1591552.0, 982528.0, 1458944.0
         assert algorithmic == n * ((64 + 192) * full + (256 + 768) * trunk + 128 * refl)
         if label != "all":
-            want = n * (64 + 256 + 768 + 128 + 192) * trunk + 0.0              # the fine grid's offset queries as they are; estimates on the trunk ...
-            assert want < executed <= want + sel * (full + trunk), (executed, want)      # ... and at most (whole network + 15-slot density) on each selected sample
+            # estimates on the trunk: every sample of the main and reflected queries (less what the z-chunks skip), of the offset copies only what lies outside the
+            # main ray's relevant range; at most (whole network + 15-slot density) on each list entry
+            assert 0.5 * algorithmic < executed < 0.95 * algorithmic and executed <= n * (64 + 256 + 768 + 128 + 192) * trunk + sel * (full + trunk), (executed, algorithmic)
             # candidates: 64 samples x (coarse main + 4 offset copies + the reflected ray of each pass) + the fine main query's 192 (about 40 % of which are
-            # relevant) + the fine grid's 4 x 192 offset copies where the first launch found few enough of them relevant (FINE_OFFSET_SELECT_MAX_FRACTION)
-            assert cand in (n * (64 * 7 + 192), n * (64 * 7 + 192 + 768)) and 0.05 * cand < sel < 0.45 * cand, (sel, cand)
-            if cand == n * (64 * 7 + 192):
-                assert executed < 0.98 * algorithmic       # (MAC counts barely differ: the gain is in the estimates' plain-f16 MACs costing 4 matrix slots instead of 6-15)
+            # relevant) + the fine grid's 4 x 192 offset copies; list entries: the selected samples and the offset copies' predicted ranges
+            assert cand == n * (64 * 7 + 192 + 768) and 0.05 * cand < sel < 0.45 * cand, (sel, cand)
         else:
             assert (sel, cand) == (0, 0) and executed == algorithmic + n * 64 * trunk        # (the 15-slot density beside the coarse main query)
     # plain-f16 estimates select (nearly) the same samples as the f16 + 2 fp6 ones, and nothing that is not selected matters: the two renders agree to fp32 round-off
@@ -273,15 +273,15 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
 
 
 def test_estimates_in_z_chunks_change_nothing(R, lut):
-    """api.cpp estimate_chunked: the density estimates of the offset copies and of the fine main query run on the first samples of every (virtual) ray and on the later
-    ones only for rays whose conservative transmittance is still above 1e-12 (the skipped samples get -1e30).  Against IBLNERF_ROUTE_ESTIMATES_WHOLE: the same samples
-    refined, every map bit for bit, the per-sample weights to 1e-15 (exactly zero instead of ~1e-17 behind saturation) — and fewer MACs executed."""
+    """api.cpp estimate_chunked (round 4's route of the offset copies, IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL, and the fine main / reflected queries of every route): the
+    density estimates run on the first samples of every (virtual) ray and on the later ones only for rays whose conservative transmittance is still above 1e-12 (the
+    skipped samples get -1e30).  Against IBLNERF_ROUTE_ESTIMATES_WHOLE: the same samples refined, every map bit for bit, the per-sample weights to 1e-15 (exactly zero
+    instead of ~1e-17 behind saturation) — and fewer MACs executed."""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
     out, sel, flops = {}, {}, {}
-    for label, routing in (("chunks", ()), ("whole", ("estimates_whole",))):
+    for label, routing in (("chunks", ("offsets_estimate_all",)), ("whole", ("offsets_estimate_all", "estimates_whole"))):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
-        r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)                 # (the first launch takes the decisions)
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
         sel[label], flops[label] = r.last_selection(), r.last_executed_flops()
     assert sel["chunks"] == sel["whole"] and flops["chunks"] < 0.97 * flops["whole"], (sel, flops)
@@ -292,18 +292,66 @@ def test_estimates_in_z_chunks_change_nothing(R, lut):
             assert torch.equal(out["chunks"][k], out["whole"][k]), k
 
 
+@pytest.mark.parametrize("name", ["fitted_launch16k", "fitted2_posed4k"])
+def test_offset_copies_predicted_by_the_main_ray_change_nothing(R, lut, name):
+    """Round 5 (api.cpp offsets_on_lists, k_range_points): the samples the MAIN ray of a pass found relevant go to the offset copies' kernel without an estimate;
+    estimates run on the rest only (in front of that range for every copy, behind it for the copies still alive), followed by the copy's own selection.  Against round 4's
+    route (an estimate on every sample of every copy, IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL): every sample that route refined is refined here by the same kernel, the others
+    are clearly empty or behind saturation on either route — every map bit for bit — for a quarter fewer estimate MACs and matrix-slot units.  Both checkpoints, both
+    tables of the fine pass (the second checkpoint's silhouettes and slanted walls are where a copy and its ray disagree most)."""
+    g, sdc, sdf, _, _ = load_golden(name)
+    n = min(8192, g["rays_o"].shape[0])
+    for prec in ("f16x3_mxfp6x", "f16x3_mxfp6"):
+        out, sel, flops, slots = {}, {}, {}, {}
+        for label, routing in (("predicted", ()), ("estimate_all", ("offsets_estimate_all",))):
+            r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec, query_routing=routing)
+            out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], float(g["near"]), float(g["far"]))
+            sel[label], flops[label], slots[label] = r.last_selection(), r.last_executed_flops(), r.last_slot_units()
+            assert r.trips == 0 or name.startswith("fitted2"), r.route        # (a tripwire event moves the estimates to six slots: a different test's subject)
+            assert ("predicted range" in r.describe_route()) == (label == "predicted")
+        if sel["predicted"][1] != sel["estimate_all"][1]:
+            # the second checkpoint from the rotated camera: 43-46 % of the fine grid's offset samples are relevant — above round 4's break-even (0.42: an estimate on
+            # EVERY sample besides), so that route evaluates them whole-batch; below the predicted route's (0.85: an estimate OR an evaluation).  The samples the lists
+            # leave at their estimate are clearly empty or behind saturation: the maps agree to fp32 round-off of a weighted sum
+            assert sel["estimate_all"][1] == n * (64 * 7 + 192) and sel["predicted"][1] == n * (64 * 7 + 192 + 768)
+            for k in out["estimate_all"]:
+                assert rel_linf(out["predicted"][k].nan_to_num(7.0).cpu().numpy(), out["estimate_all"][k].nan_to_num(7.0).cpu().numpy()) <= (2e-6 if "weights" not in k else 1e-7), (prec, k)
+            continue
+        assert sel["predicted"][0] >= sel["estimate_all"][0] and flops["predicted"] < 0.92 * flops["estimate_all"]       # (the predicted ranges hold a few irrelevant samples)
+        # (matrix-slot units: a quarter to a third fewer on the fast table; on the safe table, whose list kernel spends 12 slots per 64 MACs against the estimate's 4, the few
+        # irrelevant samples inside the predicted ranges cost most of what the estimates save — 2 % on the second checkpoint's rotated view)
+        assert slots["predicted"] < (0.95 if prec == "f16x3_mxfp6x" else 1.0) * slots["estimate_all"], (flops, slots)
+        for k in out["estimate_all"]:
+            assert torch.equal(out["predicted"][k].nan_to_num(7.0), out["estimate_all"][k].nan_to_num(7.0)), (prec, k)
+
+
 def test_a_handful_of_rays_decides_nothing(R, lut):
-    """The per-network decisions behind the list refinement (empty space or fog, plain-f16 estimates or not, the fine grid's relevant share) wait for a launch of at
-    least 1 024 rays (api.cpp SELECT_MIN_RAYS): a first call of 64 rays evaluates every sample and leaves them open; the next call of 4 096 takes them."""
+    """The route of a checkpoint (empty space or fog, plain-f16 estimates or not, the fine grid's relevant shares) is measured by iblnerf_decide_route on at least
+    1 024 probe rays — Renderer.render_rays calls it on the first call of that size: a first call of 64 rays evaluates every sample and leaves the route open; the next
+    call of 4 096 decides; from then on every call takes the lists whatever its size.  Loading the same weights again — through the host packer or, as render_decomp
+    does, as device tensors (iblnerf_upload_weights_device: ADVICE r4) — withdraws the route; one imposed by set_route is taken as it is."""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
     small = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
-    assert r.last_selection() == (0, 0) and r.estimate_policy(0) == r.estimate_policy(1) == (False, False)
+    assert r.last_selection() == (0, 0) and r.estimate_policy(0) == r.estimate_policy(1) == (False, False) and r.route is None and not r.get_route()["decided"]
+    assert "NOT decided" in r.describe_route() and "whole batch" in r.describe_route()
+    with pytest.raises(R.B.IblNerfError):
+        r.decide_route(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)          # (a handful of rays must not fix a checkpoint's route)
     big = r.render_rays(g["rays_o"][:4096], g["rays_d"][:4096], 0.5, 8.0)
     sel, cand = r.last_selection()
     assert sel > 0 and cand >= 4096 * (64 * 7 + 192) and r.estimate_policy(0) == r.estimate_policy(1) == (True, True)
+    route = dict(r.route)
+    assert route["decided"] and 0.02 < route["coarse_share"] < 0.3 and 0.2 < route["fine_main_share"] < 0.6 and 0.2 < route["fine_offsets_share"] < 0.85
+    for dev in (False, True):          # another upload of network 0 / 1, by either path: the route is gone with it
+        r.load_weights(1, {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sdf.items()} if dev else sdf)
+        assert r.route is None and not r.get_route()["decided"] and r.estimate_policy(0) == (False, False)
+        r.set_route(route)
+        assert r.get_route()["decided"] and r.estimate_policy(0) == r.estimate_policy(1) == (True, True)
+        assert r.get_route()["fine_offsets_share"] == route["fine_offsets_share"]
     again = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)          # (decided: the small call now takes the lists too)
     assert r.last_selection()[1] >= 64 * (64 * 7 + 192)
+    big2 = r.render_rays(g["rays_o"][:4096], g["rays_d"][:4096], 0.5, 8.0)      # (the imposed route is the measured one: the same launches, bit for bit)
+    assert all(torch.equal(big[k], big2[k]) for k in big)
     for k in ("target_normal_map", "target_normal_map0", "depth_map", "depth_map0"):
         assert torch.equal(small[k], again[k]) and torch.equal(small[k], big[k][:64]), k
     for k in small:
@@ -350,10 +398,16 @@ def test_generated_points_are_the_batch_bit_for_bit(R, lut, prec, routing):
 
 
 def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
-    """api.cpp check_estimates, the refusing side.  A network whose last trunk layer cancels large terms — four copies of one active layer-6 feature h weighted
-    +3K, -K, -K, -K in every row of positions_linears.7 on top of the fitted weights, K = 12004.4: fp32 and every scheme with a second term per operand see the
-    weights' low bits, one f16 term rounds 3K and K to 36000 and 12008 and shifts every pre-activation of the layer by -24 h — fails the comparison on its first
-    launch and keeps the f16 + 2 fp6 estimates (the coarse pass then equals the estimates_6slot routing bit for bit); the untouched fine network passes.
+    """The guards of the estimate route on a network built to break them.  Its last trunk layer cancels large terms — four copies of one active layer-6 feature h
+    weighted +3K, -K, -K, -K in every row of positions_linears.7 on top of the fitted weights, K = 12004.4: fp32 and the three-product schemes see the weights' low
+    bits; one f16 term rounds 3K and K to 36000 and 12008 and shifts every pre-activation of the layer by -24 h; the f16 + 2 fp6 form holds the residuals -3.6 / +4.4
+    to three mantissa bits — better, still off by more than the selection margin on some samples.
+    (i)  The route's probe (api.cpp check_estimates) refuses plain-f16 estimates for this network on sight; the untouched fine network passes.
+    (ii) The TRIPWIRE (round 5; MlpArgs::trip_margin, k_select_points' audit): every list launch compares the densities it writes with the estimates they replace —
+         those of the samples it refines and of one in 64 of the samples dropped as clearly empty.  On this network the f16 + 2 fp6 estimates fail it too: the lists go
+         off (route.tripped = 2), the wrapper repeats the call, and the result is the all-points route's, bit for bit.
+    (iii) The probe may not have SEEN the bad region: a route that claims plain-f16 estimates is imposed (as a probe elsewhere in the scene would have decided it); the
+         first render trips twice — estimates to six slots, then lists off — and ends on the same result; later calls stay there.
     (The density head itself runs on the VALU from fp32 weights in every kernel: the cancellation has to sit in a matrix layer.)"""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
@@ -374,18 +428,53 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
         sd["positions_linears.6.bias"][b] = sd["positions_linears.6.bias"][a]
         sd["positions_linears.7.weight"][:, b] -= K
     sd["positions_linears.7.weight"][:, a] += 3 * K
+    ro, rd = g["rays_o"][:n], g["rays_d"][:n]
+    whole = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=("coarse_density_all_points",)).render_rays(ro, rd, 0.5, 8.0)
+    # (i), (ii)
+    r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    r.decide_route(ro, rd, 0.5, 8.0)
+    assert r.estimate_policy(0) == (True, False) and r.estimate_policy(1) == (True, True) and r.route["tripped"] == 0 and r.route["coarse_share"] < 0.3
+    got = r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.trips == 2 and r.route["tripped"] == 2 and r.last_selection() == (0, 0) and r.range_fallbacks == 0        # (the fine network's plain-f16 estimates go first, then the lists)
+    assert "lists off" in r.describe_route() and "estimate:" not in r.describe_route()
+    for k in got:
+        assert torch.equal(got[k], whole[k]), k
+    # (iii)
+    good = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    good.render_rays(ro, rd, 0.5, 8.0)
+    assert good.trips == 0 and good.route["estimates_plain_f16"] == [True, True]
+    r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    r.set_route(good.route)
+    assert r.estimate_policy(0) == (True, True)
+    got = r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.trips == 2 and r.route["tripped"] == 2 and r.estimate_policy(0) == r.estimate_policy(1) == (True, False) and r.range_fallbacks == 0
+    for k in got:
+        assert torch.equal(got[k], whole[k]), k
+    r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.trips == 2
+
+
+def test_the_tripwire_moves_the_second_checkpoint_to_six_slot_estimates(R, lut):
+    """The second fitted checkpoint passes the probe's comparison on 4 096 seeded pixels (plain-f16 estimates within half the selection margin on all of their
+    samples) — and some launch of the whole frame then refines a positive density whose plain-f16 estimate lay below -1 (the worst plain-f16 error measured on this
+    network is 1.45 against a margin of 2): the tripwire fires once, the estimates move to the f16 + 2 fp6 form (which also takes z-chunks and the offset copies'
+    ranges: six matrix slots per estimate instead of four, nothing else changes), the call is repeated, and the frame is the estimates_6slot routing's, bit for bit.
+    (Round 4 took that decision once, on the first launch, and never looked again.)"""
+    from ibl_nerf_amd import dist as D
+    g, sdc, sdf, _, _ = load_golden("fitted2_launch4k")
+    K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
     out = {}
     for label, routing in (("default", ()), ("est6", ("estimates_6slot",))):
-        r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
-        out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
-        sel, cand = r.last_selection()
-        assert cand in (n * (64 * 7 + 192), n * (64 * 7 + 192 + 768)) and 0 < sel < 0.5 * cand, (sel, cand)     # (still a scene with surfaces: the refinement itself stays on)
-        if label == "default":
-            assert r.estimate_policy(0) == (True, False) and r.estimate_policy(1) == (True, True)
-        assert r.range_fallbacks == 0
-    for k in out["default"]:
-        if k.endswith("0"):
-            assert torch.equal(out["default"][k], out["est6"][k]), k
+        r = make_renderer(R, g, sdc, sdf, lut, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        route = D.decide_on_frame(r, 800, 800, K, c2w, 0.5, 8.0)
+        assert route["estimates_plain_f16"] == [label == "default"] * 2 and route["tripped"] == 0
+        ro, rd = r.get_rays(800, 800, K, c2w)
+        out[label] = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
+        assert r.trips == (1 if label == "default" else 0) and r.route["tripped"] == (1 if label == "default" else 0) and r.last_selection()[0] > 0
+        assert r.estimate_policy(0) == r.estimate_policy(1) == (True, False) and "predicted range" in r.describe_route()
+    for k in out["est6"]:
+        assert torch.equal(out["default"][k].nan_to_num(7.0), out["est6"][k].nan_to_num(7.0)), k
 
 
 def test_fitted_wide_error_class_of_f16x3_main(R, lut):

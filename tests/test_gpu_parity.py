@@ -338,15 +338,16 @@ def test_tile_sharding_matches_full_frame(R, lut):
     K = np.array([[9.0, 0, 6], [0, 9.0, 5], [0, 0, 1]], dtype=np.float32)
     c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
     full = D.render_frame(r, H, W, K, c2w, 0.5, 8.0)
-    parts = []
-    for rank in range(3):
-        row0, n = D.tile_rows(H, rank, 3)
-        ro, rd = r.get_rays(H, W, K, c2w, row0, n)
-        m = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
-        parts.append(D.pack_maps(m, D.EXPORT_KEYS, n, W)[0])
-    cat = torch.cat(parts, 0)
     buf, layout = D.pack_maps({k: v.reshape(H * W, -1) for k, v in full.items()}, D.EXPORT_KEYS, H, W)
-    assert torch.equal(cat, buf)
+    for partition in ("contiguous", "interleaved"):
+        cat = torch.empty_like(buf)
+        for rank in range(3):
+            rows = D.tile_row_indices(H, rank, 3, partition)
+            ro, rd = r.get_rays(H, W, K, c2w)
+            sl = slice(rows.start, rows.stop, rows.step)
+            m = r.render_rays(ro[sl].reshape(-1, 3), rd[sl].reshape(-1, 3), 0.5, 8.0)
+            cat[sl] = D.pack_maps(m, D.EXPORT_KEYS, len(rows), W)[0]
+        assert torch.equal(cat, buf), partition
     ora = O.render_decomp(H, W, K, sdc, sdf, lut, 0.5, 8.0, c2w=c2w)
     assert rel_linf(full["albedo_map"].cpu().numpy(), ora["albedo_map"]) <= 2e-4
     assert rel_linf(full["target_normal_map"].cpu().numpy(), ora["target_normal_map"]) <= 1e-3

@@ -727,6 +727,20 @@ def test_tile_rows_partition():
             assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
     with pytest.raises(ValueError):
         D.tile_rows(10, 2, 2)
+    # the interleaved partition (the default since round 5): rank r takes rows r, r + world, ...; together every row once, sizes within one of each other
+    for H in (1, 7, 100, 800, 801):
+        for world in (1, 2, 3, 8):
+            tiles = [list(D.tile_row_indices(H, r, world)) for r in range(world)]
+            assert sorted(sum(tiles, [])) == list(range(H)) and all(t == list(range(r, H, world)) for r, t in enumerate(tiles))
+            assert max(map(len, tiles)) - min(map(len, tiles)) <= 1 and len(tiles[0]) == max(map(len, tiles))
+            assert [list(D.tile_row_indices(H, r, world, "contiguous")) for r in range(world)] == [list(range(a, a + n)) for a, n in (D.tile_rows(H, r, world) for r in range(world))]
+    with pytest.raises(ValueError):
+        D.tile_row_indices(10, 0, 2, "diagonal")
+    # slice_gt_rows with a row range = the rows of the [H, W] image
+    import numpy as _np
+    img = _np.arange(6 * 4 * 3).reshape(6 * 4, 3)
+    assert _np.array_equal(D.slice_gt_rows({"m": img}, 4, range(1, 6, 2))["m"], img.reshape(6, 4, 3)[1::2].reshape(-1, 3))
+    assert _np.array_equal(D.slice_gt_rows({"m": img}, 4, 2, 3)["m"], img[8:20])
 
 
 def test_auxiliary_network_blob_and_checkpoint(tmp_path):
