@@ -25,7 +25,7 @@ EXPORTS = [
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
     "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt",
-    "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units",
+    "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units", "iblnerf_trunk_density_fp32",
 ]
 
 
@@ -47,7 +47,7 @@ MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE, ROUTE_POINT_BATCH, ROUTE_COARSE_MAIN_22BIT, ROUTE_USER_TRUNK_P, ROUTE_FINE_OFFSETS_PRECISE, ROUTE_COARSE_DENSITY_ALL_POINTS = 1, 2, 4, 8, 16, 32, 64, 128   # iblnerf_options.query_routing bits
-ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE, ROUTE_OFFSETS_ESTIMATE_ALL, ROUTE_NO_RESCUE = 256, 512, 1024, 2048
+ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE, ROUTE_OFFSETS_ESTIMATE_ALL, ROUTE_NO_RESCUE, ROUTE_COARSE_DENSITY_15SLOT = 256, 512, 1024, 2048, 4096
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -90,12 +90,14 @@ class Taps(C.Structure):
 class Route(C.Structure):
     """iblnerf_route: the checkpoint's measured route (which queries run as estimate + list, on which estimates)."""
     _fields_ = [("decided", C.c_int32), ("estimates_plain_f16", C.c_int32 * 2), ("tripped", C.c_int32),
-                ("coarse_share", C.c_double), ("fine_main_share", C.c_double), ("fine_offsets_share", C.c_double)]
+                ("coarse_share", C.c_double), ("fine_main_share", C.c_double), ("fine_offsets_share", C.c_double),
+                ("select_margin", C.c_float * 2), ("estimate_error", C.c_float * 2)]
 
     def as_dict(self):
         return {"decided": bool(self.decided), "estimates_plain_f16": [bool(self.estimates_plain_f16[0]), bool(self.estimates_plain_f16[1])],
                 "tripped": int(self.tripped), "coarse_share": float(self.coarse_share), "fine_main_share": float(self.fine_main_share),
-                "fine_offsets_share": float(self.fine_offsets_share)}
+                "fine_offsets_share": float(self.fine_offsets_share), "select_margin": [float(self.select_margin[0]), float(self.select_margin[1])],
+                "estimate_error": [float(self.estimate_error[0]), float(self.estimate_error[1])]}
 
 
 class Outputs(C.Structure):
@@ -177,6 +179,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_network_query.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, C.c_int, FP, FP]
     lib.iblnerf_density_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, FP]
     lib.iblnerf_density_gradient.restype = C.c_int
+    lib.iblnerf_trunk_density_fp32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, FP]
+    lib.iblnerf_trunk_density_fp32.restype = C.c_int
     lib.iblnerf_trunk_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, FP, C.c_float, FP, FP]
     lib.iblnerf_trunk_backward.restype = C.c_int
     lib.iblnerf_trunk_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, FP]

@@ -64,6 +64,7 @@ SOURCES = [
     ("pack_kernels.hip", ["-ffp-contract=off"]),
     ("posdir_kernel.hip", []),
     ("range_kernel.hip", []),
+    ("trunk_fp32_kernel.hip", []),
     ("wgrad_kernel.hip", []),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),

@@ -34,6 +34,11 @@ constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // and offset copies each, scratch/estimate_error.py): plain f16 0.20 / 1.45 at worst (99.99 %: 0.12 / 0.84; 11 % of a density above 10), f16 + 2 fp6 below 1e-2.
 // Widening the margin is nearly free: densities between -2 and -1 are 0.2 % of the samples.
 constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
+// ... the margin is that of a network whose plain-f16 estimates are good to a third of it.  It is MEASURED, per network, by the route's probe (check_estimates): three times the
+// largest |plain-f16 - (f16 + 2 fp6)| estimate difference found where the classification happens (densities within +-8), rounded up to half a unit, never below 2 — so that
+// the tripwire (which fires at half the margin) has a factor 1.5 over anything the probe saw; a network that would need more than MARGIN_MAX keeps the f16 + 2 fp6 estimates
+// (whose own error is below 1e-2) at the base margin.  A wider margin costs the samples between -margin and -2 (0.2 % per unit on the fitted checkpoints), nothing else.
+constexpr float MARGIN_MAX = 6.0f, MARGIN_ZONE = 8.0f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
@@ -74,6 +79,8 @@ struct iblnerf_ctx {
     char* d_stream[N_SLOTS] = {};
     char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision F16_MXFP6, F16_MIXED, F16X3_MXFP6)
     char* d_stream_f16[N_SLOTS] = {};            // f16 (hi, lo) form of d_stream's layout (mlp_precision F16X3, F16X3_MXFP6)
+    float* d_blob32[2] = {};                      // networks 0 / 1 as they are: the fp32 state dict (trunk_fp32_kernel.hip reads the reference's own [out][in] rows)
+    bool density_15slot = false;                  // IBLNERF_ROUTE_COARSE_DENSITY_15SLOT: round 4's coarse density (the 15-slot form also on the lists)
     // [0] activation / input range flag of the MX kernels, [1 + slot] "a weight of this slot is outside the f16 range" (device packer)
     unsigned* d_range_flag = nullptr;
     unsigned* h_range_flag = nullptr;            // pinned snapshot for iblnerf_range_peek
@@ -97,6 +104,8 @@ struct iblnerf_ctx {
     bool est_f16 = true;                          // density estimates behind a list refinement in plain f16 (IBLNERF_ROUTE_ESTIMATES_6SLOT: on the f16 + 2 fp6 form) ...
     bool est_checked[2] = {false, false}, est_ok[2] = {false, false};   // ... once the network's first launch has shown that they are good enough (check_estimates)
     bool est_probe = false;                       // (that check's own plain-f16 launch)
+    float margin[N_SLOTS] = {2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f, 2.f};   // the selection margin of networks 0 / 1 (check_estimates; COARSE_SELECT_MARGIN until measured)
+    float est_error[2] = {-1.f, -1.f};            // ... and the largest plain-f16 estimate error the probe saw near zero density (-1: not measured)
     bool deciding = false;                        // inside iblnerf_decide_route's probe render: the only place a decision of the route is taken
     bool route_decided = false;                   // iblnerf_route.decided
     int tripped = 0;                              // the estimate tripwire has fired since the decision (fold_flags): 1 = the estimates moved to f16 + 2 fp6, 2 = the lists went off
@@ -168,13 +177,14 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->est_whole = (bits & IBLNERF_ROUTE_ESTIMATES_WHOLE) != 0;
     c->offsets_estimate_all = (bits & IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL) != 0;
     c->no_rescue = (bits & IBLNERF_ROUTE_NO_RESCUE) != 0;
+    c->density_15slot = (bits & IBLNERF_ROUTE_COARSE_DENSITY_15SLOT) != 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 4095) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..4095)");
+    if (bits < 0 || bits > 8191) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..8191)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -248,8 +258,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 4095 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..4095), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 8191 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..8191), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -344,6 +354,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
         if (c->d_stream[w]) (void)hipFree(c->d_stream[w]);
         if (c->d_stream_mx[w]) (void)hipFree(c->d_stream_mx[w]);
         if (c->d_stream_f16[w]) (void)hipFree(c->d_stream_f16[w]);
+        if (w < 2 && c->d_blob32[w]) (void)hipFree(c->d_blob32[w]);
     }
     if (c->sel_pts) (void)hipFree(c->sel_pts);
     if (c->sel_index) (void)hipFree(c->sel_index);
@@ -371,6 +382,8 @@ static void reset_route(iblnerf_ctx* c, int slot) {
     c->sel_decided = false; c->sel_on = true; c->coarse_share = -1.0;
     c->fsel_fraction = c->xsel_fraction = -1.0;
     c->est_checked[0] = c->est_checked[1] = c->est_ok[0] = c->est_ok[1] = false;
+    c->margin[0] = c->margin[1] = COARSE_SELECT_MARGIN;
+    c->est_error[0] = c->est_error[1] = -1.f;
 }
 
 static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_floats, const char* who) {
@@ -388,6 +401,10 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     if (want_f16 && !c->d_stream_f16[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_stream_f16[slot], STREAM_BYTES));
     HIP_TRY(c, hipMemcpy(c->d_stream[slot], stream.data(), STREAM_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tables[slot], tab.data(), TAB_BYTES, hipMemcpyHostToDevice));
+    if (slot < 2 && c->opt.mlp_precision != IBLNERF_MLP_BF16X3) {          // the fp32 state dict itself, for the exact-fp32 trunk of the coarse pass's density
+        if (!c->d_blob32[slot]) HIP_TRY(c, hipMalloc((void**)&c->d_blob32[slot], n_floats * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->d_blob32[slot], h_blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (want_mx || want_f16) {
         bool ok = true;                           // f16(W) must be finite: |w| < 65520 and not NaN
         for (size_t i = 0; i < n_floats && ok; ++i) ok = std::fabs(h_blob[i]) < 65504.0f;
@@ -468,6 +485,10 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
     if (wflag) HIP_TRY(c, hipMemsetAsync(wflag, 0, sizeof(unsigned), (hipStream_t)stream));
     HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_stream_f16[which], c->d_tables[which], wflag,
                                    (hipStream_t)stream));
+    if (c->opt.mlp_precision != IBLNERF_MLP_BF16X3) {
+        if (!c->d_blob32[which]) HIP_TRY(c, hipMalloc((void**)&c->d_blob32[which], n_floats * sizeof(float)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_blob32[which], d_blob, n_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     c->mx_ok[which] = true;
     c->have_net[which] = true;
     reset_route(c, which);
@@ -566,14 +587,14 @@ static bool sigma_p_available(const iblnerf_ctx* c, int which) {
 
 // One MLP launch = a kernel FAMILY (which product scheme, which weight stream) and a VARIANT of it (which layers, whole batch or list).  Every launch of a render
 // call is named by such a pair in the route table (plan_main / plan_offsets / plan_reflected below); run_launch executes one.
-enum KernelFamily { K_NONE = -1, K_BF16X3 = 0, K_F16X3, K_MX, K_MX16 };
+enum KernelFamily { K_NONE = -1, K_BF16X3 = 0, K_F16X3, K_MX, K_MX16, K_FP32 };
 struct Launch {
     int kern = K_NONE;
     int variant = 0;
     bool none() const { return kern == K_NONE; }
 };
 static const char* launch_name(const Launch& l) {
-    static const char* fam[] = {"bf16x3", "f16x3", "mx (f16 + 2 fp6)", "mx16 (plain f16)"};
+    static const char* fam[] = {"bf16x3", "f16x3", "mx (f16 + 2 fp6)", "mx16 (plain f16)", "fp32 MFMA"};
     static const char* var[] = {"FULL", "TRUNK", "REFL", "FULL_CI", "REFL_CI", "TRUNK_X (layers 0-1 3 x f16)", "TRUNK_GRAD", "TRUNK_BWD", "TRUNK_FEAT", "TRUNK_BWD_FEAT", "TRUNK_FEAT2",
                                 "TRUNK_BWD_FEAT2", "NET_BWD", "TRUNK_P (15-slot)", "?", "REFL_LIST", "FULL_LIST", "TRUNK_X_LIST", "TRUNK_LIST"};
     static thread_local char buf[96];
@@ -593,6 +614,7 @@ static double launch_slots(const Launch& l) {
     switch (l.kern) {
         case K_BF16X3: case K_F16X3: return 12.0;
         case K_MX16: return 4.0;
+        case K_FP32: return 64.0;         // v_mfma_f32_32x32x2_f32: 1/16 of the f16 rate
         case K_MX: return l.variant == VAR_TRUNK_P ? 15.0 : variant_trunk_x(l.variant) ? 7.5 : 6.0;
         default: return 0.0;
     }
@@ -677,6 +699,36 @@ struct MlpCall {
 static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which, const MlpCall& m) {
     if (l.none()) return c->fail(IBLNERF_ERR_STATE, "internal: a route table row without a kernel was executed");
     if (m.n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
+    if (l.kern == K_FP32) {
+        if (which > 1 || !c->d_blob32[which] || l.variant != VAR_TRUNK || m.gen) return c->fail(IBLNERF_ERR_STATE, "internal: the fp32 trunk serves networks 0 / 1, trunk only, points from memory");
+        TrunkFp32Args f;
+        f.blob = c->d_blob32[which];
+        for (int i = 0; i < 9; ++i) {
+            size_t w, b;
+            blob_offsets(i < 8 ? i : 10, &w, &b);       // positions_linears.0-7, sigma_linear
+            f.w_off[i] = (long)w; f.b_off[i] = (long)b;
+        }
+        f.pts = m.pts; f.n = m.n_pts; f.n_dev = m.n_pts_dev; f.out_index = m.out_index; f.out = m.out; f.out_stride = m.out_stride;
+        std::pair<hipEvent_t, hipEvent_t>* ev32 = nullptr;
+        if (c->profiling) {
+            if (c->ev_used == c->ev_pool.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(c, hipEventCreate(&e0));
+                HIP_TRY(c, hipEventCreate(&e1));
+                c->ev_pool.emplace_back(e0, e1);
+            }
+            ev32 = &c->ev_pool[c->ev_used++];
+            HIP_TRY(c, hipEventRecord(ev32->first, s));
+        }
+        HIP_TRY(c, launch_trunk_fp32(f, c->n_cu, s));
+        if (ev32) HIP_TRY(c, hipEventRecord(ev32->second, s));
+        if (m.n_pts_dev == nullptr) {
+            c->flop_exec += (double)m.n_pts * FLOP_TRUNK;
+            c->slot_units += (double)m.n_pts * FLOP_TRUNK / 128.0 * launch_slots(l);
+        }
+        if (m.count_flops) c->flop_alg += (double)m.n_pts * (m.flop_per_point >= 0.0 ? m.flop_per_point : FLOP_TRUNK);
+        return IBLNERF_OK;
+    }
     MlpArgs a;
     a.stream = l.kern == K_BF16X3 ? c->d_stream[which] : l.kern == K_F16X3 ? c->d_stream_f16[which] : c->d_stream_mx[which];
     a.range_flag = c->d_range_flag;
@@ -737,6 +789,19 @@ int iblnerf_network_query(iblnerf_ctx* c, void* stream, int which, const float* 
                          (long)n_rays * n_samples, d_out))
         return rc;
     return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+int iblnerf_trunk_density_fp32(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out))) return c->fail(IBLNERF_ERR_INVALID, "trunk_density_fp32: bad arguments");
+    if (n_pts == 0) return IBLNERF_OK;
+    if (!c->have_net[which] || !c->d_blob32[which]) return c->fail(IBLNERF_ERR_STATE, "trunk_density_fp32: weights of network %d not uploaded (or an IBLNERF_MLP_BF16X3 context)", which);
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    Launch l;
+    l.kern = K_FP32; l.variant = VAR_TRUNK;
+    MlpCall m;
+    m.pts = d_pts; m.n_pts = (long)n_pts; m.out = d_out;
+    return run_launch(c, (hipStream_t)stream, l, which, m);
 }
 
 int iblnerf_density_gradient(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out) {
@@ -1231,6 +1296,8 @@ static bool lists_possible(const iblnerf_ctx* c, int which, bool keep_all_rows) 
     return sigma_p_available(c, which) && !c->p_all_points && !c->opt.color_independent_to_direction && (c->sel_decided ? c->sel_on : can_decide);
 }
 
+static bool density_fp32(const iblnerf_ctx* c, int which) { return which < 2 && c->d_blob32[which] != nullptr && !c->density_15slot; }
+
 static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, bool keep_all_rows) {
     QueryPlan q;
     const bool can_decide = c->deciding && !keep_all_rows;
@@ -1248,6 +1315,9 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         // auxiliary network's output would; weights, depth and the fine samples are composited from it.  Only the RELEVANT samples need it.
         q.density.kern = K_MX; q.density.variant = VAR_TRUNK_P;
         q.density_on_list = !(c->p_all_points || (c->sel_decided ? !c->sel_on : !can_decide));
+        // ... and on the LIST in exact fp32 (round 5, trunk_fp32_kernel.hip): the samples that place the fine samples, ~5 per ray, at 1/16 of the f16 rate.  (A whole
+        // batch of 64 samples per ray — lists off, fog — keeps the 15-slot form: 40 ms per launch in fp32.)
+        if (q.density_on_list && density_fp32(c, which)) { q.density.kern = K_FP32; q.density.variant = VAR_TRUNK; }
     }
     if (kind == PASS_COARSE && list_ok && !keep_all_rows && (fast || three)) {
         // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
@@ -1256,6 +1326,7 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         q.list = true; q.open = !c->sel_decided; q.share_max = SELECT_MAX_FRACTION;
         q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
         q.density_list.kern = K_MX; q.density_list.variant = VAR_TRUNK_P;
+        if (density_fp32(c, which)) { q.density_list.kern = K_FP32; q.density_list.variant = VAR_TRUNK; }
     }
     if (kind == PASS_FINE && list_ok && c->sel_decided && c->sel_on && (c->fsel_fraction < 0.0 ? can_decide : c->fsel_fraction <= FINE_SELECT_MAX_FRACTION) && !keep_all_rows &&
         (fast || three)) {
@@ -1353,7 +1424,7 @@ static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, const Launch& est, in
         if (s1 <= s0) continue;
         const bool first = k == 0;
         if (!first) HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, s0, s1, COARSE_SELECT_MARGIN, t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
+        HIP_TRY(c, launch_chunk_points(ro, rd, z, z_stride, c->sig4, noise, R, S, s0, s1, c->margin[which], t_min, c->sel_pts, c->sel_index, c->sel_count, s, offsets, eps,
                                        first, FLOP_TRUNK, list_slots(est)));
         MlpCall m;
         m.pts = c->sel_pts; m.pts_per_ray = S; m.n_pts = nv * (s1 - s0); m.out = c->sig4; m.count_flops = false; m.n_pts_dev = first ? nullptr : c->sel_count; m.out_index = c->sel_index;
@@ -1375,12 +1446,17 @@ static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts,
     rc = run_mlp(c, s, VAR_TRUNK, which, c->pts, nullptr, S, n_pts, c->sig4 + n_pts, 1, Q_ESTIMATE, nullptr, false);
     c->est_probe = false;
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->sel_count + 6, 0, sizeof(int), s));
-    HIP_TRY(c, launch_compare_estimates(c->sig4 + n_pts, c->sig4, n_pts, COARSE_SELECT_MARGIN, c->sel_count + 6, s));
-    int bad = 0;
-    HIP_TRY(c, hipMemcpyAsync(&bad, c->sel_count + 6, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(c->sel_count + 6, 0, 2 * sizeof(int), s));
+    HIP_TRY(c, launch_compare_estimates(c->sig4 + n_pts, c->sig4, n_pts, COARSE_SELECT_MARGIN, MARGIN_ZONE, c->sel_count + 6, s));
+    int res[2] = {0, 0};                           // [0] overshoots beyond the conservative transmittance's allowance, [1] the bits of the largest error in the zone
+    HIP_TRY(c, hipMemcpyAsync(res, c->sel_count + 6, sizeof res, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->est_ok[which] = bad == 0;
+    float err;
+    std::memcpy(&err, &res[1], sizeof err);
+    c->est_error[which] = err;
+    const float margin = std::max(COARSE_SELECT_MARGIN, std::ceil(3.0f * err * 2.0f) / 2.0f);
+    c->est_ok[which] = res[0] == 0 && margin <= MARGIN_MAX;
+    c->margin[which] = c->est_ok[which] ? margin : COARSE_SELECT_MARGIN;
     return IBLNERF_OK;
 }
 
@@ -1419,7 +1495,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
         HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)n * RAW_CH * sizeof(float), s));
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += n;
-        HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
+        HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
                                         false, 0.f, c->raw, RAW_CH, variant_flops(q.on_list.variant) + (q.density_list.none() ? 0.0 : FLOP_TRUNK), c->main_range, nullptr,
                                         list_slots(q.on_list) + list_slots(q.density_list)));
         if (q.open) {     // the probe: does this network have empty space and surfaces, or is it fog?  / how many of the fine samples are relevant?
@@ -1433,7 +1509,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
         if (q.list) {
             MlpCall m;
             m.pts = c->sel_pts; m.dirs = p.rd; m.pts_per_ray = S; m.n_pts = n; m.out = c->raw; m.count_flops = false; m.n_pts_dev = c->sel_count; m.out_index = c->sel_index;
-            m.trip_margin = COARSE_SELECT_MARGIN;
+            m.trip_margin = c->margin[which];
             if ((rc = run_launch(c, s, q.on_list, which, m))) return rc;
             if (!q.density_list.none()) {
                 m.dirs = nullptr; m.out_stride = RAW_CH; m.trip_margin = 0.0f;
@@ -1458,7 +1534,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
             // transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest is compacted, evaluated and scattered over raw[..., 0].
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
             c->sel_candidates += n;
-            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->raw, RAW_CH, p.noise, R, S, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->raw, RAW_CH, p.noise, R, S, c->margin[which], COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
                                             c->sel_count, s, false, 0.f, nullptr, 0, FLOP_TRUNK, c->main_range, nullptr, list_slots(q.density)));
             if (!c->sel_decided) {     // (the probe, in a mode whose main query takes no list)
                 long n_sel = 0;
@@ -1500,13 +1576,13 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         MlpCall est = refine;
         // 1: the predicted range, straight to the query's kernel (no estimate underneath: no tripwire)
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, COARSE_SELECT_MARGIN, CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
+        HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
                                        FLOP_TRUNK, list_slots(q.on_list), true));
         if ((rc = run_launch(c, s, q.on_list, which, refine))) return rc;
         // 2, 3: estimates in front of it, and behind it where a copy is still alive
         for (int mode = 2; mode <= 3; ++mode) {
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, COARSE_SELECT_MARGIN, CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count,
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count,
                                            s, FLOP_TRUNK, list_slots(q.est), false));
             if ((rc = run_launch(c, s, q.est, which, est))) return rc;
         }
@@ -1519,7 +1595,7 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         if ((rc = run_launch(c, s, q.est, which, m))) return rc;
     }
     HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-    HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, nullptr, R, S, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index, c->sel_count, s, true, eps,
+    HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, nullptr, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s, true, eps,
                                     nullptr, 0, FLOP_TRUNK, nullptr, q.predicted ? c->main_range : nullptr, list_slots(q.on_list)));
     if (share) {      // the probe: (predicted +) selected share of the 4 R S samples
         unsigned long long now = 0;
@@ -1528,7 +1604,7 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         *share = (double)(now - entries_before) / (double)n4;
         if (*share > q.share_max) return IBLNERF_OK;      // (the caller runs the whole batch instead)
     }
-    refine.trip_margin = COARSE_SELECT_MARGIN;
+    refine.trip_margin = c->margin[which];
     return run_launch(c, s, q.on_list, which, refine);
 }
 
@@ -1589,11 +1665,11 @@ static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R,
     HIP_TRY(c, hipMemsetAsync(c->refl_raw, 0, (size_t)R * Sc * REFL_CH * sizeof(float), s));
     HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
     c->sel_candidates += R * Sc;
-    HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, COARSE_SELECT_MARGIN, q.t_min, c->sel_pts, c->sel_index,
+    HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, c->margin[which], q.t_min, c->sel_pts, c->sel_index,
                                     c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL, nullptr, nullptr, list_slots(q.on_list)));
     MlpCall l;
     l.pts = c->sel_pts; l.dirs = c->refl_d; l.pts_per_ray = Sc; l.n_pts = R * Sc; l.out = c->refl_raw; l.count_flops = false; l.n_pts_dev = c->sel_count; l.out_index = c->sel_index;
-    l.trip_margin = COARSE_SELECT_MARGIN;
+    l.trip_margin = c->margin[which];
     return run_launch(c, s, q.on_list, which, l);
 }
 
@@ -1657,13 +1733,14 @@ static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const fl
         const Launch est = pick_kernel(c, 0, VAR_TRUNK, Q_ESTIMATE, false);
         Launch p15;
         p15.kern = K_MX; p15.variant = VAR_TRUNK_P;
+        if (density_fp32(c, 0)) { p15.kern = K_FP32; p15.variant = VAR_TRUNK; }
         MlpCall m;
         m.pts = c->pts; m.pts_per_ray = Sc; m.n_pts = n; m.out = c->sig4;
         if ((rc = run_launch(c, s, est, 0, m))) return rc;
         est_ran = true;
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += n;
-        HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, COARSE_SELECT_MARGIN, COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+        HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, c->margin[0], COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
                                         false, 0.f, nullptr, 0, FLOP_TRUNK, nullptr, nullptr, list_slots(p15)));
         if (!c->sel_decided) {      // (the probe: this is also where a checkpoint's refinement decision is taken when no full coarse pass ever runs)
             long n_sel = 0;
@@ -1675,7 +1752,7 @@ static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const fl
         if (c->sel_on) {
             MlpCall l;
             l.pts = c->sel_pts; l.pts_per_ray = Sc; l.n_pts = n; l.out = c->sig4; l.count_flops = false; l.n_pts_dev = c->sel_count; l.out_index = c->sel_index;
-            l.trip_margin = COARSE_SELECT_MARGIN;
+            l.trip_margin = c->margin[0];
             return run_launch(c, s, p15, 0, l);
         }
     }
@@ -1941,6 +2018,7 @@ static void fill_route(const iblnerf_ctx* c, iblnerf_route* r) {
     r->coarse_share = c->coarse_share;
     r->fine_main_share = c->fsel_fraction;
     r->fine_offsets_share = c->xsel_fraction;
+    for (int w = 0; w < 2; ++w) { r->select_margin[w] = c->margin[w]; r->estimate_error[w] = c->est_error[w]; }
 }
 
 int iblnerf_get_route(iblnerf_ctx* c, iblnerf_route* out) {
@@ -1962,6 +2040,10 @@ int iblnerf_set_route(iblnerf_ctx* c, const iblnerf_route* r) {
     // (a share that was not measured switches its list off: 2.0 is above every threshold)
     c->fsel_fraction = r->fine_main_share >= 0.0 ? r->fine_main_share : 2.0;
     c->xsel_fraction = r->fine_offsets_share >= 0.0 ? r->fine_offsets_share : 2.0;
+    for (int w = 0; w < 2; ++w) {
+        c->margin[w] = (r->select_margin[w] >= COARSE_SELECT_MARGIN && r->select_margin[w] <= MARGIN_MAX) ? r->select_margin[w] : COARSE_SELECT_MARGIN;
+        c->est_error[w] = r->estimate_error[w];
+    }
     return IBLNERF_OK;
 }
 
@@ -1998,8 +2080,8 @@ int iblnerf_describe_route(iblnerf_ctx* c, char* buf, size_t n) {
         va_end(ap);
         t += line;
     };
-    add("route: %s; estimates plain f16: coarse net %d, fine net %d%s; relevant shares on the probe: coarse grid %.3f, fine main %.3f, fine offsets %.3f\n",
-        c->route_decided ? "decided" : "NOT decided (every query evaluates all of its samples)", (int)est_plain(c, 0), (int)est_plain(c, 1), c->tripped == 2 ? " (tripwire fired twice: lists off)" : c->tripped ? " (tripwire fired)" : "",
+    add("route: %s; estimates plain f16: coarse net %d (margin %.1f), fine net %d (margin %.1f)%s; relevant shares on the probe: coarse grid %.3f, fine main %.3f, fine offsets %.3f\n",
+        c->route_decided ? "decided" : "NOT decided (every query evaluates all of its samples)", (int)est_plain(c, 0), (double)c->margin[0], (int)est_plain(c, 1), (double)c->margin[1], c->tripped == 2 ? " (tripwire fired twice: lists off)" : c->tripped ? " (tripwire fired)" : "",
         c->coarse_share, c->fsel_fraction, c->xsel_fraction);
     const bool fine = c->opt.n_importance > 0;
     const int fine_net = c->have_net[1] ? 1 : 0;

@@ -214,7 +214,8 @@ hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const f
                                double flop_per_point, double slots_per_point);
 
 // counts into *bad the samples on which estimate `a` (plain f16) is half-way to a wrong k_select_points decision against estimate `b` (f16 + 2 fp6)
-hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, int* bad, hipStream_t s);
+// ... and into bad[1] the bits of the largest |a - b| among the samples with |b| <= zone (bad[0..1] zeroed by the caller)
+hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, float zone, int* bad, hipStream_t s);
 
 // iblnerf_layer_ranges (range_kernel.hip): largest |value| of each of a network's 15 wide activations on n points; blob = the fp32 state dict in device memory
 struct LayerRangeArgs {
@@ -229,6 +230,19 @@ struct LayerRangeArgs {
 hipError_t launch_layer_ranges(const LayerRangeArgs& a, hipStream_t s);
 
 hipError_t launch_posdir_mlp(const PosDirArgs& a, hipStream_t s);
+
+// The trunk (positions_linears.0-7 + sigma_linear) in exact fp32 on v_mfma_f32_32x32x2_f32 (trunk_fp32_kernel.hip), whole batch or a compact list
+struct TrunkFp32Args {
+    const float* blob;           // the network's state dict in device memory, fp32, the reference's own [out][in] layout
+    long w_off[9], b_off[9];     // float offsets of positions_linears.0-7 and sigma_linear (pack.cpp: blob_offsets, layers 0-7 and 10)
+    const float* pts;            // [n, 3]
+    long n;                      // points, or the bound that sizes the launch when n_dev is given
+    const int* n_dev;            // a list: its length in device memory (or null)
+    const int* out_index;        // a list: point i -> out[out_index[i] * out_stride] (or null: out[i * out_stride])
+    float* out;
+    int out_stride;
+};
+hipError_t launch_trunk_fp32(const TrunkFp32Args& a, int n_cu, hipStream_t s);
 
 // Weight gradient of the trunk from the backward kernel's operand stash (wgrad_kernel.hip; layout.h: STASH_*).
 struct WgradGemm {

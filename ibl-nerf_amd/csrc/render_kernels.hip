@@ -863,11 +863,18 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float*
 // Is a plain-f16 density estimate good enough for k_select_points on this network?  Two estimates of the same n samples (b: the f16 + 2 fp6 form, error < 1e-2);
 // counts the samples on which `a` is half-way to a wrong decision: a positive density estimated below -margin / 2, or a density overshot by more than the
 // conservative transmittance allows for (0.75 a - margin > b).
-__global__ void k_compare_estimates(const float* __restrict__ a, const float* __restrict__ b, long n, float margin, int* __restrict__ bad) {
+// Round 5: the first of the two (a positive density estimated below -margin / 2) became a MEASUREMENT — bad[1] receives the bits of the largest |a - b| among the
+// samples whose density b lies within +-zone, where the classification "clearly empty or not" happens; api.cpp check_estimates sets the network's margin to three times it.
+__global__ void k_compare_estimates(const float* __restrict__ a, const float* __restrict__ b, long n, float margin, float zone, int* __restrict__ bad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool wrong = i < n && ((b[i] > 0.0f && a[i] < -0.5f * margin) || (b[i] > 0.0f && 0.75f * a[i] - margin > b[i]));
+    const bool wrong = i < n && b[i] > 0.0f && 0.75f * a[i] - margin > b[i];
     const unsigned long long m = __ballot(wrong);
     if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(bad, __popcll(m));
+    float err = (i < n && fabsf(b[i]) <= zone) ? fabsf(a[i] - b[i]) : 0.0f;
+    if (!(err < 1e30f)) err = 1e30f;                      // (a NaN / inf estimate: refuse)
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) err = fmaxf(err, __shfl_xor(err, dd));
+    if ((threadIdx.x & 63) == 0 && err > 0.0f) atomicMax(reinterpret_cast<unsigned*>(bad + 1), __builtin_bit_cast(unsigned, err));      // (non-negative floats order like their bits)
 }
 
 template <int NPL, bool OFFSETS>
@@ -1429,9 +1436,9 @@ hipError_t launch_range_points(const float* rays_o, const float* rays_d, const f
     return hipGetLastError();
 }
 
-hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, int* bad, hipStream_t s) {
+hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, float zone, int* bad, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_compare_estimates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, margin, bad);
+    hipLaunchKernelGGL(k_compare_estimates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, margin, zone, bad);
     return hipGetLastError();
 }
 

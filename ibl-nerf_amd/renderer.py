@@ -437,8 +437,13 @@ class Renderer:
     # shows weights 1.2-1.9e-4, depth / albedo / roughness / irradiance <= 1.2e-4, normal 1e-4 .. 8e-4 (the rotated camera); the second, sharper one
     # weights 1.1-1.8e-3, albedo 1.7-3.7e-4 from either camera.  `weights` — the one output that sees the fine main query's density error unaveraged —
     # separates the two by a factor of six on every subset; the limits sit in the middle of that gap (log scale).
-    CAL_LIMITS = {"weights": 5e-4, "depth_map": 1.5e-4, "albedo_map": 1.5e-4, "roughness_map": 1.5e-4, "irradiance_map": 1.5e-4, "target_normal_map": 1.5e-3}
-    CAL_MAX_SHARE_ABOVE_1E3 = {"target_normal_map": 3e-3, "weights": 1e-3}
+    # Round 5 tightened the NORMAL's two limits (1.5e-3 -> 4e-4, 3e-3 -> 3e-4 of the probe's rays) on a new yardstick, the fp32 C restatement's own distance from the
+    # reference on the same rays (tests/golden/c_restatement_column.json): from the first checkpoint's rotated camera the fast table left 6 of 4 096 rays above 1e-3 on
+    # the normal where fp32 arithmetic leaves 1 and the safe table 1 — and the probe sees it (FAST vs SAFE: 99.9 % at 5e-4 .. 1.4e-3, 0.05 - 0.24 % of the rays above
+    # 1e-3, against 1.0e-4 .. 1.6e-4 and none in the frontal view).  The other limits are round 4's.  The third, hold-out checkpoint (scene 3) lands within 20 % of the
+    # `weights` limit on either side depending on the probe: near a threshold either table serves, and both hold the launch-scale rules there.
+    CAL_LIMITS = {"weights": 5e-4, "depth_map": 1.5e-4, "albedo_map": 1.5e-4, "roughness_map": 1.5e-4, "irradiance_map": 1.5e-4, "target_normal_map": 4e-4}
+    CAL_MAX_SHARE_ABOVE_1E3 = {"target_normal_map": 3e-4, "weights": 1e-3}
 
     def _set_routing(self, extra):
         B.check(self.ctx, self.lib.iblnerf_set_query_routing(self.ctx, int(self._routing | extra)))
@@ -480,6 +485,9 @@ class Renderer:
             r.estimates_plain_f16[0], r.estimates_plain_f16[1] = (int(bool(v)) for v in route["estimates_plain_f16"])
             r.tripped = int(route.get("tripped", 0))
             r.coarse_share, r.fine_main_share, r.fine_offsets_share = float(route["coarse_share"]), float(route["fine_main_share"]), float(route["fine_offsets_share"])
+            for w in range(2):
+                r.select_margin[w] = float(route.get("select_margin", [2.0, 2.0])[w])
+                r.estimate_error[w] = float(route.get("estimate_error", [-1.0, -1.0])[w])
         B.check(self.ctx, self.lib.iblnerf_set_route(self.ctx, C.byref(r)))
         self.route = self.get_route() if route is not None else None
 
@@ -644,6 +652,14 @@ class Renderer:
         if not lazy and self.out_of_range():
             return self._wide_twin().density_gradient(pts, which)
         return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape)
+
+    def trunk_density_fp32(self, pts, which=0):
+        """Raw density of network `which` at pts [n, 3] in exact fp32 on the matrix cores (iblnerf_trunk_density_fp32) -> [n]."""
+        torch = _torch()
+        pts = _dev_f32(pts, self.device).reshape(-1, 3).contiguous()
+        out = torch.empty((pts.shape[0],), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_trunk_density_fp32(self.ctx, self._stream(), int(which), pts.data_ptr(), pts.shape[0], out.data_ptr()))
+        return out
 
     def trunk_features(self, pts, which=0):
         """positions_linears.0-7 (ibl_nerf.py:160-170): the 256 post-ReLU trunk features every head of IBLNeRF.forward reads, [..., 256]."""

@@ -138,6 +138,10 @@ enum {
                                                  every copy, behind it for the copies that have not saturated by then), followed by the copy's own selection among them.
                                                  Every sample is still either evaluated by the query's kernel or judged on an estimate of its own: the prediction decides
                                                  cost, never a result (against this bit: the same samples and more refined; maps agree to ~1e-7) */
+    IBLNERF_ROUTE_COARSE_DENSITY_15SLOT = 4096, /* round 4's density of the coarse pass's relevant samples: the 15-slot form (operands to ~2^-26).  Default since round 5: EXACT
+                                                 fp32 on v_mfma_f32_32x32x2_f32 (csrc/trunk_fp32_kernel.hip: fp32 operands, products and accumulation — the arithmetic the
+                                                 reference runs; 1/16 of the f16 rate on ~5 of a ray's 64 coarse samples).  These weights place the fine samples: the
+                                                 15-slot form's 1e-6 .. 1.2e-5 on a coarse weight moved one ray's normal by 8.6e-3, fp32's 2e-6 does not */
     IBLNERF_ROUTE_NO_RESCUE = 2048,           /* no second, 15-slot evaluation of the fine pass's densities on the rays k_pass_a flags as threshold-critical (api.cpp rescue) */
     IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
                                                  f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
@@ -166,7 +170,12 @@ typedef struct iblnerf_route {
     double coarse_share;               /* share of the probe's coarse-grid samples that were relevant (neither clearly empty nor behind saturation); lists are on for
                                           the coarse main query, the coarse grid's offset copies and the reflected rays iff it is <= 0.30.  -1: not measured (lists off) */
     double fine_main_share;            /* likewise the fine main query (on a list iff <= 0.60) */
-    double fine_offsets_share;         /* likewise the fine grid's offset copies (on lists iff <= 0.42, or 0.55 where the mode refines them on three f16 products) */
+    double fine_offsets_share;         /* likewise the fine grid's offset copies (on lists iff <= 0.85 with the main ray's prediction; without it 0.42, or 0.55 where the mode
+                                          refines them on three f16 products) */
+    float select_margin[2];            /* per network: a sample whose density estimate lies below -select_margin is "clearly empty" (alpha = 0 exactly whatever the estimate's
+                                          error).  Measured by the probe: three times the largest |plain-f16 - (f16 + 2 fp6)| estimate difference it found at densities
+                                          within +-8, rounded up to half a unit, at least 2; a network that would need more than 6 keeps f16 + 2 fp6 estimates at 2 */
+    float estimate_error[2];           /* ... that largest difference (-1: not measured) */
 } iblnerf_route;
 /* Measures and freezes the route on n_rays probe rays (device pointers; 1 024 <= n_rays <= options.max_rays_per_launch; scalar planes): one render of them whose
  * outputs are discarded, with three stream synchronisations.  Needs the networks and the LUT uploaded.  *out (nullable) receives the result. */
@@ -263,6 +272,11 @@ int iblnerf_network_query(iblnerf_ctx* ctx, void* stream, int which, const float
  * transposed weight stream, the skip layer's encoding columns, and the derivative of the positional encoding.
  * d_pts [n_pts, 3] -> d_out [n_pts, 4] = (sigma, d sigma / d x, d sigma / d y, d sigma / d z). */
 int iblnerf_density_gradient(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out);
+/* The raw density (sigma_linear of the trunk, ibl_nerf.py:154-176, :200) of network `which` at n_pts points in EXACT fp32: fp32 operands, products and accumulation on
+ * v_mfma_f32_32x32x2_f32 (csrc/trunk_fp32_kernel.hip; sin / cos of the encoding in double, rounded once) — the arithmetic of the reference's own nn.Linear chain, which
+ * render_rays runs on the coarse pass's relevant samples (the densities that place the fine samples).  d_pts [n_pts, 3] -> d_out [n_pts].  Not for IBLNERF_MLP_BF16X3
+ * contexts (they keep no fp32 copy of the state dict).  1/16 of the f16 matrix rate: 98 ns per point. */
+int iblnerf_trunk_density_fp32(iblnerf_ctx* ctx, void* stream, int which, const float* d_pts, int64_t n_pts, float* d_out);
 
 /* replaces: loss.backward() through the trunk-only query network_query_fn(pts, None, fn) of a training step (train.py:479-481;
  * ibl_nerf.py:236-252, 154-176): given dL / d sigma per point, the gradient with respect to the points AND to the trunk's

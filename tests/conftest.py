@@ -35,7 +35,7 @@ def load_golden(name):
     """Returns (npz, coarse_sd, fine_sd, gt dict, edit dict) for a render fixture."""
     from ibl_nerf_amd import checkpoint as ck
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    if "ckpt" in g.files and str(g["ckpt"]) in ("fitted", "fitted2"):       # the surface-bearing checkpoints (tests/golden/fit_checkpoint.py, scene 1 | 2)
+    if "ckpt" in g.files and str(g["ckpt"]) in ("fitted", "fitted2", "fitted3"):       # the surface-bearing checkpoints (tests/golden/fit_checkpoint.py, scene 1 | 2)
         f = np.load(os.path.join(GOLDEN, str(g["ckpt"]) + "_ckpt.npz"))
         sdc, sdf = ck.blob_to_state_dict(f["coarse"]), ck.blob_to_state_dict(f["fine"])
     else:

@@ -18,6 +18,43 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def fitted_frame(torch, dist, rank, world, backend):
+    """the FITTED checkpoint's 800x800 frame (the list route on: estimates, predicted offset copies, exact-fp32 coarse density) rendered by `world`
+    ranks — interleaved rows, the route measured by every rank on the frame's seeded probe pixels — against the same frame rendered by this rank alone in one call:
+    every export map bit for bit, the same route on every rank, no tripwire event."""
+    import _pkg
+    _pkg.load()
+    from conftest import load_lut_rgb
+    from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R
+    H = W = 800
+    fl = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[fl, 0, 400], [0, fl, 400], [0, 0, 1]], dtype=np.float32)
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    f = np.load(os.path.join(ROOT, "tests", "golden", "fitted_ckpt.npz"))
+    r = R.Renderer(64, 128)
+    r.load_weights(0, ck.blob_to_state_dict(f["coarse"]))
+    r.load_weights(1, ck.blob_to_state_dict(f["fine"]))
+    r.load_lut(load_lut_rgb())
+    full = D.render_frame(r, H, W, K, c2w, 0.5, 8.0)                      # sharded: rows rank, rank + world, ... + one all-gather
+    route, policy = r.get_route(), r.policy
+    assert route["decided"] and route["coarse_share"] < 0.3 and policy["decision"] in ("fast", "safe") and r.trips == 0 and r.range_fallbacks == 0
+    ro, rd = r.get_rays(H, W, K, c2w)
+    whole = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)       # the same frame in one call of this rank (ten launches of 64 000 rays)
+    assert r.last_selection()[0] > 0                                           # (the lists are on: this is the route a frame takes)
+    for k in D.EXPORT_KEYS:
+        assert torch.equal(full[k].reshape(-1), whole[k].reshape(-1)), k
+    # one route, one decision on every rank
+    mine = torch.tensor([route["coarse_share"], route["fine_main_share"], route["fine_offsets_share"], float(sum(route["estimates_plain_f16"])),
+                         float(policy["decision"] == "safe")], dtype=torch.float64)
+    ref = mine.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, mine), (ref, mine)
+    dist.barrier()
+    print("BACKEND %s" % dist.get_backend(), flush=True)
+    print("DIST_OK %d" % rank, flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -35,6 +72,8 @@ def main():
     _pkg.load()
     from conftest import load_golden, load_lut_rgb
     from ibl_nerf_amd import dist as D, renderer as R
+    if "--fitted-frame" in sys.argv:
+        return fitted_frame(torch, dist, rank, world, backend)
     H, W = 9, 16                                           # odd row count: tiles of 5 and 4 rows -> the padded all-gather
     K = np.array([[14.0, 0, 8], [0, 14.0, 4.5], [0, 0, 1]], dtype=np.float32)
     c2w = np.concatenate([np.eye(3), np.array([[0.05], [-0.1], [0.2]])], 1).astype(np.float32)

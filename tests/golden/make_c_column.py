@@ -28,7 +28,9 @@ import iblnerf_cpu as OC  # noqa: E402
 FIXTURES = ["fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitted_posed4k", "fitted2_launch4k", "fitted2_posed4k", "fitted3_launch4k", "fitted3_posed4k",
             "fitted_launch64k"]
 MAPS = ["depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_normal_map", "n_dot_v_map", "weights", "prefiltered_reflected_map", "color_map",
-        "depth_map0", "target_normal_map0", "weights0"]
+        "specular_map", "reflected_radiance_map", "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3", "diffuse_map",
+        "radiance_map"]
+MAPS = MAPS + [k + "0" for k in MAPS]
 SCALE = 2.0 ** 14
 OUT = os.path.join(HERE, "c_restatement_column.npz")
 OUT_JSON = os.path.join(HERE, "c_restatement_column.json")

@@ -1066,6 +1066,10 @@ def main(only=None):
                     ("fitted_posed4k", dict(n_rays=4096, seed=34, weights_every=4, n_nudge=4, posed=True)),
                     ("fitted2_launch4k", dict(n_rays=4096, seed=36, weights_every=4, n_nudge=4, ckpt="fitted2")),   # the second, independent checkpoint (fit_checkpoint.py --scene 2)
                     ("fitted2_posed4k", dict(n_rays=4096, seed=37, weights_every=4, n_nudge=4, posed=True, ckpt="fitted2")),
+                    # the HOLD-OUT checkpoint (round 5, fit_checkpoint.py --scene 3: thin discs, a grazing floor, empty space at -3.5, the sharpest steps), fitted and
+                    # rendered after every threshold of the estimate / list route, the calibration and the launch-scale rules was frozen
+                    ("fitted3_launch4k", dict(n_rays=4096, seed=38, weights_every=4, n_nudge=4, ckpt="fitted3")),
+                    ("fitted3_posed4k", dict(n_rays=4096, seed=39, weights_every=4, n_nudge=4, posed=True, ckpt="fitted3")),
                     ("fitted_launch64k", dict(n_rays=65536, seed=35, n_nudge=2, compact=True)),        # one whole launch of bench.py's frame: ~40 minutes of reference CPU time
                     ("_launch_probe", dict(n_rays=64, seed=33, mode="insert_cfg5", weights_every=1))):
         if only and nm in only:

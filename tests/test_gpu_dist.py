@@ -65,6 +65,16 @@ def test_two_rank_frame_with_overrides_is_bit_identical():
     assert "DIST_OK 0" in out.stdout and "DIST_OK 1" in out.stdout
 
 
+def test_eight_rank_frame_of_the_fitted_checkpoint_is_the_one_rank_frame():
+    """The frame bench.py times — fitted checkpoint, 800x800, default renderer: estimates + lists, predicted offset copies, exact-fp32 coarse density — from EIGHT
+    ranks (interleaved rows, every rank measuring the route on the same seeded probe pixels; here sharing the one GPU over gloo) against the same frame rendered by one
+    rank in one call: every export map bit for bit on every rank, one route and one table decision everywhere (tests/dist_gpu_worker.py --fitted-frame).  Round 4's
+    per-rank first-launch decisions could not promise this."""
+    out, _ = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--fitted-frame"], nproc=8, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert all(("DIST_OK %d" % i) in out.stdout for i in range(8))
+
+
 def test_rccl_one_rank_frame_on_device_buffers():
     """The RCCL leg on one GPU: a world-size-1 `nccl` process group (librccl loaded, communicator up) and dist.render_frame's pack ->
     all_gather_into_tensor on DEVICE buffers -> unpack, under the insert / edit gt_values — the branch of dist.all_gather_frame that

@@ -30,6 +30,9 @@ surface amplifies round-off without bound in the reference itself (its two runs 
   (iii) whole frames of configs 4 / 5: the fixture pixels by rules (i) / (ii), and the override properties (masked pixels carry their
         override rows exactly).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -91,23 +94,44 @@ def ray_floor(g, key, with_param=False):
 # (refl_worst: the worst ray of a reflected-ray channel within this multiple of the reference's own worst ray — a one-sample statistic, "NOT a
 # parity claim": on the second checkpoint one ray of color_map0 flips its reflected direction, 0.22 against the reference's own 0.034, so only the
 # distribution is asserted there; depth_p99: the bulk of the depth map — from the rotated camera most rays of scene 2 cross unfitted space.)
-STRICT = dict(frac8=2000, n16=0, w_base=5e-4, w_cap=1e-3, w_p999=1e-3, p999=2e-4, refl_worst=4.0, depth_p99=2e-5, depth_p999=1e-4)
+STRICT = dict(frac8=2000, n16=0, w_base=5e-4, w_cap=1e-3, w_p999=1e-3, p999=2e-4, depth_p99=2e-5, depth_p999=1e-4)
+
+# THE YARDSTICK (round 5): what an actual fp32 implementation attains.  tests/golden/c_restatement_column.json (tests/golden/make_c_column.py) holds,
+# per launch-scale fixture and map, the fp32 C restatement's own rays above 1e-3 / 99.9th percentile / worst ray against the same reference render on the same rays.
+# Asserted against it: on the direct maps and the normal the HIP path has no more rays above the north-star 1e-3 than the C restatement has, plus an allowance that
+# scales with the launch — per 65 536 rays 2 on a direct map, 5 on the normal / n.v under the safe table and 12 under the fast one (never less than 1 / 1 / 2: counts of
+# single rays) — measured this round at 2 / 4 / 11 on the 65 536-ray launch against the C restatement's 0 / 0 / 0.  (Round 4 bounded the count by the number of rays the
+# reference's own sensitivity yardsticks flag — 17 / 642 there: true of the reference's conditioning, not an allowance anyone earned.)  The reflected-ray channels are
+# chaotic in every fp32 implementation — the C restatement itself has 2 - 8 % of a launch above 1e-3 there, and its WORST ray ranges from 1.3e-3 to 5.7e-1 over the eight
+# fixtures (0.47 - 0.57 on the hold-out's coarse pass, where the HIP path's is 0.02; 3.9e-3 on the second checkpoint's color_map0, where the HIP path's is 0.22): a worst-ray
+# bound there says nothing (round 4's `refl_worst` rule and its per-checkpoint exception are gone); their count is held to 5 x the C restatement's + 30, their distribution
+# to the reference's own as before.
+_COL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c_restatement_column.json")
+C_COLUMN = json.load(open(_COL)) if os.path.exists(_COL) else {}
+
+
+def c_allowance(key, n, decision):
+    base = key.rstrip("0")
+    # (depth / albedo / roughness / irradiance: 2 per launch; the maps that multiply two of them or carry the view-dependent radiance — diffuse, radiance_k, disp, acc: 4)
+    per_launch = (12 if decision == "fast" else 5) if base in NORMAL_LIKE else (2 if base in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_depth_map") else 4)
+    return max((2 if decision == "fast" else 1) if base in NORMAL_LIKE else 1, int(np.ceil(per_launch * n / 65536.0)))
 # what the calibration decides on each fixture's checkpoint and camera (asserted: a fast decision on the second checkpoint would be a parity bug, a safe
 # one on the first a 17 % slower frame for nothing)
-DECISION = {"fitted_launch16k": "fast", "fitted_edit_cfg4": "fast", "fitted_insert_cfg5": "fast", "fitted_posed4k": "fast", "fitted_launch64k": "fast",
-            "fitted2_launch4k": "safe", "fitted2_posed4k": "safe"}
+# (fitted_posed4k: "fast" until round 5 tightened the calibration's limits on the normal; fitted3_*: the hold-out checkpoint, decided by limits frozen before it existed)
+DECISION = {"fitted_launch16k": "fast", "fitted_edit_cfg4": "fast", "fitted_insert_cfg5": "fast", "fitted_posed4k": "safe", "fitted_launch64k": "fast",
+            "fitted2_launch4k": "safe", "fitted2_posed4k": "safe", "fitted3_launch4k": "safe", "fitted3_posed4k": "safe"}
 
 
 def rules_for(name):
-    """STRICT everywhere; the second checkpoint keeps two statements about the REFERENCE's own behaviour there (no worst-ray bound on the reflected-ray
-    channels, a wider bulk of the depth map from the rotated camera, where most rays cross space the network was never fitted on)."""
-    if not name.startswith("fitted2"):
-        return STRICT
-    return dict(STRICT, refl_worst=None, **(dict(depth_p99=1e-4, depth_p999=3e-4) if name == "fitted2_posed4k" else {}))
+    """ONE rule set for every checkpoint and camera (round 4's two exceptions for the second checkpoint are gone: its depth map's bulk is inside the strict bound since
+    the coarse density runs in fp32, and the reflected channels' worst-ray bound is gone for everyone — see C_COLUMN above)."""
+    return STRICT
 
 
-def check_against_fixture(res, g, report=None, rules=STRICT):
-    """Rules (i) and (ii) for the rays of fixture `g`; `res` holds the HIP maps of exactly those rays."""
+def check_against_fixture(res, g, report=None, rules=STRICT, name=None, decision="fast"):
+    """Rules (i) and (ii) for the rays of fixture `g`; `res` holds the HIP maps of exactly those rays.  name / decision: the fixture's row of the C-restatement column
+    and the table the renderer chose (the allowance on the normal depends on it)."""
+    col = C_COLUMN.get(name or "", {})
     we = int(g["weights_every"])
     compact = "compact" in g.files          # the 65 536-ray fixture keeps a subset of the maps
     if not compact:
@@ -133,6 +157,12 @@ def check_against_fixture(res, g, report=None, rules=STRICT):
             assert worse.sum() <= rules["n16"], (key, "rays beyond max(1e-3 | 2e-3, 16x their own reference difference):", np.flatnonzero(worse)[:8], e[worse][:8], f[worse][:8])
             # ... so a ray above the north-star 1e-3 is one the reference itself flags (own difference > 1e-3 / 8), and there are fewer of them
             assert (e > 1e-3).sum() <= (f > 1e-3 / 8).sum(), (key, int((e > 1e-3).sum()), int((f > 1e-3 / 8).sum()))
+            # ... and, the yardstick: no more of them than an fp32 implementation has on these very rays, plus the allowance
+            if key in col and k != "weights":
+                allowed = col[key]["above_1e-3"] + c_allowance(key, len(e), decision)
+                if report is not None:
+                    report[key] = report[key] + (col[key]["above_1e-3"], allowed)
+                assert (e > 1e-3).sum() <= allowed, (key, "rays above 1e-3:", int((e > 1e-3).sum()), "C restatement:", col[key]["above_1e-3"], "allowed:", allowed)
             p999 = max(1e-3 if k in NORMAL_LIKE else (rules["w_p999"] if fine_w else (1e-3 if k == "weights" else rules["p999"])), 1.5 * float(np.nanpercentile(f, 99.9)))     # ... or the reference's own 99.9th percentile (x1.5)
             assert float(np.nanpercentile(e, 99.9)) <= p999, (key, float(np.nanpercentile(e, 99.9)), p999)
         for k in REFLECTED:
@@ -145,21 +175,25 @@ def check_against_fixture(res, g, report=None, rules=STRICT):
                 if report is not None:
                     report["%s p%s" % (key, q)] = (float(np.nanpercentile(e, q)), bound)
                 assert float(np.nanpercentile(e, q)) <= bound, (key, q, float(np.nanpercentile(e, q)), bound)
-            # the worst ray: inside 4x the reference's own worst ray (the rule of the 96 .. 1 024-ray fixtures), which is NOT a parity claim
-            if rules["refl_worst"] is not None:
-                assert float(np.nanmax(e)) <= max(1e-3, rules["refl_worst"] * float(g["floor__" + key])), (key, float(np.nanmax(e)), float(g["floor__" + key]))
+            if key in col:        # (the worst ray of these channels is chaotic in every fp32 implementation: the COUNT against the C restatement's)
+                assert (e > 1e-3).sum() <= 5 * col[key]["above_1e-3"] + 30, (key, int((e > 1e-3).sum()), col[key]["above_1e-3"])
     if "out__z_std" in g.files:
         assert rel_linf(res["z_std"], g["out__z_std"]) <= max(1e-4, 4 * float(g["floor__z_std"]))
     d = per_ray(res["depth_map"], g["out__depth_map"])
     assert np.median(d) <= 2e-7 and np.percentile(d, 99) <= rules["depth_p99"] and np.percentile(d, 99.9) <= rules["depth_p999"], (np.median(d), np.percentile(d, 99), np.percentile(d, 99.9))
 
 
-@pytest.mark.parametrize("name", ["fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitted_posed4k", "fitted2_launch4k", "fitted2_posed4k"])
+@pytest.mark.parametrize("name", ["fitted_launch16k", "fitted_edit_cfg4", "fitted_insert_cfg5", "fitted_posed4k", "fitted2_launch4k", "fitted2_posed4k", "fitted3_launch4k",
+                                  "fitted3_posed4k"])
 def test_launch_scale_render_vs_reference(R, lut, name):
     """The default mode on 16 384 / 4 096 / 4 096 / 4 096 rays of the reference's own render, in ONE launch (fitted_posed4k: a rotated and
     translated camera, BASELINE configs 3 / 5's "any fixed look-at": ray origins off the axis, directions through get_rays' rotation).
     fitted2_*: the same on a SECOND checkpoint (tests/golden/fit_checkpoint.py --scene 2: other geometry, materials, light, sharper density
-    steps, another seed; fitted after the precision policy and these rules were fixed) — frontal and from the rotated camera."""
+    steps, another seed; fitted after the precision policy and these rules were fixed) — frontal and from the rotated camera.
+    fitted3_*: the HOLD-OUT (round 5, VERDICT r4 next-2 a; fit_checkpoint.py --scene 3: thin discs of one or two fine samples, a floor at grazing incidence, empty space
+    at raw density -3.5 — 1.5 above the selection margin —, the sharpest density steps of the three, other materials / light / seed), fitted and rendered by the reference
+    AFTER the selection margin, the lists' break-evens, the estimate guard, the calibration limits and these rules were frozen: a default-constructed renderer, no tripwire
+    event, no range event, the calibration's own decision, the same STRICT rules."""
     g, sdc, sdf, gt, edit = load_golden(name)
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384)
     if "c2w" in g.files:      # the fixture's rays are what get_rays builds on the device for its pose
@@ -169,12 +203,12 @@ def test_launch_scale_render_vs_reference(R, lut, name):
         assert np.array_equal(ro_d.reshape(-1, 3)[idx].cpu().numpy(), g["rays_o"]) and np.abs(rd_d.reshape(-1, 3)[idx].cpu().numpy() - g["rays_d"]).max() <= 2e-7
     assert r.mlp_precision == "auto" and r.policy is None
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
-    assert r.range_fallbacks == 0
+    assert r.range_fallbacks == 0 and r.trips == 0 and r.route["decided"] and r.route["estimates_plain_f16"] == [True, True], r.route
     assert r.policy["decision"] == DECISION[name], r.policy                  # decided on 4 096 of these very rays, before they were rendered
     for k in res:                                      # rays that end in empty space (acc = 0, fitted2_posed4k): disp = 1 / max(1e-10, depth / acc) is NaN in both
         if not k.startswith("weights"):                 # (the fixtures keep every weights_every-th row of the two weights tensors)
             assert np.array_equal(np.isnan(res[k]), np.isnan(g["out__" + k])), k
-    check_against_fixture(res, g, rules=rules_for(name))
+    check_against_fixture(res, g, rules=rules_for(name), name=name, decision=r.policy["decision"])
     psnr = 10 * np.log10(1.0 / max(np.mean((res["color_map"].astype(np.float64) - g["out__color_map"]) ** 2), 1e-30))
     # 55 dB, or what the reference's own two runs reach on these rays where that is less (its per-ray difference taken for all three channels:
     # 63.5 / 50.2 / 69.5 dB on the three fixtures; color_map carries the reflected-ray term)
@@ -193,19 +227,19 @@ def test_the_fast_table_on_the_second_checkpoint_is_what_the_calibration_says(R,
     e = per_ray(res["weights"][::int(g["weights_every"])], g["out__weights"])
     assert 1e-3 < np.percentile(e, 99.9) < 3e-3, np.percentile(e, 99.9)
     with pytest.raises(AssertionError):
-        check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"))
+        check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"), name="fitted2_launch4k", decision="fast")
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384, mlp_precision="f16x3_mxfp6x", query_routing=B.ROUTE_FINE_MAIN_PRECISE)
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), gt, **edit))
-    check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"))
+    check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"))            # round 4's rules (every ray against its own sensitivity in the reference) hold ...
     e = per_ray(res["weights"][::int(g["weights_every"])], g["out__weights"])
     assert np.percentile(e, 99.9) <= 4e-4 and e.max() <= 5e-4, (np.percentile(e, 99.9), e.max())
+    with pytest.raises(AssertionError):                                            # ... the C-restatement yardstick does not: 7 normals above 1e-3 where fp32 has 1 —
+        check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"), name="fitted2_launch4k", decision="fast")      # the fine offsets' mixed trunk form; the safe table has 2
     # the safe table = f16x3_mxfp6, bit for bit (the same kernels on every query)
     g2, sdc2, sdf2, gt2, edit2 = load_golden("fitted2_posed4k")
     ra = make_renderer(R, g2, sdc2, sdf2, lut, max_rays_per_launch=16384)
     rb = make_renderer(R, g2, sdc2, sdf2, lut, max_rays_per_launch=16384, mlp_precision="f16x3_mxfp6")
     a, b = ra.render_rays(g2["rays_o"], g2["rays_d"], 0.5, 8.0), rb.render_rays(g2["rays_o"], g2["rays_d"], 0.5, 8.0)
-    # (per-sample weights to 1e-15: a context's first launch estimates whole batches, later ones in z-chunks — a sample behind a transmittance of 1e-12 then weighs
-    # exactly zero instead of ~1e-17; every map is the same bit for bit)
     assert ra.policy["decision"] == "safe" and all(_same(a[k], b[k]) for k in a)
 
 
@@ -221,7 +255,9 @@ def test_calibration_measures_and_decides(R, lut):
     room on four different subsets of the rays (weights <= 2.5e-4 against 5e-4) -> "fast", from either camera; second checkpoint: the per-sample
     weights at 1.1-1.8e-3 on every subset -> "safe".  A new checkpoint resets the decision; a call too small to measure on renders safe and leaves
     it open; pinned modes never calibrate; precision_report is the same measurement against any reference mode."""
-    for name, want in (("fitted_launch16k", "fast"), ("fitted_posed4k", "fast"), ("fitted2_launch4k", "safe"), ("fitted2_posed4k", "safe")):
+    # (what triggers: the frontal view of the first checkpoint nothing — weights <= 2.5e-4 against 5e-4, the normal <= 2e-4 against 4e-4, no ray above 1e-3; its rotated
+    # view the NORMAL, since round 5 — 99.9 % at 5e-4 .. 1.4e-3 and 0.05 - 0.24 % of the rays above 1e-3; the second checkpoint the per-sample weights, 1.1-1.8e-3)
+    for name, want, by in (("fitted_launch16k", "fast", None), ("fitted_posed4k", "safe", "target_normal_map"), ("fitted2_launch4k", "safe", "weights"), ("fitted2_posed4k", "safe", "weights")):
         g, sdc, sdf, _, _ = load_golden(name)
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384)
         n = g["rays_o"].shape[0]
@@ -230,9 +266,13 @@ def test_calibration_measures_and_decides(R, lut):
             r.policy = None
             p = r.calibrate(ro[idx.cuda()].contiguous(), rd[idx.cuda()].contiguous(), 0.5, 8.0)
             assert p["decision"] == want and p["rays"] == len(idx), (name, p)
-            w = p["metrics"]["weights"]["p999"]
-            assert (w <= 2.5e-4) if want == "fast" else (w >= 1e-3), (name, p)
-            assert bool(p["triggers"]) == (want == "safe")
+            w, nm = p["metrics"]["weights"]["p999"], p["metrics"]["target_normal_map"]
+            if want == "fast":
+                assert w <= 2.5e-4 and nm["p999"] <= 2e-4 and nm["above_1e-3"] == 0.0 and not p["triggers"], (name, p)
+            else:
+                assert any(t.startswith(by) for t in p["triggers"]), (name, p)
+                assert (w >= 1e-3) if by == "weights" else (w <= 2.5e-4 and (nm["p999"] > 4e-4 or nm["above_1e-3"] > 3e-4)), (name, p)
+        assert r.route["decided"] and r.trips == 0                         # (the route was measured once, on the first probe; the table decisions ran under it)
     # a call too small to measure on: safe, undecided; then a frame-sized call decides; another checkpoint resets
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     g2, sdc2, sdf2, _, _ = load_golden("fitted2_launch4k")
@@ -278,7 +318,8 @@ def test_full_frame_of_config_2_at_the_fixture_pixels(R, lut):
     assert all(bool(torch.isfinite(v).all()) for v in m.values())
     idx = torch.as_tensor(g["pix"], device=rd.device)
     assert np.abs(rd[idx].cpu().numpy() - g["rays_d"]).max() <= 2e-7
-    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g)
+    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g, name="fitted_launch16k", decision=r.policy["decision"])
+    assert r.policy["decision"] == "fast" and r.trips == 0
 
 
 def test_one_whole_launch_against_the_reference(R, lut):
@@ -294,8 +335,12 @@ def test_one_whole_launch_against_the_reference(R, lut):
     idx = torch.as_tensor(g["pix"], device=rd.device)
     m = r.render_rays(ro[idx].contiguous(), rd[idx].contiguous(), 0.5, 8.0)       # ONE launch of 65 536 rays
     torch.cuda.synchronize()
-    assert r.range_fallbacks == 0
-    check_against_fixture({k: v.cpu().numpy() for k, v in m.items()}, g)
+    assert r.range_fallbacks == 0 and r.trips == 0 and r.policy["decision"] == "fast"
+    rep = {}
+    check_against_fixture({k: v.cpu().numpy() for k, v in m.items()}, g, rep, name="fitted_launch64k", decision="fast")
+    # (the whole launch under the fast table: depth / albedo / roughness / irradiance 2 rays above 1e-3 each — one extreme grazing ray, n.v = 0.01, and one more —, the
+    # normal 11, against the fp32 C restatement's 0; the safe table: 2 and 4)
+    assert rep["depth_map"][2] <= 2 and rep["target_normal_map"][2] <= 12, (rep["depth_map"], rep["target_normal_map"])
 
 
 @pytest.mark.parametrize("name,rows_fn", [("fitted_edit_cfg4", FO.edit_rows), ("fitted_insert_cfg5", FO.insert_rows)])
@@ -316,7 +361,7 @@ def test_full_frame_of_configs_4_and_5(R, lut, name, rows_fn):
     assert r.range_fallbacks == 0
     assert all(bool(torch.isfinite(v).all()) for k, v in m.items() if not k.startswith("disp_map"))
     idx = torch.as_tensor(pix, device=rd.device)
-    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g)
+    check_against_fixture({k: v[idx].cpu().numpy() for k, v in m.items()}, g, name=name, decision=r.policy["decision"])
     # override properties, all 640 000 pixels (ibl_nerf_renderer.py:253-256, :378-410): both passes
     mask_key = "edit_intrinsic_mask" if name.endswith("cfg4") else "object_insert_mask"
     level = gt[mask_key][:, 0]

@@ -513,8 +513,8 @@ def test_a_checkpoint_beyond_the_f16_range_renders_at_full_precision(R, lut):
     r = make_renderer(R, g, big_c, big_f, lut, max_rays_per_launch=16384)
     res = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0, gt, **edit))
     assert r.range_rescales >= 1 and r.range_fallbacks == 0 and r._wide is None
-    assert r.policy["decision"] == "fast"
-    LS.check_against_fixture(res, g, rules=LS.rules_for("fitted_posed4k"))
+    assert r.policy["decision"] == LS.DECISION["fitted_posed4k"]
+    LS.check_against_fixture(res, g, rules=LS.rules_for("fitted_posed4k"), name="fitted_posed4k", decision=r.policy["decision"])
     assert max(r._act_scale[1].values()) <= 2.0 ** -5 and set(r._act_scale[1]) >= set(ck.ACTIVATIONS[3:8])
 
 

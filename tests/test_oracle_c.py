@@ -190,6 +190,35 @@ def test_launch_scale_rule_on_an_independent_fp32_implementation(name, lut):
     assert rep["target_normal_map"][2] <= 2 and rep["target_normal_map0"][2] == 0          # rays above 1e-3 (the reference flags 95 / 113 and 33 / 314 of them)
 
 
+def test_c_restatement_column_is_what_this_restatement_computes(lut):
+    """tests/golden/c_restatement_column.{npz,json} (tests/golden/make_c_column.py): the yardstick the GPU tests hold the HIP path to — this fp32 restatement's own
+    per-ray distance from the reference's render on every launch-scale fixture.  Recomputed here on 384 rays of the hold-out fixture: the committed per-ray errors
+    (float16 of 2^14 x the value) are those of this code, and the JSON summary is the arrays' own."""
+    import json
+    col = np.load(os.path.join(GOLDEN, "c_restatement_column.npz"))
+    summ = json.load(open(os.path.join(GOLDEN, "c_restatement_column.json")))
+    name = "fitted3_posed4k"
+    g, sdc, sdf, gt, edit = load_golden(name)
+    n = 384
+    res = OC.render_rays(sdc, sdf, g["rays_o"][:n], g["rays_d"][:n], float(g["near"]), float(g["far"]), lut, 64, 128, gt, edit)
+    for k in ("depth_map", "albedo_map", "target_normal_map", "prefiltered_reflected_map", "target_normal_map0"):
+        ref = g["out__" + k].astype(np.float64)
+        e = np.abs(res[k].astype(np.float64).reshape((n,) + ref.shape[1:]) - ref[:n]).reshape(n, -1).max(-1) / np.abs(ref).max()
+        stored = col["%s/%s" % (name, k)][:n].astype(np.float64) / 2.0 ** 14
+        assert np.allclose(e, stored, rtol=2e-3, atol=2e-7), (k, np.abs(e - stored).max())
+    for fx, maps in summ.items():
+        if not isinstance(maps, dict):
+            continue
+        for k, v in maps.items():
+            arr = col["%s/%s" % (fx, k)].astype(np.float64) / 2.0 ** 14
+            assert v["rays"] == len(arr) and abs(int((arr > 1e-3).sum()) - v["above_1e-3"]) <= 1, (fx, k)        # (float16 rounding at the 1e-3 edge)
+    # the yardstick itself: on the direct maps and the normal an fp32 implementation leaves at most ONE ray of a launch above 1e-3 (of 65 536: none)
+    for fx, maps in summ.items():
+        if isinstance(maps, dict):
+            for k in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_normal_map"):
+                assert maps[k]["above_1e-3"] <= 1, (fx, k, maps[k])
+
+
 def test_parameter_sensitivity_matches_the_reference(lut):
     """The fourth yardstick of the launch-scale fixtures (`paramray__*`: the reference's float32 render with its checkpoint rounded to 22-bit
     mantissas, against its render with the checkpoint as it is) recomputed with the C restatement: the same distribution, ray by ray — the C
