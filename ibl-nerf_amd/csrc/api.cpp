@@ -34,10 +34,12 @@ constexpr int N_SLOTS = 10, N_AUX = 4, N_FLAGS = 1 + N_SLOTS;
 // and offset copies each, scratch/estimate_error.py): plain f16 0.20 / 1.45 at worst (99.99 %: 0.12 / 0.84; 11 % of a density above 10), f16 + 2 fp6 below 1e-2.
 // Widening the margin is nearly free: densities between -2 and -1 are 0.2 % of the samples.
 constexpr float COARSE_SELECT_MARGIN = 2.0f, COARSE_SELECT_TMIN = 1e-8f;
-// ... the margin is that of a network whose plain-f16 estimates are good to a third of it.  It is MEASURED, per network, by the route's probe (check_estimates): three times the
-// largest |plain-f16 - (f16 + 2 fp6)| estimate difference found where the classification happens (densities within +-8), rounded up to half a unit, never below 2 — so that
-// the tripwire (which fires at half the margin) has a factor 1.5 over anything the probe saw; a network that would need more than MARGIN_MAX keeps the f16 + 2 fp6 estimates
-// (whose own error is below 1e-2) at the base margin.  A wider margin costs the samples between -margin and -2 (0.2 % per unit on the fitted checkpoints), nothing else.
+// ... the margin is MEASURED, per network, by the route's probe (check_estimates): how far below zero the plain-f16 estimate puts a sample whose density is positive (the deepest
+// underestimate among the probe's samples, judged against the f16 + 2 fp6 estimate), doubled — the tripwire fires at half the margin — plus half a unit, rounded up to half
+// a unit, never below 2.  A network that would need more than MARGIN_MAX keeps the f16 + 2 fp6 estimates (error below 1e-2 on a network that fits that form) at the base margin.
+// A later tripwire event DOUBLES the margin (up to MARGIN_MAX) before it gives the plain-f16 estimates up: evidence the probe did not have.  A wider margin costs the samples
+// between -margin and -2 (0.2 % per unit on the first two fitted checkpoints; on the hold-out, whose empty space sits at -3.5, a margin of 4 makes every sample relevant and
+// the lists switch themselves off — which is why the margin follows the measured underestimate and not a multiple of the largest error).
 constexpr float MARGIN_MAX = 6.0f, MARGIN_ZONE = 8.0f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
@@ -117,6 +119,7 @@ struct iblnerf_ctx {
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
     int* sel_index = nullptr;                     // [4 * ws_rays * Sc] their flat indices
+    float* sel_est = nullptr;                     // ... and the density estimate that put each entry on the list (k_select_points est_list -> k_tripwire)
     int* sel_count = nullptr;                     // [0] this launch's list length; [2..3] (one uint64) the running total of the render call; [4..5] (one double) the list launches' 2 x MACs; [6] check_estimates' count; [8..9] (one double) the list launches' matrix-slot units
     long sel_candidates = 0;                      // ... and how many samples were candidates
     // Whether refining only the relevant samples pays is a property of the checkpoint: ~6 % of the coarse samples are relevant on a scene with surfaces, all of
@@ -301,7 +304,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         }
     if (hipMalloc((void**)&c->sel_pts, 4 * R * Sm * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sm * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->sel_count, 12 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 12 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess) {
+        hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess || hipMalloc((void**)&c->sel_est, 4 * R * Sm * sizeof(float)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
         return IBLNERF_ERR_NOMEM;
@@ -360,6 +363,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     if (c->sel_index) (void)hipFree(c->sel_index);
     if (c->sel_count) (void)hipFree(c->sel_count);
     if (c->main_range) (void)hipFree(c->main_range);
+    if (c->sel_est) (void)hipFree(c->sel_est);
     if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->bwd_stash) (void)hipFree(c->bwd_stash);
     if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -693,7 +697,8 @@ struct MlpCall {
     double flop_per_point = -1.0;       // ... priced as this (an estimate launch standing for the query it belongs to), or as the variant itself (< 0)
     const int* n_pts_dev = nullptr;     // a list: its length in device memory, n_pts = the bound that sizes the launch
     const int* out_index = nullptr;
-    float trip_margin = 0.0f;           // a list launched over the estimates that selected it: MlpArgs::trip_margin
+    float trip_margin = 0.0f;           // > 0: a list (c->sel_index / c->sel_est of the k_select_points call before it) launched over the estimates that selected it — the
+                                        // tripwire compares the refined densities with them afterwards (k_tripwire)
 };
 
 static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which, const MlpCall& m) {
@@ -722,6 +727,8 @@ static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which,
         }
         HIP_TRY(c, launch_trunk_fp32(f, c->n_cu, s));
         if (ev32) HIP_TRY(c, hipEventRecord(ev32->second, s));
+        if (m.trip_margin > 0.0f && m.n_pts_dev != nullptr && m.out_index == c->sel_index)
+            HIP_TRY(c, launch_tripwire(c->sel_est, c->sel_index, m.n_pts_dev, m.out, m.out_stride, m.trip_margin, c->d_range_flag, m.n_pts, s));
         if (m.n_pts_dev == nullptr) {
             c->flop_exec += (double)m.n_pts * FLOP_TRUNK;
             c->slot_units += (double)m.n_pts * FLOP_TRUNK / 128.0 * launch_slots(l);
@@ -742,7 +749,6 @@ static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which,
     if (m.gen) a.gen = *m.gen;
     a.n_pts_dev = m.n_pts_dev;
     a.out_index = m.out_index;
-    a.trip_margin = m.trip_margin;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (c->profiling) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -757,6 +763,9 @@ static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which,
     HIP_TRY(c, l.kern == K_MX16 ? launch_mlp_mx16(l.variant, a, c->n_cu, s) : l.kern == K_MX ? launch_mlp_mx(l.variant, a, c->n_cu, s)
                : l.kern == K_F16X3 ? launch_mlp_f16x3(l.variant, a, c->n_cu, s) : launch_mlp(l.variant, a, c->n_cu, s));
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
+    if (m.trip_margin > 0.0f && m.n_pts_dev != nullptr && m.out_index == c->sel_index)
+        HIP_TRY(c, launch_tripwire(c->sel_est, c->sel_index, m.n_pts_dev, m.out, m.out_stride * (variant_albirr(l.variant) ? RAW_CH : l.variant == VAR_REFL_LIST ? REFL_CH : 1),
+                                   m.trip_margin, c->d_range_flag, m.n_pts, s));
     // what the launch costs (whole batches here; list launches: k_count_selection adds theirs on the device, sel_count[4..7])
     const int flop_variant = l.variant == VAR_TRUNK_X ? VAR_TRUNK : l.variant;
     if (m.n_pts_dev == nullptr) {
@@ -1151,13 +1160,23 @@ static int fold_flags(iblnerf_ctx* c, const unsigned* v) {
                                      // bits 2, 3: the estimate tripwire — a list launch refined a positive density whose plain-f16 estimate was half-way to being
                                      // dropped (2), or overshot beyond what the conservative transmittance allows for (3)
     if (v[0] & 12u) {
-        // ... plain-f16 estimates: they run on the f16 + 2 fp6 form from now on; f16 + 2 fp6 estimates already (a network whose density cancels beyond THAT form's 2^-16:
-        // tests/test_gpu_fitted.py builds one): no estimate of this network can be trusted — the lists go off, every query evaluates all of its samples.  Either way the
-        // call that raised the flag is to be repeated.
-        const bool were_plain = c->est_f16 && ((c->est_checked[0] && c->est_ok[0]) || (c->est_checked[1] && c->est_ok[1]));
-        c->est_ok[0] = c->est_ok[1] = false;
-        if (!were_plain) { c->sel_decided = true; c->sel_on = false; }
-        c->tripped = were_plain ? 1 : 2;
+        // The estimate tripwire.  In order of what it costs: (1) an UNDERESTIMATE on plain-f16 estimates (bit 2 alone) doubles both selection margins, up to MARGIN_MAX — a few
+        // more samples refined; (2) otherwise the plain-f16 estimates go: f16 + 2 fp6 from now on (six matrix slots instead of four per estimate, nothing else changes);
+        // (3) on f16 + 2 fp6 estimates already (a network whose density cancels beyond THAT form's 2^-16: tests/test_gpu_fitted.py builds one) no estimate of this
+        // checkpoint can be trusted — the lists go off, every query evaluates all of its samples.  Either way the call that raised the flag is to be repeated.
+        const bool six = !c->est_f16 || (c->est_checked[0] && !c->est_ok[0]) || (c->est_checked[1] && !c->est_ok[1]);
+        if (six) {
+            c->est_ok[0] = c->est_ok[1] = false;
+            c->sel_decided = true; c->sel_on = false;
+            c->tripped = 2;
+        } else if ((v[0] & 12u) == 4u && std::min(c->margin[0], c->margin[1]) < MARGIN_MAX) {
+            for (int w = 0; w < 2; ++w) c->margin[w] = std::min(MARGIN_MAX, 2.0f * c->margin[w]);
+            c->tripped = 1;
+        } else {
+            c->est_ok[0] = c->est_ok[1] = false;
+            c->margin[0] = c->margin[1] = COARSE_SELECT_MARGIN;
+            c->tripped = 1;
+        }
     }
     for (int slot = 0; slot < N_SLOTS; ++slot)
         if (v[1 + slot]) { c->mx_ok[slot] = false; any |= 1; }
@@ -1436,7 +1455,7 @@ static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, const Launch& est, in
 
 // Once per route decision: may this network's density estimates run in plain f16?  Both estimates of the probe's main-query samples (c->pts), compared by
 // k_compare_estimates; one stream synchronisation.  A network whose plain-f16 trunk is ever half-way to a wrong selection keeps the f16 + 2 fp6 estimates.
-// (Every later list launch repeats the comparison on the samples it refines — the tripwire, MlpArgs::trip_margin.)
+// (Every later list launch repeats the comparison on the samples it refines and audits — the tripwire, k_tripwire.)
 static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts, int S) {
     c->est_checked[which] = true;
     c->est_ok[which] = false;
@@ -1454,7 +1473,7 @@ static int check_estimates(iblnerf_ctx* c, hipStream_t s, int which, long n_pts,
     float err;
     std::memcpy(&err, &res[1], sizeof err);
     c->est_error[which] = err;
-    const float margin = std::max(COARSE_SELECT_MARGIN, std::ceil(3.0f * err * 2.0f) / 2.0f);
+    const float margin = std::max(COARSE_SELECT_MARGIN, std::ceil((2.0f * err + 0.5f) * 2.0f) / 2.0f);
     c->est_ok[which] = res[0] == 0 && margin <= MARGIN_MAX;
     c->margin[which] = c->est_ok[which] ? margin : COARSE_SELECT_MARGIN;
     return IBLNERF_OK;
@@ -1497,7 +1516,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
         c->sel_candidates += n;
         HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
                                         false, 0.f, c->raw, RAW_CH, variant_flops(q.on_list.variant) + (q.density_list.none() ? 0.0 : FLOP_TRUNK), c->main_range, nullptr,
-                                        list_slots(q.on_list) + list_slots(q.density_list)));
+                                        list_slots(q.on_list) + list_slots(q.density_list), c->sel_est));
         if (q.open) {     // the probe: does this network have empty space and surfaces, or is it fog?  / how many of the fine samples are relevant?
             long n_sel = 0;
             if ((rc = read_list_length(c, s, &n_sel))) return rc;
@@ -1596,7 +1615,7 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
     }
     HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
     HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, nullptr, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s, true, eps,
-                                    nullptr, 0, FLOP_TRUNK, nullptr, q.predicted ? c->main_range : nullptr, list_slots(q.on_list)));
+                                    nullptr, 0, FLOP_TRUNK, nullptr, q.predicted ? c->main_range : nullptr, list_slots(q.on_list), c->sel_est));
     if (share) {      // the probe: (predicted +) selected share of the 4 R S samples
         unsigned long long now = 0;
         HIP_TRY(c, hipMemcpyAsync(&now, c->sel_count + 2, sizeof now, hipMemcpyDeviceToHost, s));
@@ -1666,7 +1685,7 @@ static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R,
     HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
     c->sel_candidates += R * Sc;
     HIP_TRY(c, launch_select_points(c->refl_o, c->refl_d, zc, zc_stride, c->sig4, 1, nullptr, R, Sc, c->margin[which], q.t_min, c->sel_pts, c->sel_index,
-                                    c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL, nullptr, nullptr, list_slots(q.on_list)));
+                                    c->sel_count, s, false, 0.f, c->refl_raw, REFL_CH, FLOP_REFL, nullptr, nullptr, list_slots(q.on_list), c->sel_est));
     MlpCall l;
     l.pts = c->sel_pts; l.dirs = c->refl_d; l.pts_per_ray = Sc; l.n_pts = R * Sc; l.out = c->refl_raw; l.count_flops = false; l.n_pts_dev = c->sel_count; l.out_index = c->sel_index;
     l.trip_margin = c->margin[which];
@@ -1741,7 +1760,7 @@ static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const fl
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += n;
         HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, c->margin[0], COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
-                                        false, 0.f, nullptr, 0, FLOP_TRUNK, nullptr, nullptr, list_slots(p15)));
+                                        false, 0.f, nullptr, 0, FLOP_TRUNK, nullptr, nullptr, list_slots(p15), c->sel_est));
         if (!c->sel_decided) {      // (the probe: this is also where a checkpoint's refinement decision is taken when no full coarse pass ever runs)
             long n_sel = 0;
             if ((rc = read_list_length(c, s, &n_sel))) return rc;

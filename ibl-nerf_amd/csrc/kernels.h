@@ -200,7 +200,10 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                 double list_flop_per_point = 0.0,    // what the list launches behind this selection evaluate per entry (counter[4..5] += n * that)
                                 int* range_out = nullptr,            // [R][2] (not with offsets): each ray's first and last selected sample ({S, -1}: none)
                                 const int* skip_range = nullptr,     // offsets: such a record of the MAIN rays — the samples predicted relevant by it ([first - 1, last + 1]) are not selected (again)
-                                double list_slots_per_point = 0.0);  // ... and their matrix-slot units per entry (counter[8..9])
+                                double list_slots_per_point = 0.0,   // ... and their matrix-slot units per entry (counter[8..9])
+                                float* est_list = nullptr);          // [list length] the estimate of every list entry (for launch_tripwire)
+// the estimate tripwire: after a list launch, every entry's refined density out[index[i] * out_stride] against est_list[i] (k_tripwire); raises bits 2 / 3 of *flag
+hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s);
 
 // the offset copies' samples by the main ray's relevant range (k_range_points: mode 1 the predicted range, 2 in front of it, 3 behind it for the copies still alive);
 // list length at counter[0] (zeroed by the caller), executed MACs x 2 (flop_per_point per entry) added to counter[4..5], entries to counter[2..3] if count_entries

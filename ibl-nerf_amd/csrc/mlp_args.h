@@ -32,10 +32,6 @@ struct MlpArgs {
     // out[out_index[i] * out_stride]; n_pts is then only the upper bound that sizes the launch
     const int* n_pts_dev = nullptr;
     const int* out_index = nullptr;
-    // the estimate tripwire (list forms only; 0 = off): the slot a list entry's density is scattered to still holds the ESTIMATE that selected it.  An estimate that was half-way to
-    // a wrong selection — a positive refined density estimated below -trip_margin / 2, or overshot beyond what k_select_points' conservative transmittance allows for
-    // (0.75 estimate - trip_margin > refined) — raises bit 2 (resp. bit 3) of *range_flag (k_compare_estimates' rule, checked on every list launch instead of once per checkpoint)
-    float trip_margin = 0.0f;
     float grad_scale = 1.0f;         // a power of two: dZ = grad_scale * true dZ everywhere (keeps small gradients out of the f16 denormals);
                                      // the point gradient is unscaled in the kernel, the weight gradient by the weight-gradient kernels
 };
@@ -43,14 +39,5 @@ hipError_t launch_mlp(int variant, const MlpArgs& a, int n_cu, hipStream_t strea
 hipError_t launch_mlp_f16x3(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);  // three f16 products, same stream layout with f16 pairs
 hipError_t launch_mlp_mx(int variant, const MlpArgs& a, int n_cu, hipStream_t stream);   // f16 + MX-fp6 (layout_mx.h); also VAR_TRUNK_X, its mixed trunk form
 hipError_t launch_mlp_mx16(int variant, const MlpArgs& a, int n_cu, hipStream_t stream); // plain f16 on the same stream (FULL / REFL forms only)
-
-// (device side of MlpArgs::trip_margin: `slot` is read before the refined density overwrites it)
-__device__ __forceinline__ void estimate_tripwire(const MlpArgs& a, const float* slot, float refined) {
-    if (a.trip_margin > 0.0f && a.range_flag != nullptr && refined > 0.0f) {
-        const float est = *slot;
-        if (est < -0.5f * a.trip_margin) atomicOr(a.range_flag, 4u);                          // bit 2: a positive density estimated half-way to "clearly empty"
-        else if (0.75f * est - a.trip_margin > refined) atomicOr(a.range_flag, 8u);          // bit 3: overshot beyond what the conservative transmittance allows for
-    }
-}
 
 }  // namespace ibl

@@ -948,11 +948,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
         const float* sc = tabs + TAB_SCALAR;
         if constexpr (VARIANT == VAR_TRUNK || VARIANT == VAR_TRUNK_FEAT || VARIANT == VAR_TRUNK_FEAT2) {
             const float s = part[0] + __shfl_xor(part[0], 32) + sc[0];
-            if (VARIANT == VAR_TRUNK && valid && h == 0) {
-                float* slot = a.out + (LIST ? (long)a.out_index[p] : (long)p) * a.out_stride;
-                if constexpr (LIST) estimate_tripwire(a, slot, s);
-                *slot = s;
-            }
+            if (VARIANT == VAR_TRUNK && valid && h == 0) a.out[(LIST ? (long)a.out_index[p] : (long)p) * a.out_stride] = s;
 #ifdef IBL_F16X3
             if (valid && !(fabsf(s) < __builtin_inff()) && a.range_flag != nullptr) atomicOr(a.range_flag, 1u);   // range guard (see split_pair)
 #endif
@@ -973,7 +969,6 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(MlpArgs a) {
                 if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + row * RAW_CH;
                     if (h == 0) {
-                        if constexpr (LIST) estimate_tripwire(a, o, tot[0]);
 #pragma unroll
                         for (int c = 0; c < 9; ++c) o[c] = tot[c];
                     } else {

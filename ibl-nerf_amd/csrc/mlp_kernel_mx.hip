@@ -1104,11 +1104,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
             static_for<0, 8>([&](auto I) { e7.template slice<7, decltype(I)::value>(pacc); });
             const float p0 = sig[0] + sig[1];
             const float sg = p0 + __shfl_xor(p0, 32) + tabs[TAB_SCALAR];
-            if (valid && h == 0) {
-                float* slot = a.out + (a.out_index != nullptr ? (long)a.out_index[p] : (long)p) * a.out_stride;
-                if (a.out_index != nullptr) estimate_tripwire(a, slot, sg);
-                *slot = sg;
-            }
+            if (valid && h == 0) a.out[(a.out_index != nullptr ? (long)a.out_index[p] : (long)p) * a.out_stride] = sg;
             continue;
         }
 #ifndef IBL_MX_ABLATE_PROLOGUE
@@ -1235,9 +1231,7 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
                 // (the plain TRUNK form also takes a list when it serves as the density ESTIMATE of a network whose plain-f16 estimates were refused: z-chunks and the
                 // offset copies' front / behind ranges, api.cpp estimate_chunked / offsets_on_lists — a run-time question there, like VAR_TRUNK_P's)
                 const bool scattered = LIST || (VARIANT == VAR_TRUNK && a.out_index != nullptr);
-                float* slot = a.out + (scattered ? (long)a.out_index[p] : (long)p) * a.out_stride;
-                if constexpr (LIST) estimate_tripwire(a, slot, s);
-                *slot = s;
+                a.out[(scattered ? (long)a.out_index[p] : (long)p) * a.out_stride] = s;
             }
         } else {
             float tot[RAW_CH];
@@ -1251,7 +1245,6 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
                 if constexpr (variant_albirr(VARIANT)) {
                     float* o = a.out + row * RAW_CH;
                     if (h == 0) {
-                        if constexpr (LIST) estimate_tripwire(a, o, tot[0]);
 #pragma unroll
                         for (int c = 0; c < 9; ++c) o[c] = tot[c];
                     } else {
@@ -1261,7 +1254,6 @@ __global__ __launch_bounds__(256, IBL_MX_WGS_PER_CU) void mlp_kernel(MlpArgs a) 
                 } else {
                     float* o = a.out + row * REFL_CH;
                     if (h == 0) {
-                        if constexpr (LIST) estimate_tripwire(a, o, tot[0]);
                         o[0] = tot[0];
 #pragma unroll
                         for (int c = 1; c < 7; ++c) o[c] = tot[5 + c];

@@ -860,17 +860,38 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float*
     }
 }
 
+// The estimate TRIPWIRE (round 5): after a list launch has written the refined densities, every entry's refined value against the estimate that put it on the list
+// (k_select_points' est_list: the selected samples and the audited ones).  A positive density whose estimate lay below -margin / 2 — half-way to being dropped as
+// clearly empty — raises bit 2 of the range flag; one overshot beyond what the conservative transmittance allows for (0.75 estimate - margin > refined) bit 3:
+// k_compare_estimates' rule, on every launch instead of once per checkpoint.  (A kernel of its own, 0.05 ms: inside the MLP kernels' epilogues the same comparison
+// cost the fast FULL list form its last registers — 20 bytes of scratch, 5.9 -> 9.2 ms per launch.)
+__global__ void k_tripwire(const float* __restrict__ est_list, const int* __restrict__ index, const int* __restrict__ n_dev, const float* __restrict__ out, int out_stride,
+                           float margin, unsigned* __restrict__ flag) {
+    const long n = *n_dev;
+    unsigned bits = 0u;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float refined = out[(long)index[i] * out_stride], est = est_list[i];
+        if (refined > 0.0f) bits |= est < -0.5f * margin ? 4u : (0.75f * est - margin > refined ? 8u : 0u);
+    }
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) bits |= (unsigned)__shfl_xor((int)bits, dd);
+    if ((threadIdx.x & 63) == 0 && bits != 0u) atomicOr(flag, bits);
+}
+
 // Is a plain-f16 density estimate good enough for k_select_points on this network?  Two estimates of the same n samples (b: the f16 + 2 fp6 form, error < 1e-2);
 // counts the samples on which `a` is half-way to a wrong decision: a positive density estimated below -margin / 2, or a density overshot by more than the
 // conservative transmittance allows for (0.75 a - margin > b).
-// Round 5: the first of the two (a positive density estimated below -margin / 2) became a MEASUREMENT — bad[1] receives the bits of the largest |a - b| among the
-// samples whose density b lies within +-zone, where the classification "clearly empty or not" happens; api.cpp check_estimates sets the network's margin to three times it.
+// Round 5: the first of the two (a positive density estimated below -margin / 2) became a MEASUREMENT — bad[1] receives the bits of the deepest UNDERESTIMATE: the largest
+// -a among the samples whose density b is positive (and within `zone`: a large density underestimated by a few per cent is no classification question).  That is how far
+// below zero this network's plain-f16 estimate puts a sample that is NOT empty; api.cpp check_estimates sets the network's selection margin from it.  (An OVERestimate of an
+// empty sample only costs its refinement.)
 __global__ void k_compare_estimates(const float* __restrict__ a, const float* __restrict__ b, long n, float margin, float zone, int* __restrict__ bad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool wrong = i < n && b[i] > 0.0f && 0.75f * a[i] - margin > b[i];
     const unsigned long long m = __ballot(wrong);
     if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(bad, __popcll(m));
-    float err = (i < n && fabsf(b[i]) <= zone) ? fabsf(a[i] - b[i]) : 0.0f;
+    float err = (i < n && b[i] > 0.0f && b[i] <= zone) ? fmaxf(-a[i], 0.0f) : 0.0f;
+    if (i < n && b[i] > 0.0f && b[i] <= zone && a[i] != a[i]) err = 1e30f;
     if (!(err < 1e30f)) err = 1e30f;                      // (a NaN / inf estimate: refuse)
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) err = fmaxf(err, __shfl_xor(err, dd));
@@ -881,7 +902,8 @@ template <int NPL, bool OFFSETS>
 __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
                                                       const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
                                                       float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
-                                                      float* __restrict__ est_out, int est_stride, int* __restrict__ range_out, const int* __restrict__ skip_range) {
+                                                      float* __restrict__ est_out, int est_stride, int* __restrict__ range_out, const int* __restrict__ skip_range,
+                                                      float* __restrict__ est_list) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;      // (virtual) ray
     const bool live = vr_raw < (OFFSETS ? 4 * R : R);                // (a dead wave of the last block still takes part in the block's count)
@@ -891,7 +913,7 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
     const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
     const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     const float* zrow = zbase + (long)z_stride * r;
-    float z[NPL], sg[NPL];
+    float z[NPL], sg[NPL], sg_est[NPL];
     double om[NPL];
     double lane_prod = 1.0;
 #pragma unroll
@@ -900,6 +922,7 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
         z[i] = s < S ? zrow[s] : 0.0f;
         const float zn = s + 1 < S ? zrow[s + 1] : 0.0f;
         sg[i] = s < S ? sigma[(vr * S + s) * (long)sigma_stride] : -1e30f;
+        sg_est[i] = sg[i];                                            // (the network's own estimate, before any density noise: what the tripwire compares)
         if (est_out != nullptr && s < S && live) est_out[(vr * S + s) * (long)est_stride] = sg[i];     // the estimate itself, as the density of the samples nobody refines
         if (noise != nullptr && s < S) sg[i] = sg[i] + noise[r * S + s];
         const float dist = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
@@ -934,7 +957,7 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
         const bool reachable = live && s < S && T > (double)t_min && !(s >= skip_lo && s <= skip_hi);
         sel[i] = reachable && sg[i] > -margin;
         // the AUDIT (round 5): one in AUDIT_ONE_IN of the samples dropped as clearly empty goes to the list all the same.  Its refined density replaces the estimate
-        // (both <= 0: alpha = 0 either way, no map changes) — and the list kernel's tripwire (MlpArgs::trip_margin) sees an estimate that was GROSSLY wrong, which no
+        // (both <= 0: alpha = 0 either way, no map changes) — and the tripwire behind the list launch (k_tripwire) sees an estimate that was GROSSLY wrong, which no
         // selected sample would show: a positive density estimated below -margin is never selected, so never refined, so never compared.  Chosen by a hash of the
         // sample's flat index: the same samples on every route and rank.
         const bool audit = reachable && !sel[i] && ((unsigned)(vr * S + s) * 2654435761u) >> (32 - AUDIT_LOG2) == 0u;
@@ -986,6 +1009,7 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
             pts_out[3 * (long)pos + 1] = p[1];
             pts_out[3 * (long)pos + 2] = p[2];
             index_out[pos] = (int)flat;
+            if (est_list != nullptr) est_list[pos] = sg_est[i];      // the estimate that selected (or audited) this entry: k_tripwire compares the refined density with it
         }
         before += __popcll(masks[i]);
     }
@@ -1389,16 +1413,16 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
 
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps,
-                                float* est_out, int est_stride, double list_flop_per_point, int* range_out, const int* skip_range, double list_slots_per_point) {
+                                float* est_out, int est_stride, double list_flop_per_point, int* range_out, const int* skip_range, double list_slots_per_point, float* est_list) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
     const hipError_t e = by_npl(S, [&](auto N) {
         if (offsets)
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list);
         else
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list);
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point, list_slots_per_point, 1);
@@ -1433,6 +1457,13 @@ hipError_t launch_range_points(const float* rays_o, const float* rays_d, const f
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, slots_per_point, count_entries ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s) {
+    if (n_bound <= 0 || flag == nullptr) return hipSuccess;
+    const long blocks = (n_bound + 255) / 256;
+    hipLaunchKernelGGL(k_tripwire, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, est_list, index, n_dev, out, out_stride, margin, flag);
     return hipGetLastError();
 }
 

@@ -564,7 +564,7 @@ class Renderer:
 
     @staticmethod
     def trips_in_a_row(retry):
-        return 3 if retry == "trip2" else 2 if retry == "trip" else 1
+        return 1 + int(retry[4:]) if isinstance(retry, str) and retry.startswith("trip") else 1
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""
@@ -1043,15 +1043,16 @@ class Renderer:
         bits = 0 if lazy else self.range_bits()
         if bits & 12 and not bits & 1:
             # the estimate tripwire: a list launch of this call refined a positive density whose plain-f16 estimate was half-way to dropping it.  The library
-            # has moved the estimates to the f16 + 2 fp6 form (error < 1e-2 on a network that fits that form) — or, if they were there already, switched the
-            # lists off; the call is repeated.
+            # has doubled the selection margins — or moved the estimates to the f16 + 2 fp6 form (error < 1e-2 on a network that fits that form), or, if they
+            # were there already, switched the lists off; the call is repeated.
             self.trips += 1
             self.trip_bits = getattr(self, "trip_bits", 0) | (bits & 12)
             self.route = self.get_route() if self.route is not None else None
-            if self.trips_in_a_row(_retry) > 2:
+            n_trips = self.trips_in_a_row(_retry)
+            if n_trips > 5:          # (margins 2 -> 4 -> 6, estimates to six slots, lists off: four events at most)
                 raise B.IblNerfError("the estimate tripwire fired with the lists off: an internal error")
             return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk,
-                                    raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, _retry="trip2" if _retry == "trip" else "trip", **edit)
+                                    raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, _retry="trip%d" % n_trips, **edit)
         if bits & 1:
             again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, **edit)
             if _retry is not True and n:

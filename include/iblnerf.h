@@ -164,18 +164,20 @@ typedef struct iblnerf_route {
     int32_t estimates_plain_f16[2];    /* per network: its density estimates run in plain f16 (4 matrix slots per 64 MACs); 0: on the f16 + 2 fp6 form (6), because the
                                           probe found a plain-f16 estimate half-way to a wrong selection, because the tripwire fired since, or IBLNERF_ROUTE_ESTIMATES_6SLOT */
     int32_t tripped;                   /* the estimate tripwire (every list launch checks the estimates it overwrites — those of the samples it refines and of one in 64
-                                          of the samples dropped as clearly empty, the audit — bits 2 / 3 of the range flag) has fired since the decision: 1 = the plain-f16
-                                          estimates were withdrawn, 2 = it fired on f16 + 2 fp6 estimates too and the lists went off (iblnerf_range_status folds the
-                                          flag in; the call that raised it must be repeated: ibl-nerf_amd/renderer.py does) */
+                                          of the samples dropped as clearly empty, the audit — bits 2 / 3 of the range flag) has fired since the decision: 1 = the selection
+                                          margins were doubled (an underestimate, margins below 6) or the plain-f16 estimates withdrawn, 2 = it fired on f16 + 2 fp6
+                                          estimates too and the lists went off (iblnerf_range_status folds the flag in; the call that raised it must be repeated:
+                                          ibl-nerf_amd/renderer.py does) */
     double coarse_share;               /* share of the probe's coarse-grid samples that were relevant (neither clearly empty nor behind saturation); lists are on for
                                           the coarse main query, the coarse grid's offset copies and the reflected rays iff it is <= 0.30.  -1: not measured (lists off) */
     double fine_main_share;            /* likewise the fine main query (on a list iff <= 0.60) */
     double fine_offsets_share;         /* likewise the fine grid's offset copies (on lists iff <= 0.85 with the main ray's prediction; without it 0.42, or 0.55 where the mode
                                           refines them on three f16 products) */
     float select_margin[2];            /* per network: a sample whose density estimate lies below -select_margin is "clearly empty" (alpha = 0 exactly whatever the estimate's
-                                          error).  Measured by the probe: three times the largest |plain-f16 - (f16 + 2 fp6)| estimate difference it found at densities
-                                          within +-8, rounded up to half a unit, at least 2; a network that would need more than 6 keeps f16 + 2 fp6 estimates at 2 */
-    float estimate_error[2];           /* ... that largest difference (-1: not measured) */
+                                          error).  Measured by the probe: twice the deepest underestimate it found (how far below zero the plain-f16 estimate puts a sample
+                                          whose f16 + 2 fp6 estimate is positive) + 0.5, rounded up to half a unit, at least 2; a network that would need more than 6 keeps
+                                          f16 + 2 fp6 estimates at 2; doubled by a tripwire event */
+    float estimate_error[2];           /* ... that deepest underestimate (-1: not measured) */
 } iblnerf_route;
 /* Measures and freezes the route on n_rays probe rays (device pointers; 1 024 <= n_rays <= options.max_rays_per_launch; scalar planes): one render of them whose
  * outputs are discarded, with three stream synchronisations.  Needs the networks and the LUT uploaded.  *out (nullable) receives the result. */

@@ -57,7 +57,7 @@ for sub in ("pmc_mfma", "pmc_sq", "pmc_fetch", "pmc_write"):
 print("== derived (MLP kernels)")
 derived = {}
 for k, v in pmc.items():
-    if "mlp_kernel" not in k:
+    if "mlp_kernel" not in k and "k_trunk_fp32" not in k:
         continue
     d = {}
     if "GRBM_GUI_ACTIVE" in v:

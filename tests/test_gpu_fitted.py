@@ -453,11 +453,12 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
     bits; one f16 term rounds 3K and K to 36000 and 12008 and shifts every pre-activation of the layer by -24 h; the f16 + 2 fp6 form holds the residuals -3.6 / +4.4
     to three mantissa bits — better, still off by more than the selection margin on some samples.
     (i)  The route's probe (api.cpp check_estimates) refuses plain-f16 estimates for this network on sight; the untouched fine network passes.
-    (ii) The TRIPWIRE (round 5; MlpArgs::trip_margin, k_select_points' audit): every list launch compares the densities it writes with the estimates they replace —
+    (ii) The TRIPWIRE (round 5; k_tripwire, k_select_points' audit): every list launch compares the densities it writes with the estimates they replace —
          those of the samples it refines and of one in 64 of the samples dropped as clearly empty.  On this network the f16 + 2 fp6 estimates fail it too: the lists go
          off (route.tripped = 2), the wrapper repeats the call, and the result is the all-points route's, bit for bit.
-    (iii) The probe may not have SEEN the bad region: a route that claims plain-f16 estimates is imposed (as a probe elsewhere in the scene would have decided it); the
-         first render trips twice — estimates to six slots, then lists off — and ends on the same result; later calls stay there.
+    (iii) The probe may not have SEEN the bad region: a route that claims plain-f16 estimates at the base margin is imposed (as a probe elsewhere in the scene would
+         have decided it); the first render walks the whole ladder — margins 2 -> 4 -> 6, estimates to six slots, lists off: four events — and ends on the same result;
+         later calls stay there.
     (The density head itself runs on the VALU from fp32 weights in every kernel: the cancellation has to sit in a matrix layer.)"""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
@@ -485,7 +486,7 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
     r.decide_route(ro, rd, 0.5, 8.0)
     assert r.estimate_policy(0) == (True, False) and r.estimate_policy(1) == (True, True) and r.route["tripped"] == 0 and r.route["coarse_share"] < 0.3
     got = r.render_rays(ro, rd, 0.5, 8.0)
-    assert r.trips == 2 and r.route["tripped"] == 2 and r.last_selection() == (0, 0) and r.range_fallbacks == 0        # (the fine network's plain-f16 estimates go first, then the lists)
+    assert r.trips == 1 and r.route["tripped"] == 2 and r.last_selection() == (0, 0) and r.range_fallbacks == 0        # (a network on six-slot estimates already: straight to "lists off")
     assert "lists off" in r.describe_route() and "estimate:" not in r.describe_route()
     for k in got:
         assert torch.equal(got[k], whole[k]), k
@@ -497,43 +498,45 @@ def test_plain_f16_estimates_are_refused_where_they_are_not_good_enough(R, lut):
     r.set_route(good.route)
     assert r.estimate_policy(0) == (True, True)
     got = r.render_rays(ro, rd, 0.5, 8.0)
-    assert r.trips == 2 and r.route["tripped"] == 2 and r.estimate_policy(0) == r.estimate_policy(1) == (True, False) and r.range_fallbacks == 0
+    assert r.trips == 4 and r.route["tripped"] == 2 and r.estimate_policy(0) == r.estimate_policy(1) == (True, False) and r.range_fallbacks == 0
     for k in got:
         assert torch.equal(got[k], whole[k]), k
     r.render_rays(ro, rd, 0.5, 8.0)
-    assert r.trips == 2
+    assert r.trips == 4
 
 
-def test_the_second_checkpoint_takes_a_wider_margin_or_six_slot_estimates(R, lut):
-    """Plain-f16 density estimates of the second fitted checkpoint are off by up to 0.9 / 1.1 in raw density near zero (coarse / fine network) — under round 4's fixed
-    selection margin of 2 the tripwire fires on some launch of the whole frame (a positive density whose estimate lay below -1) and the estimates move to the f16 + 2 fp6
-    form: 330 k rays/s instead of 560 k.  So the margin is MEASURED (api.cpp check_estimates): the probe's largest estimate difference in the classification zone x 3,
-    rounded up to half a unit: 3.0 / 3.5 here — the whole frame renders without a tripwire event, on plain-f16 estimates.  With round 4's margin imposed the event
-    happens, once; the estimates move to six slots (which also take z-chunks and the offset copies' ranges: nothing else changes), the call is repeated, and the frame is
-    the estimates_6slot routing's, bit for bit."""
+def test_the_selection_margin_is_measured_and_the_tripwire_widens_it(R, lut):
+    """How far below zero does a network's plain-f16 estimate put a sample that is NOT empty?  The route's probe measures it (api.cpp check_estimates: the deepest
+    underestimate among the probe's samples, judged against the f16 + 2 fp6 estimate) and sets the selection margin to twice that + 0.5 (>= 2): underestimates of
+    0.03 / 0.08 on the first fitted checkpoint, 0.7 on the second — inside the base margin of 2 on the probe's 4 096 pixels.  Some launch of the second checkpoint's
+    whole frame then refines a positive density whose estimate lay below -1: the tripwire fires, both margins double (2 -> 4: evidence the probe did not have), the call is
+    repeated and the context STAYS on plain-f16 estimates (round 4, which took the decision once on the first launch, never saw the event; giving the estimates up
+    instead costs 330 k against 510 k rays/s).  A wider margin refines a few more samples and changes nothing that carries a weight: the frame agrees with the six-slot
+    estimates' to fp32 round-off of a weighted sum."""
     from ibl_nerf_amd import dist as D
     g, sdc, sdf, _, _ = load_golden("fitted2_launch4k")
     K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], dtype=np.float32)
     c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    g1, sdc1, sdf1, _, _ = load_golden("fitted_launch16k")
+    r1 = make_renderer(R, g1, sdc1, sdf1, lut, mlp_precision="f16x3_mxfp6x")
+    route1 = D.decide_on_frame(r1, 800, 800, K, c2w, 0.5, 8.0)
+    assert route1["select_margin"] == [2.0, 2.0] and 0.0 <= max(route1["estimate_error"]) < 0.3, route1
     out = {}
-    for label, routing in (("measured", ()), ("margin2", ()), ("est6", ("estimates_6slot",))):
+    for label, routing in (("measured", ()), ("est6", ("estimates_6slot",))):
         r = make_renderer(R, g, sdc, sdf, lut, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         route = D.decide_on_frame(r, 800, 800, K, c2w, 0.5, 8.0)
-        assert route["estimates_plain_f16"] == [label != "est6"] * 2 and route["tripped"] == 0
-        if label == "est6":
-            assert route["select_margin"] == [2.0, 2.0] and route["estimate_error"] == [-1.0, -1.0]
-        else:
-            assert 0.5 < route["estimate_error"][0] < 1.0 < route["estimate_error"][1] < 1.3 and route["select_margin"] == [3.0, 3.5], route
-        if label == "margin2":
-            r.set_route(dict(route, select_margin=[2.0, 2.0]))
+        assert route["estimates_plain_f16"] == [label != "est6"] * 2 and route["tripped"] == 0 and route["select_margin"] == [2.0, 2.0]
+        assert route["estimate_error"] == [-1.0, -1.0] if label == "est6" else all(0.4 < e < 0.75 for e in route["estimate_error"]), route
         ro, rd = r.get_rays(800, 800, K, c2w)
         out[label] = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
-        assert r.trips == (1 if label == "margin2" else 0) and r.route["tripped"] == (1 if label == "margin2" else 0) and r.last_selection()[0] > 0
-        assert r.estimate_policy(0) == r.estimate_policy(1) == (True, label == "measured") and "predicted range" in r.describe_route()
-    for k in out["est6"]:
-        assert torch.equal(out["margin2"][k].nan_to_num(7.0), out["est6"][k].nan_to_num(7.0)), k
-    # the wider margin selects a few more samples and changes nothing that carries a weight: the measured-margin frame against the six-slot one
-    for k in ("depth_map", "target_normal_map", "albedo_map", "weights"):
+        assert r.last_selection()[0] > 0 and "predicted range" in r.describe_route() and r.estimate_policy(0) == r.estimate_policy(1) == (True, label != "est6")
+        if label == "measured":
+            assert r.trips == 1 and r.route["tripped"] == 1 and r.route["select_margin"] == [4.0, 4.0] and r.trip_bits == 4, r.route
+            again = r.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 0.5, 8.0)
+            assert r.trips == 1 and all(torch.equal(again[k].nan_to_num(7.0), out[label][k].nan_to_num(7.0)) for k in again)
+        else:
+            assert r.trips == 0
+    for k in ("depth_map", "target_normal_map", "albedo_map", "weights", "depth_map0", "target_normal_map0"):
         assert rel_linf(out["measured"][k].cpu().numpy(), out["est6"][k].cpu().numpy()) <= (1e-7 if k == "weights" else 2e-6), k
 
 
