@@ -113,8 +113,10 @@ struct iblnerf_ctx {
     int tripped = 0;                              // the estimate tripwire has fired since the decision (fold_flags): 1 = the estimates moved to f16 + 2 fp6, 2 = the lists went off
     double coarse_share = -1.0;                   // the probe's relevant share of the coarse grid (sel_on = it is <= SELECT_MAX_FRACTION)
     bool offsets_estimate_all = false;            // IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL: round 4's offsets (an estimate on every sample of every copy)
-    bool no_rescue = false;                       // IBLNERF_ROUTE_NO_RESCUE
     int* main_range = nullptr;                    // [ws_rays][2] first / last relevant sample of each ray's main query in the current pass (k_select_points range_out)
+    unsigned long long* tier_mask = nullptr;      // [ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers)
+    float tier_tau = 0.0f;                        // ... their threshold on T_s dist_s |depth - z_s| (iblnerf_set_offset_tier_threshold; 0 = no tiers, the default)
+    bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
     double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
@@ -179,15 +181,15 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->est_f16 = (bits & IBLNERF_ROUTE_ESTIMATES_6SLOT) == 0;
     c->est_whole = (bits & IBLNERF_ROUTE_ESTIMATES_WHOLE) != 0;
     c->offsets_estimate_all = (bits & IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL) != 0;
-    c->no_rescue = (bits & IBLNERF_ROUTE_NO_RESCUE) != 0;
     c->density_15slot = (bits & IBLNERF_ROUTE_COARSE_DENSITY_15SLOT) != 0;
+    c->no_offset_tiers = (bits & IBLNERF_ROUTE_NO_OFFSET_TIERS) != 0;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 8191) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..8191)");
+    if (bits < 0 || bits > 16383) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..16383)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -261,8 +263,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 8191 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..8191), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 16383 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..16383), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -304,7 +306,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
         }
     if (hipMalloc((void**)&c->sel_pts, 4 * R * Sm * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sm * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->sel_count, 12 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 12 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess || hipMalloc((void**)&c->sel_est, 4 * R * Sm * sizeof(float)) != hipSuccess) {
+        hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess || hipMalloc((void**)&c->sel_est, 4 * R * Sm * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->tier_mask, 4 * R * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
         return IBLNERF_ERR_NOMEM;
@@ -364,6 +367,7 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     if (c->sel_count) (void)hipFree(c->sel_count);
     if (c->main_range) (void)hipFree(c->main_range);
     if (c->sel_est) (void)hipFree(c->sel_est);
+    if (c->tier_mask) (void)hipFree(c->tier_mask);
     if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->bwd_stash) (void)hipFree(c->bwd_stash);
     if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -1300,6 +1304,8 @@ struct QueryPlan {
     Launch est;                      // the density estimate
     int cut0 = 0, cut1 = 0;          // ... in z-chunks [0, cut0) | [cut0, cut1) | [cut1, S), the later ones only for rays not yet saturated (0, 0: every sample at once)
     bool predicted = false;          // offset copies: the main ray's relevant range goes to the list without an estimate, estimates on the rest only (offsets_on_lists)
+    bool tiers = false;              // ... and the predicted range in two tiers: the samples k_importance flags on `on_list_precise`, the others on `on_list`
+    Launch on_list_precise;          // ... which also takes what the copy's OWN selection adds outside the predicted range (none: `on_list` does)
     float t_min = COARSE_SELECT_TMIN;
     Launch on_list;                  // the relevant samples
     Launch density_list;             // coarse main query: its density once more on the 15-slot form, same list
@@ -1408,6 +1414,16 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
             else q.on_list = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
             if (est_chunks(c, which)) { q.cut0 = (3 * S) / 4; q.cut1 = (7 * S) / 8; }
             q.predicted = could_predict;
+            // The fast table's mixed trunk form is good to 1.5e-3 in raw density, and 7 of the 8 rays of a 65 536-ray launch it left above 1e-3 on the normal (the safe
+            // table: 1, the fp32 C restatement: 0) turned out to owe it to the samples OUTSIDE the predicted range — what a copy's own selection adds where its ray found
+            // nothing relevant: a silhouette, the fringe of a haze; there a copy's depth hangs on one or two samples (scratch/which_query.py, scratch/tier_sweep.py).
+            // They are ~2 % of the refined samples: on three f16 products (what the safe table runs everywhere) they cost 1 % of a frame and the fast table's normals
+            // become the safe table's.  (Offset TIERS — the predicted range itself split by k_importance's bound T_s dist_s |depth - z_s| on the main ray, flagged
+            // samples on the precise kernel — were built for the same rays and measured: they remove one ray at 4 % of a frame; off by default, tier_tau = 0.)
+            if (q.predicted && fine_x_fast && c->d_stream_f16[which] != nullptr && c->mx_ok[which] && !c->no_offset_tiers) {
+                q.on_list_precise = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
+                q.tiers = c->tier_tau > 0.0f;
+            }
         }
     }
     return q;
@@ -1593,11 +1609,15 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
     }
     if (q.predicted) {
         MlpCall est = refine;
-        // 1: the predicted range, straight to the query's kernel (no estimate underneath: no tripwire)
-        HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-        HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
-                                       FLOP_TRUNK, list_slots(q.on_list), true));
-        if ((rc = run_launch(c, s, q.on_list, which, refine))) return rc;
+        // 1: the predicted range, straight to the query's kernel (no estimate underneath: no tripwire) — in one list, or in two tiers by k_importance's flags
+        if (q.tiers) HIP_TRY(c, launch_importance(p.rd, p.z, p.z_stride, c->raw, RAW_CH, R, S, c->tier_tau, c->tier_mask, s));
+        for (int tier = q.tiers ? 1 : 0; tier >= 0; --tier) {
+            const Launch& k = (q.tiers && tier == 1) ? q.on_list_precise : q.on_list;
+            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
+                                           FLOP_TRUNK, list_slots(k), true, q.tiers ? c->tier_mask : nullptr, tier));
+            if ((rc = run_launch(c, s, k, which, refine))) return rc;
+        }
         // 2, 3: estimates in front of it, and behind it where a copy is still alive
         for (int mode = 2; mode <= 3; ++mode) {
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
@@ -1624,7 +1644,7 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         if (*share > q.share_max) return IBLNERF_OK;      // (the caller runs the whole batch instead)
     }
     refine.trip_margin = c->margin[which];
-    return run_launch(c, s, q.on_list, which, refine);
+    return run_launch(c, s, q.on_list_precise.none() ? q.on_list : q.on_list_precise, which, refine);
 }
 
 // The offset copies of a pass (or the density-gradient rows of the autograd normal modes) into c->sig4.
@@ -2019,6 +2039,13 @@ int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
     return IBLNERF_OK;
 }
 
+int iblnerf_set_offset_tier_threshold(iblnerf_ctx* c, float tau) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!(tau >= 0.0f)) return c->fail(IBLNERF_ERR_INVALID, "set_offset_tier_threshold: tau >= 0 (0 = no tiers)");
+    c->tier_tau = tau;
+    return IBLNERF_OK;
+}
+
 int iblnerf_last_slot_units(iblnerf_ctx* c, double* slot_units) {
     if (!c || !slot_units) return IBLNERF_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->opt.device));
@@ -2113,10 +2140,12 @@ int iblnerf_describe_route(iblnerf_ctx* c, char* buf, size_t n) {
             return;
         }
         add("%-7s %-10s estimate: %s", pass, query, launch_name(q.est));
-        if (q.predicted) add(" on the samples outside the main ray's relevant range only (predicted range -> list directly)");
+        if (q.predicted) add(" on the samples outside the main ray's relevant range only (predicted range -> list directly%s)", q.tiers ? ", in two tiers" : "");
         else if (q.cut1 > 0) add(" in z-chunks [0,%d) [%d,%d) [%d,%d)", q.cut0, q.cut0, q.cut1, q.cut1, S);
         else add(" on every sample");
         add("; select T > %.0e; list: %s", (double)q.t_min, launch_name(q.on_list));
+        if (q.tiers) add(" | flagged samples (T dist |depth - z| > %.0e): %s", (double)c->tier_tau, launch_name(q.on_list_precise));
+        if (!q.on_list_precise.none()) add(" | own selection outside the predicted range: %s", launch_name(q.on_list_precise));
         if (!q.density_list.none()) add(" + %s", launch_name(q.density_list));
         add("\n");
     };

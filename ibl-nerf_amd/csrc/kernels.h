@@ -208,7 +208,12 @@ hipError_t launch_tripwire(const float* est_list, const int* index, const int* n
 // the offset copies' samples by the main ray's relevant range (k_range_points: mode 1 the predicted range, 2 in front of it, 3 behind it for the copies still alive);
 // list length at counter[0] (zeroed by the caller), executed MACs x 2 (flop_per_point per entry) added to counter[4..5], entries to counter[2..3] if count_entries
 hipError_t launch_range_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const int* main_range, long R, int S, int mode,
-                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries);
+                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries,
+                               const unsigned long long* tier_mask = nullptr, int tier = 0);   // mode 1: only the samples whose k_importance flag equals `tier`
+// per sample of the R main rays: does T_s dist_s |depth - z_s| (from the main query's densities, element (r, s) at (r S + s) * sigma_stride) exceed tau?  mask [R][4] uint64:
+// bit `lane` of mask[4 r + i] <-> sample lane * NPL + i (NPL = ceil(S / 64): the layout k_range_points reads)
+hipError_t launch_importance(const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, long R, int S, float tau, unsigned long long* mask,
+                             hipStream_t s);
 
 // estimates in two z-chunks: points + flat indices of samples [s0, s1) of every (virtual) ray (first: of all rays, in ray order; else: of the rays not yet saturated
 // behind their first s0 samples — list length at counter[0], executed MACs added to counter[4..5]; the others' samples get the density -1e30)

@@ -793,10 +793,13 @@ __device__ __forceinline__ void predicted_range(const int* __restrict__ main_ran
 //                                                     does, from the front estimates and the refined densities already in `sigma` — is still above t_min; the other
 //                                                     copies' samples behind get the density -1e30 (behind saturation, never relevant), exactly as k_chunk_points does.
 // Every sample of every copy lands in exactly one of the three; the prediction decides what a sample costs, never what it yields.
+// tier_mask / tier (mode 1 only; api.cpp offset tiers): the predicted range split by k_importance's per-sample flags of the MAIN ray — tier 1 emits the flagged samples
+// (where a density error would move the copy's depth most: they go to the precise kernel), tier 0 the others; null = the whole range.
 template <int NPL>
 __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride,
                                                                     float* __restrict__ sigma, const int* __restrict__ main_range, long R, int S, int mode, float margin,
-                                                                    float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter) {
+                                                                    float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
+                                                                    const unsigned long long* __restrict__ tier_mask, int tier) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;
     const bool live = vr_raw < 4 * R;
@@ -826,9 +829,21 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float*
         for (int dd = 1; dd < 64; dd <<= 1) lane_prod *= __shfl_xor(lane_prod, dd);
         alive = lane_prod > (double)t_min;
     }
+    bool emit[NPL];
+    unsigned long long masks[NPL];
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        bool e = alive && s >= s0 && s < s1;
+        if (tier_mask != nullptr) e = e && (int)((tier_mask[4 * r + i] >> lane) & 1ull) == tier;
+        emit[i] = e;
+        masks[i] = __ballot(e);
+        total += __popcll(masks[i]);
+    }
     __shared__ int wave_total[SELECT_WAVES];
     __shared__ int block_base;
-    if (lane == 0) wave_total[wave] = alive ? s1 - s0 : 0;
+    if (lane == 0) wave_total[wave] = total;
     __syncthreads();
     if (threadIdx.x == 0) {
         int sum = 0;
@@ -841,22 +856,74 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float*
     for (int w = 0; w < wave; ++w) base += wave_total[w];
     PointGen g;
     g.rays_o = rays_o; g.rays_d = rays_d; g.z = zbase; g.z_stride = z_stride; g.S = S; g.RS = (unsigned)(R * S); g.eps = eps;
+    int before = 0;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
-        if (!live || s < s0 || s >= s1) continue;
         const unsigned flat = (unsigned)(vr * S + s);
-        if (!alive) {
-            sigma[flat] = -1e30f;
-            continue;
+        if (live && !alive && s >= s0 && s < s1) sigma[flat] = -1e30f;          // (mode 3, a copy that has saturated: behind saturation, never relevant)
+        if (emit[i]) {
+            float p[3];
+            gen_offset_point(g, flat, p[0], p[1], p[2]);
+            const long pos = (long)base + before + __popcll(masks[i] & ((1ull << lane) - 1ull));
+            pts_out[3 * pos] = p[0];
+            pts_out[3 * pos + 1] = p[1];
+            pts_out[3 * pos + 2] = p[2];
+            index_out[pos] = (int)flat;
         }
-        float p[3];
-        gen_offset_point(g, flat, p[0], p[1], p[2]);
-        const long pos = (long)base + (s - s0);
-        pts_out[3 * pos] = p[0];
-        pts_out[3 * pos + 1] = p[1];
-        pts_out[3 * pos + 2] = p[2];
-        index_out[pos] = (int)flat;
+        before += __popcll(masks[i]);
+    }
+}
+
+// Where would an error on an offset copy's density move its depth most?  d depth / d sigma_s = T_s dist_s exp(-sigma_s dist_s) (z_s - depth behind s): per sample of
+// the MAIN ray (0.01 beside the copy: the same transmittance profile to first order) the bound T_s dist_s |depth - z_s|, from the main query's own densities.  Samples above
+// `tau` are flagged (bit `lane` of mask[4 r + i] <-> sample lane NPL + i): the fine grid's offset copies evaluate them on three f16 products, the others on the mixed
+// trunk form, whose 1.5e-3 in raw density then moves a copy's depth by < tau x 1.5e-3 x (unflagged samples) — with tau = 5e-6 and 192 samples below 1.5e-6, i.e. 7e-5 on
+// the normal.  (The rays this is for: a soft haze of small positive density in front of the surface — every sample of it sees the whole depth behind it.)
+template <int NPL>
+__global__ __launch_bounds__(256) void k_importance(const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride, const float* __restrict__ sigma,
+                                                    int sigma_stride, long R, int S, float tau, unsigned long long* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float norm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float* zrow = zbase + (long)z_stride * r;
+    float z[NPL], dist[NPL], alpha[NPL];
+    double om[NPL], lane_prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        z[i] = s < S ? zrow[s] : 0.0f;
+        const float zn = s + 1 < S ? zrow[s + 1] : 0.0f;
+        const float sg = s < S ? sigma[(r * S + s) * (long)sigma_stride] : 0.0f;
+        dist[i] = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
+        alpha[i] = s < S ? 1.0f - expf(-fmaxf(sg, 0.0f) * dist[i]) : 0.0f;
+        om[i] = s < S ? (double)((1.0f - alpha[i]) + 1e-10f) : 1.0;
+        lane_prod *= om[i];
+    }
+    double incl = lane_prod;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const double o = __shfl_up(incl, dd);
+        if (lane >= dd) incl *= o;
+    }
+    double T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.0;
+    float Ts[NPL], depth = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        Ts[i] = (float)T;
+        depth += alpha[i] * Ts[i] * z[i];
+        T *= om[i];
+    }
+    depth = wave_sum(depth);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int s = lane * NPL + i;
+        const bool flag = s < S && Ts[i] * fminf(dist[i], 1.0f) * fabsf(depth - z[i]) > tau;
+        const unsigned long long m = __ballot(flag);
+        if (lane == 0) mask[4 * r + i] = m;
     }
 }
 
@@ -1447,13 +1514,22 @@ hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const f
     return hipGetLastError();
 }
 
+hipError_t launch_importance(const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, long R, int S, float tau, unsigned long long* mask,
+                             hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    return by_npl(S, [&](auto N) {
+        hipLaunchKernelGGL((k_importance<decltype(N)::value>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, rays_d, z, z_stride, sigma, sigma_stride, R, S, tau, mask);
+    });
+}
+
 hipError_t launch_range_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, float* sigma, const int* main_range, long R, int S, int mode,
-                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries) {
+                               float margin, float t_min, float eps, float* pts_out, int* index_out, int* counter, hipStream_t s, double flop_per_point, double slots_per_point, bool count_entries,
+                               const unsigned long long* tier_mask, int tier) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)((4 * R + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
     const hipError_t e = by_npl(S, [&](auto N) {
         hipLaunchKernelGGL((k_range_points<decltype(N)::value>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, main_range, R, S, mode, margin, t_min, eps, pts_out,
-                           index_out, counter);
+                           index_out, counter, tier_mask, tier);
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, flop_per_point, slots_per_point, count_entries ? 1 : 0);

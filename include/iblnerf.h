@@ -142,7 +142,11 @@ enum {
                                                  fp32 on v_mfma_f32_32x32x2_f32 (csrc/trunk_fp32_kernel.hip: fp32 operands, products and accumulation — the arithmetic the
                                                  reference runs; 1/16 of the f16 rate on ~5 of a ray's 64 coarse samples).  These weights place the fine samples: the
                                                  15-slot form's 1e-6 .. 1.2e-5 on a coarse weight moved one ray's normal by 8.6e-3, fp32's 2e-6 does not */
-    IBLNERF_ROUTE_NO_RESCUE = 2048,           /* no second, 15-slot evaluation of the fine pass's densities on the rays k_pass_a flags as threshold-critical (api.cpp rescue) */
+    IBLNERF_ROUTE_NO_OFFSET_TIERS = 8192,     /* F16X3_MXFP6X, fast table: the fine grid's offset copies on the mixed trunk form everywhere (round 4).  Default since round 5:
+                                                 the samples a copy's OWN selection adds outside the main ray's relevant range (a silhouette, the fringe of a haze: ~2 % of the
+                                                 refined samples, where a copy's depth hangs on one or two of them) on three f16 products — 7 of the 8 normals the fast table
+                                                 alone left above 1e-3 on a 65 536-ray launch; and, with iblnerf_set_offset_tier_threshold > 0, the predicted range itself in
+                                                 two tiers by the bound T_s dist_s |depth - z_s| of the main ray (api.cpp plan_offsets, k_importance; off by default) */
     IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
                                                  f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
                                                  only has to be right to within the selection margin of 1.0 in raw density */
@@ -185,6 +189,8 @@ int iblnerf_decide_route(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, 
 /* Imposes a route (e.g. the one another rank or an earlier run decided); decided = 0 withdraws it. */
 int iblnerf_set_route(iblnerf_ctx* ctx, const iblnerf_route* route);
 int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
+/* Measurement hook: the threshold of the offset tiers (IBLNERF_ROUTE_NO_OFFSET_TIERS above; default 0 = no tiers). */
+int iblnerf_set_offset_tier_threshold(iblnerf_ctx* ctx, float tau);
 /* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
  * Writes at most n bytes including the terminating 0; returns the length the full text needs (snprintf's convention), < 0 on error. */
 int iblnerf_describe_route(iblnerf_ctx* ctx, char* buf, size_t n);

@@ -212,7 +212,9 @@ def test_refinement_on_the_relevant_samples_only(R, lut):
     out = {}
     # (the coarse pass's density on the 15-slot form in all three, which is what the all-points routing evaluates whole-batch: the comparison is about WHERE queries are
     # evaluated, not in which arithmetic — the default's exact-fp32 density on the list has its own test, test_exact_fp32_trunk_on_the_matrix_cores)
-    for label, routing in (("selected", ("coarse_density_15slot",)), ("est6", ("estimates_6slot", "coarse_density_15slot")), ("all", ("coarse_density_all_points",))):
+    # (likewise no_offset_tiers: the copies' own-selection samples on the mixed trunk form, as the whole-batch launch runs them)
+    for label, routing in (("selected", ("coarse_density_15slot", "no_offset_tiers")), ("est6", ("estimates_6slot", "coarse_density_15slot", "no_offset_tiers")),
+                           ("all", ("coarse_density_all_points",))):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         assert r.estimate_policy(0) == (False, False) and r.route is None
         out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], 0.5, 8.0)
@@ -320,6 +322,27 @@ def test_exact_fp32_trunk_on_the_matrix_cores(R, lut):
         assert rel_linf(out["fp32"][k], out["15slot"][k]) <= 5e-5, k
 
 
+def test_own_selection_samples_of_the_offset_copies_run_precise(R, lut):
+    """The fast table's last normals above 1e-3 (round 5, scratch/which_query.py).  Of the 8 rays of the 65 536-ray launch fixture that the fast table alone left above
+    1e-3 on the normal, 7 owed it not to the mixed trunk form's 1.5e-3 in raw density on the bulk of the offset copies' samples, but on the ~2 % of them OUTSIDE the main
+    ray's relevant range — what a copy's own selection adds where its ray found nothing: a silhouette, the fringe of a haze, where a copy's depth hangs on one or two
+    samples.  Those run on three f16 products by default (IBLNERF_ROUTE_NO_OFFSET_TIERS: on the mixed trunk form, round 4): on the launch-scale fixture the worst normal
+    of the fast table drops from 3.5e-3 to below 1e-3 — the fp32 C restatement's class — for the same matrix-slot units to three digits."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    out, slots = {}, {}
+    for label, routing in (("default", ()), ("round4", ("no_offset_tiers",))):
+        r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384, mlp_precision="f16x3_mxfp6x", query_routing=routing)
+        out[label] = to_np(r.render_rays(g["rays_o"], g["rays_d"], 0.5, 8.0))
+        slots[label] = r.last_slot_units()
+        assert ("own selection outside the predicted range: f16x3 TRUNK_LIST" in r.describe_route()) == (label == "default")
+    err = {lab: np.abs(m["target_normal_map"] - g["out__target_normal_map"]).max(-1) for lab, m in out.items()}
+    assert err["round4"].max() > 2e-3 and (err["round4"] > 1e-3).sum() >= 1, err["round4"].max()
+    assert err["default"].max() <= 1e-3 and np.percentile(err["default"], 99.9) <= np.percentile(err["round4"], 99.9), (err["default"].max(), np.percentile(err["default"], 99.9))
+    assert abs(slots["default"] / slots["round4"] - 1.0) < 0.01
+    for k in ("depth_map", "albedo_map", "weights", "target_normal_map0", "depth_map0"):      # (nothing but the fine pass's normal reads the offset copies)
+        assert np.array_equal(out["default"][k], out["round4"][k]), k
+
+
 def test_estimates_in_z_chunks_change_nothing(R, lut):
     """api.cpp estimate_chunked (round 4's route of the offset copies, IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL, and the fine main / reflected queries of every route): the
     density estimates run on the first samples of every (virtual) ray and on the later ones only for rays whose conservative transmittance is still above 1e-12 (the
@@ -351,7 +374,9 @@ def test_offset_copies_predicted_by_the_main_ray_change_nothing(R, lut, name):
     n = min(8192, g["rays_o"].shape[0])
     for prec in ("f16x3_mxfp6x", "f16x3_mxfp6"):
         out, sel, flops, slots = {}, {}, {}, {}
-        for label, routing in (("predicted", ()), ("estimate_all", ("offsets_estimate_all",))):
+        # (no_offset_tiers: the samples a copy's own selection adds on the table's own kernel in both routes — the default moves them to three f16 products,
+        # test_own_selection_samples_of_the_offset_copies_run_precise)
+        for label, routing in (("predicted", ("no_offset_tiers",)), ("estimate_all", ("offsets_estimate_all",))):
             r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec, query_routing=routing)
             out[label] = r.render_rays(g["rays_o"][:n], g["rays_d"][:n], float(g["near"]), float(g["far"]))
             sel[label], flops[label], slots[label] = r.last_selection(), r.last_executed_flops(), r.last_slot_units()
@@ -381,7 +406,7 @@ def test_a_handful_of_rays_decides_nothing(R, lut):
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     # (coarse_density_15slot: the whole-batch coarse density of an undecided context runs on the 15-slot form; with the same form on the lists the two routes are
     # comparable bit for bit, which is what the last block of this test asserts)
-    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=("coarse_density_15slot",))
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=("coarse_density_15slot", "no_offset_tiers"))
     small = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
     assert r.last_selection() == (0, 0) and r.estimate_policy(0) == r.estimate_policy(1) == (False, False) and r.route is None and not r.get_route()["decided"]
     assert "NOT decided" in r.describe_route() and "whole batch" in r.describe_route()
@@ -425,7 +450,7 @@ def test_density_only_coarse_pass_refines_the_same_samples(R, lut):
         assert torch.equal(out["lean"][k], out["full"][k]), k
 
 
-@pytest.mark.parametrize("prec,routing", [("f16x3", ()), ("bf16x3", ()), ("f16x3_mxfp6x", ("coarse_density_all_points",)), ("f16x3_mxfp6x", ())])
+@pytest.mark.parametrize("prec,routing", [("f16x3", ()), ("bf16x3", ()), ("f16x3_mxfp6x", ("coarse_density_all_points",)), ("f16x3_mxfp6x", ("no_offset_tiers",))])
 def test_generated_points_are_the_batch_bit_for_bit(R, lut, prec, routing):
     """csrc/gen_points.h: the epsilon-offset copies generated in the MLP kernels' input stage (contraction on) are the points k_make_points writes into a batch
     (IBLNERF_ROUTE_POINT_BATCH; render_kernels.hip, contraction off) — on a rotated camera away from the origin, where o + d z and d_x^2 + 1 round differently as
@@ -437,7 +462,7 @@ def test_generated_points_are_the_batch_bit_for_bit(R, lut, prec, routing):
     for label, extra in (("generated", ()), ("batch", ("point_batch",))):
         r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision=prec, query_routing=tuple(routing) + extra)
         out[label] = r.render_rays(g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]))
-    if routing == () and prec == "f16x3_mxfp6x":
+    if routing == ("no_offset_tiers",) and prec == "f16x3_mxfp6x":
         # (the batch routing evaluates the offset copies whole, the default refines lists of them: the same arithmetic on the relevant samples, estimates on the rest)
         # fine grid: TRUNK_X either way; coarse grid: the 15-slot form on the list against three f16 products on the batch
         assert float((out["generated"]["target_normal_map"] - out["batch"]["target_normal_map"]).abs().max()) <= 2e-6
@@ -522,7 +547,9 @@ def test_the_selection_margin_is_measured_and_the_tripwire_widens_it(R, lut):
     route1 = D.decide_on_frame(r1, 800, 800, K, c2w, 0.5, 8.0)
     assert route1["select_margin"] == [2.0, 2.0] and 0.0 <= max(route1["estimate_error"]) < 0.3, route1
     out = {}
-    for label, routing in (("measured", ()), ("est6", ("estimates_6slot",))):
+    # (no_offset_tiers: every refined offset sample on the same kernel — with the default, a wider margin moves samples between the predicted range (mixed trunk form) and
+    # the copies' own selections (three f16 products), which is a change of arithmetic, not of what carries a weight)
+    for label, routing in (("measured", ("no_offset_tiers",)), ("est6", ("estimates_6slot", "no_offset_tiers"))):
         r = make_renderer(R, g, sdc, sdf, lut, mlp_precision="f16x3_mxfp6x", query_routing=routing)
         route = D.decide_on_frame(r, 800, 800, K, c2w, 0.5, 8.0)
         assert route["estimates_plain_f16"] == [label != "est6"] * 2 and route["tripped"] == 0 and route["select_margin"] == [2.0, 2.0]

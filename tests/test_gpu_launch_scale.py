@@ -99,8 +99,9 @@ STRICT = dict(frac8=2000, n16=0, w_base=5e-4, w_cap=1e-3, w_p999=1e-3, p999=2e-4
 # THE YARDSTICK (round 5): what an actual fp32 implementation attains.  tests/golden/c_restatement_column.json (tests/golden/make_c_column.py) holds,
 # per launch-scale fixture and map, the fp32 C restatement's own rays above 1e-3 / 99.9th percentile / worst ray against the same reference render on the same rays.
 # Asserted against it: on the direct maps and the normal the HIP path has no more rays above the north-star 1e-3 than the C restatement has, plus an allowance that
-# scales with the launch — per 65 536 rays 2 on a direct map, 5 on the normal / n.v under the safe table and 12 under the fast one (never less than 1 / 1 / 2: counts of
-# single rays) — measured this round at 2 / 4 / 11 on the 65 536-ray launch against the C restatement's 0 / 0 / 0.  (Round 4 bounded the count by the number of rays the
+# scales with the launch — per 65 536 rays 2 on depth / albedo / roughness / irradiance, 5 on the normal / n.v, under either table (never less than 1 / 2: counts of
+# single rays) — measured at the end of this round at 0 / 2 (fast table; safe: 0 / 1) on the 65 536-ray launch against the C restatement's 0 / 0, and EQUAL to the C
+# restatement's counts on the seven 4 096 / 16 384-ray fixtures (round 4: 2 / 20 on the launch).  (Round 4 bounded the count by the number of rays the
 # reference's own sensitivity yardsticks flag — 17 / 642 there: true of the reference's conditioning, not an allowance anyone earned.)  The reflected-ray channels are
 # chaotic in every fp32 implementation — the C restatement itself has 2 - 8 % of a launch above 1e-3 there, and its WORST ray ranges from 1.3e-3 to 5.7e-1 over the eight
 # fixtures (0.47 - 0.57 on the hold-out's coarse pass, where the HIP path's is 0.02; 3.9e-3 on the second checkpoint's color_map0, where the HIP path's is 0.22): a worst-ray
@@ -113,8 +114,8 @@ C_COLUMN = json.load(open(_COL)) if os.path.exists(_COL) else {}
 def c_allowance(key, n, decision):
     base = key.rstrip("0")
     # (depth / albedo / roughness / irradiance: 2 per launch; the maps that multiply two of them or carry the view-dependent radiance — diffuse, radiance_k, disp, acc: 4)
-    per_launch = (12 if decision == "fast" else 5) if base in NORMAL_LIKE else (2 if base in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_depth_map") else 4)
-    return max((2 if decision == "fast" else 1) if base in NORMAL_LIKE else 1, int(np.ceil(per_launch * n / 65536.0)))
+    per_launch = 5 if base in NORMAL_LIKE else (2 if base in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_depth_map") else 4)
+    return max(2 if base in NORMAL_LIKE else 1, int(np.ceil(per_launch * n / 65536.0)))
 # what the calibration decides on each fixture's checkpoint and camera (asserted: a fast decision on the second checkpoint would be a parity bug, a safe
 # one on the first a 17 % slower frame for nothing)
 # (fitted_posed4k: "fast" until round 5 tightened the calibration's limits on the normal; fitted3_*: the hold-out checkpoint, decided by limits frozen before it existed)
@@ -233,8 +234,7 @@ def test_the_fast_table_on_the_second_checkpoint_is_what_the_calibration_says(R,
     check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"))            # round 4's rules (every ray against its own sensitivity in the reference) hold ...
     e = per_ray(res["weights"][::int(g["weights_every"])], g["out__weights"])
     assert np.percentile(e, 99.9) <= 4e-4 and e.max() <= 5e-4, (np.percentile(e, 99.9), e.max())
-    with pytest.raises(AssertionError):                                            # ... the C-restatement yardstick does not: 7 normals above 1e-3 where fp32 has 1 —
-        check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"), name="fitted2_launch4k", decision="fast")      # the fine offsets' mixed trunk form; the safe table has 2
+    check_against_fixture(res, g, rules=rules_for("fitted2_launch4k"), name="fitted2_launch4k", decision="fast")      # ... and so does the C-restatement yardstick
     # the safe table = f16x3_mxfp6, bit for bit (the same kernels on every query)
     g2, sdc2, sdf2, gt2, edit2 = load_golden("fitted2_posed4k")
     ra = make_renderer(R, g2, sdc2, sdf2, lut, max_rays_per_launch=16384)
@@ -338,9 +338,9 @@ def test_one_whole_launch_against_the_reference(R, lut):
     assert r.range_fallbacks == 0 and r.trips == 0 and r.policy["decision"] == "fast"
     rep = {}
     check_against_fixture({k: v.cpu().numpy() for k, v in m.items()}, g, rep, name="fitted_launch64k", decision="fast")
-    # (the whole launch under the fast table: depth / albedo / roughness / irradiance 2 rays above 1e-3 each — one extreme grazing ray, n.v = 0.01, and one more —, the
-    # normal 11, against the fp32 C restatement's 0; the safe table: 2 and 4)
-    assert rep["depth_map"][2] <= 2 and rep["target_normal_map"][2] <= 12, (rep["depth_map"], rep["target_normal_map"])
+    # (VERDICT r4's bar for this launch: 0 depth / <= 5 normal rays above 1e-3, where round 4 had 2 / 20 and the fp32 C restatement has 0 / 0.  Measured: 0 / 2 under the
+    # fast table — the coarse density in the reference's own fp32 summation order, the copies' own-selection samples on three f16 products —, 0 / 1 under the safe one)
+    assert rep["depth_map"][2] == 0 and rep["albedo_map"][2] == 0 and rep["target_normal_map"][2] <= 5, (rep["depth_map"], rep["albedo_map"], rep["target_normal_map"])
 
 
 @pytest.mark.parametrize("name,rows_fn", [("fitted_edit_cfg4", FO.edit_rows), ("fitted_insert_cfg5", FO.insert_rows)])
