@@ -35,13 +35,14 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # per mlp_precision: (dtype string, kernels, matrix-core products per algorithmic MAC)
 MODES = {
     "auto": ("per checkpoint, measured at load (renderer.calibrate): the fast table f16x3_mxfp6x — f16 hi/lo splits x3 products (~2^-22 per operand) where errors are amplified "
-             "(coarse grid's offset queries, auxiliary networks), the coarse pass's density on three f16 + three MX-fp6 products (~2^-26), f16 + 2x MX-fp6 (~2^-16) for the "
+             "(coarse grid's offset queries, auxiliary networks, the offset copies' own-selection samples), the coarse pass's density — it places the fine samples — in "
+             "EXACT fp32 (fp32 MFMA, the reference's own summation order), f16 + 2x MX-fp6 (~2^-16) for the "
              "main queries' other channels, layers 2-7 of the fine offsets and the reflected-ray queries — or, where that leaves the checkpoint's per-sample weights / maps "
              "beyond the calibration limits against it, f16x3_mxfp6 (x3 f16 products for every query but the reflected-ray ones); fp32 accumulate.  Since round 4 "
-             "each query of the fast table (and the coarse / reflected ones of the safe table) runs as a plain-f16 density ESTIMATE on every sample and in the precision "
-             "named here only on the samples that can carry a weight (k_select_points; roofline.executed)",
-             "ibl::mxk16::mlp_kernel<TRUNK> (estimates) + ibl::mxk::mlp_kernel<TRUNK_X_LIST|FULL_LIST|REFL_LIST|TRUNK_P> (relevant samples)",
-             "1 f16 product on every sample (density estimate); on the relevant samples 3 f16 + 3 block-scaled fp6 products in the coarse pass (density and offsets), "
+             "each query runs as a plain-f16 density ESTIMATE on its samples (round 5: of the offset copies only those outside the main ray's relevant range) and in the "
+             "precision named here only on the samples that can carry a weight (k_select_points, k_range_points; config.route_table; roofline.executed)",
+             "ibl::mxk16::mlp_kernel<TRUNK> (estimates) + ibl::mxk::mlp_kernel<TRUNK_X_LIST|FULL_LIST|REFL_LIST> + ibl::f16x3k::mlp_kernel<TRUNK_LIST> + k_trunk_fp32 (relevant samples)",
+             "1 f16 product per estimated sample; on the relevant samples fp32 products for the coarse density, 3 f16 products for the coarse grid's offset copies, "
              "1 f16 + 2 block-scaled fp6 products elsewhere in the fast table (layers 0-1 of the fine offsets: 3 f16), 3 f16 products in the safe one"),
     "f16x3_mxfp6": ("f16 hi/lo splits x3 products (~2^-22 per operand) for every query but the reflected-ray ones, which run "
                     "f16 + 2x MX-fp6 residual products (~2^-16); fp32 accumulate",
@@ -389,7 +390,7 @@ def main():
             r4.load_weights(1, f4)
             r4.load_lut(lut)
             pol4 = D.calibrate_on_frame(r4, H, W, K, c2w, NEAR, FAR)
-            r4.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+            r4.render_rays(ro, rd, NEAR, FAR)          # (one untimed frame: a tripwire event — once per checkpoint, the call repeated — must not land in the timed one)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             r4.render_rays(ro, rd, NEAR, FAR)
