@@ -1419,7 +1419,10 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
             // nothing relevant: a silhouette, the fringe of a haze; there a copy's depth hangs on one or two samples (scratch/which_query.py, scratch/tier_sweep.py).
             // They are ~2 % of the refined samples: on three f16 products (what the safe table runs everywhere) they cost 1 % of a frame and the fast table's normals
             // become the safe table's.  (Offset TIERS — the predicted range itself split by k_importance's bound T_s dist_s |depth - z_s| on the main ray, flagged
-            // samples on the precise kernel — were built for the same rays and measured: they remove one ray at 4 % of a frame; off by default, tier_tau = 0.)
+            // samples on the precise kernel — were built for the same rays and measured: they remove one ray at 4 % of a frame; off by default, tier_tau = 0.
+            // The other direction was measured too (scratch/lean_sweep.py, experiment hook since removed): the predicted range on the plain f16 + 2 fp6 trunk, 6 slots
+            // instead of 7.5, puts 8 normals of the 65 536-ray launch and 113 of the second checkpoint's 4 096 rays above 1e-3; the coarse grid's copies on the mixed
+            // trunk form 4 coarse normals.  The table is at its floor.)
             if (q.predicted && fine_x_fast && c->d_stream_f16[which] != nullptr && c->mx_ok[which] && !c->no_offset_tiers) {
                 q.on_list_precise = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
                 q.tiers = c->tier_tau > 0.0f;
@@ -2045,6 +2048,7 @@ int iblnerf_set_offset_tier_threshold(iblnerf_ctx* c, float tau) {
     c->tier_tau = tau;
     return IBLNERF_OK;
 }
+
 
 int iblnerf_last_slot_units(iblnerf_ctx* c, double* slot_units) {
     if (!c || !slot_units) return IBLNERF_ERR_INVALID;
