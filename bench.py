@@ -473,6 +473,8 @@ def main():
                                       # what governs speed on a power-bound chip (STATE.md section 2): per launch points x 64-MAC groups x the matrix slots its
                                       # product scheme spends per group (plain f16 4, f16 + 2 fp6 6, mixed trunk 7.5, three f16 products 12, 15-slot 15), per ray
                                       "slot_units_per_ray": slot_units / max(n_rows * W, 1),
+                                      "slot_unit": "64 MACs of one sample x the matrix slots its product scheme spends on them (plain f16 4, f16 + 2 fp6 6, mixed trunk 7.5, 3 x f16 12, 15-slot 15, fp32 64), summed over the last step's MLP launches",
+                                      "ps_per_slot_unit": (mlp_ms * 1e9 / max(slot_units, 1.0)) if mlp_ms > 0 else None,
                                       "note": "2 x nn.Linear MACs of the launches as run (estimates: trunk only; head layers, 15-slot densities and refinements: selected samples only)"},
                          "note": "algorithmic FLOPs (2 x nn.Linear MACs) counted once; per MAC the kernel issues " + MODES[args.mlp_precision][2]},
         }
