@@ -117,6 +117,7 @@ struct iblnerf_ctx {
     unsigned long long* tier_mask = nullptr;      // [ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers)
     float tier_tau = 0.0f;                        // ... their threshold on T_s dist_s |depth - z_s| (iblnerf_set_offset_tier_threshold; 0 = no tiers, the default)
     bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
+    bool ci_embedded[2] = {false, false};          // colour-independent context: slot's packed streams carry the identity in place of the feature / view layers
     double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
     float* sel_pts = nullptr;                     // [4 * ws_rays * Sc, 3] compact list of the relevant coarse samples' points (k_select_points; 4: the offset copies)
@@ -397,6 +398,19 @@ static void reset_route(iblnerf_ctx* c, int slot) {
 static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_floats, const char* who) {
     if (n_floats != blob_floats())
         return c->fail(IBLNERF_ERR_INVALID, "%s: blob has %zu floats, the IBLNeRF state dict has %zu", who, n_floats, blob_floats());
+    std::vector<float> embedded;
+    if (slot < 2 && c->opt.color_independent_to_direction) {
+        // is_color_independent_to_direction (ibl_nerf.py:192): the radiance heads read the trunk's output, feature_linear / views_linears are unused.  The packed
+        // streams carry the identity in their place (kernels.h launch_identity_embed) — the forward's _CI instantiations skip those layers, the fused backward
+        // (VAR_NET_BWD, built for the full architecture) runs through them and finds h2 = h7
+        embedded.assign(h_blob, h_blob + n_floats);
+        size_t vw, vb, fw, fb;
+        blob_offsets(8, &vw, &vb); blob_offsets(9, &fw, &fb);
+        std::fill(embedded.begin() + vw, embedded.begin() + vb + 256, 0.0f);
+        std::fill(embedded.begin() + fw, embedded.begin() + fb + 256, 0.0f);
+        for (int o = 0; o < 256; ++o) { embedded[vw + (size_t)o * 283 + o] = 1.0f; embedded[fw + (size_t)o * 256 + o] = 1.0f; }
+        h_blob = embedded.data();
+    }
     std::vector<char> stream((size_t)STREAM_BYTES);
     std::vector<float> tab((size_t)TAB_FLOATS);
     pack_network(h_blob, stream.data(), tab.data());
@@ -428,6 +442,7 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
         HIP_TRY(c, hipMemcpy(c->d_stream_mx[slot], smx.data(), mx::STREAM_BYTES, hipMemcpyHostToDevice));
     }
     c->have_net[slot] = true;
+    if (slot < 2) c->ci_embedded[slot] = !embedded.empty();
     reset_route(c, slot);
     return IBLNERF_OK;
 }
@@ -491,12 +506,20 @@ int iblnerf_upload_weights_device(iblnerf_ctx* c, void* stream, int which, const
     // kernel until its next upload (the activation flag alone cannot be relied on: inf * 0 or -inf through a ReLU can hide it)
     unsigned* wflag = c->d_range_flag ? c->d_range_flag + 1 + which : nullptr;
     if (wflag) HIP_TRY(c, hipMemsetAsync(wflag, 0, sizeof(unsigned), (hipStream_t)stream));
-    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_stream_f16[which], c->d_tables[which], wflag,
-                                   (hipStream_t)stream));
+    c->ci_embedded[which] = false;
     if (c->opt.mlp_precision != IBLNERF_MLP_BF16X3) {
         if (!c->d_blob32[which]) HIP_TRY(c, hipMalloc((void**)&c->d_blob32[which], n_floats * sizeof(float)));
         HIP_TRY(c, hipMemcpyAsync(c->d_blob32[which], d_blob, n_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (c->opt.color_independent_to_direction) {            // (upload_slot: the identity in place of the unused feature / view layers)
+            size_t vw, vb, fw, fb;
+            blob_offsets(8, &vw, &vb); blob_offsets(9, &fw, &fb);
+            HIP_TRY(c, launch_identity_embed(c->d_blob32[which], vw, vb, fw, fb, (hipStream_t)stream));
+            d_blob = c->d_blob32[which];
+            c->ci_embedded[which] = true;
+        }
     }
+    HIP_TRY(c, launch_pack_weights(d_blob, maps, c->d_stream[which], c->d_stream_mx[which], c->d_stream_f16[which], c->d_tables[which], wflag,
+                                   (hipStream_t)stream));
     c->mx_ok[which] = true;
     c->have_net[which] = true;
     reset_route(c, which);
@@ -875,9 +898,18 @@ int iblnerf_network_backward(iblnerf_ctx* c, void* stream, int which, const floa
     if (!c) return IBLNERF_ERR_INVALID;
     if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_viewdirs || !d_draw)))
         return c->fail(IBLNERF_ERR_INVALID, "network_backward: bad arguments");
-    if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "network_backward: not built for colour-independent networks");
-    return trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, nullptr, grad_scale, d_out, d_grad, d_viewdirs, n_samples,
-                               nullptr, d_draw);
+    const bool ci = c->opt.color_independent_to_direction;
+    if (ci && (which < 0 || which > 1 || !c->ci_embedded[which]))
+        return c->fail(IBLNERF_ERR_STATE, "network_backward: a colour-independent network's backward needs an mlp_precision that keeps the fp32 state dict (not bf16x3)");
+    const int rc = trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, nullptr, grad_scale, d_out, d_grad, d_viewdirs, n_samples,
+                                       nullptr, d_draw);
+    if (rc || !ci) return rc;
+    // the identity layers standing in for feature_linear / views_linears.0 are not parameters of such a network (ibl_nerf.py:192: unused, no gradient)
+    size_t vw, vb, fw, fb;
+    blob_offsets(8, &vw, &vb); blob_offsets(9, &fw, &fb);
+    HIP_TRY(c, hipMemsetAsync(d_grad + vw, 0, (vb + 256 - vw) * sizeof(float), (hipStream_t)stream));
+    HIP_TRY(c, hipMemsetAsync(d_grad + fw, 0, (fb + 256 - fw) * sizeof(float), (hipStream_t)stream));
+    return IBLNERF_OK;
 }
 
 int iblnerf_trunk_features2_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_rays, int n_samples,
@@ -1066,8 +1098,22 @@ int iblnerf_ray_outputs_backward(iblnerf_ctx* c, void* stream, const float* d_ma
     return iblnerf_ray_outputs_backward_gt(c, stream, d_maps, d_n_dot_v, d_env, depth0, up, nullptr, n_rays, d_dmaps);
 }
 
+static int ray_outputs_backward_impl(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
+                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps);
+
 int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
+    return ray_outputs_backward_impl(c, stream, d_maps, d_n_dot_v, d_env, depth0, nullptr, up, ovr, n_rays, d_dmaps);
+}
+
+int iblnerf_ray_outputs_backward_rays(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, const float* d_depth0,
+                                      const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
+    if (c && n_rays > 0 && d_n_dot_v && !d_depth0) return c->fail(IBLNERF_ERR_INVALID, "ray_outputs_backward_rays: d_depth0 [n_rays] is required with d_n_dot_v");
+    return ray_outputs_backward_impl(c, stream, d_maps, d_n_dot_v, d_env, 1.0f, d_depth0, up, ovr, n_rays, d_dmaps);
+}
+
+static int ray_outputs_backward_impl(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
+                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (ovr && ovr->mode != 0)
         return c->fail(IBLNERF_ERR_STATE, "ray_outputs_backward: edit / insert overrides in a gradient-carrying render are not built (only the *_from_gt constants)");
@@ -1078,7 +1124,7 @@ int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* c, void* stream, const float* d
     if (n_rays == 0) return IBLNERF_OK;
     HIP_TRY(c, hipSetDevice(c->opt.device));
     RayBwdArgs a{};
-    a.x = d_maps; a.ndv = d_n_dot_v; a.env = d_env; a.lut = c->d_lut; a.depth0 = depth0;
+    a.x = d_maps; a.ndv = d_n_dot_v; a.env = d_env; a.lut = c->d_lut; a.depth0 = depth0; a.depth0_ray = d_depth0;
     a.out_mode = (c->opt.gamma_correct ? 1 : 0) | (c->opt.use_radiance_linear ? 2 : 0);
     a.lut_f0 = c->opt.lut_coefficient_f0; a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.g_color = up->color_map; a.g_radiance = up->radiance_map;
@@ -1115,6 +1161,15 @@ int iblnerf_sample_points(iblnerf_ctx* c, void* stream, const float* d_rays_o, c
     if (n_rays == 0) return IBLNERF_OK;
     HIP_TRY(c, hipSetDevice(c->opt.device));
     HIP_TRY(c, launch_make_points(0, d_rays_o, d_rays_d, d_z, n_samples, 0.f, (long)n_rays, n_samples, d_pts, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_coarse_z_rays(iblnerf_ctx* c, void* stream, const float* d_near, const float* d_far, const float* d_t_rand, int64_t n_rays, float* d_z) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (n_rays < 0 || (n_rays > 0 && (!d_z || !d_near || !d_far))) return c->fail(IBLNERF_ERR_INVALID, "coarse_z_rays: bad arguments");
+    if (n_rays == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, launch_ray_grid(d_near, d_far, c->Sc, c->opt.lindisp, d_t_rand, (long)n_rays, d_z, (hipStream_t)stream));
     return IBLNERF_OK;
 }
 

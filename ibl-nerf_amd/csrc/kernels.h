@@ -14,6 +14,10 @@ struct PackMaps {                 // device copies of pack.cpp's build_pack_maps
     const int* mx;
     const int* tab;
 };
+// A colour-independent network (ibl_nerf.py:192) as a member of the built architecture: feature_linear = I, views_linears.0 = [I | 0], zero biases — the view layer's
+// output IS the trunk's (h >= 0 after its ReLU, so the view layer's ReLU changes nothing), which is what such a network's radiance heads read.  Written over those two
+// layers of a device copy of the state dict (offsets in floats: pack.h blob_offsets(8 | 9)).
+hipError_t launch_identity_embed(float* d_blob, size_t views_w, size_t views_b, size_t feat_w, size_t feat_b, hipStream_t s);
 hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, char* d_stream_f16,
                                float* d_tab, unsigned* d_range_flag, hipStream_t s);   // either fast stream may be null
 
@@ -130,6 +134,7 @@ struct RayBwdArgs {
     const float* env;        // [n, 4, 3] linear reflected-ray maps (radiance, coarse radiances 1..3)
     const float* lut;        // [3, 512, 512]
     float depth0;            // (near + far) / 2
+    const float* depth0_ray = nullptr;   // ... per ray [n] (per-ray near / far planes), or nullptr
     int out_mode;            // bit 0 gamma_correct, bit 1 use_radiance_linear (out_map)
     int lut_f0, correct_depth;
     const float *g_color, *g_radiance, *g_radiance_k[3], *g_irradiance, *g_albedo, *g_roughness, *g_specular, *g_diffuse, *g_prefiltered,

@@ -128,6 +128,21 @@ __global__ void k_pack_tab(const float* blob, const int* map, float* tab, int n)
 
 }  // namespace
 
+namespace {
+// views_linears.0 [256 out][283 in] <- [I | 0], feature_linear [256][256] <- I, both biases <- 0
+__global__ void k_identity_embed(float* views_w, float* views_b, float* feat_w, float* feat_b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 256 * 283) views_w[i] = (i / 283 == i % 283) ? 1.0f : 0.0f;
+    if (i < 256 * 256) feat_w[i] = (i / 256 == i % 256) ? 1.0f : 0.0f;
+    if (i < 256) { views_b[i] = 0.0f; feat_b[i] = 0.0f; }
+}
+}  // namespace
+
+hipError_t launch_identity_embed(float* d_blob, size_t views_w, size_t views_b, size_t feat_w, size_t feat_b, hipStream_t s) {
+    hipLaunchKernelGGL(k_identity_embed, dim3((256 * 283 + 255) / 256), dim3(256), 0, s, d_blob + views_w, d_blob + views_b, d_blob + feat_w, d_blob + feat_b);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* d_stream_bf16, char* d_stream_mx, char* d_stream_f16,
                                float* d_tab, unsigned* d_range_flag, hipStream_t s) {
     const long n16 = (long)N_CHUNKS * CHUNK_KSTEPS * 512;

@@ -1641,9 +1641,10 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         // mip level (:453-467); the depth inside it carries no gradient (depth_map.detach())
         float level = rough_net, dlevel = 1.0f;
         if (a.correct_depth) {
-            const float v = rough_net * depth / a.depth0;
+            const float d0 = a.depth0_ray != nullptr ? a.depth0_ray[r] : a.depth0;
+            const float v = rough_net * depth / d0;
             level = fminf(fmaxf(v, 0.0f), 1.0f);
-            dlevel = (v >= 0.0f && v <= 1.0f) ? depth / a.depth0 : 0.0f;
+            dlevel = (v >= 0.0f && v <= 1.0f) ? depth / d0 : 0.0f;
         }
         int i1 = (int)(level * 3.0f);
         i1 = i1 < 0 ? 0 : (i1 > 3 ? 3 : i1);

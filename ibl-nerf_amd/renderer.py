@@ -760,7 +760,8 @@ class Renderer:
         """dL/d(output maps) -> dL/d(linear direct maps [n, 19]) through the ray-sized part of raw2outputs (iblnerf_ray_outputs_backward): `maps` = the
         pass's linear maps (composite_direct), `upstream` = {map name: gradient or None}; n_dot_v [n] / env [n, 4, 3] = the pass's no-grad
         quantities (None, None for approximate_radiance=False).  gt: {"albedo" [n,3], "roughness" [n], "irradiance" [n,3], "depth" [n]} — the target maps
-        of the calculate_*_from_gt / depth_map_from_ground_truth flags that are on, constants of the backward (iblnerf_ray_outputs_backward_gt)."""
+        of the calculate_*_from_gt / depth_map_from_ground_truth flags that are on, constants of the backward (iblnerf_ray_outputs_backward_gt).
+        depth0: (near + far) / 2, a float — or a [n] tensor under per-ray planes (iblnerf_ray_outputs_backward_rays)."""
         torch = _torch()
         x = _dev_f32(maps, self.device).reshape(-1, 19)
         n = x.shape[0]
@@ -790,9 +791,16 @@ class Renderer:
                     t = _dev_f32(gt[name], self.device).reshape(n, ch).contiguous()
                     keep.append(t)
                     setattr(ov, field, t.data_ptr())
-        B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward_gt(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
-                                                                   None if ev is None else ev.data_ptr(), float(depth0), C.byref(up),
-                                                                   None if ov is None else C.byref(ov), n, dx.data_ptr()))
+        if torch.is_tensor(depth0):
+            d0 = _dev_f32(depth0, self.device).reshape(n).contiguous()
+            keep.append(d0)
+            B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward_rays(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
+                                                                         None if ev is None else ev.data_ptr(), d0.data_ptr(), C.byref(up),
+                                                                         None if ov is None else C.byref(ov), n, dx.data_ptr()))
+        else:
+            B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward_gt(self.ctx, self._stream(), x.data_ptr(), None if ndv is None else ndv.data_ptr(),
+                                                                       None if ev is None else ev.data_ptr(), float(depth0), C.byref(up),
+                                                                       None if ov is None else C.byref(ov), n, dx.data_ptr()))
         self._keep_up = keep      # the inputs must outlive the asynchronous launch (same stream as torch's allocator, but some are temporaries of this call)
         return dx
 
@@ -1415,38 +1423,36 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
     nf = (_plane(near, ro_f.shape[0]), _plane(far, ro_f.shape[0]))
     smp = dict(perturb=float(kwargs.get("perturb", 0.) or 0.), pytest=bool(kwargs.get("pytest", False)), chunk=chunk)
     approx = bool(kwargs.get("approximate_radiance", False))
-    if (is_depth_only or not approx or training) and (viewdirs_src is not None or any(_torch().is_tensor(v) for v in nf)):
-        raise NotImplementedError("c2w_staticcam and per-ray near / far planes are built for the inference render (approximate_radiance=True, no gradients)")
     if is_depth_only or not approx or training:
-        # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays, no overrides
-        # the four ground-truth substitutions are built for the gradient-carrying approximate_radiance render (constants of its backward: training.render_rays_train)
+        # the paths only a training run takes (train.py:285-297, :366-374): built from the stages of render_rays.  The four ground-truth substitutions and the
+        # edit / insert overrides are constants of a backward (training.render_rays_train: override_rows, _gt_constants); is_depth_only returns before raw2outputs
+        # reads any of them (:197-198), auxiliary networks included
         gt_flags = {k: True for k in ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth")
                     if _truthy(edit.get(k))}
-        gt_ok = training and approx and not is_depth_only
-        flags_on = any(_truthy(v) for k, v in edit.items() if (k in _SWITCHES or k in FROM_GT_FLAGS) and not (gt_ok and k in gt_flags))
         aux_on = any(v is not None for v in r._aux.values())           # (load_aux(name, None) leaves a {name: None} entry: a cleared network is no network)
         if training and kwargs.get("infer_depth") and any(getattr(p, "requires_grad", False) for p in getattr(kwargs.get("depth_mlp"), "parameters", lambda: [])()):
             # train.py:351-379 reads ret['inferred_depth_map'] and backpropagates loss_depth_random into depth_mlp; the posdir kernel has no backward
             raise NotImplementedError("a depth_mlp with trainable parameters in a gradient-carrying render (infer_depth training, train.py:351-379) is not built: "
                                       "its inferred_depth_map would carry no grad_fn and the network would silently never train; evaluate depth_mlp in torch, "
                                       "or freeze it (requires_grad_(False)) to render with it")
-        if flags_on or aux_on or _ci_net(kwargs["network_fn"]):
-            raise NotImplementedError("edit / insert overrides, *_from_gt flags, auxiliary and colour-independent networks are not built "
-                                      "for is_depth_only, approximate_radiance=False and gradient-carrying renders (no shipped config has them; keep the "
-                                      "reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
+        if not is_depth_only and aux_on:
+            raise NotImplementedError("auxiliary networks are not built for approximate_radiance=False and gradient-carrying renders (no shipped config has them; "
+                                      "keep the reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
+        ovr = {k: v for k, v in edit.items() if k not in FROM_GT_FLAGS}
         std = float(kwargs.get("raw_noise_std", 0.) or 0.)
         if is_depth_only:                                                       # raw2outputs_depth (:197-198)
             ret = T.render_rays_depth_only(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
                                       approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std,
-                                      gt_values=kwargs.get("gt_values"), from_gt=gt_flags if gt_ok else None, **smp)
+                                      gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr, **smp)
         else:
-            ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, **smp)
+            ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr, **smp)
         if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:
             # :722-726 runs whatever the pass type; a constant here (a trainable depth_mlp was refused above), appended last as in the reference
             with _torch().no_grad():
-                vd = rd_f / rd_f.norm(dim=-1, keepdim=True)
+                vd = rd_f if viewdirs_src is None else viewdirs_src          # (c2w_staticcam: the other pose's directions, :791-795)
+                vd = vd / vd.norm(dim=-1, keepdim=True)
                 ret["inferred_depth_map"] = _torch().relu(r.posdir_query(ro_f, vd)[:, 0, 0])
         return {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in ret.items()}
     ret = r.render_rays(ro_f, rd_f, *nf, kwargs.get("gt_values"), raw_noise_std=float(kwargs.get("raw_noise_std", 0.) or 0.), **smp, **edit)

@@ -18,8 +18,9 @@ Nothing of size [n_rays, n_samples] is computed by torch: such tensors exist onl
 (and roughness_linear unless freeze_roughness) receive gradients — the upstream rows of the frozen outputs are zeroed and the gradients
 of the frozen layers dropped.
 
-Not built here (raise): edit / insert overrides and the *_from_gt flags in a training step, auxiliary and colour-independent networks,
-a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.  (raw_noise_std > 0 is: the step's noise rows are drawn once, added to the
+Edit / insert overrides and the four *_from_gt substitutions are constants of the backward (override_rows, _gt_constants), under either value of
+approximate_radiance; colour-independent networks run the same backward with the identity in place of their unused feature / view layers.
+Not built here (raise): auxiliary networks, a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.  (raw_noise_std > 0 is: the step's noise rows are drawn once, added to the
 density the compositing reads in both directions, and are constants of the backward.)
 """
 from __future__ import annotations
@@ -116,6 +117,102 @@ def _ray_outputs(x, consts, flags, gt=None):
     return res
 
 
+def override_rows(r, n, gt_values, edit, approximate_radiance, chunk=None):
+    """The edit / insert overrides of raw2outputs (ibl_nerf_renderer.py:218-238 masks; :253-256 depth; :378-410 albedo / roughness / irradiance — the latter three only
+    inside `if approximate_radiance`) as RAY-sized rows: {"depth" | "albedo" | "roughness" | "irradiance": (mask [n] bool, values [n] or [n, 3])} in the order the
+    reference assigns them.  In the reference they are in-place masked assignments on the target maps: the masked rows become constants of the step (no gradient
+    reaches the network's own map there, neither through the output of that name nor through the shading), the other rows are untouched.  The forward applies
+    them in pass A (iblnerf_overrides); a backward substitutes them into the linear maps it differentiates at and zeroes dL/d(those entries).
+    (The normal overrides make n.v and the reflected ray constants of the backward already: both are computed under no_grad / detached, :358-361, :442.)"""
+    torch = _torch()
+    from .renderer import _dev_f32, _truthy, resolve_edit_roughness
+    edit = edit or {}
+    gv = gt_values or {}
+    on = lambda k: _truthy(edit.get(k, False))
+    ei, io = on("edit_intrinsic"), on("insert_object")
+    if not ei and not io:
+        return {}
+    dev = r.device
+    row = lambda key: _dev_f32(gv[key], dev).reshape(n, -1)
+    mask_img = row("edit_intrinsic_mask" if ei else "object_insert_mask")[:, 0]
+    nobj = int(edit.get("num_edit_objects" if ei else "num_insert_objects") or 0)
+    assert nobj > 0, "num_edit_objects must be greater than 0" if ei else "num_insert_objects must be greater than 0"
+    masks = [torch.logical_and(11 * (i + 1) / 255. > mask_img, mask_img > 9 * (i + 1) / 255.) for i in range(nobj)]        # :224-226, :234-236
+    mask_all = mask_img > 0
+    out = {}
+
+    def per_object(values, width):
+        """the objects' masks assigned in order (a later object wins where two masks overlap — they cannot: disjoint grey-level bands)"""
+        m = torch.zeros((n,), dtype=torch.bool, device=dev)
+        v = torch.zeros((n, width), dtype=torch.float32, device=dev)
+        for i, val in enumerate(values):
+            if val is None:
+                continue
+            m = m | masks[i]
+            v[masks[i]] = torch.as_tensor(val, dtype=torch.float32, device=dev).reshape(1, width)
+        return m, (v if width > 1 else v[:, 0])
+
+    if ei:
+        if on("edit_depth"):
+            out["depth"] = (mask_all, row("edit_depth")[:, 0])
+        if approximate_radiance:
+            if on("edit_albedo"):
+                if on("edit_albedo_by_img"):
+                    out["albedo"] = (mask_all, row("edit_albedo")[:, :3])
+                else:
+                    alb = list(edit.get("editing_target_albedo_list") or [])
+                    out["albedo"] = per_object([alb[3 * i:3 * i + 3] for i in range(nobj)], 3)
+            if on("edit_roughness"):
+                if on("edit_roughness_by_img"):
+                    per_ray = (_dev_f32(gv["_edit_roughness_resolved"], dev).reshape(n) if "_edit_roughness_resolved" in gv
+                               else resolve_edit_roughness(mask_img, row("edit_roughness")[:, 0], chunk))
+                    out["roughness"] = (mask_all, per_ray)
+                else:
+                    out["roughness"] = per_object(list(edit.get("editing_target_roughness_list") or [])[:nobj], 1)
+    else:
+        out["depth"] = (mask_all, row("object_insert_depth")[:, 0])
+        if approximate_radiance:
+            rgh = list(edit.get("inserting_target_roughness_list") or [])
+            alb = list(edit.get("inserting_target_albedo_list") or [])
+            irr = list(edit.get("inserting_target_irradiance_list") or [])
+            out["roughness"] = per_object(rgh[:nobj], 1)
+            out["irradiance"] = per_object([v if v > 0 else None for v in irr[:nobj]], 1)                                    # :406-407
+            out["albedo"] = per_object([alb[3 * i:3 * i + 3] for i in range(nobj)], 3)
+    return out
+
+
+# the columns of the linear direct maps (Renderer.MAP_SLOTS order) an override of that name replaces
+_OVERRIDE_COLS = {"depth": slice(0, 1), "albedo": slice(2, 5), "roughness": slice(5, 6), "irradiance": slice(6, 7)}
+
+
+def _apply_overrides(x, gt_const, rows):
+    """(x', gt') with the override rows substituted where the reference's in-place assignments land: in the ground-truth map when a *_from_gt flag made that the
+    target (:321-330: target_albedo_map = gt_values["albedo"], then target_albedo_map[mask] = ...), else in the network's own map."""
+    torch = _torch()
+    if not rows:
+        return x, gt_const
+    x = x.clone()
+    gt_const = dict(gt_const or {})
+    for name, (mask, vals) in rows.items():
+        if gt_const.get(name) is not None:
+            g = gt_const[name].clone()
+            v = vals if vals.dim() == g.dim() else vals[:, None].expand_as(g)
+            gt_const[name] = torch.where(mask[:, None] if g.dim() == 2 else mask, v, g).contiguous()
+        else:
+            cols = _OVERRIDE_COLS[name]
+            v = vals if vals.dim() == 2 else vals[:, None]
+            x[:, cols] = torch.where(mask[:, None], v, x[:, cols])
+    return x, gt_const
+
+
+def _zero_overridden(dx, gt_const, rows):
+    """dL/d(linear maps) of the rows an override made constants"""
+    for name, (mask, _) in (rows or {}).items():
+        if (gt_const or {}).get(name) is None:
+            dx[:, _OVERRIDE_COLS[name]] = dx[:, _OVERRIDE_COLS[name]].masked_fill(mask[:, None], 0.0)
+    return dx
+
+
 def _flags(r):
     o = r.opt
     return dict(gamma_correct=bool(o.gamma_correct), use_radiance_linear=bool(o.use_radiance_linear),
@@ -149,8 +246,20 @@ class _Stages:
         return torch.empty(sh, dtype=torch.float32, device=self.r.device)
 
     def coarse_z(self, near, far, t_rand, n):
+        """near / far: floats, or one plane per ray ([n] tensors: render_decomp's [n, 1] near / far, ibl_nerf_renderer.py:802-805)"""
+        torch = _torch()
         z = self._e(n, self.r.N_samples)
-        B.check(self.ctx, self.lib.iblnerf_coarse_z(self.ctx, self.r._stream(), float(near), float(far), None if t_rand is None else t_rand.data_ptr(), n, z.data_ptr()))
+        tr = None if t_rand is None else t_rand.data_ptr()
+        if torch.is_tensor(near) or torch.is_tensor(far):
+            from .renderer import _dev_f32
+            nr, fr = (_dev_f32(v, self.r.device).reshape(-1).contiguous() if torch.is_tensor(v) else torch.full((n,), float(v), dtype=torch.float32, device=self.r.device)
+                      for v in (near, far))
+            if nr.numel() != n or fr.numel() != n:
+                raise RuntimeError("near / far planes must have one entry per ray (%d), got %s" % (n, [int(nr.numel()), int(fr.numel())]))
+            B.check(self.ctx, self.lib.iblnerf_coarse_z_rays(self.ctx, self.r._stream(), nr.data_ptr(), fr.data_ptr(), tr, n, z.data_ptr()))
+            self._keep = (nr, fr)
+        else:
+            B.check(self.ctx, self.lib.iblnerf_coarse_z(self.ctx, self.r._stream(), float(near), float(far), tr, n, z.data_ptr()))
         return z
 
     def points(self, ro, rd, z):
@@ -207,8 +316,10 @@ def _with_noise(raw, noise):
     return out
 
 
-def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags, noise=(None, None)):
-    """render_rays with approximate_radiance=False from its stages: (result dict, what a backward needs)."""
+def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags, noise=(None, None), gt_const=None, rows=None):
+    """render_rays with approximate_radiance=False from its stages: (result dict, what a backward needs).  gt_const: the target maps of the *_from_gt flags that are
+    on (raw2outputs substitutes them whatever approximate_radiance is, :251-252, :320-330); rows: override_rows(approximate_radiance=False) — the depth overrides,
+    the only ones outside `if approximate_radiance` (:253-256)."""
     torch = _torch()
     n = ro.shape[0]
     zc = st.coarse_z(near, far, t_rand, n)
@@ -219,14 +330,27 @@ def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags, noise=(None, Non
     mf, wf = r.composite_direct(rawf, zf, rd)
     res = {}
     for sfx, m, w in (("", mf, wf), ("0", mc, wc)):
-        o = _ray_outputs(m, None, flags)
+        m_eff, gt_eff = _apply_overrides(m, gt_const, rows)
+        o = _ray_outputs(m_eff, None, flags, gt_eff)
         o["weights"] = w
         res.update({k + sfx: o[k] for k in BASE_KEYS})
     res["z_std"] = zstd       # (no synchronisation: every launch is on torch's current stream, whose allocator reuses freed blocks in stream order)
     return res, dict(zc=zc, zf=zf, rawc=rawc, rawf=rawf)
 
 
-def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None, raw_noise_std=0.):
+def _gt_constants(r, n, gt_values, from_gt):
+    """{"albedo" [n, 3], "roughness" [n], "irradiance" [n, 3], "depth" [n]} of the *_from_gt flags that are on (:251-252, :320-330)"""
+    from .renderer import _dev_f32
+    gt_const, gv = {}, gt_values or {}
+    for flag, key, ch in (("calculate_albedo_from_gt", "albedo", 3), ("calculate_roughness_from_gt", "roughness", 1),
+                          ("calculate_irradiance_from_gt", "irradiance", 3), ("depth_map_from_ground_truth", "depth", 1)):
+        if (from_gt or {}).get(flag):
+            t = _dev_f32(gv[key], r.device).reshape(n, -1)
+            gt_const[key] = (t[:, :3] if ch == 3 else t[:, 0]).contiguous()      # gt_values["roughness"][..., 0] (:326), gt_values["depth"][..., 0] (:252)
+    return gt_const
+
+
+def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, chunk=None, raw_noise_std=0., gt_values=None, from_gt=None, edit=None):
     """approximate_radiance=False without autograd (e.g. a validation render during the warm-up iterations): the reference's result dict."""
     from .renderer import _dev_f32
     torch = _torch()
@@ -235,13 +359,15 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
         raise NotImplementedError("approximate_radiance=False is built for N_importance > 0 (every shipped config)")
     t_rand, u = _draws(r, ro.shape[0], perturb, pytest, chunk)
     noise = r.noise_rows(ro.shape[0], raw_noise_std, pytest, chunk) if raw_noise_std > 0. else (None, None)
+    n = ro.shape[0]
     with torch.no_grad():
-        res, _ = _forward_direct(r, _Stages(r), ro, rd, near, far, t_rand, u, _flags(r), noise)
+        res, _ = _forward_direct(r, _Stages(r), ro, rd, near, far, t_rand, u, _flags(r), noise, _gt_constants(r, n, gt_values, from_gt),
+                                 override_rows(r, n, gt_values, edit, False, chunk))
     return res
 
 
 def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None,
-                      raw_noise_std=0., gt_values=None, from_gt=None):
+                      raw_noise_std=0., gt_values=None, from_gt=None, edit=None):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
     `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
     teacher_maps (parity tests; the backward's counterpart of iblnerf_composite_pass): {n_dot_v_map[0], reflected_radiance_map[0],
@@ -261,24 +387,24 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
         if set(nm) != set(ALL_PARAMS):
             raise NotImplementedError("the fused backward is built for the shipped IBLNeRF architecture (46 parameters per network)")
     params = [nm[k] for nm in named for k in ALL_PARAMS]
+    ci = bool(r.opt.color_independent_to_direction)      # (the context's streams carry the identity in place of the unused layers: iblnerf_network_backward)
     frozen = [bool(getattr(net, "freeze_radiance", False)) for net in (net_c, net_f)]
     frozen_rough = [bool(getattr(net, "freeze_roughness", False)) for net in (net_c, net_f)]
     st = _Stages(r)
-    depth0 = 0.5 * (float(near) + float(far))
+    if torch.is_tensor(near) or torch.is_tensor(far):      # per-ray planes: a mip-level depth_0 per ray (:455-457)
+        as_t = lambda v: _dev_f32(v, r.device).reshape(-1) if torch.is_tensor(v) else torch.full((n,), float(v), dtype=torch.float32, device=r.device)
+        depth0 = ((as_t(far) + as_t(near)) * 0.5).contiguous()
+    else:
+        depth0 = 0.5 * (float(near) + float(far))
     lut_t = _dev_f32(lut, r.device)
     # calculate_*_from_gt / depth_map_from_ground_truth (render kwargs of a step; :251-252, :320-330): the forward substitutes the target maps (pass A), the backward
     # takes them as constants — no gradient reaches the network's own map through the shading or through the output of the same name
     from_gt = {k: True for k, v in (from_gt or {}).items() if v}
-    gt_const = {}
-    if from_gt:
-        if not approximate_radiance:
-            raise NotImplementedError("*_from_gt flags in a gradient-carrying render are built for approximate_radiance=True")
-        gv = gt_values or {}
-        for flag, key, name, ch in (("calculate_albedo_from_gt", "albedo", "albedo", 3), ("calculate_roughness_from_gt", "roughness", "roughness", 1),
-                                    ("calculate_irradiance_from_gt", "irradiance", "irradiance", 3), ("depth_map_from_ground_truth", "depth", "depth", 1)):
-            if from_gt.get(flag):
-                t = _dev_f32(gv[key], r.device).reshape(n, -1)
-                gt_const[name] = (t[:, :3] if ch == 3 else t[:, 0]).contiguous()      # gt_values["roughness"][..., 0] (:326), gt_values["depth"][..., 0] (:252)
+    gt_const = _gt_constants(r, n, gt_values, from_gt)
+    # edit / insert overrides (:218-256, :378-410): masked rows of the target maps become constants of the step — substituted into the linear maps the backward
+    # differentiates at, their dL/d(entries) zeroed (override_rows); the forward applies them in pass A as the inference path does
+    edit = {k: v for k, v in (edit or {}).items() if k not in from_gt}
+    rows = override_rows(r, n, gt_values, edit, approximate_radiance, chunk)
 
     keys = [k + s for s in ("", "0") for k in (RESULT_ORDER if approximate_radiance else BASE_KEYS)] + ["z_std"]
 
@@ -294,11 +420,11 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18), envc=st._e(n, 4, 3), envf=st._e(n, 4, 3))
                 taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
                 taps.d_env_coarse, taps.d_env_fine = sv["envc"].data_ptr(), sv["envf"].data_ptr()    # the linear reflected-ray maps, exact (no gamma round trip)
-                res = r.render_rays(ro_, rd_, near, far, gt_values if from_gt else None, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std,
-                                    noise=None if noise[0] is None else noise, **from_gt)
+                res = r.render_rays(ro_, rd_, near, far, gt_values if (from_gt or rows) else None, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std,
+                                    noise=None if noise[0] is None else noise, chunk=chunk, **from_gt, **(edit if rows else {}))
                 sv["rawc"], sv["rawf"] = _with_noise(sv["rawc"], noise[0]), _with_noise(sv["rawf"], noise[1])     # (the taps are the network's rows: the noise is added in pass A)
             else:
-                res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise)
+                res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise, gt_const, rows)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
             if approximate_radiance:
                 src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})
@@ -324,6 +450,7 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             r.last_backward_ok = None
             for which, sfx, z, raw in ((0, "0", sv["zc"], sv["rawc"]), (1, "", sv["zf"], sv["rawf"])):
                 lin, _ = r.composite_direct(raw, z, sv["rd"], want_weights=False)
+                lin, gt_eff = _apply_overrides(lin, gt_const, rows)
                 consts = sv.get("consts" + sfx)
                 if FUSED_SHADING_BACKWARD:                           # one launch (iblnerf_ray_outputs_backward) instead of ~160 ray-sized ones
                     ups = {k: gout.get(k + sfx) for k in SHADED_KEYS if (consts is not None or k in BASE_KEYS)}
@@ -331,17 +458,18 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                         if name in gt_const:
                             ups.pop(name + "_map", None)
                     dx = r.ray_outputs_backward(lin, ups, None if consts is None else consts["n_dot_v"], None if consts is None else consts["env"],
-                                                depth0, gt=gt_const or None)
+                                                depth0, gt=gt_eff or None)
                 else:                                                # the same by torch autograd (the tests' reference for the kernel above)
                     with torch.enable_grad():
                         x = lin.detach().requires_grad_(True)
-                        outs = _ray_outputs(x, consts, flags, gt_const)
+                        outs = _ray_outputs(x, consts, flags, gt_eff)
                         pairs = [(outs[k], gout[k + sfx]) for k in outs if gout.get(k + sfx) is not None and outs[k].requires_grad]     # (a *_from_gt output is a constant)
                         if pairs:
                             (dx,) = torch.autograd.grad([o for o, _ in pairs], x, [g.reshape(o.shape).to(o.dtype) for o, g in pairs], allow_unused=True)
                             dx = torch.zeros_like(lin) if dx is None else dx
                         else:
                             dx = torch.zeros_like(lin)
+                dx = _zero_overridden(dx, gt_const, rows)
                 gw = gout.get("weights" + sfx)
                 draw = r.composite_direct_backward(raw, z, sv["rd"], dx.contiguous(), None if gw is None else gw.contiguous())
                 if frozen[which]:                                     # forward_freezed: sigma, radiance and the coarse radiances are computed under no_grad
@@ -356,6 +484,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     gk = grads[k]
                     if frozen[which] and not (k.startswith(UNFROZEN) and not (frozen_rough[which] and k.startswith("roughness_linear."))):
                         gk = None                                        # h is computed under no_grad: nothing reaches the trunk / view layers
+                    if ci and k.startswith(("feature_linear.", "views_linears.")):
+                        gk = None                                        # is_color_independent_to_direction (ibl_nerf.py:192): unused parameters, no gradient
                     grads_all.append(gk)
             if r.range_check == "lazy" and len(oks) == 2:
                 # one decision for the step: an overflow in either network's backward skips BOTH networks' gradients (the range flag is sticky on

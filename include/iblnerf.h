@@ -365,6 +365,8 @@ int iblnerf_composite_direct_backward_full(iblnerf_ctx* ctx, void* stream, const
  *   iblnerf_composite_sigma  raw2outputs_depth (:118-152, is_depth_only): d_sigma [n_rays, n_samples] (a trunk-only query's output) ->
  *                          d_weights [n_rays, n_samples], d_depth [n_rays], d_visibility [n_rays] (the full transmittance product). */
 int iblnerf_coarse_z(iblnerf_ctx* ctx, void* stream, float near_, float far_, const float* d_t_rand, int64_t n_rays, float* d_z);
+/* ... with one near / far plane per ray (render_decomp's `near` / `far` as [n, 1] tensors, ibl_nerf_renderer.py:802-805 -> :668-674): d_near, d_far [n_rays]. */
+int iblnerf_coarse_z_rays(iblnerf_ctx* ctx, void* stream, const float* d_near, const float* d_far, const float* d_t_rand, int64_t n_rays, float* d_z);
 int iblnerf_sample_points(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t n_rays,
                           int n_samples, float* d_pts);
 int iblnerf_fine_z(iblnerf_ctx* ctx, void* stream, const float* d_z_coarse, const float* d_weights_coarse, int64_t n_rays, const float* d_u,
@@ -459,6 +461,10 @@ int iblnerf_ray_outputs_backward(iblnerf_ctx* ctx, void* stream, const float* d_
  * sets the mip level, :457-460).  overrides->mode must be 0 (edit / insert in a gradient-carrying render: IBLNERF_ERR_STATE); overrides = NULL is the entry above. */
 int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
                                     const iblnerf_maps* d_upstream, const iblnerf_overrides* overrides, int64_t n_rays, float* d_dmaps);
+/* ... with per-ray near / far planes: the mip level's depth_0 = (near + far) / 2 is then a value per ray (:455-457, `depth_0[..., 0]`): d_depth0 [n_rays]
+ * (every entry positive; read only under correct_depth_for_prefiltered_radiance with d_n_dot_v given). */
+int iblnerf_ray_outputs_backward_rays(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, const float* d_depth0,
+                                      const iblnerf_maps* d_upstream, const iblnerf_overrides* overrides, int64_t n_rays, float* d_dmaps);
 
 
 /* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,

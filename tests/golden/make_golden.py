@@ -539,6 +539,12 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
         out.update(H=np.int64(H), W=np.int64(W), K=K, c2w=c2w, c2w_staticcam=c2w_static, near=np.float32(0.5), far=np.float32(8.0))
         out["aux__depth_mlp"] = np.int64(aux_seed)
         out["flag__infer_depth"] = np.asarray(True)
+        # f-3 leftover (round 5): the same argument through the two render types only a training run takes — is_depth_only (:197-198) and approximate_radiance=False
+        with torch.no_grad():
+            extra = {"depthonly": R.render_decomp(H, W, K, chunk=H * W, c2w=torch.from_numpy(c2w), c2w_staticcam=torch.from_numpy(c2w_static), gt_values={},
+                                                  approximate_radiance=False, is_depth_only=True, **kw, **EDIT_KEYS_OFF),
+                     "direct": R.render_decomp(H, W, K, chunk=H * W, c2w=torch.from_numpy(c2w), c2w_staticcam=torch.from_numpy(c2w_static), gt_values={},
+                                               approximate_radiance=False, **kw, **EDIT_KEYS_OFF)}
     else:
         n = 96
         o, d, pix, focal = camera_rays(rng, n)
@@ -549,14 +555,23 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
             ret = R.render_decomp(800, 800, K, chunk=n, rays=torch.from_numpy(np.stack([o, d], 0)), near=torch.from_numpy(near), far=torch.from_numpy(far),
                                   gt_values={}, approximate_radiance=True, **kw, **EDIT_KEYS_OFF)
         out.update(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=near, far=far)
+        with torch.no_grad():
+            extra = {"depthonly": R.render_decomp(800, 800, K, chunk=n, rays=torch.from_numpy(np.stack([o, d], 0)), near=torch.from_numpy(near), far=torch.from_numpy(far),
+                                                  gt_values={}, approximate_radiance=False, is_depth_only=True, **kw, **EDIT_KEYS_OFF),
+                     "direct": R.render_decomp(800, 800, K, chunk=n, rays=torch.from_numpy(np.stack([o, d], 0)), near=torch.from_numpy(near), far=torch.from_numpy(far),
+                                               gt_values={}, approximate_radiance=False, **kw, **EDIT_KEYS_OFF)}
     for k, v in ret.items():
         out["out__" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+    for tag, res_ in extra.items():
+        for k, v in res_.items():
+            out["%s__out__%s" % (tag, k)] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s %s  %d maps  %.2f MB" % (name, kind, len(ret), os.path.getsize(path) / 1e6))
 
 
-def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=()):
+def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=(), override=None,
+                       color_independent=False, planes=False):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -566,7 +581,11 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
         warmup    approximate_radiance=False  (the first N_iter_ignore_approximated_radiance iterations, :295)
         full      approximate_radiance=True
         frozen    approximate_radiance=True with freeze_radiance = freeze_roughness = True on both networks (:279-283: forward_freezed)
-        depth     is_depth_only=True, approximate_radiance=False (:366-374): forward only (its depth_map is detached in the loss)"""
+        depth     is_depth_only=True, approximate_radiance=False (:366-374): forward only (its depth_map is detached in the loss)
+    override: None | "edit" | "insert" (f-3 leftover, round 5): the step with the edit / insert overrides of raw2outputs on (:218-256, :378-410) — tests/frame_overrides.py's
+    analytic images at the fixture's pixels; "edit" = config 4's kwargs plus an albedo list and a depth image, so that all four masked assignments are exercised.
+    color_independent: both networks with is_color_independent_to_direction=True (ibl_nerf.py:75, :192: the radiance heads read the trunk's output, feature_linear and
+    views_linears are unused and get no gradient) — the fitted checkpoint's weights taken as such a network's."""
     tmp = tempfile.mkdtemp()
     try:
         kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128))      # [0] = render_kwargs_train
@@ -577,6 +596,11 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     kw.update(near=0.5, far=8.0, pytest=True)
+    if planes:      # per-ray near / far planes as [n, 1] tensors (:802-805): a z grid per ray (:668-674) and a per-ray depth_0 in the mip level (:455-457)
+        prng = np.random.RandomState(4300)
+        plane_near = (0.4 + 0.3 * prng.uniform(0, 1, (n_rays, 1))).astype(np.float32)
+        plane_far = (7.0 + 2.0 * prng.uniform(0, 1, (n_rays, 1))).astype(np.float32)
+        kw.update(near=torch.from_numpy(plane_near), far=torch.from_numpy(plane_far))
     if raw_noise_std > 0:       # train.py's raw_noise_std (:208-216, :242): density noise on the main query of each pass; the pytest hook draws it uniform
         kw["raw_noise_std"] = raw_noise_std
     # from_gt: names of the ground-truth substitutions switched on (render kwargs, ibl_nerf.py:411-416; raw2outputs :251-252, :320-330) with seeded gt_values
@@ -589,14 +613,28 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
             kw[flag] = True
             gt_values[key] = gt_rng.uniform(lo, hi, (n_rays, ch)).astype(np.float32)
     kw["brdf_lut"] = lut
+    if color_independent:
+        for k_ in ("network_fn", "network_fine"):
+            kw[k_].is_color_independent_to_direction = True
     rng = np.random.RandomState(4100)
     o, d, pix, focal = camera_rays(rng, n_rays)
+    edit_kw = dict(EDIT_KEYS_OFF)
+    if override is not None:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import frame_overrides as FO
+        if override == "edit":
+            edit_kw.update(FO.EDIT_CFG4, edit_albedo=True, editing_target_albedo_list=[0.8, 0.2, 0.3], edit_depth=True)
+            gt_values.update(FO.edit_rows(pix))
+            gt_values["edit_depth"] = (2.0 + 0.5 * (pix % 800).astype(np.float32) / np.float32(800))[:, None].astype(np.float32)
+        else:
+            edit_kw.update(FO.INSERT_CFG5)
+            gt_values.update(FO.insert_rows(pix))
     K = np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32)
     rays = torch.from_numpy(np.stack([o, d], 0))
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import train_loss as TL
     tg, beta = TL.targets(rng, n_rays), TL.BETA
-    out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(0.5), far=np.float32(8.0), chunk=np.int64(n_rays),
+    out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=plane_near if planes else np.float32(0.5), far=plane_far if planes else np.float32(8.0), chunk=np.int64(n_rays),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))), ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
                ckpt=np.array("fitted"))
     for k, v in tg.items():
@@ -609,14 +647,18 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     for k, v in gt_values.items():
         out["gt__" + k] = v
     out["from_gt"] = np.array(sorted(from_gt))
+    out["override"] = np.array(override or "")
+    out["color_independent"] = np.asarray(bool(color_independent))
+    import json as _json
+    out["edit_kwargs"] = np.array(_json.dumps({k: v for k, v in edit_kw.items() if EDIT_KEYS_OFF.get(k, None) != v}))
     for phase in phases:
         for _, net in nets:
             net.zero_grad()
             net.freeze_radiance = net.freeze_roughness = phase == "frozen"
         approx = phase in ("full", "frozen")
         with torch.enable_grad():
-            res = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values={k: torch.from_numpy(v) for k, v in gt_values.items()},
-                                  approximate_radiance=approx, is_depth_only=phase == "depth", **kw, **EDIT_KEYS_OFF)
+            res = R.render_decomp(800, 800, K, chunk=n_rays, rays=rays, gt_values={k: torch.from_numpy(v.copy()) for k, v in gt_values.items()},
+                                  approximate_radiance=approx, is_depth_only=phase == "depth", **kw, **edit_kw)
             for k, v in res.items():
                 out["%s__out__%s" % (phase, k)] = v.detach().numpy().copy()
             if phase == "depth":
@@ -987,6 +1029,17 @@ def main(only=None):
     if not only or "train_step_from_gt" in only:    # ... with the four ground-truth substitutions on (f-3: constants of the backward)
         train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt", phases=("full",),
                            from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
+    if not only or "train_step_from_gt_warmup" in only:   # f-3 leftover (round 5): the substitutions during the warm-up iterations (approximate_radiance=False)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt_warmup", phases=("warmup",),
+                           from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
+    if not only or "train_step_edit" in only:       # f-3 leftover (round 5): edit / insert overrides inside a gradient-carrying render
+        train_step_fixture(torch, R, M, lut, fixture="train_step_edit", phases=("warmup", "full"), override="edit")
+    if not only or "train_step_insert" in only:
+        train_step_fixture(torch, R, M, lut, fixture="train_step_insert", phases=("warmup", "full"), override="insert")
+    if not only or "train_step_planes" in only:     # f-3 leftover (round 5): per-ray near / far planes in a gradient-carrying render
+        train_step_fixture(torch, R, M, lut, fixture="train_step_planes", phases=("warmup", "full", "depth"), planes=True)
+    if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
+        train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
         train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt2", phases=("full",),
                            from_gt=("calculate_roughness_from_gt", "depth_map_from_ground_truth"))

@@ -300,6 +300,45 @@ def test_render_decomp_static_camera_and_per_ray_planes(R, lut, tmp_path):
     assert rel_linf(got["depth_map"], ora["depth_map"]) <= 2e-4 and rel_linf(got["weights0"], ora["weights0"]) <= 2e-4
 
 
+def test_static_camera_and_per_ray_planes_in_the_training_only_render_types(R, lut, tmp_path):
+    """f-3 leftover closed in round 5: c2w_staticcam and per-ray near / far planes through is_depth_only (raw2outputs_depth, :197-198) and approximate_radiance=False —
+    the two render types only a training run takes (train.py:285-297, :366-374), which used to raise.  Fixtures staticcam_g10 / nearfar_g10 carry the reference's
+    own runs of both (`depthonly__out__*`, `direct__out__*`): per-ray planes give every ray its own z grid (iblnerf_coarse_z_rays); the static camera's other pose
+    reaches only inferred_depth_map (:722-726, appended whatever the pass type)."""
+    import os
+    from ibl_nerf_amd import checkpoint as ck, model as M
+    g, sdc, sdf, _, _ = load_golden("staticcam_g10")
+    os.makedirs(tmp_path / "exp")
+    ck.save_checkpoint(str(tmp_path / "exp" / "000001.tar"), 1, sdc, sdf, aux=golden_aux(g))
+    _, kw, *_ = M.create_IBLNeRF(M.default_args(basedir=str(tmp_path), no_reload=False, infer_depth=True))
+    kw.update(near=float(g["near"]), far=float(g["far"]), brdf_lut=torch.from_numpy(lut), max_rays_per_launch=64)
+    H, W = int(g["H"]), int(g["W"])
+    for tag, extra in (("depthonly", dict(approximate_radiance=False, is_depth_only=True)), ("direct", dict(approximate_radiance=False))):
+        ret = to_np(R.render_decomp(H, W, g["K"], c2w=torch.from_numpy(g["c2w"]), c2w_staticcam=torch.from_numpy(g["c2w_staticcam"]), gt_values={}, **extra, **kw))
+        want = sorted(k[len(tag) + 7:] for k in g.files if k.startswith(tag + "__out__"))
+        assert sorted(ret) == want and list(ret)[-1] == "inferred_depth_map", (tag, sorted(ret), want)
+        for k in want:
+            ref = g["%s__out__%s" % (tag, k)]
+            assert ret[k].shape == ref.shape and rel_linf(ret[k], ref) <= (1e-5 if k == "inferred_depth_map" else 2e-4), (tag, k, rel_linf(ret[k], ref))
+        plain = to_np(R.render_decomp(H, W, g["K"], c2w=torch.from_numpy(g["c2w_staticcam"]), gt_values={}, **extra, **kw))
+        assert all(np.array_equal(plain[k], ret[k]) for k in ret if k != "inferred_depth_map") and rel_linf(plain["inferred_depth_map"], ret["inferred_depth_map"]) > 1e-3
+
+    g, sdc, sdf, _, _ = load_golden("nearfar_g10")
+    kw["network_fn"].load_state_dict(sdc)
+    kw["network_fine"].load_state_dict(sdf)
+    kw2 = {k: v for k, v in kw.items() if k not in ("near", "far", "infer_depth", "depth_mlp")}
+    K = np.array([[692.8203, 0, 400], [0, 692.8203, 400], [0, 0, 1]], dtype=np.float32)
+    rays = torch.from_numpy(np.stack([g["rays_o"], g["rays_d"]], 0))
+    for tag, extra in (("depthonly", dict(approximate_radiance=False, is_depth_only=True)), ("direct", dict(approximate_radiance=False))):
+        ret = to_np(R.render_decomp(800, 800, K, rays=rays, near=torch.from_numpy(g["near"]), far=torch.from_numpy(g["far"]), gt_values={}, **extra, **kw2))
+        want = sorted(k[len(tag) + 7:] for k in g.files if k.startswith(tag + "__out__"))
+        assert sorted(ret) == want, (tag, sorted(ret), want)
+        for k in want:
+            assert rel_linf(ret[k], g["%s__out__%s" % (tag, k)]) <= (1e-4 if k == "z_std" else 2e-4), (tag, k, rel_linf(ret[k], g["%s__out__%s" % (tag, k)]))
+        sca = to_np(R.render_decomp(800, 800, K, rays=rays, near=0.5, far=8.0, gt_values={}, **extra, **kw2))
+        assert rel_linf(sca["depth_map"], g[tag + "__out__depth_map"]) > 1e-2                        # the planes matter
+
+
 def test_edit_roughness_by_img_follows_the_reference_chunking(R, lut):
     """edit_roughness_by_img (ibl_nerf_renderer.py:394-395): `target_roughness_map[mask_all] = gt_values["edit_roughness"][mask_all][0]` runs inside
     raw2outputs, i.e. once per `chunk` rays — every masked ray takes the FIRST masked row of ITS chunk, the one place where the reference's result
