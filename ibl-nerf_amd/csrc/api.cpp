@@ -899,7 +899,8 @@ int iblnerf_network_backward(iblnerf_ctx* c, void* stream, int which, const floa
     if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_viewdirs || !d_draw)))
         return c->fail(IBLNERF_ERR_INVALID, "network_backward: bad arguments");
     const bool ci = c->opt.color_independent_to_direction;
-    if (ci && (which < 0 || which > 1 || !c->ci_embedded[which]))
+    if (which < 0 || which > 1) return c->fail(IBLNERF_ERR_INVALID, "network_backward: which must be 0 / 1");
+    if (ci && !c->ci_embedded[which])
         return c->fail(IBLNERF_ERR_STATE, "network_backward: a colour-independent network's backward needs an mlp_precision that keeps the fp32 state dict (not bf16x3)");
     const int rc = trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, nullptr, grad_scale, d_out, d_grad, d_viewdirs, n_samples,
                                        nullptr, d_draw);
@@ -918,12 +919,34 @@ int iblnerf_trunk_features2_backward(iblnerf_ctx* c, void* stream, int which, co
     if (n_rays < 0 || n_samples < 1 || (n_rays > 0 && (!d_viewdirs || !d_dh7 || !d_dh2)))
         return c->fail(IBLNERF_ERR_INVALID, "trunk_features2_backward: bad arguments");
     if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "trunk_features2_backward: a colour-independent network has no feature / view layers");
+    if (which < 0 || which > 1) return c->fail(IBLNERF_ERR_INVALID, "trunk_features2_backward: which must be 0 / 1");
     return trunk_backward_impl(c, stream, which, d_pts, (int64_t)n_rays * n_samples, nullptr, d_dh7, grad_scale, d_out, d_grad, d_viewdirs, n_samples, d_dh2);
+}
+
+int iblnerf_aux_query(iblnerf_ctx* c, void* stream, int kind, const float* d_pts, int64_t n_pts, float* d_out) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (kind < 0 || kind >= N_AUX || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out))) return c->fail(IBLNERF_ERR_INVALID, "aux_query: bad arguments");
+    if (!c->aux_on[kind]) return c->fail(IBLNERF_ERR_STATE, "aux_query: auxiliary network %d not uploaded (every output channel)", kind);
+    if (n_pts == 0) return IBLNERF_OK;
+    if (n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "aux_query: more than 2^31 points");
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    for (int ch = 0; ch < AUX_CHANNELS[kind]; ++ch)
+        if (int rc = run_mlp(c, (hipStream_t)stream, VAR_TRUNK, AUX_SLOT0[kind] + ch, d_pts, nullptr, 1, (long)n_pts, d_out + ch, AUX_CHANNELS[kind], Q_AUX)) return rc;
+    return arm_range_snapshot(c, (hipStream_t)stream);
+}
+
+int iblnerf_aux_backward(iblnerf_ctx* c, void* stream, int kind, int channel, const float* d_pts, int64_t n_pts, const float* d_dout,
+                         float grad_scale, float* d_out, float* d_grad) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (kind < 0 || kind >= N_AUX || channel < 0 || channel >= AUX_CHANNELS[kind < 0 || kind >= N_AUX ? 0 : kind] || (n_pts > 0 && !d_dout))
+        return c->fail(IBLNERF_ERR_INVALID, "aux_backward: bad arguments");
+    return trunk_backward_impl(c, stream, AUX_SLOT0[kind] + channel, d_pts, n_pts, d_dout, nullptr, grad_scale, d_out, d_grad);
 }
 
 int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                            float grad_scale, float* d_out, float* d_grad) {
     if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1) return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: which must be 0 / 1");
     if (n_pts > 0 && !d_dsigma) return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
     return trunk_backward_impl(c, stream, which, d_pts, n_pts, d_dsigma, nullptr, grad_scale, d_out, d_grad);
 }
@@ -931,6 +954,7 @@ int iblnerf_trunk_backward(iblnerf_ctx* c, void* stream, int which, const float*
 int iblnerf_trunk_features_backward(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dh7,
                                     float grad_scale, float* d_out, float* d_grad) {
     if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1) return c->fail(IBLNERF_ERR_INVALID, "trunk_features_backward: which must be 0 / 1");
     if (n_pts > 0 && !d_dh7) return c->fail(IBLNERF_ERR_INVALID, "trunk_features_backward: bad arguments");
     return trunk_backward_impl(c, stream, which, d_pts, n_pts, nullptr, d_dh7, grad_scale, d_out, d_grad);
 }
@@ -938,7 +962,7 @@ int iblnerf_trunk_features_backward(iblnerf_ctx* c, void* stream, int which, con
 static int trunk_backward_impl(iblnerf_ctx* c, void* stream, int which, const float* d_pts, int64_t n_pts, const float* d_dsigma,
                                const float* d_dh7, float grad_scale, float* d_out, float* d_grad, const float* d_dirs, int pts_per_ray,
                                const float* d_dh2, const float* d_draw) {
-    if (which < 0 || which > 1 || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)) || !d_grad)
+    if (which < 0 || which >= N_SLOTS || n_pts < 0 || (n_pts > 0 && (!d_pts || !d_out)) || !d_grad)      // (`which`: a weight slot — network 0 / 1, or an auxiliary network's channel)
         return c->fail(IBLNERF_ERR_INVALID, "trunk_backward: bad arguments");
     int gs_exp = 0;
     if (!(grad_scale > 0.0f) || std::frexp(grad_scale, &gs_exp) != 0.5f)

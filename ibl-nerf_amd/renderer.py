@@ -896,6 +896,59 @@ class Renderer:
             off += o * i + o
         return out[:, 0].reshape(pts.shape[:-1]), out[:, 1:].reshape(pts.shape), grads
 
+    def aux_query(self, name, pts):
+        """network_query_fn(pts, None, <name>) of an auxiliary network ('albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' | 'normal_mlp', ibl_nerf_renderer.py:267-303):
+        pts [..., 3] -> raw outputs [..., out_ch] (iblnerf_aux_query)."""
+        torch = _torch()
+        kind, out_ch = B.AUX_KINDS[name]
+        pts = _dev_f32(pts, self.device)
+        flat = pts.reshape(-1, 3)
+        out = torch.empty((flat.shape[0], out_ch), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_aux_query(self.ctx, self._stream(), kind, flat.data_ptr(), flat.shape[0], out.data_ptr()))
+        return out.reshape(tuple(pts.shape[:-1]) + (out_ch,))
+
+    def aux_backward(self, name, pts, dout, grad_scale=None):
+        """Backward of aux_query(name, pts): dL/d(raw outputs) [..., out_ch] -> the gradients of the PositionMLP's parameters in its state-dict shapes
+        (positions_linears.0-7, out_linears): one iblnerf_aux_backward per output channel — the channels share the trunk, whose gradient is their sum.
+        Loss scaling as trunk_backward (one scale for all channels)."""
+        torch = _torch()
+        kind, out_ch = B.AUX_KINDS[name]
+        flat = _dev_f32(pts, self.device).reshape(-1, 3)
+        d = _dev_f32(dout, self.device).reshape(-1, out_ch)
+        if d.shape[0] != flat.shape[0]:
+            raise ValueError("aux_backward: one upstream gradient row per point")
+        total = None
+        oks = []
+        for ch in range(out_ch):
+            col = d[:, ch].contiguous()
+            out = torch.empty((flat.shape[0], 4), dtype=torch.float32, device=self.device)
+            grad = torch.empty((self.lib.iblnerf_blob_floats(),), dtype=torch.float32, device=self.device)
+            self.last_backward_ok = None
+            self._run_backward(col, lambda up, sc, ch=ch, out=out, grad=grad: B.check(self.ctx, self.lib.iblnerf_aux_backward(
+                self.ctx, self._stream(), kind, ch, flat.data_ptr(), flat.shape[0], up.data_ptr(), sc, out.data_ptr(), grad.data_ptr())),
+                out, grad, grad_scale, "aux_backward")
+            if getattr(self, "last_backward_ok", None) is not None:
+                oks.append(self.last_backward_ok)
+            g, off = {}, 0
+            for nm, o, i in ck.SCHEMA:
+                if nm.startswith("positions_linears."):
+                    g[nm + ".weight"], g[nm + ".bias"] = grad[off:off + o * i].view(o, i), grad[off + o * i:off + o * i + o]
+                elif nm == "sigma_linear":
+                    g["row_w"], g["row_b"] = grad[off:off + o * i].view(i), grad[off + o * i:off + o * i + o].view(())
+                off += o * i + o
+            if total is None:
+                total = {k: v.clone() for k, v in g.items() if k.startswith("positions_linears.")}
+                total["out_linears.weight"] = torch.zeros((out_ch, 256), dtype=torch.float32, device=self.device)
+                total["out_linears.bias"] = torch.zeros((out_ch,), dtype=torch.float32, device=self.device)
+            else:
+                for k in g:
+                    if k.startswith("positions_linears."):
+                        total[k] += g[k]
+            total["out_linears.weight"][ch] = g["row_w"]
+            total["out_linears.bias"][ch] = g["row_b"]
+        self.last_backward_ok = None if not oks else (oks[0] if len(oks) == 1 else torch.stack(oks).all())
+        return total
+
     def sample_pdf(self, bins, weights, N_samples, det=True, pytest=False, u=None):
         """nerf_renderer_helper.py:91-134.  det=False draws u ~ U[0,1) on the device (or takes `u` [n, N_samples]); pytest=True
         takes numpy's seed-0 stream as the reference's test path does (:106-113)."""
@@ -1429,15 +1482,12 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
         # reads any of them (:197-198), auxiliary networks included
         gt_flags = {k: True for k in ("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth")
                     if _truthy(edit.get(k))}
-        aux_on = any(v is not None for v in r._aux.values())           # (load_aux(name, None) leaves a {name: None} entry: a cleared network is no network)
         if training and kwargs.get("infer_depth") and any(getattr(p, "requires_grad", False) for p in getattr(kwargs.get("depth_mlp"), "parameters", lambda: [])()):
             # train.py:351-379 reads ret['inferred_depth_map'] and backpropagates loss_depth_random into depth_mlp; the posdir kernel has no backward
             raise NotImplementedError("a depth_mlp with trainable parameters in a gradient-carrying render (infer_depth training, train.py:351-379) is not built: "
-                                      "its inferred_depth_map would carry no grad_fn and the network would silently never train; evaluate depth_mlp in torch, "
+                                      "its inferred_depth_map would carry no grad_fn and the network would silently never train (the reference's own loss.backward() "
+                                      "raises there too: render_rays squeezes the ReLU's output in place, ibl_nerf_renderer.py:724-725); evaluate depth_mlp in torch, "
                                       "or freeze it (requires_grad_(False)) to render with it")
-        if not is_depth_only and aux_on:
-            raise NotImplementedError("auxiliary networks are not built for approximate_radiance=False and gradient-carrying renders (no shipped config has them; "
-                                      "keep the reference's render loop with model.training_network_query_fn for such a run: it fuses the no-grad queries)")
         ovr = {k: v for k, v in edit.items() if k not in FROM_GT_FLAGS}
         std = float(kwargs.get("raw_noise_std", 0.) or 0.)
         if is_depth_only:                                                       # raw2outputs_depth (:197-198)
@@ -1445,7 +1495,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
         elif training:
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
                                       approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std,
-                                      gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr, **smp)
+                                      gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr,
+                                      aux_nets={k: kwargs.get(k) for k in B.AUX_KINDS if kwargs.get(k) is not None}, **smp)
         else:
             ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr, **smp)
         if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:

@@ -43,6 +43,11 @@ SHADED_KEYS = ("color_map", "radiance_map", "radiance_map_1", "radiance_map_2", 
                "specular_map", "diffuse_map", "prefiltered_reflected_map", "disp_map", "acc_map", "depth_map", "target_depth_map")
 
 
+# auxiliary networks (ibl_nerf_renderer.py:291-303): the raw columns their outputs replace; normal_mlp (:267-275) feeds inferred_normal_map instead
+AUX_COLS = {"albedo_mlp": slice(1, 4), "roughness_mlp": slice(4, 5), "irradiance_mlp": slice(5, 6)}
+AUX_PARAMS = tuple("positions_linears.%d.%s" % (i, t) for i in range(8) for t in ("weight", "bias")) + ("out_linears.weight", "out_linears.bias")
+
+
 def _torch():
     import torch
     return torch
@@ -53,7 +58,7 @@ def is_training_call(kw):
     torch = _torch()
     if not torch.is_grad_enabled():
         return False
-    for net in (kw.get("network_fn"), kw.get("network_fine")):
+    for net in (kw.get("network_fn"), kw.get("network_fine")) + tuple(kw.get(k) for k in AUX_COLS) + ((kw.get("normal_mlp"),) if kw.get("infer_normal") else ()):
         ps = getattr(net, "parameters", None)
         if ps is not None and any(getattr(p, "requires_grad", False) for p in ps()):
             return True
@@ -302,6 +307,37 @@ def render_rays_depth_only(r, rays_o, rays_d, near, far, perturb=0., pytest=Fals
     return {"depth_map": df, "weights": wf, "visibility": vf, "depth_map0": dc, "weights0": wc, "visibility0": vc, "z_std": zstd}
 
 
+def _aux_names(r):
+    """the auxiliary networks loaded on the context, as raw2outputs consults them"""
+    return [k for k in ("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp") if r._aux.get(k) is not None]
+
+
+def _aux_columns(r, raw, pts):
+    """raw rows with the albedo / roughness / irradiance columns replaced by the auxiliary networks' outputs (:291-303), as the render path's workspace holds them"""
+    names = [k for k in _aux_names(r) if k in AUX_COLS]
+    if not names:
+        return raw
+    if "irradiance_mlp" in names and r.opt.use_radiance_linear:
+        raise NotImplementedError("an irradiance_mlp under use_radiance_linear outside the inference render: its samples take a sigmoid where the compositing stage "
+                                  "applies radiance_f (ibl_nerf_renderer.py:300-303)")
+    raw = raw.clone()
+    for k in names:
+        raw[..., AUX_COLS[k]] = r.aux_query(k, pts)
+    return raw
+
+
+def _inferred_normal(r, pts, weights, ro, rd, target_depth):
+    """inferred_normal_map (:266-275) and what its backward needs: normal_mlp at every sample, composited with the detached weights — or, infer_normal_at_surface,
+    once per ray at x_surface = rays_o + rays_d * target_depth_map (detached, :262-263).  -> (map [n, 3], query points, d map / d raw as a factor [.., 3] of the upstream)"""
+    torch = _torch()
+    if r.opt.infer_normal_at_surface:
+        xs = (ro + rd * target_depth.detach()[:, None]).contiguous()
+        s_ = torch.sigmoid(r.aux_query("normal_mlp", xs))                       # [n, 3]
+        return 2 * s_ - 1, xs, 2 * s_ * (1 - s_)
+    s_ = torch.sigmoid(r.aux_query("normal_mlp", pts))                          # [n, S, 3]
+    return torch.sum(weights[..., None] * (2 * s_ - 1), -2), pts, weights[..., None] * (2 * s_ * (1 - s_))
+
+
 BASE_KEYS = ["radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3", "irradiance_map", "albedo_map", "roughness_map", "disp_map",
              "acc_map", "depth_map", "target_depth_map", "weights"]          # raw2outputs' non-None entries without approximate_radiance, in its order (:494-525)
 
@@ -323,17 +359,22 @@ def _forward_direct(r, st, ro, rd, near, far, t_rand, u, flags, noise=(None, Non
     torch = _torch()
     n = ro.shape[0]
     zc = st.coarse_z(near, far, t_rand, n)
-    rawc = _with_noise(r.network_query(st.points(ro, rd, zc), rd, 0), noise[0])
+    pc = st.points(ro, rd, zc)
+    rawc = _with_noise(_aux_columns(r, r.network_query(pc, rd, 0), pc), noise[0])
     mc, wc = r.composite_direct(rawc, zc, rd)
     zf, zstd = st.fine_z(zc, wc, u)
-    rawf = _with_noise(r.network_query(st.points(ro, rd, zf), rd, 1 if r.has_fine else 0), noise[1])
+    pf = st.points(ro, rd, zf)
+    rawf = _with_noise(_aux_columns(r, r.network_query(pf, rd, 1 if r.has_fine else 0), pf), noise[1])
     mf, wf = r.composite_direct(rawf, zf, rd)
     res = {}
-    for sfx, m, w in (("", mf, wf), ("0", mc, wc)):
+    normal_on = "normal_mlp" in _aux_names(r)
+    for sfx, m, w, p in (("", mf, wf, pf), ("0", mc, wc, pc)):
         m_eff, gt_eff = _apply_overrides(m, gt_const, rows)
         o = _ray_outputs(m_eff, None, flags, gt_eff)
         o["weights"] = w
         res.update({k + sfx: o[k] for k in BASE_KEYS})
+        if normal_on:
+            res["inferred_normal_map" + sfx] = _inferred_normal(r, p, w, ro, rd, o["target_depth_map"])[0]
     res["z_std"] = zstd       # (no synchronisation: every launch is on torch's current stream, whose allocator reuses freed blocks in stream order)
     return res, dict(zc=zc, zf=zf, rawc=rawc, rawf=rawf)
 
@@ -367,9 +408,12 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
 
 
 def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None,
-                      raw_noise_std=0., gt_values=None, from_gt=None, edit=None):
+                      raw_noise_std=0., gt_values=None, from_gt=None, edit=None, aux_nets=None):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
     `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
+    aux_nets: {'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' | 'normal_mlp': module} — the auxiliary networks loaded on `r` (ibl_nerf.py:305-323 registers
+    them with the optimizer): their outputs replace the main network's albedo / roughness / irradiance columns in both passes (the main network gets no gradient
+    there), normal_mlp feeds inferred_normal_map; a module with trainable parameters receives its gradients (Renderer.aux_backward), summed over the passes.
     teacher_maps (parity tests; the backward's counterpart of iblnerf_composite_pass): {n_dot_v_map[0], reflected_radiance_map[0],
     reflected_coarse_radiance_map_k[0]} taken as the shading backward's constants instead of this forward's own — the reflected-ray maps are
     ill-conditioned in the reference itself, and d color / d roughness is proportional to them."""
@@ -406,7 +450,27 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
     edit = {k: v for k, v in (edit or {}).items() if k not in from_gt}
     rows = override_rows(r, n, gt_values, edit, approximate_radiance, chunk)
 
-    keys = [k + s for s in ("", "0") for k in (RESULT_ORDER if approximate_radiance else BASE_KEYS)] + ["z_std"]
+    aux = _aux_names(r)
+    normal_on = "normal_mlp" in aux
+    aux_named = {}
+    for name in aux:
+        mod = (aux_nets or {}).get(name)
+        nm = dict(mod.named_parameters()) if hasattr(mod, "named_parameters") else {}
+        if nm and any(p_.requires_grad for p_ in nm.values()):
+            if set(nm) != set(AUX_PARAMS):
+                raise NotImplementedError("an auxiliary network's backward is built for PositionMLP(D=8, W=256) (networks/MLP.py:6-30): positions_linears.0-7, out_linears")
+            aux_named[name] = nm
+    if "normal_mlp" in aux_named and r.normal_mode == "inferred_normal_map":
+        raise NotImplementedError("a trainable normal_mlp as the target normal (target_normal_map_for_radiance_calculation='inferred_normal_map') in a gradient-carrying "
+                                  "render: the shading's n.v would carry a gradient, and the fused shading backward holds it constant")
+    if "irradiance_mlp" in aux and r.opt.use_radiance_linear:
+        raise NotImplementedError("an irradiance_mlp under use_radiance_linear in a gradient-carrying render (its samples take a sigmoid, ibl_nerf_renderer.py:300-303)")
+    aux_params = [aux_named[name][k] for name in aux_named for k in AUX_PARAMS]
+    order = list(RESULT_ORDER if approximate_radiance else BASE_KEYS)
+    if normal_on:      # results["inferred_normal_map"] sits before target_normal_map / disp_map (:517-518)
+        i_n = 16 if approximate_radiance else order.index("disp_map")
+        order = order[:i_n] + ["inferred_normal_map"] + order[i_n:]
+    keys = [k + s for s in ("", "0") for k in order] + ["z_std"]
 
     class _Fn(torch.autograd.Function):
         @staticmethod
@@ -426,6 +490,8 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             else:
                 res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise, gt_const, rows)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
+            if normal_on:
+                ctx.saved.update(tdepth=res["target_depth_map"].detach().clone(), tdepth0=res["target_depth_map0"].detach().clone())
             if approximate_radiance:
                 src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})
                 for sfx, tap in (("", "envf"), ("0", "envc")):
@@ -447,9 +513,16 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             sv = ctx.saved
             gout = dict(zip(keys, gouts))
             grads_all, oks = [], []
+            aux_grads = {name: None for name in aux_named}
+
+            def aux_add(name, g):
+                if getattr(r, "last_backward_ok", None) is not None:
+                    oks.append(r.last_backward_ok)
+                aux_grads[name] = g if aux_grads[name] is None else {k: aux_grads[name][k] + g[k] for k in g}
+
             r.last_backward_ok = None
             for which, sfx, z, raw in ((0, "0", sv["zc"], sv["rawc"]), (1, "", sv["zf"], sv["rawf"])):
-                lin, _ = r.composite_direct(raw, z, sv["rd"], want_weights=False)
+                lin, w_pass = r.composite_direct(raw, z, sv["rd"], want_weights="normal_mlp" in aux_named)
                 lin, gt_eff = _apply_overrides(lin, gt_const, rows)
                 consts = sv.get("consts" + sfx)
                 if FUSED_SHADING_BACKWARD:                           # one launch (iblnerf_ray_outputs_backward) instead of ~160 ray-sized ones
@@ -477,7 +550,19 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     draw[..., 6:] = 0
                     if frozen_rough[which]:
                         draw[..., 4] = 0
-                _, grads = r.network_backward(st.points(sv["ro"], sv["rd"], z), sv["rd"], draw, which)
+                pts = st.points(sv["ro"], sv["rd"], z)
+                for name in aux:      # the auxiliary networks' columns (:291-303): their gradient goes to them, none of it to the main network
+                    if name in AUX_COLS:
+                        if name in aux_named:
+                            aux_add(name, r.aux_backward(name, pts, draw[..., AUX_COLS[name]].contiguous()))
+                        draw[..., AUX_COLS[name]] = 0
+                gn = gout.get("inferred_normal_map" + sfx)
+                if "normal_mlp" in aux_named and gn is not None:
+                    _, qpts, fac = _inferred_normal(r, pts, w_pass, sv["ro"], sv["rd"], sv["tdepth" + sfx])
+                    gn = gn.reshape(n, 3)
+                    aux_add("normal_mlp", r.aux_backward("normal_mlp", qpts, (gn * fac) if fac.dim() == 2 else (gn[:, None, :] * fac)))
+                r.last_backward_ok = None
+                _, grads = r.network_backward(pts, sv["rd"], draw, which)
                 if getattr(r, "last_backward_ok", None) is not None:
                     oks.append(r.last_backward_ok)
                 for k in ALL_PARAMS:
@@ -487,17 +572,20 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     if ci and k.startswith(("feature_linear.", "views_linears.")):
                         gk = None                                        # is_color_independent_to_direction (ibl_nerf.py:192): unused parameters, no gradient
                     grads_all.append(gk)
-            if r.range_check == "lazy" and len(oks) == 2:
-                # one decision for the step: an overflow in either network's backward skips BOTH networks' gradients (the range flag is sticky on
-                # the device until the next call settles it, so the second call's view already includes the first's overflow; this also zeroes the
-                # first network's gradients when only the second overflowed)
-                both = oks[0] & oks[1]
+            for name in aux_named:
+                for k in AUX_PARAMS:
+                    grads_all.append(None if aux_grads[name] is None else aux_grads[name][k])
+            if r.range_check == "lazy" and len(oks) >= 2:
+                # one decision for the step: an overflow in any network's backward skips EVERY network's gradients (the range flag is sticky on
+                # the device until the next call settles it, so a later call's view already includes an earlier overflow; this also zeroes the
+                # first network's gradients when only a later one overflowed)
+                both = torch.stack([o.reshape(()) for o in oks]).all()
                 grads_all = [None if gk is None else torch.where(both, gk, torch.zeros((), dtype=gk.dtype, device=gk.device)) for gk in grads_all]
             out = []
-            for i, (p, gk) in enumerate(zip(params, grads_all)):
+            for i, (p, gk) in enumerate(zip(params + aux_params, grads_all)):
                 # (views of the call's own gradient blob, a fresh tensor per network_backward: no copy — 92 launches less per step)
                 out.append(gk.reshape(p.shape).to(p.device) if (gk is not None and ctx.needs_input_grad[2 + i]) else None)
             return (None, None) + tuple(out)
 
-    outs = _Fn.apply(ro, rd, *params)
+    outs = _Fn.apply(ro, rd, *params, *aux_params)
     return dict(zip(keys, outs))

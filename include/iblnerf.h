@@ -232,6 +232,16 @@ int iblnerf_upload_weights_device(iblnerf_ctx* ctx, void* stream, int which, con
  * or, with options.infer_normal_at_surface, evaluated at the surface point).  The network takes effect in iblnerf_render_rays once all its
  * channels are uploaded, for both passes, until iblnerf_clear_aux.  Cost: one trunk evaluation per sample and channel. */
 enum { IBLNERF_AUX_ALBEDO = 0, IBLNERF_AUX_ROUGHNESS = 1, IBLNERF_AUX_IRRADIANCE = 2, IBLNERF_AUX_NORMAL = 3 };
+/* An auxiliary network on its own — network_query_fn(pts, None, albedo_mlp | roughness_mlp | irradiance_mlp | normal_mlp) (ibl_nerf_renderer.py:267-303) and, for a
+ * training step (the reference registers these networks' parameters with the optimizer, ibl_nerf.py:305-323), its backward.
+ *   iblnerf_aux_query     d_pts [n_pts, 3] -> d_out [n_pts, channels] raw outputs (before the sigmoid), channels = 3 (albedo, normal) or 1.
+ *   iblnerf_aux_backward  dL/d(raw output `channel`) d_dout [n_pts] -> d_out [n_pts, 4] = (the channel's raw output, dL/dx, dL/dy, dL/dz) and d_grad
+ *                         [iblnerf_blob_floats()] in the IBLNeRF blob layout an auxiliary channel is uploaded in: positions_linears.0-7 hold THIS CHANNEL's
+ *                         contribution to the shared trunk's gradient (sum over the channels), sigma_linear holds row `channel` of out_linears.  grad_scale: as
+ *                         iblnerf_trunk_backward. */
+int iblnerf_aux_query(iblnerf_ctx* ctx, void* stream, int kind, const float* d_pts, int64_t n_pts, float* d_out);
+int iblnerf_aux_backward(iblnerf_ctx* ctx, void* stream, int kind, int channel, const float* d_pts, int64_t n_pts, const float* d_dout,
+                         float grad_scale, float* d_out, float* d_grad);
 int iblnerf_upload_aux_weights(iblnerf_ctx* ctx, int kind, int channel, const float* h_blob, size_t n_floats);
 int iblnerf_clear_aux(iblnerf_ctx* ctx, int kind);
 

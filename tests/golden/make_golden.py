@@ -571,7 +571,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
 
 
 def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=(), override=None,
-                       color_independent=False, planes=False):
+                       color_independent=False, planes=False, aux=False, stable_rays=False):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -588,10 +588,18 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     views_linears are unused and get no gradient) — the fitted checkpoint's weights taken as such a network's."""
     tmp = tempfile.mkdtemp()
     try:
-        kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128))      # [0] = render_kwargs_train
+        kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128, aux=aux, infer_normal=aux))      # [0] = render_kwargs_train
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     assert kw["perturb"] == 1.0
+    aux_seeds = {}
+    if aux:      # f-3 leftover (round 5): the auxiliary networks (ibl_nerf.py:293-323: all registered with the optimizer) with seeded weights, trainable
+        for j, aux_name in enumerate(("albedo_mlp", "roughness_mlp", "irradiance_mlp", "normal_mlp")):
+            aux_seeds[aux_name] = 7100 + j
+            kw[aux_name].load_state_dict({k: torch.from_numpy(v) for k, v in ck.synthetic_position_mlp(aux_seeds[aux_name], ck.AUX_OUT_CH.get(aux_name, 3), 1.0).items()})
+        # (no depth_mlp: with infer_depth the reference's own loss.backward() raises — render_rays squeezes the ReLU's output in place, ibl_nerf_renderer.py:724-725:
+        # "one of the variables needed for gradient computation has been modified by an inplace operation ... output 0 of ReluBackward0")
+        assert kw["infer_normal"] is True
     sd_c, sd_f = fitted_state_dicts()
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
@@ -618,6 +626,41 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
             kw[k_].is_color_independent_to_direction = True
     rng = np.random.RandomState(4100)
     o, d, pix, focal = camera_rays(rng, n_rays)
+    if stable_rays:
+        # The fine network's (and the auxiliary networks') gradients depend on which BIN of the inverse CDF each stochastic fine sample falls into; a draw u within a few
+        # ulps of a cdf entry lands in another bin under any other rounding of the coarse weights (tests/test_gpu_training.py: z_std of such a ray moves by 4e-3).  For a
+        # fixture that pins a gradient PATH rather than that threshold, rays whose closest |u - cdf| is below 3e-6 (50 ulps of the cdf) in the reference's own run are replaced (the draw
+        # of row i belongs to row i — numpy's seed-0 stream — so the replacement keeps its row) until none is left.
+        pdf0, cap = R.sample_pdf, {}
+
+        def spy(bins, weights, N, det=False, pytest=False):
+            w_ = weights + 1e-5
+            pdf_ = w_ / torch.sum(w_, -1, keepdim=True)
+            cdf_ = torch.cat([torch.zeros_like(pdf_[..., :1]), torch.cumsum(pdf_, -1)], -1)
+            np.random.seed(0)
+            u_ = np.random.rand(*(list(cdf_.shape[:-1]) + [N]))
+            pn = pdf_.detach().numpy().astype(np.float64)
+            big = np.concatenate([pn[:, :1], np.maximum(pn[:, 1:], pn[:, :-1]), pn[:, -1:]], -1) > 1e-3      # cdf entries beside a bin that holds mass (a flip between two empty bins moves a weightless sample)
+            dist = np.abs(u_[:, :, None] - cdf_.detach().numpy().astype(np.float64)[:, None, :])
+            cap["margin"] = np.where(big[:, None, :], dist, np.inf).min((-1, -2))
+            return pdf0(bins, weights, N, det=det, pytest=pytest)
+
+        for _ in range(12):
+            R.sample_pdf = spy
+            try:
+                with torch.no_grad():
+                    R.render_decomp(800, 800, np.array([[focal, 0, 400], [0, focal, 400], [0, 0, 1]], dtype=np.float32), chunk=n_rays, rays=torch.from_numpy(np.stack([o, d], 0)),
+                                    gt_values={}, approximate_radiance=False, **kw, **EDIT_KEYS_OFF)
+            finally:
+                R.sample_pdf = pdf0
+            crit = np.flatnonzero(cap["margin"] < 3e-6)
+            if not len(crit):
+                break
+            o2, d2, pix2, _ = camera_rays(rng, len(crit))
+            o[crit], d[crit], pix[crit] = o2, d2, pix2
+        else:
+            raise RuntimeError("stable_rays: still threshold-critical rays after 12 rounds")
+        stable_margin = float(cap["margin"].min())
     edit_kw = dict(EDIT_KEYS_OFF)
     if override is not None:
         sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -634,6 +677,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import train_loss as TL
     tg, beta = TL.targets(rng, n_rays), TL.BETA
+    if aux:
+        tg.update(TL.aux_targets(rng, n_rays))
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=plane_near if planes else np.float32(0.5), far=plane_far if planes else np.float32(8.0), chunk=np.int64(n_rays),
                ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))), ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
                ckpt=np.array("fitted"))
@@ -641,12 +686,16 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
         out["target__" + k] = v
     for k, v in beta.items():
         out["beta__" + k] = np.float64(v)
-    nets = (("c", kw["network_fn"]), ("f", kw["network_fine"]))
+    nets = (("c", kw["network_fn"]), ("f", kw["network_fine"])) + tuple((nm, kw[nm]) for nm in aux_seeds)
+    for nm, sd_seed in aux_seeds.items():
+        out["aux__" + nm] = np.int64(sd_seed)
 
     out["raw_noise_std"] = np.float32(raw_noise_std)
     for k, v in gt_values.items():
         out["gt__" + k] = v
     out["from_gt"] = np.array(sorted(from_gt))
+    if stable_rays:
+        out["stable_rays_min_margin"] = np.float64(stable_margin)
     out["override"] = np.array(override or "")
     out["color_independent"] = np.asarray(bool(color_independent))
     import json as _json
@@ -668,6 +717,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
         out[phase + "__loss"] = np.float64(loss.item())
         for tag, net in nets:
             for name, prm in net.named_parameters():
+                if tag in aux_seeds and name.endswith(".weight") and name.split(".")[1] in ("1", "2", "3", "4", "6"):
+                    continue      # (an auxiliary network's fixture keeps every bias — each is the sum of its layer's dZ, so the whole dgrad chain is pinned — and the weights of layers 0, 5, 7 and out_linears)
                 out["%s__grad_%s__%s" % (phase, tag, name)] = (prm.grad.numpy().copy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32))
     for _, net in nets:
         net.freeze_radiance = net.freeze_roughness = False
@@ -1038,6 +1089,8 @@ def main(only=None):
         train_step_fixture(torch, R, M, lut, fixture="train_step_insert", phases=("warmup", "full"), override="insert")
     if not only or "train_step_planes" in only:     # f-3 leftover (round 5): per-ray near / far planes in a gradient-carrying render
         train_step_fixture(torch, R, M, lut, fixture="train_step_planes", phases=("warmup", "full", "depth"), planes=True)
+    if not only or "train_step_aux" in only:        # f-3 leftover (round 5): auxiliary networks (albedo / roughness / irradiance / normal) trained by the step
+        train_step_fixture(torch, R, M, lut, fixture="train_step_aux", phases=("warmup", "full"), aux=True, stable_rays=True)
     if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
         train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth

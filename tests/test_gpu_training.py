@@ -235,10 +235,13 @@ def test_training_step_with_ground_truth_targets(lut, name, fused, teacher):
 
 
 def _grads_against(G, phase, nets):
-    """{parameter: |got - ref| max / the tensor's (or, for an N = 1 / 3 head's bias, its layer's) largest reference entry}, and the names whose reference gradient is zero"""
+    """{parameter: |got - ref| max / the tensor's (or, for an N = 1 / 3 head's bias, its layer's) largest reference entry}, and the names whose reference gradient is zero.
+    nets: (network_fn, network_fine) or [(tag, module), ...]; parameters the fixture does not hold are skipped."""
     worst, zero = {}, []
-    for tag, net in (("c", nets[0]), ("f", nets[1])):
+    for tag, net in ((("c", nets[0]), ("f", nets[1])) if not isinstance(nets[0], tuple) else nets):
         for pname, prm in net.named_parameters():
+            if "%s__grad_%s__%s" % (phase, tag, pname) not in G.files:
+                continue
             ref = G["%s__grad_%s__%s" % (phase, tag, pname)]
             got = np.zeros_like(ref) if prm.grad is None else prm.grad.cpu().numpy()
             scale = float(np.abs(ref).max())
@@ -249,7 +252,12 @@ def _grads_against(G, phase, nets):
             if pname.endswith(".bias") and ref.size <= 3:
                 scale = max(scale, float(np.abs(G["%s__grad_%s__%s" % (phase, tag, pname[:-4] + "weight")]).max()))
             worst[tag + "." + pname] = float(np.abs(got - ref).max()) / scale
+            P99[tag + "." + pname] = float(np.percentile(np.abs(got - ref), 99)) / scale
     return worst, zero
+
+
+P99 = {}      # (side channel of _grads_against: the 99th percentile of the same per-entry distance — robust against one unit's flipped ReLU pass bit)
+
 
 
 def test_ground_truth_targets_during_the_warm_up(lut):
@@ -329,6 +337,98 @@ def test_training_step_with_edit_and_insert_overrides(lut, name, phase, fused):
         TL.total_loss(torch, res0, {k[8:]: G[k] for k in G.files if k.startswith("target__")}, True).backward()
         w0, _ = _grads_against(G, phase, nets)
         assert max(w0["c.albedo_linear.weight"], w0["f.albedo_linear.weight"]) > 2e-2, (w0["c.albedo_linear.weight"], w0["f.albedo_linear.weight"])
+
+
+@pytest.mark.parametrize("name", ["albedo_mlp", "roughness_mlp"])
+def test_auxiliary_network_backward_matches_autograd(lut, name):
+    """Renderer.aux_query / aux_backward (iblnerf_aux_query, iblnerf_aux_backward: one trunk backward per output channel, trunk gradients summed) against torch
+    autograd through the same PositionMLP in float64, on random points and upstream gradients: outputs to 2e-5, all 18 parameter gradients to 1e-3."""
+    from torch_ref import AuxShaped, embed
+    from ibl_nerf_amd import renderer as R, checkpoint as ck
+    out_ch = ck.AUX_OUT_CH[name]
+    sd = ck.synthetic_position_mlp(77, out_ch, 1.0)
+    r = R.Renderer(64, 128, max_rays_per_launch=256)
+    r.load_weights(0, ck.synthetic_state_dict(5)); r.load_lut(lut)
+    r.load_aux(name, sd)
+    gen = torch.Generator().manual_seed(11)
+    pts = (torch.rand((96, 40, 3), generator=gen) * 4 - 2).cuda()
+    dout = torch.randn((96, 40, out_ch), generator=gen).cuda()
+    net = AuxShaped(out_ch, sd).double().cuda()
+    out_ref = net(embed(pts.double(), 10))
+    (out_ref * dout.double()).sum().backward()
+    out = r.aux_query(name, pts)
+    assert rel_linf(out.cpu().numpy(), out_ref.detach().cpu().numpy()) <= 2e-5
+    grads = r.aux_backward(name, pts, dout)
+    assert sorted(grads) == sorted(n for n, _ in net.named_parameters())
+    rep = {n: rel_linf(grads[n].cpu().numpy(), p.grad.cpu().numpy()) for n, p in net.named_parameters()}
+    assert max(rep.values()) <= 1e-3, rep
+
+
+@pytest.mark.parametrize("phase", ["warmup", "full"])
+def test_training_step_with_auxiliary_networks(lut, phase):
+    """f-3 leftover closed in round 5: albedo_mlp / roughness_mlp / irradiance_mlp / normal_mlp (PositionMLP, networks/MLP.py:6-30; ibl_nerf.py:305-323 registers them with
+    the optimizer) in a gradient-carrying render.  Their outputs replace the main network's albedo / roughness / irradiance samples in both passes
+    (ibl_nerf_renderer.py:291-303): the main network's heads behind those columns get exactly nothing, the auxiliary networks get the columns' gradient — one
+    iblnerf_aux_backward per output channel, the channels' trunk gradients summed, the two passes' summed; normal_mlp is trained through inferred_normal_map (:266-275).
+    Fixture = the reference's own loss.backward() with all four networks (seeded weights) and a target-normal loss: every bias of every auxiliary layer (= the sum of that
+    layer's dZ) and the weights of layers 0, 5, 7 and out_linears, beside the two main networks' 92 tensors."""
+    import train_loss as TL
+    from torch_ref import AuxShaped
+    from ibl_nerf_amd import renderer as R, checkpoint as ck
+    G = np.load(os.path.join(GOLDEN, "train_step_aux.npz"))
+    nets, kw, K, rays = _setup(G, lut, phase)
+    aux = {k[5:]: AuxShaped(ck.AUX_OUT_CH[k[5:]], ck.synthetic_position_mlp(int(G[k]), ck.AUX_OUT_CH[k[5:]], 1.0)).cuda() for k in G.files if k.startswith("aux__")}
+    assert sorted(aux) == ["albedo_mlp", "irradiance_mlp", "normal_mlp", "roughness_mlp"]
+    kw.update(aux, infer_normal=True)
+    approx = phase == "full"
+    if approx:      # the reference's own no-grad maps (n.v, reflected-ray maps) as the shading backward's constants: they carry the eps-normal's own 1e-3 differences into
+        # d color / d irradiance = (1 - F) (1 - metallic) albedo, which a random-init network's cancelling bias sums amplify (2.4e-2 on one bias without them)
+        kw["teacher_maps"] = {k[11:]: torch.from_numpy(G[k]).cuda() for k in G.files if k.startswith("full__out__") and k[11:].startswith(("n_dot_v_map", "reflected_"))}
+    # (a) every aux_backward call of the step against torch autograd (float64) through the same PositionMLP on the call's own points and upstream rows
+    from torch_ref import embed
+    calls, orig = [], R.Renderer.aux_backward
+
+    def checked(self, name, pts, dout, grad_scale=None):
+        g = orig(self, name, pts, dout, grad_scale)
+        net = AuxShaped(ck.AUX_OUT_CH[name], {k: v.detach().cpu() for k, v in aux[name].state_dict().items()}).double().cuda()
+        with torch.enable_grad():
+            out = net(embed(pts.reshape(-1, 3).double(), 10))
+            (out * dout.reshape(out.shape).double()).sum().backward()
+        calls.append((name, max(rel_linf(g[n].cpu().numpy(), q.grad.cpu().numpy()) for n, q in net.named_parameters())))
+        return g
+
+    R.Renderer.aux_backward = checked
+    try:
+        res = R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values={}, approximate_radiance=approx, **kw)
+        loss = TL.total_loss(torch, res, {k[8:]: G[k] for k in G.files if k.startswith("target__")}, approx)
+        loss.backward()
+    finally:
+        R.Renderer.aux_backward = orig
+    assert sorted(c[0] for c in calls) == sorted(2 * list(aux)) and max(c[1] for c in calls) <= 1e-3, calls          # (both passes, all four networks)
+    assert sorted(res.keys()) == sorted(k[len(phase) + 7:] for k in G.files if k.startswith(phase + "__out__"))
+    for k in ("radiance_map", "albedo_map", "irradiance_map", "roughness_map", "inferred_normal_map", "depth_map", "disp_map", "acc_map", "weights"):
+        for sfx in ("", "0"):
+            e = rel_linf(res[k + sfx].detach().cpu().numpy(), G["%s__out__%s" % (phase, k + sfx)])
+            assert e <= 1e-3, (k + sfx, e)
+    assert abs(float(loss.detach()) - float(G[phase + "__loss"])) <= (3e-4 if approx else 2e-5) * float(G[phase + "__loss"])
+    # (b) end to end against the reference's loss.backward()
+    worst, zero = _grads_against(G, phase, [("c", nets[0]), ("f", nets[1])] + sorted(aux.items()))
+    replaced = ("albedo_feature_linear.", "albedo_linear.", "roughness_linear.", "irradiance_feature_linear.", "irradiance_linear.")
+    assert sorted(zero) == sorted(t + "." + n for t, net in (("c", nets[0]), ("f", nets[1])) for n, _ in net.named_parameters() if n.startswith(replaced)), zero
+    assert len(worst) == 92 - len(zero) + 4 * (8 + 3 + 2), len(worst)
+    # The auxiliary networks are random-init (gain 1): their first layers weigh the encoding's high frequencies as much as the low ones, and the fine pass's samples
+    # sit where this path's coarse weights put them — 1e-5 from the reference's own (weights0 to 7e-6), i.e. 5e-3 rad in sin(2^9 x): the gradients of layers 0-1
+    # differ by up to 1e-2 of their largest entry end to end while every call is right to 5e-4 on its own inputs ((a) above; measured: scratch/aux_step_dbg.py).
+    # The fitted main networks, smooth in x, stay inside the plain step's bars.
+    early = ("positions_linears.0.", "positions_linears.1.")
+    lim = lambda k: (1.5e-2 if any(e in k for e in early) else 5e-3) if k.split(".")[0] in aux else (      # (5e-3: the layers below a unit whose pass bit flipped, see below)
+        5e-3 if (approx and "roughness" in k) else (1.5e-3 if (approx and k.startswith("f.")) else 1e-3))
+    # ... and one hidden unit's ReLU pass bit may differ from the reference's fp32 forward on a heavy sample (z = 0 to rounding; tests/test_gpu_gradnormal.py): that unit's
+    # bias entry and weight row then carry the sample's whole contribution — measured here: irradiance_mlp.positions_linears.3.bias, one entry, 2.4e-2.  So the bars hold
+    # for 99 % of every tensor's entries, and for every entry at 3e-2.
+    bad = {k: (v, P99[k]) for k, v in worst.items() if (P99[k] if k.split(".")[0] in aux else v) > lim(k) or v > 3e-2}
+    assert not bad, bad
+    assert sum(v > lim(k) for k, v in worst.items()) <= 3, {k: v for k, v in worst.items() if v > lim(k)}
 
 
 @pytest.mark.parametrize("phase", ["warmup", "full", "depth"])

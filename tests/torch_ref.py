@@ -6,6 +6,26 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class AuxShaped(nn.Module):
+    """Parameter holder with the schema of the reference's PositionMLP (src/networks/MLP.py:6-30): positions_linears.0-7 + out_linears."""
+
+    def __init__(self, out_ch, sd=None):
+        super().__init__()
+        W, ch = 256, 63
+        self.positions_linears = nn.ModuleList([nn.Linear(ch, W)] + [nn.Linear(W + ch if i == 4 else W, W) for i in range(7)])
+        self.out_linears = nn.Linear(W, out_ch)
+        if sd is not None:
+            self.load_state_dict({k: torch.as_tensor(v).clone() for k, v in sd.items()})
+
+    def forward(self, e_pts):
+        h = e_pts
+        for i, l in enumerate(self.positions_linears):
+            h = F.relu(l(h))
+            if i == 4:
+                h = torch.cat([e_pts, h], -1)
+        return self.out_linears(h)
+
+
 class RefShaped(nn.Module):
     def __init__(self, sd=None):
         super().__init__()
