@@ -1123,7 +1123,13 @@ int iblnerf_ray_outputs_backward(iblnerf_ctx* c, void* stream, const float* d_ma
 }
 
 static int ray_outputs_backward_impl(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
-                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps);
+                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps, float* d_denv = nullptr);
+
+int iblnerf_ray_outputs_backward_env(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
+                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps, float* d_denv) {
+    if (c && n_rays > 0 && (!d_n_dot_v || !d_denv)) return c->fail(IBLNERF_ERR_INVALID, "ray_outputs_backward_env: needs d_n_dot_v / d_env (approximate_radiance) and d_denv");
+    return ray_outputs_backward_impl(c, stream, d_maps, d_n_dot_v, d_env, d_depth0 ? 1.0f : depth0, d_depth0, up, ovr, n_rays, d_dmaps, d_denv);
+}
 
 int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0,
                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
@@ -1137,7 +1143,7 @@ int iblnerf_ray_outputs_backward_rays(iblnerf_ctx* c, void* stream, const float*
 }
 
 static int ray_outputs_backward_impl(iblnerf_ctx* c, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
-                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps) {
+                                     const iblnerf_maps* up, const iblnerf_overrides* ovr, int64_t n_rays, float* d_dmaps, float* d_denv) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (ovr && ovr->mode != 0)
         return c->fail(IBLNERF_ERR_STATE, "ray_outputs_backward: edit / insert overrides in a gradient-carrying render are not built (only the *_from_gt constants)");
@@ -1148,7 +1154,7 @@ static int ray_outputs_backward_impl(iblnerf_ctx* c, void* stream, const float* 
     if (n_rays == 0) return IBLNERF_OK;
     HIP_TRY(c, hipSetDevice(c->opt.device));
     RayBwdArgs a{};
-    a.x = d_maps; a.ndv = d_n_dot_v; a.env = d_env; a.lut = c->d_lut; a.depth0 = depth0; a.depth0_ray = d_depth0;
+    a.x = d_maps; a.ndv = d_n_dot_v; a.env = d_env; a.lut = c->d_lut; a.depth0 = depth0; a.depth0_ray = d_depth0; a.denv = d_denv;
     a.out_mode = (c->opt.gamma_correct ? 1 : 0) | (c->opt.use_radiance_linear ? 2 : 0);
     a.lut_f0 = c->opt.lut_coefficient_f0; a.correct_depth = c->opt.correct_depth_for_prefiltered_radiance;
     a.g_color = up->color_map; a.g_radiance = up->radiance_map;

@@ -135,6 +135,7 @@ struct RayBwdArgs {
     const float* lut;        // [3, 512, 512]
     float depth0;            // (near + far) / 2
     const float* depth0_ray = nullptr;   // ... per ray [n] (per-ray near / far planes), or nullptr
+    float* denv = nullptr;               // out, optional: dL/d env [n, 4, 3] (use_gradient_for_incident_radiance: the reflected-ray maps carry a gradient)
     int out_mode;            // bit 0 gamma_correct, bit 1 use_radiance_linear (out_map)
     int lut_f0, correct_depth;
     const float *g_color, *g_radiance, *g_radiance_k[3], *g_irradiance, *g_albedo, *g_roughness, *g_specular, *g_diffuse, *g_prefiltered,

@@ -1652,6 +1652,9 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
         const float rem = level * 3.0f - (float)i1;
         const float* env = a.env + 12 * r;
         float g_rough = 0.f, g_e0 = 0.f, g_e1 = 0.f, g_rem = 0.f, g_irr = 0.f;
+        float g_env[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g_env[i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float alb = alb_gt ? a.gt_albedo[3 * r + c] : x[2 + c];
@@ -1686,6 +1689,12 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
             if (!alb_gt) dx[2 + c] += g_alb;
             g_rough += G_F0 * (0.04f - alb);                                                      // d F0 / d rough through metallic = 1 - rough
             g_rem += G_pref * (env[3 * i2 + c] - env[3 * i1 + c]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g_env[3 * k + c] += (k == i1 ? G_pref * (1.0f - rem) : 0.0f) + (k == i2 ? G_pref * rem : 0.0f);      // :461-467
+        }
+        if (a.denv != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a.denv[12 * r + i] = g_env[i];
         }
         g_rough += g_e0 * de0 + g_e1 * de1;
         dx[5] += 3.0f * g_rem * dlevel + (rough_gt ? 0.0f : g_rough);     // (the mip level reads the network's roughness_map whatever the target is)

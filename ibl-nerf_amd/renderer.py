@@ -737,16 +737,17 @@ class Renderer:
                                                             None if w is None else w.data_ptr()))
         return maps, w
 
-    def composite_direct_backward(self, raw, z_vals, rays_d, dmaps, dweights=None):
-        """dL/d maps [n, 19] (+ dL/d weights [n, S]) -> dL/d raw [n, S, 18]."""
+    def composite_direct_backward(self, raw, z_vals, rays_d, dmaps, dweights=None, full=False):
+        """dL/d maps [n, 19] (+ dL/d weights [n, S]) -> dL/d raw [n, S, 18].  full=True: without the reference's stop-gradients — every map differentiated through the
+        live weights (iblnerf_composite_direct_backward_full), which is raw2outputs_simple's arithmetic (ibl_nerf_renderer.py:38-66: the reflected rays)."""
         torch = _torch()
         raw, z, rd = _dev_f32(raw, self.device), _dev_f32(z_vals, self.device), _dev_f32(rays_d, self.device)
         n, S = raw.shape[0], raw.shape[1]
         dm = _dev_f32(dmaps, self.device).reshape(n, 19)
         dw = None if dweights is None else _dev_f32(dweights, self.device).reshape(n, S)
         draw = torch.empty((n, S, 18), dtype=torch.float32, device=self.device)
-        B.check(self.ctx, self.lib.iblnerf_composite_direct_backward(self.ctx, self._stream(), raw.data_ptr(), z.data_ptr(), rd.data_ptr(), n, S, dm.data_ptr(),
-                                                                     None if dw is None else dw.data_ptr(), draw.data_ptr()))
+        entry = self.lib.iblnerf_composite_direct_backward_full if full else self.lib.iblnerf_composite_direct_backward
+        B.check(self.ctx, entry(self.ctx, self._stream(), raw.data_ptr(), z.data_ptr(), rd.data_ptr(), n, S, dm.data_ptr(), None if dw is None else dw.data_ptr(), draw.data_ptr()))
         return draw
 
     # output map -> (iblnerf_maps field, index in a [3] pointer array or None, channels): the maps whose upstream gradient iblnerf_ray_outputs_backward reads
@@ -756,12 +757,13 @@ class Renderer:
                  "diffuse_map": ("diffuse_map", None, 3), "prefiltered_reflected_map": ("prefiltered_reflected_map", None, 3), "disp_map": ("disp_map", None, 1),
                  "acc_map": ("acc_map", None, 1), "depth_map": ("depth_map", None, 1), "target_depth_map": ("target_depth_map", None, 1)}
 
-    def ray_outputs_backward(self, maps, upstream, n_dot_v=None, env=None, depth0=1.0, gt=None):
+    def ray_outputs_backward(self, maps, upstream, n_dot_v=None, env=None, depth0=1.0, gt=None, want_denv=False):
         """dL/d(output maps) -> dL/d(linear direct maps [n, 19]) through the ray-sized part of raw2outputs (iblnerf_ray_outputs_backward): `maps` = the
         pass's linear maps (composite_direct), `upstream` = {map name: gradient or None}; n_dot_v [n] / env [n, 4, 3] = the pass's no-grad
         quantities (None, None for approximate_radiance=False).  gt: {"albedo" [n,3], "roughness" [n], "irradiance" [n,3], "depth" [n]} — the target maps
         of the calculate_*_from_gt / depth_map_from_ground_truth flags that are on, constants of the backward (iblnerf_ray_outputs_backward_gt).
-        depth0: (near + far) / 2, a float — or a [n] tensor under per-ray planes (iblnerf_ray_outputs_backward_rays)."""
+        depth0: (near + far) / 2, a float — or a [n] tensor under per-ray planes (iblnerf_ray_outputs_backward_rays).
+        want_denv (use_gradient_for_incident_radiance): returns (dmaps, dL/d env [n, 4, 3]) (iblnerf_ray_outputs_backward_env)."""
         torch = _torch()
         x = _dev_f32(maps, self.device).reshape(-1, 19)
         n = x.shape[0]
@@ -791,6 +793,15 @@ class Renderer:
                     t = _dev_f32(gt[name], self.device).reshape(n, ch).contiguous()
                     keep.append(t)
                     setattr(ov, field, t.data_ptr())
+        if want_denv:
+            denv = torch.empty((n, 4, 3), dtype=torch.float32, device=self.device)
+            d0 = _dev_f32(depth0, self.device).reshape(n).contiguous() if torch.is_tensor(depth0) else None
+            keep.append(d0)
+            B.check(self.ctx, self.lib.iblnerf_ray_outputs_backward_env(self.ctx, self._stream(), x.data_ptr(), ndv.data_ptr(), ev.data_ptr(), 1.0 if d0 is not None else float(depth0),
+                                                                        None if d0 is None else d0.data_ptr(), C.byref(up), None if ov is None else C.byref(ov), n,
+                                                                        dx.data_ptr(), denv.data_ptr()))
+            self._keep_up = keep
+            return dx, denv
         if torch.is_tensor(depth0):
             d0 = _dev_f32(depth0, self.device).reshape(n).contiguous()
             keep.append(d0)
@@ -1496,7 +1507,8 @@ def render_decomp(H, W, K, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1.
             ret = T.render_rays_train(r, ro_f, rd_f, *nf, kwargs["network_fn"], kwargs.get("network_fine"), kwargs["brdf_lut"],
                                       approximate_radiance=approx, teacher_maps=kwargs.get("teacher_maps"), raw_noise_std=std,
                                       gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr,
-                                      aux_nets={k: kwargs.get(k) for k in B.AUX_KINDS if kwargs.get(k) is not None}, **smp)
+                                      aux_nets={k: kwargs.get(k) for k in B.AUX_KINDS if kwargs.get(k) is not None},
+                                      incident_gradient=_truthy(kwargs.get("use_gradient_for_incident_radiance", False)), **smp)
         else:
             ret = T.render_rays_direct(r, ro_f, rd_f, *nf, raw_noise_std=std, gt_values=kwargs.get("gt_values"), from_gt=gt_flags, edit=ovr, **smp)
         if kwargs.get("infer_depth") and r._depth_mlp is not None and "inferred_depth_map" not in ret:

@@ -20,7 +20,9 @@ of the frozen layers dropped.
 
 Edit / insert overrides and the four *_from_gt substitutions are constants of the backward (override_rows, _gt_constants), under either value of
 approximate_radiance; colour-independent networks run the same backward with the identity in place of their unused feature / view layers.
-Not built here (raise): auxiliary networks, a depth_mlp's gradients (infer_depth), use_gradient_for_incident_radiance.  (raw_noise_std > 0 is: the step's noise rows are drawn once, added to the
+Auxiliary networks receive their columns' gradients (Renderer.aux_backward); use_gradient_for_incident_radiance carries dL/d(reflected-ray maps) through the
+reflected query into the pass's network.  Not built here (raise): a trainable depth_mlp (infer_depth; the reference's own backward raises there), a trainable
+normal_mlp as the target normal.  (raw_noise_std > 0 is: the step's noise rows are drawn once, added to the
 density the compositing reads in both directions, and are constants of the backward.)
 """
 from __future__ import annotations
@@ -408,9 +410,12 @@ def render_rays_direct(r, rays_o, rays_d, near, far, perturb=0., pytest=False, c
 
 
 def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approximate_radiance, perturb=0., pytest=False, chunk=None, teacher_maps=None,
-                      raw_noise_std=0., gt_values=None, from_gt=None, edit=None, aux_nets=None):
+                      raw_noise_std=0., gt_values=None, from_gt=None, edit=None, aux_nets=None, incident_gradient=False):
     """render_rays + raw2outputs for a training step: the reference's result dict whose tensors carry a grad_fn into the parameters of
     `net_c` (network_fn) and `net_f` (network_fine).  `r`: the Renderer holding both networks' current weights (renderer_for).
+    incident_gradient (use_gradient_for_incident_radiance, ibl_nerf_renderer.py:442-453): the reflected-ray query carries a gradient — dL/d(the four reflected-ray maps)
+    from the shading backward goes through raw2outputs_simple (every map on the live weights, :38-66) into the pass's own network at the reflected rays' points
+    (x_surface and the reflected direction are detached / no-grad quantities: nothing but the network's parameters receives it).
     aux_nets: {'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp' | 'normal_mlp': module} — the auxiliary networks loaded on `r` (ibl_nerf.py:305-323 registers
     them with the optimizer): their outputs replace the main network's albedo / roughness / irradiance columns in both passes (the main network gets no gradient
     there), normal_mlp feeds inferred_normal_map; a module with trainable parameters receives its gradients (Renderer.aux_backward), summed over the passes.
@@ -490,10 +495,16 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
             else:
                 res, sv = _forward_direct(r, st, ro_, rd_, near, far, t_rand, u, flags, noise, gt_const, rows)
             ctx.saved = dict(sv, ro=ro_, rd=rd_)
-            if normal_on:
+            if normal_on or (incident_gradient and approximate_radiance):
                 ctx.saved.update(tdepth=res["target_depth_map"].detach().clone(), tdepth0=res["target_depth_map0"].detach().clone())
+            if incident_gradient and approximate_radiance:
+                tm = {k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items() if k.startswith(("target_normal_map", "target_depth_map"))}
+                ctx.saved.update(tnormal=tm.get("target_normal_map", res["target_normal_map"]).detach().clone(),
+                                 tnormal0=tm.get("target_normal_map0", res["target_normal_map0"]).detach().clone())
+                if "target_depth_map" in tm:      # (parity tests: the reflected rays' origin and direction as the reference had them — x_surface :262, the normal :358-361)
+                    ctx.saved.update(tdepth=tm["target_depth_map"].clone(), tdepth0=tm["target_depth_map0"].clone())
             if approximate_radiance:
-                src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items()})
+                src = dict(res, **{k: _dev_f32(v, r.device).reshape(res[k].shape) for k, v in (teacher_maps or {}).items() if k in res})
                 for sfx, tap in (("", "envf"), ("0", "envc")):
                     if teacher_maps:                                 # parity tests: the reference's own (gamma-corrected) maps, inverted
                         env = torch.stack([_ungamma(src[k + sfx], flags["gamma_correct"]) for k in
@@ -530,8 +541,12 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     for name in ("albedo", "roughness", "irradiance"):          # (an output map that IS the ground truth carries no gradient; the irradiance one is [n, 3] then)
                         if name in gt_const:
                             ups.pop(name + "_map", None)
-                    dx = r.ray_outputs_backward(lin, ups, None if consts is None else consts["n_dot_v"], None if consts is None else consts["env"],
-                                                depth0, gt=gt_eff or None)
+                    denv = None
+                    if incident_gradient and consts is not None:
+                        dx, denv = r.ray_outputs_backward(lin, ups, consts["n_dot_v"], consts["env"], depth0, gt=gt_eff or None, want_denv=True)
+                    else:
+                        dx = r.ray_outputs_backward(lin, ups, None if consts is None else consts["n_dot_v"], None if consts is None else consts["env"],
+                                                    depth0, gt=gt_eff or None)
                 else:                                                # the same by torch autograd (the tests' reference for the kernel above)
                     with torch.enable_grad():
                         x = lin.detach().requires_grad_(True)
@@ -563,6 +578,23 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     aux_add("normal_mlp", r.aux_backward("normal_mlp", qpts, (gn * fac) if fac.dim() == 2 else (gn[:, None, :] * fac)))
                 r.last_backward_ok = None
                 _, grads = r.network_backward(pts, sv["rd"], draw, which)
+                if incident_gradient and consts is not None and not frozen[which]:      # (forward_freezed computes sigma and every radiance under no_grad: nothing to carry)
+                    # the reflected ray of this pass (:438-440): x_surface + reflected_dir * z_vals_constant (the coarse grid, jitter included, :694), queried on the
+                    # pass's own network (:451); raw2outputs_simple composites radiance and the three coarse radiances on the live weights
+                    if not FUSED_SHADING_BACKWARD:
+                        raise NotImplementedError("use_gradient_for_incident_radiance needs the fused shading backward (dL/d env)")
+                    if getattr(r, "last_backward_ok", None) is not None:
+                        oks.append(r.last_backward_ok)
+                    nrm, xs = sv["tnormal" + sfx], (sv["ro"] + sv["rd"] * sv["tdepth" + sfx][:, None]).contiguous()
+                    rdir = (sv["rd"] - 2 * torch.sum(nrm * sv["rd"], -1, keepdim=True) * nrm).contiguous()
+                    rpts = st.points(xs, rdir, sv["zc"])
+                    rraw = r.network_query(rpts, rdir, which)
+                    dm = torch.zeros((n, 19), dtype=torch.float32, device=r.device)
+                    dm[:, 7:19] = denv.reshape(n, 12)
+                    rdraw = r.composite_direct_backward(rraw, sv["zc"], rdir, dm, None, full=True)
+                    r.last_backward_ok = None
+                    _, g2 = r.network_backward(rpts, rdir, rdraw, which)
+                    grads = {k: grads[k] + g2[k] for k in grads}
                 if getattr(r, "last_backward_ok", None) is not None:
                     oks.append(r.last_backward_ok)
                 for k in ALL_PARAMS:

@@ -475,6 +475,11 @@ int iblnerf_ray_outputs_backward_gt(iblnerf_ctx* ctx, void* stream, const float*
  * (every entry positive; read only under correct_depth_for_prefiltered_radiance with d_n_dot_v given). */
 int iblnerf_ray_outputs_backward_rays(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, const float* d_depth0,
                                       const iblnerf_maps* d_upstream, const iblnerf_overrides* overrides, int64_t n_rays, float* d_dmaps);
+/* ... under use_gradient_for_incident_radiance (:442-453: the reflected-ray query runs WITH gradients): also d_denv [n_rays, 4, 3] out = dL/d(the linear reflected-ray
+ * maps d_env) through the mip interpolation (:461-467) — what the caller carries on through raw2outputs_simple (iblnerf_composite_direct_backward_full on the
+ * reflected rays' rows: every map on the live weights, :38-66) and the reflected query's network (iblnerf_network_backward).  depth0: scalar, or d_depth0 [n_rays]. */
+int iblnerf_ray_outputs_backward_env(iblnerf_ctx* ctx, void* stream, const float* d_maps, const float* d_n_dot_v, const float* d_env, float depth0, const float* d_depth0,
+                                     const iblnerf_maps* d_upstream, const iblnerf_overrides* overrides, int64_t n_rays, float* d_dmaps, float* d_denv);
 
 
 /* replaces: batchify_rays -> render_rays -> raw2outputs (nerf_models/ibl_nerf_renderer.py:735-756,

@@ -571,7 +571,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
 
 
 def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=(), override=None,
-                       color_independent=False, planes=False, aux=False, stable_rays=False):
+                       color_independent=False, planes=False, aux=False, stable_rays=False, incident_gradient=False):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -621,6 +621,9 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
             kw[flag] = True
             gt_values[key] = gt_rng.uniform(lo, hi, (n_rays, ch)).astype(np.float32)
     kw["brdf_lut"] = lut
+    if incident_gradient:      # use_gradient_for_incident_radiance (:442-453): the reflected-ray query runs with gradients
+        kw["use_gradient_for_incident_radiance"] = True
+    out_extra = {"incident_gradient": np.asarray(bool(incident_gradient))}
     if color_independent:
         for k_ in ("network_fn", "network_fine"):
             kw[k_].is_color_independent_to_direction = True
@@ -696,6 +699,7 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     out["from_gt"] = np.array(sorted(from_gt))
     if stable_rays:
         out["stable_rays_min_margin"] = np.float64(stable_margin)
+    out.update(out_extra)
     out["override"] = np.array(override or "")
     out["color_independent"] = np.asarray(bool(color_independent))
     import json as _json
@@ -1091,6 +1095,8 @@ def main(only=None):
         train_step_fixture(torch, R, M, lut, fixture="train_step_planes", phases=("warmup", "full", "depth"), planes=True)
     if not only or "train_step_aux" in only:        # f-3 leftover (round 5): auxiliary networks (albedo / roughness / irradiance / normal) trained by the step
         train_step_fixture(torch, R, M, lut, fixture="train_step_aux", phases=("warmup", "full"), aux=True, stable_rays=True)
+    if not only or "train_step_incident" in only:   # f-3 leftover (round 5): use_gradient_for_incident_radiance
+        train_step_fixture(torch, R, M, lut, fixture="train_step_incident", phases=("full", "frozen"), incident_gradient=True)
     if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
         train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
