@@ -397,11 +397,18 @@ def test_network_backward_on_the_fitted_checkpoint_and_ragged_sizes(R, lut):
             assert np.median(list(report.values())) <= 1e-3 and max(report.values()) <= 2e-2, {k: "%.1e" % v for k, v in report.items() if v > 1e-3}
     dz, gz = r.network_backward(pts, dirs, np.zeros_like(draw), 0)
     assert float(dz.abs().max()) == 0.0 and all(float(v.abs().max()) == 0.0 for v in gz.values())
+    # a colour-independent context (round 5): its packed streams carry the identity in place of the unused feature / view layers, so the same fused backward runs — the
+    # stand-ins get zeros, the radiance heads read the trunk's output (tests/test_gpu_training.py pins the gradients against the reference's loss.backward())
     ci = R.Renderer(64, 0, max_rays_per_launch=64, color_independent_to_direction=True)
     ci.load_weights(0, sd)
+    _, gci = ci.network_backward(pts, dirs, draw, 0)
+    assert all(float(gci[k].abs().max()) == 0.0 for k in ("feature_linear.weight", "feature_linear.bias", "views_linears.0.weight", "views_linears.0.bias"))
+    assert float(gci["radiance_linear.weight"].abs().max()) > 0 and float(gci["positions_linears.0.weight"].abs().max()) > 0
+    cib = R.Renderer(64, 0, max_rays_per_launch=64, color_independent_to_direction=True, mlp_precision="bf16x3")      # (no f16x3 stream, no fp32 state dict: refused)
+    cib.load_weights(0, sd)
     from ibl_nerf_amd.binding import IblNerfError
     with pytest.raises(IblNerfError):
-        ci.network_backward(pts, dirs, draw, 0)
+        cib.network_backward(pts, dirs, draw, 0)
 
 
 def test_lazy_loss_scaling_never_synchronises_and_skips_an_overflowed_step(R, lut):
