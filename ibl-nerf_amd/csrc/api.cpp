@@ -117,6 +117,7 @@ struct iblnerf_ctx {
     unsigned long long* tier_mask = nullptr;      // [ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers)
     float tier_tau = 0.0f;                        // ... their threshold on T_s dist_s |depth - z_s| (iblnerf_set_offset_tier_threshold; 0 = no tiers, the default)
     bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
+    float tmin_main = COARSE_SELECT_TMIN, tmin_offsets = OFFSET_SELECT_TMIN, tmin_chunk = CHUNK_TMIN;     // iblnerf_set_select_tmin
     bool ci_embedded[2] = {false, false};          // colour-independent context: slot's packed streams carry the identity in place of the feature / view layers
     double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
@@ -1410,6 +1411,7 @@ static bool density_fp32(const iblnerf_ctx* c, int which) { return which < 2 && 
 
 static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, bool keep_all_rows) {
     QueryPlan q;
+    q.t_min = c->tmin_main;
     const bool can_decide = c->deciding && !keep_all_rows;
     const bool list_ok = lists_possible(c, which, keep_all_rows);
     const int prec = c->opt.mlp_precision;
@@ -1455,7 +1457,7 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
     const bool coarse_grid = kind != PASS_FINE;
     const int qclass = coarse_grid ? Q_OFFSET_COARSE : Q_OFFSET_FINE;
     const bool tilt = c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION_EPSILON;
-    q.t_min = OFFSET_SELECT_TMIN;
+    q.t_min = c->tmin_offsets;
     if (c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT || c->opt.normal_mode == IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION) {
         q.gradient = true;
         q.whole = pick_kernel(c, which, VAR_TRUNK_GRAD, qclass, false);
@@ -1519,6 +1521,7 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
 
 static QueryPlan plan_reflected(const iblnerf_ctx* c, int which, bool keep_all_rows) {
     QueryPlan q;
+    q.t_min = c->tmin_main;
     const int Sc = c->Sc;
     q.whole = pick_kernel(c, which, VAR_REFL, Q_REFL, false);
     q.est = pick_kernel(c, which, VAR_TRUNK, Q_ESTIMATE, false);
@@ -1607,7 +1610,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
     bool est_counted = false;
     int rc;
     if (q.list) {
-        if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, false, 0.f, p.noise, q.cut0, q.cut1, CHUNK_TMIN, FLOP_FULL);
+        if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, false, 0.f, p.noise, q.cut0, q.cut1, c->tmin_chunk, FLOP_FULL);
         else {
             MlpCall m;
             m.pts = c->pts; m.pts_per_ray = S; m.n_pts = n; m.out = c->sig4; m.flop_per_point = FLOP_FULL;
@@ -1657,7 +1660,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
             // transmittance of 1e-8 carries — with everything behind it — a weight below 1e-8.  The rest is compacted, evaluated and scattered over raw[..., 0].
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
             c->sel_candidates += n;
-            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->raw, RAW_CH, p.noise, R, S, c->margin[which], COARSE_SELECT_TMIN, c->sel_pts, c->sel_index,
+            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->raw, RAW_CH, p.noise, R, S, c->margin[which], c->tmin_main, c->sel_pts, c->sel_index,
                                             c->sel_count, s, false, 0.f, nullptr, 0, FLOP_TRUNK, c->main_range, nullptr, list_slots(q.density)));
             if (!c->sel_decided) {     // (the probe, in a mode whose main query takes no list)
                 long n_sel = 0;
@@ -1702,20 +1705,20 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         for (int tier = q.tiers ? 1 : 0; tier >= 0; --tier) {
             const Launch& k = (q.tiers && tier == 1) ? q.on_list_precise : q.on_list;
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count, s,
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], c->tmin_chunk, eps, c->sel_pts, c->sel_index, c->sel_count, s,
                                            FLOP_TRUNK, list_slots(k), true, q.tiers ? c->tier_mask : nullptr, tier));
             if ((rc = run_launch(c, s, k, which, refine))) return rc;
         }
         // 2, 3: estimates in front of it, and behind it where a copy is still alive
         for (int mode = 2; mode <= 3; ++mode) {
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, c->margin[which], CHUNK_TMIN, eps, c->sel_pts, c->sel_index, c->sel_count,
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, c->margin[which], c->tmin_chunk, eps, c->sel_pts, c->sel_index, c->sel_count,
                                            s, FLOP_TRUNK, list_slots(q.est), false));
             if ((rc = run_launch(c, s, q.est, which, est))) return rc;
         }
         c->flop_alg += (double)n4 * FLOP_TRUNK;
     } else if (q.cut1 > 0) {
-        if ((rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, true, eps, nullptr, q.cut0, q.cut1, CHUNK_TMIN, FLOP_TRUNK))) return rc;
+        if ((rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, true, eps, nullptr, q.cut0, q.cut1, c->tmin_chunk, FLOP_TRUNK))) return rc;
     } else {
         MlpCall m;
         m.pts_per_ray = S; m.n_pts = n4; m.out = c->sig4; m.gen = &g;
@@ -1783,7 +1786,7 @@ static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R,
         return run_launch(c, s, q.whole, which, m);
     }
     int rc;
-    if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, q.cut0, q.cut1, CHUNK_TMIN, FLOP_REFL);
+    if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, q.cut0, q.cut1, c->tmin_chunk, FLOP_REFL);
     else {
         m.pts = c->pts; m.out = c->sig4; m.flop_per_point = FLOP_REFL;
         rc = run_launch(c, s, q.est, which, m);
@@ -1867,7 +1870,7 @@ static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const fl
         est_ran = true;
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += n;
-        HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, c->margin[0], COARSE_SELECT_TMIN, c->sel_pts, c->sel_index, c->sel_count, s,
+        HIP_TRY(c, launch_select_points(ro, rd, zc, zcs, c->sig4, 1, noise, R, Sc, c->margin[0], c->tmin_main, c->sel_pts, c->sel_index, c->sel_count, s,
                                         false, 0.f, nullptr, 0, FLOP_TRUNK, nullptr, nullptr, list_slots(p15), c->sel_est));
         if (!c->sel_decided) {      // (the probe: this is also where a checkpoint's refinement decision is taken when no full coarse pass ever runs)
             long n_sel = 0;
@@ -2124,6 +2127,14 @@ int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
     double on_lists = 0.0;
     HIP_TRY(c, hipMemcpy(&on_lists, c->sel_count + 4, sizeof on_lists, hipMemcpyDeviceToHost));
     *flop_executed = c->flop_exec + on_lists;
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_select_tmin(iblnerf_ctx* c, float t_main, float t_offsets, float t_chunk) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!(t_main > 0.f && t_main < 1.f && t_offsets > 0.f && t_offsets < 1.f && t_chunk > 0.f && t_chunk < 1.f))
+        return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must lie in (0, 1)");
+    c->tmin_main = t_main; c->tmin_offsets = t_offsets; c->tmin_chunk = t_chunk;
     return IBLNERF_OK;
 }
 
