@@ -106,6 +106,116 @@ def scale_activations(sd, t, color_independent=False):
     return out
 
 
+def arch_schema(D=8, W=256, multires=10, multires_views=4):
+    """(name, out, in) of IBLNeRF(D, W, input_ch = 3 + 6 multires, input_ch_views = 3 + 6 multires_views, skips=[4], coarse_radiance_number=3) in registration order
+    (ibl_nerf.py:45-72; create_IBLNeRF fixes skips = [4], :265: positions_linears.5 takes cat([x, h]) when it exists, i.e. for D >= 6)."""
+    ch, chv = 3 + 6 * multires, 3 + 6 * multires_views
+    sch = [("positions_linears.0", W, ch)] + [("positions_linears.%d" % (i + 1), W, W + ch if i == 4 else W) for i in range(D - 1)]
+    sch += [("views_linears.0", W, chv + W), ("feature_linear", W, W), ("sigma_linear", 1, W), ("albedo_feature_linear", W // 2, W), ("albedo_linear", 3, W // 2),
+            ("roughness_linear", 1, W), ("irradiance_feature_linear", W // 2, W), ("irradiance_linear", 1, W // 2), ("radiance_linear", 3, W)]
+    sch += [("additional_radiance_feature_linear.%d" % i, W // 2, W) for i in range(3)] + [("additional_radiance_linear.%d" % i, 3, W // 2) for i in range(3)]
+    return tuple(sch)
+
+
+def arch_of(sd):
+    """(D, W, multires, multires_views) of an IBLNeRF state dict, from its shapes."""
+    shp = lambda k: tuple(int(v) for v in sd[k].shape)
+    W, ch = shp("positions_linears.0.weight")
+    D = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("positions_linears.") and k.endswith(".weight"))
+    chv = shp("views_linears.0.weight")[1] - W
+    if (ch - 3) % 6 or (chv - 3) % 6:
+        raise ValueError("not a positional-encoding width: input_ch %d, input_ch_views %d" % (ch, chv))
+    return D, W, (ch - 3) // 6, (chv - 3) // 6
+
+
+SHIPPED_ARCH = (8, 256, 10, 4)
+
+
+def synthetic_arch_state_dict(seed, arch, gain=1.0, sigma_bias=0.3):
+    """synthetic_state_dict for IBLNeRF(*arch): same stream discipline (U(-g / sqrt(fan_in), g / sqrt(fan_in)) per tensor in registration order)."""
+    rng = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name, out_f, in_f in arch_schema(*arch):
+        bound = gain / np.sqrt(in_f)
+        sd[name + ".weight"] = rng.uniform(-bound, bound, size=(out_f, in_f)).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-bound, bound, size=(out_f,)).astype(np.float32)
+    sd["sigma_linear.bias"][:] = np.float32(sigma_bias)
+    return sd
+
+
+def embed_architecture(sd):
+    """A SMALLER IBLNeRF as a member of the built architecture (D = 8, W = 256, multires 10 / 4): the same function, exactly.
+      narrower layers (W < 256, W // 2 < 128): zero rows and columns — an absent unit is a unit that outputs relu(0) = 0 and is read with weight 0;
+      fewer frequencies (multires < 10, multires_views < 4): the encoding [x, sin 2^0 x, cos 2^0 x, sin 2^1 x, ...] of the smaller network is a PREFIX of the built one's
+        (positional_embedder.py:21-34): zero columns for the frequencies it does not have;
+      fewer trunk layers (D < 8): identity layers behind the last one — the trunk's activations are >= 0 after their ReLU, so relu(I h + 0) = h; positions_linears.5
+        = [0 | I] when the smaller network has no skip layer of its own (D < 6; D = 5 does not exist in the reference: its forward concatenates behind the last layer).
+    Products with 0 and 1 and sums with 0 are exact in every product scheme of the kernels and in fp32, so the embedded network's outputs are the smaller network's to
+    the scheme's own precision.  Not embeddable (ValueError): D > 8 or D == 5, W > 256, multires > 10, multires_views > 4.  numpy arrays or torch tensors in, same kind out
+    (the reference's key order).  A state dict of the built shape is returned as it is."""
+    D, W, L, Lv = arch_of(sd)
+    if (D, W, L, Lv) == SHIPPED_ARCH:
+        return sd
+    if D > 8 or D == 5 or D < 1 or W > 256 or W < 2 or L > 10 or Lv > 4 or L < 0 or Lv < 0:
+        raise ValueError("IBLNeRF(D=%d, W=%d, multires=%d, multires_views=%d) is not a member of the built architecture (D <= 8 and != 5, W <= 256, multires <= 10, "
+                         "multires_views <= 4)" % (D, W, L, Lv))
+    small = arch_schema(D, W, L, Lv)
+    for name, o, i in small:
+        if tuple(int(v) for v in sd[name + ".weight"].shape) != (o, i):
+            raise ValueError("%s.weight has shape %s, IBLNeRF(D=%d, W=%d, ...) has (%d, %d)" % (name, tuple(sd[name + ".weight"].shape), D, W, o, i))
+    like = sd["positions_linears.0.weight"]
+    zeros = (lambda *sh: np.zeros(sh, dtype=np.float32)) if isinstance(like, np.ndarray) else (lambda *sh: like.new_zeros(sh))
+    ch, chv, H = 3 + 6 * L, 3 + 6 * Lv, W // 2
+    out = OrderedDict()
+    for name, o, i in SCHEMA:
+        out[name + ".weight"], out[name + ".bias"] = zeros(o, i), zeros(o)
+
+    def put(name, rows, blocks):
+        """blocks: (destination column, source column, width)"""
+        w = sd[name + ".weight"].detach() if hasattr(sd[name + ".weight"], "detach") else sd[name + ".weight"]
+        for dc, sc, n in blocks:
+            out[name + ".weight"][:rows, dc:dc + n] = w[:, sc:sc + n]
+        out[name + ".bias"][:rows] = sd[name + ".bias"].detach() if hasattr(sd[name + ".bias"], "detach") else sd[name + ".bias"]
+
+    P = "positions_linears.%d"
+    put(P % 0, W, [(0, 0, ch)])
+    for l in range(1, 8):
+        if l < D:
+            put(P % l, W, [(0, 0, ch), (63, ch, W)] if l == 5 else [(0, 0, W)])
+        else:      # an identity layer: relu(h) = h for h >= 0
+            c0 = 63 if l == 5 else 0
+            for u in range(W):
+                out[(P % l) + ".weight"][u, c0 + u] = 1.0
+    put("views_linears.0", W, [(0, 0, W), (256, W, chv)])
+    put("feature_linear", W, [(0, 0, W)])
+    for name, rows, width in (("sigma_linear", 1, W), ("albedo_feature_linear", H, W), ("albedo_linear", 3, H), ("roughness_linear", 1, W),
+                              ("irradiance_feature_linear", H, W), ("irradiance_linear", 1, H), ("radiance_linear", 3, W)):
+        put(name, rows, [(0, 0, width)])
+    for k in range(3):
+        put("additional_radiance_feature_linear.%d" % k, H, [(0, 0, W)])
+        put("additional_radiance_linear.%d" % k, 3, [(0, 0, H)])
+    return out
+
+
+def unembed_gradients(grads, arch):
+    """The gradients of embed_architecture's input from those of its output: the sub-blocks the smaller network's parameters were written to."""
+    D, W, L, Lv = arch
+    ch, chv, H = 3 + 6 * L, 3 + 6 * Lv, W // 2
+    out = OrderedDict()
+    for name, o, i in arch_schema(D, W, L, Lv):
+        g = grads[name + ".weight"]
+        if name == "positions_linears.5":
+            w = g[:o, :ch].new_zeros((o, i)) if hasattr(g, "new_zeros") else np.zeros((o, i), np.float32)
+            w[:, :ch], w[:, ch:] = g[:o, :ch], g[:o, 63:63 + W]
+        elif name == "views_linears.0":
+            w = g[:o, :W].new_zeros((o, i)) if hasattr(g, "new_zeros") else np.zeros((o, i), np.float32)
+            w[:, :W], w[:, W:] = g[:o, :W], g[:o, 256:256 + chv]
+        else:
+            w = g[:o, :i]
+        out[name + ".weight"], out[name + ".bias"] = w, grads[name + ".bias"][:o]
+    return out
+
+
 # Auxiliary PositionMLPs (src/networks/MLP.py:6-30, ibl_nerf.py:312-326): the main network's trunk shape + out_linears
 AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1, "normal_mlp": 3}
 TRUNK_SCHEMA = tuple(e for e in SCHEMA if e[0].startswith("positions_linears."))

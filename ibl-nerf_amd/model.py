@@ -21,19 +21,32 @@ class IBLNeRF:
 
     def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), coarse_radiance_number=3,
                  is_color_independent_to_direction=False, **_ignored):
-        if (D, W, input_ch, input_ch_views, tuple(skips), coarse_radiance_number) != (8, 256, 63, 27, (4,), 3):
-            raise NotImplementedError("the HIP path is built for the shipped architecture: D=8, W=256, multires=10, "
-                                      "multires_views=4, skips=[4], coarse_radiance_number=3")
+        # The kernels are built for D=8, W=256, multires 10 / 4; a SMALLER network is evaluated as the member of that architecture computing the same function
+        # (checkpoint.embed_architecture, applied at upload): D <= 8 (not 5: the reference's own forward fails there), W <= 256, multires <= 10, multires_views <= 4.
+        ok = (tuple(skips) == (4,) and coarse_radiance_number == 3 and 1 <= D <= 8 and D != 5 and 2 <= W <= 256 and 3 <= input_ch <= 63 and (input_ch - 3) % 6 == 0
+              and 3 <= input_ch_views <= 27 and (input_ch_views - 3) % 6 == 0)
+        if not ok:
+            raise NotImplementedError("the HIP path is built for D=8, W=256, multires=10, multires_views=4, skips=[4], coarse_radiance_number=3 and evaluates smaller "
+                                      "networks (D <= 8 and != 5, W <= 256, multires <= 10, multires_views <= 4) inside it; got D=%d, W=%d, input_ch=%d, "
+                                      "input_ch_views=%d, skips=%s, coarse_radiance_number=%d" % (D, W, input_ch, input_ch_views, list(skips), coarse_radiance_number))
+        self.arch = (int(D), int(W), (int(input_ch) - 3) // 6, (int(input_ch_views) - 3) // 6)
         self.is_color_independent_to_direction = bool(is_color_independent_to_direction)   # ibl_nerf.py:75, :192
         self.coarse_radiance_number = coarse_radiance_number
-        self._sd = ck.synthetic_state_dict(seed=0)       # placeholder values until load_state_dict
+        self._sd = ck.synthetic_state_dict(seed=0) if self.arch == ck.SHIPPED_ARCH else ck.synthetic_arch_state_dict(0, self.arch)       # placeholder values until load_state_dict
         self._version = 0
 
     def state_dict(self):
         return OrderedDict(self._sd)
 
     def load_state_dict(self, sd):
-        self._sd = ck.blob_to_state_dict(ck.state_dict_to_blob(sd))   # validates names and shapes
+        if self.arch == ck.SHIPPED_ARCH:
+            self._sd = ck.blob_to_state_dict(ck.state_dict_to_blob(sd))   # validates names and shapes
+        else:
+            sd = OrderedDict((k, np.array(ck._to_numpy(v), dtype=np.float32)) for k, v in sd.items())
+            if ck.arch_of(sd) != self.arch:
+                raise ValueError("state dict of IBLNeRF%s loaded into IBLNeRF%s" % (ck.arch_of(sd), self.arch))
+            ck.embed_architecture(sd)                                  # validates names and shapes
+            self._sd = OrderedDict((n + t, sd[n + t]) for n, _, _ in ck.arch_schema(*self.arch) for t in (".weight", ".bias"))
         self._version += 1
         for v in self._sd.values():
             v.setflags(write=False)
@@ -342,16 +355,19 @@ def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):
 def create_IBLNeRF(args):
     """ibl_nerf.py:255-428.  Returns (render_kwargs_train, render_kwargs_test, start, elapsed_time,
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
-    if args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
-        raise NotImplementedError("embedders other than multires=10 / multires_views=4 are not built")
+    if not (0 <= args.multires <= 10 and 0 <= args.multires_views <= 4) or args.i_embed != 0:
+        raise NotImplementedError("the kernels' positional encoding is built for multires <= 10 / multires_views <= 4 (i_embed = 0); fewer frequencies run inside it")
+    if (getattr(args, "infer_depth", False) or getattr(args, "infer_visibility", False) or any(getattr(args, f, False) for f in
+            ("infer_albedo_separate", "infer_roughness_separate", "infer_irradiance_separate", "infer_normal"))) and (args.netdepth, args.netwidth, args.multires, args.multires_views) != ck.SHIPPED_ARCH:
+        raise NotImplementedError("auxiliary networks (PositionMLP / PositionDirectionMLP) are built for netdepth=8, netwidth=256, multires=10, multires_views=4")
     # ibl_nerf.py:292-304: both are PositionDirectionMLPs; render_rays only ever evaluates the depth_mlp (:722-726)
     depth_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_depth", False) else None
     visibility_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_visibility", False) else None
     aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, out_ch=out_ch) if getattr(args, flag, False) else None)
            for name, flag, out_ch in (("albedo_mlp", "infer_albedo_separate", 3), ("roughness_mlp", "infer_roughness_separate", 1),
                                       ("irradiance_mlp", "infer_irradiance_separate", 1), ("normal_mlp", "infer_normal", 3))}   # ibl_nerf.py:307-326
-    mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, coarse_radiance_number=args.coarse_radiance_number,
-                         is_color_independent_to_direction=args.color_independent_to_direction)
+    mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, input_ch=3 + 6 * args.multires, input_ch_views=3 + 6 * args.multires_views,
+                         coarse_radiance_number=args.coarse_radiance_number, is_color_independent_to_direction=args.color_independent_to_direction)
     model = mk()
     model_fine = mk() if args.N_importance > 0 else None
     start, elapsed = 0, 0

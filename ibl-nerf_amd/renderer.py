@@ -177,6 +177,10 @@ class Renderer:
     def _upload(self, which, state_dict_or_blob, remember):
         torch = _torch()
         blob = state_dict_or_blob
+        if isinstance(blob, dict) and blob:
+            # a smaller IBLNeRF (netdepth / netwidth / multires / multires_views below the built 8 / 256 / 10 / 4) is uploaded as the member of the built architecture
+            # that computes the same function (checkpoint.embed_architecture: zero units, zero frequency columns, identity layers); a built-shape dict passes through
+            blob = ck.embed_architecture(blob)
         if isinstance(blob, dict) and blob and all(torch.is_tensor(v) and v.is_cuda for v in blob.values()):
             ck.check_schema(blob)
             blob = torch.cat([v.detach().reshape(-1).to(torch.float32) for v in blob.values()])

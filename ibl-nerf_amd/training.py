@@ -432,10 +432,19 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
         raise NotImplementedError("a training step reads the coarse pass's maps: coarse_outputs=True")
     flags = _flags(r)
     named = [dict(net.named_parameters()) for net in (net_c, net_f)]
-    for nm in named:
-        if set(nm) != set(ALL_PARAMS):
-            raise NotImplementedError("the fused backward is built for the shipped IBLNeRF architecture (46 parameters per network)")
-    params = [nm[k] for nm in named for k in ALL_PARAMS]
+    # smaller architectures run inside the built one (checkpoint.embed_architecture at upload): their gradients are the sub-blocks their parameters were written to
+    try:
+        archs = [ck.arch_of(nm) for nm in named]
+    except (KeyError, ValueError):
+        archs = [None, None]
+    pnames = []
+    for nm, arch in zip(named, archs):
+        want = None if arch is None else [n + t for n, _, _ in ck.arch_schema(*arch) for t in (".weight", ".bias")]
+        if want is None or set(nm) != set(want) or arch[0] > 8 or arch[0] == 5 or arch[1] > 256 or arch[2] > 10 or arch[3] > 4:
+            raise NotImplementedError("the fused backward is built for the IBLNeRF architecture (46 parameters per network at netdepth 8; netdepth <= 8 and != 5, "
+                                      "netwidth <= 256, multires <= 10, multires_views <= 4)")
+        pnames.append([k for k in ALL_PARAMS if k in nm])
+    params = [nm[k] for nm, ks in zip(named, pnames) for k in ks]
     ci = bool(r.opt.color_independent_to_direction)      # (the context's streams carry the identity in place of the unused layers: iblnerf_network_backward)
     frozen = [bool(getattr(net, "freeze_radiance", False)) for net in (net_c, net_f)]
     frozen_rough = [bool(getattr(net, "freeze_roughness", False)) for net in (net_c, net_f)]
@@ -597,7 +606,9 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                     grads = {k: grads[k] + g2[k] for k in grads}
                 if getattr(r, "last_backward_ok", None) is not None:
                     oks.append(r.last_backward_ok)
-                for k in ALL_PARAMS:
+                if archs[which] != ck.SHIPPED_ARCH:
+                    grads = ck.unembed_gradients(grads, archs[which])
+                for k in pnames[which]:
                     gk = grads[k]
                     if frozen[which] and not (k.startswith(UNFROZEN) and not (frozen_rough[which] and k.startswith("roughness_linear."))):
                         gk = None                                        # h is computed under no_grad: nothing reaches the trunk / view layers

@@ -106,14 +106,16 @@ COLOR_INDEPENDENT = False   # is_color_independent_to_direction (ibl_nerf.py:192
 
 
 def mlp_forward(sd, e_pts, e_dirs=None, color_independent=None):
-    """e_pts [P,63]; e_dirs [P,27] or None.  Returns [P,18], or [P,1] (sigma) if e_dirs is None."""
+    """e_pts [P,63]; e_dirs [P,27] or None.  Returns [P,18], or [P,1] (sigma) if e_dirs is None.
+    Any IBLNeRF(D, W, input_ch, input_ch_views, skips=[4]) (ibl_nerf.py:14-60): the depth is read off the state dict, the widths off its shapes."""
     if color_independent is None:
         color_independent = COLOR_INDEPENDENT
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("positions_linears.") and k.endswith(".weight"))
     h = e_pts
-    for i in range(8):
+    for i in range(depth):
         h = relu(_lin(sd, "positions_linears.%d" % i, h))
-        if i == 4:
-            h = np.concatenate([e_pts, h], -1)                         # :168 skip order [x63, h]
+        if i == 4 and depth > 5:
+            h = np.concatenate([e_pts, h], -1)                         # :168 skip order [x63, h] (skips = [4], ibl_nerf.py:265; for D = 5 the reference's own forward fails)
     sigma = _lin(sd, "sigma_linear", h)
     if e_dirs is None:
         return sigma                                                   # :175-176 early return
@@ -137,11 +139,13 @@ def network_query(sd, pts, viewdirs):
     pts [N,S,3]; viewdirs [N,3] (expanded over the S samples) or None."""
     pts = np.asarray(pts, dtype=F32)
     N, S, _ = pts.shape
-    e = embed(pts.reshape(-1, 3), 10)
+    n_freq = (sd["positions_linears.0.weight"].shape[1] - 3) // 6                                 # multires (10 in every shipped config)
+    e = embed(pts.reshape(-1, 3), n_freq)
     if viewdirs is None:
         return mlp_forward(sd, e).reshape(N, S, 1)
+    n_freq_views = (sd["views_linears.0.weight"].shape[1] - sd["views_linears.0.weight"].shape[0] - 3) // 6     # multires_views (4)
     d = np.broadcast_to(np.asarray(viewdirs, dtype=F32)[:, None, :], pts.shape).reshape(-1, 3)
-    return mlp_forward(sd, e, embed(d, 4)).reshape(N, S, 18)
+    return mlp_forward(sd, e, embed(d, n_freq_views)).reshape(N, S, 18)
 
 
 def position_mlp_query(aux_sd, pts):

@@ -51,11 +51,11 @@ def import_reference():
     return torch, R, M, Hh
 
 
-def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False, infer_normal=False, infer_depth=False):
-    """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt."""
+def reference_args(tmp, n_importance, n_samples=64, color_independent=False, aux=False, infer_normal=False, infer_depth=False, arch=(8, 256, 10, 4)):
+    """Effective flag values of configs/IBL-NeRF/kitchen/IBL-NeRF.txt.  arch = (netdepth, netwidth, multires, multires_views)."""
     os.makedirs(os.path.join(tmp, "exp"), exist_ok=True)
     return SimpleNamespace(
-        multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, N_samples=n_samples,
+        multires=arch[2], multires_views=arch[3], i_embed=0, netdepth=arch[0], netwidth=arch[1], N_samples=n_samples,
         N_importance=n_importance, netchunk=65536, coarse_radiance_number=3,
         color_independent_to_direction=color_independent, use_illumination_feature_layer=False,
         use_instance_feature_layer=False, device="cpu", infer_depth=infer_depth, infer_visibility=False,
@@ -291,14 +291,16 @@ def fitted_state_dicts(which="fitted"):
 
 def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mode="plain", n_keep=6, flags=None,
                 n_samples=64, near=0.5, far=8.0, posed=False, color_independent=False, aux=False, infer_normal=False,
-                fitted=False, record_floor=False, infer_depth=False, perturb=False, raw_noise_std=0.0, autograd=False):
+                fitted=False, record_floor=False, infer_depth=False, perturb=False, raw_noise_std=0.0, autograd=False, arch=None):
     tmp = tempfile.mkdtemp()
     try:
-        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal, infer_depth))
+        _, kw, *_ = M.create_IBLNeRF(reference_args(tmp, n_importance, n_samples, color_independent, aux, infer_normal, infer_depth, arch=arch or ck.SHIPPED_ARCH))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     sd_c = ck.synthetic_state_dict(seed=2 * seed, gain=gain)
     sd_f = ck.synthetic_state_dict(seed=2 * seed + 1, gain=gain)
+    if arch is not None:      # a smaller IBLNeRF (netdepth, netwidth, multires, multires_views): the reference builds and runs it as such
+        sd_c, sd_f = ck.synthetic_arch_state_dict(2 * seed, arch, gain), ck.synthetic_arch_state_dict(2 * seed + 1, arch, gain)
     if fitted:                                   # the surface-bearing checkpoint instead of a random-init one
         sd_c, sd_f = fitted_state_dicts()
     n_keep = min(n_keep, n_rays)
@@ -435,9 +437,11 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(near), far=np.float32(far),
                gain=np.float64(gain), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1),
                n_importance=np.int64(n_importance), n_samples=np.int64(n_samples),
-               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))),
-               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_c)))),
+               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_f)))),
                mode=np.array(mode))
+    if arch is not None:
+        out["arch"] = np.asarray(arch, dtype=np.int64)
     for k, v in (flags or {}).items():
         out["flag__" + k] = np.asarray(v)
     if fitted:
@@ -571,7 +575,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
 
 
 def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=(), override=None,
-                       color_independent=False, planes=False, aux=False, stable_rays=False, incident_gradient=False):
+                       color_independent=False, planes=False, aux=False, stable_rays=False, incident_gradient=False, arch=None):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -588,7 +592,7 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     views_linears are unused and get no gradient) — the fitted checkpoint's weights taken as such a network's."""
     tmp = tempfile.mkdtemp()
     try:
-        kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128, aux=aux, infer_normal=aux))      # [0] = render_kwargs_train
+        kw, _, *_ = M.create_IBLNeRF(reference_args(tmp, 128, aux=aux, infer_normal=aux, arch=arch or ck.SHIPPED_ARCH))      # [0] = render_kwargs_train
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     assert kw["perturb"] == 1.0
@@ -601,6 +605,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
         # "one of the variables needed for gradient computation has been modified by an inplace operation ... output 0 of ReluBackward0")
         assert kw["infer_normal"] is True
     sd_c, sd_f = fitted_state_dicts()
+    if arch is not None:      # a smaller IBLNeRF (netdepth, netwidth, multires, multires_views) with seeded weights: there is no fitted checkpoint of that shape
+        sd_c, sd_f = ck.synthetic_arch_state_dict(8100, arch, 1.5), ck.synthetic_arch_state_dict(8101, arch, 1.5)
     kw["network_fn"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_c.items()})
     kw["network_fine"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
     kw.update(near=0.5, far=8.0, pytest=True)
@@ -659,8 +665,8 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
             crit = np.flatnonzero(cap["margin"] < 3e-6)
             if not len(crit):
                 break
-            o2, d2, pix2, _ = camera_rays(rng, len(crit))
-            o[crit], d[crit], pix[crit] = o2, d2, pix2
+            o2, d2, pix2, _ = camera_rays(rng, len(crit) + 4)      # (camera_rays pins its first four rays to the frame's corners)
+            o[crit], d[crit], pix[crit] = o2[4:], d2[4:], pix2[4:]
         else:
             raise RuntimeError("stable_rays: still threshold-critical rays after 12 rounds")
         stable_margin = float(cap["margin"].min())
@@ -683,8 +689,10 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
     if aux:
         tg.update(TL.aux_targets(rng, n_rays))
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=plane_near if planes else np.float32(0.5), far=plane_far if planes else np.float32(8.0), chunk=np.int64(n_rays),
-               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_c))), ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(sd_f))),
-               ckpt=np.array("fitted"))
+               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_c)))),
+               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_f)))), ckpt=np.array("fitted" if arch is None else "arch"))
+    if arch is not None:
+        out["arch"] = np.asarray(arch, dtype=np.int64)
     for k, v in tg.items():
         out["target__" + k] = v
     for k, v in beta.items():
@@ -1097,6 +1105,8 @@ def main(only=None):
         train_step_fixture(torch, R, M, lut, fixture="train_step_aux", phases=("warmup", "full"), aux=True, stable_rays=True)
     if not only or "train_step_incident" in only:   # f-3 leftover (round 5): use_gradient_for_incident_radiance
         train_step_fixture(torch, R, M, lut, fixture="train_step_incident", phases=("full", "frozen"), incident_gradient=True)
+    if not only or "train_step_arch" in only:       # round 5: a training step of a smaller architecture (evaluated inside the built one; gradients = sub-blocks)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_arch", phases=("warmup", "full"), arch=(6, 128, 6, 2), stable_rays=True)
     if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
         train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
@@ -1137,6 +1147,11 @@ def main(only=None):
     run_fixture("variant_small_g10", torch, R, M, lut, n_rays=96, n_importance=48, gain=1.0, seed=6, n_samples=32,
                 near=1.0, far=5.0, posed=True,
                 flags=dict(epsilon=0.02, gamma_correct=False, correct_depth_for_prefiltered_radiance_infer=False))
+    # smaller architectures (round 5; ibl_nerf.py:14-60 takes any netdepth / netwidth, config_parser.py any multires / multires_views): the reference builds and runs them
+    # as such; this library evaluates them inside the built 8 x 256 / 10 / 4 architecture (checkpoint.embed_architecture).
+    run_fixture("arch_6x128_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=21, arch=(6, 128, 6, 2))       # own skip layer, fewer frequencies
+    run_fixture("arch_4x64_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, arch=(4, 64, 10, 4))        # no skip layer: four identity layers
+    run_fixture("arch_7x200_g10", torch, R, M, lut, n_rays=48, n_importance=64, gain=1.0, seed=23, arch=(7, 200, 8, 3), mode="insert")     # odd width, one identity layer, insert overrides
     # is_color_independent_to_direction (ibl_nerf.py:192): radiance heads on the trunk output, no feature / view layers
     run_fixture("colorindep_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=8, color_independent=True)
     # ground-truth normals instead of the eps-normal (no offset queries)

@@ -512,6 +512,46 @@ def test_training_step_with_auxiliary_networks(lut, phase):
     assert sum(v > lim(k) for k, v in worst.items()) <= 3, {k: v for k, v in worst.items() if v > lim(k)}
 
 
+@pytest.mark.parametrize("phase", ["warmup", "full"])
+def test_training_step_of_a_smaller_architecture(lut, phase):
+    """Round 5: IBLNeRF(netdepth=6, netwidth=128, multires=6, multires_views=2) — the reference takes any (ibl_nerf.py:14-60) — trained by a step on the fused path.  The
+    context holds the network EMBEDDED in the built architecture (checkpoint.embed_architecture: zero units, zero frequency columns, identity layers 6-7), the same
+    kernels run forward and backward, and the gradients of the module's own (small) parameters are the sub-blocks they were written to (unembed_gradients).  Fixture =
+    the reference's own loss.backward() on such a network (seeded weights, rays whose stochastic samples sit clear of a bin boundary): all 92 tensors, small shapes."""
+    import train_loss as TL
+    from torch_ref import RefShaped
+    from ibl_nerf_amd import renderer as R, checkpoint as ck
+    G = np.load(os.path.join(GOLDEN, "train_step_arch.npz"))
+    arch = tuple(int(v) for v in G["arch"])
+    sdc, sdf = ck.synthetic_arch_state_dict(8100, arch, 1.5), ck.synthetic_arch_state_dict(8101, arch, 1.5)
+    assert ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sdc))) == str(G["ck_coarse"])
+    nets = RefShaped(sdc, arch).cuda(), RefShaped(sdf, arch).cuda()
+    for net in nets:
+        net.coarse_radiance_number = 3
+    kw = dict(network_fn=nets[0], network_fine=nets[1], N_samples=64, N_importance=128, perturb=1.0, pytest=True, raw_noise_std=0.0,
+              brdf_lut=torch.from_numpy(lut).cuda(), lut_coefficient="F", gamma_correct=True, correct_depth_for_prefiltered_radiance_infer=True,
+              epsilon=0.01, target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_epsilon", use_radiance_linear=False,
+              lindisp=False, near=float(G["near"]), far=float(G["far"]))
+    f_ = np.float32(0.5 * 800 / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[f_, 0, 400], [0, f_, 400], [0, 0, 1]], dtype=np.float32)
+    rays = torch.from_numpy(np.stack([G["rays_o"], G["rays_d"]], 0)).cuda()
+    approx = phase == "full"
+    res = R.render_decomp(800, 800, K, chunk=int(G["chunk"]), rays=rays, gt_values={}, approximate_radiance=approx, **kw)
+    for k in ("radiance_map", "albedo_map", "irradiance_map", "roughness_map", "depth_map", "disp_map", "acc_map", "weights"):
+        for sfx in ("", "0"):
+            e = rel_linf(res[k + sfx].detach().cpu().numpy(), G["%s__out__%s" % (phase, k + sfx)])
+            assert e <= 1e-3, (k + sfx, e)
+    loss = TL.total_loss(torch, res, {k[8:]: G[k] for k in G.files if k.startswith("target__")}, approx)
+    assert abs(float(loss.detach()) - float(G[phase + "__loss"])) <= (3e-4 if approx else 2e-5) * float(G[phase + "__loss"])
+    loss.backward()
+    assert all(p.grad is not None and p.grad.shape == p.shape for net in nets for p in net.parameters())
+    worst, zero = _grads_against(G, phase, nets)
+    assert len(worst) == 2 * 2 * (6 + 15) and not zero, (len(worst), zero)
+    lim = lambda k: 5e-3 if (approx and "roughness_linear" in k) else (1.5e-3 if (approx and k.startswith("f.")) else 1e-3)
+    bad = {k: v for k, v in worst.items() if v > lim(k)}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("phase", ["warmup", "full", "depth"])
 def test_training_step_with_per_ray_planes(lut, phase):
     """f-3 leftover closed in round 5: per-ray near / far planes ([n, 1] tensors, ibl_nerf_renderer.py:802-805) in the renders of a training step — a z grid per ray

@@ -99,6 +99,42 @@ def test_render_rays_end_to_end(name, lut):
         assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
 
 
+@pytest.mark.parametrize("name", ["arch_6x128_g10", "arch_4x64_g10", "arch_7x200_g10"])
+def test_smaller_architectures_inside_the_built_one(name, lut):
+    """Round 5: the reference accepts any netdepth / netwidth / multires / multires_views (ibl_nerf.py:14-60, config_parser.py); the kernels are built for 8 / 256 / 10 / 4
+    and evaluate a SMALLER network as the member of that architecture that computes the same function (ibl-nerf_amd/checkpoint.py embed_architecture: zero units, zero
+    frequency columns, identity layers behind the last trunk layer).  Fixtures = the reference's own renders of IBLNeRF(6, 128, L=6 / 2), (4, 64, 10 / 4: no skip layer),
+    (7, 200, 8 / 3, insert overrides).  Here, on the CPU: the C restatement — which knows only the built shape — renders the EMBEDDED state dicts to the fixtures at the
+    bars of every other fixture, i.e. the embedding is exact in fp32; the numpy oracle renders the small networks as such (tests/test_oracle_golden.py)."""
+    from ibl_nerf_amd import checkpoint as ck
+    g, sdc, sdf, gt, edit = load_golden(name)
+    arch = tuple(int(v) for v in g["arch"])
+    assert ck.arch_of(sdc) == arch and arch != ck.SHIPPED_ARCH
+    big_c, big_f = ck.embed_architecture(sdc), ck.embed_architecture(sdf)
+    assert ck.arch_of(big_c) == ck.SHIPPED_ARCH and ck.embed_architecture(big_c) is big_c
+    res = OC.render_rays(big_c, big_f, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), lut, n_samples(g), int(g["n_importance"]), gt, edit, golden_flags(g))
+    assert sorted(res.keys()) == sorted(k[5:] for k in g.files if k.startswith("out__"))
+    for sfx in ("", "0"):
+        for k in DIRECT:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 5e-6 * (4 if sfx == "" else 1), (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+        for k in DERIVED:
+            assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= 6e-4, (k + sfx, rel_linf(res[k + sfx], g["out__" + k + sfx]))
+    # the gradients of the small network's parameters are sub-blocks of the embedded network's (training: checkpoint.unembed_gradients)
+    rng = np.random.RandomState(0)
+    gbig = {k: rng.randn(*v.shape).astype(np.float32) for k, v in big_c.items()}
+    gsmall = ck.unembed_gradients(gbig, arch)
+    assert list(gsmall) == list(sdc) and all(gsmall[k].shape == sdc[k].shape for k in sdc)
+    eps = {k: rng.randn(*v.shape).astype(np.float32) for k, v in sdc.items()}
+    moved = ck.embed_architecture({k: sdc[k] + eps[k] for k in sdc})
+    lhs = sum(float(np.sum((moved[k] - big_c[k]).astype(np.float64) * gbig[k])) for k in big_c)          # <embed(sd + eps) - embed(sd), G> = <eps, unembed(G)>
+    rhs = sum(float(np.sum(eps[k].astype(np.float64) * gsmall[k])) for k in sdc)
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    # what is not a member raises
+    for bad in ((9, 128, 10, 4), (5, 128, 10, 4), (8, 320, 10, 4), (8, 256, 11, 4)):
+        with pytest.raises(ValueError):
+            ck.embed_architecture(ck.synthetic_arch_state_dict(0, bad))
+
+
 @pytest.mark.parametrize("name", FITTED_FIXTURES)
 def test_fitted_checkpoint_end_to_end(name, lut):
     """The checkpoint with surfaces, all rays of every fixture (fitted_wide: 1 024 — the numpy oracle's test stops at 256)."""

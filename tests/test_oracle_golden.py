@@ -115,7 +115,7 @@ def test_render_rays_end_to_end(name, lut):
             assert rel_linf(res[k + sfx], g["out__" + k + sfx]) <= (5e-2 if wide else 6e-4), k + sfx
     if int(g["n_importance"]) > 0:
         assert rel_linf(res["z_std"], g["out__z_std"]) <= 5e-6
-        assert np.abs(st["z_samples"] - g["pdf_samples"]).max() <= 2e-5
+        assert np.abs(st["z_samples"] - g["pdf_samples"]).max() <= (4e-5 if name.startswith("arch_") else 2e-5)      # (a narrow random-init network's density is nearly flat: pdf ~1e-3, see below)
         # stage-wise (teacher-forced) sample_pdf on the reference's own inputs
         assert np.abs(O.sample_pdf(g["pdf_bins"], g["pdf_weights"], int(g["n_importance"])) - g["pdf_samples"]).max() <= 2e-5  # 1 ulp of cdf / pdf(~2e-3) * bin width
     for p in (["c", "f"] if int(g["n_importance"]) > 0 else ["c"]):

@@ -27,10 +27,11 @@ class AuxShaped(nn.Module):
 
 
 class RefShaped(nn.Module):
-    def __init__(self, sd=None):
+    def __init__(self, sd=None, arch=(8, 256, 10, 4)):
+        """arch = (netdepth, netwidth, multires, multires_views) (ibl_nerf.py:14-60 with skips = [4])"""
         super().__init__()
-        W, ch, chv = 256, 63, 27
-        self.positions_linears = nn.ModuleList([nn.Linear(ch, W)] + [nn.Linear(W + ch if i == 4 else W, W) for i in range(7)])
+        D, W, ch, chv = arch[0], arch[1], 3 + 6 * arch[2], 3 + 6 * arch[3]
+        self.positions_linears = nn.ModuleList([nn.Linear(ch, W)] + [nn.Linear(W + ch if i == 4 else W, W) for i in range(D - 1)])
         self.views_linears = nn.ModuleList([nn.Linear(chv + W, W)])
         self.feature_linear = nn.Linear(W, W)
         self.sigma_linear = nn.Linear(W, 1)
