@@ -693,8 +693,15 @@ def test_checkpoint_roundtrip_and_discovery():
     with tempfile.TemporaryDirectory() as d2:
         os.makedirs(os.path.join(d2, "exp"))
         assert M.create_IBLNeRF(M.default_args(basedir=d2, infer_normal=True))[1]["normal_mlp"].out_ch == 3
-    with pytest.raises(NotImplementedError):
-        M.IBLNeRF(W=128)
+    # a smaller architecture is a container of its own shapes (evaluated inside the built one at upload: checkpoint.embed_architecture); a larger one is refused
+    small = M.IBLNeRF(D=6, W=128, input_ch=39, input_ch_views=15)
+    assert small.arch == (6, 128, 6, 2) and ck.arch_of(small.state_dict()) == (6, 128, 6, 2)
+    small.load_state_dict(ck.synthetic_arch_state_dict(3, (6, 128, 6, 2)))
+    with pytest.raises(ValueError):
+        small.load_state_dict(ck.synthetic_state_dict(3))
+    for bad in (dict(W=512), dict(D=9), dict(D=5), dict(input_ch=69), dict(coarse_radiance_number=2), dict(skips=(3,))):
+        with pytest.raises(NotImplementedError):
+            M.IBLNeRF(**bad)
 
 
 def test_unsupported_flags_raise():
