@@ -575,7 +575,7 @@ def seam_fixture(name, torch, R, M, lut, kind, seed):
 
 
 def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases=("warmup", "full", "frozen", "depth"), raw_noise_std=0.0, from_gt=(), override=None,
-                       color_independent=False, planes=False, aux=False, stable_rays=False, incident_gradient=False, arch=None):
+                       color_independent=False, planes=False, aux=False, stable_rays=False, incident_gradient=False, arch=None, sparse_grads=False):
     """loss.backward() of a training step through the reference's own render_decomp (train.py:285-297, :326-441, :479-481) on the
     fitted checkpoint: render_kwargs_train (perturb = 1) with its pytest hook for deterministic draws, gradients enabled, and the losses of
     train.py that need no dataset: radiance (fine + coarse pass, :332), the three coarse radiances (:336-341), approximated radiance
@@ -731,6 +731,9 @@ def train_step_fixture(torch, R, M, lut, n_rays=64, fixture="train_step", phases
             for name, prm in net.named_parameters():
                 if tag in aux_seeds and name.endswith(".weight") and name.split(".")[1] in ("1", "2", "3", "4", "6"):
                     continue      # (an auxiliary network's fixture keeps every bias — each is the sum of its layer's dZ, so the whole dgrad chain is pinned — and the weights of layers 0, 5, 7 and out_linears)
+                if sparse_grads and tag in ("c", "f") and name.endswith(".weight") and prm.numel() > 40000 and name != "positions_linears.7.weight":
+                    continue      # (a variant's fixture: every bias — the sum of its layer's dZ: the whole dgrad chain — every head and 128-wide feature layer, the trunk's
+                    #               first and last weight; the weight-gradient GEMMs of the wide layers are pinned by train_step.npz, which keeps all 92 tensors)
                 out["%s__grad_%s__%s" % (phase, tag, name)] = (prm.grad.numpy().copy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32))
     for _, net in nets:
         net.freeze_radiance = net.freeze_roughness = False
@@ -1093,22 +1096,22 @@ def main(only=None):
         train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt", phases=("full",),
                            from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
     if not only or "train_step_from_gt_warmup" in only:   # f-3 leftover (round 5): the substitutions during the warm-up iterations (approximate_radiance=False)
-        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt_warmup", phases=("warmup",),
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt_warmup", phases=("warmup",), sparse_grads=True,
                            from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
     if not only or "train_step_edit" in only:       # f-3 leftover (round 5): edit / insert overrides inside a gradient-carrying render
-        train_step_fixture(torch, R, M, lut, fixture="train_step_edit", phases=("warmup", "full"), override="edit")
+        train_step_fixture(torch, R, M, lut, fixture="train_step_edit", phases=("warmup", "full"), override="edit", sparse_grads=True)
     if not only or "train_step_insert" in only:
-        train_step_fixture(torch, R, M, lut, fixture="train_step_insert", phases=("warmup", "full"), override="insert")
+        train_step_fixture(torch, R, M, lut, fixture="train_step_insert", phases=("warmup", "full"), override="insert", sparse_grads=True)
     if not only or "train_step_planes" in only:     # f-3 leftover (round 5): per-ray near / far planes in a gradient-carrying render
-        train_step_fixture(torch, R, M, lut, fixture="train_step_planes", phases=("warmup", "full", "depth"), planes=True)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_planes", phases=("warmup", "full", "depth"), planes=True, sparse_grads=True)
     if not only or "train_step_aux" in only:        # f-3 leftover (round 5): auxiliary networks (albedo / roughness / irradiance / normal) trained by the step
-        train_step_fixture(torch, R, M, lut, fixture="train_step_aux", phases=("warmup", "full"), aux=True, stable_rays=True)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_aux", phases=("warmup", "full"), aux=True, stable_rays=True, sparse_grads=True)
     if not only or "train_step_incident" in only:   # f-3 leftover (round 5): use_gradient_for_incident_radiance
-        train_step_fixture(torch, R, M, lut, fixture="train_step_incident", phases=("full", "frozen"), incident_gradient=True)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_incident", phases=("full", "frozen"), incident_gradient=True, sparse_grads=True)
     if not only or "train_step_arch" in only:       # round 5: a training step of a smaller architecture (evaluated inside the built one; gradients = sub-blocks)
-        train_step_fixture(torch, R, M, lut, fixture="train_step_arch", phases=("warmup", "full"), arch=(6, 128, 6, 2), stable_rays=True)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_arch", phases=("warmup", "full"), arch=(6, 128, 6, 2), stable_rays=True, sparse_grads=True)
     if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
-        train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True, sparse_grads=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
         train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt2", phases=("full",),
                            from_gt=("calculate_roughness_from_gt", "depth_map_from_ground_truth"))
