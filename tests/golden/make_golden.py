@@ -1091,9 +1091,9 @@ def main(only=None):
     if not only or "train_step" in only:
         train_step_fixture(torch, R, M, lut)
     if not only or "train_step_noise" in only:      # the same step with raw_noise_std = 1 (f-3: density noise inside a gradient-carrying render)
-        train_step_fixture(torch, R, M, lut, fixture="train_step_noise", phases=("warmup", "full"), raw_noise_std=1.0)
+        train_step_fixture(torch, R, M, lut, fixture="train_step_noise", phases=("warmup", "full"), raw_noise_std=1.0, sparse_grads=True)
     if not only or "train_step_from_gt" in only:    # ... with the four ground-truth substitutions on (f-3: constants of the backward)
-        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt", phases=("full",),
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt", phases=("full",), sparse_grads=True,
                            from_gt=("calculate_albedo_from_gt", "calculate_roughness_from_gt", "calculate_irradiance_from_gt", "depth_map_from_ground_truth"))
     if not only or "train_step_from_gt_warmup" in only:   # f-3 leftover (round 5): the substitutions during the warm-up iterations (approximate_radiance=False)
         train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt_warmup", phases=("warmup",), sparse_grads=True,
@@ -1113,7 +1113,7 @@ def main(only=None):
     if not only or "train_step_ci" in only:         # f-3 leftover (round 5): colour-independent networks in the backward
         train_step_fixture(torch, R, M, lut, fixture="train_step_ci", phases=("warmup", "full", "frozen"), color_independent=True, sparse_grads=True)
     if not only or "train_step_from_gt2" in only:   # ... and with two of them: albedo and irradiance from the networks, roughness and depth from the ground truth
-        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt2", phases=("full",),
+        train_step_fixture(torch, R, M, lut, fixture="train_step_from_gt2", phases=("full",), sparse_grads=True,
                            from_gt=("calculate_roughness_from_gt", "depth_map_from_ground_truth"))
     if not only or "sample_pdf_spiky" in only:
         sample_pdf_spiky(torch, Hh)

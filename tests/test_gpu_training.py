@@ -79,21 +79,9 @@ def test_training_step_gradients_against_the_reference(G, GN, lut, phase, teache
     loss = TL.total_loss(torch, res, tg, approx)
     assert abs(float(loss.detach()) - float(G[phase + "__loss"])) <= (3e-4 if approx else 2e-5) * float(G[phase + "__loss"]), (float(loss.detach()), float(G[phase + "__loss"]))
     loss.backward()
-    worst = {}
-    for tag, net in (("c", nets[0]), ("f", nets[1])):
-        for name, prm in net.named_parameters():
-            ref = G["%s__grad_%s__%s" % (phase, tag, name)]
-            got = np.zeros_like(ref) if prm.grad is None else prm.grad.cpu().numpy()
-            scale = float(np.abs(ref).max())
-            if scale == 0.0:                      # a frozen layer: no gradient at all
-                assert float(np.abs(got).max()) == 0.0, (tag, name)
-                continue
-            if name.endswith(".bias") and ref.size <= 3:
-                # the bias of an N = 1 / 3 head is ONE sum over all points and cancels (irradiance_linear.bias of the fine network: -5e-4 beside
-                # a weight gradient of 6e-2): measured against the layer's gradient, i.e. the larger of the two tensors' largest entries
-                scale = max(scale, float(np.abs(G["%s__grad_%s__%s" % (phase, tag, name[:-4] + "weight")]).max()))
-            worst[tag + "." + name] = float(np.abs(got - ref).max()) / scale
-    assert len(worst) == (92 if phase != "frozen" else 2 * 8), len(worst)      # frozen: albedo / irradiance feature layers and heads (roughness frozen too)
+    worst, _ = _grads_against(G, phase, nets)      # (a frozen layer: exactly no gradient; the bias of an N = 1 / 3 head is ONE cancelling sum over all points — irradiance_linear.bias of
+    # the fine network: -5e-4 beside a weight gradient of 6e-2 —: measured against the layer's gradient)
+    assert len(worst) == (_stored(G, phase) if phase != "frozen" else 2 * 8) and _stored(G, phase) == (76 if noise else 92), len(worst)      # frozen: albedo / irradiance feature layers and heads (roughness frozen too)
     # roughness_linear under approximate_radiance: d color / d roughness is proportional to the prefiltered reflected-ray maps, which are
     # ill-conditioned in the reference itself (its float64 and float32 runs differ by 1e-2 .. 1e-1 there): end to end 5e-3, and 1e-3 with the
     # reference's own reflected-ray maps and n.v as the backward's constants (teacher forcing, below)
@@ -209,22 +197,10 @@ def test_training_step_with_ground_truth_targets(lut, name, fused, teacher):
         loss.backward()
     finally:
         T.FUSED_SHADING_BACKWARD = True
-    worst, zero = {}, []
-    for tag, net in (("c", nets[0]), ("f", nets[1])):
-        for pname, prm in net.named_parameters():
-            ref = G["full__grad_%s__%s" % (tag, pname)]
-            got = np.zeros_like(ref) if prm.grad is None else prm.grad.cpu().numpy()
-            scale = float(np.abs(ref).max())
-            if scale == 0.0:
-                assert float(np.abs(got).max()) == 0.0, (tag, pname)
-                zero.append(tag + "." + pname)
-                continue
-            if pname.endswith(".bias") and ref.size <= 3:
-                scale = max(scale, float(np.abs(G["full__grad_%s__%s" % (tag, pname[:-4] + "weight")]).max()))
-            worst[tag + "." + pname] = float(np.abs(got - ref).max()) / scale
+    worst, zero = _grads_against(G, "full", nets)
     if "calculate_albedo_from_gt" in flags:      # albedo_map IS the ground truth and the shading reads the ground truth: the albedo branch gets nothing
         assert any(k.endswith("albedo_linear.weight") for k in zero), zero
-    assert len(worst) + len(zero) == 92
+    assert len(worst) + len(zero) == _stored(G, "full") == 76
     # roughness_linear: under calculate_roughness_from_gt its ONLY gradient is the mip interpolation between the reflected-ray maps (the LUT and Fresnel read the
     # ground truth), i.e. proportional to differences of maps that are ill-conditioned in the reference itself: 8.6e-3 end to end (5e-3 in the plain step, where the
     # LUT term dominates); with the reference's own reflected-ray maps as the backward's constants 2.4e-3 / 8e-4 on the two fixtures (what is left is the mip
