@@ -623,7 +623,15 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 # the device until the next call settles it, so a later call's view already includes an earlier overflow; this also zeroes the
                 # first network's gradients when only a later one overflowed)
                 both = torch.stack([o.reshape(()) for o in oks]).all()
-                grads_all = [None if gk is None else torch.where(both, gk, torch.zeros((), dtype=gk.dtype, device=gk.device)) for gk in grads_all]
+                skip = ~both
+                # (the per-parameter gradients are views of a few blobs — one per backward call: the blobs are zeroed in place, one launch each instead of one per tensor)
+                bases = {}
+                for gk in grads_all:
+                    if gk is not None:
+                        base = gk._base if gk._base is not None else gk
+                        bases[base.data_ptr()] = base
+                for base in bases.values():
+                    base.masked_fill_(skip, 0.0)
             out = []
             for i, (p, gk) in enumerate(zip(params + aux_params, grads_all)):
                 # (views of the call's own gradient blob, a fresh tensor per network_backward: no copy — 92 launches less per step)
