@@ -856,6 +856,56 @@ def test_training_ray_section_reproduces_the_reference_maps(lut):
     assert float(dx[:, 0].abs().max()) == 0.0 and float(dx[:, 7:].abs().max()) == 0.0      # depth is detached in the mip level (:455); radiance does not feed color_map
 
 
+@pytest.mark.parametrize("name", ["train_step_edit", "train_step_insert"])
+def test_override_rows_are_the_reference_overrides(name):
+    """training.override_rows (round 5) — the edit / insert overrides of raw2outputs as ray-sized (mask, value) rows for a training step's backward — against the
+    reference's own output maps of a step rendered with them (fixtures train_step_edit / train_step_insert, tests/frame_overrides.py's images at the step's pixels):
+    on the masked rays the reference's roughness_map / albedo_map / irradiance_map / target_depth_map ARE the rows' values (albedo through its gamma, irradiance
+    through output_f), elsewhere they are not; outside approximate_radiance only the depth rows exist.  And the backward's two halves: substituting the rows into
+    the maps and zeroing the overridden entries' gradient is autograd through where(mask, value, x)."""
+    import json
+    import types
+    torch = pytest.importorskip("torch")
+    from conftest import GOLDEN
+    from ibl_nerf_amd import training as T
+    G = np.load(os.path.join(GOLDEN, name + ".npz"))
+    edit = json.loads(str(G["edit_kwargs"]))
+    gt = {k[4:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("gt__")}
+    r = types.SimpleNamespace(device=torch.device("cpu"))
+    n = int(G["rays_o"].shape[0])
+    rows = T.override_rows(r, n, gt, edit, True, int(G["chunk"]))
+    assert sorted(rows) == (["albedo", "depth", "roughness"] if name.endswith("edit") else ["albedo", "depth", "irradiance", "roughness"])
+    assert sorted(T.override_rows(r, n, gt, edit, False, int(G["chunk"]))) == ["depth"]                  # :253-256 are outside `if approximate_radiance`
+    assert T.override_rows(r, n, gt, {}, True) == {}
+    gamma = lambda v: (v + 1e-12) ** (1.0 / 2.2)
+    for sfx in ("", "0"):
+        out = {k: torch.from_numpy(G["full__out__" + k + sfx]) for k in ("roughness_map", "albedo_map", "irradiance_map", "target_depth_map", "depth_map")}
+        m, v = rows["roughness"]
+        assert 5 <= int(m.sum()) <= n - 5 and torch.equal(out["roughness_map"][m], v[m]) and not torch.equal(out["roughness_map"][~m], v[~m])
+        m, v = rows["albedo"]
+        assert float((out["albedo_map"][m] - gamma(v[m])).abs().max()) <= 1e-6
+        m, v = rows["depth"]
+        assert torch.equal(out["target_depth_map"][m], v[m]) and torch.equal(out["depth_map"][m], v[m])      # target_depth_map IS depth_map: the assignment lands in both (:250-256)
+        if "irradiance" in rows:
+            m, v = rows["irradiance"]
+            assert int(m.sum()) > 0 and float((out["irradiance_map"][m].reshape(-1) - gamma(v[m])).abs().max()) <= 1e-6
+    # the backward's two halves against autograd through the masked assignment
+    rng = np.random.RandomState(0)
+    x = torch.from_numpy(rng.uniform(0.1, 0.9, (n, 19)).astype(np.float32)).double().requires_grad_(True)
+    rows64 = {k: (m, v.double()) for k, (m, v) in rows.items()}
+    flags = dict(gamma_correct=True, use_radiance_linear=False, lut_coefficient="F", correct_depth=True)
+    keys = ("albedo_map", "roughness_map", "irradiance_map", "depth_map", "target_depth_map", "disp_map", "radiance_map")
+    up = {k: torch.from_numpy(rng.randn(n, 3 if k in ("albedo_map", "radiance_map") else 1)).double() for k in keys}
+    x_eff, _ = T._apply_overrides(x, None, rows64)
+    outs = T._ray_outputs(x_eff, None, flags)
+    (g_auto,) = torch.autograd.grad([outs[k] for k in keys], x, [up[k].reshape(outs[k].shape) for k in keys])
+    xe = x_eff.detach().requires_grad_(True)
+    outs2 = T._ray_outputs(xe, None, flags)
+    (g_eff,) = torch.autograd.grad([outs2[k] for k in keys], xe, [up[k].reshape(outs2[k].shape) for k in keys])
+    g_mine = T._zero_overridden(g_eff.clone(), None, rows64)
+    assert torch.allclose(g_mine, g_auto, rtol=0, atol=1e-12) and float(g_auto[rows["roughness"][0], 5].abs().max()) == 0.0 and float(g_auto[:, 7:10].abs().min()) > 0
+
+
 def test_bench_plain_multi_gpu_invocation_spawns_a_child_launcher(monkeypatch):
     """`python bench.py --gpus N` (N > 1) without a launcher in front — the form the driver types: bench.py starts
     `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` as a CHILD (subprocess.run, never exec: on the GPU pool an exec from
