@@ -2134,6 +2134,8 @@ int iblnerf_set_select_tmin(iblnerf_ctx* c, float t_main, float t_offsets, float
     if (!c) return IBLNERF_ERR_INVALID;
     if (!(t_main > 0.f && t_main < 1.f && t_offsets > 0.f && t_offsets < 1.f && t_chunk > 0.f && t_chunk < 1.f))
         return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must lie in (0, 1)");
+    if (!(t_chunk <= t_offsets && t_offsets <= t_main))      // (a chunk threshold above the copies' own leaves samples without an estimate that the selection still audits)
+        return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must be ordered t_chunk <= t_offsets <= t_main");
     c->tmin_main = t_main; c->tmin_offsets = t_offsets; c->tmin_chunk = t_chunk;
     return IBLNERF_OK;
 }

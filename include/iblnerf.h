@@ -192,7 +192,9 @@ int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
 /* Measurement hook: the threshold of the offset tiers (IBLNERF_ROUTE_NO_OFFSET_TIERS above; default 0 = no tiers). */
 /* (experiment hook, round 5) the transmittance thresholds of the per-sample selection: a sample behind a CONSERVATIVE transmittance (composited from 0.75 x the density
  * estimate - margin) below the threshold is left at its estimate — it carries, with everything behind it, a weight below the threshold.  t_main: main and reflected
- * queries (default 1e-8), t_offsets: the offset copies' own selection (1e-10), t_chunk: which rays still need estimates behind a z-chunk / the predicted range (1e-12). */
+ * queries (default 1e-8), t_offsets: the offset copies' own selection (1e-10), t_chunk: which rays still need estimates behind a z-chunk / the predicted range (1e-12).
+ * Ordered t_chunk <= t_offsets <= t_main (IBLNERF_ERR_INVALID otherwise).  Measured (scratch/tmin_ab.py): 1e-5 / 1e-7 / 1e-9 renders 3 % faster and moves the worst
+ * normal of a frame by 1.2e-5; the defaults keep the lists within 2e-6 of evaluating every sample. */
 int iblnerf_set_select_tmin(iblnerf_ctx* ctx, float t_main, float t_offsets, float t_chunk);
 int iblnerf_set_offset_tier_threshold(iblnerf_ctx* ctx, float tau);
 /* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
