@@ -46,7 +46,7 @@ constexpr float MARGIN_MAX = 6.0f, MARGIN_ZONE = 8.0f;
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
 // estimate_chunked: a ray counts as saturated behind its first chunk below this transmittance — two decades under the selection's own thresholds, so that what a
 // skipped sample could have carried (its weight set to exactly zero instead of < 1e-12) is far below half an ulp of any map: renders stay bit-identical
-constexpr float CHUNK_TMIN = 1e-12f;
+constexpr float CHUNK_TMIN = 0.0f;      // 0: the query's own selection threshold (a value > 0 overrides it: round 4 used 1e-12 for every query)
 // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
 constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
 // ... with the main ray's prediction a sample costs an estimate OR an evaluation (offsets_on_lists): in MAC terms the lists then always pay; what remains against them are the
@@ -117,7 +117,8 @@ struct iblnerf_ctx {
     unsigned long long* tier_mask = nullptr;      // [ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers)
     float tier_tau = 0.0f;                        // ... their threshold on T_s dist_s |depth - z_s| (iblnerf_set_offset_tier_threshold; 0 = no tiers, the default)
     bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
-    float tmin_main = COARSE_SELECT_TMIN, tmin_offsets = OFFSET_SELECT_TMIN, tmin_chunk = CHUNK_TMIN;     // iblnerf_set_select_tmin
+    float tmin_main = COARSE_SELECT_TMIN, tmin_offsets = OFFSET_SELECT_TMIN, tmin_chunk = CHUNK_TMIN;     // iblnerf_set_select_tmin (tmin_chunk 0: each query's own threshold)
+    float chunk_t(float own) const { return tmin_chunk > 0.f ? tmin_chunk : own; }
     bool ci_embedded[2] = {false, false};          // colour-independent context: slot's packed streams carry the identity in place of the feature / view layers
     double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
@@ -1538,8 +1539,9 @@ static QueryPlan plan_reflected(const iblnerf_ctx* c, int which, bool keep_all_r
 static double list_slots(const Launch& l) { return l.none() ? 0.0 : variant_flops(l.variant) / 128.0 * launch_slots(l); }
 
 // A density estimate of the S samples of nv = (offsets ? 4 R : R) (virtual) rays in up to THREE z-chunks: samples [0, cut0) of every ray, then [cut0, cut1) and
-// [cut1, S) only of the rays whose transmittance behind the samples in front of the chunk — composited conservatively from those estimates — is not yet below t_min (CHUNK_TMIN); the other rays'
-// later samples get -1e30 (k_select_points would not select them either: its transmittance only falls, and its thresholds are higher).  On the coarse grid half of the rays saturate in
+// [cut1, S) only of the rays whose transmittance behind the samples in front of the chunk — composited conservatively from those estimates — is not yet below t_min; the other rays'
+// later samples get -1e30.  t_min is the query's own selection threshold (round 5; 1e-12 for every query before): k_select_points would not select those samples whatever their
+// estimate — its transmittance only falls — so estimating them bought nothing but weights below the threshold for samples that are dropped anyway (5.5 % of a frame).  On the coarse grid half of the rays saturate in
 // the first half of the grid, on the fine grid a quarter to a half of them before its last quarter (scratch/saturation_depth.py).  Rows land in c->sig4 [nv, S].
 static int estimate_chunked(iblnerf_ctx* c, hipStream_t s, const Launch& est, int which, const float* ro, const float* rd, const float* z, int z_stride, int S, long R, bool offsets,
                             float eps, const float* noise, int cut0, int cut1, float t_min, double flop_alg_per_point) {
@@ -1610,7 +1612,7 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
     bool est_counted = false;
     int rc;
     if (q.list) {
-        if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, false, 0.f, p.noise, q.cut0, q.cut1, c->tmin_chunk, FLOP_FULL);
+        if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, false, 0.f, p.noise, q.cut0, q.cut1, c->chunk_t(q.t_min), FLOP_FULL);
         else {
             MlpCall m;
             m.pts = c->pts; m.pts_per_ray = S; m.n_pts = n; m.out = c->sig4; m.flop_per_point = FLOP_FULL;
@@ -1705,20 +1707,20 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
         for (int tier = q.tiers ? 1 : 0; tier >= 0; --tier) {
             const Launch& k = (q.tiers && tier == 1) ? q.on_list_precise : q.on_list;
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], c->tmin_chunk, eps, c->sel_pts, c->sel_index, c->sel_count, s,
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, 1, c->margin[which], c->chunk_t(q.t_min), eps, c->sel_pts, c->sel_index, c->sel_count, s,
                                            FLOP_TRUNK, list_slots(k), true, q.tiers ? c->tier_mask : nullptr, tier));
             if ((rc = run_launch(c, s, k, which, refine))) return rc;
         }
         // 2, 3: estimates in front of it, and behind it where a copy is still alive
         for (int mode = 2; mode <= 3; ++mode) {
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
-            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, c->margin[which], c->tmin_chunk, eps, c->sel_pts, c->sel_index, c->sel_count,
+            HIP_TRY(c, launch_range_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, c->main_range, R, S, mode, c->margin[which], c->chunk_t(q.t_min), eps, c->sel_pts, c->sel_index, c->sel_count,
                                            s, FLOP_TRUNK, list_slots(q.est), false));
             if ((rc = run_launch(c, s, q.est, which, est))) return rc;
         }
         c->flop_alg += (double)n4 * FLOP_TRUNK;
     } else if (q.cut1 > 0) {
-        if ((rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, true, eps, nullptr, q.cut0, q.cut1, c->tmin_chunk, FLOP_TRUNK))) return rc;
+        if ((rc = estimate_chunked(c, s, q.est, which, p.ro, p.rd, p.z, p.z_stride, S, R, true, eps, nullptr, q.cut0, q.cut1, c->chunk_t(q.t_min), FLOP_TRUNK))) return rc;
     } else {
         MlpCall m;
         m.pts_per_ray = S; m.n_pts = n4; m.out = c->sig4; m.gen = &g;
@@ -1786,7 +1788,7 @@ static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R,
         return run_launch(c, s, q.whole, which, m);
     }
     int rc;
-    if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, q.cut0, q.cut1, c->tmin_chunk, FLOP_REFL);
+    if (q.cut1 > 0) rc = estimate_chunked(c, s, q.est, which, c->refl_o, c->refl_d, zc, zc_stride, Sc, R, false, 0.f, nullptr, q.cut0, q.cut1, c->chunk_t(q.t_min), FLOP_REFL);
     else {
         m.pts = c->pts; m.out = c->sig4; m.flop_per_point = FLOP_REFL;
         rc = run_launch(c, s, q.est, which, m);
@@ -2132,8 +2134,8 @@ int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
 
 int iblnerf_set_select_tmin(iblnerf_ctx* c, float t_main, float t_offsets, float t_chunk) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (!(t_main > 0.f && t_main < 1.f && t_offsets > 0.f && t_offsets < 1.f && t_chunk > 0.f && t_chunk < 1.f))
-        return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must lie in (0, 1)");
+    if (!(t_main > 0.f && t_main < 1.f && t_offsets > 0.f && t_offsets < 1.f && t_chunk >= 0.f && t_chunk < 1.f))
+        return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must lie in (0, 1) (t_chunk 0: each query's own)");
     if (!(t_chunk <= t_offsets && t_offsets <= t_main))      // (a chunk threshold above the copies' own leaves samples without an estimate that the selection still audits)
         return c->fail(IBLNERF_ERR_INVALID, "set_select_tmin: thresholds must be ordered t_chunk <= t_offsets <= t_main");
     c->tmin_main = t_main; c->tmin_offsets = t_offsets; c->tmin_chunk = t_chunk;

@@ -11,7 +11,7 @@ g, sdc, sdf, gt, edit = load_golden("fitted_launch16k")
 f_ = np.float32(0.5 * 800 / np.tan(0.5 * np.deg2rad(60.0)))
 Kc = np.array([[f_, 0, 400], [0, f_, 400], [0, 0, 1]], dtype=np.float32)
 c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
-settings = {"r4": (1e-8, 1e-10, 1e-12), "chunk9": (1e-8, 1e-10, 1e-9), "chunk8": (1e-8, 1e-10, 1e-8), "main6chunk9": (1e-6, 1e-10, 1e-9), "loose": (1e-5, 1e-7, 1e-9)}
+settings = {"r4": (1e-8, 1e-10, 1e-12), "own": (1e-8, 1e-10, 0.0), "chunk10": (1e-8, 1e-10, 1e-10)}
 rs = {}
 for k, tm in settings.items():
     r = R.Renderer(64, 128, max_rays_per_launch=65536)
@@ -32,4 +32,4 @@ for rep in range(5):
         times[k].append((time.time() - t0) / 2 * 1e3)
 for k, r in rs.items():
     sel = r.last_selection()
-    print("%-8s %s  frame ms %s  median %.1f  refined %.4f" % (k, settings[k], ["%.0f" % t for t in times[k]], np.median(times[k]), sel[0] / sel[1]))
+    print("%-8s %s  frame ms %s  median %.1f  refined %.4f" % (k, settings[k], ["%.0f" % t for t in times[k]], np.median(times[k]), sel[0] / max(sel[1], 1)))

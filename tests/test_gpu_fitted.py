@@ -345,9 +345,10 @@ def test_own_selection_samples_of_the_offset_copies_run_precise(R, lut):
 
 def test_estimates_in_z_chunks_change_nothing(R, lut):
     """api.cpp estimate_chunked (round 4's route of the offset copies, IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL, and the fine main / reflected queries of every route): the
-    density estimates run on the first samples of every (virtual) ray and on the later ones only for rays whose conservative transmittance is still above 1e-12 (the
-    skipped samples get -1e30).  Against IBLNERF_ROUTE_ESTIMATES_WHOLE: the same samples refined, every map bit for bit, the per-sample weights to 1e-15 (exactly zero
-    instead of ~1e-17 behind saturation) — and fewer MACs executed."""
+    density estimates run on the first samples of every (virtual) ray and on the later ones only for rays whose conservative transmittance is still above the query's OWN
+    selection threshold (1e-8 main / reflected, 1e-10 offset copies; the skipped samples get -1e30 — round 4 kept estimating down to 1e-12, i.e. samples the selection
+    drops whatever their estimate: 5.7 % of a frame, scratch/tmin_ab.py).  Against IBLNERF_ROUTE_ESTIMATES_WHOLE: the same samples refined, every map bit for bit, the
+    per-sample weights to 1e-10 (exactly zero instead of < 6e-12 behind saturation: the conservative transmittance is 0.75 x the estimate's) — and fewer MACs executed."""
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     n = 8192
     out, sel, flops = {}, {}, {}
@@ -358,7 +359,7 @@ def test_estimates_in_z_chunks_change_nothing(R, lut):
     assert sel["chunks"] == sel["whole"] and flops["chunks"] < 0.97 * flops["whole"], (sel, flops)
     for k in out["whole"]:
         if k == "weights":
-            assert float((out["chunks"][k] - out["whole"][k]).abs().max()) <= 1e-15
+            assert float((out["chunks"][k] - out["whole"][k]).abs().max()) <= 1e-10
         else:
             assert torch.equal(out["chunks"][k], out["whole"][k]), k
 
