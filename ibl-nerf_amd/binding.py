@@ -24,7 +24,7 @@ EXPORTS = [
     "iblnerf_composite_direct", "iblnerf_composite_direct_backward", "iblnerf_trim", "iblnerf_composite_direct_backward_full",
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
-    "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt", "iblnerf_ray_outputs_backward_rays", "iblnerf_coarse_z_rays", "iblnerf_aux_query", "iblnerf_aux_backward", "iblnerf_ray_outputs_backward_env", "iblnerf_set_select_tmin",
+    "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt", "iblnerf_ray_outputs_backward_rays", "iblnerf_coarse_z_rays", "iblnerf_aux_query", "iblnerf_aux_backward", "iblnerf_ray_outputs_backward_env", "iblnerf_set_select_tmin", "iblnerf_set_chunk_cuts",
     "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units", "iblnerf_trunk_density_fp32", "iblnerf_set_offset_tier_threshold",
 ]
 
@@ -209,6 +209,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_coarse_z.restype = C.c_int
     lib.iblnerf_ray_outputs_backward_env.argtypes = [C.c_void_p, C.c_void_p, FP, FP, FP, C.c_float, FP, C.POINTER(Maps), C.POINTER(Overrides), C.c_int64, FP, FP]
     lib.iblnerf_ray_outputs_backward_env.restype = C.c_int
+    lib.iblnerf_set_chunk_cuts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.iblnerf_set_chunk_cuts.restype = C.c_int
     lib.iblnerf_set_select_tmin.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
     lib.iblnerf_set_select_tmin.restype = C.c_int
     lib.iblnerf_aux_query.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FP, C.c_int64, FP]

@@ -119,6 +119,7 @@ struct iblnerf_ctx {
     bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
     float tmin_main = COARSE_SELECT_TMIN, tmin_offsets = OFFSET_SELECT_TMIN, tmin_chunk = CHUNK_TMIN;     // iblnerf_set_select_tmin (tmin_chunk 0: each query's own threshold)
     float chunk_t(float own) const { return tmin_chunk > 0.f ? tmin_chunk : own; }
+    int cuts_fine[2] = {0, 0}, cuts_refl[2] = {0, 0};      // iblnerf_set_chunk_cuts (0: the built-in fractions)
     bool ci_embedded[2] = {false, false};          // colour-independent context: slot's packed streams carry the identity in place of the feature / view layers
     double slot_units = 0.0;                      // matrix-slot units of the last render call's whole-batch launches (launch_slots; list launches: sel_count[8..9])
     bool p_all_points = false;                    // IBLNERF_ROUTE_COARSE_DENSITY_ALL_POINTS: the 15-slot form on every coarse sample, not only the relevant ones
@@ -1449,6 +1450,7 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         q.list = true; q.open = c->fsel_fraction < 0.0; q.share_max = FINE_SELECT_MAX_FRACTION;
         q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
         if (est_chunks(c, which)) { q.cut0 = (3 * S) / 4; q.cut1 = (7 * S) / 8; }
+        if (est_chunks(c, which) && c->cuts_fine[1] > 0 && c->cuts_fine[1] < S) { q.cut0 = c->cuts_fine[0]; q.cut1 = c->cuts_fine[1]; }
     }
     return q;
 }
@@ -1532,6 +1534,7 @@ static QueryPlan plan_reflected(const iblnerf_ctx* c, int which, bool keep_all_r
         q.list = true;
         q.on_list = pick_kernel(c, which, VAR_REFL_LIST, Q_ESTIMATE, false);
         if (est_chunks(c, which)) { q.cut0 = Sc / 2; q.cut1 = (3 * Sc) / 4; }
+        if (est_chunks(c, which) && c->cuts_refl[1] > 0 && c->cuts_refl[1] < Sc) { q.cut0 = c->cuts_refl[0]; q.cut1 = c->cuts_refl[1]; }
     }
     return q;
 }
@@ -2129,6 +2132,14 @@ int iblnerf_last_executed_flops(iblnerf_ctx* c, double* flop_executed) {
     double on_lists = 0.0;
     HIP_TRY(c, hipMemcpy(&on_lists, c->sel_count + 4, sizeof on_lists, hipMemcpyDeviceToHost));
     *flop_executed = c->flop_exec + on_lists;
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_chunk_cuts(iblnerf_ctx* c, int fine_cut0, int fine_cut1, int refl_cut0, int refl_cut1) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (fine_cut0 < 0 || fine_cut1 < fine_cut0 || refl_cut0 < 0 || refl_cut1 < refl_cut0 || (fine_cut1 > 0 && fine_cut0 < 1) || (refl_cut1 > 0 && refl_cut0 < 1))
+        return c->fail(IBLNERF_ERR_INVALID, "set_chunk_cuts: 1 <= cut0 <= cut1 (0, 0: the built-in cuts)");
+    c->cuts_fine[0] = fine_cut0; c->cuts_fine[1] = fine_cut1; c->cuts_refl[0] = refl_cut0; c->cuts_refl[1] = refl_cut1;
     return IBLNERF_OK;
 }
 

@@ -196,6 +196,9 @@ int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
  * Ordered t_chunk <= t_offsets <= t_main (IBLNERF_ERR_INVALID otherwise).  Measured (scratch/tmin_ab.py): 1e-5 / 1e-7 / 1e-9 renders 3 % faster and moves the worst
  * normal of a frame by 1.2e-5; the defaults keep the lists within 2e-6 of evaluating every sample. */
 int iblnerf_set_select_tmin(iblnerf_ctx* ctx, float t_main, float t_offsets, float t_chunk);
+/* (experiment hook, round 5) where the z-chunked estimates of the fine main query ([0, cut0) of every ray, [cut0, cut1) and [cut1, S) of the rays still alive) and of the
+ * reflected rays are cut, in samples; 0, 0 = the built-in cuts (3/4 and 7/8 of the fine grid, 1/2 and 3/4 of the reflected ray's).  Results do not depend on the cuts. */
+int iblnerf_set_chunk_cuts(iblnerf_ctx* ctx, int fine_cut0, int fine_cut1, int refl_cut0, int refl_cut1);
 int iblnerf_set_offset_tier_threshold(iblnerf_ctx* ctx, float tau);
 /* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
  * Writes at most n bytes including the terminating 0; returns the length the full text needs (snprintf's convention), < 0 on error. */
