@@ -44,9 +44,11 @@ constexpr float MARGIN_MAX = 6.0f, MARGIN_ZONE = 8.0f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
-// estimate_chunked: a ray counts as saturated behind its first chunk below this transmittance — two decades under the selection's own thresholds, so that what a
-// skipped sample could have carried (its weight set to exactly zero instead of < 1e-12) is far below half an ulp of any map: renders stay bit-identical
-constexpr float CHUNK_TMIN = 0.0f;      // 0: the query's own selection threshold (a value > 0 overrides it: round 4 used 1e-12 for every query)
+// estimate_chunked / k_range_points mode 3: a ray counts as saturated behind a chunk (or behind the predicted range) below this transmittance.  0 = the query's own selection
+// threshold: the selection drops every sample behind it whatever its estimate, so an estimate there buys only a weight below the threshold for a sample that is dropped anyway
+// (set to exactly zero instead).  Round 4 used 1e-12 for every query — two decades under the thresholds, for bit-identical weights — and paid 5.7 % of a frame for it
+// (scratch/tmin_ab.py); a value > 0 overrides (iblnerf_set_select_tmin).
+constexpr float CHUNK_TMIN = 0.0f;
 // the fine grid's offset copies: estimate (0.53 of a TRUNK_X evaluation, 0.40 of a three-product TRUNK one) + share x that evaluation
 constexpr double FINE_OFFSET_SELECT_MAX_FRACTION = 0.42, FINE_OFFSET_SELECT_MAX_FRACTION_3 = 0.55;
 // ... with the main ray's prediction a sample costs an estimate OR an evaluation (offsets_on_lists): in MAC terms the lists then always pay; what remains against them are the
