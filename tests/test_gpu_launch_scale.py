@@ -341,6 +341,18 @@ def test_one_whole_launch_against_the_reference(R, lut):
     # (VERDICT r4's bar for this launch: 0 depth / <= 5 normal rays above 1e-3, where round 4 had 2 / 20 and the fp32 C restatement has 0 / 0.  Measured: 0 / 2 under the
     # fast table — the coarse density in the reference's own fp32 summation order, the copies' own-selection samples on three f16 products —, 0 / 1 under the safe one)
     assert rep["depth_map"][2] == 0 and rep["albedo_map"][2] == 0 and rep["target_normal_map"][2] <= 5, (rep["depth_map"], rep["albedo_map"], rep["target_normal_map"])
+    # ... and the estimates' z-chunks / ranges stopping at each query's own selection threshold (the round's last change) against estimating every sample of every ray
+    # (IBLNERF_ROUTE_ESTIMATES_WHOLE): the same samples refined; every map of the launch within 1e-7 of its largest value (the samples behind the threshold are dropped on
+    # either route — what differs is their weight: exactly zero instead of below 1e-8 — on 8 192 rays every map is bit-identical, tests/test_gpu_fitted.py)
+    # (both with round 4's offsets route, IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL: the copies' estimates in z-chunks too, the same candidates on either side)
+    outs = {}
+    for label, routing in (("chunks", ("offsets_estimate_all",)), ("whole", ("offsets_estimate_all", "estimates_whole"))):
+        w = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=65536, query_routing=routing)
+        outs[label] = (w.render_rays(ro[idx].contiguous(), rd[idx].contiguous(), 0.5, 8.0), w.last_selection(), w.last_executed_flops())
+    assert outs["chunks"][1] == outs["whole"][1] and outs["chunks"][2] < 0.95 * outs["whole"][2], (outs["chunks"][1:], outs["whole"][1:])
+    for k in outs["whole"][0]:
+        d = float((outs["chunks"][0][k] - outs["whole"][0][k]).abs().max() / outs["whole"][0][k].abs().max().clamp_min(1e-30))
+        assert d <= 1e-7, (k, d)
 
 
 @pytest.mark.parametrize("name,rows_fn", [("fitted_edit_cfg4", FO.edit_rows), ("fitted_insert_cfg5", FO.insert_rows)])
