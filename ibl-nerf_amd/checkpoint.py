@@ -221,11 +221,17 @@ AUX_OUT_CH = {"albedo_mlp": 3, "roughness_mlp": 1, "irradiance_mlp": 1, "normal_
 TRUNK_SCHEMA = tuple(e for e in SCHEMA if e[0].startswith("positions_linears."))
 
 
-def synthetic_position_mlp(seed: int, out_ch: int, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
-    """A seeded PositionMLP state dict (D=8, W=256, input_ch=63, skips=[4]) in nn.Module registration order."""
+def _trunk_schema(D, W, multires):
+    ch = 3 + 6 * multires
+    return tuple([("positions_linears.0", W, ch)] + [("positions_linears.%d" % (i + 1), W, W + ch if i == 4 else W) for i in range(D - 1)])
+
+
+def synthetic_position_mlp(seed: int, out_ch: int, gain: float = 1.0, arch=None) -> "OrderedDict[str, np.ndarray]":
+    """A seeded PositionMLP state dict (D=8, W=256, input_ch=63, skips=[4]; arch = (D, W, multires[, ...]) for a smaller one) in nn.Module registration order."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for name, o, i in TRUNK_SCHEMA + (("out_linears", out_ch, 256),):
+    schema = TRUNK_SCHEMA + (("out_linears", out_ch, 256),) if arch is None else _trunk_schema(*arch[:3]) + (("out_linears", out_ch, arch[1]),)
+    for name, o, i in schema:
         sd[name + ".weight"] = (rs.randn(o, i) * gain * np.sqrt(2.0 / i)).astype(np.float32)
         sd[name + ".bias"] = (rs.randn(o) * 0.1).astype(np.float32)
     return sd
@@ -238,19 +244,119 @@ def posdir_schema(out_ch: int = 1):
                            ("views_linears.2", 128, 128), ("views_linears.3", 128, 128), ("final_linear", out_ch, 128))
 
 
-def synthetic_position_direction_mlp(seed: int, out_ch: int = 1, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
-    """A seeded PositionDirectionMLP state dict in nn.Module registration order."""
+def synthetic_position_direction_mlp(seed: int, out_ch: int = 1, gain: float = 1.0, arch=None) -> "OrderedDict[str, np.ndarray]":
+    """A seeded PositionDirectionMLP state dict in nn.Module registration order (arch = (D, W, multires, multires_views) for a smaller one: D // 2 view layers of W // 2)."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for name, o, i in posdir_schema(out_ch):
+    schema = posdir_schema(out_ch)
+    if arch is not None:
+        D, W, L, Lv = arch
+        schema = _trunk_schema(D, W, L) + (("feature_linear", W, W), ("views_linears.0", W // 2, W + 3 + 6 * Lv)) + \
+            tuple(("views_linears.%d" % l, W // 2, W // 2) for l in range(1, max(D // 2, 1))) + (("final_linear", out_ch, W // 2),)
+    for name, o, i in schema:
         sd[name + ".weight"] = (rs.randn(o, i) * gain * np.sqrt(2.0 / i)).astype(np.float32)
         sd[name + ".bias"] = (rs.randn(o) * 0.1).astype(np.float32)
     return sd
 
 
+def _trunk_arch(sd):
+    """(D, W, multires) of a state dict's positions_linears.* (PositionMLP / PositionDirectionMLP / IBLNeRF)"""
+    W, ch = (int(v) for v in sd["positions_linears.0.weight"].shape)
+    D = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("positions_linears.") and k.endswith(".weight"))
+    if (ch - 3) % 6:
+        raise ValueError("not a positional-encoding width: input_ch %d" % ch)
+    return D, W, (ch - 3) // 6
+
+
+def _embed_trunk(sd, out, D, W, ch):
+    """positions_linears.0-7 of the built shape from a smaller trunk (embed_architecture's rules: zero units, zero frequency columns, identity layers behind the last one)"""
+    if D > 8 or D == 5 or D < 1 or W > 256 or W < 2 or ch > 63:
+        raise ValueError("a trunk of D=%d, W=%d, input_ch=%d is not a member of the built architecture (D <= 8 and != 5, W <= 256, multires <= 10)" % (D, W, ch))
+    P = "positions_linears.%d"
+    val = lambda k: sd[k].detach() if hasattr(sd[k], "detach") else sd[k]
+    for l in range(8):
+        w, b = out[(P % l) + ".weight"], out[(P % l) + ".bias"]
+        if l < D:
+            src = val((P % l) + ".weight")
+            want = (W, ch) if l == 0 else ((W, W + ch) if l == 5 else (W, W))
+            if tuple(int(v) for v in src.shape) != want:
+                raise ValueError("%s.weight has shape %s, expected %s" % (P % l, tuple(src.shape), want))
+            if l == 0:
+                w[:W, :ch] = src
+            elif l == 5:
+                w[:W, :ch], w[:W, 63:63 + W] = src[:, :ch], src[:, ch:]
+            else:
+                w[:W, :W] = src
+            b[:W] = val((P % l) + ".bias")
+        else:
+            c0 = 63 if l == 5 else 0
+            for u in range(W):
+                w[u, c0 + u] = 1.0
+
+
+def embed_position_mlp(sd):
+    """A smaller PositionMLP (networks/MLP.py:6-30: albedo_mlp / roughness_mlp / irradiance_mlp / normal_mlp under netdepth / netwidth / multires below the built
+    8 / 256 / 10) as the member of the built shape that computes the same function (embed_architecture's rules).  A built-shape dict is returned as it is."""
+    D, W, L = _trunk_arch(sd)
+    if (D, W, L) == (8, 256, 10):
+        return sd
+    out_ch = int(sd["out_linears.weight"].shape[0])
+    if tuple(int(v) for v in sd["out_linears.weight"].shape) != (out_ch, W):
+        raise ValueError("out_linears.weight has shape %s, expected (%d, %d)" % (tuple(sd["out_linears.weight"].shape), out_ch, W))
+    like = sd["positions_linears.0.weight"]
+    zeros = (lambda *sh: np.zeros(sh, dtype=np.float32)) if isinstance(like, np.ndarray) else (lambda *sh: like.new_zeros(sh))
+    out = OrderedDict()
+    for name, o, i in TRUNK_SCHEMA + (("out_linears", out_ch, 256),):
+        out[name + ".weight"], out[name + ".bias"] = zeros(o, i), zeros(o)
+    _embed_trunk(sd, out, D, W, 3 + 6 * L)
+    val = lambda k: sd[k].detach() if hasattr(sd[k], "detach") else sd[k]
+    out["out_linears.weight"][:, :W] = val("out_linears.weight")
+    out["out_linears.bias"][:] = val("out_linears.bias")
+    return out
+
+
+def embed_position_direction_mlp(sd):
+    """A smaller PositionDirectionMLP (networks/MLP.py:32-74: the depth_mlp of infer_depth) inside the built shape: the trunk as above; feature_linear and the view
+    layers (W // 2 wide, D // 2 of them) with zero units, zero direction frequencies and — for D < 8 — identity view layers behind the last one (their inputs are
+    >= 0 after the ReLU); final_linear padded."""
+    D, W, L = _trunk_arch(sd)
+    H = W // 2
+    chv = int(sd["views_linears.0.weight"].shape[1]) - W
+    n_view = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("views_linears.") and k.endswith(".weight"))
+    if (D, W, L, chv, n_view) == (8, 256, 10, 27, 4):
+        return sd
+    if (chv - 3) % 6 or chv > 27 or chv < 3 or n_view != max(D // 2, 1) or n_view > 4:
+        raise ValueError("not a PositionDirectionMLP inside the built shape: D=%d, W=%d, input_ch_views=%d, %d view layers" % (D, W, chv, n_view))
+    out_ch = int(sd["final_linear.weight"].shape[0])
+    like = sd["positions_linears.0.weight"]
+    zeros = (lambda *sh: np.zeros(sh, dtype=np.float32)) if isinstance(like, np.ndarray) else (lambda *sh: like.new_zeros(sh))
+    out = OrderedDict()
+    for name, o, i in posdir_schema(out_ch):
+        out[name + ".weight"], out[name + ".bias"] = zeros(o, i), zeros(o)
+    _embed_trunk(sd, out, D, W, 3 + 6 * L)
+    val = lambda k: sd[k].detach() if hasattr(sd[k], "detach") else sd[k]
+    out["feature_linear.weight"][:W, :W] = val("feature_linear.weight")
+    out["feature_linear.bias"][:W] = val("feature_linear.bias")
+    w0 = val("views_linears.0.weight")
+    out["views_linears.0.weight"][:H, :W], out["views_linears.0.weight"][:H, 256:256 + chv] = w0[:, :W], w0[:, W:]
+    out["views_linears.0.bias"][:H] = val("views_linears.0.bias")
+    for l in range(1, 4):
+        if l < n_view:
+            out["views_linears.%d.weight" % l][:H, :H] = val("views_linears.%d.weight" % l)
+            out["views_linears.%d.bias" % l][:H] = val("views_linears.%d.bias" % l)
+        else:
+            for u in range(H):
+                out["views_linears.%d.weight" % l][u, u] = 1.0
+    out["final_linear.weight"][:, :H] = val("final_linear.weight")
+    out["final_linear.bias"][:] = val("final_linear.bias")
+    return out
+
+
 def posdir_blob(sd) -> np.ndarray:
     """A PositionDirectionMLP state dict -> the flat fp32 blob of iblnerf_upload_posdir_mlp (weight [out,in] row-major, then bias,
     layer after layer).  Validates names, order and shapes."""
+    if "positions_linears.0.weight" in sd and "views_linears.0.weight" in sd and "final_linear.weight" in sd:
+        sd = embed_position_direction_mlp(sd)      # (a smaller network: the member of the built shape that computes the same function)
     out_ch = int(_to_numpy(sd["final_linear.bias"]).shape[0]) if "final_linear.bias" in sd else 1
     want = [n + sfx for n, _, _ in posdir_schema(out_ch) for sfx in (".weight", ".bias")]
     if list(sd.keys()) != want:
@@ -267,6 +373,8 @@ def posdir_blob(sd) -> np.ndarray:
 def aux_channel_blob(aux_sd, channel: int) -> np.ndarray:
     """One output channel of a PositionMLP as an IBLNeRF-schema blob for iblnerf_upload_aux_weights: its
     positions_linears.*, row `channel` of out_linears in the place of sigma_linear, zeros elsewhere."""
+    if "positions_linears.0.weight" in aux_sd and "out_linears.weight" in aux_sd:
+        aux_sd = embed_position_mlp(aux_sd)        # (a smaller network: the member of the built shape that computes the same function)
     want = [n + sfx for n, _, _ in TRUNK_SCHEMA for sfx in (".weight", ".bias")] + ["out_linears.weight", "out_linears.bias"]
     if list(aux_sd.keys()) != want:
         raise KeyError("not a PositionMLP state dict (D=8, W=256, skips=[4]): %s" % list(aux_sd.keys())[:4])

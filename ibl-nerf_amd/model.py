@@ -64,10 +64,13 @@ class PositionMLP:
     """Weight container with the schema of src/networks/MLP.py:6-30 (albedo_mlp / roughness_mlp / irradiance_mlp)."""
 
     def __init__(self, D=8, W=256, input_ch=63, out_ch=3, skips=(4,)):
-        if (D, W, input_ch, tuple(skips)) != (8, 256, 63, (4,)) or out_ch not in (1, 3):
-            raise NotImplementedError("auxiliary networks are built for D=8, W=256, multires=10, skips=[4], out_ch 1 or 3")
+        ok = tuple(skips) == (4,) and out_ch in (1, 3) and 1 <= D <= 8 and D != 5 and 2 <= W <= 256 and 3 <= input_ch <= 63 and (input_ch - 3) % 6 == 0
+        if not ok:
+            raise NotImplementedError("auxiliary networks are built for D=8, W=256, multires=10, skips=[4], out_ch 1 or 3, and evaluate smaller ones (D <= 8 and != 5, "
+                                      "W <= 256, multires <= 10) inside that shape")
         self.out_ch = out_ch
-        self._sd = ck.synthetic_position_mlp(0, out_ch)
+        self.arch = (int(D), int(W), (int(input_ch) - 3) // 6)
+        self._sd = ck.synthetic_position_mlp(0, out_ch, arch=None if self.arch == (8, 256, 10) else self.arch)
         self._version = 0
 
     def state_dict(self):
@@ -76,6 +79,8 @@ class PositionMLP:
     def load_state_dict(self, sd):
         sd = OrderedDict((k, np.array(ck._to_numpy(v), dtype=np.float32)) for k, v in sd.items())
         ck.aux_channel_blob(sd, 0)                      # validates names and shapes
+        if ck._trunk_arch(sd) != self.arch:
+            raise ValueError("state dict of PositionMLP%s loaded into PositionMLP%s" % (ck._trunk_arch(sd), self.arch))
         if sd["out_linears.weight"].shape[0] != self.out_ch:
             raise ValueError("out_linears has %d rows, this network %d" % (sd["out_linears.weight"].shape[0], self.out_ch))
         self._sd = sd
@@ -93,10 +98,13 @@ class PositionDirectionMLP:
     """Weight container with the schema of src/networks/MLP.py:32-74 (the depth_mlp of infer_depth, ibl_nerf.py:293-297)."""
 
     def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, out_ch=1, skips=(4,)):
-        if (D, W, input_ch, input_ch_views, tuple(skips)) != (8, 256, 63, 27, (4,)):
-            raise NotImplementedError("PositionDirectionMLP is built for D=8, W=256, multires=10, multires_views=4, skips=[4]")
+        ok = (tuple(skips) == (4,) and 2 <= D <= 8 and D != 5 and 2 <= W <= 256 and 3 <= input_ch <= 63 and (input_ch - 3) % 6 == 0
+              and 3 <= input_ch_views <= 27 and (input_ch_views - 3) % 6 == 0)
+        if not ok:
+            raise NotImplementedError("PositionDirectionMLP is built for D=8, W=256, multires=10, multires_views=4, skips=[4], and evaluates smaller ones inside that shape")
         self.out_ch = out_ch
-        self._sd = ck.synthetic_position_direction_mlp(0, out_ch)
+        self.arch = (int(D), int(W), (int(input_ch) - 3) // 6, (int(input_ch_views) - 3) // 6)
+        self._sd = ck.synthetic_position_direction_mlp(0, out_ch, arch=None if self.arch == ck.SHIPPED_ARCH else self.arch)
         self._version = 0
 
     def state_dict(self):
@@ -357,13 +365,11 @@ def create_IBLNeRF(args):
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
     if not (0 <= args.multires <= 10 and 0 <= args.multires_views <= 4) or args.i_embed != 0:
         raise NotImplementedError("the kernels' positional encoding is built for multires <= 10 / multires_views <= 4 (i_embed = 0); fewer frequencies run inside it")
-    if (getattr(args, "infer_depth", False) or getattr(args, "infer_visibility", False) or any(getattr(args, f, False) for f in
-            ("infer_albedo_separate", "infer_roughness_separate", "infer_irradiance_separate", "infer_normal"))) and (args.netdepth, args.netwidth, args.multires, args.multires_views) != ck.SHIPPED_ARCH:
-        raise NotImplementedError("auxiliary networks (PositionMLP / PositionDirectionMLP) are built for netdepth=8, netwidth=256, multires=10, multires_views=4")
     # ibl_nerf.py:292-304: both are PositionDirectionMLPs; render_rays only ever evaluates the depth_mlp (:722-726)
-    depth_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_depth", False) else None
-    visibility_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, out_ch=1) if getattr(args, "infer_visibility", False) else None
-    aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, out_ch=out_ch) if getattr(args, flag, False) else None)
+    in_ch, in_chv = 3 + 6 * args.multires, 3 + 6 * args.multires_views
+    depth_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, input_ch=in_ch, input_ch_views=in_chv, out_ch=1) if getattr(args, "infer_depth", False) else None
+    visibility_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, input_ch=in_ch, input_ch_views=in_chv, out_ch=1) if getattr(args, "infer_visibility", False) else None
+    aux = {name: (PositionMLP(D=args.netdepth, W=args.netwidth, input_ch=in_ch, out_ch=out_ch) if getattr(args, flag, False) else None)
            for name, flag, out_ch in (("albedo_mlp", "infer_albedo_separate", 3), ("roughness_mlp", "infer_roughness_separate", 1),
                                       ("irradiance_mlp", "infer_irradiance_separate", 1), ("normal_mlp", "infer_normal", 3))}   # ibl_nerf.py:307-326
     mk = lambda: IBLNeRF(D=args.netdepth, W=args.netwidth, input_ch=3 + 6 * args.multires, input_ch_views=3 + 6 * args.multires_views,

@@ -214,6 +214,7 @@ class Renderer:
             B.check(self.ctx, self.lib.iblnerf_clear_aux(self.ctx, kind))
         else:
             sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
+            sd = ck.embed_position_mlp(sd)          # (a smaller PositionMLP: the member of the built shape that computes the same function)
             if tuple(sd["out_linears.weight"].shape) != (out_ch, 256):
                 raise ValueError("%s.out_linears must be [%d,256]" % (name, out_ch))
             for ch in range(out_ch):

@@ -153,11 +153,12 @@ def position_mlp_query(aux_sd, pts):
     after layer 4) then out_linears, no activation.  pts [N,S,3] -> [N,S,out_ch]."""
     pts = np.asarray(pts, dtype=F32)
     N, S, _ = pts.shape
-    e = embed(pts.reshape(-1, 3), 10)
+    depth = 1 + max(int(k.split(".")[1]) for k in aux_sd if k.startswith("positions_linears.") and k.endswith(".weight"))      # (any D / W / multires: read off the state dict)
+    e = embed(pts.reshape(-1, 3), (aux_sd["positions_linears.0.weight"].shape[1] - 3) // 6)
     h = e
-    for i in range(8):
+    for i in range(depth):
         h = relu(_lin(aux_sd, "positions_linears.%d" % i, h))
-        if i == 4:
+        if i == 4 and depth > 5:
             h = np.concatenate([e, h], -1)
     return _lin(aux_sd, "out_linears", h).reshape(N, S, -1).astype(F32)
 
@@ -167,15 +168,18 @@ def position_direction_mlp_query(sd, pts, viewdirs):
     ibl_nerf.py:236-252): pts [N,S,3], viewdirs [N,3] -> [N,S,out_ch].  Trunk as IBLNeRF's, feature_linear without activation,
     cat([feature, embedded dirs]) through four ReLU view layers of width 128, final_linear."""
     N, S = pts.shape[:2]
-    e_p = embed(pts.reshape(-1, 3), 10)
-    e_d = embed(np.repeat(viewdirs[:, None, :], S, 1).reshape(-1, 3), 4)
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("positions_linears.") and k.endswith(".weight"))
+    n_view = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("views_linears.") and k.endswith(".weight"))
+    width = sd["positions_linears.0.weight"].shape[0]
+    e_p = embed(pts.reshape(-1, 3), (sd["positions_linears.0.weight"].shape[1] - 3) // 6)
+    e_d = embed(np.repeat(viewdirs[:, None, :], S, 1).reshape(-1, 3), (sd["views_linears.0.weight"].shape[1] - width - 3) // 6)
     h = e_p
-    for i in range(8):
+    for i in range(depth):
         h = relu(_lin(sd, "positions_linears.%d" % i, h))
-        if i == 4:
+        if i == 4 and depth > 5:
             h = np.concatenate([e_p, h], -1)
     h = np.concatenate([_lin(sd, "feature_linear", h), e_d], -1)
-    for i in range(4):
+    for i in range(n_view):
         h = relu(_lin(sd, "views_linears.%d" % i, h))
     return _lin(sd, "final_linear", h).reshape(N, S, -1)
 

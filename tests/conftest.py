@@ -55,8 +55,9 @@ def load_golden(name):
 def golden_aux(g):
     """{'albedo_mlp' | 'roughness_mlp' | 'irradiance_mlp': PositionMLP state dict} of a fixture rendered with auxiliary networks."""
     from ibl_nerf_amd import checkpoint as ck
-    return {k[5:]: (ck.synthetic_position_direction_mlp(int(g[k]), 1, float(g["gain"])) if k == "aux__depth_mlp"
-                    else ck.synthetic_position_mlp(int(g[k]), ck.AUX_OUT_CH[k[5:]], float(g["gain"]))) for k in g.files if k.startswith("aux__")}
+    arch = tuple(int(v) for v in g["arch"]) if "arch" in g.files else None       # (a smaller architecture: every network of the fixture in its own shapes)
+    return {k[5:]: (ck.synthetic_position_direction_mlp(int(g[k]), 1, float(g["gain"]), arch) if k == "aux__depth_mlp"
+                    else ck.synthetic_position_mlp(int(g[k]), ck.AUX_OUT_CH[k[5:]], float(g["gain"]), arch)) for k in g.files if k.startswith("aux__")}
 
 
 def rel_linf(x, ref):
@@ -68,7 +69,7 @@ def rel_linf(x, ref):
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
-                   "infernormal_surface_g10", "inferdepth_g10", "edit3_g10", "arch_6x128_g10", "arch_4x64_g10", "arch_7x200_g10"]
+                   "infernormal_surface_g10", "inferdepth_g10", "edit3_g10", "arch_6x128_g10", "arch_4x64_g10", "arch_7x200_g10", "arch_aux_6x128_g10"]
 FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert", "fitted_wide"]   # rendered by the reference from the fitted checkpoint (fitted_wide: 1 024 rays, maps only)
 
 
@@ -139,4 +140,4 @@ def teacher_pass(g, p):
 
 # fixtures whose recorded main-network raw rows are the whole input of raw2outputs (no auxiliary / normal network outputs, which the
 # recorder does not keep)
-TEACHER_FIXTURES = [n for n in RENDER_FIXTURES if not n.startswith(("auxmlp", "infernormal", "inferdepth"))] + FITTED_FIXTURES
+TEACHER_FIXTURES = [n for n in RENDER_FIXTURES if not n.startswith(("auxmlp", "infernormal", "inferdepth", "arch_aux"))] + FITTED_FIXTURES

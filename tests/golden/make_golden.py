@@ -311,16 +311,16 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     if aux:  # infer_{albedo,roughness,irradiance}_separate: seeded PositionMLPs (src/networks/MLP.py) beside the main networks
         for j, aux_name in enumerate(("albedo_mlp", "roughness_mlp", "irradiance_mlp")):
             aux_seeds[aux_name] = 100 * seed + j
-            sd_a = ck.synthetic_position_mlp(aux_seeds[aux_name], ck.AUX_OUT_CH[aux_name], gain)
+            sd_a = ck.synthetic_position_mlp(aux_seeds[aux_name], ck.AUX_OUT_CH[aux_name], gain, arch)
             kw[aux_name].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
     if infer_normal:  # normal_mlp: a PositionMLP with three outputs (ibl_nerf.py:307-310)
         aux_seeds["normal_mlp"] = 100 * seed + 3
-        sd_a = ck.synthetic_position_mlp(aux_seeds["normal_mlp"], 3, gain)
+        sd_a = ck.synthetic_position_mlp(aux_seeds["normal_mlp"], 3, gain, arch)
         kw["normal_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
         assert kw["infer_normal"] is True
     if infer_depth:   # depth_mlp: a PositionDirectionMLP evaluated once per ray at the origin (ibl_nerf_renderer.py:722-726)
         aux_seeds["depth_mlp"] = 100 * seed + 1   # (a seed whose outputs straddle 0: the relu of :724 is exercised)
-        sd_a = ck.synthetic_position_direction_mlp(aux_seeds["depth_mlp"], 1, gain)
+        sd_a = ck.synthetic_position_direction_mlp(aux_seeds["depth_mlp"], 1, gain, arch)
         kw["depth_mlp"].load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()})
         assert kw["infer_depth"] is True
     kw.update(near=near, far=far)
@@ -1155,6 +1155,8 @@ def main(only=None):
     run_fixture("arch_6x128_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=21, arch=(6, 128, 6, 2))       # own skip layer, fewer frequencies
     run_fixture("arch_4x64_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=22, arch=(4, 64, 10, 4))        # no skip layer: four identity layers
     run_fixture("arch_7x200_g10", torch, R, M, lut, n_rays=48, n_importance=64, gain=1.0, seed=23, arch=(7, 200, 8, 3), mode="insert")     # odd width, one identity layer, insert overrides
+    # ... with every auxiliary network in the same small shape (PositionMLP x 4, the depth_mlp a PositionDirectionMLP with D // 2 = 3 view layers of W // 2)
+    run_fixture("arch_aux_6x128_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=24, arch=(6, 128, 6, 2), aux=True, infer_normal=True, infer_depth=True)
     # is_color_independent_to_direction (ibl_nerf.py:192): radiance heads on the trunk output, no feature / view layers
     run_fixture("colorindep_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=8, color_independent=True)
     # ground-truth normals instead of the eps-normal (no offset queries)

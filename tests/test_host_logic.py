@@ -702,6 +702,20 @@ def test_checkpoint_roundtrip_and_discovery():
     for bad in (dict(W=512), dict(D=9), dict(D=5), dict(input_ch=69), dict(coarse_radiance_number=2), dict(skips=(3,))):
         with pytest.raises(NotImplementedError):
             M.IBLNeRF(**bad)
+    # ... the auxiliary networks likewise (create_IBLNeRF builds them with the same netdepth / netwidth / multires, ibl_nerf.py:293-323)
+    with tempfile.TemporaryDirectory() as d3:
+        os.makedirs(os.path.join(d3, "exp"))
+        kw4 = M.create_IBLNeRF(M.default_args(basedir=d3, netdepth=6, netwidth=128, multires=6, multires_views=2, infer_albedo_separate=True, infer_normal=True, infer_depth=True))[1]
+    assert kw4["albedo_mlp"].arch == (6, 128, 6) and kw4["normal_mlp"].out_ch == 3 and kw4["depth_mlp"].arch == (6, 128, 6, 2)
+    sd_small = ck.synthetic_position_mlp(4, 3, 1.0, (6, 128, 6))
+    kw4["albedo_mlp"].load_state_dict(sd_small)
+    big = ck.embed_position_mlp(sd_small)
+    assert big["out_linears.weight"].shape == (3, 256) and ck.embed_position_mlp(big) is big and ck.aux_channel_blob(sd_small, 1).size == ck.N_PARAMS
+    pd = ck.embed_position_direction_mlp(kw4["depth_mlp"].state_dict())
+    assert list(pd) == [n + t for n, _, _ in ck.posdir_schema(1) for t in (".weight", ".bias")] and np.array_equal(pd["views_linears.3.weight"][:64, :64], np.eye(64, dtype=np.float32)) and float(np.abs(pd["views_linears.3.weight"]).sum()) == 64.0      # (D // 2 = 3 view layers of W // 2 = 64: the fourth is the identity on the live units)
+    assert ck.posdir_blob(kw4["depth_mlp"].state_dict()).size == 644865
+    with pytest.raises(NotImplementedError):
+        M.PositionMLP(D=8, W=512)
 
 
 def test_unsupported_flags_raise():
