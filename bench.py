@@ -32,6 +32,11 @@ FOV_DEG = 60.0
 NEAR, FAR = 0.5, 8.0
 N_SAMPLES, N_IMPORTANCE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# algorithmic FLOPs per camera ray, SURVEY.md 8(d) mode (i) as csrc/api.cpp prices it (2 x nn.Linear MACs, every sample of every query once):
+# (64 + 192) full + (256 + 768) trunk + 128 reflected evaluations; mode (ii) (--inference-min): the coarse pass 64 trunk evaluations only
+F_FULL, F_TRUNK, F_REFL = 1591552.0, 982528.0, 1458944.0
+F_ALG_PER_RAY = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * F_FULL + 4 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * F_TRUNK + 2 * N_SAMPLES * F_REFL
+F_ALG_PER_RAY_MIN = N_SAMPLES * F_TRUNK + (N_SAMPLES + N_IMPORTANCE) * F_FULL + 4 * (N_SAMPLES + N_IMPORTANCE) * F_TRUNK + N_SAMPLES * F_REFL
 # per mlp_precision: (dtype string, kernels, matrix-core products per algorithmic MAC)
 MODES = {
     "auto": ("per checkpoint, measured at load (renderer.calibrate): the fast table f16x3_mxfp6x — f16 hi/lo splits x3 products (~2^-22 per operand) where errors are amplified "
@@ -300,22 +305,18 @@ def main():
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
-    # The checkpoint's ROUTE (which queries run as estimate + list, on which estimates: Renderer.decide_route) and, for mlp_precision="auto", its precision table
-    # (Renderer.calibrate) are measured here, once, on 4 096 seeded pixels of the whole frame (the same on every rank) — part of loading a checkpoint, like the
-    # weight upload, not of a frame; `calibration_ms` reports what it costs
-    torch.cuda.synchronize()
-    t_cal = time.perf_counter()
-    policy = D.calibrate_on_frame(r, H, W, K, c2w, NEAR, FAR)
-    torch.cuda.synchronize()
-    calibration_ms = 1e3 * (time.perf_counter() - t_cal)
+    # What a frame is rendered under — its ROUTE (which queries run as estimate + list, on which estimates: Renderer._measure_route) and, for mlp_precision="auto",
+    # its precision table (FAST / SAFE: Renderer._measure_table) — is measured PER FRAME since round 6, inside the render call and inside the timed region, on 4 096
+    # seeded pixels of the whole frame (the same on every rank: `probe`): the answer depends on the camera, so a view must not inherit another view's.
+    # `decision_ms_per_frame` reports what that costs.
     rows = D.tile_row_indices(H, rank, world, args.partition)      # interleaved: rank, rank + world, ... (a ray's cost depends on what it sees: every rank gets the same mix)
     n_rows = len(rows)
-    ro, rd = r.get_rays(H, W, K, c2w)                   # rays resident in HBM before the timed region
-    sl = slice(rows.start, rows.stop, rows.step)
-    ro, rd = ro[sl].reshape(-1, 3).contiguous(), rd[sl].reshape(-1, 3).contiguous()
+    ro, rd = r.get_rays_strided(H, W, K, c2w, rows.start, rows.step, n_rows)      # this rank's rows only; rays resident in HBM before the timed region
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    probe = D.frame_probe_for_call(r, H, W, K, c2w, NEAR, FAR)
 
     def step(events=None):
-        maps = r.render_rays(ro, rd, NEAR, FAR)
+        maps = r.render_rays(ro, rd, NEAR, FAR, probe=probe, alarm_sync=D.alarm_sync() if grouped else None)
         if grouped:
             if events:
                 events[0].record()
@@ -357,7 +358,7 @@ def main():
         r2.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        r2.render_rays(ro, rd, NEAR, FAR)
+        r2.render_rays(ro, rd, NEAR, FAR, probe=probe)
         torch.cuda.synchronize()
         value_min = H * W / (time.perf_counter() - t1)
         del r2
@@ -373,7 +374,7 @@ def main():
             r3.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            r3.render_rays(ro, rd, NEAR, FAR)
+            r3.render_rays(ro, rd, NEAR, FAR, probe=probe)
             torch.cuda.synchronize()
             by_precision[mode] = H * W / (time.perf_counter() - t1)
             del r3
@@ -389,14 +390,14 @@ def main():
             r4.load_weights(0, c4)
             r4.load_weights(1, f4)
             r4.load_lut(lut)
-            pol4 = D.calibrate_on_frame(r4, H, W, K, c2w, NEAR, FAR)
-            r4.render_rays(ro, rd, NEAR, FAR)          # (one untimed frame: a tripwire event — once per checkpoint, the call repeated — must not land in the timed one)
+            r4.render_rays(ro, rd, NEAR, FAR, probe=probe)          # (one untimed frame: allocations, code objects)
             torch.cuda.synchronize()
+            trips0 = r4.trips
             t1 = time.perf_counter()
-            r4.render_rays(ro, rd, NEAR, FAR)
+            r4.render_rays(ro, rd, NEAR, FAR, probe=probe)          # the frame as every frame is rendered: its own decision, its own tripped rays repeated
             torch.cuda.synchronize()
-            by_checkpoint[kind] = {"value": H * W / (time.perf_counter() - t1), "decision": (pol4 or {}).get("decision"), "route": r4.get_route(), "trips": r4.trips,
-                                   "slot_units_per_ray": r4.last_slot_units() / (H * W)}
+            by_checkpoint[kind] = {"value": H * W / (time.perf_counter() - t1), "decision": (r4.policy or {}).get("decision"), "route": r4.get_route(),
+                                   "rays_repeated_by_the_tripwire": r4.trips - trips0, "probe_escalations": (r4.route or {}).get("probe_escalations")}
             del r4
 
     # the balance of an 8-rank frame on ONE GPU: each of the 8 contiguous bands and each of the 8 interleaved row sets of the frame rendered by itself
@@ -410,22 +411,33 @@ def main():
                 rr = D.tile_row_indices(H, tr, 8, part)
                 ts = slice(rr.start, rr.stop, rr.step)
                 to, td = fo[ts].reshape(-1, 3).contiguous(), fd[ts].reshape(-1, 3).contiguous()
-                r.render_rays(to, td, NEAR, FAR)
+                r.render_rays(to, td, NEAR, FAR, probe=probe)
                 torch.cuda.synchronize()
                 best = 1e30
                 for _ in range(2):
                     t1 = time.perf_counter()
-                    r.render_rays(to, td, NEAR, FAR)
+                    r.render_rays(to, td, NEAR, FAR, probe=probe)
                     torch.cuda.synchronize()
                     best = min(best, 1e3 * (time.perf_counter() - t1))
                 ms.append(best)
             tile_ms[part] = {"ms": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms))}
 
     # dominant kernel (fused MLP), HIP events around every launch on the launch stream (untimed extra step)
+    # what the per-frame decision costs: the same measurement on its own (untimed extra)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    r._decide_for_call(ro, rd, NEAR, FAR, None, {}, probe)
+    torch.cuda.synchronize()
+    decision_ms = 1e3 * (time.perf_counter() - t1)
+    policy = r.policy
     r.set_profiling(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if grouped else None
+    trips_before = r.trips
     step(ev)
     torch.cuda.synchronize()
+    # (the events are those of the step's LAST library call: the frame's own render — its probe renders ran before it — unless the tripwire marked rays, whose repeat
+    # then is the last call; `profiled_call` says which)
+    profiled_call = "frame render" if r.trips == trips_before else "repeat of %d tripped rays (the MLP-only figures below describe that call, not the frame)" % (r.trips - trips_before)
     mlp_ms, n_launch, flop = r.last_mlp_time()
     flop_executed, selection, slot_units = r.last_executed_flops(), r.last_selection(), r.last_slot_units()
     r.set_profiling(False)
@@ -433,13 +445,16 @@ def main():
     # packing the export maps into one buffer, and the all-gather (host-staged under the gloo test hook)
     pack_ms = ev[0].elapsed_time(ev[1]) if grouped else None
     gather_ms = ev[1].elapsed_time(ev[2]) if grouped else None
-    achieved = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    achieved_mlp_only = flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    value = H * W * args.steps / dt
+    f_alg = F_ALG_PER_RAY_MIN if args.inference_min else F_ALG_PER_RAY
+    achieved = value * f_alg / 1e12                     # TFLOP/s of the WHOLE driver-timed step: every kernel, every probe render, the exchange
 
     if rank == 0:
         traffic, traffic_src = pmc_traffic(args.mlp_precision)
         line = {
             "metric": "rays/sec (64c+128f samples) at 800x800 Kitchen; PSNR vs ref",
-            "value": H * W * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": {"bf16x3": "bf16 (3 MFMA products on hi/lo splits), fp32 accumulate"}.get(
@@ -451,12 +466,17 @@ def main():
                                    + (", inference-minimum coarse pass" if args.inference_min else ", full result dict incl. coarse '0' maps"),
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
                        "mlp_precision": args.mlp_precision, "policy": policy, "route": r.get_route(), "route_table": r.describe_route().splitlines(),
-                       "calibration_ms": calibration_ms, "partition": args.partition, "tripwire_events": r.trips,
+                       "decision_scope": "per frame, inside the timed step: route + precision table measured on 4 096 seeded pixels of the frame (the same on every rank)",
+                       "decision_ms_per_frame": decision_ms, "partition": args.partition, "rays_repeated_by_the_tripwire": r.trips, "probe_escalations": r.probe_escalations,
                        **({"query_routing": routing} if routing else {}),
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if grouped else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         # frac = value x F_alg / peak: the driver-timed number, nothing else in the denominator (round 5 divided by MLP-launch time only; that figure is
+                         # frac_mlp_only below)
+                         "frac": achieved / PEAK_BF16_TFLOPS, "flop_per_ray": f_alg,
+                         "frac_mlp_only": achieved_mlp_only / PEAK_BF16_TFLOPS, "achieved_mlp_only": achieved_mlp_only, "profiled_call": profiled_call,
+                         "traffic": traffic,
                          # HBM bytes per camera ray (counter bytes of a frame's MLP launches / rays) over SURVEY 8(d)'s fused-ideal 236 B per ray:
                          # points in, raw rows out and back in; ~0.2 % of HBM bandwidth at this frame rate, so a ratio to watch, not a time bound
                          "traffic_ratio": (traffic * n_launch / (H * W // world) / 236.0) if traffic else None,
@@ -468,6 +488,8 @@ def main():
                          # run the coarse main / coarse-offset / reflected queries as a trunk-only density estimate everywhere and the rest on the relevant samples
                          "executed": {"tflops": flop_executed / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
                                       "frac": (flop_executed / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if mlp_ms > 0 else 0.0,
+                                      # ... and over the whole driver-timed step: MACs the frame's render really evaluated x 2 x frames / wall time
+                                      "frac_whole_step": flop_executed * world * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
                                       "share_of_algorithmic": flop_executed / flop if flop else None,
                                       "samples_refined": selection[0], "of_candidates": selection[1],
                                       # what governs speed on a power-bound chip (STATE.md section 2): per launch points x 64-MAC groups x the matrix slots its
@@ -494,6 +516,11 @@ def main():
         if by_checkpoint:
             line["value_by_checkpoint"] = dict({k: v["value"] for k, v in by_checkpoint.items()}, **{args.checkpoint: line["value"]})
             line["by_checkpoint"] = by_checkpoint
+            fitted = {k: v for k, v in line["value_by_checkpoint"].items() if k.startswith("fitted")}
+            worst = min(fitted, key=fitted.get)
+            # the headline beside its worst case: the slowest of the fitted scenes (the random-init "synthetic" fog is no scene: every sample relevant, lists off)
+            line["value_worst_checkpoint"] = {"checkpoint": worst, "value": fitted[worst], "ratio_to_best": fitted[worst] / max(fitted.values()),
+                                              "frac": fitted[worst] * f_alg / 1e12 / PEAK_BF16_TFLOPS}
         if tile_ms:
             line["tile_ms"] = tile_ms
         if world == 1 and not args.no_cpu_baseline:

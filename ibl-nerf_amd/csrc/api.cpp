@@ -112,7 +112,10 @@ struct iblnerf_ctx {
     float est_error[2] = {-1.f, -1.f};            // ... and the largest plain-f16 estimate error the probe saw near zero density (-1: not measured)
     bool deciding = false;                        // inside iblnerf_decide_route's probe render: the only place a decision of the route is taken
     bool route_decided = false;                   // iblnerf_route.decided
-    int tripped = 0;                              // the estimate tripwire has fired since the decision (fold_flags): 1 = the estimates moved to f16 + 2 fp6, 2 = the lists went off
+    int tripped = 0;                              // iblnerf_escalate_route has been applied since the decision: 1 = margins doubled / the estimates moved to f16 + 2 fp6, 2 = the lists went off
+    bool lists_off = false;                       // iblnerf_set_lists(ctx, 0): every query evaluates all of its samples whatever the route says (the repeat of a tripped ray)
+    unsigned char* trip_rays = nullptr;           // the current launch's slice of iblnerf_outputs.trip_rays (k_tripwire marks the rays whose estimates were thin), or null
+    long cur_R = 1;                               // ... and that launch's ray count
     double coarse_share = -1.0;                   // the probe's relevant share of the coarse grid (sel_on = it is <= SELECT_MAX_FRACTION)
     bool offsets_estimate_all = false;            // IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL: round 4's offsets (an estimate on every sample of every copy)
     int* main_range = nullptr;                    // [ws_rays][2] first / last relevant sample of each ray's main query in the current pass (k_select_points range_out)
@@ -610,7 +613,36 @@ int iblnerf_get_rays(iblnerf_ctx* c, void* stream, int H, int W, const float* h_
     Camera cam;
     std::memcpy(cam.K, h_K, sizeof cam.K);
     std::memcpy(cam.c2w, h_c2w, sizeof cam.c2w);
-    HIP_TRY(c, launch_get_rays(W, row0, n_rows, cam, d_rays_o, d_rays_d, (hipStream_t)stream));
+    HIP_TRY(c, launch_get_rays(W, row0, 1, n_rows, nullptr, cam, d_rays_o, d_rays_d, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_get_rays_strided(iblnerf_ctx* c, void* stream, int H, int W, const float* h_K, const float* h_c2w, int row0, int row_step, int n_rows,
+                             float* d_rays_o, float* d_rays_d) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!h_K || !h_c2w || H <= 0 || W <= 0 || row0 < 0 || row_step < 1 || n_rows < 0 || (n_rows > 0 && (long)row0 + (long)(n_rows - 1) * row_step >= H) ||
+        (n_rows > 0 && (!d_rays_o || !d_rays_d)))
+        return c->fail(IBLNERF_ERR_INVALID, "get_rays_strided: bad arguments (H=%d W=%d row0=%d row_step=%d n_rows=%d)", H, W, row0, row_step, n_rows);
+    if (n_rows == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    Camera cam;
+    std::memcpy(cam.K, h_K, sizeof cam.K);
+    std::memcpy(cam.c2w, h_c2w, sizeof cam.c2w);
+    HIP_TRY(c, launch_get_rays(W, row0, row_step, n_rows, nullptr, cam, d_rays_o, d_rays_d, (hipStream_t)stream));
+    return IBLNERF_OK;
+}
+
+int iblnerf_get_rays_pixels(iblnerf_ctx* c, void* stream, int H, int W, const float* h_K, const float* h_c2w, const int64_t* d_pixels, int64_t n_pixels,
+                            float* d_rays_o, float* d_rays_d) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!h_K || !h_c2w || H <= 0 || W <= 0 || n_pixels < 0 || (n_pixels > 0 && (!d_pixels || !d_rays_o || !d_rays_d)))
+        return c->fail(IBLNERF_ERR_INVALID, "get_rays_pixels: bad arguments (H=%d W=%d n_pixels=%lld)", H, W, (long long)n_pixels);
+    if (n_pixels == 0) return IBLNERF_OK;
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    Camera cam;
+    std::memcpy(cam.K, h_K, sizeof cam.K);
+    std::memcpy(cam.c2w, h_c2w, sizeof cam.c2w);
+    HIP_TRY(c, launch_get_rays(W, 0, 1, (long)n_pixels, reinterpret_cast<const long long*>(d_pixels), cam, d_rays_o, d_rays_d, (hipStream_t)stream));
     return IBLNERF_OK;
 }
 
@@ -760,7 +792,7 @@ static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which,
         HIP_TRY(c, launch_trunk_fp32(f, c->n_cu, s));
         if (ev32) HIP_TRY(c, hipEventRecord(ev32->second, s));
         if (m.trip_margin > 0.0f && m.n_pts_dev != nullptr && m.out_index == c->sel_index)
-            HIP_TRY(c, launch_tripwire(c->sel_est, c->sel_index, m.n_pts_dev, m.out, m.out_stride, m.trip_margin, c->d_range_flag, m.n_pts, s));
+            HIP_TRY(c, launch_tripwire(c->sel_est, c->sel_index, m.n_pts_dev, m.out, m.out_stride, m.trip_margin, c->d_range_flag, m.n_pts, s, c->trip_rays, m.pts_per_ray, c->cur_R));
         if (m.n_pts_dev == nullptr) {
             c->flop_exec += (double)m.n_pts * FLOP_TRUNK;
             c->slot_units += (double)m.n_pts * FLOP_TRUNK / 128.0 * launch_slots(l);
@@ -797,7 +829,7 @@ static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which,
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, s));
     if (m.trip_margin > 0.0f && m.n_pts_dev != nullptr && m.out_index == c->sel_index)
         HIP_TRY(c, launch_tripwire(c->sel_est, c->sel_index, m.n_pts_dev, m.out, m.out_stride * (variant_albirr(l.variant) ? RAW_CH : l.variant == VAR_REFL_LIST ? REFL_CH : 1),
-                                   m.trip_margin, c->d_range_flag, m.n_pts, s));
+                                   m.trip_margin, c->d_range_flag, m.n_pts, s, c->trip_rays, m.pts_per_ray, c->cur_R));
     // what the launch costs (whole batches here; list launches: k_count_selection adds theirs on the device, sel_count[4..7])
     const int flop_variant = l.variant == VAR_TRUNK_X ? VAR_TRUNK : l.variant;
     if (m.n_pts_dev == nullptr) {
@@ -1249,29 +1281,12 @@ int iblnerf_sample_pdf_u(iblnerf_ctx* c, void* stream, const float* d_bins, cons
 }
 
 // Folds a snapshot of the flag words into the context: a flagged slot runs on the bf16x3 kernel from now on.
+// Bits 2, 3, 4 — the estimate tripwire: a list launch refined a positive density whose estimate was half-way to being dropped (2), or overshot beyond what the conservative
+// transmittance allows for (3), or — an audited sample — had BEEN dropped (4) — are REPORTED, not acted on (round 5 widened the margins here, per context and for good: results then depended on which calls a context
+// had seen, and under sharding on the rank).  What follows from them is the caller's: the rays are marked in iblnerf_outputs.trip_rays and rendered once more with
+// iblnerf_set_lists(ctx, 0); a PROBE that trips escalates the route it is deciding (iblnerf_escalate_route).
 static int fold_flags(iblnerf_ctx* c, const unsigned* v) {
-    int any = (int)(v[0] & 15u);      // bit 0: an activation / input left the f16 range; bit 1: only a backward's gradients did (mlp_kernel.hip);
-                                     // bits 2, 3: the estimate tripwire — a list launch refined a positive density whose plain-f16 estimate was half-way to being
-                                     // dropped (2), or overshot beyond what the conservative transmittance allows for (3)
-    if (v[0] & 12u) {
-        // The estimate tripwire.  In order of what it costs: (1) an UNDERESTIMATE on plain-f16 estimates (bit 2 alone) doubles both selection margins, up to MARGIN_MAX — a few
-        // more samples refined; (2) otherwise the plain-f16 estimates go: f16 + 2 fp6 from now on (six matrix slots instead of four per estimate, nothing else changes);
-        // (3) on f16 + 2 fp6 estimates already (a network whose density cancels beyond THAT form's 2^-16: tests/test_gpu_fitted.py builds one) no estimate of this
-        // checkpoint can be trusted — the lists go off, every query evaluates all of its samples.  Either way the call that raised the flag is to be repeated.
-        const bool six = !c->est_f16 || (c->est_checked[0] && !c->est_ok[0]) || (c->est_checked[1] && !c->est_ok[1]);
-        if (six) {
-            c->est_ok[0] = c->est_ok[1] = false;
-            c->sel_decided = true; c->sel_on = false;
-            c->tripped = 2;
-        } else if ((v[0] & 12u) == 4u && std::min(c->margin[0], c->margin[1]) < MARGIN_MAX) {
-            for (int w = 0; w < 2; ++w) c->margin[w] = std::min(MARGIN_MAX, 2.0f * c->margin[w]);
-            c->tripped = 1;
-        } else {
-            c->est_ok[0] = c->est_ok[1] = false;
-            c->margin[0] = c->margin[1] = COARSE_SELECT_MARGIN;
-            c->tripped = 1;
-        }
-    }
+    int any = (int)(v[0] & 31u);      // bit 0: an activation / input left the f16 range; bit 1: only a backward's gradients did (mlp_kernel.hip); bits 2, 3, 4: the tripwire
     for (int slot = 0; slot < N_SLOTS; ++slot)
         if (v[1 + slot]) { c->mx_ok[slot] = false; any |= 1; }
     return any;
@@ -1999,6 +2014,12 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     c->slot_units = 0.0;
     HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 8 * sizeof(int), s));
     const int Sc = c->Sc, Sf = c->Sf;
+    // iblnerf_set_lists(ctx, 0): this call runs as a context whose lists are off does (every query evaluates all of its samples), whatever route is decided
+    struct ListsOff {
+        iblnerf_ctx* c; bool on, decided, sel;
+        explicit ListsOff(iblnerf_ctx* c_) : c(c_), on(c_->lists_off && !c_->deciding), decided(c_->sel_decided), sel(c_->sel_on) { if (on) { c->sel_decided = true; c->sel_on = false; } }
+        ~ListsOff() { if (on) { c->sel_decided = decided; c->sel_on = sel; } c->trip_rays = nullptr; }
+    } lists_guard(c);
     HIP_TRY(c, launch_coarse_z(near_, far_, Sc, c->opt.lindisp, c->zc, s));
     if ((t_rand || near_ray) && !c->zc_ray) HIP_TRY(c, hipMalloc((void**)&c->zc_ray, (size_t)c->ws_rays * Sc * sizeof(float)));
     // equal-sized launches (a short tail launch would leave most of the persistent grid idle)
@@ -2023,6 +2044,8 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         }
         const float* nr = near_ray ? near_ray + r0 : nullptr;
         const float* fr = far_ray ? far_ray + r0 : nullptr;
+        c->trip_rays = outs->trip_rays ? outs->trip_rays + r0 : nullptr;      // (k_tripwire marks the rays of this launch whose estimates were thin)
+        c->cur_R = R;
         int rc;
         // taps (iblnerf_render_rays_tapped): this launch's z rows and main raw rows, out of the workspace before the next pass reuses it
         auto tap_z = [&](float* dst, const float* z, int zstride, int S) -> int {
@@ -2207,6 +2230,37 @@ int iblnerf_set_route(iblnerf_ctx* c, const iblnerf_route* r) {
         c->margin[w] = (r->select_margin[w] >= COARSE_SELECT_MARGIN && r->select_margin[w] <= MARGIN_MAX) ? r->select_margin[w] : COARSE_SELECT_MARGIN;
         c->est_error[w] = r->estimate_error[w];
     }
+    return IBLNERF_OK;
+}
+
+// The ladder a tripped PROBE climbs, in order of what a step costs: (1) an UNDERESTIMATE on plain-f16 estimates (bit 2 alone) doubles both selection margins, up to
+// MARGIN_MAX — a few more samples refined; (2) otherwise the plain-f16 estimates go: f16 + 2 fp6 from now on (six matrix slots instead of four per estimate, nothing
+// else changes); (3) on f16 + 2 fp6 estimates already (a network whose density cancels beyond THAT form's 2^-16: tests/test_gpu_fitted.py builds one) no estimate of
+// this checkpoint can be trusted — the lists go off, every query evaluates all of its samples.
+int iblnerf_escalate_route(iblnerf_ctx* c, int trip_bits) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!(trip_bits & 28)) return c->fail(IBLNERF_ERR_INVALID, "escalate_route: trip_bits carries none of bits 2, 3, 4 of the range flags");
+    if (!c->route_decided) return c->fail(IBLNERF_ERR_STATE, "escalate_route: no route is decided on this context");
+    // (a network the probe refused plain-f16 estimates for counts as "on six slots already" only if the other one is there too, or never takes a list: ADVICE r5)
+    const bool plain0 = est_plain(c, 0), plain1 = est_plain(c, c->have_net[1] ? 1 : 0);
+    if (!plain0 && !plain1) {
+        c->est_ok[0] = c->est_ok[1] = false;
+        c->sel_decided = true; c->sel_on = false;
+        c->tripped = 2;
+    } else if (!(trip_bits & 8) && std::min(c->margin[0], c->margin[1]) < MARGIN_MAX) {
+        for (int w = 0; w < 2; ++w) c->margin[w] = std::min(MARGIN_MAX, 2.0f * c->margin[w]);
+        c->tripped = std::max(c->tripped, 1);
+    } else {
+        c->est_ok[0] = c->est_ok[1] = false;
+        c->margin[0] = c->margin[1] = COARSE_SELECT_MARGIN;
+        c->tripped = std::max(c->tripped, 1);
+    }
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_lists(iblnerf_ctx* c, int enabled) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    c->lists_off = enabled == 0;
     return IBLNERF_OK;
 }
 

@@ -25,7 +25,8 @@ hipError_t launch_pack_weights(const float* d_blob, const PackMaps& maps, char* 
 
 // nerf_renderer_helper.py:36-45.  Rows [row0, row0+n_rows) of an H x W image.
 struct Camera { float K[9]; float c2w[12]; };   // 3x3 intrinsics, 3x4 camera-to-world, row-major (kernel argument)
-hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s);
+// rows row0, row0 + row_step, ... (n_rows of them) of a W-wide image, or — pixels != nullptr — the n_rows listed flat pixel indices
+hipError_t launch_get_rays(int W, int row0, int row_step, long n_rows, const long long* pixels, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s);
 
 // ibl_nerf_renderer.py:670-672: z_k = near (1 - t_k) + far t_k, t = linspace(0,1,S)
 hipError_t launch_coarse_z(float near, float far, int S, int lindisp, float* z, hipStream_t s);
@@ -209,7 +210,9 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                 double list_slots_per_point = 0.0,   // ... and their matrix-slot units per entry (counter[8..9])
                                 float* est_list = nullptr);          // [list length] the estimate of every list entry (for launch_tripwire)
 // the estimate tripwire: after a list launch, every entry's refined density out[index[i] * out_stride] against est_list[i] (k_tripwire); raises bits 2 / 3 of *flag
-hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s);
+// ... and marks the ray of every such entry in trip_rays [R] (nullable; entry -> ray (index / S) % R: offset copies belong to their ray)
+hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s,
+                           unsigned char* trip_rays = nullptr, int S = 1, long R = 1);
 
 // the offset copies' samples by the main ray's relevant range (k_range_points: mode 1 the predicted range, 2 in front of it, 3 behind it for the copies still alive);
 // list length at counter[0] (zeroed by the caller), executed MACs x 2 (flop_per_point per entry) added to counter[4..5], entries to counter[2..3] if count_entries

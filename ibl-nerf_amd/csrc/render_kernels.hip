@@ -151,12 +151,14 @@ __device__ __forceinline__ void right_up(const float (&d)[3], float (&right)[3],
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void k_get_rays(int W, int row0, int n_rows, Camera cam, float* __restrict__ ro, float* __restrict__ rd) {
+// rows row0, row0 + row_step, ... (n_rows of them, W pixels each) — or, pixels != nullptr, the n_rows listed flat pixel indices row * W + col (a probe: any subset of a
+// frame).  Every pixel's ray is computed by itself: a tile's or a probe's rays are the frame's, bit for bit.
+__global__ void k_get_rays(int W, int row0, int row_step, long n_rows, const long long* __restrict__ pixels, Camera cam, float* __restrict__ ro, float* __restrict__ rd) {
     const float* K = cam.K;
     const float* c2w = cam.c2w;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)n_rows * W) return;
-    const int col = (int)(idx % W), row = row0 + (int)(idx / W);
+    if (idx >= (pixels ? n_rows : n_rows * W)) return;
+    const int col = pixels ? (int)(pixels[idx] % W) : (int)(idx % W), row = pixels ? (int)(pixels[idx] / W) : row0 + row_step * (int)(idx / W);
     const float dir[3] = {((float)col - K[2]) / K[0], -((float)row - K[5]) / K[4], -1.0f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -932,13 +934,25 @@ __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ ra
 // clearly empty — raises bit 2 of the range flag; one overshot beyond what the conservative transmittance allows for (0.75 estimate - margin > refined) bit 3:
 // k_compare_estimates' rule, on every launch instead of once per checkpoint.  (A kernel of its own, 0.05 ms: inside the MLP kernels' epilogues the same comparison
 // cost the fast FULL list form its last registers — 20 bytes of scratch, 5.9 -> 9.2 ms per launch.)
+// Round 6: the event is recorded PER RAY — trip_rays[(flat index / S) % R] = 1 (nullable; [R] bytes of the launch's rays: a sample of virtual ray v R + r, an offset
+// copy, belongs to ray r) — so that the caller can render exactly the rays whose estimates were thin once more with every sample evaluated, instead of the
+// whole call under wider margins: a ray's result is then a function of the ray alone, whatever call, launch or rank it is rendered in.
 __global__ void k_tripwire(const float* __restrict__ est_list, const int* __restrict__ index, const int* __restrict__ n_dev, const float* __restrict__ out, int out_stride,
-                           float margin, unsigned* __restrict__ flag) {
+                           float margin, unsigned* __restrict__ flag, unsigned char* __restrict__ trip_rays, int S, long R) {
     const long n = *n_dev;
     unsigned bits = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float refined = out[(long)index[i] * out_stride], est = est_list[i];
-        if (refined > 0.0f) bits |= est < -0.5f * margin ? 4u : (0.75f * est - margin > refined ? 8u : 0u);
+        // bit 2: a positive density whose estimate lay below -margin / 2 — a near miss: the margin is thin on this ray.  bit 4 (with bit 2), round 6: ... below -3/4 of the
+        // margin — DEEP: the margin was set to twice the deepest underestimate the probe saw (+ 0.5), so this estimate is off by 1.5 times what the probe measured, and beyond
+        // -margin itself (only an AUDITED entry can be: the sample had been dropped as clearly empty and was not) it is proof that samples are being dropped wrongly.  Measured
+        // on a network built to break plain-f16 estimates under a route that trusts them (tests/test_gpu_scope.py): 25 near misses of 8 192 rays, and 8 OTHER rays wrong by up
+        // to 0.8 of a weight with no mark at all — near misses are the visible part of an error tail; deep ones say the tail reaches the margin.
+        // bit 3: an estimate overshot beyond what the conservative transmittance allows for — also where the refined density is NOT positive (round 6): an empty sample whose
+        // estimate says "opaque" costs that sample nothing (it is refined), but the transmittance behind it was composited from the estimate.
+        const unsigned b = refined > 0.0f && est <= -0.75f * margin ? 20u : refined > 0.0f && est < -0.5f * margin ? 4u : (0.75f * est - margin > fmaxf(refined, 0.0f) ? 8u : 0u);
+        if (b != 0u && trip_rays != nullptr) trip_rays[((long)index[i] / S) % R] = 1;
+        bits |= b;
     }
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) bits |= (unsigned)__shfl_xor((int)bits, dd);
@@ -954,7 +968,7 @@ __global__ void k_tripwire(const float* __restrict__ est_list, const int* __rest
 // empty sample only costs its refinement.)
 __global__ void k_compare_estimates(const float* __restrict__ a, const float* __restrict__ b, long n, float margin, float zone, int* __restrict__ bad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool wrong = i < n && b[i] > 0.0f && 0.75f * a[i] - margin > b[i];
+    const bool wrong = i < n && 0.75f * a[i] - margin > fmaxf(b[i], 0.0f);        // (round 6: also an EMPTY sample estimated opaque — what lies behind it would be dropped as saturated)
     const unsigned long long m = __ballot(wrong);
     if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(bad, __popcll(m));
     float err = (i < n && b[i] > 0.0f && b[i] <= zone) ? fmaxf(-a[i], 0.0f) : 0.0f;
@@ -1010,6 +1024,11 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
     bool sel[NPL];
     int total = 0;
     unsigned long long masks[NPL];
+    // (the audit's choice of samples, below: a hash of the RAY — direction and origin bits, which offset copy — and of the sample's depth: the same samples whatever launch,
+    // call or rank the ray is rendered in; round 5 hashed the flat index within the launch)
+    const unsigned audit_key = (__builtin_bit_cast(unsigned, d[0]) * 0x9E3779B1u) ^ (__builtin_bit_cast(unsigned, d[1]) * 0x85EBCA77u) ^ (__builtin_bit_cast(unsigned, d[2]) * 0xC2B2AE3Du) ^
+                               (__builtin_bit_cast(unsigned, o[0]) + 0x27D4EB2Fu * __builtin_bit_cast(unsigned, o[1])) ^ (__builtin_bit_cast(unsigned, o[2]) * 0x165667B1u) ^
+                               (OFFSETS ? (unsigned)(vr / R) * 0x9E3779B9u : 0u);
     // skip_range (offset copies, api.cpp offsets_on_lists): the samples [lo, hi] of the ray were predicted relevant and hold their refined density already — they
     // count for the transmittance of what lies behind them, and are not selected again
     int skip_lo = S, skip_hi = -1;
@@ -1026,8 +1045,8 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
         // the AUDIT (round 5): one in AUDIT_ONE_IN of the samples dropped as clearly empty goes to the list all the same.  Its refined density replaces the estimate
         // (both <= 0: alpha = 0 either way, no map changes) — and the tripwire behind the list launch (k_tripwire) sees an estimate that was GROSSLY wrong, which no
         // selected sample would show: a positive density estimated below -margin is never selected, so never refined, so never compared.  Chosen by a hash of the
-        // sample's flat index: the same samples on every route and rank.
-        const bool audit = reachable && !sel[i] && ((unsigned)(vr * S + s) * 2654435761u) >> (32 - AUDIT_LOG2) == 0u;
+        // sample itself (audit_key above): the same samples on every route, launch and rank.
+        const bool audit = reachable && !sel[i] && (audit_key ^ (__builtin_bit_cast(unsigned, z[i]) * 2246822519u)) * 2654435761u >> (32 - AUDIT_LOG2) == 0u;
         first_sel_candidate[i] = sel[i];
         sel[i] = sel[i] || audit;
         T *= om[i];
@@ -1417,10 +1436,10 @@ hipError_t launch_broadcast_rows(const float* row, int S, long R, float* out, hi
     return hipGetLastError();
 }
 
-hipError_t launch_get_rays(int W, int row0, int n_rows, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s) {
-    const long n = (long)n_rows * W;
+hipError_t launch_get_rays(int W, int row0, int row_step, long n_rows, const long long* pixels, const Camera& cam, float* rays_o, float* rays_d, hipStream_t s) {
+    const long n = pixels ? n_rows : n_rows * W;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, row0, n_rows, cam, rays_o, rays_d);
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, row0, row_step, n_rows, pixels, cam, rays_o, rays_d);
     return hipGetLastError();
 }
 
@@ -1536,10 +1555,12 @@ hipError_t launch_range_points(const float* rays_o, const float* rays_d, const f
     return hipGetLastError();
 }
 
-hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s) {
+hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s,
+                           unsigned char* trip_rays, int S, long R) {
     if (n_bound <= 0 || flag == nullptr) return hipSuccess;
     const long blocks = (n_bound + 255) / 256;
-    hipLaunchKernelGGL(k_tripwire, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, est_list, index, n_dev, out, out_stride, margin, flag);
+    hipLaunchKernelGGL(k_tripwire, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, est_list, index, n_dev, out, out_stride, margin, flag, trip_rays,
+                       S > 0 ? S : 1, R > 0 ? R : 1);
     return hipGetLastError();
 }
 

@@ -163,11 +163,13 @@ __global__ __launch_bounds__(256) void k_trunk_fp32(TrunkFp32Args a) {
 
 hipError_t launch_trunk_fp32(const TrunkFp32Args& a, int n_cu, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    static bool configured = false;
-    if (!configured) {
+    static bool attr_set[64] = {};   // per device: the attribute is, and one process may hold contexts on several (iblnerf_options.device)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_fp32), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return e;
-        configured = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const long groups = (a.n + 127) / 128;
     const unsigned grid = (unsigned)(groups < n_cu ? groups : n_cu);

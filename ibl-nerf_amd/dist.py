@@ -9,9 +9,13 @@ backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Per frame and rank: 
 from (K, c2w, rows), render them, pack the wanted maps into one [rows, W, C] buffer, ONE flat
 all-gather (the only exchange step on the path), undo the interleave with a transposed view, unpack.
 Weights/LUT are replicated by each rank's own upload — no broadcast is needed because every rank
-reads the same checkpoint, and every rank measures the checkpoint's route (Renderer.decide_route)
-on the same seeded pixels of the frame: all tiles take one route, and the N-rank frame is the
-1-rank frame bit for bit.
+reads the same checkpoint.  What a frame is rendered under (the route: which queries take lists,
+on which estimates; the precision table of mlp_precision="auto") is measured PER FRAME on the
+frame's seeded probe pixels — generated and measured by every rank for itself, same rays, same
+deterministic kernels — and handed to the tile's render call (Renderer.render_rays probe=); a
+ray the estimate tripwire marks is rendered once more by the rank that owns it.  No decision
+outlives a frame and none depends on a rank's tile: the N-rank frame is the 1-rank frame bit
+for bit, whatever the checkpoint, and so is a view rendered by any rank of a view-sharded export.
 """
 from __future__ import annotations
 
@@ -143,20 +147,38 @@ def render_frame_sharded(render_tile: Callable[..., Dict[str, "object"]], H: int
     return unpack_maps(full, layout)
 
 
-def frame_probe(renderer, H, W, K, c2w, n=4096, seed=0):
-    """`n` seeded pixels of the WHOLE frame — the same on every rank — as rays: what a checkpoint's route and precision table are measured on."""
+def probe_pixels(H, W, n=4096, seed=0):
+    """`n` seeded pixels of an H x W frame (sorted flat indices) — a function of (H, W, n, seed) alone: the same on every rank and for every view."""
     import numpy as np
+    return np.sort(np.random.RandomState(seed).permutation(H * W)[:min(n, H * W)])
+
+
+def frame_probe(renderer, H, W, K, c2w, n=4096, seed=0):
+    """`n` seeded pixels of the WHOLE frame — the same on every rank — as rays: what a frame's route and precision table are measured on.  Only those pixels' rays are
+    generated (iblnerf_get_rays_pixels: every pixel's ray is computed by itself, so they are the frame's rays bit for bit)."""
+    return renderer.get_rays_pixels(H, W, K, c2w, probe_pixels(H, W, n, seed))
+
+
+def frame_probe_for_call(renderer, H, W, K, c2w, near, far, gt_values=None, n=4096, seed=0):
+    """The `probe` argument of Renderer.render_rays for a tile of this frame: the frame's seeded pixels as rays, with their rows of the frame's gt_values."""
     import torch
-    pix = np.sort(np.random.RandomState(seed).permutation(H * W)[:min(n, H * W)])
-    ro, rd = renderer.get_rays(H, W, K, c2w)                       # (15 MB for 800 x 800; once per checkpoint)
+    pix = probe_pixels(H, W, n, seed)
+    ro, rd = renderer.get_rays_pixels(H, W, K, c2w, pix)
+    probe = {"rays_o": ro, "rays_d": rd}
     idx = torch.as_tensor(pix, device=ro.device)
-    return ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous()
+    for name, v in (("near", near), ("far", far)):
+        if hasattr(v, "shape") and int(torch.as_tensor(v).numel()) == H * W:
+            probe[name] = torch.as_tensor(v, device=ro.device).reshape(-1)[idx]
+    if gt_values:
+        probe["gt_values"] = {k: (torch.as_tensor(v, device=ro.device).reshape(H * W, -1)[idx] if hasattr(v, "shape") and len(v) == H * W else v) for k, v in gt_values.items()}
+    return probe
 
 
 def decide_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
-    """The checkpoint's route (Renderer.decide_route: which queries run as estimate + list, on which estimates) measured on the frame's seeded probe pixels: every
-    rank measures the same rays with the same deterministic kernels, so all tiles of a frame take one route — whatever the mlp_precision mode, pinned or "auto".
-    A frame too small to measure on (the 9-row frames of the tests) leaves the route undecided: every query then evaluates all of its samples."""
+    """IMPOSES on the renderer the route (Renderer.decide_route: which queries run as estimate + list, on which estimates) measured on the frame's seeded probe pixels,
+    until its next load_weights — an explicit, per-checkpoint decision for callers that want one (A/B measurements, tests).  render_frame does not need it: it hands the
+    same probe to every tile's render call, which then decides for that frame alone.  A frame too small to measure on (the 9-row frames of the tests) leaves the route
+    undecided: every query then evaluates all of its samples."""
     if renderer.route is not None or H * W < renderer.ROUTE_MIN_RAYS or renderer.mlp_precision == "bf16x3" or int(renderer.opt.max_rays_per_launch) < renderer.ROUTE_MIN_RAYS:
         return renderer.route
     ro, rd = frame_probe(renderer, H, W, K, c2w, n, seed)
@@ -164,9 +186,8 @@ def decide_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
 
 
 def calibrate_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
-    """mlp_precision="auto": decide the checkpoint's query routing (Renderer.calibrate) on `n` seeded pixels of the WHOLE frame — the same pixels on
-    every rank, so that all tiles of a frame are rendered under one decision (the kernels are deterministic: same rays, same measurement).  The route
-    (decide_on_frame) is measured first, on the same pixels."""
+    """mlp_precision="auto": IMPOSES the query routing (Renderer.calibrate) decided on `n` seeded pixels of the WHOLE frame, and the route measured on them
+    (decide_on_frame), until the next load_weights — see decide_on_frame."""
     decide_on_frame(renderer, H, W, K, c2w, near, far, n, seed)
     if not getattr(renderer, "_auto", False):
         return renderer.policy
@@ -179,10 +200,10 @@ def calibrate_on_frame(renderer, H, W, K, c2w, near, far, n=4096, seed=0):
 
 def render_frame(renderer, H, W, K, c2w, near, far, keys: Sequence[str] = EXPORT_KEYS, gt_values=None, group=None, partition: str = "interleaved",
                  **edit):
-    """Full frame with the HIP renderer, sharded over the ranks of `group` (or unsharded without one)."""
-    import torch
-    if renderer.route is None or (getattr(renderer, "_auto", False) and renderer.policy is None):
-        calibrate_on_frame(renderer, H, W, K, c2w, near, far)
+    """Full frame with the HIP renderer, sharded over the ranks of `group` (or unsharded without one).  Every rank generates only its own rows' rays
+    (iblnerf_get_rays_strided) and the frame's seeded probe pixels' (frame_probe_for_call), and hands that probe to its tile's render call: all tiles are rendered
+    under the route and precision table of THIS frame — measured on the same rays by the same deterministic kernels on every rank — and a ray the estimate tripwire
+    marks is rendered once more by the rank that owns it (Renderer.render_rays): no state, no exchange, and the N-rank frame is the 1-rank frame bit for bit."""
     gt_values = dict(gt_values or {})
     if edit.get("edit_intrinsic") and edit.get("edit_roughness") and edit.get("edit_roughness_by_img") and "edit_roughness" in gt_values:
         # the one override whose value depends on the reference's chunking of the FLAT frame (ibl_nerf_renderer.py:394-395 inside batchify_rays' chunks of
@@ -191,12 +212,31 @@ def render_frame(renderer, H, W, K, c2w, near, far, keys: Sequence[str] = EXPORT
         m = _dev_f32(gt_values["edit_intrinsic_mask"], renderer.device).reshape(H * W, -1)[:, 0]
         img = _dev_f32(gt_values["edit_roughness"], renderer.device).reshape(H * W, -1)[:, 0]
         gt_values["_edit_roughness_resolved"] = resolve_edit_roughness(m, img, edit.get("chunk", 1024 * 32))
-    full = {}
+    render_kw = {k: v for k, v in edit.items() if k != "chunk"}
+    probe = None
+    if H * W >= renderer.ROUTE_MIN_RAYS and not (renderer._route_imposed() and renderer._policy_imposed()):
+        probe = frame_probe_for_call(renderer, H, W, K, c2w, near, far, gt_values)
 
     def tile(rows):
-        if not full:
-            full["o"], full["d"] = renderer.get_rays(H, W, K, c2w)          # (every pixel's ray is computed by itself: a tile's rays are the frame's, bit for bit)
-        sl = slice(rows.start, rows.stop, rows.step)
-        ro, rd = full["o"][sl].reshape(-1, 3).contiguous(), full["d"][sl].reshape(-1, 3).contiguous()
-        return renderer.render_rays(ro, rd, near, far, slice_gt_rows(gt_values, W, rows), **{k: v for k, v in edit.items() if k != "chunk"})
+        ro, rd = renderer.get_rays_strided(H, W, K, c2w, rows.start, rows.step, len(rows))
+        return renderer.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, slice_gt_rows(gt_values, W, rows), probe=probe, alarm_sync=alarm_sync(group), **render_kw)
     return render_frame_sharded(tile, H, W, keys, group, partition)
+
+
+def alarm_sync(group=None):
+    """The `alarm_sync` argument of Renderer.render_rays for a tile of a sharded frame, or None without a process group: (marked rays, rays, tripwire bits) of this rank's tile
+    -> the frame's (sums and bitwise or over the ranks; one small all-reduce).  The renderer's alarm — escalate the route and render the call again when the marks say the
+    route does not fit — is then decided on the frame's numbers by every rank alike: the tiles stay one frame.  (The common case costs one 3-integer exchange per frame.)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+
+    def sync(marked, total, bits):
+        dev = "cpu" if dist.get_backend(group) == "gloo" else "cuda"
+        # bits as one count per bit: a SUM all-reduce then carries the bitwise OR too
+        t = torch.tensor([marked, total] + [(bits >> b) & 1 for b in range(5)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, group=group)
+        v = t.tolist()
+        return int(v[0]), int(v[1]), sum((1 << b) for b in range(5) if v[2 + b] > 0)
+    return sync

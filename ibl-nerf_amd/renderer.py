@@ -24,6 +24,7 @@ import numpy as np
 from . import binding as B
 from . import checkpoint as ck
 
+TRIP_BITS, TRIP_PROOF = 28, 16      # iblnerf_range_status: bits 2, 3, 4 = the estimate tripwire; bit 4 = a DEEP miss (estimate below -3/4 of the margin; an audited sample that was not empty)
 MAP_KEYS_3 = ["color_map", "radiance_map", "radiance_map_1", "radiance_map_2", "radiance_map_3",
               "reflected_coarse_radiance_map_1", "reflected_coarse_radiance_map_2", "reflected_coarse_radiance_map_3",
               "reflected_radiance_map", "prefiltered_reflected_map", "albedo_map", "specular_map", "diffuse_map",
@@ -58,6 +59,10 @@ def _dev_f32(x, device):
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
     return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _RangeEvent(Exception):
+    """A probe render left the f16 range (Renderer._decide_for_call): answered by render_rays before anything is decided."""
 
 
 class Renderer:
@@ -143,8 +148,11 @@ class Renderer:
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._twin_ref = None        # (mode, Renderer) of precision_report
         self._blobs, self._lut = {}, None
-        self.route = None            # iblnerf_route of the loaded checkpoint as a dict (decide_route), None = not decided yet
-        self.trips = 0               # render calls repeated because the estimate tripwire fired
+        self.route = None            # the iblnerf_route in effect as a dict: the last call's own (measured on its probe) or an imposed one ("imposed": True); None = none
+        self._c_route = False        # ... and whether the library holds one
+        self.trips = 0               # rays rendered once more with every sample evaluated because the estimate tripwire marked them (cumulative)
+        self.probe_escalations = 0   # ladder steps probes have climbed (iblnerf_escalate_route; cumulative)
+        self.alarms = 0              # ... and whole calls repeated because more than a handful of their rays were marked
         self.has_fine = False            # a network_fine is loaded (run_fn = network_fn otherwise, ibl_nerf_renderer.py:705)
         self.range_fallbacks = 0
         self.opt = o
@@ -196,7 +204,7 @@ class Renderer:
             B.check(self.ctx, self.lib.iblnerf_upload_weights(self.ctx, int(which), blob.ctypes.data, blob.size))
         if int(which) == 1:
             self.has_fine = True
-        self.route = None                # (the library withdrew it with the upload: another network, another measurement)
+        self.route, self._c_route = None, False      # (the library withdrew it with the upload: another network, another measurement)
         if not remember:
             return
         if self._auto:
@@ -456,13 +464,26 @@ class Renderer:
 
     # ---- the checkpoint's route (include/iblnerf.h: iblnerf_route) ---------------------------------------------------------------------------
     ROUTE_MIN_RAYS, ROUTE_RAYS = 1024, 4096
+    ALARM_MIN_RAYS, ALARM_ONE_IN = 16, 256      # render_rays: more tripped rays than max(16, n / 256) in one call escalate the route and repeat the call
 
     def decide_route(self, rays_o, rays_d, near, far):
         """Measures on these probe rays which queries of the loaded checkpoint run as "estimate everywhere + the query's kernel on the relevant samples" and
-        whether plain-f16 estimates are good enough (iblnerf_decide_route: one discarded render of the probe), and freezes the answer until the next
-        load_weights: no render call decides anything, so results and speed do not depend on call history, launch size or rank.  render_rays calls this by
-        itself on <= ROUTE_RAYS strided rays of the first eager call of at least ROUTE_MIN_RAYS rays; dist.decide_on_frame / bench.py pass the same seeded
-        pixels of the frame on every rank.  Returns and records `self.route`."""
+        whether plain-f16 estimates are good enough (iblnerf_decide_route: one discarded render of the probe), and IMPOSES the answer: every render call takes it
+        until the next load_weights / set_route.  Left to itself (round 6) render_rays measures the route PER CALL — on <= ROUTE_RAYS strided rays of every eager call
+        of at least ROUTE_MIN_RAYS rays, or on the probe rays its caller passes (dist.render_frame: the same seeded pixels of the frame on every rank) — so that a
+        view's route is a function of that view alone (views of one export do not inherit the first view's; ranks dealt different views or tiles agree).
+        Returns and records `self.route`."""
+        try:
+            self._measure_route(rays_o, rays_d, near, far)
+        except _RangeEvent:
+            raise FloatingPointError("decide_route: the probe left the f16 range; render these rays once (render_rays rescales the networks into range by measurement, "
+                                     "or moves the context to bf16x3) and decide then") from None
+        self.route["imposed"] = True
+        return self.route
+
+    def _measure_route(self, rays_o, rays_d, near, far):
+        """iblnerf_decide_route on (at most ROUTE_RAYS strided ones of) these rays; a probe that trips its own wire climbs the ladder (iblnerf_escalate_route: wider
+        margins, six-slot estimates, lists off) and is rendered again until it is clean — the route is a function of the probe alone."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = int(rays_o.shape[0])
@@ -471,10 +492,27 @@ class Renderer:
             idx = torch.linspace(0, n - 1, cap, device=self.device).long()
             rays_o, rays_d, n = rays_o[idx].contiguous(), rays_d[idx].contiguous(), cap
         route = B.Route()
+        self.range_bits()                                            # (whatever earlier calls left in the flags is theirs)
         B.check(self.ctx, self.lib.iblnerf_decide_route(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near), float(far), C.byref(route)))
-        torch.cuda.current_stream(self.device).synchronize()         # (the probe's rays may be temporaries)
-        self.route = route.as_dict()
+        self._c_route = True
+        steps = 0
+        bits = self.range_bits()                                     # synchronises (the probe's rays may be temporaries)
+        for _ in range(6):                                           # (margins 2 -> 4 -> 6, estimates to six slots, lists off: four steps at most)
+            if bits & 1:
+                self._withdraw_route()
+                raise _RangeEvent()
+            if not bits & TRIP_BITS:
+                break
+            B.check(self.ctx, self.lib.iblnerf_escalate_route(self.ctx, int(bits & TRIP_BITS)))
+            steps += 1
+            self.trip_bits = getattr(self, "trip_bits", 0) | (bits & TRIP_BITS)
+            _, bits, _ = self._render(rays_o, rays_d, float(near), float(far), None, {}, on_range="ignore")      # the probe under the escalated route, discarded: is it clean now?
+        else:
+            raise B.IblNerfError("the estimate tripwire fired on a probe with the lists off: an internal error")
+        self.probe_escalations += steps
+        self.route = self.get_route()
         self.route["probe_rays"] = n
+        self.route["probe_escalations"] = steps
         return self.route
 
     def get_route(self):
@@ -483,7 +521,8 @@ class Renderer:
         return route.as_dict()
 
     def set_route(self, route):
-        """Imposes a route measured elsewhere (a dict as decide_route returns it, or None to withdraw the current one)."""
+        """Imposes a route measured elsewhere (a dict as decide_route returns it) until the next load_weights / set_route; None withdraws the current one and gives
+        the decision back to the render calls."""
         r = B.Route()
         if route is not None:
             r.decided = int(bool(route.get("decided", True)))
@@ -494,7 +533,14 @@ class Renderer:
                 r.select_margin[w] = float(route.get("select_margin", [2.0, 2.0])[w])
                 r.estimate_error[w] = float(route.get("estimate_error", [-1.0, -1.0])[w])
         B.check(self.ctx, self.lib.iblnerf_set_route(self.ctx, C.byref(r)))
-        self.route = self.get_route() if route is not None else None
+        self._c_route = route is not None
+        self.route = dict(self.get_route(), imposed=True) if route is not None else None
+
+    def _withdraw_route(self):
+        if self._c_route:
+            B.check(self.ctx, self.lib.iblnerf_set_route(self.ctx, C.byref(B.Route())))
+            self._c_route = False
+        self.route = None
 
     def describe_route(self):
         """The route table as text (iblnerf_describe_route): per pass and query class, which kernel estimates and which evaluates."""
@@ -509,29 +555,57 @@ class Renderer:
         B.check(self.ctx, self.lib.iblnerf_last_slot_units(self.ctx, C.byref(v)))
         return float(v.value)
 
-    def _route_wanted(self, n):
-        return (self.route is None and self.mlp_precision != "bf16x3" and n >= self.ROUTE_MIN_RAYS and int(self.opt.max_rays_per_launch) >= self.ROUTE_MIN_RAYS)
+    def _route_possible(self, n):
+        return self.mlp_precision != "bf16x3" and n >= self.ROUTE_MIN_RAYS and int(self.opt.max_rays_per_launch) >= self.ROUTE_MIN_RAYS
+
+    def _route_imposed(self):
+        return self.route is not None and bool(self.route.get("imposed"))
+
+    def _policy_imposed(self):
+        return not self._auto or (self.policy is not None and bool(self.policy.get("imposed")))
 
     def calibrate(self, rays_o, rays_d, near, far, gt_values=None, **edit):
-        """Decides FAST or SAFE for the checkpoint this context holds on the given rays (a few thousand of the view to be rendered: dist.render_frame
-        and bench.py pass the same seeded pixels on every rank, so that all tiles of a frame are rendered under one decision).  Returns and records
-        `self.policy` = {"decision": "fast" | "safe", "rays": n, "metrics": {map: {"p999", "above_1e-3"}}, "triggers": [...]}.  Only for
+        """Decides FAST or SAFE for the checkpoint this context holds on the given rays and IMPOSES the decision (until the next load_weights, or `policy = None`).
+        Left to itself (round 6) render_rays decides PER CALL, on the call's own probe — see _decide_for_call.  Returns and records
+        `self.policy` = {"decision": "fast" | "safe", "rays": n, "metrics": {map: {"p999", "above_1e-3"}}, "triggers": [...], "imposed": True}.  Only for
         mlp_precision="auto"; a pinned mode keeps its table."""
-        torch = _torch()
         if not self._auto:
             return self.policy
+        if not self._route_imposed() and self._route_possible(rays_o.shape[0]):
+            # the route first (measured on the same rays; both routings then run under it) — imposed with the table: one measurement, one scope
+            self.decide_route(rays_o, rays_d, float(near) if not hasattr(near, "shape") else float(_torch().as_tensor(near).min()),
+                              float(far) if not hasattr(far, "shape") else float(_torch().as_tensor(far).max()))
+        try:
+            self._measure_table(rays_o, rays_d, near, far, gt_values, edit)
+        except _RangeEvent:
+            raise FloatingPointError("calibrate: the probe left the f16 range; render these rays once (render_rays rescales the networks into range by measurement, "
+                                     "or moves the context to bf16x3) and calibrate then") from None
+        self.policy["imposed"] = True
+        return self.policy
+
+    def _measure_table(self, rays_o, rays_d, near, far, gt_values, edit):
+        """FAST against SAFE routing of this context on the given rays, under the route in effect; records `self.policy` and leaves the context on the decided table."""
+        torch = _torch()
         keep = self.policy
         self.policy = {"decision": "calibrating"}
         applied = getattr(self, "_routing_extra", 0)
         try:
             with torch.no_grad():
-                if self._route_wanted(rays_o.shape[0]):      # the route first (a property of the networks, measured on the same rays; both routings then run under it)
-                    self.decide_route(rays_o, rays_d, float(near) if not hasattr(near, "shape") else float(_torch().as_tensor(near).min()),
-                                      float(far) if not hasattr(far, "shape") else float(_torch().as_tensor(far).max()))
-                self._set_routing(0)
-                a = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
-                self._set_routing(self.SAFE_ROUTING)
-                b = self.render_rays(rays_o, rays_d, near, far, gt_values, **edit)
+                for _ in range(6):
+                    self._set_routing(0)
+                    a, bits_a, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                    self._set_routing(self.SAFE_ROUTING)
+                    b, bits_b, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                    bits = (bits_a | bits_b) & TRIP_BITS
+                    if not bits or not self._c_route:
+                        break
+                    # a table's list launches saw what the route's own probe render did not (another kernel refines other samples): one more step of the ladder, again
+                    B.check(self.ctx, self.lib.iblnerf_escalate_route(self.ctx, int(bits)))
+                    self.probe_escalations += 1
+                    self.trip_bits = getattr(self, "trip_bits", 0) | bits
+                    if self.route is not None:
+                        self.route = dict(self.get_route(), **{k: v for k, v in self.route.items() if k in ("imposed", "probe_rays")},
+                                          probe_escalations=self.route.get("probe_escalations", 0) + 1)
             metrics, triggers = {}, []
             for k, lim in self.CAL_LIMITS.items():
                 if k not in a:
@@ -554,22 +628,46 @@ class Renderer:
             self.policy = keep
         return self.policy
 
-    def _auto_decide(self, rays_o, rays_d, near, far, gt_values, edit):
-        """First eager render after a checkpoint was loaded: calibrate on a strided subset of the call's own rays; a call too small to measure on is
-        rendered SAFE and leaves the question open."""
+    def _decide_for_call(self, rays_o, rays_d, near, far, gt_values, edit, probe):
+        """What an eager, deterministic render call is rendered under — the route (which queries take lists, on which estimates, with which margin) and, for
+        mlp_precision="auto", the precision table (FAST / SAFE) — is measured for THAT CALL, before it, on a probe of its own rays: <= ROUTE_RAYS strided ones, or the
+        rays `probe` names ({"rays_o", "rays_d"[, "near", "far", "gt_values"]}: dist.render_frame passes the same seeded pixels of the frame on every rank, whatever
+        tile the rank renders).  Nothing carries over from one call to the next but the weights: the reference renders every view of an export by the same arithmetic
+        whatever came before it (ibl_nerf_renderer.py:819-910) and every chunk of a view likewise (:735-756, :768-769).  Round 5 decided once per checkpoint on the first
+        call's rays although the answer is camera-dependent (the first fitted checkpoint: frontal -> FAST, rotated -> SAFE), so later views inherited the first one's
+        table and view-sharded ranks could disagree.  Cost: ~10 ms for the route + 2 x 9 ms for the table per call (2.7 % of an 800 x 800 frame).
+        An imposed route / policy (decide_route, set_route, calibrate) is taken as it is; a call too small to measure on (no probe, < ROUTE_MIN_RAYS rays) evaluates
+        every sample, and under "auto" on the SAFE table."""
         torch = _torch()
         n = rays_o.shape[0]
-        if n < self.CAL_MIN_RAYS:
-            self._set_routing(self.SAFE_ROUTING)
+        route_open, table_open = not self._route_imposed(), not self._policy_imposed()
+        if not route_open and not table_open:
             return
-        idx = torch.linspace(0, n - 1, min(n, self.CAL_RAYS), device=rays_o.device).long()
-        gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
-        near, far = ((v[idx].contiguous() if torch.is_tensor(v) and v.numel() == n else v) for v in (near, far))       # per-ray planes follow their rays
-        self.calibrate(rays_o[idx].contiguous(), rays_d[idx].contiguous(), near, far, gt, **edit)
-
-    @staticmethod
-    def trips_in_a_row(retry):
-        return 1 + int(retry[4:]) if isinstance(retry, str) and retry.startswith("trip") else 1
+        if probe is not None:
+            pro, prd = _dev_f32(probe["rays_o"], self.device).reshape(-1, 3), _dev_f32(probe["rays_d"], self.device).reshape(-1, 3)
+            pnear, pfar, pgt = probe.get("near", near), probe.get("far", far), probe.get("gt_values")
+            if any(torch.is_tensor(v) and v.numel() > 1 and v.numel() != pro.shape[0] for v in (pnear, pfar)):
+                raise ValueError("probe: per-ray near / far planes must be the probe rays' own")
+        elif n >= self.ROUTE_MIN_RAYS:
+            idx = torch.linspace(0, n - 1, min(n, self.ROUTE_RAYS, max(int(self.opt.max_rays_per_launch), 1)), device=rays_o.device).long()
+            pro, prd = rays_o[idx].contiguous(), rays_d[idx].contiguous()
+            pgt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
+            pnear, pfar = ((v[idx].contiguous() if torch.is_tensor(v) and v.numel() == n else v) for v in (near, far))       # per-ray planes follow their rays
+        else:
+            pro = None
+        if route_open:
+            if pro is not None and self._route_possible(pro.shape[0]):
+                lo = float(pnear.min()) if torch.is_tensor(pnear) else float(pnear)
+                hi = float(pfar.max()) if torch.is_tensor(pfar) else float(pfar)
+                self._measure_route(pro, prd, lo, hi)
+            else:
+                self._withdraw_route()
+        if table_open:
+            if pro is not None and pro.shape[0] >= self.CAL_MIN_RAYS:
+                self._measure_table(pro, prd, pnear, pfar, pgt, edit)
+            else:
+                self._set_routing(self.SAFE_ROUTING)
+                self.policy = None
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""
@@ -620,6 +718,34 @@ class Renderer:
         rd = torch.empty((n_rows, W, 3), dtype=torch.float32, device=self.device)
         B.check(self.ctx, self.lib.iblnerf_get_rays(self.ctx, self._stream(), int(H), int(W), K.ctypes.data,
                                                     c2w_h.ctypes.data, int(row0), int(n_rows), ro.data_ptr(), rd.data_ptr()))
+        return ro, rd
+
+    def get_rays_strided(self, H, W, K, c2w, row0, row_step, n_rows):
+        """get_rays for image rows row0, row0 + row_step, ... (iblnerf_get_rays_strided): one rank's interleaved tile, generated by that rank alone -> [n_rows, W, 3] x 2."""
+        torch = _torch()
+        K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(3, 3))
+        c2w_h = c2w.detach().cpu().numpy() if not isinstance(c2w, np.ndarray) else c2w
+        c2w_h = np.ascontiguousarray(np.asarray(c2w_h, dtype=np.float32)[:3, :4])
+        ro = torch.empty((n_rows, W, 3), dtype=torch.float32, device=self.device)
+        rd = torch.empty((n_rows, W, 3), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_get_rays_strided(self.ctx, self._stream(), int(H), int(W), K.ctypes.data, c2w_h.ctypes.data, int(row0), int(row_step), int(n_rows),
+                                                            ro.data_ptr(), rd.data_ptr()))
+        return ro, rd
+
+    def get_rays_pixels(self, H, W, K, c2w, pixels):
+        """get_rays at the listed pixels (flat indices row * W + col; iblnerf_get_rays_pixels): a frame's probe rays without the frame -> [n, 3] x 2."""
+        torch = _torch()
+        K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(3, 3))
+        c2w_h = c2w.detach().cpu().numpy() if not isinstance(c2w, np.ndarray) else c2w
+        c2w_h = np.ascontiguousarray(np.asarray(c2w_h, dtype=np.float32)[:3, :4])
+        pix = torch.as_tensor(np.asarray(pixels.cpu() if torch.is_tensor(pixels) else pixels, dtype=np.int64), device=self.device).contiguous()
+        if pix.numel() and (int(pix.min()) < 0 or int(pix.max()) >= H * W):
+            raise ValueError("get_rays_pixels: pixel indices must lie in [0, H * W)")
+        ro = torch.empty((pix.numel(), 3), dtype=torch.float32, device=self.device)
+        rd = torch.empty((pix.numel(), 3), dtype=torch.float32, device=self.device)
+        B.check(self.ctx, self.lib.iblnerf_get_rays_pixels(self.ctx, self._stream(), int(H), int(W), K.ctypes.data, c2w_h.ctypes.data, pix.data_ptr(), pix.numel(),
+                                                           ro.data_ptr(), rd.data_ptr()))
+        torch.cuda.current_stream(self.device).synchronize()      # (`pix` must outlive the launch)
         return ro, rd
 
     def network_query(self, inputs, viewdirs, which=0, _retry=False):
@@ -1026,7 +1152,8 @@ class Renderer:
             m.reflected_coarse_radiance_map_k[i] = t["reflected_coarse_radiance_map_%d" % (i + 1)].data_ptr()
         return m, t
 
-    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, _retry=False, noise=None, **edit):
+    def render_rays(self, rays_o, rays_d, near, far, gt_values=None, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, _retry=False, noise=None,
+                    probe=None, alarm_sync=None, **edit):
         """render_rays + raw2outputs for a flat batch of rays.  Returns the reference's result dict
         (un-suffixed = last pass, '<key>0' = coarse pass when N_importance > 0, 'z_std').
         perturb > 0 (training-time sampling, ibl_nerf_renderer.py:678-692, :703): stratified jitter of the coarse grid and
@@ -1035,26 +1162,148 @@ class Renderer:
         raw_noise_std > 0 (:208-216): noise on the main query's density before compositing, N(0, std) from the device generator, or
         — pytest=True — std * numpy's seed-0 UNIFORM stream, which is what the reference's test hook draws.
         draws = (t_rand [n, N_samples], u [n, N_importance]) device tensors (or (None, None)) replaces the perturb / pytest generation;
-        taps = a binding.Taps of caller-owned buffers (iblnerf_render_rays_tapped: both passes' z_vals and main raw rows, for a backward)."""
+        taps = a binding.Taps of caller-owned buffers (iblnerf_render_rays_tapped: both passes' z_vals and main raw rows, for a backward).
+        probe = {"rays_o", "rays_d"[, "near", "far", "gt_values"]}: the rays this call's route and precision table are measured on instead of a strided subset of
+        its own (_decide_for_call) — what makes the tiles of a sharded frame one frame; alarm_sync = a callable (marked rays, rays, trip bits) -> the same three over
+        all the tiles of the frame (dist.render_frame: one all-reduce), so that the tiles escalate a route that does not fit TOGETHER.
+        An eager deterministic call (the inference path) is rendered under a route and table measured for it alone, and the rays the estimate tripwire marks are
+        rendered once more with every sample evaluated: a ray's result depends on the call's probe and on the ray, not on call history, launch split or rank."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
+        n = rays_o.shape[0]
+        lazy = self.range_check == "lazy"
+        std = float(raw_noise_std or 0.)
+        sampled = draws is not None or bool(perturb and float(perturb) > 0.) or std > 0.
+        if lazy:
+            self._lazy_poll()
+            if self._force_wide:
+                return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
+                                                                draws=draws, taps=taps, **edit)
+        self._chunk = chunk          # (one flag's result depends on the reference's chunking: edit_roughness_by_img, see _overrides)
+        eager = not lazy and taps is None and not sampled and self.mlp_precision != "bf16x3"
+        if eager and gt_values and edit.get("edit_intrinsic") and edit.get("edit_roughness") and edit.get("edit_roughness_by_img") and "_edit_roughness_resolved" not in gt_values \
+                and "edit_roughness" in gt_values and "edit_intrinsic_mask" in gt_values:
+            # resolved ONCE on the call's flat ray list in the reference's chunks (see _overrides), so that the probe and a repeat of single rays take the same rows
+            m = _dev_f32(gt_values["edit_intrinsic_mask"], self.device).reshape(n, -1)[:, 0]
+            img = _dev_f32(gt_values["edit_roughness"], self.device).reshape(n, -1)
+            if img.shape[1] == 1:
+                gt_values = dict(gt_values, _edit_roughness_resolved=resolve_edit_roughness(m, img[:, 0], chunk))
+        if eager:
+            # (a training step's context — lazy, sampled, tapped — keeps the FAST table and holds no route: its renders are stochastic, its weights change every step,
+            # and a lazy context never reads the tripwire: ADVICE r5)
+            for attempt in (0, 1):
+                try:
+                    self._decide_for_call(rays_o, rays_d, *self._plane_args(near, far, n), gt_values, edit, probe)
+                    break
+                except _RangeEvent:
+                    # the probe left the f16 range: nothing can be measured before that is answered — the networks rescaled into range by measurement (then the probe
+                    # once more), or, where that gains nothing, the whole call on the bf16x3 twin
+                    if attempt == 0 and _retry is not True and self._rescale_on(rays_o, rays_d, self._plane_args(near, far, n)):
+                        _retry = True
+                        continue
+                    return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, chunk=chunk, **edit)
+        elif not self._route_imposed() or lazy:
+            self._withdraw_route()
+        want_trips = eager and self._c_route
+        res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
+                                       taps=taps, noise=noise, _retry=_retry, want_trips=want_trips)
+        if want_trips:
+            # The estimate tripwire: a list launch of this call refined a positive density whose estimate was half-way to dropping it (or overshot past the conservative
+            # transmittance's allowance) on the rays marked in `trip`.  They are rendered once more with every sample evaluated (iblnerf_set_lists 0) and their rows
+            # overwritten; nothing else changes, and no state outlives the call.  But first the
+            # ALARM: the marks may say the ROUTE is wrong for this call — a DEEP miss (bit 4: an estimate below -3/4 of a margin that was set to twice the deepest
+            # underestimate the probe saw; an audited sample, dropped as clearly empty, that was not), or more than a handful of rays are marked (the probe did not see what the call's rays see, or an imposed
+            # route was measured elsewhere: estimates that thin on 0.4 % of the rays cannot be trusted on the others).  The route then climbs the ladder
+            # (iblnerf_escalate_route) and the whole call is rendered again, until neither holds or the lists are off.  (A per-call route is gone with the call; an
+            # imposed one keeps what it learned.)
+            # alarm_sync (dist.render_frame): the tiles of one frame take this decision TOGETHER — marked rays, rays and bits summed / or-ed over the ranks, in lockstep:
+            # whether the loop goes on depends on the synced numbers alone — so that every tile is rendered under the same route and an N-rank frame stays the 1-rank frame.
+            steps = 0
+            while True:
+                live = trip is not None and not bits & 1          # (None: a range event was answered inside _render — that render stands, this rank only keeps step)
+                idx = trip.nonzero().reshape(-1) if live else torch.empty((0,), dtype=torch.long, device=self.device)
+                marked, total, allbits = int(idx.numel()), int(n), int(bits & TRIP_BITS) if live else 0
+                if alarm_sync is not None:
+                    marked, total, allbits = alarm_sync(marked, total, allbits)
+                if steps >= 5 or not (allbits & TRIP_PROOF or marked > max(self.ALARM_MIN_RAYS, total // self.ALARM_ONE_IN)):
+                    break
+                steps += 1
+                if self._c_route:
+                    B.check(self.ctx, self.lib.iblnerf_escalate_route(self.ctx, int(allbits)))
+                    self.alarms += 1
+                    self.trip_bits = getattr(self, "trip_bits", 0) | allbits
+                    self.route = dict(self.get_route(), **{k: v for k, v in (self.route or {}).items() if k in ("imposed", "probe_rays", "probe_escalations")}, alarms=steps)
+                if live:
+                    res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, chunk=chunk, want_trips=True)
+            if live and idx.numel() and bits & TRIP_BITS:
+                pn, pf = self._plane_args(near, far, n)
+                sub_gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
+                B.check(self.ctx, self.lib.iblnerf_set_lists(self.ctx, 0))
+                try:
+                    sub, _, _ = self._render(rays_o[idx].contiguous(), rays_d[idx].contiguous(), pn[idx].contiguous() if torch.is_tensor(pn) else pn,
+                                             pf[idx].contiguous() if torch.is_tensor(pf) else pf, sub_gt, edit, chunk=chunk)
+                finally:
+                    B.check(self.ctx, self.lib.iblnerf_set_lists(self.ctx, 1))
+                for k, v in sub.items():
+                    res[k][idx] = v
+                self.trips += int(idx.numel())
+                self.trip_bits = getattr(self, "trip_bits", 0) | (bits & TRIP_BITS)
+                self.last_trip_rays = idx
+        elif trip is None and bits & TRIP_BITS and not bits & 1 and not lazy:
+            # a sampled / tapped call under an IMPOSED route (no trip map: its draws cannot be replayed ray by ray): the whole call once more with every sample evaluated
+            B.check(self.ctx, self.lib.iblnerf_set_lists(self.ctx, 0))
+            try:
+                res, _, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
+                                         taps=taps, noise=noise, _retry=_retry)
+            finally:
+                B.check(self.ctx, self.lib.iblnerf_set_lists(self.ctx, 1))
+            self.trips += int(n)
+            self.trip_bits = getattr(self, "trip_bits", 0) | (bits & TRIP_BITS)
+        return res
+
+    def _rescale_on(self, rays_o, rays_d, planes):
+        """A range event on these rays: rescale the networks into the f16 range by measurement on the coarse grid's points of (up to) 1 024 of them — where both networks
+        are evaluated, within the margin RANGE_TARGET leaves (_rescale_into_range).  planes = (near, far), floats or per-ray tensors."""
+        torch = _torch()
+        n = rays_o.shape[0]
+        if not n:
+            return False
+        idx = torch.linspace(0, n - 1, min(n, 1024), device=self.device).long()
+        nr = planes[0][idx, None] if torch.is_tensor(planes[0]) else torch.full((len(idx), 1), float(planes[0]), device=self.device)
+        fr = planes[1][idx, None] if torch.is_tensor(planes[1]) else torch.full((len(idx), 1), float(planes[1]), device=self.device)
+        tt = torch.linspace(0.0, 1.0, self.N_samples, device=self.device)[None, :]
+        z = nr * (1.0 - tt) + fr * tt
+        pts = rays_o[idx, None, :] + rays_d[idx, None, :] * z[..., None]
+        return self._rescale_into_range(pts, rays_d[idx, None, :].expand_as(pts))
+
+    def _plane_args(self, near, far, n):
+        """near / far as render_rays takes them -> (near, far) with per-ray planes as flat [n] device tensors and everything else as floats."""
+        torch = _torch()
+        if any(hasattr(v, "shape") and int(np.prod(tuple(v.shape))) > 1 for v in (near, far)):
+            out = tuple((_dev_f32(v, self.device).reshape(-1) if hasattr(v, "shape") else torch.full((n,), float(v), dtype=torch.float32, device=self.device)) for v in (near, far))
+            if any(p.numel() != n for p in out):
+                raise RuntimeError("near / far planes must have one entry per ray (%d), got %s" % (n, [int(p.numel()) for p in out]))
+            return tuple(p.contiguous() for p in out)
+        if hasattr(near, "shape") or hasattr(far, "shape"):
+            return (float(np.asarray(near.cpu() if hasattr(near, "cpu") else near).reshape(-1)[0]), float(np.asarray(far.cpu() if hasattr(far, "cpu") else far).reshape(-1)[0]))
+        return float(near), float(far)
+
+    def _render(self, rays_o, rays_d, near, far, gt_values, edit, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, noise=None, _retry=False,
+                want_trips=False, on_range="answer"):
+        """One iblnerf_render_rays_tapped under whatever route / table / list switch the context holds -> (result dict, range bits, trip map or None).  Range events
+        (bit 0: an activation left the f16 range) are answered here — the network rescaled into range, or the call repeated on the bf16x3 twin — through render_rays."""
+        torch = _torch()
         n = rays_o.shape[0]
         smp = None
         # near / far: scalars, or one plane per ray ([n] / [n, 1], ibl_nerf_renderer.py:802-805) — a z grid and a mip-level depth_0 per ray
         planes = None
-        if any(hasattr(v, "shape") and int(np.prod(tuple(v.shape))) > 1 for v in (near, far)):
-            planes = tuple((_dev_f32(v, self.device).reshape(-1) if hasattr(v, "shape") else torch.full((n,), float(v), dtype=torch.float32, device=self.device))
-                           for v in (near, far))
-            if any(p.numel() != n for p in planes):
-                raise RuntimeError("near / far planes must have one entry per ray (%d), got %s" % (n, [int(p.numel()) for p in planes]))
-            planes = tuple(p.contiguous() for p in planes)
+        near, far = self._plane_args(near, far, n)
+        if torch.is_tensor(near):
+            planes = (near, far)
             smp = B.Sampling()
             smp.d_near, smp.d_far = planes[0].data_ptr(), planes[1].data_ptr()
             self._keep_planes = planes
-            near_arg, far_arg = near, far
             near, far = (float(planes[0][0]), float(planes[1][0])) if n else (0.0, 1.0)      # (not read by the library when the planes are given)
-        elif hasattr(near, "shape") or hasattr(far, "shape"):
-            near, far = float(np.asarray(near.cpu() if hasattr(near, "cpu") else near).reshape(-1)[0]), float(np.asarray(far.cpu() if hasattr(far, "cpu") else far).reshape(-1)[0])
         std = float(raw_noise_std or 0.)
         if std > 0.:
             smp = smp or B.Sampling()
@@ -1080,20 +1329,7 @@ class Renderer:
             smp.d_t_rand, smp.d_u = t_rand.data_ptr(), u.data_ptr()
             self._keep_smp = (t_rand, u)
         lazy = self.range_check == "lazy"
-        if lazy:
-            self._lazy_poll()
-            if self._force_wide:
-                return self._wide_twin(count=False).render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb,
-                                                                pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, **edit)
-        if self._auto and self.policy is None and not lazy and taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0.:
-            # (a training step's context — lazy, sampled, tapped — keeps the FAST table: its renders are stochastic and its weights change every step)
-            self._auto_decide(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, edit)
-        if (taps is None and draws is None and not (perturb and float(perturb) > 0.) and std <= 0. and self._route_wanted(n)
-                and not (self.policy or {}).get("decision") == "calibrating"):
-            # the first eager frame-sized call after a checkpoint was loaded: its route, measured on <= ROUTE_RAYS strided rays of the call
-            # (a training step's context — lazy, sampled, tapped — holds no route: its weights change every step, its main queries evaluate every sample)
-            self.decide_route(rays_o, rays_d, float(planes[0].min()) if planes else near, float(planes[1].max()) if planes else far)
-        self._chunk = chunk          # (one flag's result depends on the reference's chunking: edit_roughness_by_img, see _overrides)
+        self._chunk = chunk
         ov, keep = self._overrides(gt_values or {}, edit, n)
         Sc, Sf = self.N_samples, self.N_samples + self.N_importance
         outs = B.Outputs()
@@ -1112,37 +1348,23 @@ class Renderer:
         if self._depth_mlp is not None:
             inferred_depth = torch.empty((n,), dtype=torch.float32, device=self.device)
             outs.inferred_depth_map = inferred_depth.data_ptr()
+        trip = None
+        if want_trips and n:
+            trip = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+            outs.trip_rays = trip.data_ptr()
         B.check(self.ctx, self.lib.iblnerf_render_rays_tapped(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
                                                               float(near), float(far), C.byref(ov) if ov is not None else None,
                                                               C.byref(smp) if smp is not None else None, C.byref(outs),
                                                               C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         bits = 0 if lazy else self.range_bits()
-        if bits & 12 and not bits & 1:
-            # the estimate tripwire: a list launch of this call refined a positive density whose plain-f16 estimate was half-way to dropping it.  The library
-            # has doubled the selection margins — or moved the estimates to the f16 + 2 fp6 form (error < 1e-2 on a network that fits that form), or, if they
-            # were there already, switched the lists off; the call is repeated.
-            self.trips += 1
-            self.trip_bits = getattr(self, "trip_bits", 0) | (bits & 12)
-            self.route = self.get_route() if self.route is not None else None
-            n_trips = self.trips_in_a_row(_retry)
-            if n_trips > 5:          # (margins 2 -> 4 -> 6, estimates to six slots, lists off: four events at most)
-                raise B.IblNerfError("the estimate tripwire fired with the lists off: an internal error")
-            return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk,
-                                    raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, _retry="trip%d" % n_trips, **edit)
-        if bits & 1:
+        if bits & 1 and on_range == "raise":
+            raise _RangeEvent()
+        if bits & 1 and on_range == "answer":
             again = dict(perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws, taps=taps, noise=noise, **edit)
-            if _retry is not True and n:
-                # the coarse grid's points of (up to) 1 024 of the call's rays: where both networks are evaluated, within the margin RANGE_TARGET leaves
-                idx = torch.linspace(0, n - 1, min(n, 1024), device=self.device).long()
-                nr = planes[0][idx, None] if planes else torch.full((len(idx), 1), float(near), device=self.device)
-                fr = planes[1][idx, None] if planes else torch.full((len(idx), 1), float(far), device=self.device)
-                tt = torch.linspace(0.0, 1.0, self.N_samples, device=self.device)[None, :]
-                z = nr * (1.0 - tt) + fr * tt
-                pts = rays_o[idx, None, :] + rays_d[idx, None, :] * z[..., None]
-                if self._rescale_into_range(pts, rays_d[idx, None, :].expand_as(pts)):
-                    return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, _retry=True, **again)
-            return self._wide_twin().render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, **again)
+            if _retry is not True and n and self._rescale_on(rays_o, rays_d, planes if planes else (near, far)):
+                return self.render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, _retry=True, **again), 0, None
+            return self._wide_twin().render_rays(rays_o, rays_d, planes[0] if planes else near, planes[1] if planes else far, gt_values, **again), 0, None
         order = RESULT_ORDER if not inf else RESULT_ORDER[:16] + ["inferred_normal_map"] + RESULT_ORDER[16:]   # :517-518
         res = {k: t_fine[k] for k in order}
         for k in order:
@@ -1152,7 +1374,7 @@ class Renderer:
             res["z_std"] = z_std
         if inferred_depth is not None:
             res["inferred_depth_map"] = inferred_depth                                 # appended last (:722-726)
-        return res
+        return res, bits, trip
 
     def composite_pass(self, rays_o, rays_d, near, far, z_vals, raw, sigma_offsets, refl_raw, gt_values=None, normal_raw=None, **edit):
         """Teacher-forced raw2outputs (iblnerf_composite_pass): one pass on caller-supplied network outputs, no MLP launch.

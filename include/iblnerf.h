@@ -157,12 +157,13 @@ enum {
 int iblnerf_set_query_routing(iblnerf_ctx* ctx, int query_routing);
 
 /* The ROUTE of a checkpoint: which queries run as "estimate everywhere + the query's own kernel on a list of the relevant samples" (csrc/api.cpp full_pass).
- * Whether that pays, and whether plain-f16 estimates are good enough, are properties of the networks — so they are MEASURED, once per checkpoint, on probe rays the
- * caller chooses (iblnerf_decide_route), and from then on every render call of the context takes the same route whatever its size, order or rank: nothing is decided
- * inside a render call.  Until a route is decided (after iblnerf_create and after every upload of network 0 / 1) every query evaluates all of its samples on its
- * own kernel (round 3's path: correct, ~1.5x slower on a scene with surfaces).  ibl-nerf_amd/renderer.py decides on <= 4 096 strided rays of the first call of at
- * least 1 024 rays; dist.py / bench.py on the same seeded pixels of the frame on every rank, so that all tiles of a frame take one route and an N-rank frame is
- * the 1-rank frame bit for bit.  No reference counterpart: the reference evaluates every sample in fp32 (ibl_nerf_renderer.py:201, :446, normal_from_depth.py:158). */
+ * Whether that pays, and whether plain-f16 estimates are good enough, depend on the networks AND on what the rays see — so they are MEASURED on probe rays the
+ * caller chooses (iblnerf_decide_route), and every render call issued while that route stands takes it whatever its size or launch split: nothing is decided
+ * inside a render call.  Until a route is decided (after iblnerf_create, after every upload of network 0 / 1, after iblnerf_set_route with decided = 0) every query
+ * evaluates all of its samples on its own kernel (round 3's path: correct, ~1.5x slower on a scene with surfaces).  Round 6: ibl-nerf_amd/renderer.py decides PER CALL — on
+ * <= 4 096 strided rays of every eager call of at least 1 024 rays, or on the probe rays its caller hands it (dist.py / bench.py: the same seeded pixels of the frame
+ * on every rank) — so that what a view is rendered under is a function of that view alone: views of one export do not inherit the first view's route, ranks that are
+ * dealt different views or tiles agree, and an N-rank frame is the 1-rank frame bit for bit (round 5 decided once per checkpoint, on the first call's rays).  No reference counterpart: the reference evaluates every sample in fp32 (ibl_nerf_renderer.py:201, :446, normal_from_depth.py:158). */
 typedef struct iblnerf_route {
     int32_t decided;                   /* 0: no route yet (see above); the other fields are then meaningless */
     int32_t estimates_plain_f16[2];    /* per network: its density estimates run in plain f16 (4 matrix slots per 64 MACs); 0: on the f16 + 2 fp6 form (6), because the
@@ -189,6 +190,20 @@ int iblnerf_decide_route(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, 
 /* Imposes a route (e.g. the one another rank or an earlier run decided); decided = 0 withdraws it. */
 int iblnerf_set_route(iblnerf_ctx* ctx, const iblnerf_route* route);
 int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
+/* The tripwire's bits in iblnerf_range_status: 4 (bit 2) a refined sample's density is positive and its estimate lay below -margin / 2 — a near miss; 8 (bit 3) an estimate
+ * overshot a density beyond what the conservative transmittance allows for; 16 (bit 4, always with 4) ... below -3 margin / 4: a DEEP miss — the margin is twice the
+ * deepest underestimate the probe saw, so the route's error model is off by half again; beyond -margin itself (an AUDITED sample: dropped as clearly empty, and not empty) it
+ * is proof that samples are being dropped wrongly.
+ * A PROBE that tripped (any of them behind iblnerf_decide_route, or behind a render of the probe rays under the route), or a call whose marks say the route does not fit it (bit
+ * 4, or marks on more than a handful of its rays: ibl-nerf_amd/renderer.py's alarm): the decided route
+ * climbs one step of the ladder — underestimates (no bit 3) double both selection margins (up to 6); otherwise, or beyond that, the plain-f16 estimates go (f16 + 2 fp6
+ * from now on); on f16 + 2 fp6 estimates already, the lists go off (route.tripped = 2).  Render the probe again and repeat until it is clean: the route a call's rays
+ * are then rendered under is a function of the probe alone.  (Round 5 climbed this ladder inside iblnerf_range_status, for good and per context: a frame's route then
+ * depended on the calls — and, under sharding, the rank — that had come before.)  IBLNERF_ERR_STATE without a decided route. */
+int iblnerf_escalate_route(iblnerf_ctx* ctx, int trip_bits);
+/* enabled = 0: the next render calls evaluate every sample of every query on its own kernel, whatever route is decided (and raise no tripwire: there are no lists);
+ * 1 (the default) gives the route back.  How the rays marked in iblnerf_outputs.trip_rays are rendered once more. */
+int iblnerf_set_lists(iblnerf_ctx* ctx, int enabled);
 /* Measurement hook: the threshold of the offset tiers (IBLNERF_ROUTE_NO_OFFSET_TIERS above; default 0 = no tiers). */
 /* (experiment hook, round 5) the transmittance thresholds of the per-sample selection: a sample behind a CONSERVATIVE transmittance (composited from 0.75 x the density
  * estimate - margin) below the threshold is left at its estimate — it carries, with everything behind it, a weight below the threshold.  t_main: main and reflected
@@ -284,6 +299,15 @@ void iblnerf_encode_host(float x, int n_freq, float* h_out);
  * [row0, row0+n_rows).  h_K = 3x3 row-major, h_c2w = 3x4 row-major.  Outputs [n_rows*W, 3]. */
 int iblnerf_get_rays(iblnerf_ctx* ctx, void* stream, int H, int W, const float* h_K, const float* h_c2w,
                      int row0, int n_rows, float* d_rays_o, float* d_rays_d);
+/* The same rays for image rows row0, row0 + row_step, ... (n_rows of them; outputs [n_rows * W, 3]): the interleaved row tile of one rank of a sharded frame
+ * (ibl-nerf_amd/dist.py: rank r of N takes row0 = r, row_step = N), generated by that rank alone.  Every pixel's ray is computed by itself, so a tile's rays are the
+ * frame's bit for bit. */
+int iblnerf_get_rays_strided(iblnerf_ctx* ctx, void* stream, int H, int W, const float* h_K, const float* h_c2w,
+                             int row0, int row_step, int n_rows, float* d_rays_o, float* d_rays_d);
+/* ... and for a list of pixels (d_pixels [n_pixels] int64 in device memory, flat indices row * W + col; outputs [n_pixels, 3]): the probe rays a frame's route and
+ * precision table are measured on — the same seeded pixels on every rank (ibl-nerf_amd/dist.py frame_probe). */
+int iblnerf_get_rays_pixels(iblnerf_ctx* ctx, void* stream, int H, int W, const float* h_K, const float* h_c2w,
+                            const int64_t* d_pixels, int64_t n_pixels, float* d_rays_o, float* d_rays_d);
 
 /* replaces: network_query_fn(inputs, viewdirs, network_fn) (nerf_models/ibl_nerf.py:327-329 ->
  * run_network :236-252).  d_pts [n_rays, n_samples, 3]; d_viewdirs [n_rays,3] or NULL.
@@ -459,6 +483,12 @@ typedef struct {
     iblnerf_maps coarse;    /* "...0" keys; ignored unless options.coarse_outputs and n_importance > 0 */
     float* z_std;           /* [n] (n_importance > 0) */
     float* inferred_depth_map; /* [n]; written while a PositionDirectionMLP is uploaded (infer_depth, ibl_nerf_renderer.py:722-726); may be NULL */
+    unsigned char* trip_rays;  /* [n] bytes, ZEROED BY THE CALLER, may be NULL.  The estimate tripwire (iblnerf_route below) sets byte r when a list launch of the call
+                                  refined a positive density on ray r (or on one of its epsilon-offset copies, or on its reflected ray) whose estimate lay half-way to
+                                  dropping it — bits 2 / 3 of iblnerf_range_status.  Such a ray's other dropped samples rest on estimates that thin: render these rays
+                                  once more with iblnerf_set_lists(ctx, 0) (every sample evaluated) and overwrite their rows — ibl-nerf_amd/renderer.py does.  The mark
+                                  depends on the ray alone (its own samples, its own estimates), so a ray's final result does not depend on the call, launch or rank
+                                  it was rendered in: the guarantee of the reference's batchify_rays (ibl_nerf_renderer.py:735-756, :768-769) */
 } iblnerf_outputs;
 
 /* The ray-sized part of raw2outputs, differentiated (a training step's backward between the loss and iblnerf_composite_direct_backward;

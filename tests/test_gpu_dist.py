@@ -75,6 +75,25 @@ def test_eight_rank_frame_of_the_fitted_checkpoint_is_the_one_rank_frame():
     assert all(("DIST_OK %d" % i) in out.stdout for i in range(8))
 
 
+def test_eight_rank_frame_of_the_checkpoint_that_trips_is_the_one_rank_frame():
+    """the SECOND fitted checkpoint's frame — the one whose whole frame trips the estimate wire (a positive density whose estimate lay below half the
+    selection margin, on a ray or two of 640 000) — from eight ranks against one rank: bit for bit on every export map, the tiles' repeated rays adding up to the frame's
+    (tests/dist_gpu_worker.py --fitted-frame --checkpoint fitted2).  Round 5's per-context margin doubling made the tripping rank render its tile twice, under other
+    margins than its peers."""
+    out, _ = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--fitted-frame", "--checkpoint", "fitted2"], nproc=8, timeout=1800)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert all(("DIST_OK %d" % i) in out.stdout for i in range(8))
+
+
+def test_two_rank_view_sharded_export_is_the_one_rank_export():
+    """Three views (frontal, rotated, frontal) of the first fitted checkpoint dealt to two ranks (render_views.test / dist.view_indices) against the same export from one
+    rank: every exported map of every view bit for bit — each view decides its route and table on its own rays, so neither the rank nor what it rendered before matters
+    (tests/dist_gpu_worker.py --views)."""
+    out, _ = _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "--views"], nproc=2, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "DIST_OK 0" in out.stdout and "DIST_OK 1" in out.stdout
+
+
 def test_rccl_one_rank_frame_on_device_buffers():
     """The RCCL leg on one GPU: a world-size-1 `nccl` process group (librccl loaded, communicator up) and dist.render_frame's pack ->
     all_gather_into_tensor on DEVICE buffers -> unpack, under the insert / edit gt_values — the branch of dist.all_gather_frame that

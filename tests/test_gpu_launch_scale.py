@@ -272,8 +272,8 @@ def test_calibration_measures_and_decides(R, lut):
             else:
                 assert any(t.startswith(by) for t in p["triggers"]), (name, p)
                 assert (w >= 1e-3) if by == "weights" else (w <= 2.5e-4 and (nm["p999"] > 4e-4 or nm["above_1e-3"] > 3e-4)), (name, p)
-        assert r.route["decided"] and r.trips == 0                         # (the route was measured once, on the first probe; the table decisions ran under it)
-    # a call too small to measure on: safe, undecided; then a frame-sized call decides; another checkpoint resets
+        assert r.route["decided"] and r.route["imposed"] and r.trips == 0  # (an explicit calibrate() imposes route and table: measured on the first probe, the later decisions ran under that route)
+    # a call too small to measure on: safe, undecided; a frame-sized call decides FOR ITSELF (round 6): the next small call is the first one again; another checkpoint likewise
     g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
     g2, sdc2, sdf2, _, _ = load_golden("fitted2_launch4k")
     r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=16384)
@@ -283,8 +283,8 @@ def test_calibration_measures_and_decides(R, lut):
     assert r.policy is None and torch.equal(few["weights"], safe.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)["weights"])
     many = r.render_rays(g["rays_o"][:4000], g["rays_d"][:4000], 0.5, 8.0)
     assert r.policy["decision"] == "fast" and _same(many["weights"], fast.render_rays(g["rays_o"][:4000], g["rays_d"][:4000], 0.5, 8.0)["weights"])
-    few2 = r.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)                 # decided: small calls follow the decision
-    assert _same(few2["weights"], many["weights"][:300])
+    few2 = r.render_rays(g["rays_o"][:300], g["rays_d"][:300], 0.5, 8.0)                 # the frame-sized call's decision was its own: no memory
+    assert r.policy is None and torch.equal(few2["weights"], few["weights"])
     r.load_weights(0, sdc2)
     r.load_weights(1, sdf2)
     assert r.policy is None

@@ -1,0 +1,166 @@
+"""Round 6: WHAT a render call is rendered under is decided for that call alone (route and precision table measured on a probe of the call's own rays, or on the
+probe its caller hands it), and a ray the estimate tripwire marks is rendered once more by itself.  Nothing carries over from one call to the next but the weights —
+what the reference guarantees by construction: every view of an export, and every chunk of a view, goes through the same arithmetic whatever came before it
+(/root/reference/src/nerf_models/ibl_nerf_renderer.py:735-756, :768-769, :819-910).  Round 5 froze both decisions on the first frame-sized call of a checkpoint although
+the answer is camera-dependent (VERDICT r5 weak-1 / missing-1)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import test_gpu_launch_scale as LS  # noqa: E402
+from test_gpu_parity import make_renderer, to_np  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def R():
+    from ibl_nerf_amd import binding as B, renderer
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    B.load_library()
+    return renderer
+
+
+def _same(a, b):
+    return all(torch.equal(a[k].nan_to_num(7.0), b[k].nan_to_num(7.0)) for k in a)
+
+
+def test_one_renderer_two_poses_each_view_decides_for_itself(R, lut):
+    """One default-constructed Renderer renders the frontal view's fixture (fitted_launch16k: the FAST table holds) and then the rotated camera's (fitted_posed4k: the
+    normal needs SAFE) — each view is measured on its own rays and passes the STRICT launch-scale rules against the reference's render; then the frontal view again,
+    which is its first render bit for bit (round 5: the first view's table served every later pose).  The reverse order on a fresh context gives the same bits."""
+    ga, sdc, sdf, gta, edita = load_golden("fitted_launch16k")
+    gb, _, _, gtb, editb = load_golden("fitted_posed4k")
+    assert LS.DECISION["fitted_launch16k"] == "fast" and LS.DECISION["fitted_posed4k"] == "safe"
+    r = make_renderer(R, ga, sdc, sdf, lut)
+    assert r.mlp_precision == "auto" and r.policy is None and r.route is None
+    a1 = r.render_rays(ga["rays_o"], ga["rays_d"], 0.5, 8.0, gta, **edita)
+    assert r.policy["decision"] == "fast" and not r.policy.get("imposed") and r.route["decided"] and not r.route.get("imposed")
+    LS.check_against_fixture(to_np(a1), ga, rules=LS.rules_for("fitted_launch16k"), name="fitted_launch16k", decision="fast")
+    b1 = r.render_rays(gb["rays_o"], gb["rays_d"], float(gb["near"]), float(gb["far"]), gtb, **editb)
+    assert r.policy["decision"] == "safe", r.policy                                  # measured on THIS view's rays
+    LS.check_against_fixture(to_np(b1), gb, rules=LS.rules_for("fitted_posed4k"), name="fitted_posed4k", decision="safe")
+    a2 = r.render_rays(ga["rays_o"], ga["rays_d"], 0.5, 8.0, gta, **edita)
+    assert r.policy["decision"] == "fast" and _same(a1, a2)                          # ... and the frontal view is FAST again: no demotion, no memory
+    assert r.trips == 0 and r.alarms == 0 and r.range_fallbacks == 0
+    r2 = make_renderer(R, ga, sdc, sdf, lut)
+    b0 = r2.render_rays(gb["rays_o"], gb["rays_d"], float(gb["near"]), float(gb["far"]), gtb, **editb)
+    a0 = r2.render_rays(ga["rays_o"], ga["rays_d"], 0.5, 8.0, gta, **edita)
+    assert _same(b0, b1) and _same(a0, a1)
+
+
+def test_a_call_is_rendered_as_if_it_were_the_first(R, lut):
+    """Call history changes nothing: a 64-ray call (too small to measure on: every sample evaluated, SAFE table) gives the same bits before and after a frame-sized
+    call has decided FAST with lists for itself; an IMPOSED route / table (decide_route, set_route, calibrate) is the explicit exception and is withdrawn by
+    set_route(None) / policy = None / load_weights."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    r = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096)
+    small = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
+    assert r.last_selection() == (0, 0) and r.route is None and r.policy is None and not r.get_route()["decided"]
+    big = r.render_rays(g["rays_o"][:8192], g["rays_d"][:8192], 0.5, 8.0)
+    assert r.last_selection()[0] > 0 and r.route["decided"] and r.route["probe_rays"] == 4096 and r.policy["decision"] == "fast"
+    again = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
+    assert r.last_selection() == (0, 0) and r.route is None and r.policy is None and not r.get_route()["decided"] and _same(small, again)
+    # imposing: the measured route and table now serve the small call too ...
+    route = r.decide_route(g["rays_o"][:8192], g["rays_d"][:8192], 0.5, 8.0)
+    assert route["imposed"] and r.calibrate(torch.from_numpy(g["rays_o"][:8192:2].copy()).cuda(), torch.from_numpy(g["rays_d"][:8192:2].copy()).cuda(), 0.5, 8.0)["imposed"]
+    listed = r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0)
+    assert r.last_selection()[1] >= 64 * (64 * 7 + 192) and r.route["imposed"] and r.policy["decision"] == "fast"
+    for k in ("depth_map", "albedo_map", "target_normal_map", "weights"):
+        assert float((listed[k] - small[k]).abs().max() / small[k].abs().max()) <= 5e-4, k          # (another table, lists: the same picture)
+    # ... until it is withdrawn
+    r.set_route(None)
+    r.policy = None
+    assert _same(r.render_rays(g["rays_o"][:64], g["rays_d"][:64], 0.5, 8.0), small)
+    assert _same(r.render_rays(g["rays_o"][:8192], g["rays_d"][:8192], 0.5, 8.0), big)
+
+
+def _frame(r, K=None, c2w=None):
+    H = W = 800
+    fl = np.float32(0.5 * W / np.tan(0.5 * np.deg2rad(60.0)))
+    K = np.array([[fl, 0, 400], [0, fl, 400], [0, 0, 1]], dtype=np.float32) if K is None else K
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32) if c2w is None else c2w
+    ro, rd = r.get_rays(H, W, K, c2w)
+    return H, W, K, c2w, ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+
+def test_tripped_rays_are_repeated_by_themselves_and_the_split_of_a_frame_changes_nothing(R, lut):
+    """The second fitted checkpoint's 800 x 800 frame: the probe's 4 096 pixels measure a selection margin of 2; somewhere in the frame's 640 000 rays a list launch then
+    refines a positive density whose estimate lay below -1 — the tripwire.  Round 5 doubled the context's margins for good and rendered the whole frame again (so an 8-rank
+    frame was not the 1-rank frame: only the rank that owned the sample re-rendered, under other margins than its peers).  Round 6: k_tripwire marks the RAY, the wrapper
+    renders the marked rays once more with every sample evaluated and overwrites their rows; the route is untouched.  A ray's result is then a function of (probe, ray):
+    the frame in one call == the frame as two halves == the frame as 8 interleaved row tiles, bit for bit, on every map."""
+    from ibl_nerf_amd import dist as D
+    g, sdc, sdf, _, _ = load_golden("fitted2_launch4k")
+    r = make_renderer(R, g, sdc, sdf, lut)
+    H, W, K, c2w, ro, rd = _frame(r)
+    probe = D.frame_probe_for_call(r, H, W, K, c2w, 0.5, 8.0)
+    assert probe["rays_d"].shape == (4096, 3) and torch.equal(probe["rays_d"], rd[torch.as_tensor(D.probe_pixels(H, W), device=ro.device)])     # the frame's own rays, bit for bit
+    whole = r.render_rays(ro, rd, 0.5, 8.0, probe=probe)
+    assert r.trips >= 1 and r.alarms == 0 and r.route["select_margin"] == [2.0, 2.0] and r.route["tripped"] == 0 and r.policy["decision"] == "safe", (r.trips, r.route)
+    marked = set(int(i) for i in r.last_trip_rays.cpu())
+    assert 1 <= len(marked) <= 64, len(marked)
+    n = ro.shape[0]
+    t0 = r.trips
+    halves = [r.render_rays(ro[a:b].contiguous(), rd[a:b].contiguous(), 0.5, 8.0, probe=probe) for a, b in ((0, n // 3), (n // 3, n))]
+    assert r.trips - t0 == len(marked)                                                # the same rays are marked whatever call they are rendered in
+    for k in whole:
+        assert torch.equal(torch.cat([h[k] for h in halves]).nan_to_num(7.0), whole[k].nan_to_num(7.0)), k
+    tiles = D.render_frame(r, H, W, K, c2w, 0.5, 8.0)                                 # (no process group: one tile; the rays generated row-strided)
+    for k in D.EXPORT_KEYS:
+        assert torch.equal(tiles[k].reshape(-1).nan_to_num(7.0), whole[k].reshape(-1).nan_to_num(7.0)), k
+    rows = [D.tile_row_indices(H, t, 8) for t in range(8)]
+    parts = []
+    for rr in rows:
+        to, td = r.get_rays_strided(H, W, K, c2w, rr.start, rr.step, len(rr))
+        parts.append(r.render_rays(to.reshape(-1, 3), td.reshape(-1, 3), 0.5, 8.0, probe=probe))
+    for k in ("depth_map", "target_normal_map", "color_map", "albedo_map", "weights"):
+        full = torch.stack([p[k].reshape((len(rows[0]), W) + tuple(p[k].shape[1:])) for p in parts], 1).reshape((H * W,) + tuple(parts[0][k].shape[1:]))
+        assert torch.equal(full.nan_to_num(7.0), whole[k].nan_to_num(7.0)), k
+    # the marked rays' rows are the every-sample evaluation's: the frame rendered with the lists off altogether has them bit for bit (the other rays differ by what the
+    # two routes' coarse densities differ by — exact fp32 on the lists, the 15-slot form on whole batches: other fine samples on the reference's own sensitive rays)
+    r.lib.iblnerf_set_lists(r.ctx, 0)
+    try:
+        nolist, _, _ = r._render(ro, rd, 0.5, 8.0, None, {})
+    finally:
+        r.lib.iblnerf_set_lists(r.ctx, 1)
+    idx = torch.as_tensor(sorted(marked), device=ro.device)
+    for k in ("depth_map", "target_normal_map", "weights", "albedo_map"):
+        assert torch.equal(nolist[k][idx], whole[k][idx]), k
+
+
+def test_a_route_that_does_not_fit_the_call_raises_the_alarm(R, lut):
+    """An audited sample — dropped as clearly empty — that turns out NOT to be empty (bit 4 of the range flags), or marks on more rays than max(16, n / 256), say the ROUTE
+    is wrong for the call (its probe did not see what the call's rays see, or it was imposed from elsewhere): the route climbs the ladder (iblnerf_escalate_route: margins
+    2 -> 4 -> 6, six-slot estimates, lists off) and the whole call is rendered again.  Built here by imposing the route measured on the fitted network — plain-f16 estimates,
+    margin 2 — onto a network built to break plain-f16 estimates (test_gpu_fitted.cancelling_network: errors up to 6 in raw density); the result is the every-sample
+    render's, bit for bit."""
+    import test_gpu_fitted as TF
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    sd = TF.cancelling_network(g, sdc)
+    n = 8192
+    ro, rd = g["rays_o"][:n], g["rays_d"][:n]
+    whole = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x", query_routing=("coarse_density_all_points",)).render_rays(ro, rd, 0.5, 8.0)
+    good = make_renderer(R, g, sdc, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    good.render_rays(ro, rd, 0.5, 8.0)
+    assert good.trips == 0 and good.route["estimates_plain_f16"] == [True, True]
+    r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    r.set_route(good.route)
+    assert r.estimate_policy(0) == (True, True) and r.route["imposed"]
+    got = r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.alarms >= 1 and r.route["tripped"] == 2 and r.route["imposed"] and r.range_fallbacks == 0, (r.alarms, r.route)
+    for k in got:
+        assert torch.equal(got[k], whole[k]), k
+    a = r.alarms
+    r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.alarms == a                                                              # (an imposed route keeps what it learned)
+    # left to itself the call's own probe sees the network for what it is: plain-f16 estimates refused on sight, the ladder climbed on the probe (and, for what only the
+    # call's other rays show, by the alarm): the same result
+    r = make_renderer(R, g, sd, sdf, lut, max_rays_per_launch=4096, mlp_precision="f16x3_mxfp6x")
+    got = r.render_rays(ro, rd, 0.5, 8.0)
+    assert r.route["tripped"] == 2 and r.probe_escalations >= 1 and r.last_selection() == (0, 0), (r.route, r.probe_escalations, r.alarms)
+    for k in got:
+        assert torch.equal(got[k], whole[k]), k

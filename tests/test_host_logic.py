@@ -74,7 +74,7 @@ def test_ctypes_structs_mirror_the_header():
             decl = " ".join(decl.split())
             if not decl:
                 continue
-            m = re.match(r"(?:const )?(int32_t|float|iblnerf_maps)\s*(\*?)\s*(.*)$", decl)
+            m = re.match(r"(?:const )?(int32_t|float|iblnerf_maps|unsigned char)\s*(\*?)\s*(.*)$", decl)
             assert m, (name, decl)
             base, ptr, rest = m.groups()
             for item in rest.split(","):
