@@ -26,7 +26,7 @@ EXPORTS = [
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
     "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt", "iblnerf_ray_outputs_backward_rays", "iblnerf_coarse_z_rays", "iblnerf_aux_query", "iblnerf_aux_backward", "iblnerf_ray_outputs_backward_env", "iblnerf_set_select_tmin", "iblnerf_set_chunk_cuts",
     "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units", "iblnerf_trunk_density_fp32", "iblnerf_set_offset_tier_threshold",
-    "iblnerf_escalate_route", "iblnerf_set_lists", "iblnerf_get_rays_strided", "iblnerf_get_rays_pixels",
+    "iblnerf_escalate_route", "iblnerf_set_lists", "iblnerf_get_rays_strided", "iblnerf_get_rays_pixels", "iblnerf_set_tier_thresholds",
 ]
 
 
@@ -48,7 +48,7 @@ MLP_BF16X3, MLP_F16_MXFP6, MLP_F16_MIXED, MLP_F16X3, MLP_F16X3_MXFP6, MLP_F16X3_
 MLP_PRECISIONS = {"bf16x3": MLP_BF16X3, "f16_mxfp6": MLP_F16_MXFP6, "f16_mixed": MLP_F16_MIXED, "f16x3": MLP_F16X3,
                   "f16x3_mxfp6": MLP_F16X3_MXFP6, "f16x3_main": MLP_F16X3_MAIN, "f16x3_mxfp6x": MLP_F16X3_MXFP6X}
 ROUTE_COARSE_OFFSETS_MIXED, ROUTE_USER_TRUNK_MIXED, ROUTE_FINE_MAIN_PRECISE, ROUTE_POINT_BATCH, ROUTE_COARSE_MAIN_22BIT, ROUTE_USER_TRUNK_P, ROUTE_FINE_OFFSETS_PRECISE, ROUTE_COARSE_DENSITY_ALL_POINTS = 1, 2, 4, 8, 16, 32, 64, 128   # iblnerf_options.query_routing bits
-ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE, ROUTE_OFFSETS_ESTIMATE_ALL, ROUTE_COARSE_DENSITY_15SLOT, ROUTE_NO_OFFSET_TIERS = 256, 512, 1024, 4096, 8192
+ROUTE_ESTIMATES_6SLOT, ROUTE_ESTIMATES_WHOLE, ROUTE_OFFSETS_ESTIMATE_ALL, ROUTE_COARSE_DENSITY_15SLOT, ROUTE_NO_OFFSET_TIERS, ROUTE_FINE_TIERS = 256, 512, 1024, 4096, 8192, 16384
 AUX_KINDS = {"albedo_mlp": (0, 3), "roughness_mlp": (1, 1), "irradiance_mlp": (2, 1), "normal_mlp": (3, 3)}   # render kwarg -> (IBLNERF_AUX_*, out_ch)
 
 
@@ -156,6 +156,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_get_route.restype = C.c_int
     lib.iblnerf_describe_route.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.iblnerf_describe_route.restype = C.c_int
+    lib.iblnerf_set_tier_thresholds.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.iblnerf_set_tier_thresholds.restype = C.c_int
     lib.iblnerf_set_offset_tier_threshold.argtypes = [C.c_void_p, C.c_float]
     lib.iblnerf_set_offset_tier_threshold.restype = C.c_int
     lib.iblnerf_last_slot_units.argtypes = [C.c_void_p, C.POINTER(C.c_double)]

@@ -44,6 +44,10 @@ constexpr float MARGIN_MAX = 6.0f, MARGIN_ZONE = 8.0f;
 // ... the offset copies' depths are differenced and divided by 2 epsilon: S x TMIN x far / (2 epsilon) bounds what the samples left at their estimate can move the
 // normal by (192 x 1e-8 x 8 / 0.02 = 8e-4, measured 3.5e-4 on one ray of a frame); two more decades of transmittance cost a sample or two per copy
 constexpr float OFFSET_SELECT_TMIN = 1e-10f;
+// The TIERED table's thresholds (IBLNERF_ROUTE_FINE_TIERS; k_importance).  Offset copies: T_s dist_s |depth - z_s| of the main ray above 5e-5 -> three f16 products; measured
+// (scratch/tier_probe.py, 4 096-pixel probes of four checkpoint x camera cases whose normals need the SAFE table: 99.9 % at 5e-4 .. 2.2e-3 against SAFE under the fast table) a
+// threshold of 1e-4 leaves 7e-5 .. 1.2e-4 and no ray above 1e-3 at +1..3 % of a frame, 2e-5 the same at +2..4 %; SAFE itself costs +10 %.  Main query: own weight above 1e-3.
+constexpr float TIER_TAU_OFFSETS = 5e-5f, TIER_TAU_MAIN = 2e-3f;
 // estimate_chunked / k_range_points mode 3: a ray counts as saturated behind a chunk (or behind the predicted range) below this transmittance.  0 = the query's own selection
 // threshold: the selection drops every sample behind it whatever its estimate, so an estimate there buys only a weight below the threshold for a sample that is dropped anyway
 // (set to exactly zero instead).  Round 4 used 1e-12 for every query — two decades under the thresholds, for bit-identical weights — and paid 5.7 % of a frame for it
@@ -119,9 +123,13 @@ struct iblnerf_ctx {
     double coarse_share = -1.0;                   // the probe's relevant share of the coarse grid (sel_on = it is <= SELECT_MAX_FRACTION)
     bool offsets_estimate_all = false;            // IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL: round 4's offsets (an estimate on every sample of every copy)
     int* main_range = nullptr;                    // [ws_rays][2] first / last relevant sample of each ray's main query in the current pass (k_select_points range_out)
-    unsigned long long* tier_mask = nullptr;      // [ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers)
+    unsigned long long* tier_mask = nullptr;      // [2][ws_rays][4] k_importance's per-sample flags of the fine pass's main rays (offset tiers; the main query's own two masks)
     float tier_tau = 0.0f;                        // ... their threshold on T_s dist_s |depth - z_s| (iblnerf_set_offset_tier_threshold; 0 = no tiers, the default)
     bool no_offset_tiers = false;                 // IBLNERF_ROUTE_NO_OFFSET_TIERS
+    bool fine_tiers = false;                      // IBLNERF_ROUTE_FINE_TIERS: the TIERED table — the fine pass's main query and offset copies on the fast forms except where
+                                                  // an error would show: the samples k_importance flags go to the three-product kernels
+    float tier_tau_main = 0.0f;                   // ... the main query's threshold on a sample's own weight (0: TIER_TAU_MAIN)
+    bool tier_single = false;                     // (experiment, env IBLNERF_TIER_TWO_PHASE=1) the fine main query's tiers all decided on the refined densities: flagged samples evaluated twice
     float tmin_main = COARSE_SELECT_TMIN, tmin_offsets = OFFSET_SELECT_TMIN, tmin_chunk = CHUNK_TMIN;     // iblnerf_set_select_tmin (tmin_chunk 0: each query's own threshold)
     float chunk_t(float own) const { return tmin_chunk > 0.f ? tmin_chunk : own; }
     int cuts_fine[2] = {0, 0}, cuts_refl[2] = {0, 0};      // iblnerf_set_chunk_cuts (0: the built-in fractions)
@@ -192,13 +200,15 @@ static void apply_routing(iblnerf_ctx* c, int bits) {
     c->offsets_estimate_all = (bits & IBLNERF_ROUTE_OFFSETS_ESTIMATE_ALL) != 0;
     c->density_15slot = (bits & IBLNERF_ROUTE_COARSE_DENSITY_15SLOT) != 0;
     c->no_offset_tiers = (bits & IBLNERF_ROUTE_NO_OFFSET_TIERS) != 0;
+    c->fine_tiers = (bits & IBLNERF_ROUTE_FINE_TIERS) != 0;
+    c->tier_single = std::getenv("IBLNERF_TIER_TWO_PHASE") != nullptr;
 }
 
 extern "C" {
 
 int iblnerf_set_query_routing(iblnerf_ctx* c, int bits) {
     if (!c) return IBLNERF_ERR_INVALID;
-    if (bits < 0 || bits > 16383) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..16383)");
+    if (bits < 0 || bits > 32767) return c->fail(IBLNERF_ERR_INVALID, "set_query_routing: a set of IBLNERF_ROUTE_* bits (0..32767)");
     apply_routing(c, bits);
     return IBLNERF_OK;
 }
@@ -272,8 +282,8 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
                          "IBLNERF_NORMAL_DEPTH_GRADIENT (4) or IBLNERF_NORMAL_DEPTH_GRADIENT_DIRECTION (5)";
         return IBLNERF_ERR_INVALID;
     }
-    if (opts->query_routing < 0 || opts->query_routing > 16383 || opts->persistent_workgroups < 0) {
-        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..16383), persistent_workgroups >= 0";
+    if (opts->query_routing < 0 || opts->query_routing > 32767 || opts->persistent_workgroups < 0) {
+        g_create_error = "query_routing must be a set of IBLNERF_ROUTE_* bits (0..32767), persistent_workgroups >= 0";
         return IBLNERF_ERR_INVALID;
     }
     if (opts->mlp_precision < IBLNERF_MLP_BF16X3 || opts->mlp_precision > IBLNERF_MLP_F16X3_MXFP6X) {
@@ -316,7 +326,7 @@ int iblnerf_create(const iblnerf_options* opts, iblnerf_ctx** out_ctx) {
     if (hipMalloc((void**)&c->sel_pts, 4 * R * Sm * 3 * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->sel_index, 4 * R * Sm * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->sel_count, 12 * sizeof(int)) != hipSuccess || hipMemset(c->sel_count, 0, 12 * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->main_range, 2 * R * sizeof(int)) != hipSuccess || hipMalloc((void**)&c->sel_est, 4 * R * Sm * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&c->tier_mask, 4 * R * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->tier_mask, 2 * 4 * R * sizeof(unsigned long long)) != hipSuccess) {
         g_create_error = "hipMalloc of the render workspace failed";
         iblnerf_destroy(c);
         return IBLNERF_ERR_NOMEM;
@@ -1456,6 +1466,10 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         // set to exactly zero moved z_std of one ray of a frame by 5e-5)
         q.list = true; q.open = !c->sel_decided; q.share_max = SELECT_MAX_FRACTION;
         q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
+        if (fast && c->fine_tiers && !c->deciding && c->d_stream_f16[which] != nullptr && c->mx_ok[which]) {      // (the TIERED table: see the fine pass below)
+            q.tiers = true;
+            q.on_list_precise = pick_kernel(c, which, VAR_FULL_LIST, Q_LIST3, false);
+        }
         q.density_list.kern = K_MX; q.density_list.variant = VAR_TRUNK_P;
         if (density_fp32(c, which)) { q.density_list.kern = K_FP32; q.density_list.variant = VAR_TRUNK; }
     }
@@ -1466,6 +1480,12 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         // The selected rows are those of the FULL form bit for bit (same kernel arithmetic); the others: the plain-f16 density estimate, zero channels.
         q.list = true; q.open = c->fsel_fraction < 0.0; q.share_max = FINE_SELECT_MAX_FRACTION;
         q.on_list = pick_kernel(c, which, VAR_FULL_LIST, fast ? Q_ESTIMATE : Q_LIST3, false);
+        // the TIERED table (round 6): the fast form for every relevant sample but the handful per ray that carry a weight above the threshold — those on three f16 products
+        // (what the safe table runs everywhere: its per-sample weights, at the fast table's price + 1 %)
+        if (fast && c->fine_tiers && !c->deciding && c->d_stream_f16[which] != nullptr && c->mx_ok[which]) {
+            q.tiers = true;
+            q.on_list_precise = pick_kernel(c, which, VAR_FULL_LIST, Q_LIST3, false);
+        }
         if (est_chunks(c, which)) { q.cut0 = (3 * S) / 4; q.cut1 = (7 * S) / 8; }
         if (est_chunks(c, which) && c->cuts_fine[1] > 0 && c->cuts_fine[1] < S) { q.cut0 = c->cuts_fine[0]; q.cut1 = c->cuts_fine[1]; }
     }
@@ -1532,7 +1552,7 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
             // trunk form 4 coarse normals.  The table is at its floor.)
             if (q.predicted && fine_x_fast && c->d_stream_f16[which] != nullptr && c->mx_ok[which] && !c->no_offset_tiers) {
                 q.on_list_precise = pick_kernel(c, which, VAR_TRUNK_LIST, Q_LIST3, false);
-                q.tiers = c->tier_tau > 0.0f;
+                q.tiers = c->tier_tau > 0.0f || c->fine_tiers;
             }
         }
     }
@@ -1643,9 +1663,26 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
         HIP_TRY(c, hipMemsetAsync(c->raw, 0, (size_t)n * RAW_CH * sizeof(float), s));
         HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
         c->sel_candidates += n;
+        // The fine pass's tiers are decided BEFORE the lists are evaluated, on the density estimates (k_importance mode 1: own weight above the threshold — the samples of a
+        // surface, whose densities are large and whose estimates are good to 11 %), so that every sample is evaluated once; what the estimates cannot tell — a hazy ray, whose
+        // whole weight is a few small densities an estimate misses by its absolute error of ~1 — is found afterwards on the refined densities and evaluated once more (below).
+        // (Measured: deciding all tiers afterwards, every flagged sample twice, costs 1.7 x as much.)  The coarse pass (5 relevant samples per ray) decides afterwards.
+        const bool single = q.tiers && !c->tier_single && kind == PASS_FINE;
+        if (single) {
+            HIP_TRY(c, launch_importance(p.rd, p.z, p.z_stride, c->sig4, 1, R, S, c->tier_tau_main > 0.0f ? c->tier_tau_main : TIER_TAU_MAIN, c->tier_mask, s, 4, c->margin[which]));
+            HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
+                                            false, 0.f, c->raw, RAW_CH, variant_flops(q.on_list_precise.variant), c->main_range, nullptr, list_slots(q.on_list_precise), c->sel_est,
+                                            c->tier_mask, 1));
+            MlpCall t;
+            t.pts = c->sel_pts; t.dirs = p.rd; t.pts_per_ray = S; t.n_pts = n; t.out = c->raw; t.count_flops = false; t.n_pts_dev = c->sel_count; t.out_index = c->sel_index;
+            t.trip_margin = c->margin[which];
+            if ((rc = run_launch(c, s, q.on_list_precise, which, t))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+        }
         HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
-                                        false, 0.f, c->raw, RAW_CH, variant_flops(q.on_list.variant) + (q.density_list.none() ? 0.0 : FLOP_TRUNK), c->main_range, nullptr,
-                                        list_slots(q.on_list) + list_slots(q.density_list), c->sel_est));
+                                        false, 0.f, single ? nullptr : c->raw, RAW_CH, variant_flops(q.on_list.variant) + (q.density_list.none() ? 0.0 : FLOP_TRUNK),
+                                        single ? nullptr : c->main_range, nullptr, list_slots(q.on_list) + list_slots(q.density_list), c->sel_est,
+                                        single ? c->tier_mask : nullptr, 0));
         if (q.open) {     // the probe: does this network have empty space and surfaces, or is it fog?  / how many of the fine samples are relevant?
             long n_sel = 0;
             if ((rc = read_list_length(c, s, &n_sel))) return rc;
@@ -1659,6 +1696,32 @@ static int run_main_query(iblnerf_ctx* c, hipStream_t s, int which, int kind, co
             m.pts = c->sel_pts; m.dirs = p.rd; m.pts_per_ray = S; m.n_pts = n; m.out = c->raw; m.count_flops = false; m.n_pts_dev = c->sel_count; m.out_index = c->sel_index;
             m.trip_margin = c->margin[which];
             if ((rc = run_launch(c, s, q.on_list, which, m))) return rc;
+            if (q.tiers) {
+                // The TIERED table's second tier (fine pass: its hazy-ray fix-up only, k_importance mode 3): of the samples just refined on the fast form, those whose own weight — now from the REFINED densities, good to 1e-3 of
+                // themselves; the estimates that chose the list can be off by a unit of raw density, which misjudges a weight — exceeds the threshold are evaluated once
+                // more on three f16 products and their rows overwritten (k_importance mode 1; the selection below repeats k_select_points' with that filter: same samples,
+                // same estimates, no audit, no range).
+                const bool density_only = q.on_list_precise.variant == VAR_TRUNK_LIST;
+                // (fine pass: what the estimates' tiers MISSED — a sample whose refined weight exceeds the threshold although its estimate said empty (a haze of density 0.5
+                // estimated at -0.2: 0.1 % of the second checkpoint's rays, whose per-sample weights otherwise stay at 6e-4 of SAFE's whatever the threshold), and the hazy rays —
+                // into the second mask, less what the first one sent to the precise kernel already)
+                unsigned long long* mask2 = single ? c->tier_mask + 4 * c->ws_rays : c->tier_mask;
+                HIP_TRY(c, launch_importance(p.rd, p.z, p.z_stride, c->raw, RAW_CH, R, S, c->tier_tau_main > 0.0f ? c->tier_tau_main : TIER_TAU_MAIN, mask2, s,
+                                             kind != PASS_FINE ? 1 : 2, 0.0f, single ? c->tier_mask : nullptr));
+                HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+                HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
+                                                false, 0.f, nullptr, 0, variant_flops(q.on_list_precise.variant), nullptr, nullptr, list_slots(q.on_list_precise), c->sel_est,
+                                                mask2, 1));
+                MlpCall t;
+                t.pts = c->sel_pts; t.dirs = density_only ? nullptr : p.rd; t.pts_per_ray = S; t.n_pts = n; t.out = c->raw; t.count_flops = false; t.n_pts_dev = c->sel_count;
+                t.out_index = c->sel_index; t.out_stride = density_only ? RAW_CH : 1;
+                if ((rc = run_launch(c, s, q.on_list_precise, which, t))) return rc;
+                if (!q.density_list.none()) {      // (the coarse pass: the whole list once more for its exact-fp32 density, which goes over every row's density LAST)
+                    HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
+                    HIP_TRY(c, launch_select_points(p.ro, p.rd, p.z, p.z_stride, c->sig4, 1, p.noise, R, S, c->margin[which], q.t_min, c->sel_pts, c->sel_index, c->sel_count, s,
+                                                    false, 0.f, nullptr, 0, 0.0, nullptr, nullptr, 0.0, c->sel_est));
+                }
+            }
             if (!q.density_list.none()) {
                 m.dirs = nullptr; m.out_stride = RAW_CH; m.trip_margin = 0.0f;
                 if ((rc = run_launch(c, s, q.density_list, which, m))) return rc;
@@ -1723,7 +1786,7 @@ static int offsets_on_lists(iblnerf_ctx* c, hipStream_t s, int which, const Quer
     if (q.predicted) {
         MlpCall est = refine;
         // 1: the predicted range, straight to the query's kernel (no estimate underneath: no tripwire) — in one list, or in two tiers by k_importance's flags
-        if (q.tiers) HIP_TRY(c, launch_importance(p.rd, p.z, p.z_stride, c->raw, RAW_CH, R, S, c->tier_tau, c->tier_mask, s));
+        if (q.tiers) HIP_TRY(c, launch_importance(p.rd, p.z, p.z_stride, c->raw, RAW_CH, R, S, c->tier_tau > 0.0f ? c->tier_tau : TIER_TAU_OFFSETS, c->tier_mask, s));
         for (int tier = q.tiers ? 1 : 0; tier >= 0; --tier) {
             const Launch& k = (q.tiers && tier == 1) ? q.on_list_precise : q.on_list;
             HIP_TRY(c, hipMemsetAsync(c->sel_count, 0, sizeof(int), s));
@@ -2178,6 +2241,14 @@ int iblnerf_set_select_tmin(iblnerf_ctx* c, float t_main, float t_offsets, float
     return IBLNERF_OK;
 }
 
+int iblnerf_set_tier_thresholds(iblnerf_ctx* c, float tau_offsets, float tau_main) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (!(tau_offsets >= 0.0f) || !(tau_main >= 0.0f)) return c->fail(IBLNERF_ERR_INVALID, "set_tier_thresholds: thresholds >= 0 (0 = the built-in ones)");
+    c->tier_tau = tau_offsets;
+    c->tier_tau_main = tau_main;
+    return IBLNERF_OK;
+}
+
 int iblnerf_set_offset_tier_threshold(iblnerf_ctx* c, float tau) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (!(tau >= 0.0f)) return c->fail(IBLNERF_ERR_INVALID, "set_offset_tier_threshold: tau >= 0 (0 = no tiers)");
@@ -2315,7 +2386,8 @@ int iblnerf_describe_route(iblnerf_ctx* c, char* buf, size_t n) {
         else if (q.cut1 > 0) add(" in z-chunks [0,%d) [%d,%d) [%d,%d)", q.cut0, q.cut0, q.cut1, q.cut1, S);
         else add(" on every sample");
         add("; select T > %.0e; list: %s", (double)q.t_min, launch_name(q.on_list));
-        if (q.tiers) add(" | flagged samples (T dist |depth - z| > %.0e): %s", (double)c->tier_tau, launch_name(q.on_list_precise));
+        if (q.tiers && q.predicted) add(" | flagged samples (T dist |depth - z| > %.0e): %s", (double)(c->tier_tau > 0.0f ? c->tier_tau : TIER_TAU_OFFSETS), launch_name(q.on_list_precise));
+        if (q.tiers && !q.predicted) add(" | samples of weight > %.0e: %s", (double)(c->tier_tau_main > 0.0f ? c->tier_tau_main : TIER_TAU_MAIN), launch_name(q.on_list_precise));
         if (!q.on_list_precise.none()) add(" | own selection outside the predicted range: %s", launch_name(q.on_list_precise));
         if (!q.density_list.none()) add(" + %s", launch_name(q.density_list));
         add("\n");

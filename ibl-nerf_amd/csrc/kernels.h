@@ -208,7 +208,8 @@ hipError_t launch_select_points(const float* rays_o, const float* rays_d, const 
                                 int* range_out = nullptr,            // [R][2] (not with offsets): each ray's first and last selected sample ({S, -1}: none)
                                 const int* skip_range = nullptr,     // offsets: such a record of the MAIN rays — the samples predicted relevant by it ([first - 1, last + 1]) are not selected (again)
                                 double list_slots_per_point = 0.0,   // ... and their matrix-slot units per entry (counter[8..9])
-                                float* est_list = nullptr);          // [list length] the estimate of every list entry (for launch_tripwire)
+                                float* est_list = nullptr,           // [list length] the estimate of every list entry (for launch_tripwire)
+                                const unsigned long long* tier_mask = nullptr, int tier = 0);   // only the selected samples whose k_importance flag equals `tier` (audits: tier 0)
 // the estimate tripwire: after a list launch, every entry's refined density out[index[i] * out_stride] against est_list[i] (k_tripwire); raises bits 2 / 3 of *flag
 // ... and marks the ray of every such entry in trip_rays [R] (nullable; entry -> ray (index / S) % R: offset copies belong to their ray)
 hipError_t launch_tripwire(const float* est_list, const int* index, const int* n_dev, const float* out, int out_stride, float margin, unsigned* flag, long n_bound, hipStream_t s,
@@ -221,8 +222,9 @@ hipError_t launch_range_points(const float* rays_o, const float* rays_d, const f
                                const unsigned long long* tier_mask = nullptr, int tier = 0);   // mode 1: only the samples whose k_importance flag equals `tier`
 // per sample of the R main rays: does T_s dist_s |depth - z_s| (from the main query's densities, element (r, s) at (r S + s) * sigma_stride) exceed tau?  mask [R][4] uint64:
 // bit `lane` of mask[4 r + i] <-> sample lane * NPL + i (NPL = ceil(S / 64): the layout k_range_points reads)
+// mode 1: the sample's own weight alpha_s T_s exceeds tau (the fine main query's tiers, from its density estimates)
 hipError_t launch_importance(const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, long R, int S, float tau, unsigned long long* mask,
-                             hipStream_t s);
+                             hipStream_t s, int mode = 0, float margin = 0.0f, const unsigned long long* exclude = nullptr);   // mode 4: mode 1 on density ESTIMATES, the transmittance taken conservatively (margin)
 
 // estimates in two z-chunks: points + flat indices of samples [s0, s1) of every (virtual) ray (first: of all rays, in ray order; else: of the rays not yet saturated
 // behind their first s0 samples — list length at counter[0], executed MACs added to counter[4..5]; the others' samples get the density -1e30)

@@ -882,9 +882,14 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_range_points(const float*
 // `tau` are flagged (bit `lane` of mask[4 r + i] <-> sample lane NPL + i): the fine grid's offset copies evaluate them on three f16 products, the others on the mixed
 // trunk form, whose 1.5e-3 in raw density then moves a copy's depth by < tau x 1.5e-3 x (unflagged samples) — with tau = 5e-6 and 192 samples below 1.5e-6, i.e. 7e-5 on
 // the normal.  (The rays this is for: a soft haze of small positive density in front of the surface — every sample of it sees the whole depth behind it.)
+// mode 1 (round 6, the fine MAIN query's tiers): where would an error on the main query's OWN density move its per-sample weights most?  d w_s / d sigma_s = T_s dist_s
+// exp(-sigma_s dist_s), and every weight behind s moves by -w_j dist_s d sigma_s: with a relative error eps on sigma_s, at most eps T_s x exp(-x), x = sigma_s dist_s — of the
+// order of the sample's own weight.  Samples whose own weight alpha_s T_s (from `sigma`: here the query's density ESTIMATES, before the list is refined) exceeds `tau` are
+// flagged: the main query evaluates them on three f16 products, the others — thousands of them per ray-weight above tau, each moving a weight by < eps tau — on the fast form.
 template <int NPL>
 __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ rays_d, const float* __restrict__ zbase, int z_stride, const float* __restrict__ sigma,
-                                                    int sigma_stride, long R, int S, float tau, unsigned long long* __restrict__ mask) {
+                                                    int sigma_stride, long R, int S, float tau, unsigned long long* __restrict__ mask, int mode, float margin,
+                                                    const unsigned long long* __restrict__ exclude) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -901,7 +906,12 @@ __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ ra
         const float sg = s < S ? sigma[(r * S + s) * (long)sigma_stride] : 0.0f;
         dist[i] = (s == S - 1 ? 1e10f : (zn - z[i])) * norm;
         alpha[i] = s < S ? 1.0f - expf(-fmaxf(sg, 0.0f) * dist[i]) : 0.0f;
-        om[i] = s < S ? (double)((1.0f - alpha[i]) + 1e-10f) : 1.0;
+        // mode 4 (the fine main query's tiers, decided on density ESTIMATES): the transmittance a sample's weight is judged by is k_select_points' CONSERVATIVE one — the
+        // densities in front taken at 3/4 of their estimate less the margin — so that an estimate that overshoots what lies in front (11 % of a large density, a unit of a
+        // small one) cannot hide a sample that carries weight (measured on the second checkpoint: with the plain transmittance 0.1 % of the rays kept a heavy sample on the
+        // fast form and the per-sample weights stayed at 6e-4 of SAFE's whatever the threshold)
+        const float a_t = (mode == 4 && s < S) ? 1.0f - expf(-fmaxf(sg * 0.75f - margin, 0.0f) * dist[i]) : alpha[i];
+        om[i] = s < S ? (double)((1.0f - a_t) + 1e-10f) : 1.0;
         lane_prod *= om[i];
     }
     double incl = lane_prod;
@@ -912,20 +922,27 @@ __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ ra
     }
     double T = __shfl_up(incl, 1);
     if (lane == 0) T = 1.0;
-    float Ts[NPL], depth = 0.0f;
+    float Ts[NPL], depth = 0.0f, acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         Ts[i] = (float)T;
         depth += alpha[i] * Ts[i] * z[i];
+        acc += alpha[i] * Ts[i];
         T *= om[i];
     }
     depth = wave_sum(depth);
+    acc = wave_sum(acc);
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
-        const bool flag = s < S && Ts[i] * fminf(dist[i], 1.0f) * fabsf(depth - z[i]) > tau;
+        // mode 1: own weight above tau.  mode 3 (the fine main query's fix-up, from REFINED densities): a HAZY ray — the fast form's density carries an ABSOLUTE error of
+        // ~5e-3 (raw density is a small difference of large terms), i.e. ~T_s dist_s 5e-3 on a weight whatever the sample's own: nothing on a ray that ends on a surface
+        // (acc ~ 1), 14 % on a ray whose whole weight is 1.5e-3 (measured: one sample of sigma 0.034; the output lambdas' pow(x, 1 / 2.2) then shows it as 3e-3 of the
+        // albedo map) — every visible sample of a ray with T_s dist_s > acc is flagged.  mode 2: both.
+        const bool heavy = Ts[i] * alpha[i] > tau, hazy = Ts[i] * fminf(dist[i], 1.0f) > acc && Ts[i] > 1e-4f;
+        const bool flag = s < S && (mode == 0 ? Ts[i] * fminf(dist[i], 1.0f) * fabsf(depth - z[i]) > tau : (mode == 1 || mode == 4) ? heavy : mode == 3 ? hazy : (heavy || hazy));
         const unsigned long long m = __ballot(flag);
-        if (lane == 0) mask[4 * r + i] = m;
+        if (lane == 0) mask[4 * r + i] = exclude != nullptr ? m & ~exclude[4 * r + i] : m;      // (exclude: the samples an earlier mask flagged already)
     }
 }
 
@@ -984,7 +1001,7 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
                                                       const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise, long R, int S, float margin,
                                                       float t_min, float eps, float* __restrict__ pts_out, int* __restrict__ index_out, int* __restrict__ counter,
                                                       float* __restrict__ est_out, int est_stride, int* __restrict__ range_out, const int* __restrict__ skip_range,
-                                                      float* __restrict__ est_list) {
+                                                      float* __restrict__ est_list, const unsigned long long* __restrict__ tier_mask, int tier) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long vr_raw = (long)blockIdx.x * SELECT_WAVES + wave;      // (virtual) ray
     const bool live = vr_raw < (OFFSETS ? 4 * R : R);                // (a dead wave of the last block still takes part in the block's count)
@@ -1048,6 +1065,13 @@ __global__ __launch_bounds__(64 * SELECT_WAVES) void k_select_points(const float
         // sample itself (audit_key above): the same samples on every route, launch and rank.
         const bool audit = reachable && !sel[i] && (audit_key ^ (__builtin_bit_cast(unsigned, z[i]) * 2246822519u)) * 2654435761u >> (32 - AUDIT_LOG2) == 0u;
         first_sel_candidate[i] = sel[i];
+        // tier_mask / tier (round 6, the fine main query in two tiers: api.cpp run_main_query): this pass emits only the selected samples whose k_importance flag equals
+        // `tier`; the ray's range (range_out) is that of both tiers together, the audited samples ride with tier 0
+        if (tier_mask != nullptr) {
+            const bool flagged = ((tier_mask[4 * r + i] >> lane) & 1ull) != 0ull;
+            sel[i] = sel[i] && (flagged == (tier == 1));
+            sel[i] = sel[i] || (audit && tier == 0);
+        } else
         sel[i] = sel[i] || audit;
         T *= om[i];
         masks[i] = __ballot(sel[i]);
@@ -1499,16 +1523,17 @@ hipError_t launch_sigma_weights(const float* rays_d, const float* z, int z_strid
 
 hipError_t launch_select_points(const float* rays_o, const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, const float* noise,
                                 long R, int S, float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps,
-                                float* est_out, int est_stride, double list_flop_per_point, int* range_out, const int* skip_range, double list_slots_per_point, float* est_list) {
+                                float* est_out, int est_stride, double list_flop_per_point, int* range_out, const int* skip_range, double list_slots_per_point, float* est_list,
+                                const unsigned long long* tier_mask, int tier) {
     if (R <= 0) return hipSuccess;
     const dim3 grid((unsigned)(((offsets ? 4 * R : R) + SELECT_WAVES - 1) / SELECT_WAVES)), block(64 * SELECT_WAVES);
     const hipError_t e = by_npl(S, [&](auto N) {
         if (offsets)
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, true>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list, tier_mask, tier);
         else
             hipLaunchKernelGGL((k_select_points<decltype(N)::value, false>), grid, block, 0, s, rays_o, rays_d, z, z_stride, sigma, sigma_stride, noise, R, S, margin,
-                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list);
+                               t_min, eps, pts_out, index_out, counter, est_out, est_stride, range_out, skip_range, est_list, tier_mask, tier);
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_count_selection, dim3(1), dim3(1), 0, s, counter, list_flop_per_point, list_slots_per_point, 1);
@@ -1534,10 +1559,11 @@ hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const f
 }
 
 hipError_t launch_importance(const float* rays_d, const float* z, int z_stride, const float* sigma, int sigma_stride, long R, int S, float tau, unsigned long long* mask,
-                             hipStream_t s) {
+                             hipStream_t s, int mode, float margin, const unsigned long long* exclude) {
     if (R <= 0) return hipSuccess;
     return by_npl(S, [&](auto N) {
-        hipLaunchKernelGGL((k_importance<decltype(N)::value>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, rays_d, z, z_stride, sigma, sigma_stride, R, S, tau, mask);
+        hipLaunchKernelGGL((k_importance<decltype(N)::value>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, rays_d, z, z_stride, sigma, sigma_stride, R, S, tau, mask, mode, margin,
+                           exclude);
     });
 }
 

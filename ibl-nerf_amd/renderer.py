@@ -164,6 +164,10 @@ class Renderer:
             raise B.IblNerfError("iblnerf_create failed (%d): %s" % (rc, self.lib.iblnerf_last_error(None).decode()))
         self.ctx = ctx
         self._keep = []
+        import os
+        if os.environ.get("IBLNERF_TIER_TAUS"):          # (measurement hook: "tau_offsets,tau_main" of the TIERED table, 0 = built-in; scratch/ sweeps)
+            to, tm = (float(v) for v in os.environ["IBLNERF_TIER_TAUS"].split(","))
+            B.check(self.ctx, self.lib.iblnerf_set_tier_thresholds(self.ctx, to, tm))
 
     def __del__(self):
         try:
@@ -444,6 +448,11 @@ class Renderer:
     # the strict rules on both.  So the table is not assumed: the first frame-sized call after a checkpoint is loaded renders <= CAL_RAYS of its own
     # rays under both routings (same context, iblnerf_set_query_routing; ~2 x 12 ms) and keeps FAST only if it stays within CAL_LIMITS of SAFE.
     SAFE_ROUTING = B.ROUTE_FINE_MAIN_PRECISE | B.ROUTE_FINE_OFFSETS_PRECISE
+    # TIERED (round 6) = the fast table's kernels, except that the samples an error would show on — the main query's samples of weight > 1e-3, the offset copies' samples
+    # where T dist |depth - z| of the main ray > 5e-5 (k_importance) — run on three f16 products: within 1.2e-4 (99.9 %) of SAFE's per-sample weights and normals on every
+    # checkpoint x camera case that refuses FAST, for +4..6 % of a frame where SAFE costs +15 % (scratch/tiered_probe.py; thresholds fixed on the first two checkpoints,
+    # then confirmed on the hold-out).  The decision is three-way: FAST if it holds the limits against SAFE, else TIERED if IT does, else SAFE.
+    TIERED_ROUTING = B.ROUTE_FINE_TIERS
     CAL_RAYS, CAL_MIN_RAYS = 4096, 2048       # (a 99.9th percentile needs a few thousand rays: on 586 rays it is the worst ray)
     # per-ray deviation FAST vs SAFE (max over a map's channels over the map's largest value): 99.9th percentile limits, and the share of rays above 1e-3.
     # Measured (scratch/calibration_probe.py, gpurun_out/r4b/calibration.txt; subsets of 1 024 .. 4 096 rays): the checkpoint the FAST table was fixed on
@@ -606,23 +615,34 @@ class Renderer:
                     if self.route is not None:
                         self.route = dict(self.get_route(), **{k: v for k, v in self.route.items() if k in ("imposed", "probe_rays")},
                                           probe_escalations=self.route.get("probe_escalations", 0) + 1)
-            metrics, triggers = {}, []
-            for k, lim in self.CAL_LIMITS.items():
-                if k not in a:
-                    continue
-                x, y = a[k].double().reshape(a[k].shape[0], -1), b[k].double().reshape(a[k].shape[0], -1)
-                e = (x - y).abs().nan_to_num(0.0).amax(-1) / y.abs().nan_to_num(0.0).amax().clamp_min(1e-30)
-                p999 = float(torch.quantile(e.cpu(), 0.999))
-                share = float((e > 1e-3).double().mean())
-                metrics[k] = {"p999": p999, "above_1e-3": share}
-                if p999 > lim:
-                    triggers.append("%s p99.9 %.1e > %.1e" % (k, p999, lim))
-                if share > self.CAL_MAX_SHARE_ABOVE_1E3.get(k, 1.0):
-                    triggers.append("%s: %.2f %% of the rays above 1e-3" % (k, 100 * share))
-            safe = bool(triggers)
-            applied = self.SAFE_ROUTING if safe else 0
-            keep = {"decision": "safe" if safe else "fast", "rays": int(a["depth_map"].shape[0]), "metrics": metrics, "triggers": triggers,
-                    "routing": int(self._routing | (self.SAFE_ROUTING if safe else 0))}
+            def judge(x_maps):
+                metrics, triggers = {}, []
+                for k, lim in self.CAL_LIMITS.items():
+                    if k not in x_maps:
+                        continue
+                    x, y = x_maps[k].double().reshape(x_maps[k].shape[0], -1), b[k].double().reshape(b[k].shape[0], -1)
+                    e = (x - y).abs().nan_to_num(0.0).amax(-1) / y.abs().nan_to_num(0.0).amax().clamp_min(1e-30)
+                    p999 = float(torch.quantile(e.cpu(), 0.999))
+                    share = float((e > 1e-3).double().mean())
+                    metrics[k] = {"p999": p999, "above_1e-3": share}
+                    if p999 > lim:
+                        triggers.append("%s p99.9 %.1e > %.1e" % (k, p999, lim))
+                    if share > self.CAL_MAX_SHARE_ABOVE_1E3.get(k, 1.0):
+                        triggers.append("%s: %.2f %% of the rays above 1e-3" % (k, 100 * share))
+                return metrics, triggers
+
+            metrics, triggers = judge(a)
+            decision, applied = ("fast", 0) if not triggers else ("safe", self.SAFE_ROUTING)
+            keep = {"rays": int(a["depth_map"].shape[0]), "metrics": metrics, "triggers": triggers}
+            if triggers and self.TIERED_ROUTING:
+                # FAST does not hold here: the TIERED table (the fast forms, three f16 products on the samples k_importance flags) against the same yardstick and limits
+                self._set_routing(self.TIERED_ROUTING)
+                c_maps, bits_c, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                m2, t2 = judge(c_maps)
+                keep["metrics_tiered"], keep["triggers_tiered"] = m2, t2
+                if not t2 and not bits_c & TRIP_PROOF:
+                    decision, applied = "tiered", self.TIERED_ROUTING
+            keep["decision"], keep["routing"] = decision, int(self._routing | applied)
         finally:
             self._set_routing(applied)          # (also after an exception inside a probe render: the context goes back to the routing it had — ADVICE r4)
             self.policy = keep

@@ -147,6 +147,13 @@ enum {
                                                  refined samples, where a copy's depth hangs on one or two of them) on three f16 products — 7 of the 8 normals the fast table
                                                  alone left above 1e-3 on a 65 536-ray launch; and, with iblnerf_set_offset_tier_threshold > 0, the predicted range itself in
                                                  two tiers by the bound T_s dist_s |depth - z_s| of the main ray (api.cpp plan_offsets, k_importance; off by default) */
+    IBLNERF_ROUTE_FINE_TIERS = 16384,         /* F16X3_MXFP6X: the TIERED table (round 6) — between the fast table and the safe one (both IBLNERF_ROUTE_FINE_*_PRECISE bits).  The fine pass's
+                                                 main query and offset copies stay on the fast forms except where an error would show: of the main query's relevant samples
+                                                 those whose own weight (from the density estimates) exceeds 1e-3 — a handful per ray — and of the offset copies' predicted
+                                                 range those where T_s dist_s |depth - z_s| of the main ray exceeds 5e-5 go to the three-product f16 kernels (k_importance; the
+                                                 bound on what a density error there moves a weight / a copy's depth by).  Measured on 4 096-pixel probes of the checkpoint x
+                                                 camera cases that need the safe table: per-sample weights and normals within 1.2e-4 of the safe table's at 99.9 %, no ray
+                                                 above 1e-3, for +2..4 % of a frame where the safe table costs +15 % (ibl-nerf_amd/renderer.py decides per call: fast, tiered or safe) */
     IBLNERF_ROUTE_ESTIMATES_6SLOT = 256       /* the density ESTIMATES behind a list refinement (which samples are relevant; the density of those that are not) on the
                                                  f16 + 2 fp6 form (2^-16 per operand) instead of plain f16 (2^-11: 4 matrix slots per 64 MACs instead of 6).  An estimate
                                                  only has to be right to within the selection margin of 1.0 in raw density */
@@ -215,6 +222,8 @@ int iblnerf_set_select_tmin(iblnerf_ctx* ctx, float t_main, float t_offsets, flo
  * reflected rays are cut, in samples; 0, 0 = the built-in cuts (3/4 and 7/8 of the fine grid, 1/2 and 3/4 of the reflected ray's).  Results do not depend on the cuts. */
 int iblnerf_set_chunk_cuts(iblnerf_ctx* ctx, int fine_cut0, int fine_cut1, int refl_cut0, int refl_cut1);
 int iblnerf_set_offset_tier_threshold(iblnerf_ctx* ctx, float tau);
+/* (measurement hook) the thresholds of IBLNERF_ROUTE_FINE_TIERS: tau_offsets on T_s dist_s |depth - z_s| (built-in 5e-5), tau_main on a sample's own weight (1e-3); 0 = built-in. */
+int iblnerf_set_tier_thresholds(iblnerf_ctx* ctx, float tau_offsets, float tau_main);
 /* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
  * Writes at most n bytes including the terminating 0; returns the length the full text needs (snprintf's convention), < 0 on error. */
 int iblnerf_describe_route(iblnerf_ctx* ctx, char* buf, size_t n);

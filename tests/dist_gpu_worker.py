@@ -39,7 +39,7 @@ def fitted_frame(torch, dist, rank, world, backend, kind="fitted"):
     r.load_lut(load_lut_rgb())
     full = D.render_frame(r, H, W, K, c2w, 0.5, 8.0)                      # sharded: rows rank, rank + world, ... + one all-gather
     route, policy, tile_trips = r.get_route(), r.policy, r.trips
-    assert route["decided"] and route["coarse_share"] < 0.3 and policy["decision"] in ("fast", "safe") and r.alarms == 0 and r.range_fallbacks == 0
+    assert route["decided"] and route["coarse_share"] < 0.3 and policy["decision"] in ("fast", "tiered", "safe") and r.alarms == 0 and r.range_fallbacks == 0
     assert not r.route.get("imposed") and not policy.get("imposed") and route["tripped"] == 0
     ro, rd = r.get_rays(H, W, K, c2w)
     # the same frame in one call of this rank (ten launches of 64 000 rays), on the frame's probe — what dist.render_frame does without a group
@@ -55,7 +55,7 @@ def fitted_frame(torch, dist, rank, world, backend, kind="fitted"):
     assert int(t.item()) == frame_trips, (int(t.item()), frame_trips)
     # one route, one decision on every rank
     mine = torch.tensor([route["coarse_share"], route["fine_main_share"], route["fine_offsets_share"], float(sum(route["estimates_plain_f16"])),
-                         float(policy["decision"] == "safe")], dtype=torch.float64)
+                         float(("fast", "tiered", "safe").index(policy["decision"]))], dtype=torch.float64)
     ref = mine.clone()
     dist.broadcast(ref, 0)
     assert torch.equal(ref, mine), (ref, mine)
