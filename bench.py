@@ -237,6 +237,143 @@ def parity_vs_reference_fixture(frame_maps_fn):
     return out
 
 
+def _trainable_module(sd):
+    """An nn.Module holding one IBLNeRF network's parameters under the reference's state-dict names and registration order (nerf_models/ibl_nerf.py:45-72): what
+    train.py hands render_decomp as network_fn / network_fine and its optimizer steps.  Parameters only — the forward and backward arithmetic is the library's."""
+    import torch
+    import torch.nn as nn
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            groups = {}
+            for key, v in sd.items():
+                name, leaf = key.rsplit(".", 1)
+                groups.setdefault(name, {})[leaf] = v
+            done = set()
+            for name, wb in groups.items():          # in the state dict's own order: render_decomp's device upload flattens parameters in registration order
+                parts = name.split(".")
+                if len(parts) == 2 and parts[1].isdigit():
+                    if parts[0] in done:
+                        continue
+                    done.add(parts[0])
+                    members = sorted((int(k.split(".")[1]), k) for k in groups if k.split(".")[0] == parts[0] and len(k.split(".")) == 2)
+                    setattr(self, parts[0], nn.ModuleList([nn.Linear(groups[k]["weight"].shape[1], groups[k]["weight"].shape[0]) for _, k in members]))
+                else:
+                    setattr(self, name, nn.Linear(wb["weight"].shape[1], wb["weight"].shape[0]))
+            self.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in sd.items()})
+            self.coarse_radiance_number = 3
+    return Net()
+
+
+def reference_train_record(n):
+    """The reference's own training step timed on the CPU of the build container (tests/golden/time_reference_train_cpu.py; the reference cannot travel to the GPU box)."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_train_cpu_timing.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    ent = rec["rays"].get(str(n))
+    if not ent:
+        return None
+    threads = max(ent["threads"], key=int)
+    t = ent["threads"][threads]
+    return {"value": t["rays_per_s"], "unit": "rays/s", "cores": int(threads), "kind": "reference", "seconds_per_step": t["seconds_per_step"],
+            "render_s": t["render_s"], "loss_backward_s": t["loss_backward_s"], "adam_s": t["adam_s"], "host": rec["host"], "torch": rec["torch"],
+            "sample": "%d-ray training step (render_decomp with render_kwargs_train -> losses -> loss.backward() -> Adam), fitted checkpoint, %s threads, build container "
+                      "(a RECORDED figure: the reference cannot travel to the GPU box)" % (n, threads),
+            "source": "tests/golden/reference_train_cpu_timing.json"}
+
+
+# algorithmic FLOPs of a training step per ray: the forward as the inference path's (every sample of every query), and the backward of the two passes' MAIN queries —
+# data and weight gradients, 2 x the forward's MACs each; the offset copies and the reflected rays run under no_grad in the reference (ibl_nerf_renderer.py:358-361, :442-448)
+F_TRAIN_BWD_PER_RAY = 2.0 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * F_FULL
+
+
+def train_bench(args):
+    """`bench.py --train`: the training step of train.py:286-297 / :326-441 / :479-481 on the fused path — render_decomp with trainable networks (perturb = 1: stratified
+    jitter + stochastic fine samples), the dataset-free losses, loss.backward() through the one autograd Function of ibl-nerf_amd/training.py, Adam — per ray count; the
+    headline is the reference's default batch, N_rand = 4 096 (config_parser.py:65).  One JSON line."""
+    import torch
+    pkg = _pkg.load()
+    from ibl_nerf_amd import renderer as R
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import train_loss as TL          # (the losses of train.py that need no dataset: shared with the fixtures made from the reference's own loss.backward())
+    torch.cuda.set_device(0)
+    sdc, sdf = load_checkpoint(args.checkpoint)
+    lut = torch.from_numpy(load_lut()).cuda()
+    K, _ = camera()
+    fl = float(K[0, 0])
+    sizes = [int(v) for v in args.train_rays.split(",")]
+    by_rays, line = {}, None
+    for n in sizes:
+        nets = _trainable_module(sdc).cuda(), _trainable_module(sdf).cuda()
+        opt = torch.optim.Adam([p for net in nets for p in net.parameters()], lr=5e-4, betas=(0.9, 0.999))
+        kw = dict(network_fn=nets[0], network_fine=nets[1], N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, perturb=1.0, raw_noise_std=0.0, brdf_lut=lut, lut_coefficient="F",
+                  gamma_correct=True, correct_depth_for_prefiltered_radiance_infer=True, epsilon=0.01, use_radiance_linear=False, lindisp=False, near=NEAR, far=FAR,
+                  target_normal_map_for_radiance_calculation="normal_map_from_depth_gradient_epsilon", max_rays_per_launch=max(n, 1024))
+        rng = np.random.RandomState(0)
+        pix = rng.permutation(H * W)[:n]
+        i, j = (pix % W).astype(np.float32), (pix // W).astype(np.float32)
+        d = np.stack([(i - W / 2) / fl, -(j - H / 2) / fl, -np.ones_like(i)], -1).astype(np.float32)
+        rays = torch.from_numpy(np.stack([np.zeros_like(d), d], 0)).cuda()
+        tg = {k: torch.from_numpy(v).cuda() for k, v in TL.targets(rng, n).items()}
+
+        def step():
+            res = R.render_decomp(H, W, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+            loss = TL.total_loss(torch, res, tg, True)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
+        for _ in range(max(args.warmup, 2)):
+            l0 = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        # the same step in three parts (untimed extra steps)
+        parts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            res = R.render_decomp(H, W, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+            torch.cuda.synchronize(); b = time.perf_counter()
+            lv = TL.total_loss(torch, res, tg, True); opt.zero_grad(); lv.backward()
+            torch.cuda.synchronize(); c = time.perf_counter()
+            opt.step()
+            torch.cuda.synchronize(); e = time.perf_counter()
+            parts.append((b - a, c - b, e - c))
+        pm = np.array(parts).min(0)
+        r = R.renderer_for(dict(kw, _lazy_range_check=True))
+        f_step = F_ALG_PER_RAY + F_TRAIN_BWD_PER_RAY
+        by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": 1e3 * pm[0], "loss_backward_ms": 1e3 * pm[1], "adam_ms": 1e3 * pm[2],
+                           "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
+                           "skipped_steps": int(getattr(r, "skipped_steps", 0)), "range_fallbacks": int(r.range_fallbacks),
+                           "reference_in_build_container": reference_train_record(n)}
+    head = str(args.train_headline if str(args.train_headline) in by_rays else sizes[-1])
+    hb = by_rays[head]
+    f_step = F_ALG_PER_RAY + F_TRAIN_BWD_PER_RAY
+    line = {"metric": "training rays/sec (64c+128f samples, one step = render + losses + backward + Adam)", "value": hb["rays_per_s"], "unit": "rays/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16 (3 MFMA products on hi/lo splits, forward and backward; f16 operand stash with a power-of-two loss scale), fp32 accumulate, fp32 Adam",
+            "data": "synthetic (fitted checkpoint as the starting point, seeded pixels of the synthetic 800x800 camera, seeded targets)",
+            "config": {"workload": "training step of train.py:286-297 / :479-481 at N_rand = %s rays (the reference's default batch is 4096, config_parser.py:65), 64+128 samples, "
+                                   "approximate_radiance=True, perturb = 1, every sample evaluated (a training context holds no route)" % head,
+                       "checkpoint": args.checkpoint, "rays_per_step": int(head), "optimizer": "torch.optim.Adam(lr 5e-4) over both networks' 92 tensors", "parallelism": "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": hb["rays_per_s"] * f_step / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": hb["frac"], "traffic": None,
+                         "flop_per_ray": f_step, "flop_forward_per_ray": F_ALG_PER_RAY, "flop_backward_per_ray": F_TRAIN_BWD_PER_RAY,
+                         "kernel": "f16x3k::mlp_kernel<FULL|TRUNK> (forward) + f16x3k::mlp_kernel<NET_BWD> (forward recompute + data gradient + operand stash) + k_wgrad (weight gradients)",
+                         "note": "algorithmic FLOPs: the forward priced as the inference path's (every sample of every query, once), the backward as data + weight gradients of the two "
+                                 "passes' main queries (the offset copies and reflected rays carry no gradient in the reference); three f16 products per MAC are issued, counted once; "
+                                 "a step of 512 rays is launch- and latency-bound (8 000 points per MLP launch on 256 CUs), see by_rays"},
+            "cpu_baseline": hb["reference_in_build_container"] or {"value": None, "unit": "rays/s", "cores": 0, "kind": "reference", "sample": "not recorded"},
+            "by_rays": by_rays}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,9 +395,14 @@ def main():
     ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved", help="how the frame's rows are dealt to the ranks (dist.tile_row_indices)")
     ap.add_argument("--tile-times", action="store_true", help="also time each of the 8 contiguous and 8 interleaved row tiles of the frame by itself on this one GPU "
                                                               "(the balance of an 8-rank frame, measured without an 8-GPU node) and report them as `tile_ms`")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step instead (render + losses + backward + Adam; SURVEY.md 8 f-3): one JSON line of its own")
+    ap.add_argument("--train-rays", default="512,1024,4096", help="--train: ray counts of the steps timed")
+    ap.add_argument("--train-headline", type=int, default=4096, help="--train: the ray count `value` is quoted on (the reference's default N_rand)")
     ap.add_argument("--query-routing", default="", help="comma-separated iblnerf_options.query_routing names (A/B measurements, e.g. point_batch)")
     args = ap.parse_args()
     routing = [n for n in args.query_routing.split(",") if n]
+    if args.train:
+        return train_bench(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (this process has not touched HIP and never

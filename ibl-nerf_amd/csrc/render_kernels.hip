@@ -1649,7 +1649,10 @@ __global__ void k_ray_outputs_bwd(RayBwdArgs a, long n) {
     }
     if (!irr_gt) dx[6] += up1(a.g_irradiance) * d_out_map(x[6], on);
     if (!rough_gt) dx[5] += up1(a.g_roughness);
-    if (a.g_disp) {                                          // 1 / max(1e-10, depth / acc) (:258)
+    // (an upstream gradient of exactly zero is an output the loss does not read — autograd hands the Function zeros for those — and contributes nothing, as in the
+    // reference, where no backward runs through an unused output: a ray whose weights sum to zero has disp = 1 / max(1e-10, 0 / 0) = NaN there too, and its 0 x NaN here
+    // poisoned dL/d depth, the whole batch's upstream maximum with it, and every later step of a training run: bench.py --train found it)
+    if (a.g_disp && a.g_disp[r] != 0.0f) {                   // 1 / max(1e-10, depth / acc) (:258)
         const float q = depth / acc;
         const float share = q > 1e-10f ? 1.0f : (q == 1e-10f ? 0.5f : 0.0f);
         const float dq = -a.g_disp[r] / (fmaxf(q, 1e-10f) * fmaxf(q, 1e-10f)) * share;

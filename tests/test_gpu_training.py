@@ -163,6 +163,34 @@ def test_ray_outputs_backward_matches_autograd(lut, flags):
         r.ray_outputs_backward(xt, {}, nd, ev, depth0=0.0)
 
 
+def test_an_empty_ray_does_not_poison_the_batch(lut):
+    """Round 6 (found by `bench.py --train`: after a dozen Adam steps one of 512 rays had coarse weights summing to exactly zero, and every later step returned zero
+    gradients): such a ray's disp_map is 1 / max(1e-10, 0 / 0) = NaN, in the reference too (ibl_nerf_renderer.py:258) — but train.py's losses do not read disp_map, so no
+    backward runs through it there.  The fused backward receives autograd's ZEROS for unused outputs: 0 x d disp / d (depth, acc) must be 0, not NaN, or the batch's upstream
+    maximum — the power-of-two normaliser of the f16 gradient chain — is NaN and all 92 gradients with it."""
+    from ibl_nerf_amd import binding as B, renderer as R, training as T
+    B.load_library()
+    r = R.Renderer(64, 128, max_rays_per_launch=1024)
+    r.load_lut(lut)
+    rng = np.random.RandomState(11)
+    n = 256
+    x = np.concatenate([rng.uniform(1.0, 6.0, (n, 1)), rng.uniform(0.5, 1.0, (n, 1)), rng.uniform(0.03, 0.97, (n, 17))], 1).astype(np.float32)
+    x[:4, :2] = 0.0                                                    # empty rays: depth = acc = 0 (every alpha exactly zero)
+    xt = torch.from_numpy(x).cuda()
+    nd, ev = torch.from_numpy(rng.uniform(0, 1, n).astype(np.float32)).cuda(), torch.from_numpy(rng.uniform(0.02, 0.9, (n, 4, 3)).astype(np.float32)).cuda()
+    ups = {k: torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).cuda() for k in ("color_map", "radiance_map", "albedo_map")}
+    ups["disp_map"] = torch.zeros(n, device="cuda")                    # what autograd hands a Function for an output the loss does not read
+    ups["acc_map"] = torch.zeros(n, device="cuda")
+    got = r.ray_outputs_backward(xt, ups, nd, ev, 4.25)
+    assert bool(torch.isfinite(got).all())
+    ref = r.ray_outputs_backward(xt, {k: v for k, v in ups.items() if k not in ("disp_map", "acc_map")}, nd, ev, 4.25)
+    assert torch.equal(got, ref)
+    # ... and where the loss DOES read disp_map the empty ray's gradient is the reference's: NaN (max(1e-10, NaN) = NaN in torch), on that ray only
+    ups["disp_map"] = torch.ones(n, device="cuda")
+    got = r.ray_outputs_backward(xt, ups, nd, ev, 4.25)
+    assert bool(torch.isfinite(got[4:]).all())
+
+
 @pytest.mark.parametrize("name,fused,teacher", [("train_step_from_gt", True, False), ("train_step_from_gt", False, False), ("train_step_from_gt2", True, False),
                                                 ("train_step_from_gt", True, True), ("train_step_from_gt2", True, True)])
 def test_training_step_with_ground_truth_targets(lut, name, fused, teacher):
