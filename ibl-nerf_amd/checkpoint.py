@@ -143,6 +143,15 @@ def synthetic_arch_state_dict(seed, arch, gain=1.0, sigma_bias=0.3):
     return sd
 
 
+def _set_identity(w, n, c0):
+    """w[u, c0 + u] = 1 for u < n in ONE operation (a numpy array or a torch tensor on any device): a Python loop is n tiny kernel launches per identity layer on a
+    device tensor, and a training step uploads both networks every step."""
+    if hasattr(w, "fill_diagonal_"):
+        w[:n, c0:c0 + n].fill_diagonal_(1.0)
+    else:
+        np.fill_diagonal(w[:n, c0:c0 + n], 1.0)
+
+
 def embed_architecture(sd):
     """A SMALLER IBLNeRF as a member of the built architecture (D = 8, W = 256, multires 10 / 4): the same function, exactly.
       narrower layers (W < 256, W // 2 < 128): zero rows and columns — an absent unit is a unit that outputs relu(0) = 0 and is read with weight 0;
@@ -184,8 +193,7 @@ def embed_architecture(sd):
             put(P % l, W, [(0, 0, ch), (63, ch, W)] if l == 5 else [(0, 0, W)])
         else:      # an identity layer: relu(h) = h for h >= 0
             c0 = 63 if l == 5 else 0
-            for u in range(W):
-                out[(P % l) + ".weight"][u, c0 + u] = 1.0
+            _set_identity(out[(P % l) + ".weight"], W, c0)
     put("views_linears.0", W, [(0, 0, W), (256, W, chv)])
     put("feature_linear", W, [(0, 0, W)])
     for name, rows, width in (("sigma_linear", 1, W), ("albedo_feature_linear", H, W), ("albedo_linear", 3, H), ("roughness_linear", 1, W),
@@ -290,8 +298,7 @@ def _embed_trunk(sd, out, D, W, ch):
             b[:W] = val((P % l) + ".bias")
         else:
             c0 = 63 if l == 5 else 0
-            for u in range(W):
-                w[u, c0 + u] = 1.0
+            _set_identity(w, W, c0)
 
 
 def embed_position_mlp(sd):
@@ -345,8 +352,7 @@ def embed_position_direction_mlp(sd):
             out["views_linears.%d.weight" % l][:H, :H] = val("views_linears.%d.weight" % l)
             out["views_linears.%d.bias" % l][:H] = val("views_linears.%d.bias" % l)
         else:
-            for u in range(H):
-                out["views_linears.%d.weight" % l][u, u] = 1.0
+            _set_identity(out["views_linears.%d.weight" % l], H, 0)
     out["final_linear.weight"][:, :H] = val("final_linear.weight")
     out["final_linear.bias"][:] = val("final_linear.bias")
     return out

@@ -471,8 +471,13 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
         mod = (aux_nets or {}).get(name)
         nm = dict(mod.named_parameters()) if hasattr(mod, "named_parameters") else {}
         if nm and any(p_.requires_grad for p_ in nm.values()):
-            if set(nm) != set(AUX_PARAMS):
-                raise NotImplementedError("an auxiliary network's backward is built for PositionMLP(D=8, W=256) (networks/MLP.py:6-30): positions_linears.0-7, out_linears")
+            shapes = {k: tuple(v.shape) for k, v in nm.items()}
+            if set(nm) != set(AUX_PARAMS) or shapes.get("positions_linears.0.weight") != (256, 63) or any(shapes["positions_linears.%d.weight" % l][0] != 256 for l in range(8)):
+                # (load_aux embeds SMALLER PositionMLPs for rendering; their gradients would come back in the built shape and have no unembed — refuse by name, not with a
+                # size mismatch deep inside the backward: ADVICE r5)
+                raise NotImplementedError("a TRAINABLE auxiliary network's backward is built for PositionMLP(D=8, W=256, multires=10) (networks/MLP.py:6-30): positions_linears.0-7 "
+                                          "[256, ...], out_linears — got %s: %s; freeze it (requires_grad_(False)) to render with it, or train it at the built shape"
+                                          % (name, {k: v for k, v in sorted(shapes.items())[:3]}))
             aux_named[name] = nm
     if "normal_mlp" in aux_named and r.normal_mode == "inferred_normal_map":
         raise NotImplementedError("a trainable normal_mlp as the target normal (target_normal_map_for_radiance_calculation='inferred_normal_map') in a gradient-carrying "

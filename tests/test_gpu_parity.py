@@ -80,6 +80,19 @@ def test_get_rays(R):
     ro, rd = r.get_rays(800, 800, K, c2w)
     oo, od = O.get_rays(800, 800, K, c2w)
     assert np.array_equal(ro.cpu().numpy(), oo) and np.abs(rd.cpu().numpy() - od).max() <= 2e-7
+    # round 6: one rank's interleaved rows (iblnerf_get_rays_strided) and a probe's pixel list (iblnerf_get_rays_pixels) are the frame's rays bit for bit
+    for rank, world in ((0, 8), (3, 8), (7, 8), (1, 3)):
+        n_rows = len(range(rank, 800, world))
+        so, sd = r.get_rays_strided(800, 800, K, c2w, rank, world, n_rows)
+        assert torch.equal(sd, rd[rank::world]) and torch.equal(so, ro[rank::world]) and sd.shape == (n_rows, 800, 3)
+    pix = np.sort(np.random.RandomState(3).permutation(640000)[:5000])
+    po, pd = r.get_rays_pixels(800, 800, K, c2w, pix)
+    idx = torch.as_tensor(pix, device=rd.device)
+    assert torch.equal(pd, rd.reshape(-1, 3)[idx]) and torch.equal(po, ro.reshape(-1, 3)[idx])
+    with pytest.raises(ValueError):
+        r.get_rays_pixels(800, 800, K, c2w, np.array([640000]))
+    with pytest.raises(R.B.IblNerfError):
+        r.get_rays_strided(800, 800, K, c2w, 7, 8, 101)          # (row 7 + 100 * 8 = 807 is outside the image)
 
 
 def test_sample_pdf(R):
