@@ -1,6 +1,7 @@
 // C-ABI implementation (include/iblnerf.h): context, weight/LUT upload, workspace, and the
 // render_rays orchestration that strings the kernels together.
 #include "../../include/iblnerf.h"
+#include "../../include/iblnerf_experimental.h"
 
 #include <hip/hip_runtime.h>
 

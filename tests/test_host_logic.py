@@ -24,7 +24,8 @@ def lib():
 
 
 def test_library_exports_every_declared_symbol(lib):
-    hdr = open(os.path.join(ROOT, "include", "iblnerf.h")).read()
+    import glob
+    hdr = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))      # the boundary (iblnerf.h) and the measurement hooks (iblnerf_experimental.h)
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = sorted(set(re.findall(r"\b(iblnerf_[a-z_0-9]+)\s*\(", hdr)))
     assert declared == sorted(B.EXPORTS)
