@@ -2337,14 +2337,21 @@ int iblnerf_set_lists(iblnerf_ctx* c, int enabled) {
 }
 
 int iblnerf_decide_route(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_, iblnerf_route* out) {
+    return iblnerf_decide_route_outputs(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, nullptr, nullptr, out);
+}
+
+int iblnerf_decide_route_outputs(iblnerf_ctx* c, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                                 const iblnerf_overrides* ovr, const iblnerf_outputs* outs_or_null, iblnerf_route* out) {
     if (!c) return IBLNERF_ERR_INVALID;
     if (!d_rays_o || !d_rays_d || n_rays < SELECT_MIN_RAYS || n_rays > c->ws_rays)
         return c->fail(IBLNERF_ERR_INVALID, "decide_route: needs %ld <= n_rays <= max_rays_per_launch (%ld) probe rays", SELECT_MIN_RAYS, c->ws_rays);
     reset_route(c, 0);
-    iblnerf_outputs outs;                          // every map null: the probe's results are discarded
+    iblnerf_outputs outs;                          // every map null: the probe's results are discarded ...
     std::memset(&outs, 0, sizeof outs);
+    if (outs_or_null) outs = *outs_or_null;        // ... or kept: the probe's render under the table in effect, for a caller that compares tables on the same rays
+    outs.trip_rays = nullptr;                      // (a probe that trips escalates its route: iblnerf_escalate_route)
     c->deciding = true;
-    const int rc = iblnerf_render_rays_tapped(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, nullptr, nullptr, &outs, nullptr);
+    const int rc = iblnerf_render_rays_tapped(c, stream, d_rays_o, d_rays_d, n_rays, near_, far_, outs_or_null ? ovr : nullptr, nullptr, &outs, nullptr);
     c->deciding = false;
     if (rc) { reset_route(c, 0); return rc; }
     // whatever the probe did not reach stays off: from here on nothing is decided inside a render call

@@ -490,9 +490,11 @@ class Renderer:
         self.route["imposed"] = True
         return self.route
 
-    def _measure_route(self, rays_o, rays_d, near, far):
+    def _measure_route(self, rays_o, rays_d, near, far, keep_maps=False, gt_values=None, edit=None):
         """iblnerf_decide_route on (at most ROUTE_RAYS strided ones of) these rays; a probe that trips its own wire climbs the ladder (iblnerf_escalate_route: wider
-        margins, six-slot estimates, lists off) and is rendered again until it is clean — the route is a function of the probe alone."""
+        margins, six-slot estimates, lists off) and is rendered again until it is clean — the route is a function of the probe alone.
+        keep_maps: the probe's render under the table in effect is returned (iblnerf_decide_route_outputs; scalar planes and exactly these rays — no subsampling), or
+        None when the probe had to be escalated (its last render was a discarded one)."""
         torch = _torch()
         rays_o, rays_d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
         n = int(rays_o.shape[0])
@@ -500,12 +502,17 @@ class Renderer:
         if n > cap:
             idx = torch.linspace(0, n - 1, cap, device=self.device).long()
             rays_o, rays_d, n = rays_o[idx].contiguous(), rays_d[idx].contiguous(), cap
+            keep_maps = False
         route = B.Route()
         self.range_bits()                                            # (whatever earlier calls left in the flags is theirs)
-        B.check(self.ctx, self.lib.iblnerf_decide_route(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near), float(far), C.byref(route)))
+        maps = None
+        if keep_maps:
+            maps, bits, _ = self._render(rays_o, rays_d, float(near), float(far), gt_values, edit or {}, on_range="ignore", decide=route)
+        else:
+            B.check(self.ctx, self.lib.iblnerf_decide_route(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near), float(far), C.byref(route)))
+            bits = self.range_bits()                                 # synchronises (the probe's rays may be temporaries)
         self._c_route = True
         steps = 0
-        bits = self.range_bits()                                     # synchronises (the probe's rays may be temporaries)
         for _ in range(6):                                           # (margins 2 -> 4 -> 6, estimates to six slots, lists off: four steps at most)
             if bits & 1:
                 self._withdraw_route()
@@ -514,6 +521,7 @@ class Renderer:
                 break
             B.check(self.ctx, self.lib.iblnerf_escalate_route(self.ctx, int(bits & TRIP_BITS)))
             steps += 1
+            maps = None
             self.trip_bits = getattr(self, "trip_bits", 0) | (bits & TRIP_BITS)
             _, bits, _ = self._render(rays_o, rays_d, float(near), float(far), None, {}, on_range="ignore")      # the probe under the escalated route, discarded: is it clean now?
         else:
@@ -522,7 +530,7 @@ class Renderer:
         self.route = self.get_route()
         self.route["probe_rays"] = n
         self.route["probe_escalations"] = steps
-        return self.route
+        return maps if keep_maps else self.route
 
     def get_route(self):
         route = B.Route()
@@ -592,17 +600,21 @@ class Renderer:
         self.policy["imposed"] = True
         return self.policy
 
-    def _measure_table(self, rays_o, rays_d, near, far, gt_values, edit):
-        """FAST against SAFE routing of this context on the given rays, under the route in effect; records `self.policy` and leaves the context on the decided table."""
+    def _measure_table(self, rays_o, rays_d, near, far, gt_values, edit, fast_maps=None):
+        """FAST against SAFE routing of this context on the given rays, under the route in effect; records `self.policy` and leaves the context on the decided table.
+        fast_maps: the FAST render of these very rays if the caller has it already (the route probe's own render, _measure_route keep_maps)."""
         torch = _torch()
         keep = self.policy
         self.policy = {"decision": "calibrating"}
         applied = getattr(self, "_routing_extra", 0)
         try:
             with torch.no_grad():
-                for _ in range(6):
+                for attempt in range(6):
                     self._set_routing(0)
-                    a, bits_a, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                    if fast_maps is not None and attempt == 0:
+                        a, bits_a = fast_maps, 0
+                    else:
+                        a, bits_a, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
                     self._set_routing(self.SAFE_ROUTING)
                     b, bits_b, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
                     bits = (bits_a | bits_b) & TRIP_BITS
@@ -675,16 +687,23 @@ class Renderer:
             pnear, pfar = ((v[idx].contiguous() if torch.is_tensor(v) and v.numel() == n else v) for v in (near, far))       # per-ray planes follow their rays
         else:
             pro = None
+        fast_maps = None
         if route_open:
             if pro is not None and self._route_possible(pro.shape[0]):
                 lo = float(pnear.min()) if torch.is_tensor(pnear) else float(pnear)
                 hi = float(pfar.max()) if torch.is_tensor(pfar) else float(pfar)
-                self._measure_route(pro, prd, lo, hi)
+                # (both open, scalar planes: the route probe's own render — under the FAST table — is the table decision's FAST render: one probe render less per call)
+                both = table_open and pro.shape[0] >= self.CAL_MIN_RAYS and not torch.is_tensor(pnear) and not torch.is_tensor(pfar) and pro.shape[0] <= min(self.ROUTE_RAYS, int(self.opt.max_rays_per_launch))
+                if both:
+                    self._set_routing(0)
+                    fast_maps = self._measure_route(pro, prd, lo, hi, keep_maps=True, gt_values=pgt, edit=edit)
+                else:
+                    self._measure_route(pro, prd, lo, hi)
             else:
                 self._withdraw_route()
         if table_open:
             if pro is not None and pro.shape[0] >= self.CAL_MIN_RAYS:
-                self._measure_table(pro, prd, pnear, pfar, pgt, edit)
+                self._measure_table(pro, prd, pnear, pfar, pgt, edit, fast_maps=fast_maps)
             else:
                 self._set_routing(self.SAFE_ROUTING)
                 self.policy = None
@@ -1309,7 +1328,7 @@ class Renderer:
         return float(near), float(far)
 
     def _render(self, rays_o, rays_d, near, far, gt_values, edit, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, noise=None, _retry=False,
-                want_trips=False, on_range="answer"):
+                want_trips=False, on_range="answer", decide=None):
         """One iblnerf_render_rays_tapped under whatever route / table / list switch the context holds -> (result dict, range bits, trip map or None).  Range events
         (bit 0: an activation left the f16 range) are answered here — the network rescaled into range, or the call repeated on the bf16x3 twin — through render_rays."""
         torch = _torch()
@@ -1372,10 +1391,14 @@ class Renderer:
         if want_trips and n:
             trip = torch.zeros((n,), dtype=torch.uint8, device=self.device)
             outs.trip_rays = trip.data_ptr()
-        B.check(self.ctx, self.lib.iblnerf_render_rays_tapped(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
-                                                              float(near), float(far), C.byref(ov) if ov is not None else None,
-                                                              C.byref(smp) if smp is not None else None, C.byref(outs),
-                                                              C.byref(taps) if taps is not None else None))
+        if decide is not None:      # the route's probe with its render kept (iblnerf_decide_route_outputs; scalar planes, no sampling: a probe of an eager call)
+            B.check(self.ctx, self.lib.iblnerf_decide_route_outputs(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n, float(near), float(far),
+                                                                    C.byref(ov) if ov is not None else None, C.byref(outs), C.byref(decide)))
+        else:
+            B.check(self.ctx, self.lib.iblnerf_render_rays_tapped(self.ctx, self._stream(), rays_o.data_ptr(), rays_d.data_ptr(), n,
+                                                                  float(near), float(far), C.byref(ov) if ov is not None else None,
+                                                                  C.byref(smp) if smp is not None else None, C.byref(outs),
+                                                                  C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
         bits = 0 if lazy else self.range_bits()
         if bits & 1 and on_range == "raise":

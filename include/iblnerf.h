@@ -525,6 +525,12 @@ int iblnerf_render_rays(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, c
                         int64_t n_rays, float near_, float far_, const iblnerf_overrides* overrides,
                         const iblnerf_outputs* outputs);
 
+/* iblnerf_decide_route with the probe's render KEPT: outs (nullable: then exactly iblnerf_decide_route) receives the maps of the probe rays, rendered under the table in
+ * effect while the route is being decided (overrides as iblnerf_render_rays takes them, nullable) — what ibl-nerf_amd/renderer.py's per-call table decision uses as its
+ * FAST render, so that a call's decisions cost one probe render less.  outs->trip_rays is ignored (a probe that trips escalates its route). */
+int iblnerf_decide_route_outputs(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                                 const iblnerf_overrides* overrides, const iblnerf_outputs* outs, iblnerf_route* out);
+
 /* Training-time sampling (perturb > 0; nerf_models/ibl_nerf_renderer.py:678-692, nerf_renderer_helper.py:98-113): the caller supplies
  * the uniform [0,1) draws, so that any generator — torch's on the device, or numpy's seeded stream of the reference's `pytest` path —
  * gives the reference's samples.  d_t_rand [n_rays, N_samples]: stratified jitter of the coarse grid (which then is per ray, also
