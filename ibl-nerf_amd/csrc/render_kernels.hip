@@ -339,10 +339,14 @@ __global__ __launch_bounds__(256) void k_pass_a(PassAArgs a, PassOutputs out, in
             if (out.weights) out.weights[(long)r * S + s] = w[i];
             depth += w[i] * z[i];
             acc += w[i];
-            const float* row = a.raw + ((long)r * S + s) * RAW_CH;
+            // (a sample whose weight is exactly zero — alpha = 0: nine in ten on a scene with surfaces — adds +0 to every sum whatever its row holds: the row is not read;
+            // 885 MB of raw rows per launch set of the fine pass otherwise)
+            if (w[i] != 0.0f) {
+                const float* row = a.raw + ((long)r * S + s) * RAW_CH;
 #pragma unroll
-            for (int c = 0; c < 17; ++c)   // albedo, roughness: sigmoid; irradiance, radiances: radiance_f (:281-318)
-                ch[c] += w[i] * ((c < 4 || (c == 4 && a.irradiance_sigmoid)) ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], a.radiance_linear));
+                for (int c = 0; c < 17; ++c)   // albedo, roughness: sigmoid; irradiance, radiances: radiance_f (:281-318)
+                    ch[c] += w[i] * ((c < 4 || (c == 4 && a.irradiance_sigmoid)) ? sigmoidf_(row[1 + c]) : radiance_f(row[1 + c], a.radiance_linear));
+            }
         }
     }
     depth = wave_sum(depth);
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256) void k_pass_b(PassBArgs a) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int s = lane * NPL + i;
-        if (s < S) {
+        if (s < S && w[i] != 0.0f) {      // (a weightless sample adds +0 whatever its row holds: not read)
             const float* row = a.refl_raw + ((long)r * S + s) * REFL_CH;
 #pragma unroll
             for (int c = 0; c < 12; ++c) maps[c] += w[i] * radiance_f(row[1 + c], a.radiance_linear);

@@ -1241,8 +1241,13 @@ class Renderer:
                         _retry = True
                         continue
                     return self._wide_twin().render_rays(rays_o, rays_d, near, far, gt_values, chunk=chunk, **edit)
-        elif not self._route_imposed() or lazy:
-            self._withdraw_route()
+        else:
+            if not self._route_imposed() or lazy:
+                self._withdraw_route()
+            if self._auto and not self._policy_imposed() and getattr(self, "_routing_extra", 0):
+                # (a sampled / tapped / lazy call runs on the FAST table whatever an earlier eager call on this context decided for itself: no memory here either)
+                self._set_routing(0)
+                self.policy = None
         want_trips = eager and self._c_route
         res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
                                        taps=taps, noise=noise, _retry=_retry, want_trips=want_trips)
