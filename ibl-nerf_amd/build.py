@@ -65,6 +65,7 @@ SOURCES = [
     ("posdir_kernel.hip", []),
     ("range_kernel.hip", []),
     ("trunk_fp32_kernel.hip", []),
+    ("generic_mlp.hip", []),
     ("wgrad_kernel.hip", []),
     ("api.cpp", ["-x", "hip"]),
     ("pack.cpp", ["-x", "hip"]),

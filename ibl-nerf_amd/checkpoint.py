@@ -131,6 +131,40 @@ def arch_of(sd):
 SHIPPED_ARCH = (8, 256, 10, 4)
 
 
+def is_member_of_built(arch):
+    """Can IBLNeRF(D, W, multires, multires_views) be embedded exactly in the built 8 x 256 / 10 / 4 architecture (embed_architecture)?"""
+    D, W, L, Lv = arch
+    return 1 <= D <= 8 and D != 5 and 2 <= W <= 256 and 0 <= L <= 10 and 0 <= Lv <= 4
+
+
+def is_generic_arch(arch):
+    """An architecture the fused kernels cannot hold but csrc/generic_mlp.hip can (iblnerf_upload_weights_arch): layer by layer in exact fp32, every sample evaluated."""
+    D, W, L, Lv = arch
+    return not is_member_of_built(arch) and 1 <= D <= 32 and D != 5 and 2 <= W <= 4096 and W % 2 == 0 and 0 <= L <= 24 and 0 <= Lv <= 24
+
+
+def weights_checksum(sd):
+    """blob_checksum of a state dict of ANY architecture: of the built-shape blob it is uploaded as when it is a member of the built architecture (what the fixtures
+    have always recorded), of its own flattening (arch_blob) otherwise."""
+    arch = arch_of(sd)
+    return blob_checksum(state_dict_to_blob(embed_architecture(sd))) if is_member_of_built(arch) else blob_checksum(arch_blob(sd, arch))
+
+
+def arch_blob(sd, arch=None):
+    """An IBLNeRF state dict of ANY architecture flattened in registration order (arch_schema): what iblnerf_upload_weights_arch takes.  Validates names and shapes."""
+    arch = arch or arch_of(sd)
+    parts = []
+    for name, o, i in arch_schema(*arch):
+        w, b = _to_numpy(sd[name + ".weight"]), _to_numpy(sd[name + ".bias"])
+        if tuple(w.shape) != (o, i) or tuple(b.shape) != (o,):
+            raise ValueError("state dict does not follow the IBLNeRF%s schema: %s is %s / %s, expected (%d, %d) / (%d,)" % (arch, name, tuple(w.shape), tuple(b.shape), o, i, o))
+        parts += [w.reshape(-1), b.reshape(-1)]
+    extra = set(sd) - {n + t for n, _, _ in arch_schema(*arch) for t in (".weight", ".bias")}
+    if extra:
+        raise ValueError("state dict holds tensors outside the IBLNeRF%s schema: %s" % (arch, sorted(extra)[:4]))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
 def synthetic_arch_state_dict(seed, arch, gain=1.0, sigma_bias=0.3):
     """synthetic_state_dict for IBLNeRF(*arch): same stream discipline (U(-g / sqrt(fan_in), g / sqrt(fan_in)) per tensor in registration order)."""
     rng = np.random.RandomState(seed)

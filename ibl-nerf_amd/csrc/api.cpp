@@ -88,6 +88,10 @@ struct iblnerf_ctx {
     char* d_stream[N_SLOTS] = {};
     char* d_stream_mx[N_SLOTS] = {};             // f16 + MX-fp6 form (mlp_precision F16_MXFP6, F16_MIXED, F16X3_MXFP6)
     char* d_stream_f16[N_SLOTS] = {};            // f16 (hi, lo) form of d_stream's layout (mlp_precision F16X3, F16X3_MXFP6)
+    GenericNet generic[2];                        // networks 0 / 1 of an architecture OUTSIDE the built one (iblnerf_upload_weights_arch): blob != null = this slot runs
+                                                  // on generic_mlp.hip — every sample of every query, layer by layer in exact fp32; no lists, no estimates, no backward
+    float* generic_ws = nullptr;                  // ... its activation workspace (grown on demand)
+    size_t generic_ws_floats = 0;
     float* d_blob32[2] = {};                      // networks 0 / 1 as they are: the fp32 state dict (trunk_fp32_kernel.hip reads the reference's own [out][in] rows)
     bool density_15slot = false;                  // IBLNERF_ROUTE_COARSE_DENSITY_15SLOT: round 4's coarse density (the 15-slot form also on the lists)
     // [0] activation / input range flag of the MX kernels, [1 + slot] "a weight of this slot is outside the f16 range" (device packer)
@@ -388,6 +392,8 @@ void iblnerf_destroy(iblnerf_ctx* c) {
     if (c->main_range) (void)hipFree(c->main_range);
     if (c->sel_est) (void)hipFree(c->sel_est);
     if (c->tier_mask) (void)hipFree(c->tier_mask);
+    for (int w = 0; w < 2; ++w) if (c->generic[w].blob) (void)hipFree(const_cast<float*>(c->generic[w].blob));
+    if (c->generic_ws) (void)hipFree(c->generic_ws);
     if (c->d_posdir) (void)hipFree(c->d_posdir);
     if (c->bwd_stash) (void)hipFree(c->bwd_stash);
     if (c->bwd_partial) (void)hipFree(c->bwd_partial);
@@ -462,7 +468,29 @@ static int upload_slot(iblnerf_ctx* c, int slot, const float* h_blob, size_t n_f
     }
     c->have_net[slot] = true;
     if (slot < 2) c->ci_embedded[slot] = !embedded.empty();
+    if (slot < 2 && c->generic[slot].blob) { (void)hipFree(const_cast<float*>(c->generic[slot].blob)); c->generic[slot] = GenericNet(); }
     reset_route(c, slot);
+    return IBLNERF_OK;
+}
+
+int iblnerf_upload_weights_arch(iblnerf_ctx* c, int which, const float* h_blob, size_t n_floats, int netdepth, int netwidth, int multires, int multires_views) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    if (which < 0 || which > 1 || !h_blob) return c->fail(IBLNERF_ERR_INVALID, "upload_weights_arch: which must be 0 or 1, blob non-null");
+    if (netdepth < 1 || netdepth > 32 || netdepth == 5 || netwidth < 2 || netwidth > 4096 || (netwidth & 1) || multires < 0 || multires > 24 || multires_views < 0 || multires_views > 24)
+        return c->fail(IBLNERF_ERR_INVALID, "upload_weights_arch: IBLNeRF(D=%d, W=%d, multires=%d, multires_views=%d) is outside 1 <= D <= 32 (D != 5: the reference's own "
+                                            "forward fails there), even 2 <= W <= 4096, 0 <= multires, multires_views <= 24", netdepth, netwidth, multires, multires_views);
+    if (c->opt.color_independent_to_direction) return c->fail(IBLNERF_ERR_STATE, "upload_weights_arch: colour-independent networks are built for the fused architecture only");
+    const long want = generic_blob_floats(netdepth, netwidth, multires, multires_views);
+    if ((long)n_floats != want) return c->fail(IBLNERF_ERR_INVALID, "upload_weights_arch: blob has %zu floats, IBLNeRF(D=%d, W=%d, %d / %d) has %ld", n_floats, netdepth, netwidth, multires, multires_views, want);
+    HIP_TRY(c, hipSetDevice(c->opt.device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->generic[which].blob) { (void)hipFree(const_cast<float*>(c->generic[which].blob)); c->generic[which] = GenericNet(); }
+    float* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, n_floats * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(d, h_blob, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    c->generic[which].blob = d; c->generic[which].D = netdepth; c->generic[which].W = netwidth; c->generic[which].L = multires; c->generic[which].Lv = multires_views;
+    c->have_net[which] = true;
+    reset_route(c, which);
     return IBLNERF_OK;
 }
 
@@ -658,9 +686,11 @@ int iblnerf_get_rays_pixels(iblnerf_ctx* c, void* stream, int H, int W, const fl
 }
 
 // The coarse pass's density comes from the 15-slot form (VAR_TRUNK_P) where the mode keeps the fast stream and the network fits f16
+static bool is_generic(const iblnerf_ctx* c, int which) { return which >= 0 && which < 2 && c->generic[which].blob != nullptr; }
+
 static bool sigma_p_available(const iblnerf_ctx* c, int which) {
     const int prec = c->opt.mlp_precision;
-    return c->coarse_sigma_p && c->mx_ok[which] && c->d_stream_mx[which] != nullptr &&
+    return !is_generic(c, which) && c->coarse_sigma_p && c->mx_ok[which] && c->d_stream_mx[which] != nullptr &&
            (prec == IBLNERF_MLP_F16X3_MXFP6X || prec == IBLNERF_MLP_F16X3_MXFP6 || prec == IBLNERF_MLP_F16X3_MAIN);
 }
 
@@ -776,9 +806,43 @@ struct MlpCall {
                                         // tripwire compares the refined densities with them afterwards (k_tripwire)
 };
 
+// A network outside the built architecture: generic_mlp.hip, whole batches only (its context never holds a route: sigma_p_available is false for it).
+static int run_generic(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which, const MlpCall& m) {
+    const GenericNet& g = c->generic[which];
+    if (m.n_pts_dev != nullptr || m.out_index != nullptr || m.gen != nullptr)
+        return c->fail(IBLNERF_ERR_STATE, "internal: a list / generated-point launch reached a network of a generic architecture");
+    int variant;
+    if (l.variant == VAR_FULL || l.variant == VAR_FULL_CI) variant = 0;
+    else if (l.variant == VAR_TRUNK || l.variant == VAR_TRUNK_P || l.variant == VAR_TRUNK_X) variant = 1;
+    else if (l.variant == VAR_REFL || l.variant == VAR_REFL_CI) variant = 2;
+    else return c->fail(IBLNERF_ERR_STATE, "this query (kernel variant %d: a backward or feature query) is not built for IBLNeRF(D=%d, W=%d, multires %d / %d): the fused "
+                                           "backward exists for the built 8 x 256 / 10 / 4 architecture and the smaller ones embedded in it", l.variant, g.D, g.W, g.L, g.Lv);
+    const int ppr = m.pts_per_ray > 0 ? m.pts_per_ray : 1;
+    long chunk = (65536 / ppr) * (long)ppr;
+    if (chunk <= 0) chunk = ppr;
+    const size_t need = generic_workspace_floats(g.W, g.L, g.Lv, chunk);
+    if (need > c->generic_ws_floats) {
+        if (c->generic_ws) { HIP_TRY(c, hipStreamSynchronize(s)); (void)hipFree(c->generic_ws); c->generic_ws = nullptr; c->generic_ws_floats = 0; }
+        HIP_TRY(c, hipMalloc((void**)&c->generic_ws, need * sizeof(float)));
+        c->generic_ws_floats = need;
+    }
+    HIP_TRY(c, launch_generic_mlp(g, variant, m.pts, m.dirs, ppr, m.n_pts, m.out, m.out_stride, c->generic_ws, chunk, s));
+    // (algorithmic FLOPs: 2 x the nn.Linear MACs of THIS architecture)
+    const double ch = 3 + 6 * g.L, chv = 3 + 6 * g.Lv, W = g.W, H = g.W / 2;
+    double trunk = ch * W + W;
+    for (int k = 1; k < g.D; ++k) trunk += (k == 5 ? W + ch : W) * W;
+    const double full = trunk + 2 * (W * H) + 3 * H + H + W + W * W + (chv + W) * W + 3 * W + 3 * (W * H + 3 * H);
+    const double flop = 2.0 * (variant == 1 ? trunk : variant == 0 ? full : full - (2 * (W * H) + 3 * H + H + W));
+    if (m.count_flops) c->flop_alg += (double)m.n_pts * flop;
+    c->flop_exec += (double)m.n_pts * flop;
+    c->slot_units += (double)m.n_pts * flop / 128.0 * 64.0;
+    return IBLNERF_OK;
+}
+
 static int run_launch(iblnerf_ctx* c, hipStream_t s, const Launch& l, int which, const MlpCall& m) {
     if (l.none()) return c->fail(IBLNERF_ERR_STATE, "internal: a route table row without a kernel was executed");
     if (m.n_pts >= (1L << 31)) return c->fail(IBLNERF_ERR_INVALID, "more than 2^31 points in one MLP launch");
+    if (is_generic(c, which)) return run_generic(c, s, l, which, m);
     if (l.kern == K_FP32) {
         if (which > 1 || !c->d_blob32[which] || l.variant != VAR_TRUNK || m.gen) return c->fail(IBLNERF_ERR_STATE, "internal: the fp32 trunk serves networks 0 / 1, trunk only, points from memory");
         TrunkFp32Args f;
@@ -1505,7 +1569,7 @@ static QueryPlan plan_offsets(const iblnerf_ctx* c, int which, int kind, int S, 
         return q;
     }
     if (gt_normal || c->opt.normal_mode == IBLNERF_NORMAL_INFERRED) { q.run = false; return q; }
-    if (tilt || !c->fuse_points) {
+    if (tilt || !c->fuse_points || is_generic(c, which)) {      // (a generic architecture reads its points from memory: the [4][R][S][3] batch)
         q.point_batch = true;
         q.whole = pick_kernel(c, which, VAR_TRUNK, qclass, false);
         return q;

@@ -232,6 +232,17 @@ hipError_t launch_chunk_points(const float* rays_o, const float* rays_d, const f
                                float margin, float t_min, float* pts_out, int* index_out, int* counter, hipStream_t s, bool offsets, float eps, bool first,
                                double flop_per_point, double slots_per_point);
 
+// networks outside the built architecture (generic_mlp.hip): layer-by-layer exact-fp32 evaluation on the matrix cores, activations in HBM
+struct GenericNet {
+    const float* blob = nullptr;     // the state dict flattened in registration order (checkpoint.arch_schema), fp32, device memory
+    int D = 8, W = 256, L = 10, Lv = 4;
+};
+long generic_blob_floats(int D, int W, int L, int Lv);
+size_t generic_workspace_floats(int W, int L, int Lv, long chunk);
+// variant 0 FULL -> out [n][18], 1 TRUNK -> out[p * out_stride], 2 REFL -> out [n][13]; dirs [n / pts_per_ray][3] (not read by TRUNK); chunk: a multiple of pts_per_ray
+hipError_t launch_generic_mlp(const GenericNet& g, int variant, const float* pts, const float* dirs, int pts_per_ray, long n, float* out, int out_stride, float* ws,
+                              long chunk, hipStream_t s);
+
 // counts into *bad the samples on which estimate `a` (plain f16) is half-way to a wrong k_select_points decision against estimate `b` (f16 + 2 fp6)
 // ... and into bad[1] the bits of the largest |a - b| among the samples with |b| <= zone (bad[0..1] zeroed by the caller)
 hipError_t launch_compare_estimates(const float* a, const float* b, long n, float margin, float zone, int* bad, hipStream_t s);

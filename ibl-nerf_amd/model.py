@@ -23,11 +23,15 @@ class IBLNeRF:
                  is_color_independent_to_direction=False, **_ignored):
         # The kernels are built for D=8, W=256, multires 10 / 4; a SMALLER network is evaluated as the member of that architecture computing the same function
         # (checkpoint.embed_architecture, applied at upload): D <= 8 (not 5: the reference's own forward fails there), W <= 256, multires <= 10, multires_views <= 4.
-        ok = (tuple(skips) == (4,) and coarse_radiance_number == 3 and 1 <= D <= 8 and D != 5 and 2 <= W <= 256 and 3 <= input_ch <= 63 and (input_ch - 3) % 6 == 0
-              and 3 <= input_ch_views <= 27 and (input_ch_views - 3) % 6 == 0)
+        # Round 6: anything LARGER (D <= 32, even W <= 4096, multires / multires_views <= 24) runs on csrc/generic_mlp.hip — layer by layer in exact fp32 on the matrix
+        # cores, every sample of every query, no backward: correct and slow (checkpoint.is_generic_arch; iblnerf_upload_weights_arch).
+        shape_ok = (input_ch - 3) % 6 == 0 and (input_ch_views - 3) % 6 == 0 and input_ch >= 3 and input_ch_views >= 3
+        arch = (int(D), int(W), (int(input_ch) - 3) // 6, (int(input_ch_views) - 3) // 6) if shape_ok else None
+        ok = tuple(skips) == (4,) and coarse_radiance_number == 3 and shape_ok and (ck.is_member_of_built(arch) or (ck.is_generic_arch(arch) and not is_color_independent_to_direction))
         if not ok:
-            raise NotImplementedError("the HIP path is built for D=8, W=256, multires=10, multires_views=4, skips=[4], coarse_radiance_number=3 and evaluates smaller "
-                                      "networks (D <= 8 and != 5, W <= 256, multires <= 10, multires_views <= 4) inside it; got D=%d, W=%d, input_ch=%d, "
+            raise NotImplementedError("the HIP path is built for D=8, W=256, multires=10, multires_views=4, skips=[4], coarse_radiance_number=3, evaluates smaller "
+                                      "networks (D <= 8 and != 5, W <= 256, multires <= 10, multires_views <= 4) inside it and larger ones (D <= 32 and != 5, even W <= 4096, "
+                                      "multires, multires_views <= 24; not colour-independent) layer by layer; got D=%d, W=%d, input_ch=%d, "
                                       "input_ch_views=%d, skips=%s, coarse_radiance_number=%d" % (D, W, input_ch, input_ch_views, list(skips), coarse_radiance_number))
         self.arch = (int(D), int(W), (int(input_ch) - 3) // 6, (int(input_ch_views) - 3) // 6)
         self.is_color_independent_to_direction = bool(is_color_independent_to_direction)   # ibl_nerf.py:75, :192
@@ -45,7 +49,10 @@ class IBLNeRF:
             sd = OrderedDict((k, np.array(ck._to_numpy(v), dtype=np.float32)) for k, v in sd.items())
             if ck.arch_of(sd) != self.arch:
                 raise ValueError("state dict of IBLNeRF%s loaded into IBLNeRF%s" % (ck.arch_of(sd), self.arch))
-            ck.embed_architecture(sd)                                  # validates names and shapes
+            if ck.is_member_of_built(self.arch):
+                ck.embed_architecture(sd)                              # validates names and shapes
+            else:
+                ck.arch_blob(sd, self.arch)                            # likewise
             self._sd = OrderedDict((n + t, sd[n + t]) for n, _, _ in ck.arch_schema(*self.arch) for t in (".weight", ".bias"))
         self._version += 1
         for v in self._sd.values():
@@ -363,8 +370,9 @@ def training_network_query_fn(grad_query_fn, fused_trunk_backward=False):
 def create_IBLNeRF(args):
     """ibl_nerf.py:255-428.  Returns (render_kwargs_train, render_kwargs_test, start, elapsed_time,
     grad_vars, optimizer) with grad_vars/optimizer = None (forward-only build)."""
-    if not (0 <= args.multires <= 10 and 0 <= args.multires_views <= 4) or args.i_embed != 0:
-        raise NotImplementedError("the kernels' positional encoding is built for multires <= 10 / multires_views <= 4 (i_embed = 0); fewer frequencies run inside it")
+    if not (0 <= args.multires <= 24 and 0 <= args.multires_views <= 24) or args.i_embed != 0:
+        raise NotImplementedError("the positional encoding is built for multires, multires_views <= 24 (i_embed = 0): <= 10 / <= 4 inside the fused kernels, more on the "
+                                  "layer-by-layer path (csrc/generic_mlp.hip)")
     # ibl_nerf.py:292-304: both are PositionDirectionMLPs; render_rays only ever evaluates the depth_mlp (:722-726)
     in_ch, in_chv = 3 + 6 * args.multires, 3 + 6 * args.multires_views
     depth_mlp = PositionDirectionMLP(D=args.netdepth, W=args.netwidth, input_ch=in_ch, input_ch_views=in_chv, out_ch=1) if getattr(args, "infer_depth", False) else None

@@ -148,6 +148,7 @@ class Renderer:
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
         self._twin_ref = None        # (mode, Renderer) of precision_report
         self._blobs, self._lut = {}, None
+        self._generic = {}           # network slot -> (D, W, multires, multires_views) of a network on the layer-by-layer path (outside the built architecture)
         self.route = None            # the iblnerf_route in effect as a dict: the last call's own (measured on its probe) or an imposed one ("imposed": True); None = none
         self._c_route = False        # ... and whether the library holds one
         self.trips = 0               # rays rendered once more with every sample evaluated because the estimate tripwire marked them (cumulative)
@@ -189,6 +190,22 @@ class Renderer:
     def _upload(self, which, state_dict_or_blob, remember):
         torch = _torch()
         blob = state_dict_or_blob
+        if isinstance(blob, dict) and blob and int(which) < 2:
+            arch = ck.arch_of(blob)
+            if not ck.is_member_of_built(arch):
+                # an architecture the fused kernels cannot hold (netdepth > 8, netwidth > 256, multires > 10 / 4): csrc/generic_mlp.hip — layer by layer, exact fp32
+                if not ck.is_generic_arch(arch):
+                    raise NotImplementedError("IBLNeRF%s is outside what either path is built for (D <= 32 and != 5, even W <= 4096, multires / multires_views <= 24)" % (arch,))
+                flat = ck.arch_blob(blob, arch)
+                B.check(self.ctx, self.lib.iblnerf_upload_weights_arch(self.ctx, int(which), flat.ctypes.data, flat.size, *arch))
+                self._generic[int(which)] = arch
+                if int(which) == 1:
+                    self.has_fine = True
+                self.route, self._c_route = None, False
+                if self._auto:
+                    self.policy = None
+                return
+            self._generic.pop(int(which), None)
         if isinstance(blob, dict) and blob:
             # a smaller IBLNeRF (netdepth / netwidth / multires / multires_views below the built 8 / 256 / 10 / 4) is uploaded as the member of the built architecture
             # that computes the same function (checkpoint.embed_architecture: zero units, zero frequency columns, identity layers); a built-shape dict passes through
@@ -1219,7 +1236,8 @@ class Renderer:
                 return self._wide_twin(count=False).render_rays(rays_o, rays_d, near, far, gt_values, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std,
                                                                 draws=draws, taps=taps, **edit)
         self._chunk = chunk          # (one flag's result depends on the reference's chunking: edit_roughness_by_img, see _overrides)
-        eager = not lazy and taps is None and not sampled and self.mlp_precision != "bf16x3"
+        # (a network on the layer-by-layer path has nothing to decide: every sample of every query is evaluated in exact fp32)
+        eager = not lazy and taps is None and not sampled and self.mlp_precision != "bf16x3" and not self._generic
         if eager and gt_values and edit.get("edit_intrinsic") and edit.get("edit_roughness") and edit.get("edit_roughness_by_img") and "_edit_roughness_resolved" not in gt_values \
                 and "edit_roughness" in gt_values and "edit_intrinsic_mask" in gt_values:
             # resolved ONCE on the call's flat ray list in the reference's chunks (see _overrides), so that the probe and a repeat of single rays take the same rows

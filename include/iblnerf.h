@@ -233,6 +233,15 @@ size_t iblnerf_blob_floats(void);
  * in registration order, weight [out,in] row-major then bias.  Weights are copied (re-upload after
  * an optimizer step).  Synchronous. */
 int iblnerf_upload_weights(iblnerf_ctx* ctx, int which, const float* h_blob, size_t n_floats);
+/* Round 6: a network OUTSIDE the built architecture — IBLNeRF(D = netdepth, W = netwidth, input_ch = 3 + 6 multires, input_ch_views = 3 + 6 multires_views, skips = [4],
+ * coarse_radiance_number = 3) with 1 <= netdepth <= 32 (not 5: the reference's own forward fails there), even 2 <= netwidth <= 4096, 0 <= multires, multires_views <= 24;
+ * src/nerf_models/ibl_nerf.py:14-60 and config_parser.py's --netdepth / --netwidth / --multires / --multires_views accept any.  h_blob = the state dict's tensors in
+ * registration order, [out, in] row-major weight then bias per layer (ibl-nerf_amd/checkpoint.py arch_schema / arch_blob).  Such a network is evaluated by
+ * csrc/generic_mlp.hip: layer by layer in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), activations in HBM, every sample of every query — no lists, no
+ * estimates (the context holds no route), no backward (the gradient entry points return IBLNERF_ERR_STATE for this slot), not for colour-independent contexts;
+ * ~1/20 of the fused kernels' rate at the built width.  Networks INSIDE the built architecture (smaller ones) are embedded exactly by the caller and uploaded with
+ * iblnerf_upload_weights.  A later iblnerf_upload_weights for the same slot takes the slot back to the fused kernels. */
+int iblnerf_upload_weights_arch(iblnerf_ctx* ctx, int which, const float* h_blob, size_t n_floats, int netdepth, int netwidth, int multires, int multires_views);
 
 /* Same, with the blob already in device memory (e.g. torch.cat of the module's parameters): packed by a kernel
  * enqueued on `stream`, no host copy and no synchronisation — the cheap way to follow an optimizer step

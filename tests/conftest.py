@@ -45,8 +45,8 @@ def load_golden(name):
     else:
         sdc = ck.synthetic_state_dict(int(g["seed_coarse"]), float(g["gain"]))
         sdf = ck.synthetic_state_dict(int(g["seed_fine"]), float(g["gain"]))
-    assert ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sdc))) == str(g["ck_coarse"])
-    assert ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sdf))) == str(g["ck_fine"])
+    assert ck.weights_checksum(sdc) == str(g["ck_coarse"])
+    assert ck.weights_checksum(sdf) == str(g["ck_fine"])
     edit = {k[6:]: g[k].tolist() for k in g.files if k.startswith("edit__")}
     gt = {k[4:]: g[k] for k in g.files if k.startswith("gt__")}
     return g, sdc, sdf, gt, edit
@@ -69,7 +69,8 @@ def rel_linf(x, ref):
 RENDER_FIXTURES = ["cfg1_coarse_g10", "plain_g10", "plain_g16", "edit_g10", "insert_g10", "variant_lin_g10",
                    "edit2_g10", "variant_small_g10", "gtnormal_g10", "colorindep_g10", "fromgt_g10", "fromgt_insert_g10", "dirnormal_g10", "auxmlp_g10",
                    "auxmlp_lin_g10", "infernormal_g10", "infernormal_target_g10",
-                   "infernormal_surface_g10", "inferdepth_g10", "edit3_g10", "arch_6x128_g10", "arch_4x64_g10", "arch_7x200_g10", "arch_aux_6x128_g10"]
+                   "infernormal_surface_g10", "inferdepth_g10", "edit3_g10", "arch_6x128_g10", "arch_4x64_g10", "arch_7x200_g10", "arch_aux_6x128_g10",
+                   "arch_10x384_g10", "arch_8x512_g10"]      # (the last two: LARGER than the built architecture — round 6, the layer-by-layer path csrc/generic_mlp.hip)
 FITTED_FIXTURES = ["fitted_plain", "fitted_edit", "fitted_insert", "fitted_wide"]   # rendered by the reference from the fitted checkpoint (fitted_wide: 1 024 rays, maps only)
 
 

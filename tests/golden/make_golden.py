@@ -437,8 +437,8 @@ def _run_fixture(name, torch, R, M, lut, *, n_rays, n_importance, gain, seed, mo
     out = dict(rays_o=o, rays_d=d, pix=pix.astype(np.int64), near=np.float32(near), far=np.float32(far),
                gain=np.float64(gain), seed_coarse=np.int64(2 * seed), seed_fine=np.int64(2 * seed + 1),
                n_importance=np.int64(n_importance), n_samples=np.int64(n_samples),
-               ck_coarse=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_c)))),
-               ck_fine=np.array(ck.blob_checksum(ck.state_dict_to_blob(ck.embed_architecture(sd_f)))),
+               ck_coarse=np.array(ck.weights_checksum(sd_c)),
+               ck_fine=np.array(ck.weights_checksum(sd_f)),
                mode=np.array(mode))
     if arch is not None:
         out["arch"] = np.asarray(arch, dtype=np.int64)
@@ -1157,6 +1157,9 @@ def main(only=None):
     run_fixture("arch_7x200_g10", torch, R, M, lut, n_rays=48, n_importance=64, gain=1.0, seed=23, arch=(7, 200, 8, 3), mode="insert")     # odd width, one identity layer, insert overrides
     # ... with every auxiliary network in the same small shape (PositionMLP x 4, the depth_mlp a PositionDirectionMLP with D // 2 = 3 view layers of W // 2)
     run_fixture("arch_aux_6x128_g10", torch, R, M, lut, n_rays=48, n_importance=128, gain=1.0, seed=24, arch=(6, 128, 6, 2), aux=True, infer_normal=True, infer_depth=True)
+    # LARGER architectures (round 6: csrc/generic_mlp.hip evaluates them layer by layer in exact fp32): deeper, wider, more frequencies than the built 8 x 256 / 10 / 4
+    run_fixture("arch_10x384_g10", torch, R, M, lut, n_rays=48, n_importance=64, gain=1.0, seed=25, arch=(10, 384, 12, 5))     # two layers behind the skip layer more, 1.5 x the width, 12 / 5 frequencies
+    run_fixture("arch_8x512_g10", torch, R, M, lut, n_rays=40, n_importance=64, gain=1.0, seed=26, arch=(8, 512, 10, 4), mode="edit")      # the built depth at twice the width, edit overrides
     # is_color_independent_to_direction (ibl_nerf.py:192): radiance heads on the trunk output, no feature / view layers
     run_fixture("colorindep_g10", torch, R, M, lut, n_rays=64, n_importance=128, gain=1.0, seed=8, color_independent=True)
     # ground-truth normals instead of the eps-normal (no offset queries)

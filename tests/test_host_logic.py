@@ -700,7 +700,15 @@ def test_checkpoint_roundtrip_and_discovery():
     small.load_state_dict(ck.synthetic_arch_state_dict(3, (6, 128, 6, 2)))
     with pytest.raises(ValueError):
         small.load_state_dict(ck.synthetic_state_dict(3))
-    for bad in (dict(W=512), dict(D=9), dict(D=5), dict(input_ch=69), dict(coarse_radiance_number=2), dict(skips=(3,))):
+    # (round 6: a LARGER one is a container too — evaluated layer by layer, csrc/generic_mlp.hip; what stays refused: D = 5, odd or huge widths, other skips / radiance counts)
+    for arch_kw, arch in ((dict(W=512), (8, 512, 10, 4)), (dict(D=9), (9, 256, 10, 4)), (dict(input_ch=69), (8, 256, 11, 4)), (dict(D=12, W=384, input_ch_views=33), (12, 384, 10, 5))):
+        big = M.IBLNeRF(**arch_kw)
+        assert big.arch == arch and ck.is_generic_arch(arch) and not ck.is_member_of_built(arch)
+        big.load_state_dict(ck.synthetic_arch_state_dict(5, arch))
+        assert ck.arch_blob(big.state_dict()).size == sum(o * i + o for _, o, i in ck.arch_schema(*arch))
+    with pytest.raises(NotImplementedError):
+        M.IBLNeRF(W=512, is_color_independent_to_direction=True)
+    for bad in (dict(D=5), dict(W=257), dict(W=8192), dict(D=40), dict(input_ch=70), dict(coarse_radiance_number=2), dict(skips=(3,))):
         with pytest.raises(NotImplementedError):
             M.IBLNeRF(**bad)
     # ... the auxiliary networks likewise (create_IBLNeRF builds them with the same netdepth / netwidth / multires, ibl_nerf.py:293-323)
