@@ -658,6 +658,44 @@ def test_a_training_step_takes_no_routing_decisions(G, lut):
     assert r.last_selection()[0] > 0
 
 
+def test_the_backward_runs_on_the_live_samples_only(G, lut):
+    """Round 6 (training.network_backward_live): a pass's dead samples — density not positive: alpha = 0, the ReLU dead, the whole dL/d raw row exactly zero — are dropped
+    before the fused backward; every parameter gradient of both networks against the same step on every sample, to fp32 round-off of the weight-gradient sums, for a
+    third of the points.  (pytest = True: both steps take the same draws.)"""
+    import train_loss as TL
+    from conftest import load_golden
+    from ibl_nerf_amd import renderer as R, training as T
+    g = load_golden("fitted_launch16k")[0]
+    rays = torch.from_numpy(np.stack([g["rays_o"][:3072], g["rays_d"][:3072]], 0)).cuda()
+    rng = np.random.RandomState(5)
+    tg = {k: torch.from_numpy(v).cuda() for k, v in TL.targets(rng, 3072).items()}
+    grads, points = {}, {}
+    keep = T.COMPACT_MIN_POINTS
+    try:
+        for label, threshold in (("all", 1 << 60), ("live", 0)):
+            T.COMPACT_MIN_POINTS = threshold
+            nets, kw, K, _ = _setup(G, lut, "full")
+            kw = dict(kw, pytest=True)
+            r = R.renderer_for(dict(kw, _lazy_range_check=True))
+            seen = []
+            orig = r.network_backward
+            r.network_backward = lambda pts, vd, draw, which=0, grad_scale=None, _o=orig, _s=seen: (_s.append(int(pts.shape[0]) * int(pts.shape[1])), _o(pts, vd, draw, which, grad_scale))[1]
+            try:
+                res = R.render_decomp(800, 800, K, chunk=3072, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+                TL.total_loss(torch, res, tg, True).backward()
+            finally:
+                r.network_backward = orig
+            grads[label] = {t + "." + k: p.grad.clone() for t, net in zip(("c", "f"), nets) for k, p in net.named_parameters() if p.grad is not None}
+            points[label] = list(seen)
+    finally:
+        T.COMPACT_MIN_POINTS = keep
+    assert points["all"] == [3072 * 64, 3072 * 192] and points["live"][0] < 0.3 * 3072 * 64 and points["live"][1] < 0.6 * 3072 * 192, points
+    assert set(grads["all"]) == set(grads["live"]) and len(grads["all"]) >= 88
+    for k, a in grads["all"].items():
+        b = grads["live"][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-12), (k, float((a - b).abs().max()), float(a.abs().max()))
+
+
 def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
     """The fused shading backward against the autograd one inside a whole step: every parameter gradient of both networks."""
     import train_loss as TL
