@@ -996,3 +996,35 @@ def test_bench_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 0.67
     assert abs(d["value"] - 640000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                       # that leg (and its PSNR check against the oracle) was switched off
+    # round 6: frac is the DRIVER-TIMED fraction — value x algorithmic FLOPs per ray / peak, nothing else in the denominator; the MLP-only figure and the executed MACs beside it
+    assert abs(rf["frac"] - d["value"] * rf["flop_per_ray"] / 1e12 / rf["peak"]) < 1e-9 and rf["flop_per_ray"] == 256 * 1591552.0 + 1024 * 982528.0 + 128 * 1458944.0
+    assert rf["frac_mlp_only"] >= rf["frac"] and 0.0 < rf["executed"]["frac_whole_step"] < rf["frac"]
+    assert d["config"]["decision_scope"].startswith("per frame") and d["config"]["decision_ms_per_frame"] > 0 and d["config"]["policy"]["decision"] in ("fast", "tiered", "safe")
+    worst = d["value_worst_checkpoint"]
+    assert worst["checkpoint"] in d["value_by_checkpoint"] and worst["value"] == min(v for k, v in d["value_by_checkpoint"].items() if k.startswith("fitted"))
+    assert 0.5 < worst["ratio_to_best"] <= 1.0
+
+
+def test_training_bench_line_contract():
+    """bench.py --train prints ONE JSON line of the same shape for the TRAINING step (render + losses + backward + Adam): value = rays of the headline step / its time,
+    a roofline object on forward + main-query-backward FLOPs, the reference's own CPU step (recorded in the build container) as cpu_baseline, the loss going down."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--train", "--train-rays", "512,2048", "--train-headline", "2048", "--steps", "8", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "rays/s" and "training" in d["metric"] and "workload" in d["config"] and d["config"]["rays_per_step"] == 2048
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["flop_per_ray"] == rf["flop_forward_per_ray"] + rf["flop_backward_per_ray"] and rf["flop_backward_per_ray"] == 2.0 * 256 * 1591552.0
+    assert abs(rf["frac"] - d["value"] * rf["flop_per_ray"] / 1e12 / rf["peak"]) < 1e-9 and 0.01 < rf["frac"] < 0.5
+    assert set(d["by_rays"]) == {"512", "2048"}
+    for v in d["by_rays"].values():
+        assert v["skipped_steps"] == 0 and v["range_fallbacks"] == 0 and v["loss_last"] < v["loss_first"], v
+    ref = d["by_rays"]["512"]["reference_in_build_container"]
+    assert ref["kind"] == "reference" and ref["cores"] == 8 and ref["value"] > 0 and d["by_rays"]["512"]["rays_per_s"] > 100 * ref["value"]
