@@ -96,3 +96,39 @@ def test_two_rank_view_sharding(tmp_path):
     out = tmp_path / "logs_eval" / "tiny" / "testset_002000"
     names = sorted(os.listdir(out))
     assert len(names) == 21 * N_TEST and all(("rgb_%03d.png" % i) in names for i in range(N_TEST))
+
+
+def _alarm_worker(rank, world, init_file, out_dir):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+    from ibl_nerf_amd import dist as D
+    sync = D.alarm_sync()
+    assert sync is not None
+    # rank r reports r + 1 marked rays of 100 (r + 1) rays; rank 1 saw a deep miss (bits 4 | 16), rank 2 an overshoot (bit 8), rank 0 nothing
+    got = sync(rank + 1, 100 * (rank + 1), (0, 20, 8)[rank])
+    torch.save(got, os.path.join(out_dir, "alarm%d.pt" % rank))
+    # the probe / pixel helpers are functions of their arguments alone: every rank draws the same pixels
+    torch.save(D.probe_pixels(800, 800), os.path.join(out_dir, "pix%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_ranks_take_the_alarm_decision_on_the_frames_numbers():
+    """Round 6: dist.alarm_sync — what Renderer.render_rays calls with its tile's (marked rays, rays, tripwire bits) — returns the FRAME's numbers on every rank (sums and the
+    bitwise OR, one all-reduce): the decision to escalate the route and render the call again is the same everywhere.  Without a group (or with one rank) there is nothing
+    to agree on: None.  The frame's probe pixels are a function of (H, W, n, seed): the same on every rank."""
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+    from ibl_nerf_amd import dist as D
+    assert D.alarm_sync() is None
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_alarm_worker, args=(3, os.path.join(d, "rdzv"), d), nprocs=3, join=True)
+        got = [torch.load(os.path.join(d, "alarm%d.pt" % r)) for r in range(3)]
+        pix = [torch.load(os.path.join(d, "pix%d.pt" % r), weights_only=False) for r in range(3)]
+    assert got[0] == got[1] == got[2] == (6, 600, 28)
+    assert np.array_equal(pix[0], pix[1]) and np.array_equal(pix[0], pix[2]) and len(pix[0]) == 4096 and np.all(np.diff(pix[0]) > 0) and pix[0].max() < 640000
+    assert not np.array_equal(D.probe_pixels(800, 800, seed=1), pix[0]) and len(D.probe_pixels(9, 16)) == 144
