@@ -661,6 +661,7 @@ class Renderer:
                 return metrics, triggers
 
             metrics, triggers = judge(a)
+            c_maps = None
             decision, applied = ("fast", 0) if not triggers else ("safe", self.SAFE_ROUTING)
             keep = {"rays": int(a["depth_map"].shape[0]), "metrics": metrics, "triggers": triggers}
             if triggers and self.TIERED_ROUTING:
@@ -672,6 +673,8 @@ class Renderer:
                 if not t2 and not bits_c & TRIP_PROOF:
                     decision, applied = "tiered", self.TIERED_ROUTING
             keep["decision"], keep["routing"] = decision, int(self._routing | applied)
+            # (the renders themselves: when the probe is the whole call — a call of <= ROUTE_RAYS rays — the decided table's render IS the call's result)
+            self._table_maps = {"fast": a, "safe": b, "tiered": c_maps if (triggers and self.TIERED_ROUTING) else None}
         finally:
             self._set_routing(applied)          # (also after an exception inside a probe render: the context goes back to the routing it had — ADVICE r4)
             self.policy = keep
@@ -691,7 +694,7 @@ class Renderer:
         n = rays_o.shape[0]
         route_open, table_open = not self._route_imposed(), not self._policy_imposed()
         if not route_open and not table_open:
-            return
+            return None
         if probe is not None:
             pro, prd = _dev_f32(probe["rays_o"], self.device).reshape(-1, 3), _dev_f32(probe["rays_d"], self.device).reshape(-1, 3)
             pnear, pfar, pgt = probe.get("near", near), probe.get("far", far), probe.get("gt_values")
@@ -720,10 +723,16 @@ class Renderer:
                 self._withdraw_route()
         if table_open:
             if pro is not None and pro.shape[0] >= self.CAL_MIN_RAYS:
+                self._table_maps = None
                 self._measure_table(pro, prd, pnear, pfar, pgt, edit, fast_maps=fast_maps)
+                if probe is None and pro.shape[0] == n and route_open and self._table_maps is not None:
+                    # the probe WAS the call (n <= ROUTE_RAYS: every ray measured on): the decided table's probe render is the call's render — a function of the call's
+                    # rays alone, like everything else here — and is not rendered a third time
+                    return self._table_maps.get(self.policy["decision"])
             else:
                 self._set_routing(self.SAFE_ROUTING)
                 self.policy = None
+        return None
 
     def trim(self):
         """Frees the fused backward's workspace (iblnerf_trim)."""
@@ -1248,9 +1257,10 @@ class Renderer:
         if eager:
             # (a training step's context — lazy, sampled, tapped — keeps the FAST table and holds no route: its renders are stochastic, its weights change every step,
             # and a lazy context never reads the tripwire: ADVICE r5)
+            decided_maps = None
             for attempt in (0, 1):
                 try:
-                    self._decide_for_call(rays_o, rays_d, *self._plane_args(near, far, n), gt_values, edit, probe)
+                    decided_maps = self._decide_for_call(rays_o, rays_d, *self._plane_args(near, far, n), gt_values, edit, probe)
                     break
                 except _RangeEvent:
                     # the probe left the f16 range: nothing can be measured before that is answered — the networks rescaled into range by measurement (then the probe
@@ -1266,6 +1276,8 @@ class Renderer:
                 # (a sampled / tapped / lazy call runs on the FAST table whatever an earlier eager call on this context decided for itself: no memory here either)
                 self._set_routing(0)
                 self.policy = None
+        if eager and decided_maps is not None:
+            return decided_maps
         want_trips = eager and self._c_route
         res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
                                        taps=taps, noise=noise, _retry=_retry, want_trips=want_trips)
