@@ -1502,6 +1502,8 @@ static bool lists_possible(const iblnerf_ctx* c, int which, bool keep_all_rows) 
 }
 
 static bool density_fp32(const iblnerf_ctx* c, int which) { return which < 2 && c->d_blob32[which] != nullptr && !c->density_15slot; }
+// the coarse density of a WHOLE batch in exact fp32 too: where it is cheap (a launch of fewer rays than a route needs) or explicit (the repeat of tripped rays)
+static bool whole_batch_fp32(const iblnerf_ctx* c) { return c->lists_off || (!c->route_decided && !c->deciding && c->cur_R < SELECT_MIN_RAYS); }
 
 static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, bool keep_all_rows) {
     QueryPlan q;
@@ -1524,6 +1526,11 @@ static QueryPlan plan_main(const iblnerf_ctx* c, int which, int kind, int S, boo
         // ... and on the LIST in exact fp32 (round 5, trunk_fp32_kernel.hip): the samples that place the fine samples, ~5 per ray, at 1/16 of the f16 rate.  (A whole
         // batch of 64 samples per ray — lists off, fog — keeps the 15-slot form: 40 ms per launch in fp32.)
         if (q.density_on_list && density_fp32(c, which)) { q.density.kern = K_FP32; q.density.variant = VAR_TRUNK; }
+        // Round 6: ... and on EVERY coarse sample where that is affordable and the arithmetic must not depend on how a ray came to be evaluated whole — the repeat of a
+        // tripped ray (iblnerf_set_lists 0: a handful of rays) and a call too small to hold a route (< SELECT_MIN_RAYS rays: 0.8 ms).  The 15-slot form's 1e-6 .. 1.2e-5 on a
+        // coarse weight moved the fine samples of one ray in 16 384 far enough for its normal to differ by 8.6e-3 between a 1 023-ray call and a frame; in fp32 they agree.
+        // (not a training step's tapped forward: 512 rays x 64 samples in fp32 would add 12 % to a 5 ms step, and its gradients are pinned on the 15-slot density)
+        else if (!q.density_on_list && !keep_all_rows && density_fp32(c, which) && whole_batch_fp32(c)) { q.density.kern = K_FP32; q.density.variant = VAR_TRUNK; }
     }
     if (kind == PASS_COARSE && list_ok && !keep_all_rows && (fast || three)) {
         // (the coarse main query: its other channels on the table's kernel for weighted sums, its density on the 15-slot form either way)
@@ -2035,6 +2042,13 @@ static int density_pass(iblnerf_ctx* c, hipStream_t s, const float* ro, const fl
             l.trip_margin = c->margin[0];
             return run_launch(c, s, p15, 0, l);
         }
+    }
+    if (density_fp32(c, 0) && sigma_p_available(c, 0) && whole_batch_fp32(c)) {      // (plan_main's rule for the whole-batch density, here for the density-only coarse pass)
+        Launch f32;
+        f32.kern = K_FP32; f32.variant = VAR_TRUNK;
+        MlpCall m;
+        m.pts = c->pts; m.pts_per_ray = Sc; m.n_pts = n; m.out = c->sig4; m.count_flops = !est_ran;
+        return run_launch(c, s, f32, 0, m);
     }
     return run_mlp(c, s, VAR_TRUNK, 0, c->pts, nullptr, Sc, n, c->sig4, 1, Q_MAIN_COARSE, nullptr, !est_ran);   // (algorithmic FLOPs: once per query)
 }

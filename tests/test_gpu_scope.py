@@ -120,16 +120,18 @@ def test_tripped_rays_are_repeated_by_themselves_and_the_split_of_a_frame_change
     for k in ("depth_map", "target_normal_map", "color_map", "albedo_map", "weights"):
         full = torch.stack([p[k].reshape((len(rows[0]), W) + tuple(p[k].shape[1:])) for p in parts], 1).reshape((H * W,) + tuple(parts[0][k].shape[1:]))
         assert torch.equal(full.nan_to_num(7.0), whole[k].nan_to_num(7.0)), k
-    # the marked rays' rows are the every-sample evaluation's: the frame rendered with the lists off altogether has them bit for bit (the other rays differ by what the
-    # two routes' coarse densities differ by — exact fp32 on the lists, the 15-slot form on whole batches: other fine samples on the reference's own sensitive rays)
+    # the marked rays' rows are the every-sample evaluation's (iblnerf_set_lists 0; the coarse density in exact fp32 there too): rendering exactly those rays with the lists
+    # off gives their rows bit for bit — whichever call marked them
+    idx = torch.as_tensor(sorted(marked), device=ro.device)
     r.lib.iblnerf_set_lists(r.ctx, 0)
     try:
-        nolist, _, _ = r._render(ro, rd, 0.5, 8.0, None, {})
+        alone, _, _ = r._render(ro[idx].contiguous(), rd[idx].contiguous(), 0.5, 8.0, None, {})
+        one, _, _ = r._render(ro[idx[:1]].contiguous(), rd[idx[:1]].contiguous(), 0.5, 8.0, None, {})
     finally:
         r.lib.iblnerf_set_lists(r.ctx, 1)
-    idx = torch.as_tensor(sorted(marked), device=ro.device)
-    for k in ("depth_map", "target_normal_map", "weights", "albedo_map"):
-        assert torch.equal(nolist[k][idx], whole[k][idx]), k
+    for k in whole:
+        assert torch.equal(alone[k].nan_to_num(7.0), whole[k][idx].nan_to_num(7.0)), k
+        assert torch.equal(one[k].nan_to_num(7.0), whole[k][idx[:1]].nan_to_num(7.0)), k
 
 
 def test_a_route_that_does_not_fit_the_call_raises_the_alarm(R, lut):
@@ -164,3 +166,28 @@ def test_a_route_that_does_not_fit_the_call_raises_the_alarm(R, lut):
     assert r.route["tripped"] == 2 and r.probe_escalations >= 1 and r.last_selection() == (0, 0), (r.route, r.probe_escalations, r.alarms)
     for k in got:
         assert torch.equal(got[k], whole[k]), k
+
+
+def test_call_sizes_around_the_decision_thresholds(R, lut):
+    """0, 1, 1 023 rays: nothing to measure on — every sample evaluated, SAFE table.  1 024 .. 2 047: a route of the call's own, SAFE table.  2 048 .. 4 096: the call is its
+    own probe and the decided table's probe render is returned.  4 097 and more: a strided probe, then the render.  Whatever the size, a ray's maps agree with the same ray's
+    in a call of another size to well within the parity bar (the tables differ by at most the calibration limits), and the same call twice gives the same bits."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    r = make_renderer(R, g, sdc, sdf, lut)
+    ro, rd = torch.from_numpy(g["rays_o"]).cuda(), torch.from_numpy(g["rays_d"]).cuda()
+    empty = r.render_rays(ro[:0], rd[:0], 0.5, 8.0)
+    assert all(v.shape[0] == 0 for v in empty.values()) and r.route is None
+    ref = r.render_rays(ro[:8192], rd[:8192], 0.5, 8.0)
+    assert r.policy["decision"] == "fast" and r.route["probe_rays"] == 4096
+    seen = {}
+    for n in (1, 1023, 1024, 2047, 2048, 4096, 4097):
+        out = r.render_rays(ro[:n].contiguous(), rd[:n].contiguous(), 0.5, 8.0)
+        seen[n] = (None if r.route is None else r.route["probe_rays"], None if r.policy is None else r.policy["decision"], r.last_selection()[1] > 0)
+        again = r.render_rays(ro[:n].contiguous(), rd[:n].contiguous(), 0.5, 8.0)
+        assert _same(out, again), n
+        for k in ("depth_map", "albedo_map", "roughness_map", "irradiance_map", "target_normal_map", "radiance_map"):
+            e = float((out[k] - ref[k][:n]).abs().max() / ref[k].abs().max())
+            assert e <= 5e-4, (n, k, e)
+    assert seen[1] == seen[1023] == (None, None, False)
+    assert seen[1024] == (1024, None, True) and seen[2047] == (2047, None, True)
+    assert seen[2048] == (2048, "fast", True) and seen[4096] == (4096, "fast", True) and seen[4097] == (4096, "fast", True), seen
