@@ -328,12 +328,17 @@ def train_bench(args):
 
         for _ in range(max(args.warmup, 2)):
             l0 = step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
+        # K timed steps between synchronisations, three times over; the best of the three (a 512-ray step is launch- and host-bound: 5 ms of ~300 launches, and the
+        # box's host is shared — single repetitions scatter by 30 %)
+        dts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            torch.cuda.synchronize()
+            dts.append((time.perf_counter() - t0) / args.steps)
+        dt = min(dts)
         # the same step in three parts (untimed extra steps)
         parts = []
         for _ in range(3):
@@ -349,7 +354,7 @@ def train_bench(args):
         r = R.renderer_for(dict(kw, _lazy_range_check=True))
         f_step = F_ALG_PER_RAY + F_TRAIN_BWD_PER_RAY
         by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": 1e3 * pm[0], "loss_backward_ms": 1e3 * pm[1], "adam_ms": 1e3 * pm[2],
-                           "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
+                           "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "ms_per_step_repetitions": [1e3 * v for v in dts], "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
                            "skipped_steps": int(getattr(r, "skipped_steps", 0)), "range_fallbacks": int(r.range_fallbacks),
                            "reference_in_build_container": reference_train_record(n)}
     head = str(args.train_headline if str(args.train_headline) in by_rays else sizes[-1])
