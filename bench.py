@@ -318,26 +318,36 @@ def train_bench(args):
         rays = torch.from_numpy(np.stack([np.zeros_like(d), d], 0)).cuda()
         tg = {k: torch.from_numpy(v).cuda() for k, v in TL.targets(rng, n).items()}
 
-        def step():
-            res = R.render_decomp(H, W, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+        def step(**over):
+            res = R.render_decomp(H, W, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, **over))
             loss = TL.total_loss(torch, res, tg, True)
             opt.zero_grad()
             loss.backward()
             opt.step()
             return loss
 
-        for _ in range(max(args.warmup, 2)):
-            l0 = step()
-        # K timed steps between synchronisations, three times over; the best of the three (a 512-ray step is launch- and host-bound: 5 ms of ~300 launches, and the
-        # box's host is shared — single repetitions scatter by 30 %)
-        dts = []
-        for _ in range(3):
+        def timed(**over):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                loss = step()
+                last = step(**over)
             torch.cuda.synchronize()
-            dts.append((time.perf_counter() - t0) / args.steps)
+            return (time.perf_counter() - t0) / args.steps, last
+
+        for _ in range(max(args.warmup, 2)):
+            l0 = step()
+        # K timed steps between synchronisations, three times over, ALTERNATING between the product's default — the forward under a route (Renderer.training_lists;
+        # measured every 64 steps inside the timed region, calls of >= 1 024 rays) — and the same steps with every sample of every query evaluated (train_lists = 0:
+        # round 5's forward); the best of each three.  (A 512-ray step is launch- and host-bound — 5 ms of ~300 launches on a shared host — and a block of twenty
+        # 4 096-ray steps lasts 0.4 s, inside the clock transients of a power-bound chip: single repetitions scatter by 30 %, and the second thing timed sees a warmer
+        # chip than the first — hence the alternation.)
+        dts, dts_all = [], []
+        for _ in range(3):
+            dt_, loss = timed()
+            dts.append(dt_)
+            step(train_lists=0)
+            dts_all.append(timed(train_lists=0)[0])
+            step()
         dt = min(dts)
         # the same step in three parts (untimed extra steps)
         parts = []
@@ -353,8 +363,12 @@ def train_bench(args):
         pm = np.array(parts).min(0)
         r = R.renderer_for(dict(kw, _lazy_range_check=True))
         f_step = F_ALG_PER_RAY + F_TRAIN_BWD_PER_RAY
+        ts = r.training_state()
         by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": 1e3 * pm[0], "loss_backward_ms": 1e3 * pm[1], "adam_ms": 1e3 * pm[2],
-                           "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "ms_per_step_repetitions": [1e3 * v for v in dts], "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
+                           "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "ms_per_step_repetitions": [1e3 * v for v in dts],
+                           "ms_per_step_every_sample": 1e3 * min(dts_all), "ms_per_step_every_sample_repetitions": [1e3 * v for v in dts_all],
+                           "route": None if ts is None else {k: ts[k] for k in ("step", "measured", "events", "near_misses")},
+                           "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
                            "skipped_steps": int(getattr(r, "skipped_steps", 0)), "range_fallbacks": int(r.range_fallbacks),
                            "reference_in_build_container": reference_train_record(n)}
     head = str(args.train_headline if str(args.train_headline) in by_rays else sizes[-1])
@@ -365,7 +379,8 @@ def train_bench(args):
             "dtype": "f16 (3 MFMA products on hi/lo splits, forward and backward; f16 operand stash with a power-of-two loss scale), fp32 accumulate, fp32 Adam",
             "data": "synthetic (fitted checkpoint as the starting point, seeded pixels of the synthetic 800x800 camera, seeded targets)",
             "config": {"workload": "training step of train.py:286-297 / :479-481 at N_rand = %s rays (the reference's default batch is 4096, config_parser.py:65), 64+128 samples, "
-                                   "approximate_radiance=True, perturb = 1, every sample evaluated (a training context holds no route)" % head,
+                                   "approximate_radiance=True, perturb = 1; the forward under a route measured on the step's rays every 64 steps (estimates + lists, Renderer.training_lists: "
+                                   "calls of >= 1024 rays; by_rays.*.ms_per_step_every_sample = the same steps with every sample evaluated)" % head,
                        "checkpoint": args.checkpoint, "rays_per_step": int(head), "optimizer": "torch.optim.Adam(lr 5e-4) over both networks' 92 tensors", "parallelism": "single GPU"},
             "roofline": {"bound": "mfma", "achieved": hb["rays_per_s"] * f_step / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": hb["frac"], "traffic": None,
                          "flop_per_ray": f_step, "flop_forward_per_ray": F_ALG_PER_RAY, "flop_backward_per_ray": F_TRAIN_BWD_PER_RAY,

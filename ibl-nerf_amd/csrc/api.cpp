@@ -123,6 +123,7 @@ struct iblnerf_ctx {
     bool route_decided = false;                   // iblnerf_route.decided
     int tripped = 0;                              // iblnerf_escalate_route has been applied since the decision: 1 = margins doubled / the estimates moved to f16 + 2 fp6, 2 = the lists went off
     bool lists_off = false;                       // iblnerf_set_lists(ctx, 0): every query evaluates all of its samples whatever the route says (the repeat of a tripped ray)
+    bool tapped_lists = false;                    // iblnerf_set_tapped_lists(ctx, 1): a tapped call's MAIN queries follow the decided route too (the taps' unlisted rows: estimate, zeros)
     unsigned char* trip_rays = nullptr;           // the current launch's slice of iblnerf_outputs.trip_rays (k_tripwire marks the rays whose estimates were thin), or null
     long cur_R = 1;                               // ... and that launch's ray count
     double coarse_share = -1.0;                   // the probe's relevant share of the coarse grid (sel_on = it is <= SELECT_MAX_FRACTION)
@@ -2156,6 +2157,8 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
     c->slot_units = 0.0;
     HIP_TRY(c, hipMemsetAsync(c->sel_count + 2, 0, 8 * sizeof(int), s));
     const int Sc = c->Sc, Sf = c->Sf;
+    // a tapped call's backward reads every main raw row — unless the caller said its backward needs the live rows only (iblnerf_set_tapped_lists) and a route is decided
+    const bool keep_rows = taps != nullptr && !(c->tapped_lists && c->route_decided);
     // iblnerf_set_lists(ctx, 0): this call runs as a context whose lists are off does (every query evaluates all of its samples), whatever route is decided
     struct ListsOff {
         iblnerf_ctx* c; bool on, decided, sel;
@@ -2203,14 +2206,14 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         };
         if (!fine) {
             rc = full_pass(c, s, 0, PASS_SINGLE, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->fine, r0, Sc, irr_ch), zc, zcs,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, keep_rows);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
             continue;
         }
         if (c->opt.coarse_outputs) {
             rc = full_pass(c, s, 0, PASS_COARSE, ro, rd, R, zc, zcs, Sc, c->w_c, near_, far_, o, slice_maps(outs->coarse, r0, Sc, irr_ch), zc, zcs,
-                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, taps != nullptr);
+                           noise_c ? noise_c + r0 * Sc : nullptr, taps && taps->d_env_coarse ? taps->d_env_coarse + r0 * 12 : nullptr, nr, fr, keep_rows);
             if (rc) return rc;
             if (taps && ((rc = tap_z(taps->d_z_coarse, zc, zcs, Sc)) || (rc = tap_raw(taps->d_raw_coarse, Sc)))) return rc;
         } else {   // density only: all the fine sampling needs from the coarse network
@@ -2222,7 +2225,7 @@ int iblnerf_render_rays_tapped(iblnerf_ctx* c, void* stream, const float* d_rays
         HIP_TRY(c, launch_fine_z(zc, zcs, Sc, c->w_c, R, c->opt.n_importance, u_rand ? u_rand + r0 * c->opt.n_importance : nullptr, c->z_fine,
                                  outs->z_std ? outs->z_std + r0 : nullptr, s));
         rc = full_pass(c, s, fine_net, PASS_FINE, ro, rd, R, c->z_fine, Sf, Sf, c->w_f, near_, far_, o, slice_maps(outs->fine, r0, Sf, irr_ch), zc, zcs,
-                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr, taps != nullptr);
+                       noise_f ? noise_f + r0 * Sf : nullptr, taps && taps->d_env_fine ? taps->d_env_fine + r0 * 12 : nullptr, nr, fr, keep_rows);
         if (rc) return rc;
         if (taps && ((rc = tap_z(taps->d_z_fine, c->z_fine, Sf, Sf)) || (rc = tap_raw(taps->d_raw_fine, Sf)))) return rc;
     }
@@ -2411,6 +2414,12 @@ int iblnerf_escalate_route(iblnerf_ctx* c, int trip_bits) {
 int iblnerf_set_lists(iblnerf_ctx* c, int enabled) {
     if (!c) return IBLNERF_ERR_INVALID;
     c->lists_off = enabled == 0;
+    return IBLNERF_OK;
+}
+
+int iblnerf_set_tapped_lists(iblnerf_ctx* c, int enabled) {
+    if (!c) return IBLNERF_ERR_INVALID;
+    c->tapped_lists = enabled != 0;
     return IBLNERF_OK;
 }
 

@@ -529,6 +529,7 @@ def render_rays_train(r, rays_o, rays_d, near, far, net_c, net_f, lut, *, approx
                 sv = dict(zc=st._e(n, Sc), zf=st._e(n, Sf), rawc=st._e(n, Sc, 18), rawf=st._e(n, Sf, 18), envc=st._e(n, 4, 3), envf=st._e(n, 4, 3))
                 taps.d_z_coarse, taps.d_z_fine, taps.d_raw_coarse, taps.d_raw_fine = (sv[k].data_ptr() for k in ("zc", "zf", "rawc", "rawf"))
                 taps.d_env_coarse, taps.d_env_fine = sv["envc"].data_ptr(), sv["envf"].data_ptr()    # the linear reflected-ray maps, exact (no gamma round trip)
+                r._training_route(ro_, rd_, near, far)      # (Renderer.training_lists: the step's forward under a route — estimates + lists — or, off, every sample)
                 res = r.render_rays(ro_, rd_, near, far, gt_values if (from_gt or rows) else None, draws=(t_rand, u), taps=taps, raw_noise_std=raw_noise_std,
                                     noise=None if noise[0] is None else noise, chunk=chunk, **from_gt, **(edit if rows else {}))
                 sv["rawc"], sv["rawf"] = _with_noise(sv["rawc"], noise[0]), _with_noise(sv["rawf"], noise[1])     # (the taps are the network's rows: the noise is added in pass A)

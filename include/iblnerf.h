@@ -211,6 +211,12 @@ int iblnerf_escalate_route(iblnerf_ctx* ctx, int trip_bits);
 /* enabled = 0: the next render calls evaluate every sample of every query on its own kernel, whatever route is decided (and raise no tripwire: there are no lists);
  * 1 (the default) gives the route back.  How the rays marked in iblnerf_outputs.trip_rays are rendered once more. */
 int iblnerf_set_lists(iblnerf_ctx* ctx, int enabled);
+/* enabled = 1: a TAPPED call (iblnerf_render_rays_tapped with taps: a training step's forward, train.py:286-297) evaluates its main queries under the decided route as
+ * an untapped call does — estimates everywhere, the query's kernel on the relevant samples — instead of on every sample (the default, 0: the taps then hold every raw
+ * row).  The tapped raw rows of the samples NOT on a list are (density estimate, zeros): a clearly empty sample (alpha = 0 exactly, a dead ReLU in front of its
+ * density: every gradient through it is exactly zero) or one behind a transmittance of 1e-8 (gradients below 1e-8 of the ray's).  For callers whose backward reads
+ * the live rows only (ibl-nerf_amd/training.py network_backward_live).  Without a decided route nothing changes. */
+int iblnerf_set_tapped_lists(iblnerf_ctx* ctx, int enabled);
 /* The route as text: one line per (pass, query class) = which kernel estimates it (or none), in which z-chunks, and which kernel evaluates the list / the whole batch.
  * Writes at most n bytes including the terminating 0; returns the length the full text needs (snprintf's convention), < 0 on error. */
 int iblnerf_describe_route(iblnerf_ctx* ctx, char* buf, size_t n);
