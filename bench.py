@@ -336,9 +336,13 @@ def train_bench(args):
 
         for _ in range(max(args.warmup, 2)):
             l0 = step()
+        t_warm = time.perf_counter()                      # (a power-bound chip: the first second of work runs at boost clocks no training run sees — warm it up)
+        while time.perf_counter() - t_warm < 1.5 and not args.no_extras:      # (--no-extras: a profiling run)
+            step()
+            torch.cuda.synchronize()
         # K timed steps between synchronisations, three times over, ALTERNATING between the product's default — the forward under a route (Renderer.training_lists;
         # measured every 64 steps inside the timed region, calls of >= 1 024 rays) — and the same steps with every sample of every query evaluated (train_lists = 0:
-        # round 5's forward); the best of each three.  (A 512-ray step is launch- and host-bound — 5 ms of ~300 launches on a shared host — and a block of twenty
+        # round 5's forward), after 1.5 s of untimed steps; the MEDIAN of each three.  (A 512-ray step is launch- and host-bound — 5 ms of ~300 launches on a shared host — and a block of twenty
         # 4 096-ray steps lasts 0.4 s, inside the clock transients of a power-bound chip: single repetitions scatter by 30 %, and the second thing timed sees a warmer
         # chip than the first — hence the alternation.)
         dts, dts_all = [], []
@@ -348,7 +352,7 @@ def train_bench(args):
             step(train_lists=0)
             dts_all.append(timed(train_lists=0)[0])
             step()
-        dt = min(dts)
+        dt = sorted(dts)[1]                               # the median of the three
         # the same step in three parts (untimed extra steps)
         parts = []
         for _ in range(3):
@@ -366,7 +370,7 @@ def train_bench(args):
         ts = r.training_state()
         by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": 1e3 * pm[0], "loss_backward_ms": 1e3 * pm[1], "adam_ms": 1e3 * pm[2],
                            "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "ms_per_step_repetitions": [1e3 * v for v in dts],
-                           "ms_per_step_every_sample": 1e3 * min(dts_all), "ms_per_step_every_sample_repetitions": [1e3 * v for v in dts_all],
+                           "ms_per_step_every_sample": 1e3 * sorted(dts_all)[1], "ms_per_step_every_sample_repetitions": [1e3 * v for v in dts_all],
                            "route": None if ts is None else {k: ts[k] for k in ("step", "measured", "events", "near_misses")},
                            "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
                            "skipped_steps": int(getattr(r, "skipped_steps", 0)), "range_fallbacks": int(r.range_fallbacks),
