@@ -1963,7 +1963,7 @@ static int run_reflected_query(iblnerf_ctx* c, hipStream_t s, int which, long R,
 
 // One raw2outputs pass (ibl_nerf_renderer.py:153-527) over R rays of the current launch.
 // zc / zc_stride: z_vals_constant, the coarse grid the reflected ray is sampled on (one shared row, or per-ray rows under perturb).
-// keep_all_rows: a tapped call (a training step's forward: the backward reads every raw row) — its main queries evaluate every sample.
+// keep_all_rows: a tapped call whose backward reads every raw row (a training step's forward without iblnerf_set_tapped_lists) — its main queries evaluate every sample.
 static int full_pass(iblnerf_ctx* c, hipStream_t s, int which, int kind, const float* ro, const float* rd, long R, const float* z,
                      int z_stride, int S, float* weights, float near_, float far_, const OverrideArgs& ov,
                      const PassOutputs& out, const float* zc, int zc_stride, const float* noise,

@@ -1331,8 +1331,9 @@ class Renderer:
             if img.shape[1] == 1:
                 gt_values = dict(gt_values, _edit_roughness_resolved=resolve_edit_roughness(m, img[:, 0], chunk))
         if eager:
-            # (a training step's context — lazy, sampled, tapped — keeps the FAST table and holds no route: its renders are stochastic, its weights change every step,
-            # and a lazy context never reads the tripwire: ADVICE r5)
+            # (a training step's context — lazy, sampled, tapped — keeps the FAST table and takes no decision per call: its renders are stochastic and its weights change
+            # every step.  It holds a route only under training_lists — measured every so many steps, the tripwire read from the flag snapshot; otherwise none, since
+            # a lazy context that never looks at the tripwire must not drop samples: ADVICE r5)
             decided_maps = None
             for attempt in (0, 1):
                 try:

@@ -779,6 +779,48 @@ def test_training_steps_under_a_route_follow_the_every_sample_steps(G, lut):
     assert max(abs(x - y) / abs(x) for x, y in zip(la, lb)) <= 2e-2, [(x, y) for x, y in zip(la, lb)][::8]
 
 
+def test_a_stale_training_route_is_caught_by_the_tripwire(G, lut):
+    """The weights move between two measurements of a training route.  Built to the extreme: the route measured on the fitted coarse network (plain-f16 estimates,
+    margin 2) left in place for a step on a network that breaks plain-f16 estimates (test_gpu_fitted.cancelling_network).  That step's list launches raise the
+    tripwire (an audited drop that was not empty); nothing synchronises — the NEXT step sees the event in the flag snapshot, withdraws the route and measures it again
+    on the weights as they are (plain-f16 estimates refused), and runs clean."""
+    import test_gpu_fitted as TF
+    import train_loss as TL
+    from conftest import load_golden
+    from torch_ref import RefShaped
+    from ibl_nerf_amd import renderer as R
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    n = 4096
+    rays = _step_rays(n)
+    tg = {k: torch.from_numpy(v).cuda() for k, v in TL.targets(np.random.RandomState(3), n).items()}
+    nets, kw, K, _ = _setup(G, lut, "full")
+    kw = dict(kw, pytest=True, max_rays_per_launch=4096)
+    res = R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    r = R.renderer_for(dict(kw, _lazy_range_check=True))
+    good = dict(r.training_state()["route"])
+    assert good["estimates_plain_f16"] == [True, True] and r.training_state()["events"] == 0
+    bad = RefShaped({k: torch.from_numpy(v) for k, v in TF.cancelling_network(g, sdc).items()}).cuda()
+    bad.coarse_radiance_number = 3
+    kw = dict(kw, network_fn=bad)
+    before = r.training_state()
+    res = R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)       # the stale route, one step
+    assert r.training_state()["measured"] == before["measured"] and r.route["estimates_plain_f16"] == [True, True]
+    torch.cuda.synchronize()
+    res = R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)       # the event is seen, the route measured again
+    st = r.training_state()
+    assert st["events"] == 1 and st["measured"] == before["measured"] + 1, st
+    assert not st["route"]["estimates_plain_f16"][0] or st["route"]["tripped"] >= 1 or st["route"]["select_margin"][0] > good["select_margin"][0], st["route"]
+    TL.total_loss(torch, res, tg, True).backward()
+    torch.cuda.synchronize()
+    R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
+    assert r.training_state()["events"] == 1 and not r.check_range()
+    # ... and the step after the event matches the every-sample step on the direct maps
+    ref = R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **dict(kw, train_lists=0))
+    for k in ("albedo_map", "depth_map", "acc_map", "depth_map0"):
+        d = (res[k].detach() - ref[k].detach()).abs().reshape(n, -1).amax(-1) / float(ref[k].detach().abs().max())
+        assert float(torch.quantile(d, 0.99)) <= 1e-4 and int((d > 1e-3).sum()) <= 6, (k, float(d.max()))
+
+
 def test_training_step_is_the_same_on_both_shading_backwards(G, lut):
     """The fused shading backward against the autograd one inside a whole step: every parameter gradient of both networks."""
     import train_loss as TL
