@@ -349,13 +349,15 @@ def train_bench(args):
         for _ in range(3):
             dt_, loss = timed()
             dts.append(dt_)
+            if args.no_extras:                            # (a profiling run: the default path's kernels only)
+                continue
             step(train_lists=0)
             dts_all.append(timed(train_lists=0)[0])
             step()
         dt = sorted(dts)[1]                               # the median of the three
         # the same step in three parts (untimed extra steps)
         parts = []
-        for _ in range(3):
+        for _ in range(0 if args.no_extras else 3):
             torch.cuda.synchronize(); a = time.perf_counter()
             res = R.render_decomp(H, W, K, chunk=n, rays=rays, gt_values={}, approximate_radiance=True, **kw)
             torch.cuda.synchronize(); b = time.perf_counter()
@@ -364,13 +366,13 @@ def train_bench(args):
             opt.step()
             torch.cuda.synchronize(); e = time.perf_counter()
             parts.append((b - a, c - b, e - c))
-        pm = np.array(parts).min(0)
+        pm = np.array(parts).min(0) if parts else [None] * 3
         r = R.renderer_for(dict(kw, _lazy_range_check=True))
         f_step = F_ALG_PER_RAY + F_TRAIN_BWD_PER_RAY
         ts = r.training_state()
-        by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": 1e3 * pm[0], "loss_backward_ms": 1e3 * pm[1], "adam_ms": 1e3 * pm[2],
+        by_rays[str(n)] = {"rays_per_s": n / dt, "ms_per_step": 1e3 * dt, "render_ms": pm[0] and 1e3 * pm[0], "loss_backward_ms": pm[1] and 1e3 * pm[1], "adam_ms": pm[2] and 1e3 * pm[2],
                            "frac": n / dt * f_step / 1e12 / PEAK_BF16_TFLOPS, "ms_per_step_repetitions": [1e3 * v for v in dts],
-                           "ms_per_step_every_sample": 1e3 * sorted(dts_all)[1], "ms_per_step_every_sample_repetitions": [1e3 * v for v in dts_all],
+                           "ms_per_step_every_sample": 1e3 * sorted(dts_all)[1] if dts_all else None, "ms_per_step_every_sample_repetitions": [1e3 * v for v in dts_all],
                            "route": None if ts is None else {k: ts[k] for k in ("step", "measured", "events", "near_misses")},
                            "loss_first": float(l0.detach()), "loss_last": float(loss.detach()),
                            "skipped_steps": int(getattr(r, "skipped_steps", 0)), "range_fallbacks": int(r.range_fallbacks),
