@@ -779,6 +779,61 @@ def test_training_steps_under_a_route_follow_the_every_sample_steps(G, lut):
     assert max(abs(x - y) / abs(x) for x, y in zip(la, lb)) <= 2e-2, [(x, y) for x, y in zip(la, lb)][::8]
 
 
+@pytest.mark.parametrize("variant", ["noise", "aux", "incident", "from_gt"])
+def test_training_steps_under_a_route_on_the_step_variants(G, lut, variant):
+    """The variants of a training step that the reference's fixtures pin at 64 rays (too few for a route), at 2 048 rays under a route against the same step on every
+    sample: density noise (raw_noise_std = 1: the selection judges estimate + noise), the four auxiliary networks (their columns replace the main network's; they
+    are trained), the incident-radiance gradient (the reflected ray's query carries a gradient) and a ground-truth substitution."""
+    import train_loss as TL
+    from torch_ref import AuxShaped
+    from ibl_nerf_amd import renderer as R, checkpoint as ck
+    n = 2048
+    rays = _step_rays(n)
+    rng = np.random.RandomState(11)
+    tg = {k: torch.from_numpy(v).cuda() for k, v in TL.targets(rng, n).items()}
+    gt_albedo = torch.from_numpy(rng.uniform(0.1, 0.9, (n, 3)).astype(np.float32)).cuda()
+    out = {}
+    for label, every in (("all", 0), ("lists", 64)):
+        nets, kw, K, _ = _setup(G, lut, "full")
+        kw = dict(kw, pytest=True, train_lists=every, max_rays_per_launch=4096)
+        gt_values, mods = {}, list(zip(("c", "f"), nets))
+        if variant == "noise":
+            kw["raw_noise_std"] = 1.0
+        elif variant == "aux":
+            aux = {name: AuxShaped(ck.AUX_OUT_CH[name], ck.synthetic_position_mlp(40 + i, ck.AUX_OUT_CH[name], 1.0)).cuda()
+                   for i, name in enumerate(("albedo_mlp", "irradiance_mlp", "normal_mlp", "roughness_mlp"))}
+            kw.update(aux, infer_normal=True)
+            mods += sorted(aux.items())
+        elif variant == "incident":
+            kw["use_gradient_for_incident_radiance"] = True
+        else:
+            kw["calculate_albedo_from_gt"] = True
+            gt_values = {"albedo": gt_albedo}
+        res = R.render_decomp(800, 800, K, chunk=n, rays=rays, gt_values=gt_values, approximate_radiance=True, **kw)
+        r = R.renderer_for(dict(kw, _lazy_range_check=True))
+        sel = r.last_selection()
+        loss = TL.total_loss(torch, res, tg, True)
+        loss.backward()
+        assert not r.check_range()
+        out[label] = dict(loss=float(loss.detach()), sel=sel, state=r.training_state(), res={k: v.detach().clone() for k, v in res.items()},
+                          grads={t + "." + k: p.grad.clone() for t, net in mods for k, p in net.named_parameters() if p.grad is not None})
+    a, b = out["all"], out["lists"]
+    assert a["state"] is None and b["state"]["measured"] == 1 and b["state"]["events"] == 0 and 0 < b["sel"][0] < 0.6 * b["sel"][1], (b["state"], b["sel"])
+    assert abs(a["loss"] - b["loss"]) <= 1e-4 * abs(a["loss"]), (a["loss"], b["loss"])
+    stats = {}
+    for k in ("albedo_map", "roughness_map", "irradiance_map", "depth_map", "acc_map", "albedo_map0", "depth_map0"):
+        d = (a["res"][k] - b["res"][k]).abs().reshape(n, -1).amax(-1) / max(float(a["res"][k].abs().max()), 1e-12)
+        stats[k] = (round(float(torch.quantile(d, 0.99)), 7), int((d > 1e-3).sum()), round(float(d.max()), 5))
+    assert all(v[0] <= 1e-4 and v[1] <= 4 for v in stats.values()), stats
+    assert set(a["grads"]) == set(b["grads"]) and len(a["grads"]) >= 80
+    worst = {k: float((a["grads"][k] - b["grads"][k]).abs().max()) / max(float(a["grads"][k].abs().max()), 1e-30) for k in a["grads"]}
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    # (one hidden unit's ReLU pass bit on a heavy sample of a reflected ray — whose direction hangs on the normal, which differs by 7e-5 between the two routes — puts
+    # that sample's whole contribution into one bias entry and one weight row: measured 3.2e-3 on f.positions_linears.2 under the incident gradient; cf. the
+    # auxiliary-network test above)
+    assert len(bad) <= (2 if variant == "incident" else 0) and all(v <= 1e-2 for v in bad.values()), (bad, stats)
+
+
 def test_a_stale_training_route_is_caught_by_the_tripwire(G, lut):
     """The weights move between two measurements of a training route.  Built to the extreme: the route measured on the fitted coarse network (plain-f16 estimates,
     margin 2) left in place for a step on a network that breaks plain-f16 estimates (test_gpu_fitted.cancelling_network).  That step's list launches raise the
