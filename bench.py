@@ -426,6 +426,8 @@ def main():
     ap.add_argument("--train-rays", default="512,1024,4096", help="--train: ray counts of the steps timed")
     ap.add_argument("--train-headline", type=int, default=4096, help="--train: the ray count `value` is quoted on (the reference's default N_rand)")
     ap.add_argument("--query-routing", default="", help="comma-separated iblnerf_options.query_routing names (A/B measurements, e.g. point_batch)")
+    ap.add_argument("--single-stream", action="store_true", help="render every call on one context and one stream (Renderer.pair_streams = False): profiling runs, "
+                                                                 "whose per-kernel durations should not include another stream's kernels")
     args = ap.parse_args()
     routing = [n for n in args.query_routing.split(",") if n]
     if args.train:
@@ -474,6 +476,7 @@ def main():
     r.load_weights(0, sdc)
     r.load_weights(1, sdf)
     r.load_lut(lut)
+    r.pair_streams = not args.single_stream
     # What a frame is rendered under — its ROUTE (which queries run as estimate + list, on which estimates: Renderer._measure_route) and, for mlp_precision="auto",
     # its precision table (FAST / SAFE: Renderer._measure_table) — is measured PER FRAME since round 6, inside the render call and inside the timed region, on 4 096
     # seeded pixels of the whole frame (the same on every rank: `probe`): the answer depends on the camera, so a view must not inherit another view's.
@@ -524,7 +527,7 @@ def main():
         r2.load_weights(0, sdc)
         r2.load_weights(1, sdf)
         r2.load_lut(lut)
-        r2.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+        r2.render_rays(ro, rd, NEAR, FAR, probe=probe)           # (one untimed frame: allocations, code objects, the second context of the stream pair)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         r2.render_rays(ro, rd, NEAR, FAR, probe=probe)
@@ -532,7 +535,7 @@ def main():
         value_min = H * W / (time.perf_counter() - t1)
         del r2
 
-    # the same frame in the other product schemes, one frame each after a 65 536-ray warm-up — reported as extras, never as `value`
+    # the same frame in the other product schemes, one frame each after one untimed frame — reported as extras, never as `value`
     by_precision = {}
     if world == 1 and args.mlp_precision == "auto" and not args.inference_min and not args.no_extras:
         for mode in ("f16x3_mxfp6x", "f16x3_mxfp6", "f16_mxfp6"):
@@ -540,7 +543,7 @@ def main():
             r3.load_weights(0, sdc)
             r3.load_weights(1, sdf)
             r3.load_lut(lut)
-            r3.render_rays(ro[:65536], rd[:65536], NEAR, FAR)
+            r3.render_rays(ro, rd, NEAR, FAR, probe=probe)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             r3.render_rays(ro, rd, NEAR, FAR, probe=probe)
@@ -559,14 +562,16 @@ def main():
             r4.load_weights(0, c4)
             r4.load_weights(1, f4)
             r4.load_lut(lut)
-            r4.render_rays(ro, rd, NEAR, FAR, probe=probe)          # (one untimed frame: allocations, code objects)
+            for _ in range(2):                                      # (two untimed frames: allocations, code objects; a checkpoint that answers an f16 range event by
+                r4.render_rays(ro, rd, NEAR, FAR, probe=probe)      # rescaling does so in the first, and builds the second context of its stream pair in the second)
             torch.cuda.synchronize()
             trips0 = r4.trips
             t1 = time.perf_counter()
             r4.render_rays(ro, rd, NEAR, FAR, probe=probe)          # the frame as every frame is rendered: its own decision, its own tripped rays repeated
             torch.cuda.synchronize()
             by_checkpoint[kind] = {"value": H * W / (time.perf_counter() - t1), "decision": (r4.policy or {}).get("decision"), "route": r4.get_route(),
-                                   "rays_repeated_by_the_tripwire": r4.trips - trips0, "probe_escalations": (r4.route or {}).get("probe_escalations")}
+                                   "rays_repeated_by_the_tripwire": r4.trips - trips0, "probe_escalations": (r4.route or {}).get("probe_escalations"),
+                                   "streams": 2 if r4._pair is not None else 1}
             del r4
 
     # the balance of an 8-rank frame on ONE GPU: each of the 8 contiguous bands and each of the 8 interleaved row sets of the frame rendered by itself
@@ -599,6 +604,9 @@ def main():
     torch.cuda.synchronize()
     decision_ms = 1e3 * (time.perf_counter() - t1)
     policy = r.policy
+    # (the profiled frame on ONE stream: the per-launch durations behind frac_mlp_only / executed / avg_launch_ms are then those of kernels running alone, comparable
+    # with the rocprofv3 summaries; the timed frames above ran their two halves on two streams unless --single-stream)
+    paired, r.pair_streams = r.pair_streams, False
     r.set_profiling(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if grouped else None
     trips_before = r.trips
@@ -610,6 +618,7 @@ def main():
     mlp_ms, n_launch, flop = r.last_mlp_time()
     flop_executed, selection, slot_units = r.last_executed_flops(), r.last_selection(), r.last_slot_units()
     r.set_profiling(False)
+    r.pair_streams = paired
     # the exchange step on its own (same untimed extra step; events on torch's current stream, where pack and all-gather are enqueued):
     # packing the export maps into one buffer, and the all-gather (host-staged under the gloo test hook)
     pack_ms = ev[0].elapsed_time(ev[1]) if grouped else None
@@ -636,7 +645,8 @@ def main():
                        "checkpoint": args.checkpoint, "rays_per_frame": H * W, "rays_per_launch": args.rays_per_launch,
                        "mlp_precision": args.mlp_precision, "policy": policy, "route": r.get_route(), "route_table": r.describe_route().splitlines(),
                        "decision_scope": "per frame, inside the timed step: route + precision table measured on 4 096 seeded pixels of the frame (the same on every rank)",
-                       "decision_ms_per_frame": decision_ms, "partition": args.partition, "rays_repeated_by_the_tripwire": r.trips, "probe_escalations": r.probe_escalations,
+                       "decision_ms_per_frame": decision_ms, "partition": args.partition,
+                       "streams": 2 if (r.pair_streams and H * W // world >= R.Renderer.PAIR_MIN_RAYS) else 1, "rays_repeated_by_the_tripwire": r.trips, "probe_escalations": r.probe_escalations,
                        **({"query_routing": routing} if routing else {}),
                        "parallelism": ("ray-tile x%d + %s all-gather" % (world, "RCCL" if backend == "nccl" else backend))
                                       if grouped else "single GPU"},

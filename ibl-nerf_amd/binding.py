@@ -25,7 +25,7 @@ EXPORTS = [
     "iblnerf_coarse_z", "iblnerf_sample_points", "iblnerf_fine_z", "iblnerf_composite_sigma", "iblnerf_render_rays_tapped",
     "iblnerf_ray_outputs_backward", "iblnerf_range_flags_async", "iblnerf_set_query_routing", "iblnerf_layer_ranges", "iblnerf_last_selection",
     "iblnerf_last_executed_flops", "iblnerf_estimate_policy", "iblnerf_ray_outputs_backward_gt", "iblnerf_ray_outputs_backward_rays", "iblnerf_coarse_z_rays", "iblnerf_aux_query", "iblnerf_aux_backward", "iblnerf_ray_outputs_backward_env", "iblnerf_set_select_tmin", "iblnerf_set_chunk_cuts",
-    "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_describe_route", "iblnerf_last_slot_units", "iblnerf_trunk_density_fp32", "iblnerf_set_offset_tier_threshold",
+    "iblnerf_decide_route", "iblnerf_set_route", "iblnerf_get_route", "iblnerf_copy_route", "iblnerf_describe_route", "iblnerf_last_slot_units", "iblnerf_trunk_density_fp32", "iblnerf_set_offset_tier_threshold",
     "iblnerf_escalate_route", "iblnerf_set_lists", "iblnerf_set_tapped_lists", "iblnerf_get_rays_strided", "iblnerf_get_rays_pixels", "iblnerf_set_tier_thresholds", "iblnerf_decide_route_outputs", "iblnerf_upload_weights_arch",
 ]
 
@@ -156,6 +156,8 @@ def load_library(path: str = LIB_PATH):
     lib.iblnerf_set_route.restype = C.c_int
     lib.iblnerf_get_route.argtypes = [C.c_void_p, C.POINTER(Route)]
     lib.iblnerf_get_route.restype = C.c_int
+    lib.iblnerf_copy_route.argtypes = [C.c_void_p, C.c_void_p]
+    lib.iblnerf_copy_route.restype = C.c_int
     lib.iblnerf_describe_route.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.iblnerf_describe_route.restype = C.c_int
     lib.iblnerf_set_tier_thresholds.argtypes = [C.c_void_p, C.c_float, C.c_float]

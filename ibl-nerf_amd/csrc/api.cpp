@@ -2366,6 +2366,21 @@ int iblnerf_get_route(iblnerf_ctx* c, iblnerf_route* out) {
     return IBLNERF_OK;
 }
 
+int iblnerf_copy_route(iblnerf_ctx* dst, const iblnerf_ctx* src) {
+    if (!dst || !src) return IBLNERF_ERR_INVALID;
+    // the route exactly as `src` holds it, ladder steps included (iblnerf_set_route of iblnerf_get_route's struct would lose them: a margin doubled by
+    // iblnerf_escalate_route keeps its plain-f16 estimates, a route imposed with tripped = 1 does not)
+    dst->route_decided = src->route_decided;
+    dst->tripped = src->tripped;
+    dst->sel_decided = src->sel_decided; dst->sel_on = src->sel_on; dst->coarse_share = src->coarse_share;
+    dst->fsel_fraction = src->fsel_fraction; dst->xsel_fraction = src->xsel_fraction;
+    for (int w = 0; w < 2; ++w) {
+        dst->est_checked[w] = src->est_checked[w]; dst->est_ok[w] = src->est_ok[w];
+        dst->margin[w] = src->margin[w]; dst->est_error[w] = src->est_error[w];
+    }
+    return IBLNERF_OK;
+}
+
 int iblnerf_set_route(iblnerf_ctx* c, const iblnerf_route* r) {
     if (!c || !r) return IBLNERF_ERR_INVALID;
     reset_route(c, 0);

@@ -61,6 +61,9 @@ def _dev_f32(x, device):
     return x.to(device=device, dtype=torch.float32).contiguous()
 
 
+_PAIR_STREAMS = {}       # device index -> the two streams of Renderer._render_pair
+
+
 class _RangeEvent(Exception):
     """A probe render left the f16 range (Renderer._decide_for_call): answered by render_rays before anything is decided."""
 
@@ -146,6 +149,8 @@ class Renderer:
         self.range_rescales = 0
         self._depth_mlp = None
         self._wide = None            # bf16x3 twin, created on the first out-of-range event
+        self._pair = None            # the second context of _render_pair (a frame-sized call's other half, on its own stream), created on first use
+        self._pair_last = False      # the last eager call was rendered on the pair (the per-call counters below add the twin's)
         self._twin_ref = None        # (mode, Renderer) of precision_report
         self._blobs, self._lut = {}, None
         self._generic = {}           # network slot -> (D, W, multires, multires_views) of a network on the layer-by-layer path (outside the built architecture)
@@ -185,6 +190,7 @@ class Renderer:
         on the device (one torch.cat + one pack kernel on the current stream: no host copy, no synchronisation);
         anything else goes through the host packer."""
         self._act_scale.pop(int(which), None)        # the caller's own weights: any range rescaling of the previous ones is gone
+        self._pair = None                            # (built again from the new weights by the next frame-sized call)
         self._upload(which, state_dict_or_blob, remember=True)
 
     def _upload(self, which, state_dict_or_blob, remember):
@@ -250,6 +256,7 @@ class Renderer:
                 blob = np.ascontiguousarray(ck.aux_channel_blob(sd, ch), dtype=np.float32)
                 B.check(self.ctx, self.lib.iblnerf_upload_aux_weights(self.ctx, kind, ch, blob.ctypes.data, blob.size))
         self._aux[name] = state_dict
+        self._pair = None
         if self._wide is not None:
             self._wide.load_aux(name, state_dict)
 
@@ -263,6 +270,7 @@ class Renderer:
             out_ch = int(ck._to_numpy(state_dict["final_linear.bias"]).shape[0])
             B.check(self.ctx, self.lib.iblnerf_upload_posdir_mlp(self.ctx, blob.ctypes.data, blob.size, out_ch))
         self._depth_mlp = state_dict
+        self._pair = None
         if self._wide is not None:
             self._wide.load_depth_mlp(state_dict)
 
@@ -286,6 +294,7 @@ class Renderer:
         if lut.shape != (3, 512, 512):
             raise ValueError("brdf_lut must have shape [3,512,512], got %s" % (lut.shape,))
         B.check(self.ctx, self.lib.iblnerf_upload_lut(self.ctx, lut.ctypes.data))
+        self._pair = None
         if self.mlp_precision != "bf16x3":
             self._lut = lut
             if self._wide is not None:
@@ -343,6 +352,7 @@ class Renderer:
             if t != self._act_scale.get(which, {}) and t:
                 self._upload(which, ck.scale_activations(sd, t, ci), remember=False)
                 self._act_scale[which] = t
+                self._pair = None                    # (the twin of _render_pair is built again, from the rescaled networks)
                 changed = True
         if changed:
             self.range_rescales += 1
@@ -590,7 +600,7 @@ class Renderer:
         """Matrix-slot units of the last render_rays call's MLP launches (iblnerf_last_slot_units; synchronises)."""
         v = C.c_double()
         B.check(self.ctx, self.lib.iblnerf_last_slot_units(self.ctx, C.byref(v)))
-        return float(v.value)
+        return float(v.value) + (self._pair.last_slot_units() if self._pair_last and self._pair is not None else 0.0)      # (a call rendered on the pair: both halves)
 
     def _route_possible(self, n):
         return self.mlp_precision != "bf16x3" and n >= self.ROUTE_MIN_RAYS and int(self.opt.max_rays_per_launch) >= self.ROUTE_MIN_RAYS
@@ -819,6 +829,9 @@ class Renderer:
         grid's offset copies, the reflected rays), how many were evaluated there (synchronises)."""
         a, b = C.c_int64(), C.c_int64()
         B.check(self.ctx, self.lib.iblnerf_last_selection(self.ctx, C.byref(a), C.byref(b)))
+        if self._pair_last and self._pair is not None:      # (a call rendered on the pair: both halves)
+            a2, b2 = self._pair.last_selection()
+            return int(a.value) + a2, int(b.value) + b2
         return int(a.value), int(b.value)
 
     def estimate_policy(self, which=0):
@@ -833,16 +846,22 @@ class Renderer:
         last_mlp_time()'s algorithmic count, which prices every sample of every query as the reference evaluates it."""
         v = C.c_double()
         B.check(self.ctx, self.lib.iblnerf_last_executed_flops(self.ctx, C.byref(v)))
-        return float(v.value)
+        return float(v.value) + (self._pair.last_executed_flops() if self._pair_last and self._pair is not None else 0.0)
 
     def set_profiling(self, on):
         B.check(self.ctx, self.lib.iblnerf_set_profiling(self.ctx, int(bool(on))))
+        self._profiling = bool(on)
+        if self._pair is not None:
+            self._pair.set_profiling(on)
 
     def last_mlp_time(self):
         """(ms of MLP kernels in the last render_rays call, launches, algorithmic FLOPs) — HIP events
         recorded on the launch stream."""
         ms, n, fl = C.c_float(), C.c_int(), C.c_double()
         B.check(self.ctx, self.lib.iblnerf_last_mlp_time(self.ctx, C.byref(ms), C.byref(n), C.byref(fl)))
+        if self._pair_last and self._pair is not None:      # (a call rendered on the pair: the sum of both halves' launch durations — they overlap in time)
+            ms2, n2, fl2 = self._pair.last_mlp_time()
+            return ms.value + ms2, n.value + n2, fl.value + fl2
         return ms.value, n.value, fl.value
 
     def _stream(self):
@@ -1356,8 +1375,12 @@ class Renderer:
         if eager and decided_maps is not None:
             return decided_maps
         want_trips = eager and self._c_route
-        res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
-                                       taps=taps, noise=noise, _retry=_retry, want_trips=want_trips)
+        if eager and _retry is not True:
+            res, bits, trip = self._render_call(rays_o, rays_d, near, far, gt_values, edit, chunk=chunk, want_trips=want_trips)
+        else:
+            self._pair_last = False
+            res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, perturb=perturb, pytest=pytest, chunk=chunk, raw_noise_std=raw_noise_std, draws=draws,
+                                           taps=taps, noise=noise, _retry=_retry, want_trips=want_trips)
         if want_trips:
             # The estimate tripwire: a list launch of this call refined a positive density whose estimate was half-way to dropping it (or overshot past the conservative
             # transmittance's allowance) on the rays marked in `trip`.  They are rendered once more with every sample evaluated (iblnerf_set_lists 0) and their rows
@@ -1385,7 +1408,7 @@ class Renderer:
                     self.trip_bits = getattr(self, "trip_bits", 0) | allbits
                     self.route = dict(self.get_route(), **{k: v for k, v in (self.route or {}).items() if k in ("imposed", "probe_rays", "probe_escalations")}, alarms=steps)
                 if live:
-                    res, bits, trip = self._render(rays_o, rays_d, near, far, gt_values, edit, chunk=chunk, want_trips=True)
+                    res, bits, trip = self._render_call(rays_o, rays_d, near, far, gt_values, edit, chunk=chunk, want_trips=True)
             if live and idx.numel() and bits & TRIP_BITS:
                 pn, pf = self._plane_args(near, far, n)
                 sub_gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[idx] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
@@ -1411,6 +1434,95 @@ class Renderer:
             self.trips += int(n)
             self.trip_bits = getattr(self, "trip_bits", 0) | (bits & TRIP_BITS)
         return res
+
+    # ---- two halves of a frame-sized call on two contexts and two HIP streams (round 6) -------------------------------------------------------
+    # A launch set is a chain of ~75 kernels on one stream: matrix kernels that fill the chip (one wave per SIMD, most of the LDS) alternating with per-ray kernels
+    # (selection, lists, compositing: 6.6 % of GPU time, bound by latency at low occupancy) and the ragged tail of every launch.  Two launch sets are independent — but
+    # share the context's workspace, so they run one after the other.  On a SECOND context (its own workspace and weight streams: +10 GB at 327 680 rays per launch)
+    # and a second stream, one half's per-ray kernels and tails run in the wave slots the other half's matrix kernels leave free: 1 033.5 -> 995 ms per frame
+    # (scratch/two_streams.py; three or four streams: 1 003 - 1 010), every map bit for bit (a ray's result does not depend on the launch it is rendered in).
+    PAIR_MIN_RAYS = 131072
+    pair_streams = True          # (instance or class attribute: False = one context, one stream, as before)
+
+    def _pair_twin(self):
+        torch = _torch()
+        if self._pair is None:
+            t = Renderer(mlp_precision="f16x3_mxfp6x" if self._auto else self.mlp_precision, query_routing=self._routing, **self._ctor)
+            t.pair_streams = False
+            ci = bool(self.opt.color_independent_to_direction)
+            for which, blob in self._blobs.items():
+                t.load_weights(which, blob)
+                if self._act_scale.get(which):       # this context answered a range event by rescaling the network (the same function, activations scaled by powers of two)
+                    hb = blob.detach().cpu().numpy() if torch.is_tensor(blob) else blob
+                    sd = ck.blob_to_state_dict(np.ascontiguousarray(hb, dtype=np.float32)) if isinstance(hb, np.ndarray) else hb
+                    t._upload(which, ck.scale_activations(sd, self._act_scale[which], ci), remember=False)
+                    t._act_scale[which] = dict(self._act_scale[which])
+            for name, sd in self._aux.items():
+                if sd is not None:
+                    t.load_aux(name, sd)
+            if self._depth_mlp is not None:
+                t.load_depth_mlp(self._depth_mlp)
+            if self._lut is not None:
+                t.load_lut(self._lut)
+            self._pair = t
+            # one pair of streams per device for every context of the process: HIP deals streams onto a handful of hardware queues, and two streams that land on the
+            # same queue run one after the other — a fresh pair per context did (the fourth context of a process saw no overlap at all)
+            key = self.device.index
+            if key not in _PAIR_STREAMS:
+                _PAIR_STREAMS[key] = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self._pair_s = _PAIR_STREAMS[key]
+            if getattr(self, "_profiling", False):
+                t.set_profiling(True)
+        return self._pair
+
+    def _pairable(self, n):
+        return (self.pair_streams and n >= self.PAIR_MIN_RAYS and not self._force_wide and self.mlp_precision != "bf16x3" and not self._generic
+                and self.range_check == "eager" and set(self._blobs) >= ({0, 1} if self.has_fine else {0}))
+
+    def _render_call(self, rays_o, rays_d, near, far, gt_values, edit, chunk=None, want_trips=False):
+        """An eager call's render under the decisions in effect: _render on this context, or — a frame-sized call — _render_pair."""
+        n = int(rays_o.shape[0])
+        self._pair_last = False
+        if self._pairable(n):
+            out = self._render_pair(rays_o, rays_d, near, far, gt_values, edit, chunk, want_trips)
+            if out is not None:
+                return out
+        return self._render(rays_o, rays_d, near, far, gt_values, edit, chunk=chunk, want_trips=want_trips)
+
+    def _render_pair(self, rays_o, rays_d, near, far, gt_values, edit, chunk, want_trips):
+        """The call's two halves on this context and its twin, each on a stream of its own, under ONE decision (iblnerf_copy_route, the same routing bits); the flags
+        of both are read once both are done.  None = a range event (an activation left the f16 range): the caller renders the call on this context alone, where such
+        events are answered."""
+        torch = _torch()
+        n = int(rays_o.shape[0])
+        tw = self._pair_twin()
+        B.check(tw.ctx, self.lib.iblnerf_copy_route(tw.ctx, self.ctx))
+        tw._c_route = self._c_route
+        tw._set_routing(getattr(self, "_routing_extra", 0))
+        pn, pf = self._plane_args(near, far, n)
+        h = n // 2
+        main = torch.cuda.current_stream()
+        halves = []
+        for r_, st, sl in ((self, self._pair_s[0], slice(0, h)), (tw, self._pair_s[1], slice(h, n))):
+            m = sl.stop - sl.start
+            sub_gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[sl] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
+            st.wait_stream(main)                     # (the rays and override rows were produced on the caller's stream)
+            with torch.cuda.stream(st):
+                halves.append(r_._render(rays_o[sl], rays_d[sl], pn[sl].contiguous() if torch.is_tensor(pn) else pn, pf[sl].contiguous() if torch.is_tensor(pf) else pf,
+                                         sub_gt, edit, chunk=chunk, want_trips=want_trips, defer_flags=True))
+            assert halves[-1][0]["depth_map"].shape[0] == m
+        for st in self._pair_s:
+            main.wait_stream(st)
+        bits = self.range_bits() | tw.range_bits()          # (one device synchronisation: both halves are done)
+        if bits & 1:
+            return None
+        for res_, _, trip_ in halves:                       # (allocated on the side streams, consumed on the caller's)
+            for v in list(res_.values()) + ([trip_] if trip_ is not None else []):
+                v.record_stream(main)
+        res = {k: torch.cat([halves[0][0][k], halves[1][0][k]]) for k in halves[0][0]}
+        trip = torch.cat([halves[0][2], halves[1][2]]) if halves[0][2] is not None else None
+        self._pair_last = True
+        return res, bits, trip
 
     def _rescale_on(self, rays_o, rays_d, planes):
         """A range event on these rays: rescale the networks into the f16 range by measurement on the coarse grid's points of (up to) 1 024 of them — where both networks
@@ -1440,7 +1552,7 @@ class Renderer:
         return float(near), float(far)
 
     def _render(self, rays_o, rays_d, near, far, gt_values, edit, perturb=0., pytest=False, chunk=None, raw_noise_std=0., draws=None, taps=None, noise=None, _retry=False,
-                want_trips=False, on_range="answer", decide=None):
+                want_trips=False, on_range="answer", decide=None, defer_flags=False):
         """One iblnerf_render_rays_tapped under whatever route / table / list switch the context holds -> (result dict, range bits, trip map or None).  Range events
         (bit 0: an activation left the f16 range) are answered here — the network rescaled into range, or the call repeated on the bf16x3 twin — through render_rays."""
         torch = _torch()
@@ -1512,7 +1624,7 @@ class Renderer:
                                                                   C.byref(smp) if smp is not None else None, C.byref(outs),
                                                                   C.byref(taps) if taps is not None else None))
         self._keep = keep   # override rows must outlive the asynchronous launch
-        bits = 0 if lazy else self.range_bits()
+        bits = 0 if (lazy or defer_flags) else self.range_bits()          # (defer_flags: _render_pair reads both contexts' flags once both halves are issued)
         if bits & 1 and on_range == "raise":
             raise _RangeEvent()
         if bits & 1 and on_range == "answer":

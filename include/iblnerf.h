@@ -197,6 +197,10 @@ int iblnerf_decide_route(iblnerf_ctx* ctx, void* stream, const float* d_rays_o, 
 /* Imposes a route (e.g. the one another rank or an earlier run decided); decided = 0 withdraws it. */
 int iblnerf_set_route(iblnerf_ctx* ctx, const iblnerf_route* route);
 int iblnerf_get_route(iblnerf_ctx* ctx, iblnerf_route* out);
+/* The route of `src` onto `dst`, exactly — ladder steps included (a margin iblnerf_escalate_route doubled keeps its plain-f16 estimates; iblnerf_set_route of the
+ * struct iblnerf_get_route fills would not).  For two contexts of one checkpoint that render two halves of one call on two HIP streams (ibl-nerf_amd/renderer.py
+ * _render_pair: one half's per-ray kernels and launch tails run under the other half's matrix kernels, 3.7 % of a frame): both halves under one decision. */
+int iblnerf_copy_route(iblnerf_ctx* dst, const iblnerf_ctx* src);
 /* The tripwire's bits in iblnerf_range_status: 4 (bit 2) a refined sample's density is positive and its estimate lay below -margin / 2 — a near miss; 8 (bit 3) an estimate
  * overshot a density beyond what the conservative transmittance allows for; 16 (bit 4, always with 4) ... below -3 margin / 4: a DEEP miss — the margin is twice the
  * deepest underestimate the probe saw, so the route's error model is off by half again; beyond -margin itself (an AUDITED sample: dropped as clearly empty, and not empty) it

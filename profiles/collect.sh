@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"
+BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --single-stream ${BENCH_ARGS:-}"   # (one stream: a kernel's duration is its own)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 \
     -d "$OUT/pmc_mfma" -o bench -- $BENCH > "$OUT/pmc_mfma.log" 2>&1

@@ -191,3 +191,77 @@ def test_call_sizes_around_the_decision_thresholds(R, lut):
     assert seen[1] == seen[1023] == (None, None, False)
     assert seen[1024] == (1024, None, True) and seen[2047] == (2047, None, True)
     assert seen[2048] == (2048, "fast", True) and seen[4096] == (4096, "fast", True) and seen[4097] == (4096, "fast", True), seen
+
+
+def _big_call(g, copies=10):
+    ro = torch.from_numpy(np.tile(g["rays_o"], (copies, 1))).cuda()
+    rd = torch.from_numpy(np.tile(g["rays_d"], (copies, 1))).cuda()
+    return ro, rd
+
+
+def test_two_halves_on_two_streams_are_the_call(R, lut):
+    """Round 6 (_render_pair): a frame-sized call (>= PAIR_MIN_RAYS rays) is rendered in two halves on two contexts and two HIP streams — one half's per-ray kernels
+    under the other half's matrix kernels — under one decision (iblnerf_copy_route).  163 840 rays of the second checkpoint (the one whose frames trip the
+    tripwire): every map, the per-call counters and the tripped rays against the same call on one context and one stream; and the insert configuration (per-ray
+    override rows follow their rays into the halves)."""
+    g, sdc, sdf, gt, edit = load_golden("fitted2_launch4k")
+    ro, rd = _big_call(g, 40)
+    n = ro.shape[0]
+    assert n >= R.Renderer.PAIR_MIN_RAYS
+    r = make_renderer(R, g, sdc, sdf, lut)
+    r.pair_streams = False
+    nf = (float(g["near"]), float(g["far"]))
+    one = r.render_rays(ro, rd, *nf)
+    sel_one, dec_one, trips_one = r.last_selection(), r.policy["decision"], r.trips
+    assert r._pair is None
+    r.pair_streams = True
+    two = r.render_rays(ro, rd, *nf)
+    assert r._pair is not None and r._pair_last and r.policy["decision"] == dec_one and r.trips == 2 * trips_one
+    assert r.last_selection() == sel_one or trips_one                                    # (with tripped rays the last library call is their repeat)
+    assert _same(one, two)
+    again = r.render_rays(ro, rd, *nf)
+    assert _same(two, again)
+    # per-ray override rows (config 5: an inserted object) are dealt to the halves with their rays
+    gi, sdc_i, sdf_i, gti, editi = load_golden("fitted_insert_cfg5")
+    copies = -(-R.Renderer.PAIR_MIN_RAYS // gi["rays_o"].shape[0])
+    roi, rdi = _big_call(gi, copies)
+    gt_big = {k: (np.tile(v, (copies,) + (1,) * (np.ndim(v) - 1)) if hasattr(v, "shape") and np.ndim(v) >= 1 and len(v) == gi["rays_o"].shape[0] else v) for k, v in gti.items()}
+    ri = make_renderer(R, gi, sdc_i, sdf_i, lut)
+    ri.pair_streams = False
+    a = ri.render_rays(roi, rdi, float(gi["near"]), float(gi["far"]), gt_big, **editi)
+    ri.pair_streams = True
+    b = ri.render_rays(roi, rdi, float(gi["near"]), float(gi["far"]), gt_big, **editi)
+    assert ri._pair_last and _same(a, b)
+    # new weights: the twin is rebuilt from them
+    ri.load_weights(0, sdc_i)
+    assert ri._pair is None
+
+
+def test_a_range_event_on_the_pair_is_answered_on_one_context(R, lut):
+    """An activation that leaves the f16 range in either half sends the call back to this context alone, where such events are answered (rescaling, or the bf16x3
+    twin) — here the event is injected (the flag read of the pair reports bit 0 once)."""
+    g, sdc, sdf, _, _ = load_golden("fitted_launch16k")
+    ro, rd = _big_call(g, 8)
+    r = make_renderer(R, g, sdc, sdf, lut)
+    ref = r.render_rays(ro, rd, 0.5, 8.0)
+    assert r._pair_last
+    orig, fired = r.range_bits, []
+
+    def once():
+        bits = orig()
+        if r._pair is not None and not fired and getattr(r, "_in_pair", False):
+            fired.append(1)
+            return bits | 1
+        return bits
+    r.range_bits = once
+    orig_pair = r._render_pair
+
+    def pair(*a, **k):
+        r._in_pair = True
+        try:
+            return orig_pair(*a, **k)
+        finally:
+            r._in_pair = False
+    r._render_pair = pair
+    got = r.render_rays(ro, rd, 0.5, 8.0)
+    assert fired and not r._pair_last and _same(ref, got)
