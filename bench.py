@@ -25,6 +25,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (before the first HIP call of the process: the renderer's two streams need hardware queues of their own beside RCCL's — ibl-nerf_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import _pkg  # noqa: E402
 
 H = W = 800
@@ -455,16 +457,26 @@ def main():
     # same pack + all-gather path (RCCL on device buffers) as the multi-GPU runs; a plain `python bench.py` has no group and no exchange
     grouped = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     if grouped:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        # bring the RCCL communicator (rings over xGMI) up before anything is timed, even with --warmup 0
-        if backend == "nccl":
-            probe = torch.zeros(world * 256, device="cuda")
-            dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
-            del probe
-        dist.barrier()
+        # (RCCL prints its version banner on STDOUT when the communicator comes up; this command's stdout is ONE JSON line: the banner goes to stderr)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            # bring the RCCL communicator (rings over xGMI) up before anything is timed, even with --warmup 0
+            if backend == "nccl":
+                probe = torch.zeros(world * 256, device="cuda")
+                dist.all_gather_into_tensor(probe, torch.ones(256, device="cuda"))
+                torch.cuda.synchronize()
+                del probe
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     pkg = _pkg.load()
     from ibl_nerf_amd import checkpoint as ck, dist as D, renderer as R

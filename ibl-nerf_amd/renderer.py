@@ -1465,8 +1465,9 @@ class Renderer:
             if self._lut is not None:
                 t.load_lut(self._lut)
             self._pair = t
-            # one pair of streams per device for every context of the process: HIP deals streams onto a handful of hardware queues, and two streams that land on the
-            # same queue run one after the other — a fresh pair per context did (the fourth context of a process saw no overlap at all)
+            # one pair of streams per device for every context of the process: HIP deals streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default),
+            # and two streams that land on the same queue run one after the other — a fresh pair per context did (the fourth context of a process saw no overlap at
+            # all), and so does the pair of a process that holds an RCCL communicator unless there are more queues: ibl-nerf_amd/__init__.py asks for 8
             key = self.device.index
             if key not in _PAIR_STREAMS:
                 _PAIR_STREAMS[key] = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
