@@ -1441,7 +1441,7 @@ class Renderer:
     # share the context's workspace, so they run one after the other.  On a SECOND context (its own workspace and weight streams: +10 GB at 327 680 rays per launch)
     # and a second stream, one half's per-ray kernels and tails run in the wave slots the other half's matrix kernels leave free: 1 033.5 -> 995 ms per frame
     # (scratch/two_streams.py; three or four streams: 1 003 - 1 010), every map bit for bit (a ray's result does not depend on the launch it is rendered in).
-    PAIR_MIN_RAYS = 131072
+    PAIR_MIN_RAYS = 65536         # (80 000 rays — an 8-rank tile — gain 1.2 %, 160 000 2 %, 320 000 3.2 %, a frame 3.5 %: scratch/pair_tile.py)
     pair_streams = True          # (instance or class attribute: False = one context, one stream, as before)
 
     def _pair_twin(self):
