@@ -1505,13 +1505,11 @@ class Renderer:
         main = torch.cuda.current_stream()
         halves = []
         for r_, st, sl in ((self, self._pair_s[0], slice(0, h)), (tw, self._pair_s[1], slice(h, n))):
-            m = sl.stop - sl.start
             sub_gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n, -1)[sl] if hasattr(v, "shape") and len(v) == n else v) for k, v in gt_values.items()}
             st.wait_stream(main)                     # (the rays and override rows were produced on the caller's stream)
             with torch.cuda.stream(st):
                 halves.append(r_._render(rays_o[sl], rays_d[sl], pn[sl].contiguous() if torch.is_tensor(pn) else pn, pf[sl].contiguous() if torch.is_tensor(pf) else pf,
                                          sub_gt, edit, chunk=chunk, want_trips=want_trips, defer_flags=True))
-            assert halves[-1][0]["depth_map"].shape[0] == m
         for st in self._pair_s:
             main.wait_stream(st)
         bits = self.range_bits() | tw.range_bits()          # (one device synchronisation: both halves are done)
