@@ -1493,7 +1493,8 @@ class Renderer:
     def _render_pair(self, rays_o, rays_d, near, far, gt_values, edit, chunk, want_trips):
         """The call's two halves on this context and its twin, each on a stream of its own, under ONE decision (iblnerf_copy_route, the same routing bits); the flags
         of both are read once both are done.  None = a range event (an activation left the f16 range): the caller renders the call on this context alone, where such
-        events are answered."""
+        events are answered.  (What is mirrored onto the twin: weights incl. range rescaling, auxiliary networks, LUT, route, routing bits.  NOT the measurement
+        hooks of include/iblnerf_experimental.h set on this context by hand: measure with pair_streams = False.)"""
         torch = _torch()
         n = int(rays_o.shape[0])
         tw = self._pair_twin()
