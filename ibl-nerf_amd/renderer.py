@@ -703,13 +703,40 @@ class Renderer:
         self.policy["imposed"] = True
         return self.policy
 
-    def _measure_table(self, rays_o, rays_d, near, far, gt_values, edit, fast_maps=None):
+    def _measure_table(self, rays_o, rays_d, near, far, gt_values, edit, fast_maps=None, share=None):
         """FAST against SAFE routing of this context on the given rays, under the route in effect; records `self.policy` and leaves the context on the decided table.
-        fast_maps: the FAST render of these very rays if the caller has it already (the route probe's own render, _measure_route keep_maps)."""
+        fast_maps: the FAST render of these very rays if the caller has it already (the route probe's own render, _measure_route keep_maps).
+        share (dist.alarm_sync: the tiles of a sharded frame, all holding these same probe rays): every probe render here is shared out — this rank renders rows
+        rank, rank + world, ... and the ranks exchange the judged maps' rows (a ray's result does not depend on the launch it is rendered in: the assembled maps
+        are the one-rank render's bit for bit, so every rank judges the same numbers) — and the tripwire / range bits are OR-ed over the ranks, so that the
+        escalation loop runs in lockstep."""
         torch = _torch()
         keep = self.policy
         self.policy = {"decision": "calibrating"}
         applied = getattr(self, "_routing_extra", 0)
+        n_probe = int(rays_o.shape[0])
+
+        def probe_render():
+            if share is None:
+                m, bits_, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                return m, bits_
+            sl = slice(share.rank, n_probe, share.world)
+            sub_gt = None if not gt_values else {k: (_dev_f32(v, self.device).reshape(n_probe, -1)[sl].contiguous() if hasattr(v, "shape") and len(v) == n_probe else v)
+                                                 for k, v in gt_values.items()}
+            m, bits_, _ = self._render(rays_o[sl].contiguous(), rays_d[sl].contiguous(), near[sl].contiguous() if torch.is_tensor(near) else near,
+                                       far[sl].contiguous() if torch.is_tensor(far) else far, sub_gt, edit, on_range="ignore")
+            ks = [k for k in self.CAL_LIMITS if k in m]
+            rows = torch.cat([m[k].reshape(m[k].shape[0], -1) for k in ks], 1)
+            full = share.gather_rows(rows, n_probe)
+            out, c0 = {}, 0
+            for k in ks:
+                w = int(np.prod(m[k].shape[1:])) if m[k].dim() > 1 else 1
+                out[k] = full[:, c0:c0 + w].reshape((n_probe,) + tuple(m[k].shape[1:]))
+                c0 += w
+            _, _, bits_ = share(0, 0, int(bits_) & 31)          # (every rank sees every rank's events)
+            if bits_ & 1:
+                raise _RangeEvent()
+            return out, bits_
         try:
             with torch.no_grad():
                 for attempt in range(6):
@@ -717,9 +744,9 @@ class Renderer:
                     if fast_maps is not None and attempt == 0:
                         a, bits_a = fast_maps, 0
                     else:
-                        a, bits_a, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                        a, bits_a = probe_render()
                     self._set_routing(self.SAFE_ROUTING)
-                    b, bits_b, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                    b, bits_b = probe_render()
                     bits = (bits_a | bits_b) & TRIP_BITS
                     if not bits or not self._c_route:
                         break
@@ -753,20 +780,20 @@ class Renderer:
             if triggers and self.TIERED_ROUTING:
                 # FAST does not hold here: the TIERED table (the fast forms, three f16 products on the samples k_importance flags) against the same yardstick and limits
                 self._set_routing(self.TIERED_ROUTING)
-                c_maps, bits_c, _ = self._render(rays_o, rays_d, near, far, gt_values, edit, on_range="raise")
+                c_maps, bits_c = probe_render()
                 m2, t2 = judge(c_maps)
                 keep["metrics_tiered"], keep["triggers_tiered"] = m2, t2
                 if not t2 and not bits_c & TRIP_PROOF:
                     decision, applied = "tiered", self.TIERED_ROUTING
             keep["decision"], keep["routing"] = decision, int(self._routing | applied)
             # (the renders themselves: when the probe is the whole call — a call of <= ROUTE_RAYS rays — the decided table's render IS the call's result)
-            self._table_maps = {"fast": a, "safe": b, "tiered": c_maps if (triggers and self.TIERED_ROUTING) else None}
+            self._table_maps = None if share is not None else {"fast": a, "safe": b, "tiered": c_maps if (triggers and self.TIERED_ROUTING) else None}
         finally:
             self._set_routing(applied)          # (also after an exception inside a probe render: the context goes back to the routing it had — ADVICE r4)
             self.policy = keep
         return self.policy
 
-    def _decide_for_call(self, rays_o, rays_d, near, far, gt_values, edit, probe):
+    def _decide_for_call(self, rays_o, rays_d, near, far, gt_values, edit, probe, share=None):
         """What an eager, deterministic render call is rendered under — the route (which queries take lists, on which estimates, with which margin) and, for
         mlp_precision="auto", the precision table (FAST / SAFE) — is measured for THAT CALL, before it, on a probe of its own rays: <= ROUTE_RAYS strided ones, or the
         rays `probe` names ({"rays_o", "rays_d"[, "near", "far", "gt_values"]}: dist.render_frame passes the same seeded pixels of the frame on every rank, whatever
@@ -810,7 +837,8 @@ class Renderer:
         if table_open:
             if pro is not None and pro.shape[0] >= self.CAL_MIN_RAYS:
                 self._table_maps = None
-                self._measure_table(pro, prd, pnear, pfar, pgt, edit, fast_maps=fast_maps)
+                # (share: the tiles of a sharded frame hold the same probe — its table renders are shared out among them, _measure_table)
+                self._measure_table(pro, prd, pnear, pfar, pgt, edit, fast_maps=fast_maps, share=share if (probe is not None and getattr(share, "world", 1) > 1) else None)
                 if probe is None and pro.shape[0] == n and route_open and self._table_maps is not None:
                     # the probe WAS the call (n <= ROUTE_RAYS: every ray measured on): the decided table's probe render is the call's render — a function of the call's
                     # rays alone, like everything else here — and is not rendered a third time
@@ -1356,7 +1384,7 @@ class Renderer:
             decided_maps = None
             for attempt in (0, 1):
                 try:
-                    decided_maps = self._decide_for_call(rays_o, rays_d, *self._plane_args(near, far, n), gt_values, edit, probe)
+                    decided_maps = self._decide_for_call(rays_o, rays_d, *self._plane_args(near, far, n), gt_values, edit, probe, share=alarm_sync)
                     break
                 except _RangeEvent:
                     # the probe left the f16 range: nothing can be measured before that is answered — the networks rescaled into range by measurement (then the probe

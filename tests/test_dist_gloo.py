@@ -112,6 +112,10 @@ def _alarm_worker(rank, world, init_file, out_dir):
     torch.save(got, os.path.join(out_dir, "alarm%d.pt" % rank))
     # the probe / pixel helpers are functions of their arguments alone: every rank draws the same pixels
     torch.save(D.probe_pixels(800, 800), os.path.join(out_dir, "pix%d.pt" % rank))
+    # the frame's probe renders are shared out: rank r holds rows r, r + world, ... of a 10-row array (uneven: 4 / 3 / 3 rows) and every rank gets the whole of it
+    assert (sync.rank, sync.world) == (rank, world)
+    whole = torch.arange(40, dtype=torch.float32).reshape(10, 4) * 1.5
+    torch.save(sync.gather_rows(whole[rank::world].contiguous(), 10), os.path.join(out_dir, "rows%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,6 +133,8 @@ def test_three_ranks_take_the_alarm_decision_on_the_frames_numbers():
         mp.spawn(_alarm_worker, args=(3, os.path.join(d, "rdzv"), d), nprocs=3, join=True)
         got = [torch.load(os.path.join(d, "alarm%d.pt" % r)) for r in range(3)]
         pix = [torch.load(os.path.join(d, "pix%d.pt" % r), weights_only=False) for r in range(3)]
+        rows = [torch.load(os.path.join(d, "rows%d.pt" % r)) for r in range(3)]
+    assert all(torch.equal(v, torch.arange(40, dtype=torch.float32).reshape(10, 4) * 1.5) for v in rows)
     assert got[0] == got[1] == got[2] == (6, 600, 28)
     assert np.array_equal(pix[0], pix[1]) and np.array_equal(pix[0], pix[2]) and len(pix[0]) == 4096 and np.all(np.diff(pix[0]) > 0) and pix[0].max() < 640000
     assert not np.array_equal(D.probe_pixels(800, 800, seed=1), pix[0]) and len(D.probe_pixels(9, 16)) == 144
